@@ -1,0 +1,216 @@
+/*
+ * lofreq_amd.h -- C ABI of the MI355X-native LoFreq per-column SNV calling path.
+ *
+ * This is the drop-in boundary for the path
+ *     plp_to_errprobs -> qsort -> snpcaller/poissbin/pruned_calc_prob_dist -> Bonferroni emit test
+ * of `lofreq call` (reference: src/lofreq/lofreq_call.c:735-879 call_snvs,
+ * src/lofreq/snpcaller.c:346, 831, 1020, 1075).  Plain pointers and sizes only; no C++ or
+ * torch types.  INTEGRATION.md shows the binding a LoFreq maintainer adds behind the
+ * `void (*plp_proc_func)(const plp_col_t*, void*)` callback of mpileup() (plp.h:159-163).
+ *
+ * Layers:
+ *   (1) lfq_snv_batch_device  -- kernels only, device pointers, asynchronous.  Replaces, for a
+ *       batch of columns, the reference's inner numeric API plp_to_errprobs()+qsort()+snpcaller()
+ *       (snpcaller.h:72-75, 97-102).
+ *   (2) lfq_call_snvs_batch   -- the call_snvs() loop (lofreq_call.c:735-879) over a batch:
+ *       runs (1), then does the 80-bit p-value conversion with the reference's errno/fenv clamp
+ *       (snpcaller.c:1047-1059, 1169-1188), the running-Bonferroni emit test (lofreq_call.c:832),
+ *       AF/DP4/HQA/QUAL (lofreq_call.c:835-863) and strand bias (lofreq_call.c:117-129) on the host,
+ *       and returns one record per reported variant, in column order.
+ *   (3) lfq_format_snv_record / lfq_filter_records / lfq_snvqual_thresh -- VCF text (vcf.c:469-497,
+ *       608-629) and the final `lofreq filter` step that `lofreq call` runs on its own output
+ *       (lofreq_call.c:1506-1538; lofreq_filter.c).
+ *
+ * All functions return 0 on success or a negative lfq_status.  Errors never fall back to a CPU
+ * implementation: if no HIP device / kernel image is available the call fails.
+ */
+#ifndef LOFREQ_AMD_H
+#define LOFREQ_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFQ_ABI_VERSION 1
+
+typedef enum lfq_status {
+    LFQ_OK = 0,
+    LFQ_ERR_INVALID = -1,      /* bad argument */
+    LFQ_ERR_NO_DEVICE = -2,    /* no HIP device or HIP runtime error */
+    LFQ_ERR_NOMEM = -3,
+    LFQ_ERR_CAPACITY = -4,     /* caller-provided output capacity too small */
+    LFQ_ERR_UNSUPPORTED = -5,  /* option the reference rejects too (def_alt_jq == -1; approx threshold) */
+    LFQ_ERR_HIP = -6
+} lfq_status;
+
+/* varcall_conf_t flag bits (defaults.h:71-76) */
+#define LFQ_USE_BAQ 1
+#define LFQ_USE_MQ 2
+#define LFQ_USE_SQ 4
+
+/* ---- packed column batch ------------------------------------------------------------------
+ * Struct-of-arrays, one byte per observation per track, columns concatenated (CSR offsets).
+ * Built from plp_col_t's per-nucleotide int_varray_t arrays (plp.h:88-91):
+ *   nt   bits 0..2 = nt4 code (0..3 = A,C,G,T; 4 = N, skipped like snpcaller.c:386),
+ *        bit 3 = read on reverse strand (feeds fw_counts/rv_counts, plp.c:1007-1011)
+ *   bq   base quality, 0..93 (plp.c:937-953)
+ *   baq  base alignment quality 0..93; 255 = missing (-1, plp.c:956-962).  NULL track = BAQ off.
+ *   mq   mapping quality as in the BAM record, 0..255 (255 = NA is handled as snpcaller.c:451 does)
+ *   sq   source quality 0..254; 255 = missing (-1).  NULL track = no source quality.
+ * Track base pointers must be 16-byte aligned and readable up to the next multiple of 16 bytes
+ * past col_off[ncols]; col_off itself may be arbitrary (columns need not be aligned).
+ */
+#define LFQ_Q_MISSING 255
+
+typedef struct lfq_tracks {
+    const uint8_t *nt;
+    const uint8_t *bq;
+    const uint8_t *baq;        /* may be NULL */
+    const uint8_t *mq;
+    const uint8_t *sq;         /* may be NULL */
+    const uint64_t *col_off;   /* ncols + 1 entries */
+    const uint8_t *ref_base;   /* ncols ASCII reference bases (plp_col_t.ref_base) */
+    const int32_t *coverage_plp; /* ncols, or NULL: = observation count (plp_col_t.coverage_plp) */
+    const int32_t *num_bases;    /* ncols, or NULL: = observation count (plp_col_t.num_bases) */
+    int64_t ncols;
+    int64_t max_col_obs;         /* deepest column of the batch, or 0 = unknown (costs one sync) */
+} lfq_tracks;
+
+/* the SNV-path fields of varcall_conf_t (snpcaller.h:38-63); defaults: lfq_conf_init */
+typedef struct lfq_conf {
+    int32_t min_bq, min_alt_bq, def_alt_bq;
+    int32_t min_jq, min_alt_jq, def_alt_jq;
+    int32_t bonf_dynamic;
+    int32_t min_cov;
+    int64_t bonf_subst;        /* running Bonferroni factor; mutated by lfq_call_snvs_batch */
+    float sig;                 /* float, like the reference */
+    int32_t flag;
+    int64_t num_snv_tests;     /* the global of lofreq_call.c:84; mutated */
+} lfq_conf;
+
+/* dense per-column output of the counting kernel == plp_to_errprobs()'s integer outputs
+ * (snpcaller.c:346-498) plus the strand counts report_var() needs.  64 bytes. */
+typedef struct lfq_col_counts {
+    int32_t n_err_probs;       /* #probabilities the reference would hand to snpcaller */
+    int32_t alt_counts[3];     /* filtered alt counts, alleles in A,C,G,T order minus ref */
+    int32_t alt_raw_counts[3]; /* unfiltered alt counts (AF numerator, lofreq_call.c:835) */
+    int32_t alt_fw[3];         /* forward-strand part of alt_raw_counts */
+    int32_t ref_fw, ref_rv;    /* strand counts of the reference base */
+    int32_t kmax;              /* max(alt_counts) = num_failures handed to poissbin */
+    uint8_t tested;            /* column reaches the Bonferroni bump (lofreq_call.c:794-801) */
+    uint8_t gated;             /* 1 = skipped by the ref-N / coverage gates (lofreq_call.c:747,754,930) */
+    uint8_t pad_[2];
+    int32_t median_ref_bq;     /* median reference-base BQ when def_alt_bq == -1, else -1 */
+    int32_t coverage;          /* coverage_plp used for this column (DP / AF denominator) */
+} lfq_col_counts;
+
+/* status of one allele's p-value */
+enum {
+    LFQ_PV_NONE = 0,        /* count 0 or column pruned: reference returns LDBL_MAX */
+    LFQ_PV_LOG = 1,         /* logp valid: pvalue = expl(logp) (+ the reference's clamp on expl) */
+    LFQ_PV_LOG_FECLAMP = 2  /* logp valid but the reference's tail-sum exp() chain underflows
+                               (snpcaller.c:1169-1188): pvalue clamps to LDBL_MIN / LDBL_MAX */
+};
+
+/* sparse output: one record per column whose main allele survives the pruning test
+ * P(X>=K)*bonf > sig (snpcaller.c:950, 1155).  128 bytes. */
+typedef struct lfq_col_pvals {
+    int64_t col;               /* column index within the batch */
+    int64_t bonf;              /* running Bonferroni factor at this column */
+    double logp[3];            /* natural-log p-values, same allele order as the counts */
+    uint8_t status[3];
+    uint8_t pad_[5];
+    lfq_col_counts counts;     /* copy of the dense entry, so the host needs nothing else */
+    int32_t dp_rows;           /* DP rows processed (diagnostic) */
+    int32_t pad2_;
+    int64_t reserved_;
+} lfq_col_pvals;
+
+typedef struct lfq_batch_stats {
+    int64_t n_tested;          /* columns that passed the gates with >= 1 filtered alt base */
+    int64_t n_pvals;           /* records written to the sparse output */
+    int64_t n_obs;             /* observations in the batch */
+} lfq_batch_stats;
+
+/* one reported SNV == the arguments of report_var() (lofreq_call.c:862-864) */
+typedef struct lfq_snv_record {
+    int64_t col;
+    int32_t qual;              /* PROB_TO_PHREDQUAL(pvalue) */
+    int32_t dp;                /* coverage_plp */
+    int32_t alt_raw_count;     /* AF = alt_raw_count / (float) dp */
+    int32_t sb;                /* strand-bias phred (INT_MAX special case included) */
+    int32_t ref_fw, ref_rv, alt_fw, alt_rv;
+    int32_t hqa;               /* filtered alt count */
+    char ref, alt;
+    uint8_t pad_[2];
+    long double pvalue;
+} lfq_snv_record;
+
+typedef struct lfq_ctx lfq_ctx;
+
+/* --- lifetime --- */
+int lfq_abi_version(void);
+const char *lfq_strerror(int status);
+void lfq_conf_init(lfq_conf *conf);                 /* init_varcall_conf, snpcaller.c:627-651 */
+int lfq_create(lfq_ctx **ctx, int device_ordinal);  /* one context per GPU / stream */
+void lfq_destroy(lfq_ctx *ctx);
+int lfq_synchronize(lfq_ctx *ctx);
+
+/* --- layer 1: kernels --- */
+/* All pointers in `tracks` and the outputs are DEVICE pointers.  `d_counts` holds ncols entries;
+ * `d_pvals` holds pvals_capacity entries.  `bonf_base` is conf->bonf_subst before this batch.
+ * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous; `stats` is filled
+ * by lfq_batch_finish(), which waits for the batch. */
+int lfq_snv_batch_device(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *tracks,
+                         lfq_col_counts *d_counts, lfq_col_pvals *d_pvals, int64_t pvals_capacity,
+                         void *stream);
+int lfq_batch_finish(lfq_ctx *ctx, lfq_batch_stats *stats);
+
+/* --- layer 2: the call_snvs loop --- */
+/* tracks_on_device != 0: `tracks` holds device pointers (data resident in HBM);
+ * otherwise host pointers, copied to the device first.  Writes at most records_capacity
+ * records (column order) and sets *n_records.  Updates conf->bonf_subst / num_snv_tests exactly
+ * like the per-column loop of the reference.  `h_counts_or_null`: optional host copy of the dense
+ * per-column counts (ncols entries). */
+int lfq_call_snvs_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_tracks *tracks, int tracks_on_device,
+                        lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
+                        lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats);
+
+/* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
+int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,
+                       const int32_t *coverage_plp_or_null, const uint8_t *ref_base,
+                       lfq_snv_record *records, int64_t records_capacity, int64_t *n_records);
+/* expl() + the reference's clamp; exposed for tests */
+long double lfq_pvalue_from_log(double logp, int status);
+
+/* --- layer 3: output and final filter --- */
+int lfq_format_snv_record(char *buf, int buflen, const char *chrom, int64_t pos0,
+                          const lfq_snv_record *rec, const char *filter_or_null);
+int lfq_snvqual_thresh(float sig, int64_t bonf_subst);             /* lofreq_call.c:1523-1527 */
+int lfq_sb_phred(int ref_fw, int ref_rv, int alt_fw, int alt_rv);  /* lofreq_call.c:117-129 */
+double lfq_fisher_exact(int n11, int n12, int n21, int n22, double *left, double *right, double *two);
+int64_t lfq_fdr(const double *pvals, int64_t n, double alpha, int64_t num_tests, int64_t *rejected_idx);
+void lfq_bonf_corr(double *pvals, int64_t n, int64_t num_tests);
+void lfq_holm_bonf_corr(double *pvals, int64_t n, double alpha, int64_t num_tests);
+/* `lofreq filter` as `lofreq call` invokes it: keep[i] = 1 iff record i ends up PASS */
+int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thresh,
+                       int apply_defaults, uint8_t *keep);
+
+/* --- synthetic workload (bench / tests): fills device tracks per include/lofreq_synth.h --- */
+int lfq_synth_fill_device(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t plant_period,
+                          int64_t col_begin, int64_t ncols, uint8_t *d_nt, uint8_t *d_bq,
+                          uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off, uint8_t *d_ref_base,
+                          void *stream);
+
+/* --- device timing of the last batch (HIP events on the stream the kernels ran on) --- */
+typedef struct lfq_kernel_times {
+    float ms_count, ms_scan, ms_dp, ms_total;
+} lfq_kernel_times;
+int lfq_last_kernel_times(lfq_ctx *ctx, lfq_kernel_times *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

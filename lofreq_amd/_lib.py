@@ -1,0 +1,128 @@
+"""ctypes binding of liblofreq_amd.so (the C ABI declared in include/lofreq_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C lofreq_amd/csrc``.
+There is no Python or CPU fallback: if the shared object is missing, importing the compute
+entry points fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblofreq_amd.so")
+
+LFQ_OK = 0
+LFQ_ERR_CAPACITY = -4
+LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ = 1, 2, 4
+LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP = 0, 1, 2
+LFQ_Q_MISSING = 255
+
+
+class Conf(C.Structure):
+    """lfq_conf == the SNV-path fields of varcall_conf_t (snpcaller.h:38-63)."""
+    _fields_ = [
+        ("min_bq", C.c_int32), ("min_alt_bq", C.c_int32), ("def_alt_bq", C.c_int32),
+        ("min_jq", C.c_int32), ("min_alt_jq", C.c_int32), ("def_alt_jq", C.c_int32),
+        ("bonf_dynamic", C.c_int32), ("min_cov", C.c_int32),
+        ("bonf_subst", C.c_int64), ("sig", C.c_float), ("flag", C.c_int32),
+        ("num_snv_tests", C.c_int64),
+    ]
+
+
+class Tracks(C.Structure):
+    _fields_ = [
+        ("nt", C.c_void_p), ("bq", C.c_void_p), ("baq", C.c_void_p), ("mq", C.c_void_p),
+        ("sq", C.c_void_p), ("col_off", C.c_void_p), ("ref_base", C.c_void_p),
+        ("coverage_plp", C.c_void_p), ("num_bases", C.c_void_p), ("ncols", C.c_int64),
+        ("max_col_obs", C.c_int64),
+    ]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("n_tested", C.c_int64), ("n_pvals", C.c_int64), ("n_obs", C.c_int64)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_dp", C.c_float),
+                ("ms_total", C.c_float)]
+
+
+COL_COUNTS_DTYPE = np.dtype([
+    ("n_err_probs", "i4"), ("alt_counts", "i4", 3), ("alt_raw_counts", "i4", 3), ("alt_fw", "i4", 3),
+    ("ref_fw", "i4"), ("ref_rv", "i4"), ("kmax", "i4"), ("tested", "u1"), ("gated", "u1"),
+    ("pad_", "u1", 2), ("median_ref_bq", "i4"), ("coverage", "i4")], align=True)
+assert COL_COUNTS_DTYPE.itemsize == 64
+
+COL_PVALS_DTYPE = np.dtype([
+    ("col", "i8"), ("bonf", "i8"), ("logp", "f8", 3), ("status", "u1", 3), ("pad_", "u1", 5),
+    ("counts", COL_COUNTS_DTYPE), ("dp_rows", "i4"), ("pad2_", "i4"), ("reserved_", "i8")], align=True)
+assert COL_PVALS_DTYPE.itemsize == 128
+
+SNV_RECORD_DTYPE = np.dtype([
+    ("col", "i8"), ("qual", "i4"), ("dp", "i4"), ("alt_raw_count", "i4"), ("sb", "i4"),
+    ("ref_fw", "i4"), ("ref_rv", "i4"), ("alt_fw", "i4"), ("alt_rv", "i4"), ("hqa", "i4"),
+    ("ref", "S1"), ("alt", "S1"), ("pad_", "u1", 2), ("pvalue", np.longdouble)], align=True)
+assert SNV_RECORD_DTYPE.itemsize == 64, SNV_RECORD_DTYPE.itemsize
+
+# every symbol include/lofreq_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "lfq_abi_version", "lfq_strerror", "lfq_conf_init", "lfq_create", "lfq_destroy", "lfq_synchronize",
+    "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_finalize_pvals",
+    "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_snvqual_thresh", "lfq_sb_phred",
+    "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
+    "lfq_synth_fill_device", "lfq_last_kernel_times",
+]
+
+_lib = None
+
+
+def load():
+    """Load the C-ABI library; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "lofreq_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lofreq_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lfq_abi_version.restype = C.c_int
+    L.lfq_strerror.restype = C.c_char_p
+    L.lfq_strerror.argtypes = [C.c_int]
+    L.lfq_conf_init.argtypes = [C.POINTER(Conf)]
+    L.lfq_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.lfq_destroy.argtypes = [vp]
+    L.lfq_destroy.restype = None
+    L.lfq_synchronize.argtypes = [vp]
+    L.lfq_snv_batch_device.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), vp, vp, C.c_int64, vp]
+    L.lfq_batch_finish.argtypes = [vp, C.POINTER(BatchStats)]
+    L.lfq_call_snvs_batch.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int, vp, C.c_int64,
+                                      C.POINTER(C.c_int64), vp, C.POINTER(BatchStats)]
+    L.lfq_finalize_pvals.argtypes = [C.POINTER(Conf), vp, C.c_int64, vp, vp, vp, C.c_int64,
+                                     C.POINTER(C.c_int64)]
+    L.lfq_pvalue_from_log.restype = C.c_longdouble
+    L.lfq_pvalue_from_log.argtypes = [C.c_double, C.c_int]
+    L.lfq_format_snv_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, vp, C.c_char_p]
+    L.lfq_snvqual_thresh.argtypes = [C.c_float, C.c_int64]
+    L.lfq_sb_phred.argtypes = [C.c_int] * 4
+    L.lfq_fisher_exact.restype = C.c_double
+    L.lfq_fisher_exact.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double)] * 3
+    L.lfq_fdr.restype = C.c_int64
+    L.lfq_fdr.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_double, C.c_int64, C.POINTER(C.c_int64)]
+    L.lfq_bonf_corr.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int64]
+    L.lfq_bonf_corr.restype = None
+    L.lfq_holm_bonf_corr.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_double, C.c_int64]
+    L.lfq_holm_bonf_corr.restype = None
+    L.lfq_filter_records.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
+    L.lfq_synth_fill_device.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64,
+                                        vp, vp, vp, vp, vp, vp, vp]
+    L.lfq_last_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+    _lib = L
+    return L
+
+
+def check(rc, what="lofreq_amd call"):
+    if rc != LFQ_OK:
+        raise RuntimeError("%s failed: %s (%d)" % (what, load().lfq_strerror(rc).decode(), rc))

@@ -1,0 +1,270 @@
+"""Host-side mirror of LoFreq's SNV calling interface for the MI355X path.
+
+Names follow the reference: :class:`VarcallConf` is ``varcall_conf_t`` (snpcaller.h:38-63,
+defaults snpcaller.c:627-651), :class:`PileupBatch` is a batch of ``plp_col_t`` columns packed as
+byte tracks (plp.h:88-91), :meth:`SnvCaller.call_snvs` is the ``call_snvs()`` loop
+(lofreq_call.c:735-879) and :func:`filter_records` the final ``lofreq filter`` step that
+``lofreq call`` runs on its own output (lofreq_call.c:1506-1538).
+
+All compute goes through the C ABI in ``liblofreq_amd.so`` (hand-written HIP kernels); PyTorch is
+only used to own device memory for HBM-resident batches.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+NT4 = b"ACGTN"
+
+
+class VarcallConf:
+    """varcall_conf_t for the SNV path.  ``bonf_subst`` / ``num_snv_tests`` are mutated by calls."""
+
+    def __init__(self, **overrides):
+        self.c = _lib.Conf()
+        _lib.load().lfq_conf_init(C.byref(self.c))
+        for k, v in overrides.items():
+            if not hasattr(self.c, k):
+                raise AttributeError(k)
+            setattr(self.c, k, v)
+
+    def __getattr__(self, k):
+        return getattr(self.__dict__["c"], k)
+
+    def copy(self):
+        o = VarcallConf()
+        C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(_lib.Conf))
+        return o
+
+
+class PileupBatch:
+    """A batch of pileup columns as packed byte tracks (struct-of-arrays + CSR offsets).
+
+    Host batches hold numpy arrays; device batches hold torch uint8/int64 tensors resident in HBM.
+    """
+
+    def __init__(self, nt, bq, mq, col_off, ref_base, baq=None, sq=None, coverage_plp=None, num_bases=None,
+                 on_device=False, max_col_obs=0):
+        self.nt, self.bq, self.baq, self.mq, self.sq = nt, bq, baq, mq, sq
+        self.col_off, self.ref_base = col_off, ref_base
+        self.coverage_plp, self.num_bases = coverage_plp, num_bases
+        self.on_device = on_device
+        self.ncols = int(len(col_off) - 1)
+        self.max_col_obs = int(max_col_obs)
+
+    @staticmethod
+    def from_columns(columns, ref_bases, coverage_plp=None, num_bases=None):
+        """columns: list of dicts with per-observation arrays nt (0..4), strand (0/1), bq, baq, mq[, sq];
+        -1 in baq/sq means missing (encoded 255)."""
+        nts, bqs, baqs, mqs, sqs, off = [], [], [], [], [], [0]
+        has_baq = any(c.get("baq") is not None for c in columns)
+        has_sq = any(c.get("sq") is not None for c in columns)
+        for c in columns:
+            n = len(c["nt"])
+            strand = np.asarray(c.get("strand", np.zeros(n, np.int64)))
+            nts.append((np.asarray(c["nt"]).astype(np.uint8) & 7) | (strand.astype(np.uint8) << 3))
+            bqs.append(np.asarray(c["bq"]).astype(np.uint8))
+            mqs.append(np.asarray(c["mq"]).astype(np.uint8))
+            if has_baq:
+                b = np.asarray(c["baq"] if c.get("baq") is not None else np.full(n, -1))
+                baqs.append(np.where(b < 0, 255, b).astype(np.uint8))
+            if has_sq:
+                s = np.asarray(c["sq"] if c.get("sq") is not None else np.full(n, -1))
+                sqs.append(np.where(s < 0, 255, s).astype(np.uint8))
+            off.append(off[-1] + n)
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
+        rb = np.frombuffer(bytes(ref_bases), dtype=np.uint8) if isinstance(ref_bases, (bytes, bytearray, str)) \
+            else np.asarray(ref_bases, dtype=np.uint8)
+        if isinstance(ref_bases, str):
+            rb = np.frombuffer(ref_bases.encode(), dtype=np.uint8)
+        return PileupBatch(cat(nts), cat(bqs), cat(mqs), np.asarray(off, np.uint64), rb.copy(),
+                           baq=cat(baqs) if has_baq else None, sq=cat(sqs) if has_sq else None,
+                           coverage_plp=None if coverage_plp is None else np.asarray(coverage_plp, np.int32),
+                           num_bases=None if num_bases is None else np.asarray(num_bases, np.int32))
+
+    def _ptr(self, a):
+        if a is None:
+            return None
+        if self.on_device:
+            return C.c_void_p(a.data_ptr())
+        return C.c_void_p(a.ctypes.data)
+
+    def _tracks(self):
+        if not self.on_device:
+            for name in ("nt", "bq", "baq", "mq", "sq", "ref_base"):
+                a = getattr(self, name)
+                if a is not None:
+                    setattr(self, name, np.ascontiguousarray(a, dtype=np.uint8))
+            self.col_off = np.ascontiguousarray(self.col_off, dtype=np.uint64)
+        t = _lib.Tracks()
+        t.nt, t.bq, t.baq, t.mq, t.sq = (self._ptr(self.nt), self._ptr(self.bq), self._ptr(self.baq),
+                                         self._ptr(self.mq), self._ptr(self.sq))
+        t.col_off, t.ref_base = self._ptr(self.col_off), self._ptr(self.ref_base)
+        t.coverage_plp, t.num_bases = self._ptr(self.coverage_plp), self._ptr(self.num_bases)
+        t.ncols = self.ncols
+        t.max_col_obs = self.max_col_obs
+        return t
+
+
+class SnvCaller:
+    """One context per GPU (lfq_ctx).  Not thread-safe, like the reference's caller."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.L.lfq_create(C.byref(h), int(device)), "lfq_create")
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lfq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- layer 2: the call_snvs loop over one batch ------------------------------------------
+    def call_snvs(self, batch, conf, want_counts=False, records_capacity=None):
+        """-> (records[SNV_RECORD_DTYPE] in column order, counts or None, BatchStats).
+        Mutates conf.bonf_subst / conf.num_snv_tests like the reference's per-column loop."""
+        t = batch._tracks()
+        cap = int(records_capacity if records_capacity is not None else max(3 * batch.ncols, 16))
+        rec = np.zeros(cap, dtype=_lib.SNV_RECORD_DTYPE)
+        n = C.c_int64(0)
+        counts = np.zeros(batch.ncols, dtype=_lib.COL_COUNTS_DTYPE) if want_counts else None
+        st = _lib.BatchStats()
+        rc = self.L.lfq_call_snvs_batch(self.h, C.byref(conf.c), C.byref(t), 1 if batch.on_device else 0,
+                                        C.c_void_p(rec.ctypes.data), cap, C.byref(n),
+                                        C.c_void_p(counts.ctypes.data) if want_counts else None, C.byref(st))
+        _lib.check(rc, "lfq_call_snvs_batch")
+        return rec[: n.value].copy(), counts, st
+
+    # -- layer 1: kernels only, device-resident in and out --------------------------------------
+    def snv_batch_device(self, batch, conf, d_counts, d_pvals, pvals_capacity, stream=None):
+        assert batch.on_device
+        t = batch._tracks()
+        rc = self.L.lfq_snv_batch_device(self.h, C.byref(conf.c), C.byref(t), C.c_void_p(d_counts.data_ptr()),
+                                         C.c_void_p(d_pvals.data_ptr()), int(pvals_capacity),
+                                         C.c_void_p(stream) if stream else None)
+        _lib.check(rc, "lfq_snv_batch_device")
+
+    def batch_finish(self):
+        st = _lib.BatchStats()
+        _lib.check(self.L.lfq_batch_finish(self.h, C.byref(st)), "lfq_batch_finish")
+        return st
+
+    def kernel_times(self):
+        kt = _lib.KernelTimes()
+        _lib.check(self.L.lfq_last_kernel_times(self.h, C.byref(kt)))
+        return dict(ms_count=kt.ms_count, ms_scan=kt.ms_scan, ms_dp=kt.ms_dp, ms_total=kt.ms_total)
+
+    def synchronize(self):
+        _lib.check(self.L.lfq_synchronize(self.h))
+
+    # -- synthetic workload, generated directly in HBM -----------------------------------------
+    def synth_batch(self, seed, depth, ncols, plant_period=997, col_begin=0):
+        import torch
+        dev = torch.device("cuda", self.device)
+        n = ncols * depth
+        pad = (n + 15) // 16 * 16 + 16
+        nt = torch.empty(pad, dtype=torch.uint8, device=dev)
+        bq = torch.empty(pad, dtype=torch.uint8, device=dev)
+        baq = torch.empty(pad, dtype=torch.uint8, device=dev)
+        mq = torch.empty(pad, dtype=torch.uint8, device=dev)
+        off = torch.empty(ncols + 1, dtype=torch.int64, device=dev)
+        ref = torch.empty(ncols + 16, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        rc = self.L.lfq_synth_fill_device(self.h, int(seed), int(depth), int(plant_period), int(col_begin),
+                                          int(ncols), C.c_void_p(nt.data_ptr()), C.c_void_p(bq.data_ptr()),
+                                          C.c_void_p(baq.data_ptr()), C.c_void_p(mq.data_ptr()),
+                                          C.c_void_p(off.data_ptr()), C.c_void_p(ref.data_ptr()), None)
+        _lib.check(rc, "lfq_synth_fill_device")
+        self.synchronize()
+        b = PileupBatch(nt, bq, mq, off, ref, baq=baq, on_device=True, max_col_obs=depth)
+        b.ncols = ncols
+        return b
+
+
+def pvalue_from_log(logp, status):
+    """expl() + the reference's clamp (snpcaller.c:1047-1059), as np.longdouble."""
+    pv = np.zeros(1, dtype=_lib.COL_PVALS_DTYPE)
+    pv["logp"][0, 0] = logp
+    pv["status"][0, 0] = status
+    pv["counts"]["alt_counts"][0, 0] = 1
+    pv["counts"]["coverage"][0] = 1
+    pv["bonf"][0] = 0  # emit test passes for any finite p: p*0 < sig
+    conf = VarcallConf(sig=1.0)
+    rec = np.zeros(4, dtype=_lib.SNV_RECORD_DTYPE)
+    n = C.c_int64(0)
+    ref = np.frombuffer(b"A", dtype=np.uint8)
+    _lib.check(_lib.load().lfq_finalize_pvals(C.byref(conf.c), C.c_void_p(pv.ctypes.data), 1, None,
+                                              C.c_void_p(ref.ctypes.data), C.c_void_p(rec.ctypes.data), 4,
+                                              C.byref(n)))
+    if n.value == 0:
+        return np.finfo(np.longdouble).max
+    return rec["pvalue"][0]
+
+
+def finalize_pvals(conf, pvals, ref_base, coverage_plp=None):
+    """Host finishing step on sparse device records -> reported SNVs (column order)."""
+    pvals = np.ascontiguousarray(pvals, dtype=_lib.COL_PVALS_DTYPE)
+    rec = np.zeros(max(3 * len(pvals), 4), dtype=_lib.SNV_RECORD_DTYPE)
+    n = C.c_int64(0)
+    ref = np.ascontiguousarray(ref_base, dtype=np.uint8)
+    cov = None if coverage_plp is None else np.ascontiguousarray(coverage_plp, dtype=np.int32)
+    _lib.check(_lib.load().lfq_finalize_pvals(C.byref(conf.c), C.c_void_p(pvals.ctypes.data), len(pvals),
+                                              C.c_void_p(cov.ctypes.data) if cov is not None else None,
+                                              C.c_void_p(ref.ctypes.data), C.c_void_p(rec.ctypes.data),
+                                              len(rec), C.byref(n)))
+    return rec[: n.value].copy()
+
+
+def format_vcf_record(rec, chrom, pos0, filter_str=None):
+    """One VCF line, byte-identical to vcf_write_var (vcf.c:469-497) at HEAD (with ;HQA=)."""
+    buf = C.create_string_buffer(512)
+    r = np.ascontiguousarray(np.asarray(rec).reshape(1), dtype=_lib.SNV_RECORD_DTYPE)
+    n = _lib.load().lfq_format_snv_record(buf, 512, chrom.encode(), int(pos0), C.c_void_p(r.ctypes.data),
+                                          filter_str.encode() if filter_str else None)
+    return buf.raw[:n].decode()
+
+
+def snvqual_thresh(sig, bonf_subst):
+    return _lib.load().lfq_snvqual_thresh(C.c_float(sig), int(bonf_subst))
+
+
+def filter_records(records, snvqual_threshold, apply_defaults=True):
+    """`lofreq filter` as run by `lofreq call`: boolean keep mask."""
+    r = np.ascontiguousarray(records, dtype=_lib.SNV_RECORD_DTYPE)
+    keep = np.zeros(max(len(r), 1), dtype=np.uint8)
+    _lib.check(_lib.load().lfq_filter_records(C.c_void_p(r.ctypes.data), len(r), int(snvqual_threshold),
+                                              1 if apply_defaults else 0, C.c_void_p(keep.ctypes.data)))
+    return keep[: len(r)].astype(bool)
+
+
+def write_vcf_header(source="lofreq_amd call", reference=None):
+    """vcf_write_new_header (vcf.c:649-676) minus the volatile ##fileDate line."""
+    lines = ["##fileformat=VCFv4.0"]
+    if source:
+        lines.append("##source=%s" % source)
+    if reference:
+        lines.append("##reference=%s" % reference)
+    lines += [
+        '##INFO=<ID=DP,Number=1,Type=Integer,Description="Raw Depth">',
+        '##INFO=<ID=AF,Number=1,Type=Float,Description="Allele Frequency">',
+        '##INFO=<ID=SB,Number=1,Type=Integer,Description="Phred-scaled strand bias at this position">',
+        '##INFO=<ID=DP4,Number=4,Type=Integer,Description="Counts for ref-forward bases, ref-reverse, '
+        'alt-forward and alt-reverse bases">',
+        '##INFO=<ID=HQA,Number=1,Type=Integer,Description="Count of high quality alt bases supporting SNP call">',
+        '##INFO=<ID=INDEL,Number=0,Type=Flag,Description="Indicates that the variant is an INDEL.">',
+        '##INFO=<ID=CONSVAR,Number=0,Type=Flag,Description="Indicates that the variant is a consensus variant '
+        '(as opposed to a low frequency variant).">',
+        '##INFO=<ID=HRUN,Number=1,Type=Integer,Description="Homopolymer length to the right of report indel '
+        'position">',
+        "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO",
+    ]
+    return "\n".join(lines) + "\n"

@@ -1,0 +1,491 @@
+/*
+ * lfq_api.hip -- C-ABI entry points that own device state: context, workspace, the batch driver
+ * (layer 1) and the call_snvs batch loop (layer 2).  See include/lofreq_amd.h.
+ *
+ * There is deliberately no CPU fallback in this file: every compute entry point needs a HIP
+ * device and fails with LFQ_ERR_NO_DEVICE / LFQ_ERR_HIP otherwise.
+ */
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lfq_internal.h"
+#include "lofreq_synth.h"
+
+#define LFQ_TRY_HIP(expr)           \
+    do {                            \
+        hipError_t e_ = (expr);     \
+        if (e_ != hipSuccess) {     \
+            return LFQ_ERR_HIP;     \
+        }                           \
+    } while (0)
+
+#define LFQ_TRY(expr)               \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != LFQ_OK) {        \
+            return rc_;             \
+        }                           \
+    } while (0)
+
+struct lfq_ctx {
+    int device;
+    hipStream_t stream;
+    LfqLuts *d_luts;
+    /* per-batch workspace, grown on demand */
+    int64_t ws_cols;
+    uint8_t *d_flags;
+    int32_t *d_prefix, *d_qh, *d_ql, *d_counters;
+    uint64_t *d_tiles;
+    double *d_scratch;
+    int64_t scratch_doubles;
+    int32_t *h_counters;   /* pinned */
+    /* layer-2 owned outputs / staging */
+    lfq_col_counts *d_counts;
+    int64_t counts_cap;
+    lfq_col_pvals *d_pvals;
+    int64_t pvals_cap;
+    uint8_t *d_stage;
+    int64_t stage_bytes;
+    /* state of the batch in flight */
+    hipStream_t cur_stream;
+    int64_t cur_pvals_cap;
+    int64_t cur_ncols;
+    hipEvent_t ev[4];
+    lfq_kernel_times times;
+    int n_cu;
+};
+
+namespace {
+
+template <typename T>
+int grow(T **ptr, int64_t *cap, int64_t need)
+{
+    if (need <= *cap && *ptr) {
+        return LFQ_OK;
+    }
+    if (*ptr) {
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+    }
+    int64_t n = std::max<int64_t>(need, 16);
+    if (hipMalloc((void **)ptr, (size_t)n * sizeof(T)) != hipSuccess) {
+        *cap = 0;
+        return LFQ_ERR_NOMEM;
+    }
+    *cap = n;
+    return LFQ_OK;
+}
+
+/* PROB_TO_PHREDQUAL_SAFE (utils.h:46) */
+int phred_safe(double p) { return (p <= 0.0) ? INT32_MAX : (int)(-10.0 * log10l(p)); }
+
+/* Largest double x with PROB_TO_PHREDQUAL_SAFE(x) >= m: the device-side form of the integer
+ * filter `merged_qual < min_jq` (snpcaller.c:466-481) is then `prob > x`.  Found by bisection on
+ * the bit pattern with the reference's own expression, so the integer decision is identical. */
+double jq_threshold(int m)
+{
+    if (m <= 0) {
+        return INFINITY;
+    }
+    uint64_t lo = 1, hi;                /* lo: smallest positive double, phred huge */
+    double one = 2.0;
+    memcpy(&hi, &one, 8);               /* phred_safe(2.0) < 1 <= m */
+    if (phred_safe(4.9406564584124654e-324) < m) {
+        return 0.0;                     /* nothing positive passes */
+    }
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        double x;
+        memcpy(&x, &mid, 8);
+        if (phred_safe(x) >= m) {
+            lo = mid;
+        } else {
+            hi = mid;
+        }
+    }
+    double x;
+    memcpy(&x, &lo, 8);
+    return x;
+}
+
+int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P)
+{
+    if (conf->def_alt_jq == -1) {
+        return LFQ_ERR_UNSUPPORTED;     /* reference: LOG_FATAL + exit (snpcaller.c:482-484) */
+    }
+    memset(P, 0, sizeof(*P));
+    P->min_bq4 = std::min(std::max(conf->min_bq, 0), 128);
+    P->min_alt_bq4 = std::min(std::max(std::max(conf->min_bq, conf->min_alt_bq), 0), 128);
+    P->def_alt_bq = conf->def_alt_bq;
+    P->jq_reject_above = jq_threshold(conf->min_jq);
+    P->alt_jq_reject_above = jq_threshold(conf->min_alt_jq);
+    P->def_alt_jp = (conf->def_alt_jq != 0) ? pow(10.0, -1.0 * conf->def_alt_jq / 10.0) : -1.0;
+    P->general = (conf->min_jq > 0) || (conf->min_alt_jq > 0) || (conf->def_alt_bq == -1);
+    P->min_cov = conf->min_cov;
+    P->use_baq = (conf->flag & LFQ_USE_BAQ) && tr->baq;
+    P->use_mq = (conf->flag & LFQ_USE_MQ) != 0;
+    P->use_sq = (conf->flag & LFQ_USE_SQ) && tr->sq;
+    P->bonf_dynamic = conf->bonf_dynamic;
+    P->bonf_base = conf->bonf_subst;
+    P->sig = (double)conf->sig;
+    P->prune_slack = 1e-6;
+    return LFQ_OK;
+}
+
+void fill_luts(LfqLuts *L)
+{
+    for (int q = 0; q < 256; q++) {
+        const double p = pow(10.0, -1.0 * q / 10.0);    /* PHREDQUAL_TO_PROB, utils.h:42 */
+        L->bq[q] = p;
+        L->baq[q] = p;
+        L->mq[q] = p;
+        L->sq[q] = p;
+    }
+    L->baq[255] = 0.0;      /* -1: missing (snpcaller.c:321-322) */
+    L->sq[255] = 0.0;       /* snpcaller.c:307-308 */
+    L->mq[255] = 0.0;       /* MQ 255 = NA -> -1 (snpcaller.c:451-453, 313-314) */
+    L->mq[0] = 0.5;         /* MQ0_ERRPROB (snpcaller.c:64, 315-316) */
+}
+
+int ensure_workspace(lfq_ctx *c, int64_t ncols)
+{
+    if (ncols > c->ws_cols) {
+        int64_t cap = 0;
+        int64_t want = ncols + ncols / 8 + 1024;
+        if (c->d_flags) (void)hipFree(c->d_flags);
+        if (c->d_prefix) (void)hipFree(c->d_prefix);
+        if (c->d_qh) (void)hipFree(c->d_qh);
+        if (c->d_ql) (void)hipFree(c->d_ql);
+        if (c->d_tiles) (void)hipFree(c->d_tiles);
+        c->d_flags = nullptr;
+        c->d_prefix = c->d_qh = c->d_ql = nullptr;
+        c->d_tiles = nullptr;
+        c->ws_cols = 0;
+        LFQ_TRY(grow(&c->d_flags, &cap, want));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_prefix, &cap, want));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_qh, &cap, want));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_ql, &cap, want));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_tiles, &cap, want / 4096 + 8));
+        c->ws_cols = want;
+    }
+    return LFQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfq_create(lfq_ctx **out, int device_ordinal)
+{
+    if (!out) {
+        return LFQ_ERR_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev) {
+        return LFQ_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device_ordinal) != hipSuccess) {
+        return LFQ_ERR_NO_DEVICE;
+    }
+    lfq_ctx *c = (lfq_ctx *)calloc(1, sizeof(lfq_ctx));
+    if (!c) {
+        return LFQ_ERR_NOMEM;
+    }
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    c->n_cu = 256;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
+        c->n_cu = prop.multiProcessorCount;
+    }
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_counters, 8 * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_counters, 8 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 4; i++) {
+        ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    }
+    if (ok) {
+        LfqLuts h;
+        fill_luts(&h);
+        ok = hipMemcpy(c->d_luts, &h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) {
+        lfq_destroy(c);
+        return LFQ_ERR_HIP;
+    }
+    *out = c;
+    return LFQ_OK;
+}
+
+void lfq_destroy(lfq_ctx *c)
+{
+    if (!c) {
+        return;
+    }
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_qh, c->d_ql, c->d_counters, c->d_tiles,
+                    c->d_scratch, c->d_counts, c->d_pvals, c->d_stage};
+    for (void *b : bufs) {
+        if (b) (void)hipFree(b);
+    }
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (int i = 0; i < 4; i++) {
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+}
+
+int lfq_synchronize(lfq_ctx *c)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    return LFQ_OK;
+}
+
+int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
+                         lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null)
+{
+    if (!c || !conf || !tr || tr->ncols < 0 || tr->ncols > 0x7ffffff0LL) {
+        return LFQ_ERR_INVALID;
+    }
+    if (tr->ncols > 0 && (!tr->nt || !tr->bq || !tr->mq || !tr->col_off || !tr->ref_base || !d_counts
+                          || (!d_pvals && pvals_capacity > 0))) {
+        return LFQ_ERR_INVALID;
+    }
+    if ((((uintptr_t)tr->nt) | ((uintptr_t)tr->bq)) & 15u) {
+        return LFQ_ERR_INVALID;         /* 16-byte alignment contract of the track base pointers */
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
+    LfqParams P;
+    LFQ_TRY(make_params(conf, tr, &P));
+    LFQ_TRY(ensure_workspace(c, tr->ncols));
+
+    LfqTracksDev T;
+    T.nt = tr->nt;
+    T.bq = tr->bq;
+    T.baq = tr->baq;
+    T.mq = tr->mq;
+    T.sq = tr->sq;
+    T.col_off = tr->col_off;
+    T.ref_base = tr->ref_base;
+    T.coverage_plp = tr->coverage_plp;
+    T.num_bases = tr->num_bases;
+    T.ncols = tr->ncols;
+
+    LfqWork W;
+    W.tested_prefix = c->d_prefix;
+    W.q_heavy = c->d_qh;
+    W.q_light = c->d_ql;
+    W.counters = c->d_counters;
+    W.block_sums = (int32_t *)c->d_tiles;
+
+    c->cur_stream = st;
+    c->cur_pvals_cap = pvals_capacity;
+    c->cur_ncols = tr->ncols;
+    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(int32_t), st));
+    LFQ_TRY_HIP(hipEventRecord(c->ev[0], st));
+    LFQ_TRY(lfq_launch_count(T, P, c->d_luts, d_counts, c->d_flags, c->d_counters, st));
+    LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));
+    LFQ_TRY(lfq_launch_scan(tr->ncols, c->d_flags, W, st));
+    LFQ_TRY_HIP(hipEventRecord(c->ev[2], st));
+
+    /* DP scratch: 2 doubles per observation (strip boundary) + K+1 log-probabilities per
+     * resident wavefront; needs the deepest column of the batch */
+    int64_t max_depth = tr->max_col_obs;
+    if (max_depth <= 0 && tr->ncols > 0) {
+        LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LFQ_TRY_HIP(hipStreamSynchronize(st));
+        max_depth = c->h_counters[LFQ_CNT_MAXDEPTH];
+    }
+    const int64_t per_wave = 3 * max_depth + 72;
+    int n_waves = c->n_cu * 16;
+    const int64_t budget = (int64_t)1 << 29;            /* 4 GiB of doubles */
+    if (per_wave * n_waves > budget) {
+        n_waves = (int)std::max<int64_t>(64, budget / per_wave);
+    }
+    if ((int64_t)n_waves > tr->ncols) {
+        n_waves = (int)std::max<int64_t>(tr->ncols, 1);
+    }
+    LFQ_TRY(grow(&c->d_scratch, &c->scratch_doubles, per_wave * n_waves));
+    LFQ_TRY(lfq_launch_dp(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_wave, n_waves, st));
+    LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
+    return LFQ_OK;
+}
+
+int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    hipStream_t st = c->cur_stream ? c->cur_stream : c->stream;
+    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    LFQ_TRY_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->times.ms_count = ms;
+    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->times.ms_scan = ms;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->times.ms_dp = ms;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) c->times.ms_total = ms;
+    if (stats) {
+        stats->n_tested = c->h_counters[LFQ_CNT_TESTED];
+        stats->n_pvals = std::min<int64_t>(c->h_counters[LFQ_CNT_PVALS], c->cur_pvals_cap);
+        stats->n_obs = 0;
+    }
+    if (c->h_counters[LFQ_CNT_OVERFLOW]) {
+        return LFQ_ERR_CAPACITY;
+    }
+    return LFQ_OK;
+}
+
+int lfq_last_kernel_times(lfq_ctx *c, lfq_kernel_times *t)
+{
+    if (!c || !t) {
+        return LFQ_ERR_INVALID;
+    }
+    *t = c->times;
+    return LFQ_OK;
+}
+
+int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
+                        lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
+                        lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+{
+    if (!c || !conf || !tr || !n_records || tr->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_records = 0;
+    if (tr->ncols == 0) {
+        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    const int64_t ncols = tr->ncols;
+    lfq_tracks dev = *tr;
+    std::vector<uint8_t> h_ref;
+    std::vector<int32_t> h_cov;
+
+    if (!tracks_on_device) {
+        /* host buffers: stage them (padded to the 16-byte contract) in one device allocation */
+        const uint64_t n_obs = tr->col_off[ncols];
+        const int64_t trk = (int64_t)((n_obs + 15) / 16 * 16) + 16;
+        int64_t need = 5 * trk + (ncols + 1) * 8 + (ncols + 16) + 2 * (ncols * 4 + 16) + 64;
+        LFQ_TRY(grow(&c->d_stage, &c->stage_bytes, need));
+        uint8_t *p = c->d_stage;
+        auto put = [&](const void *src, int64_t bytes, int64_t reserve) -> uint8_t * {
+            uint8_t *dst = p;
+            p += (reserve + 15) / 16 * 16;
+            if (!src) {
+                return nullptr;
+            }
+            if (bytes > 0 && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                return nullptr;
+            }
+            return dst;
+        };
+        dev.nt = put(tr->nt, (int64_t)n_obs, trk);
+        dev.bq = put(tr->bq, (int64_t)n_obs, trk);
+        dev.baq = put(tr->baq, (int64_t)n_obs, trk);
+        dev.mq = put(tr->mq, (int64_t)n_obs, trk);
+        dev.sq = put(tr->sq, (int64_t)n_obs, trk);
+        dev.col_off = (const uint64_t *)put(tr->col_off, (ncols + 1) * 8, (ncols + 1) * 8);
+        dev.ref_base = put(tr->ref_base, ncols, ncols + 16);
+        dev.coverage_plp = (const int32_t *)put(tr->coverage_plp, ncols * 4, ncols * 4 + 16);
+        dev.num_bases = (const int32_t *)put(tr->num_bases, ncols * 4, ncols * 4 + 16);
+        if (!dev.nt || !dev.bq || !dev.mq || !dev.col_off || !dev.ref_base) {
+            return LFQ_ERR_HIP;
+        }
+        if (dev.max_col_obs <= 0) {
+            uint64_t md = 0;
+            for (int64_t i = 0; i < ncols; i++) {
+                md = std::max(md, tr->col_off[i + 1] - tr->col_off[i]);
+            }
+            dev.max_col_obs = (int64_t)md;
+        }
+    }
+
+    LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
+    LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
+    LFQ_TRY(lfq_snv_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
+    lfq_batch_stats st;
+    LFQ_TRY(lfq_batch_finish(c, &st));
+
+    std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
+    if (st.n_pvals > 0) {
+        LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals),
+                              hipMemcpyDeviceToHost));
+    }
+    if (h_counts_or_null) {
+        LFQ_TRY_HIP(hipMemcpy(h_counts_or_null, c->d_counts, (size_t)ncols * sizeof(lfq_col_counts),
+                              hipMemcpyDeviceToHost));
+    }
+    /* reference bases of the surviving columns (a handful of bytes when tracks live in HBM) */
+    const uint8_t *ref_host = nullptr;
+    if (!tracks_on_device) {
+        ref_host = tr->ref_base;
+    } else {
+        h_ref.assign((size_t)ncols, 'N');
+        if (st.n_pvals * 64 > ncols) {
+            LFQ_TRY_HIP(hipMemcpy(h_ref.data(), dev.ref_base, (size_t)ncols, hipMemcpyDeviceToHost));
+        } else {
+            for (const lfq_col_pvals &r : h_pv) {
+                LFQ_TRY_HIP(hipMemcpy(&h_ref[(size_t)r.col], dev.ref_base + r.col, 1, hipMemcpyDeviceToHost));
+            }
+        }
+        ref_host = h_ref.data();
+    }
+    int rc = lfq_finalize_pvals(conf, h_pv.data(), st.n_pvals, nullptr, ref_host, records, records_capacity,
+                                n_records);
+    /* Bonferroni bookkeeping of the per-column loop (lofreq_call.c:794-801) */
+    if (st.n_tested > 0) {
+        if (conf->bonf_dynamic) {
+            conf->bonf_subst = ((conf->bonf_subst == 1) ? 0 : conf->bonf_subst) + 3 * st.n_tested;
+        }
+        conf->num_snv_tests += 3 * st.n_tested;
+    }
+    st.n_obs = 0;
+    if (stats_out) {
+        *stats_out = st;
+    }
+    return rc;
+}
+
+int lfq_synth_fill_device(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t plant_period, int64_t col_begin,
+                          int64_t ncols, uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq,
+                          uint64_t *d_col_off, uint8_t *d_ref_base, void *stream_or_null)
+{
+    if (!c || !d_nt || !d_bq || !d_baq || !d_mq || !d_col_off || !d_ref_base || ncols < 0 || depth == 0) {
+        return LFQ_ERR_INVALID;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    lfq_synth_spec s;
+    memset(&s, 0, sizeof(s));
+    s.seed = seed;
+    s.depth = depth;
+    s.plant_period = plant_period;
+    for (int q = 0; q < 64; q++) {
+        const long double p = powl(10.0L, -(long double)q / 10.0L);
+        const long double t = floorl(p * 18446744073709551616.0L);
+        s.err_thresh[q] = (t >= 18446744073709551615.0L) ? UINT64_MAX : (uint64_t)t;
+    }
+    hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
+    return lfq_launch_synth(&s, col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off, d_ref_base, st);
+}
+
+}  // extern "C"

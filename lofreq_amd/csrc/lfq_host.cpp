@@ -1,0 +1,433 @@
+/*
+ * lfq_host.cpp -- host-side pieces of the SNV calling path that stay on the CPU, as in the
+ * reference: 80-bit p-value conversion with the errno/fenv clamp, the running-Bonferroni emit
+ * test, strand bias (Fisher's exact test), VCF record text, multiple-testing corrections and the
+ * final `lofreq filter` step.  Per *reported variant* work only -- negligible cost.
+ *
+ * No HIP in this file.  Reference citations are relative to src/lofreq/.
+ */
+#include <errno.h>
+#include <fenv.h>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lofreq_amd.h"
+
+namespace {
+
+/* utils.h:42 */
+inline double phred_to_prob(int q)
+{
+    return (q == INT_MAX) ? DBL_MIN : pow(10.0, -1.0 * q / 10.0);
+}
+
+/* utils.h:45: 80-bit log10, C truncation */
+inline int prob_to_phred(long double p) { return (int)(-10.0 * log10l(p)); }
+
+/* utils.h:46 */
+inline int prob_to_phred_safe(double p) { return (p <= 0.0) ? INT_MAX : (int)(-10.0 * log10l(p)); }
+
+/* utils.c:66-76 */
+inline int eps_cmp(double a, double b)
+{
+    if (fabs(a - b) < DBL_EPSILON) {
+        return 0;
+    }
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+
+struct IndexedP {
+    double p;
+    int64_t i;
+};
+
+/* the reference sorts with libc qsort + dbl_cmp (multtest.c:51-57); glibc's qsort is a stable
+ * merge sort for these sizes, so a stable sort with the same comparator reproduces its order */
+void sort_indexed(std::vector<IndexedP> &v)
+{
+    std::stable_sort(v.begin(), v.end(), [](const IndexedP &a, const IndexedP &b) { return eps_cmp(a.p, b.p) < 0; });
+}
+
+/* ---- Fisher's exact test, fet.c (samtools 0.1.18 kfunc) ---- */
+
+double log_choose(int n, int k)                             /* fet.c:13-17 */
+{
+    if (k == 0 || n == k) {
+        return 0;
+    }
+    return lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1);
+}
+
+double hypergeom(int n11, int n1_, int n_1, int n)          /* fet.c:26-29 */
+{
+    return exp(log_choose(n1_, n11) + log_choose(n - n1_, n_1 - n11) - log_choose(n, n_1));
+}
+
+struct HyperAcc {
+    int n11, n1_, n_1, n;
+    double p;
+};
+
+/* fet.c:37-61: table probability, updated incrementally except at every 11th n11 */
+double hypergeom_next(int n11, int n1_, int n_1, int n, HyperAcc &s)
+{
+    if (n1_ || n_1 || n) {
+        s.n11 = n11;
+        s.n1_ = n1_;
+        s.n_1 = n_1;
+        s.n = n;
+    } else {
+        if (n11 % 11 && n11 + s.n - s.n1_ - s.n_1) {
+            if (n11 == s.n11 + 1) {
+                s.p *= (double)(s.n1_ - s.n11) / n11 * (s.n_1 - s.n11) / (n11 + s.n - s.n1_ - s.n_1);
+                s.n11 = n11;
+                return s.p;
+            }
+            if (n11 == s.n11 - 1) {
+                s.p *= (double)s.n11 / (s.n1_ - n11) * (s.n11 + s.n - s.n1_ - s.n_1) / (s.n_1 - n11);
+                s.n11 = n11;
+                return s.p;
+            }
+        }
+        s.n11 = n11;
+    }
+    s.p = hypergeom(s.n11, s.n1_, s.n_1, s.n);
+    return s.p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfq_abi_version(void) { return LFQ_ABI_VERSION; }
+
+const char *lfq_strerror(int status)
+{
+    switch (status) {
+    case LFQ_OK: return "ok";
+    case LFQ_ERR_INVALID: return "invalid argument";
+    case LFQ_ERR_NO_DEVICE: return "no usable HIP device";
+    case LFQ_ERR_NOMEM: return "out of memory";
+    case LFQ_ERR_CAPACITY: return "output capacity too small";
+    case LFQ_ERR_UNSUPPORTED: return "unsupported option (the reference rejects it too)";
+    case LFQ_ERR_HIP: return "HIP runtime error";
+    default: return "unknown error";
+    }
+}
+
+/* snpcaller.c:627-651 */
+void lfq_conf_init(lfq_conf *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->min_bq = 6;
+    c->min_alt_bq = 6;
+    c->def_alt_bq = 0;
+    c->min_jq = 0;
+    c->min_alt_jq = 0;
+    c->def_alt_jq = 0;
+    c->bonf_dynamic = 1;
+    c->min_cov = 1;
+    c->bonf_subst = 1;
+    c->sig = 0.01;
+    c->flag = LFQ_USE_MQ | LFQ_USE_BAQ;
+    c->num_snv_tests = 0;
+}
+
+/* expl() with the reference's clamp (snpcaller.c:1047-1059 / 1169-1188).  For
+ * LFQ_PV_LOG_FECLAMP the device saw the reference's tail-sum exp() chain underflow, which
+ * leaves FE_UNDERFLOW raised in the reference no matter what expl() itself does. */
+long double lfq_pvalue_from_log(double logp, int status)
+{
+    if (status == LFQ_PV_NONE) {
+        return LDBL_MAX;
+    }
+    errno = 0;
+    feclearexcept(FE_ALL_EXCEPT);
+    long double pv = expl(logp);
+    const int errsv = errno;
+    const bool bad = errsv || fetestexcept(FE_INVALID | FE_DIVBYZERO | FE_OVERFLOW | FE_UNDERFLOW)
+                     || status == LFQ_PV_LOG_FECLAMP;
+    if (bad) {
+        pv = (pv < DBL_EPSILON) ? LDBL_MIN : LDBL_MAX;
+    }
+    return pv;
+}
+
+/* fet.c:62-99 */
+double lfq_fisher_exact(int n11, int n12, int n21, int n22, double *left_out, double *right_out,
+                        double *two_out)
+{
+    HyperAcc acc;
+    const int row1 = n11 + n12, col1 = n11 + n21, tot = n11 + n12 + n21 + n22;
+    const int hi = (col1 < row1) ? col1 : row1;
+    int lo = row1 + col1 - tot;
+    if (lo < 0) {
+        lo = 0;
+    }
+    *two_out = *left_out = *right_out = 1.;
+    if (lo == hi) {
+        return 1.;
+    }
+    const double q = hypergeom_next(n11, row1, col1, tot, acc);
+    int i, j;
+    double left, right;
+    double p = hypergeom_next(lo, 0, 0, 0, acc);
+    for (left = 0., i = lo + 1; p < 0.99999999 * q; ++i) {
+        left += p;
+        p = hypergeom_next(i, 0, 0, 0, acc);
+    }
+    --i;
+    if (p < 1.00000001 * q) {
+        left += p;
+    } else {
+        --i;
+    }
+    p = hypergeom_next(hi, 0, 0, 0, acc);
+    for (right = 0., j = hi - 1; p < 0.99999999 * q; --j) {
+        right += p;
+        p = hypergeom_next(j, 0, 0, 0, acc);
+    }
+    ++j;
+    if (p < 1.00000001 * q) {
+        right += p;
+    } else {
+        ++j;
+    }
+    *two_out = left + right;
+    if (*two_out > 1.) {
+        *two_out = 1.;
+    }
+    if (abs(i - n11) < abs(j - n11)) {
+        right = 1. - left + q;
+    } else {
+        left = 1.0 - right + q;
+    }
+    *left_out = left;
+    *right_out = right;
+    return q;
+}
+
+/* lofreq_call.c:117-129 */
+int lfq_sb_phred(int ref_fw, int ref_rv, int alt_fw, int alt_rv)
+{
+    if ((ref_fw + ref_rv) == 0 && (alt_fw == 0 || alt_rv == 0)) {
+        return INT_MAX;
+    }
+    double l, r, two;
+    (void)lfq_fisher_exact(ref_fw, ref_rv, alt_fw, alt_rv, &l, &r, &two);
+    return prob_to_phred_safe(two);
+}
+
+/* lofreq_call.c:1523-1527: float / integer division, then log10l */
+int lfq_snvqual_thresh(float sig, int64_t bonf_subst)
+{
+    int t = INT_MAX;
+    if (bonf_subst) {
+        t = prob_to_phred(sig / (long long)bonf_subst);
+        if (t < 0) {
+            t = 0;
+        }
+    }
+    return t;
+}
+
+/* The tail of call_snvs (lofreq_call.c:817-871) for the columns the device did not prune. */
+int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,
+                       const int32_t *coverage_plp_or_null, const uint8_t *ref_base,
+                       lfq_snv_record *records, int64_t records_capacity, int64_t *n_records)
+{
+    if (!conf || (!pvals && n_pvals > 0) || !n_records || n_pvals < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    std::vector<int64_t> order((size_t)n_pvals);
+    for (int64_t i = 0; i < n_pvals; i++) {
+        order[(size_t)i] = i;
+    }
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return pvals[a].col < pvals[b].col; });
+
+    static const char acgt[4] = {'A', 'C', 'G', 'T'};
+    int64_t n_out = 0;
+    for (int64_t oi = 0; oi < n_pvals; oi++) {
+        const lfq_col_pvals &r = pvals[order[(size_t)oi]];
+        const lfq_col_counts &cn = r.counts;
+        const double bonf = (double)r.bonf;
+        long double pv[3];
+        int kmax = 0;
+        for (int a = 0; a < 3; a++) {
+            pv[a] = lfq_pvalue_from_log(r.logp[a], r.status[a]);
+            kmax = std::max(kmax, cn.alt_counts[a]);
+        }
+        /* snpcaller() returns all-LDBL_MAX if the most frequent allele is not significant
+         * (snpcaller.c:1155) */
+        bool main_ok = false;
+        for (int a = 0; a < 3; a++) {
+            if (cn.alt_counts[a] == kmax && kmax > 0 && r.status[a] != LFQ_PV_NONE) {
+                main_ok = !(pv[a] * bonf > (double)conf->sig);
+                break;
+            }
+        }
+        if (!main_ok) {
+            continue;
+        }
+        char refc = ref_base ? (char)ref_base[r.col] : 'N';
+        int ref_code = -1;
+        for (int x = 0; x < 4; x++) {
+            if (acgt[x] == refc) {
+                ref_code = x;
+            }
+        }
+        if (ref_code < 0) {
+            continue;
+        }
+        const int cov = coverage_plp_or_null ? coverage_plp_or_null[r.col] : cn.coverage;
+        int ai = 0;
+        for (int x = 0; x < 4; x++) {
+            if (x == ref_code) {
+                continue;
+            }
+            const int a = ai++;
+            if (pv[a] * bonf < conf->sig) {                 /* lofreq_call.c:832 */
+                if (n_out >= records_capacity) {
+                    *n_records = n_out;
+                    return LFQ_ERR_CAPACITY;
+                }
+                lfq_snv_record &o = records[n_out++];
+                memset(&o, 0, sizeof(o));
+                o.col = r.col;
+                o.pvalue = pv[a];
+                o.qual = prob_to_phred(pv[a]);              /* lofreq_call.c:863 */
+                o.dp = cov;
+                o.alt_raw_count = cn.alt_raw_counts[a];     /* lofreq_call.c:835 */
+                o.ref_fw = cn.ref_fw;                       /* lofreq_call.c:853-857 */
+                o.ref_rv = cn.ref_rv;
+                o.alt_fw = cn.alt_fw[a];
+                o.alt_rv = cn.alt_raw_counts[a] - cn.alt_fw[a];
+                o.hqa = cn.alt_counts[a];                   /* lofreq_call.c:860 */
+                o.sb = lfq_sb_phred(o.ref_fw, o.ref_rv, o.alt_fw, o.alt_rv);
+                o.ref = refc;
+                o.alt = acgt[x];
+            }
+        }
+    }
+    *n_records = n_out;
+    return LFQ_OK;
+}
+
+/* vcf_write_var + vcf_var_sprintf_info (vcf.c:469-497, 608-629) */
+int lfq_format_snv_record(char *buf, int buflen, const char *chrom, int64_t pos0, const lfq_snv_record *rec,
+                          const char *filter_or_null)
+{
+    const float af = rec->alt_raw_count / (float)rec->dp;   /* lofreq_call.c:835 */
+    return snprintf(buf, (size_t)buflen, "%s\t%ld\t.\t%c\t%c\t%d\t%s\tDP=%d;AF=%f;SB=%d;DP4=%d,%d,%d,%d;HQA=%d\n",
+                    chrom, (long)(pos0 + 1), rec->ref, rec->alt, rec->qual,
+                    filter_or_null ? filter_or_null : ".", rec->dp, af, rec->sb, rec->ref_fw, rec->ref_rv,
+                    rec->alt_fw, rec->alt_rv, rec->hqa);
+}
+
+/* multtest.c:66-81 */
+void lfq_bonf_corr(double *pvals, int64_t n, int64_t num_tests)
+{
+    const int64_t fac = (num_tests < 1) ? n : num_tests;
+    for (int64_t i = 0; i < n; i++) {
+        pvals[i] *= fac;
+    }
+}
+
+/* multtest.c:91-136 */
+void lfq_holm_bonf_corr(double *pvals, int64_t n, double alpha, int64_t num_tests)
+{
+    std::vector<IndexedP> ix((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        ix[(size_t)i] = {pvals[i], i};
+    }
+    sort_indexed(ix);
+    int64_t lp = (num_tests < 1) ? n : num_tests;
+    double seen = n ? ix[0].p : 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        if (eps_cmp(ix[(size_t)i].p, seen) != 0) {
+            lp = (num_tests < 1) ? n - i : num_tests - i;
+            seen = ix[(size_t)i].p;
+        }
+        const double tp = ix[(size_t)i].p * 1. / lp;
+        if (eps_cmp(tp, alpha) < 0) {
+            pvals[ix[(size_t)i].i] = ix[(size_t)i].p * lp;
+        }
+    }
+}
+
+/* multtest.c:148-189 (Benjamini-Hochberg with the reference's float division) */
+int64_t lfq_fdr(const double *pvals, int64_t n, double alpha, int64_t num_tests, int64_t *rejected_idx)
+{
+    std::vector<IndexedP> ix((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        ix[(size_t)i] = {pvals[i], i};
+    }
+    sort_indexed(ix);
+    const int64_t m = (num_tests < 1) ? n : num_tests;
+    int64_t nrej = 0;
+    for (int64_t i = n; i > 0; i--) {
+        if (ix[(size_t)(i - 1)].p < (alpha * i / (float)m)) {
+            nrej = i;
+            break;
+        }
+    }
+    if (rejected_idx) {
+        for (int64_t i = 0; i < nrej; i++) {
+            rejected_idx[i] = ix[(size_t)i].i;
+        }
+    }
+    return nrej;
+}
+
+/* `lofreq filter` as `lofreq call` runs it on its own output (lofreq_call.c:1506-1538):
+ * SNV QUAL threshold (lofreq_filter.c:313-323) and, unless --no-defaults, DP >= 10
+ * (lofreq_filter.c:1095-1097, 270-305) and the strand-bias FDR filter, alpha 0.001, with the
+ * "alt mostly on one strand" compound rule (lofreq_filter.c:57, 210-236, 582-677, 1089-1094). */
+int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thresh, int apply_defaults,
+                       uint8_t *keep)
+{
+    if ((!records && n > 0) || !keep || n < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        keep[i] = 1;
+    }
+    if (apply_defaults && n > 0) {
+        const double alpha = 0.001;
+        std::vector<double> sbp((size_t)n);
+        std::vector<int64_t> rej((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            sbp[(size_t)i] = phred_to_prob(records[i].sb);            /* lofreq_filter.c:611 */
+        }
+        const int64_t nrej = lfq_fdr(sbp.data(), n, alpha, n, rej.data());
+        for (int64_t i = 0; i < nrej; i++) {
+            const lfq_snv_record &r = records[rej[(size_t)i]];
+            const float ratio = std::max(r.alt_fw, r.alt_rv) / (float)(r.alt_fw + r.alt_rv);   /* :227 */
+            if (ratio > 0.85) {
+                keep[rej[(size_t)i]] = 0;
+            }
+        }
+        for (int64_t i = 0; i < n; i++) {
+            if (records[i].dp < 10) {
+                keep[i] = 0;
+            }
+        }
+    }
+    if (snvqual_thresh) {
+        for (int64_t i = 0; i < n; i++) {
+            if (records[i].qual > -1 && records[i].qual < snvqual_thresh) {   /* lofreq_filter.c:319 */
+                keep[i] = 0;
+            }
+        }
+    }
+    return LFQ_OK;
+}
+
+}  // extern "C"

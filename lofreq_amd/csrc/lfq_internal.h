@@ -1,0 +1,79 @@
+/*
+ * lfq_internal.h -- device-side parameter blocks shared by the HIP kernels and the C-ABI layer.
+ * Not part of the public ABI.
+ */
+#ifndef LFQ_INTERNAL_H
+#define LFQ_INTERNAL_H
+
+#include <stdint.h>
+
+#include "lofreq_amd.h"
+
+/* phred -> probability tables, computed on the HOST with the same pow() call as
+ * PHREDQUAL_TO_PROB (utils.h:42) so that the quality merge is bit-identical.  Index 255 of the
+ * baq/mq/sq tables is the "missing" code (probability 0, snpcaller.c:307-331); mq[0] = 0.5
+ * (snpcaller.c:64, 315-316).  A track that is absent or switched off by `flag` is looked up at
+ * index 255 for every observation. */
+struct LfqLuts {
+    double bq[256];
+    double baq[256];
+    double mq[256];
+    double sq[256];
+};
+
+struct LfqParams {
+    int32_t min_bq4;          /* clamp(min_bq, 0, 128) */
+    int32_t min_alt_bq4;      /* clamp(max(min_bq, min_alt_bq), 0, 128): an alt base must pass both */
+    int32_t def_alt_bq;       /* 0 keep, >0 override, -1 median of reference-base BQs */
+    int32_t general;          /* 1: merged-quality filters / median override active -> slow count path */
+    double jq_reject_above;   /* observation dropped if merged prob > this (min_jq);  +inf = off */
+    double alt_jq_reject_above; /* same for alt observations (min_alt_jq) */
+    double def_alt_jp;        /* < 0: keep merged prob; else overrides it for alt observations */
+    int32_t min_cov;
+    int32_t use_baq, use_mq, use_sq;   /* track present AND enabled by conf->flag */
+    int32_t bonf_dynamic;
+    int64_t bonf_base;        /* conf->bonf_subst before this batch */
+    double sig;               /* (double)(float)conf->sig */
+    double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
+};
+
+struct LfqTracksDev {
+    const uint8_t *nt, *bq, *baq, *mq, *sq;
+    const uint64_t *col_off;
+    const uint8_t *ref_base;
+    const int32_t *coverage_plp, *num_bases;
+    int64_t ncols;
+};
+
+/* work lists and counters produced by the scan kernels, consumed by the DP kernel */
+struct LfqWork {
+    int32_t *tested_prefix;   /* [ncols] inclusive count of tested columns up to and incl. c */
+    int32_t *q_heavy;         /* [ncols] tested columns with kmax >= LFQ_HEAVY_K */
+    int32_t *q_light;         /* [ncols] the other tested columns */
+    int32_t *counters;        /* [8]: 0 n_tested, 1 n_heavy, 2 n_light, 3 heavy dequeue head,
+                                       4 n_pvals, 5 overflow flag, 6 max column depth */
+    int32_t *block_sums;      /* scan scratch */
+};
+
+#define LFQ_HEAVY_K 64
+#define LFQ_CNT_TESTED 0
+#define LFQ_CNT_HEAVY 1
+#define LFQ_CNT_LIGHT 2
+#define LFQ_CNT_HEAD 3
+#define LFQ_CNT_PVALS 4
+#define LFQ_CNT_OVERFLOW 5
+#define LFQ_CNT_MAXDEPTH 6
+
+/* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
+int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int32_t *d_counters, void *stream);
+int lfq_launch_scan(int64_t ncols, const uint8_t *d_flags, const LfqWork &w, void *stream);
+int lfq_launch_dp(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                  const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
+                  int64_t pvals_capacity, double *d_scratch, int64_t scratch_doubles_per_wave,
+                  int n_waves, void *stream);
+int lfq_launch_synth(const struct lfq_synth_spec *d_spec_host, int64_t col_begin, int64_t ncols,
+                     uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off,
+                     uint8_t *d_ref_base, void *stream);
+
+#endif

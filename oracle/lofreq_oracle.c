@@ -1,0 +1,799 @@
+/*
+ * lofreq_oracle.c -- CPU restatement of LoFreq's per-column SNV calling path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see lofreq_oracle.h).  Plain C99, scalar, one
+ * thread.  Citations are reference paths relative to src/lofreq/.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -std=gnu99, no -march, no -ffast-math:
+ * the reference is built the same way, src/lofreq/Makefile.am:1, so that the
+ * quality merge of snpcaller.c:334 is evaluated without FMA contraction).
+ */
+#define _GNU_SOURCE
+#include "lofreq_oracle.h"
+
+#include <errno.h>
+#include <fenv.h>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define ORC_LOGZERO (-1e100)   /* snpcaller.c:66 */
+#define ORC_MQ0_ERRPROB 0.5    /* snpcaller.c:64 */
+#define ORC_FE_BAD (FE_INVALID | FE_DIVBYZERO | FE_OVERFLOW | FE_UNDERFLOW)
+
+static const char ORC_NT4[5] = {'A', 'C', 'G', 'T', 'N'};   /* plp.c:49 bam_nt4_rev_table */
+
+static double orc_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* snpcaller.c:627-651 (plus lofreq_call.c:84 for the test counter) */
+void orc_conf_init(orc_conf *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->min_bq = 6;       /* defaults.h:47 */
+    c->min_alt_bq = 6;   /* defaults.h:49 */
+    c->def_alt_bq = 0;   /* defaults.h:50 */
+    c->min_jq = 0;
+    c->min_alt_jq = 0;
+    c->def_alt_jq = 0;
+    c->min_cov = 1;      /* defaults.h:64 */
+    c->bonf_dynamic = 1;
+    c->bonf_subst = 1;
+    c->sig = 0.01;       /* defaults.h:73, stored as float (snpcaller.h:53) */
+    c->flag = ORC_USE_MQ | ORC_USE_BAQ;
+    c->raw_counts_after_minbq = 0;
+    c->num_snv_tests = 0;
+}
+
+/* utils.h:42  PHREDQUAL_TO_PROB */
+double orc_phred_to_prob(int q)
+{
+    if (q == INT_MAX) {
+        return DBL_MIN;
+    }
+    return pow(10.0, -1.0 * q / 10.0);
+}
+
+/* utils.h:45  PROB_TO_PHREDQUAL: 80-bit log10l, truncation toward zero */
+int orc_prob_to_phred(long double p)
+{
+    return (int)(-10.0 * log10l(p));
+}
+
+int orc_prob_to_phred_p(const long double *p)
+{
+    return orc_prob_to_phred(*p);
+}
+
+/* utils.h:46  PROB_TO_PHREDQUAL_SAFE */
+int orc_prob_to_phred_safe(double p)
+{
+    if (p <= 0.0) {
+        return INT_MAX;
+    }
+    return (int)(-10.0 * log10l(p));
+}
+
+/* snpcaller.c:303-341.  -1 means "track missing" -> probability 0; MQ 0 -> 0.5. */
+double orc_merge_quals(int sq, int mq, int baq, int bq)
+{
+    double p_src = (sq == -1) ? 0.0 : orc_phred_to_prob(sq);
+    double p_map;
+    double p_aln = (baq == -1) ? 0.0 : orc_phred_to_prob(baq);
+    double p_base = (bq == -1) ? 0.0 : orc_phred_to_prob(bq);
+
+    if (mq == -1) {
+        p_map = 0.0;
+    } else if (mq == 0) {
+        p_map = ORC_MQ0_ERRPROB;
+    } else {
+        p_map = orc_phred_to_prob(mq);
+    }
+    /* snpcaller.c:334, same association as the C expression there */
+    return p_map + (1.0 - p_map) * p_src + (1 - p_map) * (1 - p_src) * p_aln
+           + (1 - p_map) * (1 - p_src) * (1 - p_aln) * p_base;
+}
+
+static int orc_int_cmp(const void *a, const void *b)
+{
+    int x = *(const int *)a, y = *(const int *)b;
+    return (x > y) - (x < y);
+}
+
+/* utils.c:436-457: sort a copy; even size -> truncated mean of the two middle values */
+int orc_int_median(const int *data, int n)
+{
+    int *tmp;
+    int med;
+    if (n == 0) {
+        return 0;
+    }
+    tmp = malloc(sizeof(int) * (size_t)n);
+    memcpy(tmp, data, sizeof(int) * (size_t)n);
+    qsort(tmp, (size_t)n, sizeof(int), orc_int_cmp);
+    if ((n & 1) == 0) {
+        med = (int)((tmp[n / 2] + tmp[n / 2 - 1]) / 2.0);
+    } else {
+        med = tmp[n / 2];
+    }
+    free(tmp);
+    return med;
+}
+
+/* utils.c:66-76: absolute-epsilon tolerant comparator */
+int orc_dbl_cmp(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    if (fabs(x - y) < DBL_EPSILON) {
+        return 0;
+    }
+    return (x > y) - (x < y);
+}
+
+/* snpcaller.c:693-700 */
+double orc_log_sum(double a, double b)
+{
+    if (a > b) {
+        return a + log1p(exp(b - a));
+    }
+    return b + log1p(exp(a - b));
+}
+
+/* snpcaller.c:730-741: sequential left fold from `start` to len-1 */
+double orc_probvec_tailsum(const double *pv, int start, int len)
+{
+    double acc = pv[start];
+    int i;
+    for (i = start + 1; i < len; i++) {
+        acc = orc_log_sum(acc, pv[i]);
+    }
+    return acc;
+}
+
+/* the errno / floating-point-exception clamp applied after every expl()
+ * (snpcaller.c:929-936, 1052-1059, 1174-1188) */
+static long double orc_clamp_after_expl(long double pv, int errsv)
+{
+    if (errsv || fetestexcept(ORC_FE_BAD)) {
+        return (pv < DBL_EPSILON) ? LDBL_MIN : LDBL_MAX;
+    }
+    return pv;
+}
+
+/* snpcaller.c:831-972.  Returns malloc'ed K+1 log-probabilities:
+ * [k<K] = log P(X=k), [K] = log P(X>=K); early exit returns the row at which
+ * P(X>=K)*bonf first exceeded sig. */
+double *orc_pruned_calc_prob_dist(const double *ep, int n_ep, int kmax, long long bonf, double sig,
+                                  int *rows_done)
+{
+    double *cur = malloc(sizeof(double) * (size_t)(kmax + 1));
+    double *prev = malloc(sizeof(double) * (size_t)(kmax + 1));
+    double *swp;
+    int n;
+
+    if (!cur || !prev) {
+        free(cur);
+        free(prev);
+        return NULL;
+    }
+    prev[0] = 0.0;                                          /* :863 */
+    for (n = 1; n <= n_ep; n++) {
+        double pn = ep[n - 1];
+        double l_hit, l_miss;
+        int k, kstart;
+
+        l_hit = (fabs(pn) < DBL_EPSILON) ? log(DBL_EPSILON) : log(pn);                  /* :872-876 */
+        l_miss = (fabs(pn - 1.0) < DBL_EPSILON) ? log1p(-pn + DBL_EPSILON) : log1p(-pn); /* :877-881 */
+
+        if (n < kmax) {
+            prev[n] = ORC_LOGZERO;                          /* :888-890 */
+        }
+        kstart = (n < kmax - 1) ? n : kmax - 1;             /* MIN(n, K-1), :892 */
+        for (k = kstart; k >= 1; k--) {
+            cur[k] = orc_log_sum(prev[k] + l_miss, prev[k - 1] + l_hit);   /* :894 */
+        }
+        cur[0] = prev[0] + l_miss;                          /* :899 */
+
+        if (n == kmax) {
+            cur[kmax] = prev[kmax - 1] + l_hit;             /* :913 */
+        } else if (n > kmax) {
+            long double pv;
+            int errsv;
+            cur[kmax] = orc_log_sum(prev[kmax], prev[kmax - 1] + l_hit);   /* :922 */
+            errno = 0;
+            feclearexcept(FE_ALL_EXCEPT);
+            pv = expl(cur[kmax]);
+            errsv = errno;
+            pv = orc_clamp_after_expl(pv, errsv);           /* :929-936 */
+            if (pv * (double)bonf > sig) {                  /* :950 */
+                free(prev);
+                if (rows_done) {
+                    *rows_done = n;
+                }
+                return cur;
+            }
+        }
+        swp = cur;
+        cur = prev;
+        prev = swp;
+    }
+    free(cur);
+    if (rows_done) {
+        *rows_done = n_ep;
+    }
+    return prev;                                            /* :970 */
+}
+
+/* snpcaller.c:1020-1062 */
+double *orc_poissbin(long double *pvalue, const double *ep, int n_ep, int kmax, long long bonf,
+                     double sig, int *rows_done)
+{
+    double *pv;
+    int errsv;
+    *pvalue = LDBL_MAX;
+    pv = orc_pruned_calc_prob_dist(ep, n_ep, kmax, bonf, sig, rows_done);
+    if (!pv) {
+        return NULL;
+    }
+    errno = 0;
+    feclearexcept(FE_ALL_EXCEPT);
+    *pvalue = expl(pv[kmax]);                               /* :1050 */
+    errsv = errno;
+    *pvalue = orc_clamp_after_expl(*pvalue, errsv);         /* :1052-1059 */
+    return pv;
+}
+
+/* snpcaller.c:1075-1205 (GSL approximation branch :1128-1142 not restated: it is
+ * compiled out without libgsl and off by default; approx_threshold_n > 0 is rejected
+ * upstream exactly like a no-GSL build, :1118-1125). */
+int orc_snpcaller(long double pv_out[3], double logp_out[3], const double *ep, int n_ep,
+                  const int counts[3], long long bonf, double sig, int *rows_done)
+{
+    double *probvec;
+    long double pv;
+    int i, kmax = 0;
+
+    for (i = 0; i < 3; i++) {
+        pv_out[i] = LDBL_MAX;                               /* :1101-1103 */
+        if (logp_out) {
+            logp_out[i] = NAN;
+        }
+        if (counts[i] > kmax) {
+            kmax = counts[i];
+        }
+    }
+    if (rows_done) {
+        *rows_done = 0;
+    }
+    if (kmax == 0) {
+        return 0;                                           /* :1113 */
+    }
+    probvec = orc_poissbin(&pv, ep, n_ep, kmax, bonf, sig, rows_done);   /* :1144 */
+    if (!probvec) {
+        return -1;
+    }
+    if (pv * (double)bonf > sig) {                          /* :1155 */
+        free(probvec);
+        return 0;
+    }
+    for (i = 0; i < 3; i++) {
+        double lp;
+        int errsv;
+        if (counts[i] == 0) {
+            continue;
+        }
+        errno = 0;
+        feclearexcept(FE_ALL_EXCEPT);
+        lp = orc_probvec_tailsum(probvec, counts[i], kmax + 1);   /* :1172 */
+        pv = expl(lp);
+        errsv = errno;
+        pv = orc_clamp_after_expl(pv, errsv);               /* :1174-1188 */
+        pv_out[i] = pv;
+        if (logp_out) {
+            logp_out[i] = lp;
+        }
+    }
+    free(probvec);
+    return 0;
+}
+
+static int orc_unpack_q(uint8_t v)
+{
+    return (v == ORC_Q_MISSING) ? -1 : (int)v;
+}
+
+/* snpcaller.c:346-498 on one packed column.  The reference walks plp_col_t's
+ * per-nucleotide arrays A,C,G,T (N skipped, :386); observations of one
+ * nucleotide keep their pileup (= storage) order. */
+int orc_col_errprobs(double *ep, int *n_ep, int alt_base[3], int alt_counts[3], int alt_raw[3],
+                     const uint8_t *nt, const uint8_t *bq, const uint8_t *baq, const uint8_t *mq,
+                     const uint8_t *sq, int64_t n_obs, char ref_base, const orc_conf *conf)
+{
+    int median_ref_bq = -1;
+    int alt_idx = -1;
+    int code;
+    int64_t j;
+
+    *n_ep = 0;
+    if (conf->def_alt_bq == -1) {                           /* :363-379 */
+        int ref_code = -1;
+        int64_t cnt = 0;
+        for (code = 0; code < 4; code++) {
+            if (ORC_NT4[code] == ref_base) {
+                ref_code = code;
+            }
+        }
+        if (ref_code >= 0) {
+            int *tmp = malloc(sizeof(int) * (size_t)(n_obs > 0 ? n_obs : 1));
+            for (j = 0; j < n_obs; j++) {
+                if ((nt[j] & 7) == ref_code) {
+                    tmp[cnt++] = bq[j];
+                }
+            }
+            if (cnt) {
+                median_ref_bq = orc_int_median(tmp, (int)cnt);
+            }
+            free(tmp);
+        }
+    }
+
+    for (code = 0; code < 4; code++) {                      /* :383-388, N skipped */
+        int is_alt = (ORC_NT4[code] != ref_base);
+        if (is_alt) {                                       /* :391-397 */
+            alt_idx++;
+            if (alt_idx > 2) {
+                return -1;   /* ref_base not in ACGT: caller must gate (lofreq_call.c:754) */
+            }
+            alt_base[alt_idx] = ORC_NT4[code];
+            alt_counts[alt_idx] = 0;
+            alt_raw[alt_idx] = 0;
+        }
+        for (j = 0; j < n_obs; j++) {
+            int q_base, q_aln = -1, q_map = -1, q_src = -1, q_joint;
+            double p_joint;
+            if ((nt[j] & 7) != code) {
+                continue;
+            }
+            q_base = bq[j];
+            if (is_alt && !conf->raw_counts_after_minbq) {
+                alt_raw[alt_idx]++;                         /* :418-420 (HEAD: before the BQ filter) */
+            }
+            if (q_base < conf->min_bq) {                    /* :426 */
+                continue;
+            }
+            if (is_alt && conf->raw_counts_after_minbq) {
+                alt_raw[alt_idx]++;                         /* lofreq 2.1.4 placement */
+            }
+            if (is_alt) {                                   /* :431-441 */
+                if (q_base < conf->min_alt_bq) {
+                    continue;
+                } else if (conf->def_alt_bq == -1) {
+                    q_base = median_ref_bq;
+                } else if (conf->def_alt_bq != 0) {
+                    q_base = conf->def_alt_bq;
+                }
+            }
+            if ((conf->flag & ORC_USE_BAQ) && baq) {        /* :444-446 */
+                q_aln = orc_unpack_q(baq[j]);
+            }
+            if (conf->flag & ORC_USE_MQ) {                  /* :448-453 */
+                q_map = mq[j];
+                if (q_map == 255) {
+                    q_map = -1;
+                }
+            }
+            if ((conf->flag & ORC_USE_SQ) && sq) {          /* :461-463 */
+                q_src = orc_unpack_q(sq[j]);
+            }
+            p_joint = orc_merge_quals(q_src, q_map, q_aln, q_base);   /* :465 */
+            q_joint = orc_prob_to_phred_safe(p_joint);                /* :466 */
+            if (q_joint < conf->min_jq) {                   /* :469 */
+                continue;
+            }
+            if (is_alt) {                                   /* :473-490 */
+                if (q_joint < conf->min_alt_jq) {
+                    continue;
+                } else if (conf->def_alt_jq == -1) {
+                    return -2;   /* reference aborts: "median off ref joined q not implemented" */
+                } else if (conf->def_alt_jq != 0) {
+                    p_joint = orc_phred_to_prob(conf->def_alt_jq);
+                }
+                alt_counts[alt_idx]++;
+            }
+            ep[(*n_ep)++] = p_joint;                        /* :491 */
+        }
+    }
+    return 0;
+}
+
+/* lofreq_call.c:735-879 over a batch; call_vars' ref gate (:892) included.
+ * The consensus-indel gate of call_vars (:928-931) needs cons_base, which is a
+ * pileup-side quantity: the caller expresses it through num_bases/coverage_plp. */
+int orc_call_batch(const uint8_t *nt, const uint8_t *bq, const uint8_t *baq, const uint8_t *mq,
+                   const uint8_t *sq, const uint64_t *col_off, const uint8_t *ref_base,
+                   const int32_t *coverage_plp, const int32_t *num_bases, int64_t ncols,
+                   orc_conf *conf, orc_col_result *out, orc_timing *timing)
+{
+    int64_t c;
+    uint64_t max_obs = 1;
+    double *ep;
+
+    for (c = 0; c < ncols; c++) {
+        uint64_t d = col_off[c + 1] - col_off[c];
+        if (d > max_obs) {
+            max_obs = d;
+        }
+    }
+    ep = malloc(sizeof(double) * max_obs);
+    if (!ep) {
+        return -1;
+    }
+    if (timing) {
+        timing->t_merge = timing->t_sort = timing->t_dp = 0.0;
+    }
+
+    for (c = 0; c < ncols; c++) {
+        orc_col_result *r = &out[c];
+        uint64_t o0 = col_off[c];
+        int64_t n_obs = (int64_t)(col_off[c + 1] - o0);
+        int cov = coverage_plp ? coverage_plp[c] : (int)n_obs;
+        int nb = num_bases ? num_bases[c] : (int)n_obs;
+        char ref = (char)ref_base[c];
+        int i, rc, any_alt = 0;
+        int64_t j;
+        double t0, t1, t2, t3;
+
+        memset(r, 0, sizeof(*r));
+        for (i = 0; i < 3; i++) {
+            r->pvalue[i] = LDBL_MAX;
+            r->logp[i] = NAN;
+            r->qual[i] = -1;
+        }
+        for (j = 0; j < n_obs; j++) {                       /* plp.c:1007-1011 */
+            int code = nt[o0 + j] & 7;
+            if (code > 4) {
+                code = 4;
+            }
+            if (nt[o0 + j] & 8) {
+                r->rv[code]++;
+            } else {
+                r->fw[code]++;
+            }
+        }
+        if (ref == 'N' || !(ref == 'A' || ref == 'C' || ref == 'G' || ref == 'T')) {
+            continue;                                       /* lofreq_call.c:754, 892; plp.c:819-823 */
+        }
+        if (nb * 2 < cov) {
+            continue;                                       /* lofreq_call.c:930 */
+        }
+        if (nb < conf->min_cov) {
+            continue;                                       /* lofreq_call.c:747 */
+        }
+
+        t0 = orc_now();
+        rc = orc_col_errprobs(ep, &r->n_err_probs, r->alt_base, r->alt_counts, r->alt_raw_counts,
+                              nt + o0, bq + o0, baq ? baq + o0 : NULL, mq + o0, sq ? sq + o0 : NULL,
+                              n_obs, ref, conf);
+        t1 = orc_now();
+        if (rc) {
+            free(ep);
+            return rc;
+        }
+        for (i = 0; i < 3; i++) {
+            if (r->alt_counts[i]) {
+                any_alt = 1;
+            }
+        }
+        if (timing) {
+            timing->t_merge += t1 - t0;
+        }
+        if (!any_alt) {
+            continue;                                       /* lofreq_call.c:768-780 */
+        }
+        qsort(ep, (size_t)r->n_err_probs, sizeof(double), orc_dbl_cmp);   /* lofreq_call.c:784 */
+        t2 = orc_now();
+
+        if (conf->bonf_dynamic) {                           /* lofreq_call.c:794-800 */
+            if (conf->bonf_subst == 1) {
+                conf->bonf_subst = 3;
+            } else {
+                conf->bonf_subst += 3;
+            }
+        }
+        conf->num_snv_tests += 3;                           /* lofreq_call.c:801 */
+        r->tested = 1;
+        r->bonf_used = conf->bonf_subst;
+
+        rc = orc_snpcaller(r->pvalue, r->logp, ep, r->n_err_probs, r->alt_counts, conf->bonf_subst,
+                           (double)conf->sig, &r->dp_rows);   /* lofreq_call.c:807 */
+        t3 = orc_now();
+        if (timing) {
+            timing->t_sort += t2 - t1;
+            timing->t_dp += t3 - t2;
+        }
+        if (rc) {
+            free(ep);
+            return rc;
+        }
+        for (i = 0; i < 3; i++) {
+            if (r->pvalue[i] * (double)conf->bonf_subst < conf->sig) {   /* lofreq_call.c:832 */
+                r->emitted[i] = 1;
+                r->qual[i] = orc_prob_to_phred(r->pvalue[i]);            /* lofreq_call.c:863 */
+            }
+        }
+    }
+    free(ep);
+    return 0;
+}
+
+/* ---- fet.c: Fisher's exact test (samtools 0.1.18 kfunc) ------------------ */
+
+static double orc_lchoose(int n, int k)                     /* fet.c:13-17 */
+{
+    if (k == 0 || n == k) {
+        return 0;
+    }
+    return lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1);
+}
+
+static double orc_hyper(int n11, int n1_, int n_1, int n)   /* fet.c:26-29 */
+{
+    return exp(orc_lchoose(n1_, n11) + orc_lchoose(n - n1_, n_1 - n11) - orc_lchoose(n, n_1));
+}
+
+typedef struct {
+    int n11, n1_, n_1, n;
+    double p;
+} orc_hyper_state;
+
+/* fet.c:37-61: incremental hypergeometric; re-anchored every 11th n11 */
+static double orc_hyper_step(int n11, int n1_, int n_1, int n, orc_hyper_state *s)
+{
+    if (n1_ || n_1 || n) {
+        s->n11 = n11;
+        s->n1_ = n1_;
+        s->n_1 = n_1;
+        s->n = n;
+    } else {
+        if (n11 % 11 && n11 + s->n - s->n1_ - s->n_1) {
+            if (n11 == s->n11 + 1) {
+                s->p *= (double)(s->n1_ - s->n11) / n11 * (s->n_1 - s->n11)
+                        / (n11 + s->n - s->n1_ - s->n_1);
+                s->n11 = n11;
+                return s->p;
+            }
+            if (n11 == s->n11 - 1) {
+                s->p *= (double)s->n11 / (s->n1_ - n11) * (s->n11 + s->n - s->n1_ - s->n_1)
+                        / (s->n_1 - n11);
+                s->n11 = n11;
+                return s->p;
+            }
+        }
+        s->n11 = n11;
+    }
+    s->p = orc_hyper(s->n11, s->n1_, s->n_1, s->n);
+    return s->p;
+}
+
+/* fet.c:62-99 */
+double orc_fisher_exact(int n11, int n12, int n21, int n22, double *left_out, double *right_out,
+                        double *two_out)
+{
+    orc_hyper_state st;
+    int row1 = n11 + n12, col1 = n11 + n21, tot = n11 + n12 + n21 + n22;
+    int hi = (col1 < row1) ? col1 : row1;
+    int lo = row1 + col1 - tot;
+    int i, j;
+    double p, q, left, right;
+
+    if (lo < 0) {
+        lo = 0;
+    }
+    *two_out = *left_out = *right_out = 1.;
+    if (lo == hi) {
+        return 1.;
+    }
+    q = orc_hyper_step(n11, row1, col1, tot, &st);
+    p = orc_hyper_step(lo, 0, 0, 0, &st);
+    for (left = 0., i = lo + 1; p < 0.99999999 * q; ++i) {
+        left += p;
+        p = orc_hyper_step(i, 0, 0, 0, &st);
+    }
+    --i;
+    if (p < 1.00000001 * q) {
+        left += p;
+    } else {
+        --i;
+    }
+    p = orc_hyper_step(hi, 0, 0, 0, &st);
+    for (right = 0., j = hi - 1; p < 0.99999999 * q; --j) {
+        right += p;
+        p = orc_hyper_step(j, 0, 0, 0, &st);
+    }
+    ++j;
+    if (p < 1.00000001 * q) {
+        right += p;
+    } else {
+        ++j;
+    }
+    *two_out = left + right;
+    if (*two_out > 1.) {
+        *two_out = 1.;
+    }
+    if (abs(i - n11) < abs(j - n11)) {
+        right = 1. - left + q;
+    } else {
+        left = 1.0 - right + q;
+    }
+    *left_out = left;
+    *right_out = right;
+    return q;
+}
+
+/* lofreq_call.c:117-129 */
+int orc_sb_phred(int ref_fw, int ref_rv, int alt_fw, int alt_rv)
+{
+    double l, r, two;
+    if ((ref_fw + ref_rv) == 0 && (alt_fw == 0 || alt_rv == 0)) {
+        return INT_MAX;
+    }
+    (void)orc_fisher_exact(ref_fw, ref_rv, alt_fw, alt_rv, &l, &r, &two);
+    return orc_prob_to_phred_safe(two);
+}
+
+/* vcf.c:469-497 + 608-629; AF as float division (lofreq_call.c:835) printed with %f */
+int orc_format_snv(char *buf, int buflen, const char *chrom, long pos0, char ref, char alt,
+                   int qual, int dp, int alt_raw_count, int sb, int ref_fw, int ref_rv,
+                   int alt_fw, int alt_rv, int hqa, int with_hqa, const char *filter)
+{
+    float af = alt_raw_count / (float)dp;
+    int n = snprintf(buf, (size_t)buflen, "%s\t%ld\t.\t%c\t%c\t%d\t%s\tDP=%d;AF=%f;SB=%d;DP4=%d,%d,%d,%d",
+                     chrom, pos0 + 1, ref, alt, qual, filter ? filter : ".", dp, af, sb, ref_fw,
+                     ref_rv, alt_fw, alt_rv);
+    if (with_hqa && n < buflen) {
+        n += snprintf(buf + n, (size_t)(buflen - n), ";HQA=%d", hqa);
+    }
+    if (n < buflen) {
+        n += snprintf(buf + n, (size_t)(buflen - n), "\n");
+    }
+    return n;
+}
+
+/* ---- multtest.c ----------------------------------------------------------- */
+
+typedef struct {
+    double p;
+    long i;
+} orc_ixp;
+
+static int orc_ixp_cmp(const void *a, const void *b)        /* multtest.c:51-57 */
+{
+    return orc_dbl_cmp(&((const orc_ixp *)a)->p, &((const orc_ixp *)b)->p);
+}
+
+void orc_bonf_corr(double *data, long n, long num_tests)    /* multtest.c:66-81 */
+{
+    long fac = (num_tests < 1) ? n : num_tests;
+    long i;
+    for (i = 0; i < n; i++) {
+        data[i] *= fac;
+    }
+}
+
+void orc_holm_bonf_corr(double *data, long n, double alpha, long num_tests)   /* multtest.c:91-136 */
+{
+    orc_ixp *ix = malloc(sizeof(orc_ixp) * (size_t)(n > 0 ? n : 1));
+    long i, lp = (num_tests < 1) ? n : num_tests;
+    double seen;
+    for (i = 0; i < n; i++) {
+        ix[i].i = i;
+        ix[i].p = data[i];
+    }
+    qsort(ix, (size_t)n, sizeof(orc_ixp), orc_ixp_cmp);
+    seen = n ? ix[0].p : 0.0;
+    for (i = 0; i < n; i++) {
+        double tp;
+        if (orc_dbl_cmp(&ix[i].p, &seen) != 0) {
+            lp = (num_tests < 1) ? n - i : num_tests - i;
+            seen = ix[i].p;
+        }
+        tp = ix[i].p * 1. / lp;
+        if (orc_dbl_cmp(&tp, &alpha) < 0) {
+            data[ix[i].i] = ix[i].p * lp;
+        }
+    }
+    free(ix);
+}
+
+/* multtest.c:148-189: Benjamini-Hochberg; note the float division in the threshold */
+long orc_fdr(const double *data, long n, double alpha, long num_tests, long *rejected_idx)
+{
+    orc_ixp *ix = malloc(sizeof(orc_ixp) * (size_t)(n > 0 ? n : 1));
+    long i, nrej = 0, m = (num_tests < 1) ? n : num_tests;
+    for (i = 0; i < n; i++) {
+        ix[i].i = i;
+        ix[i].p = data[i];
+    }
+    qsort(ix, (size_t)n, sizeof(orc_ixp), orc_ixp_cmp);
+    for (i = n; i > 0; i--) {
+        if (ix[i - 1].p < (alpha * i / (float)m)) {
+            nrej = i;
+            break;
+        }
+    }
+    if (rejected_idx) {
+        for (i = 0; i < nrej; i++) {
+            rejected_idx[i] = ix[i].i;
+        }
+    }
+    free(ix);
+    return nrej;
+}
+
+/* lofreq_call.c:1523-1527: float / long long division, then 80-bit log10l */
+int orc_snvqual_thresh(float sig, long long bonf_subst)
+{
+    int t = INT_MAX;
+    if (bonf_subst) {
+        t = orc_prob_to_phred(sig / bonf_subst);
+        if (t < 0) {
+            t = 0;
+        }
+    }
+    return t;
+}
+
+/* `lofreq filter` as run by `lofreq call` (lofreq_call.c:1506-1538) on SNV records:
+ *   QUAL threshold (lofreq_filter.c:313-323), and unless --no-defaults:
+ *   DP >= 10 (lofreq_filter.c:1095-1097, 270-305) and strand-bias FDR alpha 0.001 with the
+ *   "alt mostly on one strand" compound rule (lofreq_filter.c:57, 210-236, 582-677, 1089-1094).
+ * The SB multiple-testing pass runs over ALL input records (first pass of the VCF). */
+int orc_default_filter(const int *qual, const int *dp, const int *sb, const int *alt_fw,
+                       const int *alt_rv, long n, int snvqual_thresh, int apply_defaults, int *keep)
+{
+    long i;
+    for (i = 0; i < n; i++) {
+        keep[i] = 1;
+    }
+    if (apply_defaults && n > 0) {
+        double *sbp = malloc(sizeof(double) * (size_t)n);
+        long *rej = malloc(sizeof(long) * (size_t)n);
+        long nrej;
+        const double alpha = 0.001;
+        for (i = 0; i < n; i++) {
+            sbp[i] = orc_phred_to_prob(sb[i]);              /* lofreq_filter.c:611 */
+        }
+        nrej = orc_fdr(sbp, n, alpha, n, rej);              /* ntests = #variants, :620-621 */
+        for (i = 0; i < nrej; i++) {
+            long v = rej[i];
+            float ratio = ((alt_fw[v] > alt_rv[v]) ? alt_fw[v] : alt_rv[v])
+                          / (float)(alt_fw[v] + alt_rv[v]);  /* lofreq_filter.c:227 */
+            if (ratio > 0.85) {                             /* ALT_STRAND_RATIO, :57, :231 */
+                keep[v] = 0;
+            }
+        }
+        free(sbp);
+        free(rej);
+        for (i = 0; i < n; i++) {
+            if (dp[i] < 10) {                               /* :301-303 */
+                keep[i] = 0;
+            }
+        }
+    }
+    if (snvqual_thresh) {
+        for (i = 0; i < n; i++) {
+            if (qual[i] > -1 && qual[i] < snvqual_thresh) { /* :319 */
+                keep[i] = 0;
+            }
+        }
+    }
+    return 0;
+}

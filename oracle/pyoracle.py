@@ -1,0 +1,244 @@
+"""ctypes binding of oracle/liblofreq_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; nothing under lofreq_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblofreq_oracle.so")
+
+
+def build(force=False):
+    """Compile the C restatement (and, where the reference tree is mounted, oracle/_ref)."""
+    src_newer = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("lofreq_oracle.c", "lofreq_oracle.h", "synth_ref.c")
+    )
+    if force or src_newer:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    if os.path.isdir("/root/reference/src/lofreq"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+
+
+class Conf(C.Structure):
+    _fields_ = [
+        ("min_bq", C.c_int32), ("min_alt_bq", C.c_int32), ("def_alt_bq", C.c_int32),
+        ("min_jq", C.c_int32), ("min_alt_jq", C.c_int32), ("def_alt_jq", C.c_int32),
+        ("bonf_dynamic", C.c_int32), ("min_cov", C.c_int32),
+        ("bonf_subst", C.c_int64), ("sig", C.c_float), ("flag", C.c_int32),
+        ("raw_counts_after_minbq", C.c_int32), ("num_snv_tests", C.c_int64),
+    ]
+
+
+class ColResult(C.Structure):
+    _fields_ = [
+        ("n_err_probs", C.c_int32), ("alt_counts", C.c_int32 * 3),
+        ("alt_raw_counts", C.c_int32 * 3), ("alt_base", C.c_int32 * 3),
+        ("tested", C.c_int32), ("fw", C.c_int32 * 5), ("rv", C.c_int32 * 5),
+        ("bonf_used", C.c_int64), ("logp", C.c_double * 3),
+        ("pvalue", C.c_longdouble * 3), ("emitted", C.c_int32 * 3),
+        ("qual", C.c_int32 * 3), ("dp_rows", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
+COL_RESULT_DTYPE = np.dtype([
+    ("n_err_probs", "i4"), ("alt_counts", "i4", 3), ("alt_raw_counts", "i4", 3), ("alt_base", "i4", 3),
+    ("tested", "i4"), ("fw", "i4", 5), ("rv", "i4", 5), ("bonf_used", "i8"), ("logp", "f8", 3),
+    ("pvalue", np.longdouble, 3), ("emitted", "i4", 3), ("qual", "i4", 3), ("dp_rows", "i4"),
+    ("pad_", "i4")], align=True)
+assert COL_RESULT_DTYPE.itemsize == C.sizeof(ColResult), (COL_RESULT_DTYPE.itemsize, C.sizeof(ColResult))
+
+LDBL_MAX = np.finfo(np.longdouble).max
+LDBL_MIN = np.finfo(np.longdouble).tiny
+_ldp = C.POINTER(C.c_longdouble)
+
+
+class Timing(C.Structure):
+    _fields_ = [("t_merge", C.c_double), ("t_sort", C.c_double), ("t_dp", C.c_double)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("depth", C.c_uint32), ("plant_period", C.c_uint32),
+                ("err_thresh", C.c_uint64 * 64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_conf_init.argtypes = [C.POINTER(Conf)]
+        L.orc_phred_to_prob.restype = C.c_double
+        L.orc_phred_to_prob.argtypes = [C.c_int]
+        L.orc_prob_to_phred_p.restype = C.c_int
+        L.orc_prob_to_phred_p.argtypes = [_ldp]
+        L.orc_prob_to_phred_safe.restype = C.c_int
+        L.orc_prob_to_phred_safe.argtypes = [C.c_double]
+        L.orc_merge_quals.restype = C.c_double
+        L.orc_merge_quals.argtypes = [C.c_int] * 4
+        L.orc_int_median.restype = C.c_int
+        L.orc_int_median.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.orc_log_sum.restype = C.c_double
+        L.orc_log_sum.argtypes = [C.c_double, C.c_double]
+        L.orc_poissbin.restype = C.POINTER(C.c_double)
+        L.orc_poissbin.argtypes = [_ldp, C.POINTER(C.c_double), C.c_int, C.c_int,
+                                   C.c_longlong, C.c_double, C.POINTER(C.c_int)]
+        L.orc_snpcaller.restype = C.c_int
+        L.orc_snpcaller.argtypes = [_ldp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.c_int, C.POINTER(C.c_int), C.c_longlong, C.c_double,
+                                    C.POINTER(C.c_int)]
+        L.orc_call_batch.restype = C.c_int
+        L.orc_call_batch.argtypes = [u8p, u8p, u8p, u8p, u8p, C.POINTER(C.c_uint64), u8p,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64,
+                                     C.POINTER(Conf), C.POINTER(ColResult), C.POINTER(Timing)]
+        L.orc_fisher_exact.restype = C.c_double
+        L.orc_fisher_exact.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double)] * 3
+        L.orc_sb_phred.restype = C.c_int
+        L.orc_sb_phred.argtypes = [C.c_int] * 4
+        L.orc_format_snv.restype = C.c_int
+        L.orc_format_snv.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long, C.c_char, C.c_char,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_char_p]
+        L.orc_bonf_corr.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_long]
+        L.orc_holm_bonf_corr.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_double, C.c_long]
+        L.orc_fdr.restype = C.c_long
+        L.orc_fdr.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_double, C.c_long, C.POINTER(C.c_long)]
+        L.orc_snvqual_thresh.restype = C.c_int
+        L.orc_snvqual_thresh.argtypes = [C.c_float, C.c_longlong]
+        L.orc_default_filter.restype = C.c_int
+        L.orc_default_filter.argtypes = [C.POINTER(C.c_int)] * 5 + [C.c_long, C.c_int, C.c_int,
+                                                                    C.POINTER(C.c_int)]
+        L.orc_synth_init_spec.argtypes = [C.POINTER(SynthSpec), C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_synth_fill.argtypes = [C.POINTER(SynthSpec), C.c_int64, C.c_int64, u8p, u8p, u8p, u8p,
+                                     C.POINTER(C.c_uint64), u8p]
+        _lib = L
+    return _lib
+
+
+def default_conf(**kw):
+    c = Conf()
+    lib().orc_conf_init(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _u8(a):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def poissbin(err_probs, k, bonf=1, sig=1.0):
+    """-> (probvec[K] as float, pvalue as np.longdouble, rows_done)"""
+    ep = np.ascontiguousarray(err_probs, dtype=np.float64)
+    pv = np.zeros(1, np.longdouble)
+    rows = C.c_int()
+    p = lib().orc_poissbin(pv.ctypes.data_as(_ldp), ep.ctypes.data_as(C.POINTER(C.c_double)), len(ep),
+                           int(k), int(bonf), float(sig), C.byref(rows))
+    vec = np.array([p[i] for i in range(k + 1)])
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(C.cast(p, C.c_void_p))
+    return vec, pv[0], rows.value
+
+
+def snpcaller(err_probs, counts, bonf, sig):
+    ep = np.ascontiguousarray(err_probs, dtype=np.float64)
+    pv = np.zeros(3, np.longdouble)
+    lp = (C.c_double * 3)()
+    cnt = (C.c_int * 3)(*[int(x) for x in counts])
+    rows = C.c_int()
+    rc = lib().orc_snpcaller(pv.ctypes.data_as(_ldp), lp, ep.ctypes.data_as(C.POINTER(C.c_double)),
+                             len(ep), cnt, int(bonf), float(sig), C.byref(rows))
+    assert rc == 0
+    return pv, [lp[i] for i in range(3)], rows.value
+
+
+def prob_to_phred(p):
+    """PROB_TO_PHREDQUAL on an np.longdouble without losing the 80-bit range."""
+    a = np.array([p], np.longdouble)
+    return lib().orc_prob_to_phred_p(a.ctypes.data_as(_ldp))
+
+
+def call_batch(nt, bq, baq, mq, sq, col_off, ref_base, conf, coverage_plp=None, num_bases=None,
+               timing=False):
+    """Run the restated call_snvs loop; returns (structured ndarray, Timing|None). conf is mutated."""
+    col_off = np.ascontiguousarray(col_off, dtype=np.uint64)
+    ncols = len(col_off) - 1
+    keep = []
+    ptrs = []
+    for a in (nt, bq, baq, mq, sq):
+        if a is None:
+            ptrs.append(None)
+        else:
+            arr, p = _u8(a)
+            keep.append(arr)
+            ptrs.append(p)
+    rb, rbp = _u8(np.frombuffer(ref_base, dtype=np.uint8) if isinstance(ref_base, (bytes, bytearray))
+                  else ref_base)
+    cov_p = nb_p = None
+    if coverage_plp is not None:
+        cov = np.ascontiguousarray(coverage_plp, dtype=np.int32)
+        cov_p = cov.ctypes.data_as(C.POINTER(C.c_int32))
+    if num_bases is not None:
+        nb = np.ascontiguousarray(num_bases, dtype=np.int32)
+        nb_p = nb.ctypes.data_as(C.POINTER(C.c_int32))
+    out = (ColResult * max(ncols, 1))()
+    tm = Timing()
+    rc = lib().orc_call_batch(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                              col_off.ctypes.data_as(C.POINTER(C.c_uint64)), rbp, cov_p, nb_p, ncols,
+                              C.byref(conf), out, C.byref(tm))
+    if rc != 0:
+        raise RuntimeError("orc_call_batch failed: %d" % rc)
+    res = np.frombuffer(out, dtype=COL_RESULT_DTYPE, count=max(ncols, 1))[:ncols].copy()
+    return res, (tm if timing else None)
+
+
+def synth_fill(seed, depth, plant_period, col_begin, ncols):
+    """CPU generator of the synthetic workload (include/lofreq_synth.h)."""
+    spec = SynthSpec()
+    lib().orc_synth_init_spec(C.byref(spec), seed, depth, plant_period)
+    n = ncols * depth
+    nt = np.empty(n, np.uint8)
+    bq = np.empty(n, np.uint8)
+    baq = np.empty(n, np.uint8)
+    mq = np.empty(n, np.uint8)
+    off = np.empty(ncols + 1, np.uint64)
+    ref = np.empty(ncols, np.uint8)
+    u8p = C.POINTER(C.c_uint8)
+    lib().orc_synth_fill(C.byref(spec), col_begin, ncols, nt.ctypes.data_as(u8p), bq.ctypes.data_as(u8p),
+                         baq.ctypes.data_as(u8p), mq.ctypes.data_as(u8p),
+                         off.ctypes.data_as(C.POINTER(C.c_uint64)), ref.ctypes.data_as(u8p))
+    return dict(nt=nt, bq=bq, baq=baq, mq=mq, col_off=off, ref_base=ref, spec=spec)
+
+
+def ref_parts():
+    """The reference's own fet.c/multtest.c/utils.c objects (oracle/_ref), or None if absent."""
+    p = os.path.join(_HERE, "_ref", "libref_parts.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    L.kt_fisher_exact.restype = C.c_double
+    L.kt_fisher_exact.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double)] * 3
+    L.fdr.restype = C.c_long
+    L.fdr.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_double, C.c_long,
+                      C.POINTER(C.POINTER(C.c_long))]
+    L.bonf_corr.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_long]
+    L.holm_bonf_corr.argtypes = [C.POINTER(C.c_double), C.c_long, C.c_double, C.c_long]
+    L.int_median.restype = C.c_int
+    L.int_median.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.dbl_cmp.restype = C.c_int
+    L.dbl_cmp.argtypes = [C.c_void_p, C.c_void_p]
+    return L

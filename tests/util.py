@@ -1,0 +1,159 @@
+"""Shared helpers for the parity tests: seeded random pileup batches and oracle/HIP comparison."""
+import ctypes as C
+
+import numpy as np
+
+LDBL_MAX = np.finfo(np.longdouble).max
+LDBL_MIN = np.finfo(np.longdouble).tiny
+
+# tolerance stated by BASELINE.json north_star: p-values within 1e-10 relative (= 1e-10 absolute on
+# the natural log of the p-value)
+PV_LOG_TOL = 1e-10
+
+
+def random_batch(rng, ncols, depth_lo, depth_hi, alt_rate=0.002, with_sq=False, with_baq=True,
+                 low_bq_frac=0.02, n_frac=0.01, planted=None, ref_n_frac=0.0):
+    """Packed host tracks with ragged depths, N bases, low BQ, MQ 0/255, missing BAQ."""
+    depths = rng.integers(depth_lo, depth_hi + 1, size=ncols)
+    off = np.zeros(ncols + 1, np.uint64)
+    off[1:] = np.cumsum(depths)
+    n = int(off[-1])
+    ref_code = rng.integers(0, 4, size=ncols)
+    ref_base = np.frombuffer(b"ACGT", np.uint8)[ref_code].copy()
+    if ref_n_frac > 0:
+        ref_base[rng.random(ncols) < ref_n_frac] = ord("N")
+    col_of = np.repeat(np.arange(ncols), depths)
+    code = ref_code[col_of].copy()
+    rate = np.full(n, alt_rate)
+    if planted:
+        for c, af in planted.items():
+            rate[off[c]:off[c + 1]] = af
+    is_alt = rng.random(n) < rate
+    shift = rng.integers(1, 4, size=n)
+    code[is_alt] = (code[is_alt] + shift[is_alt]) % 4
+    code[rng.random(n) < n_frac] = 4
+    strand = rng.integers(0, 2, size=n)
+    nt = (code | (strand << 3)).astype(np.uint8)
+    bq = np.clip(np.round(rng.normal(33, 6, n)), 0, 93).astype(np.uint8)
+    low = rng.random(n) < low_bq_frac
+    bq[low] = rng.integers(0, 8, size=int(low.sum()))
+    mq = np.where(rng.random(n) < 0.9, 60, rng.integers(0, 61, size=n)).astype(np.uint8)
+    mq[rng.random(n) < 0.01] = 255
+    mq[rng.random(n) < 0.01] = 0
+    baq = None
+    if with_baq:
+        baq = np.where(rng.random(n) < 0.85, 93, rng.integers(0, 94, size=n)).astype(np.uint8)
+        baq[rng.random(n) < 0.02] = 255
+    sq = None
+    if with_sq:
+        sq = rng.integers(5, 60, size=n).astype(np.uint8)
+        sq[rng.random(n) < 0.05] = 255
+    return dict(nt=nt, bq=bq, baq=baq, mq=mq, sq=sq, col_off=off, ref_base=ref_base)
+
+
+def uniform_p_column(n_obs, counts, ref=b"A", bq=30):
+    """A column whose every merged error probability is exactly 10^(-bq/10) (BAQ missing, MQ NA),
+    with the given (c0, c1, c2) alt counts -- the construction behind SURVEY App. A.6."""
+    code = np.zeros(n_obs, np.int64)
+    pos = 0
+    for a, c in enumerate(counts):
+        code[pos:pos + c] = a + 1
+        pos += c
+    nt = code.astype(np.uint8)
+    nt[1::2] |= 8
+    return dict(nt=nt, bq=np.full(n_obs, bq, np.uint8), baq=np.full(n_obs, 255, np.uint8),
+                mq=np.full(n_obs, 255, np.uint8), sq=None,
+                col_off=np.array([0, n_obs], np.uint64), ref_base=np.frombuffer(ref, np.uint8).copy())
+
+
+def concat_batches(batches):
+    out = {}
+    for k in ("nt", "bq", "baq", "mq", "sq"):
+        vals = [b[k] for b in batches]
+        out[k] = None if any(v is None for v in vals) else np.concatenate(vals)
+    offs = [np.zeros(1, np.uint64)]
+    base = 0
+    for b in batches:
+        offs.append(b["col_off"][1:] + np.uint64(base))
+        base += int(b["col_off"][-1])
+    out["col_off"] = np.concatenate(offs)
+    out["ref_base"] = np.concatenate([b["ref_base"] for b in batches])
+    return out
+
+
+def to_pileup_batch(la, host):
+    return la.PileupBatch(host["nt"], host["bq"], host["mq"], host["col_off"], host["ref_base"],
+                          baq=host["baq"], sq=host["sq"], coverage_plp=host.get("coverage_plp"),
+                          num_bases=host.get("num_bases"))
+
+
+def oracle_conf(orc, **kw):
+    return orc.default_conf(**kw)
+
+
+def run_oracle(orc, host, **conf_kw):
+    oc = orc.default_conf(**conf_kw)
+    res, _ = orc.call_batch(host["nt"], host["bq"], host["baq"], host["mq"], host["sq"], host["col_off"],
+                            host["ref_base"], oc, coverage_plp=host.get("coverage_plp"),
+                            num_bases=host.get("num_bases"))
+    return res, oc
+
+
+def run_layer1(la, caller, host, conf):
+    """Upload a host batch with torch, run the kernels only, return (counts, pvals sorted by col, stats)."""
+    import torch
+    dev = torch.device("cuda", caller.device)
+
+    def up(a, dtype=torch.uint8):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a)
+        t = torch.zeros((a.size + 15) // 16 * 16 + 16, dtype=dtype, device=dev)
+        if a.size:
+            t[: a.size] = torch.from_numpy(a.view(np.uint8) if dtype == torch.uint8 else a).to(dev)
+        return t
+
+    ncols = len(host["col_off"]) - 1
+    off = torch.from_numpy(host["col_off"].astype(np.int64)).to(dev)
+    b = la.PileupBatch(up(host["nt"]), up(host["bq"]), up(host["mq"]), off, up(host["ref_base"]),
+                       baq=up(host["baq"]), sq=up(host["sq"]), on_device=True)
+    b.ncols = ncols
+    d_counts = torch.zeros(max(ncols, 1) * 64, dtype=torch.uint8, device=dev)
+    d_pvals = torch.zeros(max(ncols, 1) * 128, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    caller.snv_batch_device(b, conf, d_counts, d_pvals, max(ncols, 1))
+    st = caller.batch_finish()
+    counts = d_counts.cpu().numpy().view(la.COL_COUNTS_DTYPE)[:ncols]
+    pvals = d_pvals.cpu().numpy().view(la.COL_PVALS_DTYPE)[: st.n_pvals]
+    pvals = pvals[np.argsort(pvals["col"], kind="stable")]
+    return counts, pvals, st
+
+
+def assert_counts_equal(counts, ores, host):
+    """Integer outputs of plp_to_errprobs + the Bonferroni 'tested' flag + strand counts: bit-exact."""
+    for f in ("n_err_probs", "alt_counts", "alt_raw_counts"):
+        assert np.array_equal(counts[f], ores[f]), f
+    assert np.array_equal(counts["tested"].astype(np.int32), ores["tested"]), "tested"
+    ng = np.nonzero(counts["gated"] == 0)[0]
+    for c in ng:
+        ref = b"ACGT".find(bytes([int(host["ref_base"][c])]))
+        alts = [x for x in range(4) if x != ref]
+        assert counts["ref_fw"][c] == ores["fw"][c, ref] and counts["ref_rv"][c] == ores["rv"][c, ref], c
+        for a, x in enumerate(alts):
+            assert counts["alt_fw"][c, a] == ores["fw"][c, x], (c, a)
+            assert counts["alt_raw_counts"][c, a] - counts["alt_fw"][c, a] == ores["rv"][c, x], (c, a)
+
+
+def log_of(pv):
+    """natural log of an np.longdouble p-value as float (80-bit log, then narrowed)."""
+    return float(np.log(np.longdouble(pv)))
+
+
+def assert_pvalue_close(pv_gpu, pv_ref, tol=PV_LOG_TOL, ctx=""):
+    """Sentinels must match exactly; finite values within `tol` relative."""
+    pv_gpu, pv_ref = np.longdouble(pv_gpu), np.longdouble(pv_ref)
+    if pv_ref == LDBL_MAX or pv_ref == LDBL_MIN or pv_gpu == LDBL_MAX or pv_gpu == LDBL_MIN:
+        assert pv_gpu == pv_ref, "sentinel mismatch %s: gpu=%r ref=%r" % (ctx, pv_gpu, pv_ref)
+        return
+    d = abs(log_of(pv_gpu) - log_of(pv_ref))
+    assert d <= tol, "p-value mismatch %s: gpu=%r ref=%r |dlog|=%g" % (ctx, pv_gpu, pv_ref, d)
