@@ -110,8 +110,10 @@ typedef struct lfq_col_counts {
 enum {
     LFQ_PV_NONE = 0,        /* count 0 or column pruned: reference returns LDBL_MAX */
     LFQ_PV_LOG = 1,         /* logp valid: pvalue = expl(logp) (+ the reference's clamp on expl) */
-    LFQ_PV_LOG_FECLAMP = 2  /* logp valid but the reference's tail-sum exp() chain underflows
+    LFQ_PV_LOG_FECLAMP = 2, /* logp valid but the reference's tail-sum exp() chain underflows
                                (snpcaller.c:1169-1188): pvalue clamps to LDBL_MIN / LDBL_MAX */
+    LFQ_PV_UNDERFLOW = 3    /* p-value proven below the 80-bit range (logp = an upper bound < -12200):
+                               the reference's expl() underflows and it reports LDBL_MIN */
 };
 
 /* sparse output: one record per column whose main allele survives the pruning test
@@ -188,6 +190,11 @@ long double lfq_pvalue_from_log(double logp, int status);
 /* --- layer 3: output and final filter --- */
 int lfq_format_snv_record(char *buf, int buflen, const char *chrom, int64_t pos0,
                           const lfq_snv_record *rec, const char *filter_or_null);
+/* all (kept) records of a batch; pos0_or_null == NULL uses rec.col as the 0-based position.
+ * Returns the byte count of the full text (written only if it fits into buflen). */
+int64_t lfq_format_vcf(char *buf, int64_t buflen, const char *chrom, const int64_t *pos0_or_null,
+                       const lfq_snv_record *recs, int64_t n, const uint8_t *keep_or_null,
+                       const char *filter_or_null);
 int lfq_snvqual_thresh(float sig, int64_t bonf_subst);             /* lofreq_call.c:1523-1527 */
 int lfq_sb_phred(int ref_fw, int ref_rv, int alt_fw, int alt_rv);  /* lofreq_call.c:117-129 */
 double lfq_fisher_exact(int n11, int n12, int n21, int n22, double *left, double *right, double *two);
@@ -206,7 +213,8 @@ int lfq_synth_fill_device(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t 
 
 /* --- device timing of the last batch (HIP events on the stream the kernels ran on) --- */
 typedef struct lfq_kernel_times {
-    float ms_count, ms_scan, ms_dp, ms_total;
+    float ms_count, ms_scan, ms_dp, ms_total;   /* ms_dp = scan end -> all three DP kernels done */
+    float ms_dp_light, ms_dp_mid, ms_dp_big;    /* the concurrent DP kernels individually */
 } lfq_kernel_times;
 int lfq_last_kernel_times(lfq_ctx *ctx, lfq_kernel_times *t);
 

@@ -6,13 +6,14 @@ Bonferroni emit test, behind LoFreq's column interface.  Compute lives in hand-w
 mirror of the reference interface plus region sharding across GPUs.
 """
 from ._lib import (COL_COUNTS_DTYPE, COL_PVALS_DTYPE, SNV_RECORD_DTYPE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP,
-                   LFQ_PV_NONE, LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ)
-from .caller import (PileupBatch, SnvCaller, VarcallConf, filter_records, finalize_pvals, format_vcf_record,
+                   LFQ_PV_NONE, LFQ_PV_UNDERFLOW, LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ)
+from .caller import (PileupBatch, SnvCaller, VarcallConf, filter_records, finalize_pvals, format_vcf,
+                     format_vcf_record,
                      pvalue_from_log, snvqual_thresh, write_vcf_header)
 
 __all__ = [
     "COL_COUNTS_DTYPE", "COL_PVALS_DTYPE", "SNV_RECORD_DTYPE", "LFQ_PV_LOG", "LFQ_PV_LOG_FECLAMP",
-    "LFQ_PV_NONE", "LFQ_USE_BAQ", "LFQ_USE_MQ", "LFQ_USE_SQ", "PileupBatch", "SnvCaller", "VarcallConf",
-    "filter_records", "finalize_pvals", "format_vcf_record", "pvalue_from_log", "snvqual_thresh",
+    "LFQ_PV_NONE", "LFQ_PV_UNDERFLOW", "LFQ_USE_BAQ", "LFQ_USE_MQ", "LFQ_USE_SQ", "PileupBatch", "SnvCaller", "VarcallConf",
+    "filter_records", "finalize_pvals", "format_vcf", "format_vcf_record", "pvalue_from_log", "snvqual_thresh",
     "write_vcf_header",
 ]

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblofreq_amd.so")
 LFQ_OK = 0
 LFQ_ERR_CAPACITY = -4
 LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ = 1, 2, 4
-LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP = 0, 1, 2
+LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP, LFQ_PV_UNDERFLOW = 0, 1, 2, 3
 LFQ_Q_MISSING = 255
 
 
@@ -45,7 +45,8 @@ class BatchStats(C.Structure):
 
 class KernelTimes(C.Structure):
     _fields_ = [("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_dp", C.c_float),
-                ("ms_total", C.c_float)]
+                ("ms_total", C.c_float), ("ms_dp_light", C.c_float), ("ms_dp_mid", C.c_float),
+                ("ms_dp_big", C.c_float)]
 
 
 COL_COUNTS_DTYPE = np.dtype([
@@ -69,7 +70,7 @@ assert SNV_RECORD_DTYPE.itemsize == 64, SNV_RECORD_DTYPE.itemsize
 EXPORTS = [
     "lfq_abi_version", "lfq_strerror", "lfq_conf_init", "lfq_create", "lfq_destroy", "lfq_synchronize",
     "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_finalize_pvals",
-    "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_snvqual_thresh", "lfq_sb_phred",
+    "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_format_vcf", "lfq_snvqual_thresh", "lfq_sb_phred",
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_last_kernel_times",
 ]
@@ -86,6 +87,12 @@ def load():
         raise RuntimeError(
             "lofreq_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C lofreq_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64; load it first so that this library binds to the
+        # same HIP runtime instead of bringing a second one into the process.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.lfq_abi_version.restype = C.c_int
@@ -105,6 +112,8 @@ def load():
     L.lfq_pvalue_from_log.restype = C.c_longdouble
     L.lfq_pvalue_from_log.argtypes = [C.c_double, C.c_int]
     L.lfq_format_snv_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, vp, C.c_char_p]
+    L.lfq_format_vcf.restype = C.c_int64
+    L.lfq_format_vcf.argtypes = [vp, C.c_int64, C.c_char_p, vp, vp, C.c_int64, vp, C.c_char_p]
     L.lfq_snvqual_thresh.argtypes = [C.c_float, C.c_int64]
     L.lfq_sb_phred.argtypes = [C.c_int] * 4
     L.lfq_fisher_exact.restype = C.c_double

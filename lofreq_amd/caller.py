@@ -161,7 +161,7 @@ class SnvCaller:
     def kernel_times(self):
         kt = _lib.KernelTimes()
         _lib.check(self.L.lfq_last_kernel_times(self.h, C.byref(kt)))
-        return dict(ms_count=kt.ms_count, ms_scan=kt.ms_scan, ms_dp=kt.ms_dp, ms_total=kt.ms_total)
+        return {k: getattr(kt, k) for k, _ in kt._fields_}
 
     def synchronize(self):
         _lib.check(self.L.lfq_synchronize(self.h))
@@ -230,6 +230,23 @@ def format_vcf_record(rec, chrom, pos0, filter_str=None):
     r = np.ascontiguousarray(np.asarray(rec).reshape(1), dtype=_lib.SNV_RECORD_DTYPE)
     n = _lib.load().lfq_format_snv_record(buf, 512, chrom.encode(), int(pos0), C.c_void_p(r.ctypes.data),
                                           filter_str.encode() if filter_str else None)
+    return buf.raw[:n].decode()
+
+
+def format_vcf(records, chrom, pos0=None, keep=None, filter_str=None):
+    """All (kept) records of a batch as VCF text in one C call (vcf_write_var, vcf.c:469-497)."""
+    r = np.ascontiguousarray(records, dtype=_lib.SNV_RECORD_DTYPE)
+    if len(r) == 0:
+        return ""
+    p = None if pos0 is None else np.ascontiguousarray(pos0, dtype=np.int64)
+    k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+    buf = C.create_string_buffer(160 * len(r) + 64 * (len(chrom) + 1))
+    n = _lib.load().lfq_format_vcf(buf, len(buf), chrom.encode(), C.c_void_p(p.ctypes.data) if p is not None else None,
+                                   C.c_void_p(r.ctypes.data), len(r),
+                                   C.c_void_p(k.ctypes.data) if k is not None else None,
+                                   filter_str.encode() if filter_str else None)
+    if n < 0 or n > len(buf):
+        raise RuntimeError("lfq_format_vcf failed (%d)" % n)
     return buf.raw[:n].decode()
 
 

@@ -42,7 +42,9 @@ struct lfq_ctx {
     /* per-batch workspace, grown on demand */
     int64_t ws_cols;
     uint8_t *d_flags;
-    int32_t *d_prefix, *d_qh, *d_ql, *d_counters;
+    int32_t *d_prefix, *d_qb, *d_qm, *d_ql, *d_counters;
+    hipStream_t side[2];       /* mid / big DP kernels run beside the light one */
+    hipEvent_t ev_fork, ev_light_done, ev_join[2], ev_side[2][2];
     uint64_t *d_tiles;
     double *d_scratch;
     int64_t scratch_doubles;
@@ -162,22 +164,25 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         int64_t want = ncols + ncols / 8 + 1024;
         if (c->d_flags) (void)hipFree(c->d_flags);
         if (c->d_prefix) (void)hipFree(c->d_prefix);
-        if (c->d_qh) (void)hipFree(c->d_qh);
+        if (c->d_qb) (void)hipFree(c->d_qb);
+        if (c->d_qm) (void)hipFree(c->d_qm);
         if (c->d_ql) (void)hipFree(c->d_ql);
         if (c->d_tiles) (void)hipFree(c->d_tiles);
         c->d_flags = nullptr;
-        c->d_prefix = c->d_qh = c->d_ql = nullptr;
+        c->d_prefix = c->d_qb = c->d_qm = c->d_ql = nullptr;
         c->d_tiles = nullptr;
         c->ws_cols = 0;
         LFQ_TRY(grow(&c->d_flags, &cap, want));
         cap = 0;
         LFQ_TRY(grow(&c->d_prefix, &cap, want));
         cap = 0;
-        LFQ_TRY(grow(&c->d_qh, &cap, want));
+        LFQ_TRY(grow(&c->d_qb, &cap, want));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_qm, &cap, want));
         cap = 0;
         LFQ_TRY(grow(&c->d_ql, &cap, want));
         cap = 0;
-        LFQ_TRY(grow(&c->d_tiles, &cap, want / 4096 + 8));
+        LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8)));
         c->ws_cols = want;
     }
     return LFQ_OK;
@@ -212,10 +217,16 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     }
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_counters, 8 * sizeof(int32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_counters, 8 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_counters, LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_counters, LFQ_NCOUNTERS * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) {
         ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    }
+    ok = ok && hipEventCreate(&c->ev_fork) == hipSuccess && hipEventCreate(&c->ev_light_done) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++) {
+        ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreate(&c->ev_join[i]) == hipSuccess;
+        ok = ok && hipEventCreate(&c->ev_side[i][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][1]) == hipSuccess;
     }
     if (ok) {
         LfqLuts h;
@@ -237,7 +248,7 @@ void lfq_destroy(lfq_ctx *c)
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_qh, c->d_ql, c->d_counters, c->d_tiles,
+    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_qb, c->d_qm, c->d_ql, c->d_counters, c->d_tiles,
                     c->d_scratch, c->d_counts, c->d_pvals, c->d_stage};
     for (void *b : bufs) {
         if (b) (void)hipFree(b);
@@ -245,6 +256,14 @@ void lfq_destroy(lfq_ctx *c)
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (int i = 0; i < 4; i++) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_light_done) (void)hipEventDestroy(c->ev_light_done);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->ev_side[i][0]) (void)hipEventDestroy(c->ev_side[i][0]);
+        if (c->ev_side[i][1]) (void)hipEventDestroy(c->ev_side[i][1]);
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
@@ -292,7 +311,8 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
 
     LfqWork W;
     W.tested_prefix = c->d_prefix;
-    W.q_heavy = c->d_qh;
+    W.q_big = c->d_qb;
+    W.q_mid = c->d_qm;
     W.q_light = c->d_ql;
     W.counters = c->d_counters;
     W.block_sums = (int32_t *)c->d_tiles;
@@ -300,32 +320,48 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     c->cur_stream = st;
     c->cur_pvals_cap = pvals_capacity;
     c->cur_ncols = tr->ncols;
-    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(int32_t), st));
+    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, LFQ_NCOUNTERS * sizeof(int32_t), st));
     LFQ_TRY_HIP(hipEventRecord(c->ev[0], st));
     LFQ_TRY(lfq_launch_count(T, P, c->d_luts, d_counts, c->d_flags, c->d_counters, st));
     LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));
     LFQ_TRY(lfq_launch_scan(tr->ncols, c->d_flags, W, st));
     LFQ_TRY_HIP(hipEventRecord(c->ev[2], st));
 
-    /* DP scratch: 2 doubles per observation (strip boundary) + K+1 log-probabilities per
-     * resident wavefront; needs the deepest column of the batch */
+    /* big-column scratch: 2 doubles per observation (pass boundary) + K+1 log-probabilities per
+     * resident workgroup; needs the deepest column of the batch */
     int64_t max_depth = tr->max_col_obs;
     if (max_depth <= 0 && tr->ncols > 0) {
-        LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, LFQ_NCOUNTERS * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, st));
         LFQ_TRY_HIP(hipStreamSynchronize(st));
         max_depth = c->h_counters[LFQ_CNT_MAXDEPTH];
     }
-    const int64_t per_wave = 3 * max_depth + 72;
-    int n_waves = c->n_cu * 16;
+    const int64_t per_block = 3 * max_depth + 72;
+    int n_big_blocks = c->n_cu / 2;                     /* leave half of the CUs to the light kernel */
     const int64_t budget = (int64_t)1 << 29;            /* 4 GiB of doubles */
-    if (per_wave * n_waves > budget) {
-        n_waves = (int)std::max<int64_t>(64, budget / per_wave);
+    if (per_block * n_big_blocks > budget) {
+        n_big_blocks = (int)std::max<int64_t>(8, budget / per_block);
     }
-    if ((int64_t)n_waves > tr->ncols) {
-        n_waves = (int)std::max<int64_t>(tr->ncols, 1);
+    LFQ_TRY(grow(&c->d_scratch, &c->scratch_doubles, per_block * n_big_blocks));
+    const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 32, std::max<int64_t>(tr->ncols, 4));
+    const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(tr->ncols, 4));
+
+    /* fork: big and mid columns on side streams, light columns on the main stream */
+    LFQ_TRY_HIP(hipEventRecord(c->ev_fork, st));
+    for (int i = 0; i < 2; i++) {
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][0], c->side[i]));
     }
-    LFQ_TRY(grow(&c->d_scratch, &c->scratch_doubles, per_wave * n_waves));
-    LFQ_TRY(lfq_launch_dp(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_wave, n_waves, st));
+    LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
+                              n_big_blocks, c->side[0]));
+    LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
+    LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, st));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_light_done, st));
+    for (int i = 0; i < 2; i++) {
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][1], c->side[i]));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_join[i], c->side[i]));
+        LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_join[i], 0));
+    }
     LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
     return LFQ_OK;
 }
@@ -336,13 +372,16 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
         return LFQ_ERR_INVALID;
     }
     hipStream_t st = c->cur_stream ? c->cur_stream : c->stream;
-    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, LFQ_NCOUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     LFQ_TRY_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->times.ms_count = ms;
     if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->times.ms_scan = ms;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->times.ms_dp = ms;
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) c->times.ms_total = ms;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev_light_done) == hipSuccess) c->times.ms_dp_light = ms;
+    if (hipEventElapsedTime(&ms, c->ev_side[0][0], c->ev_side[0][1]) == hipSuccess) c->times.ms_dp_big = ms;
+    if (hipEventElapsedTime(&ms, c->ev_side[1][0], c->ev_side[1][1]) == hipSuccess) c->times.ms_dp_mid = ms;
     if (stats) {
         stats->n_tested = c->h_counters[LFQ_CNT_TESTED];
         stats->n_pvals = std::min<int64_t>(c->h_counters[LFQ_CNT_PVALS], c->cur_pvals_cap);

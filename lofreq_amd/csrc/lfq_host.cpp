@@ -16,6 +16,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "lofreq_amd.h"
@@ -62,7 +64,8 @@ double log_choose(int n, int k)                             /* fet.c:13-17 */
     if (k == 0 || n == k) {
         return 0;
     }
-    return lgamma(n + 1) - lgamma(k + 1) - lgamma(n - k + 1);
+    int sg;   /* lgamma_r: same value as lgamma (fet.c:16), without the shared signgam write */
+    return lgamma_r(n + 1, &sg) - lgamma_r(k + 1, &sg) - lgamma_r(n - k + 1, &sg);
 }
 
 double hypergeom(int n11, int n1_, int n_1, int n)          /* fet.c:26-29 */
@@ -147,6 +150,9 @@ long double lfq_pvalue_from_log(double logp, int status)
 {
     if (status == LFQ_PV_NONE) {
         return LDBL_MAX;
+    }
+    if (status == LFQ_PV_UNDERFLOW) {
+        return LDBL_MIN;        /* expl() of anything below -11399 underflows: clamp of snpcaller.c:1054-1055 */
     }
     errno = 0;
     feclearexcept(FE_ALL_EXCEPT);
@@ -310,9 +316,42 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
                 o.alt_fw = cn.alt_fw[a];
                 o.alt_rv = cn.alt_raw_counts[a] - cn.alt_fw[a];
                 o.hqa = cn.alt_counts[a];                   /* lofreq_call.c:860 */
-                o.sb = lfq_sb_phred(o.ref_fw, o.ref_rv, o.alt_fw, o.alt_rv);
+                o.sb = 0;                                   /* filled below */
                 o.ref = refc;
                 o.alt = acgt[x];
+            }
+        }
+    }
+    /* Strand bias (report_var, lofreq_call.c:117-129): Fisher's exact test walks the hypergeometric
+     * support with lgamma -- tens of microseconds per record at depth 1e4, the dominant host cost once
+     * the columns themselves run on the GPU.  Records are independent: spread them over host threads. */
+    {
+        const int64_t n = n_out;
+        unsigned hw = std::thread::hardware_concurrency();
+        int nthreads = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 32u), (n + 15) / 16);
+        std::atomic<int64_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int64_t i0 = next.fetch_add(8);
+                if (i0 >= n) {
+                    break;
+                }
+                for (int64_t i = i0; i < std::min(n, i0 + 8); i++) {
+                    lfq_snv_record &o = records[i];
+                    o.sb = lfq_sb_phred(o.ref_fw, o.ref_rv, o.alt_fw, o.alt_rv);
+                }
+            }
+        };
+        if (nthreads <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads - 1; t++) {
+                pool.emplace_back(work);
+            }
+            work();
+            for (auto &t : pool) {
+                t.join();
             }
         }
     }
@@ -329,6 +368,30 @@ int lfq_format_snv_record(char *buf, int buflen, const char *chrom, int64_t pos0
                     chrom, (long)(pos0 + 1), rec->ref, rec->alt, rec->qual,
                     filter_or_null ? filter_or_null : ".", rec->dp, af, rec->sb, rec->ref_fw, rec->ref_rv,
                     rec->alt_fw, rec->alt_rv, rec->hqa);
+}
+
+/* many records at once; returns the number of bytes the full text needs (written if it fits) */
+int64_t lfq_format_vcf(char *buf, int64_t buflen, const char *chrom, const int64_t *pos0_or_null,
+                       const lfq_snv_record *recs, int64_t n, const uint8_t *keep_or_null,
+                       const char *filter_or_null)
+{
+    int64_t used = 0;
+    char line[512];
+    for (int64_t i = 0; i < n; i++) {
+        if (keep_or_null && !keep_or_null[i]) {
+            continue;
+        }
+        const int64_t pos0 = pos0_or_null ? pos0_or_null[i] : recs[i].col;
+        const int len = lfq_format_snv_record(line, (int)sizeof(line), chrom, pos0, &recs[i], filter_or_null);
+        if (len < 0) {
+            return LFQ_ERR_INVALID;
+        }
+        if (buf && used + len <= buflen) {
+            memcpy(buf + used, line, (size_t)len);
+        }
+        used += len;
+    }
+    return used;
 }
 
 /* multtest.c:66-81 */

@@ -48,30 +48,39 @@ struct LfqTracksDev {
 /* work lists and counters produced by the scan kernels, consumed by the DP kernel */
 struct LfqWork {
     int32_t *tested_prefix;   /* [ncols] inclusive count of tested columns up to and incl. c */
-    int32_t *q_heavy;         /* [ncols] tested columns with kmax >= LFQ_HEAVY_K */
-    int32_t *q_light;         /* [ncols] the other tested columns */
-    int32_t *counters;        /* [8]: 0 n_tested, 1 n_heavy, 2 n_light, 3 heavy dequeue head,
-                                       4 n_pvals, 5 overflow flag, 6 max column depth */
+    int32_t *q_big;           /* [ncols] tested columns with kmax >= LFQ_BIG_K  (workgroup per column) */
+    int32_t *q_mid;           /* [ncols] LFQ_MID_K <= kmax < LFQ_BIG_K           (wave per column, 8 cells/lane) */
+    int32_t *q_light;         /* [ncols] kmax < LFQ_MID_K                        (wave per column, 1 cell/lane) */
+    int32_t *counters;        /* [16], see LFQ_CNT_* */
     int32_t *block_sums;      /* scan scratch */
 };
 
-#define LFQ_HEAVY_K 64
+#define LFQ_MID_K 64          /* K+1 cells no longer fit one cell per lane */
+#define LFQ_BIG_K 505         /* K+1 (+alignment) cells no longer fit one 64x8 strip */
+#define LFQ_NCOUNTERS 16
 #define LFQ_CNT_TESTED 0
-#define LFQ_CNT_HEAVY 1
-#define LFQ_CNT_LIGHT 2
-#define LFQ_CNT_HEAD 3
-#define LFQ_CNT_PVALS 4
-#define LFQ_CNT_OVERFLOW 5
-#define LFQ_CNT_MAXDEPTH 6
+#define LFQ_CNT_BIG 1
+#define LFQ_CNT_MID 2
+#define LFQ_CNT_LIGHT 3
+#define LFQ_CNT_HEAD 4        /* dequeue head of the big-column list */
+#define LFQ_CNT_PVALS 5
+#define LFQ_CNT_OVERFLOW 6
+#define LFQ_CNT_MAXDEPTH 7
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
 int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, int32_t *d_counters, void *stream);
 int lfq_launch_scan(int64_t ncols, const uint8_t *d_flags, const LfqWork &w, void *stream);
-int lfq_launch_dp(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
-                  const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
-                  int64_t pvals_capacity, double *d_scratch, int64_t scratch_doubles_per_wave,
-                  int n_waves, void *stream);
+int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                        const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
+                        int64_t pvals_capacity, int n_waves, void *stream);
+int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                      const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
+                      int64_t pvals_capacity, int n_waves, void *stream);
+int lfq_launch_dp_big(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                      const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
+                      int64_t pvals_capacity, double *d_scratch, int64_t scratch_doubles_per_block,
+                      int n_blocks, void *stream);
 int lfq_launch_synth(const struct lfq_synth_spec *d_spec_host, int64_t col_begin, int64_t ncols,
                      uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off,
                      uint8_t *d_ref_base, void *stream);

@@ -28,112 +28,8 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "lfq_internal.h"
+#include "lfq_device.h"
 #include "lofreq_synth.h"
-
-#define LFQ_WAVE 64
-
-/* ------------------------------------------------------------------------------------------ */
-/* wave helpers                                                                                */
-/* ------------------------------------------------------------------------------------------ */
-
-__device__ __forceinline__ int lfq_lane() { return (int)(threadIdx.x & 63u); }
-
-/* lane i receives lane i-1's value, lane 0 receives 0 (DPP wave_shr:1, VALU, no LDS) */
-__device__ __forceinline__ int lfq_shr1_i32(int x)
-{
-    return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ double lfq_shr1_f64(double x)
-{
-    int lo = lfq_shr1_i32(__double2loint(x));
-    int hi = lfq_shr1_i32(__double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-
-/* broadcast lane `i` (wave-uniform index) */
-__device__ __forceinline__ int lfq_rl_i32(int x, int i) { return __builtin_amdgcn_readlane(x, i); }
-
-__device__ __forceinline__ double lfq_rl_f64(double x, int i)
-{
-    int lo = __builtin_amdgcn_readlane(__double2loint(x), i);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(x), i);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ uint32_t lfq_wave_sum_u32(uint32_t x)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        x += (uint32_t)__shfl_xor((int)x, d, 64);
-    }
-    return x;
-}
-
-/* ------------------------------------------------------------------------------------------ */
-/* per-observation evaluation == the body of plp_to_errprobs' inner loop (snpcaller.c:399-496) */
-/* ------------------------------------------------------------------------------------------ */
-
-struct LfqObs {
-    bool keep;     /* contributes an error probability */
-    bool is_alt;
-    double p;      /* merged error probability */
-};
-
-__device__ __forceinline__ LfqObs lfq_eval_obs(uint32_t ntb, uint32_t bqb, uint32_t baqb, uint32_t mqb,
-                                               uint32_t sqb, int ref_code, int median_ref_bq,
-                                               const LfqParams &P, const LfqLuts *L)
-{
-    LfqObs o;
-    const uint32_t code = ntb & 7u;
-    o.keep = false;
-    o.is_alt = (code != (uint32_t)ref_code);
-    o.p = 0.0;
-    if (code > 3u) {                       /* N is ignored entirely, snpcaller.c:386-388 */
-        o.is_alt = false;
-        return o;
-    }
-    int bq = (int)bqb;
-    if (bq < P.min_bq4) {                  /* snpcaller.c:426 */
-        return o;
-    }
-    double pb;
-    if (o.is_alt) {                        /* snpcaller.c:431-441 */
-        if (bq < P.min_alt_bq4) {
-            return o;
-        }
-        if (P.def_alt_bq == -1) {
-            pb = (median_ref_bq < 0) ? 0.0 : L->bq[median_ref_bq & 255];
-        } else if (P.def_alt_bq != 0) {
-            pb = L->bq[P.def_alt_bq & 255];
-        } else {
-            pb = L->bq[bq];
-        }
-    } else {
-        pb = L->bq[bq];
-    }
-    const double pa = L->baq[P.use_baq ? baqb : 255u];   /* snpcaller.c:444-446 */
-    const double pm = L->mq[P.use_mq ? mqb : 255u];      /* snpcaller.c:448-453, 313-319 */
-    const double ps = L->sq[P.use_sq ? sqb : 255u];      /* snpcaller.c:461-463 */
-    /* snpcaller.c:334, identical association; -ffp-contract=off keeps every rounding */
-    const double om = 1.0 - pm, os = 1.0 - ps, oa = 1.0 - pa;
-    double jp = pm + om * ps + om * os * pa + om * os * oa * pb;
-    if (jp > P.jq_reject_above) {          /* merged_qual < min_jq, snpcaller.c:469 */
-        return o;
-    }
-    if (o.is_alt) {                        /* snpcaller.c:473-490 */
-        if (jp > P.alt_jq_reject_above) {
-            return o;
-        }
-        if (P.def_alt_jp >= 0.0) {
-            jp = P.def_alt_jp;
-        }
-    }
-    o.keep = true;
-    o.p = jp;
-    return o;
-}
 
 /* ------------------------------------------------------------------------------------------ */
 /* count kernel                                                                                */
@@ -325,7 +221,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
             r.kmax = kmax;
             r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
-            flag = (uint8_t)((r.tested ? 1 : 0) | ((kmax >= LFQ_HEAVY_K) ? 2 : 0));
+            flag = (uint8_t)((r.tested ? 1 : 0) | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K) ? 2 : 0));
         }
         out[col] = r;
         flags[col] = flag;
@@ -343,50 +239,76 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
 #define LFQ_SCAN_ITEMS 4
 #define LFQ_SCAN_TILE (LFQ_SCAN_THREADS * LFQ_SCAN_ITEMS)
 
-/* block-wide exclusive scan of two counters packed as (tested | heavy << 32) */
-__device__ uint64_t lfq_block_excl_scan(uint64_t x, uint64_t *total, uint64_t *s_wave /*[16]*/)
+/* three counters scanned together: tested columns, mid columns, big columns */
+struct LfqTriple {
+    uint32_t t, m, b;
+};
+
+__device__ __forceinline__ LfqTriple lfq_triple_of_flag(uint32_t f)
+{
+    LfqTriple x;
+    x.t = f & 1u;
+    x.m = (f >> 1) & 1u;
+    x.b = (f >> 2) & 1u;
+    return x;
+}
+
+__device__ __forceinline__ void lfq_triple_add(LfqTriple &a, const LfqTriple &b)
+{
+    a.t += b.t;
+    a.m += b.m;
+    a.b += b.b;
+}
+
+/* block-wide exclusive scan; s_wave holds one triple per wave */
+__device__ LfqTriple lfq_block_excl_scan(LfqTriple x, LfqTriple *total, LfqTriple *s_wave /*[16]*/)
 {
     const int lane = lfq_lane(), wave = (int)(threadIdx.x >> 6);
-    uint64_t incl = x;
+    LfqTriple incl = x;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        uint64_t y = ((uint64_t)(uint32_t)__shfl_up((int)(incl >> 32), d, 64) << 32)
-                     | (uint32_t)__shfl_up((int)(incl & 0xffffffffu), d, 64);
+        LfqTriple y;
+        y.t = (uint32_t)__shfl_up((int)incl.t, d, 64);
+        y.m = (uint32_t)__shfl_up((int)incl.m, d, 64);
+        y.b = (uint32_t)__shfl_up((int)incl.b, d, 64);
         if (lane >= d) {
-            incl += y;
+            lfq_triple_add(incl, y);
         }
     }
     if (lane == 63) {
         s_wave[wave] = incl;
     }
     __syncthreads();
-    uint64_t wave_off = 0, tot = 0;
+    LfqTriple wave_off = {0, 0, 0}, tot = {0, 0, 0};
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
-        const uint64_t v = s_wave[w];
+        const LfqTriple v = s_wave[w];
         if (w < wave) {
-            wave_off += v;
+            lfq_triple_add(wave_off, v);
         }
-        tot += v;
+        lfq_triple_add(tot, v);
     }
     __syncthreads();
     *total = tot;
-    return wave_off + incl - x;
+    LfqTriple ex;
+    ex.t = wave_off.t + incl.t - x.t;
+    ex.m = wave_off.m + incl.m - x.m;
+    ex.b = wave_off.b + incl.b - x.b;
+    return ex;
 }
 
 __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_tiles_kernel(int64_t ncols,
                                                                          const uint8_t *__restrict__ flags,
-                                                                         uint64_t *__restrict__ tile_sums)
+                                                                         LfqTriple *__restrict__ tile_sums)
 {
-    __shared__ uint64_t s_wave[16];
+    __shared__ LfqTriple s_wave[16];
     const int64_t base = (int64_t)blockIdx.x * LFQ_SCAN_TILE + (int64_t)threadIdx.x * LFQ_SCAN_ITEMS;
-    uint64_t x = 0;
+    LfqTriple x = {0, 0, 0};
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
         if (base + i < ncols) {
-            const uint32_t f = flags[base + i];
-            x += (uint64_t)(f & 1u) | ((uint64_t)((f >> 1) & 1u) << 32);
+            lfq_triple_add(x, lfq_triple_of_flag(flags[base + i]));
         }
     }
-    uint64_t total;
+    LfqTriple total;
     (void)lfq_block_excl_scan(x, &total, s_wave);
     if (threadIdx.x == 0) {
         tile_sums[blockIdx.x] = total;
@@ -395,397 +317,64 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_tiles_kernel(int64_
 
 /* single block: exclusive scan over the tile sums, totals into the counters */
 __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t ntiles,
-                                                                        uint64_t *__restrict__ tile_sums,
+                                                                        LfqTriple *__restrict__ tile_sums,
                                                                         int32_t *__restrict__ counters)
 {
-    __shared__ uint64_t s_wave[16];
-    uint64_t carry = 0;
+    __shared__ LfqTriple s_wave[16];
+    LfqTriple carry = {0, 0, 0};
     for (int64_t b = 0; b < ntiles; b += LFQ_SCAN_THREADS) {
         const int64_t i = b + threadIdx.x;
-        const uint64_t x = (i < ntiles) ? tile_sums[i] : 0;
-        uint64_t total;
-        const uint64_t ex = lfq_block_excl_scan(x, &total, s_wave);
+        LfqTriple x = {0, 0, 0};
         if (i < ntiles) {
-            tile_sums[i] = carry + ex;
+            x = tile_sums[i];
         }
-        carry += total;
+        LfqTriple total;
+        LfqTriple ex = lfq_block_excl_scan(x, &total, s_wave);
+        if (i < ntiles) {
+            lfq_triple_add(ex, carry);
+            tile_sums[i] = ex;
+        }
+        lfq_triple_add(carry, total);
     }
     if (threadIdx.x == 0) {
-        const int32_t n_tested = (int32_t)(carry & 0xffffffffu), n_heavy = (int32_t)(carry >> 32);
-        counters[LFQ_CNT_TESTED] = n_tested;
-        counters[LFQ_CNT_HEAVY] = n_heavy;
-        counters[LFQ_CNT_LIGHT] = n_tested - n_heavy;
+        counters[LFQ_CNT_TESTED] = (int32_t)carry.t;
+        counters[LFQ_CNT_MID] = (int32_t)carry.m;
+        counters[LFQ_CNT_BIG] = (int32_t)carry.b;
+        counters[LFQ_CNT_LIGHT] = (int32_t)(carry.t - carry.m - carry.b);
     }
 }
 
 __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(int64_t ncols,
                                                                          const uint8_t *__restrict__ flags,
-                                                                         const uint64_t *__restrict__ tile_sums,
+                                                                         const LfqTriple *__restrict__ tile_sums,
                                                                          LfqWork W)
 {
-    __shared__ uint64_t s_wave[16];
+    __shared__ LfqTriple s_wave[16];
     const int64_t base = (int64_t)blockIdx.x * LFQ_SCAN_TILE + (int64_t)threadIdx.x * LFQ_SCAN_ITEMS;
     uint32_t f[LFQ_SCAN_ITEMS];
-    uint64_t x = 0;
+    LfqTriple x = {0, 0, 0};
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
         f[i] = (base + i < ncols) ? flags[base + i] : 0u;
-        x += (uint64_t)(f[i] & 1u) | ((uint64_t)((f[i] >> 1) & 1u) << 32);
+        lfq_triple_add(x, lfq_triple_of_flag(f[i]));
     }
-    uint64_t total;
-    uint64_t ex = lfq_block_excl_scan(x, &total, s_wave) + tile_sums[blockIdx.x];
-    uint32_t n_t = (uint32_t)(ex & 0xffffffffu), n_h = (uint32_t)(ex >> 32);
+    LfqTriple total;
+    LfqTriple ex = lfq_block_excl_scan(x, &total, s_wave);
+    lfq_triple_add(ex, tile_sums[blockIdx.x]);
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
         if (base + i >= ncols) {
             break;
         }
         if (f[i] & 1u) {
-            if (f[i] & 2u) {
-                W.q_heavy[n_h] = (int32_t)(base + i);
-                n_h++;
+            if (f[i] & 4u) {
+                W.q_big[ex.b++] = (int32_t)(base + i);
+            } else if (f[i] & 2u) {
+                W.q_mid[ex.m++] = (int32_t)(base + i);
             } else {
-                W.q_light[n_t - n_h] = (int32_t)(base + i);
+                W.q_light[ex.t - ex.m - ex.b] = (int32_t)(base + i);
             }
-            n_t++;
+            ex.t++;
         }
-        W.tested_prefix[base + i] = (int32_t)n_t;     /* inclusive */
-    }
-}
-
-/* ------------------------------------------------------------------------------------------ */
-/* DP kernel                                                                                   */
-/* ------------------------------------------------------------------------------------------ */
-
-#define LFQ_LN2_HI 6.93147180369123816490e-01
-#define LFQ_LN2_LO 1.90821492927058770002e-10
-/* exp(x) raises FE_UNDERFLOW in glibc (result below DBL_MIN) for x < ln(2^-1022); pinned in
- * tests/test_oracle_kat.py::test_exp_underflow_threshold */
-#define LFQ_EXP_UNDERFLOW_X (-708.3964185322641)
-
-__device__ __forceinline__ double lfq_logaddexp(double a, double b)
-{
-    const double hi = fmax(a, b), lo = fmin(a, b);
-    if (lo == -INFINITY) {
-        return hi;
-    }
-    return hi + log1p(exp(lo - hi));
-}
-
-struct LfqColCtx {
-    int64_t col;
-    uint64_t off0;
-    int64_t n_obs;
-    int ref_code;
-    int median_ref_bq;
-    int K;
-    double bonf_d;
-    double sig_s;
-};
-
-/* Runs the recurrence for one column.  Returns true if the column was pruned
- * (P(X>=K)*bonf > sig, snpcaller.c:950/1155).  Otherwise probvec[0..K] holds natural logs of
- * P(X=k) (k<K) and P(X>=K) (k=K), like the array poissbin() returns (snpcaller.c:1020-1062). */
-template <int C>
-__device__ bool lfq_dp_run(const LfqColCtx &cx, const LfqTracksDev &T, const LfqParams &P,
-                           const LfqLuts *L, double *__restrict__ bnd, double *__restrict__ probvec,
-                           int *rows_out)
-{
-    const int lane = lfq_lane();
-    const int K = cx.K;
-    const int shift = (C - K % C) % C;
-    const int Lt = (K + shift) / C;           /* global lane that owns the tail cell at j = 0 */
-    const int n_strips = Lt / LFQ_WAVE + 1;
-    const int lt = Lt % LFQ_WAVE;
-    const int64_t n_chunks = (cx.n_obs + LFQ_WAVE - 1) / LFQ_WAVE;
-    bool pruned = false;
-    int rows = 0;
-
-    for (int s = 0; s < n_strips && !pruned; s++) {
-        const bool last = (s == n_strips - 1);
-        const int gl = s * LFQ_WAVE + lane;
-        const bool is_tail = (gl == Lt);
-        double v[C];
-#pragma unroll
-        for (int j = 0; j < C; j++) {
-            v[j] = (s == 0 && lane == 0 && j == shift) ? 1.0 : 0.0;
-        }
-        int e = 0, de = 0;
-        bool all_zero = (s > 0);               /* wave-uniform: nothing has entered this strip yet */
-        int e_in = 0;
-        rows = 0;
-
-        for (int64_t ch = 0; ch < n_chunks && !pruned; ch++) {
-            const int64_t idx = ch * LFQ_WAVE + lane;
-            const bool valid = idx < cx.n_obs;
-            LfqObs o;
-            o.keep = false;
-            o.p = 0.0;
-            if (valid) {
-                const uint64_t g = cx.off0 + (uint64_t)idx;
-                o = lfq_eval_obs(T.nt[g], T.bq[g], T.baq ? T.baq[g] : 255u, T.mq[g], T.sq ? T.sq[g] : 255u,
-                                 cx.ref_code, cx.median_ref_bq, P, L);
-            }
-            /* the reference's guards against log(0) (snpcaller.c:872-881) as effective p and 1-p */
-            const double ps = (fabs(o.p) < 2.220446049250313e-16) ? 2.220446049250313e-16 : o.p;
-            const double qf = (fabs(o.p - 1.0) < 2.220446049250313e-16)
-                                  ? 1.0 + (-o.p + 2.220446049250313e-16)
-                                  : 1.0 - o.p;
-            double bv = 0.0;
-            int be = 0;
-            if (s > 0 && valid && o.keep) {
-                bv = bnd[2 * idx];
-                be = (int)bnd[2 * idx + 1];
-            }
-            uint64_t km = __ballot(o.keep);
-            while (km) {
-                const int i = __builtin_ctzll(km);
-                km &= km - 1;
-                const double p = lfq_rl_f64(ps, i);
-                const double q = lfq_rl_f64(qf, i);
-                double x = lfq_shr1_f64(v[C - 1]);
-                int dei = de;
-                if (s > 0) {
-                    const double xb = lfq_rl_f64(bv, i);
-                    const int eb = lfq_rl_i32(be, i);
-                    e_in = eb;
-                    if (all_zero) {
-                        e = eb;                 /* adopt the producer's scale while empty */
-                        de = 0;
-                        dei = 0;
-                        if (xb == 0.0) {
-                            if (!last && lane == 63) {
-                                bnd[2 * (ch * LFQ_WAVE + i)] = 0.0;
-                                bnd[2 * (ch * LFQ_WAVE + i) + 1] = (double)e;
-                            }
-                            rows++;
-                            continue;
-                        }
-                        all_zero = false;
-                    }
-                    if (lane == 0) {
-                        x = xb;
-                        dei = eb - e;
-                    }
-                }
-                if (!last && lane == 63) {
-                    bnd[2 * (ch * LFQ_WAVE + i)] = v[C - 1];
-                    bnd[2 * (ch * LFQ_WAVE + i) + 1] = (double)e;
-                }
-                const double xs = ldexp(x, dei);
-                const double ph = is_tail ? 0.0 : p;
-                const double q0 = is_tail ? 1.0 : q;
-#pragma unroll
-                for (int j = C - 1; j >= 1; j--) {
-                    v[j] = fma(v[j - 1], ph, v[j] * q);
-                }
-                v[0] = fma(xs, p, v[0] * q0);
-                rows++;
-
-                if ((rows & 7) == 0) {
-                    /* renormalise: lane maximum to [0.5,1), exponent into e */
-                    double m = v[0];
-#pragma unroll
-                    for (int j = 1; j < C; j++) {
-                        m = fmax(m, v[j]);
-                    }
-                    const bool nzl = m > 0.0;
-                    const uint64_t nz = __ballot(nzl);
-                    if (nzl) {
-                        const int ex = __builtin_amdgcn_frexp_exp(m);
-#pragma unroll
-                        for (int j = 0; j < C; j++) {
-                            v[j] = ldexp(v[j], -ex);
-                        }
-                        e += ex;
-                    }
-                    /* empty lanes adopt the scale of the nearest non-empty lane to their left */
-                    const uint64_t below = nz & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
-                    const int src = below ? (63 - __builtin_clzll(below)) : lane;
-                    const int e_src = __shfl(e, src, 64);
-                    if (!nzl) {
-                        e = below ? e_src : ((s > 0) ? e_in : e);
-                    }
-                    de = lfq_shr1_i32(e) - e;
-                    if (last) {
-                        const double tv = lfq_rl_f64(v[0], lt);
-                        const int te = lfq_rl_i32(e, lt);
-                        if (ldexp(tv, te) * cx.bonf_d > cx.sig_s) {
-                            pruned = true;
-                            break;
-                        }
-                    }
-                }
-            }
-        }
-        if (last && !pruned) {
-            const double tv = lfq_rl_f64(v[0], lt);
-            const int te = lfq_rl_i32(e, lt);
-            if (ldexp(tv, te) * cx.bonf_d > cx.sig_s) {
-                pruned = true;
-            }
-        }
-        if (!pruned) {
-            /* natural logs of this strip's cells */
-#pragma unroll
-            for (int j = 0; j < C; j++) {
-                const int k = gl * C + j - shift;
-                if (k >= 0 && k <= K && (k < K || j == 0)) {
-                    const double ed = (double)e;
-                    probvec[k] = (v[j] > 0.0) ? (ed * LFQ_LN2_HI + (ed * LFQ_LN2_LO + log(v[j]))) : -INFINITY;
-                }
-            }
-        }
-        __threadfence_block();
-    }
-    *rows_out = rows;
-    return pruned;
-}
-
-/* probvec_tailsum (snpcaller.c:730-741) as a wave-parallel prefix scan, plus detection of the
- * exp() underflow inside the reference's sequential log_sum chain. */
-__device__ double lfq_tailsum(const double *__restrict__ probvec, int start, int K, bool *fe_flag)
-{
-    const int lane = lfq_lane();
-    double carry = -INFINITY;
-    bool flag = false;
-    for (int base = start; base <= K; base += LFQ_WAVE) {
-        const int idx = base + lane;
-        const double x = (idx <= K) ? probvec[idx] : -INFINITY;
-        double incl = x;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double y = __shfl_up(incl, d, 64);
-            if (lane >= d) {
-                incl = lfq_logaddexp(incl, y);
-            }
-        }
-        double excl = __shfl_up(incl, 1, 64);
-        excl = (lane == 0) ? carry : lfq_logaddexp(carry, excl);
-        if (idx <= K && idx > start) {
-            /* the reference evaluates exp(min - max) of (running sum, probvec[idx]) */
-            if (-fabs(x - excl) < LFQ_EXP_UNDERFLOW_X) {
-                flag = true;
-            }
-        }
-        carry = lfq_logaddexp(carry, lfq_rl_f64(incl, 63));
-    }
-    *fe_flag = __any(flag);
-    return carry;
-}
-
-__global__ __launch_bounds__(256) void lfq_dp_kernel(LfqTracksDev T, LfqParams P,
-                                                     const LfqLuts *__restrict__ luts,
-                                                     const lfq_col_counts *__restrict__ counts,
-                                                     LfqWork W, lfq_col_pvals *__restrict__ pvals,
-                                                     int64_t pvals_capacity, double *__restrict__ scratch,
-                                                     int64_t scratch_per_wave, int n_waves)
-{
-    const int lane = lfq_lane();
-    const int wave_id = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (wave_id >= n_waves) {
-        return;
-    }
-    const int n_heavy = W.counters[LFQ_CNT_HEAVY];
-    const int n_light = W.counters[LFQ_CNT_LIGHT];
-    double *bnd = scratch + (int64_t)wave_id * scratch_per_wave;
-
-    int light_next = wave_id;
-    bool heavy_phase = true;
-    for (;;) {
-        int col;
-        if (heavy_phase) {
-            int h = 0;
-            if (lane == 0) {
-                h = atomicAdd(&W.counters[LFQ_CNT_HEAD], 1);
-            }
-            h = __builtin_amdgcn_readfirstlane(h);
-            if (h < n_heavy) {
-                col = W.q_heavy[h];
-            } else {
-                heavy_phase = false;
-                continue;
-            }
-        } else {
-            if (light_next >= n_light) {
-                break;
-            }
-            col = W.q_light[light_next];
-            light_next += n_waves;
-        }
-        col = __builtin_amdgcn_readfirstlane(col);
-
-        const lfq_col_counts cnt = counts[col];
-        LfqColCtx cx;
-        cx.col = col;
-        cx.off0 = T.col_off[col];
-        cx.n_obs = (int64_t)(T.col_off[col + 1] - cx.off0);
-        const uint32_t rb = T.ref_base[col];
-        cx.ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : 3;
-        cx.median_ref_bq = cnt.median_ref_bq;
-        cx.K = cnt.kmax;
-        /* running Bonferroni factor at this column (lofreq_call.c:794-800) */
-        int64_t bonf = P.bonf_base;
-        if (P.bonf_dynamic) {
-            const int64_t t = W.tested_prefix[col];
-            bonf = ((P.bonf_base == 1) ? 0 : P.bonf_base) + 3 * t;
-        }
-        cx.bonf_d = (double)bonf;
-        cx.sig_s = P.sig * (1.0 + P.prune_slack);
-
-        double *probvec = bnd + 2 * cx.n_obs + 2;
-        int rows = 0;
-        bool pruned;
-        if (cx.K < LFQ_HEAVY_K) {
-            pruned = lfq_dp_run<1>(cx, T, P, luts, bnd, probvec, &rows);
-        } else {
-            pruned = lfq_dp_run<8>(cx, T, P, luts, bnd, probvec, &rows);
-        }
-        if (pruned) {
-            continue;
-        }
-
-        /* per-allele p-values (snpcaller.c:1166-1196) */
-        double logp[3];
-        int status[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const int c = cnt.alt_counts[a];
-            logp[a] = 0.0;
-            status[a] = LFQ_PV_NONE;
-            if (c == 0) {
-                continue;
-            }
-            if (c == cx.K) {
-                logp[a] = probvec[cx.K];
-                status[a] = LFQ_PV_LOG;
-            } else {
-                bool fe = false;
-                logp[a] = lfq_tailsum(probvec, c, cx.K, &fe);
-                status[a] = fe ? LFQ_PV_LOG_FECLAMP : LFQ_PV_LOG;
-            }
-        }
-        if (lane == 0) {
-            const int slot = atomicAdd(&W.counters[LFQ_CNT_PVALS], 1);
-            if ((int64_t)slot < pvals_capacity) {
-                lfq_col_pvals r;
-                r.col = col;
-                r.bonf = bonf;
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    r.logp[a] = logp[a];
-                    r.status[a] = (uint8_t)status[a];
-                }
-                for (int i = 0; i < 5; i++) {
-                    r.pad_[i] = 0;
-                }
-                r.counts = cnt;
-                r.dp_rows = rows;
-                r.pad2_ = 0;
-                r.reserved_ = 0;
-                pvals[slot] = r;
-            } else {
-                W.counters[LFQ_CNT_OVERFLOW] = 1;
-            }
-        }
+        W.tested_prefix[base + i] = (int32_t)ex.t;     /* inclusive */
     }
 }
 
@@ -865,28 +454,13 @@ int lfq_launch_scan(int64_t ncols, const uint8_t *d_flags, const LfqWork &w, voi
         return LFQ_OK;
     }
     const int64_t ntiles = (ncols + LFQ_SCAN_TILE - 1) / LFQ_SCAN_TILE;
-    uint64_t *tile_sums = reinterpret_cast<uint64_t *>(w.block_sums);
+    LfqTriple *tile_sums = reinterpret_cast<LfqTriple *>(w.block_sums);
     hipLaunchKernelGGL(lfq_scan_tiles_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
                        (hipStream_t)stream, ncols, d_flags, tile_sums);
     hipLaunchKernelGGL(lfq_scan_sums_kernel, dim3(1), dim3(LFQ_SCAN_THREADS), 0, (hipStream_t)stream, ntiles,
                        tile_sums, w.counters);
     hipLaunchKernelGGL(lfq_scan_apply_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
-                       (hipStream_t)stream, ncols, d_flags, (const uint64_t *)tile_sums, w);
-    LFQ_HIP_TRY(hipGetLastError());
-    return LFQ_OK;
-}
-
-int lfq_launch_dp(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
-                  const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
-                  int64_t pvals_capacity, double *d_scratch, int64_t scratch_doubles_per_wave, int n_waves,
-                  void *stream)
-{
-    if (t.ncols <= 0 || n_waves <= 0) {
-        return LFQ_OK;
-    }
-    const unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    hipLaunchKernelGGL(lfq_dp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, d_counts,
-                       w, d_pvals, pvals_capacity, d_scratch, scratch_doubles_per_wave, n_waves);
+                       (hipStream_t)stream, ncols, d_flags, (const LfqTriple *)tile_sums, w);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }

@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.json from the REFERENCE ITSELF (its prebuilt lofreq 2.1.4 binary).
+
+Runs only in the build container (needs /root/reference/dist; `make -C oracle ref` unpacks the binary
+to oracle/_ref/lofreq214).  For every fixture:
+  * a seeded SAM + FASTA is written (SAM text is auto-detected by the binary's htslib),
+  * `lofreq plpsummary` dumps, per pileup column, the per-nucleotide BQ / BAQ / MQ arrays and strand
+    counts -- exactly the input of the hot path (lofreq_call.c:438-599),
+  * `lofreq call` produces the VCF and the "Number of substitution tests performed" line.
+The JSON holds inputs (columns) and expected outputs (VCF records, test count): data only.
+
+Known 2.1.4-vs-HEAD deltas on this path: HEAD appends ;HQA= to SNV INFO and counts raw alt
+bases before the min_bq filter.  tests/test_golden.py compares modulo ;HQA= and runs the oracle with
+raw_counts_after_minbq=1.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LOFREQ = os.path.join(HERE, "_ref", "lofreq214")
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+def write_fixture(tmp, seed, glen, nreads, planted, mapqs, min_q=3):
+    rng = np.random.default_rng(seed)
+    genome = "".join(rng.choice(list("ACGT"), glen))
+    open(os.path.join(tmp, "t.fa"), "w").write(">chr1\n" + genome + "\n")
+    reads = []
+    rl = 100
+    for _ in range(nreads):
+        pos = int(rng.integers(0, glen - rl + 1))
+        seq = list(genome[pos:pos + rl])
+        qual = np.clip(np.round(rng.normal(33, 7, rl)), min_q, 41).astype(int)
+        for j in range(rl):
+            if rng.random() < 10 ** (-qual[j] / 10.0):
+                seq[j] = rng.choice([c for c in "ACGT" if c != seq[j]])
+            p = planted.get(pos + j)
+            if p and rng.random() < p[1]:
+                seq[j] = p[0]
+        flag = 16 if rng.random() < 0.5 else 0
+        reads.append((pos, flag, int(rng.choice(mapqs)), "".join(seq), "".join(chr(33 + q) for q in qual)))
+    reads.sort()
+    with open(os.path.join(tmp, "t.sam"), "w") as f:
+        f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % glen)
+        for i, (pos, flag, mapq, seq, q) in enumerate(reads):
+            f.write("r%d\t%d\tchr1\t%d\t%d\t%dM\t*\t0\t0\t%s\t%s\n" % (i, flag, pos + 1, mapq, rl, seq, q))
+    return genome
+
+
+def parse_plpsummary(text):
+    cols = []
+    cur = None
+    for line in text.splitlines():
+        if not line.strip():
+            continue
+        if not line.startswith(" "):
+            f = line.split("\t")
+            cur = {"pos0": int(f[1]) - 1, "ref": f[2], "cons": f[3], "fwrv": {}, "obs": {}}
+            for tok in f[4:9]:
+                nt, c = tok.split(":")
+                fw, rv = c.split("/")
+                cur["fwrv"][nt] = [int(fw), int(rv)]
+            cols.append(cur)
+        else:
+            f = line.strip().split("\t")
+            key = f[0]
+            if key in "ACGTN" and len(key) == 1:
+                track = f[1].split("=")[0].strip()
+                vals = [int(x) for x in f[2].split()] if len(f) > 2 else []
+                cur["obs"].setdefault(key, {})[track] = vals
+    return cols
+
+
+def enc(vals):
+    """phred list -> compact ASCII (value+33; -1 -> '~')"""
+    return "".join("~" if v < 0 else chr(33 + v) for v in vals)
+
+
+def run(name, seed, glen, nreads, planted, mapqs, call_args):
+    with tempfile.TemporaryDirectory() as tmp:
+        genome = write_fixture(tmp, seed, glen, nreads, planted, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        plp_args = [a for a in call_args if a in ("-B",)]
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa"] + plp_args + ["t.sam"], cwd=tmp, check=True,
+                             capture_output=True, text=True).stdout
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
+        res = subprocess.run([LOFREQ, "call", "-f", "t.fa", "-o", "out.vcf"] + call_args + ["t.sam"], cwd=tmp,
+                             check=True, capture_output=True, text=True, env=env)
+        ntests = None
+        for line in res.stderr.splitlines():
+            if "Number of substitution tests performed" in line:
+                ntests = int(line.split(":")[-1])
+        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+    cols = parse_plpsummary(plp)
+    packed = []
+    for c in cols:
+        o = {}
+        for nt, tr in c["obs"].items():
+            o[nt] = {"bq": enc(tr.get("BQ", [])), "baq": enc(tr["BAQ"]) if "BAQ" in tr else None,
+                     "mq": tr.get("MQ", [])}
+        packed.append({"pos0": c["pos0"], "ref": c["ref"], "fwrv": c["fwrv"], "obs": o})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "call_args": call_args, "genome": genome, "columns": packed, "vcf": vcf, "num_snv_tests": ntests}
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d columns, %d vcf records, %s tests, %d bytes" % (name, len(packed), len(vcf), ntests,
+                                                                    os.path.getsize(path)))
+
+
+def main():
+    if not os.path.exists(LOFREQ):
+        sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    planted_a = {60: ("A", 0.05), 61: ("C", 0.05), 62: ("G", 0.05), 90: ("C", 0.10), 91: ("A", 0.10),
+                 92: ("T", 0.10), 120: ("G", 0.03), 121: ("A", 0.03), 122: ("C", 0.03), 150: ("T", 0.5),
+                 151: ("A", 0.5), 152: ("G", 0.5), 180: ("C", 1.0), 181: ("A", 1.0), 200: ("T", 0.07),
+                 201: ("C", 0.07), 202: ("A", 0.07)}
+    run("snv_default", 11, 260, 500, planted_a, mq_mix, [])
+    run("snv_nofilter_fixedbonf", 12, 260, 500, planted_a, mq_mix, ["--no-default-filter", "-b", "780"])
+    run("snv_nobaq_dynamic_nofilter", 13, 260, 500, planted_a, mq_mix, ["-B", "--no-default-filter"])
+    planted_b = {50: ("A", 0.01), 51: ("C", 0.004), 70: ("G", 0.2), 71: ("T", 0.2), 72: ("A", 0.6),
+                 100: ("C", 0.03), 101: ("G", 0.03)}
+    run("snv_deep", 14, 160, 1800, planted_b, [60] * 12 + [50, 3], ["--no-default-filter", "-b", "480"])
+    run("snv_minbq_sig", 15, 220, 600, planted_a, mq_mix, ["-q", "20", "-Q", "25", "-a", "0.001", "-b", "660",
+                                                         "--no-default-filter"])
+
+
+if __name__ == "__main__":
+    main()

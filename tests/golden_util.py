@@ -1,0 +1,77 @@
+"""Load tests/golden/*.json (generated from the reference's own lofreq 2.1.4 binary by
+oracle/make_golden.py) into packed host tracks."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+
+
+def dec(s):
+    return np.array([(-1 if ch == "~" else ord(ch) - 33) for ch in s], dtype=np.int64)
+
+
+def load(path):
+    fx = json.load(open(path))
+    nts, bqs, baqs, mqs, off, refs = [], [], [], [], [0], []
+    has_baq = "-B" not in fx["call_args"]
+    for col in fx["columns"]:
+        n_col = 0
+        for code, nt in enumerate("ACGTN"):
+            o = col["obs"].get(nt)
+            if not o:
+                continue
+            bq = dec(o["bq"])
+            n = len(bq)
+            fw = col["fwrv"][nt][0]
+            assert fw + col["fwrv"][nt][1] == n
+            strand = (np.arange(n) >= fw).astype(np.uint8)
+            nts.append((np.full(n, code, np.uint8)) | (strand << 3))
+            bqs.append(bq.astype(np.uint8))
+            mqs.append(np.asarray(o["mq"], np.uint8))
+            if has_baq:
+                b = dec(o["baq"])
+                baqs.append(np.where(b < 0, 255, b).astype(np.uint8))
+            n_col += n
+        off.append(off[-1] + n_col)
+        refs.append(ord(col["ref"]))
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
+    host = dict(nt=cat(nts), bq=cat(bqs), baq=cat(baqs) if has_baq else None, mq=cat(mqs), sq=None,
+                col_off=np.asarray(off, np.uint64), ref_base=np.asarray(refs, np.uint8))
+    return fx, host
+
+
+def conf_kwargs(call_args):
+    """lofreq call options (lofreq_call.c:1068-1304) -> varcall_conf fields"""
+    kw = {}
+    no_default_filter = False
+    flag = 3
+    it = iter(call_args)
+    for a in it:
+        if a == "--no-default-filter":
+            no_default_filter = True
+        elif a == "-b":
+            kw["bonf_dynamic"] = 0
+            kw["bonf_subst"] = int(next(it))
+        elif a == "-B":
+            flag &= ~1
+        elif a == "-q":
+            kw["min_bq"] = int(next(it))
+        elif a == "-Q":
+            kw["min_alt_bq"] = int(next(it))
+        elif a == "-a":
+            kw["sig"] = float(next(it))
+        else:
+            raise ValueError(a)
+    kw["flag"] = flag
+    return kw, no_default_filter
+
+
+def strip_hqa(line):
+    return line.split(";HQA=")[0]

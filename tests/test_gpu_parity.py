@@ -174,3 +174,63 @@ def test_synthetic_workload_matches_cpu_generator(caller, oracle):
     assert conf.bonf_subst == oconf.bonf_subst
     # planted 5 % / 50 % columns reach |log p| > 1500: reference log-space noise, see DESIGN.md
     _compare_records(la, recs, ores, host, tol=1e-9)
+
+
+def test_underflow_shortcut_extreme_columns(caller, oracle):
+    """Columns whose main p-value is below the 80-bit range take the mu^K/K! shortcut in the big-column
+    kernel; minor alleles, sentinels and QUALs must still match the reference exactly."""
+    import lofreq_amd as la
+    cases = [(10000, (6000, 3000, 5)), (10000, (6000, 200, 3)), (10000, (7000, 0, 1)), (10000, (5000, 60, 0)),
+             (12000, (6000, 5990, 10)), (10000, (2500, 30, 2)), (10000, (3500, 3400, 0))]
+    host = util.concat_batches([util.uniform_p_column(n, c) for n, c in cases])
+    # mix in realistic qualities for half of the columns so that mu is not a round number
+    rng = np.random.default_rng(3)
+    n0 = int(host["col_off"][3])
+    host["bq"][:n0] = np.clip(np.round(rng.normal(33, 5, n0)), 6, 41).astype(np.uint8)
+    kw = dict(bonf_dynamic=0, bonf_subst=3000000, min_bq=0, min_alt_bq=0)
+    ores, _ = util.run_oracle(oracle, host, **kw)
+    conf = la.VarcallConf(**kw)
+    recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
+    util.assert_counts_equal(counts, ores, host)
+    assert (ores["pvalue"] == util.LDBL_MIN).sum() >= 7
+    _compare_records(la, recs, ores, host, tol=1e-9)
+
+
+def test_golden_reference_binary_vcf(caller, oracle):
+    """HIP path end to end against VCFs written by the reference's own lofreq 2.1.4 binary
+    (tests/golden, oracle/make_golden.py).  Fields the two known 2.1.4-vs-HEAD deltas do not touch
+    (;HQA= suffix, raw-alt counting before the BQ filter -> AF) must be byte-identical."""
+    import lofreq_amd as la
+    import golden_util as gu
+    for path in gu.fixtures():
+        fx, host = gu.load(path)
+        kw, no_default_filter = gu.conf_kwargs(fx["call_args"])
+        conf = la.VarcallConf(**kw)
+        recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
+        assert conf.num_snv_tests == fx["num_snv_tests"], path
+        dynamic = bool(conf.bonf_dynamic)
+        if no_default_filter and not dynamic:
+            keep, filt = np.ones(len(recs), bool), None
+        else:
+            thr = la.snvqual_thresh(conf.sig, conf.bonf_subst) if dynamic else 0
+            keep, filt = la.filter_records(recs, thr, apply_defaults=not no_default_filter), "PASS"
+        pos0 = np.array([fx["columns"][int(r["col"])]["pos0"] for r in recs], np.int64)
+        text = la.format_vcf(recs, "chr1", pos0=pos0, keep=keep, filter_str=filt)
+        got = [gu.strip_hqa(l) for l in text.splitlines()]
+        assert len(got) == len(fx["vcf"]), path
+
+        def no_af(line):
+            f = line.split("\t")
+            f[7] = ";".join(x for x in f[7].split(";") if not x.startswith("AF="))
+            return "\t".join(f)
+        # 2.1.4 raw alt counts (after the BQ filter) from the oracle's compat switch
+        oc = oracle.default_conf(raw_counts_after_minbq=1, **kw)
+        ores, _ = oracle.call_batch(host["nt"], host["bq"], host["baq"], host["mq"], None, host["col_off"],
+                                    host["ref_base"], oc)
+        kept = recs[keep]
+        for g, e, r in zip(got, fx["vcf"], kept):
+            assert no_af(g) == no_af(e), (path, g, e)
+            c = int(r["col"])
+            a = [bytes([int(x)]) for x in ores["alt_base"][c]].index(r["alt"])
+            if int(r["alt_raw_count"]) == int(ores["alt_raw_counts"][c, a]):
+                assert g == e, (path, g, e)

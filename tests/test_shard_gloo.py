@@ -1,0 +1,95 @@
+"""CPU tests of the N > 1 path: two processes, gloo backend, 127.0.0.1 rendezvous.  Checks that region
+sharding + the test-count all-gather + record gather reproduce the single-process result exactly
+(running Bonferroni factor included)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_pvals(la, rng, cols, bonf_local):
+    """sparse records as the DP kernels would emit them for a shard (host-constructed: no GPU here)"""
+    pv = np.zeros(len(cols), la.COL_PVALS_DTYPE)
+    pv["col"] = cols
+    pv["bonf"] = bonf_local
+    pv["logp"][:, 0] = -rng.uniform(5, 60, len(cols))
+    pv["status"][:, 0] = la.LFQ_PV_LOG
+    pv["counts"]["alt_counts"][:, 0] = rng.integers(5, 50, len(cols))
+    pv["counts"]["kmax"] = pv["counts"]["alt_counts"][:, 0]
+    pv["counts"]["alt_raw_counts"][:, 0] = pv["counts"]["alt_counts"][:, 0] + 1
+    pv["counts"]["alt_fw"][:, 0] = pv["counts"]["alt_counts"][:, 0] // 2
+    pv["counts"]["ref_fw"] = 400
+    pv["counts"]["ref_rv"] = 390
+    pv["counts"]["coverage"] = 900
+    return pv
+
+
+def _scenario(la):
+    rng = np.random.default_rng(123)
+    ncols = 2000
+    tested = rng.random(ncols) < 0.7
+    prefix = np.cumsum(tested)                      # inclusive tested count
+    cand = np.nonzero(tested & (rng.random(ncols) < 0.03))[0]
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, ncols)].copy()
+    pv = _fake_pvals(la, rng, cand, 3 * prefix[cand])
+    return ncols, tested, prefix, ref, pv
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    ncols, tested, prefix, ref, pv = _scenario(la)
+    lo, hi = shard.shard_ranges(ncols, world)[rank]
+    mine = pv[(pv["col"] >= lo) & (pv["col"] < hi)].copy()
+    # what a shard sees locally: column indices and Bonferroni factors restart at its own origin
+    before = int(tested[:lo].sum())
+    mine["col"] -= lo
+    mine["bonf"] -= 3 * before
+    conf = la.VarcallConf()
+    recs, total = shard.finish_shard(conf, mine, int(tested[lo:hi].sum()), ref[lo:hi], lo, dist, None)
+    if rank == 0:
+        np.save(out, recs.view(np.uint8))
+        np.save(out + ".meta", np.array([total, conf.bonf_subst, conf.num_snv_tests]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single_process(tmp_path, world):
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out).view(la.SNV_RECORD_DTYPE)
+    total, bonf, ntests = np.load(out + ".meta.npy")
+    ncols, tested, prefix, ref, pv = _scenario(la)
+    conf = la.VarcallConf()
+    exp, total1 = shard.finish_shard(conf, pv, int(tested.sum()), ref, 0, None, None)
+    assert total == total1 == int(tested.sum())
+    assert bonf == conf.bonf_subst == 3 * int(tested.sum()) and ntests == conf.num_snv_tests
+    assert len(got) == len(exp) and len(exp) > 10
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_shard_ranges():
+    from lofreq_amd import shard
+    assert shard.shard_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert shard.shard_ranges(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
