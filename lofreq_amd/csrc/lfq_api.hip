@@ -42,7 +42,8 @@ struct lfq_ctx {
     /* per-batch workspace, grown on demand */
     int64_t ws_cols;
     uint8_t *d_flags;
-    int32_t *d_prefix, *d_qb, *d_qm, *d_ql, *d_counters;
+    int32_t *d_prefix, *d_counters;
+    LfqEntry *d_entries;
     hipStream_t side[2];       /* mid / big DP kernels run beside the light one */
     hipEvent_t ev_fork, ev_light_done, ev_join[2], ev_side[2][2];
     uint64_t *d_tiles;
@@ -164,23 +165,18 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         int64_t want = ncols + ncols / 8 + 1024;
         if (c->d_flags) (void)hipFree(c->d_flags);
         if (c->d_prefix) (void)hipFree(c->d_prefix);
-        if (c->d_qb) (void)hipFree(c->d_qb);
-        if (c->d_qm) (void)hipFree(c->d_qm);
-        if (c->d_ql) (void)hipFree(c->d_ql);
+        if (c->d_entries) (void)hipFree(c->d_entries);
         if (c->d_tiles) (void)hipFree(c->d_tiles);
         c->d_flags = nullptr;
-        c->d_prefix = c->d_qb = c->d_qm = c->d_ql = nullptr;
+        c->d_prefix = nullptr;
+        c->d_entries = nullptr;
         c->d_tiles = nullptr;
         c->ws_cols = 0;
         LFQ_TRY(grow(&c->d_flags, &cap, want));
         cap = 0;
         LFQ_TRY(grow(&c->d_prefix, &cap, want));
         cap = 0;
-        LFQ_TRY(grow(&c->d_qb, &cap, want));
-        cap = 0;
-        LFQ_TRY(grow(&c->d_qm, &cap, want));
-        cap = 0;
-        LFQ_TRY(grow(&c->d_ql, &cap, want));
+        LFQ_TRY(grow(&c->d_entries, &cap, want));
         cap = 0;
         LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8)));
         c->ws_cols = want;
@@ -224,7 +220,9 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     }
     ok = ok && hipEventCreate(&c->ev_fork) == hipSuccess && hipEventCreate(&c->ev_light_done) == hipSuccess;
     for (int i = 0; ok && i < 2; i++) {
-        ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
         ok = ok && hipEventCreate(&c->ev_join[i]) == hipSuccess;
         ok = ok && hipEventCreate(&c->ev_side[i][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][1]) == hipSuccess;
     }
@@ -248,7 +246,7 @@ void lfq_destroy(lfq_ctx *c)
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_qb, c->d_qm, c->d_ql, c->d_counters, c->d_tiles,
+    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_entries, c->d_counters, c->d_tiles,
                     c->d_scratch, c->d_counts, c->d_pvals, c->d_stage};
     for (void *b : bufs) {
         if (b) (void)hipFree(b);
@@ -311,9 +309,7 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
 
     LfqWork W;
     W.tested_prefix = c->d_prefix;
-    W.q_big = c->d_qb;
-    W.q_mid = c->d_qm;
-    W.q_light = c->d_ql;
+    W.entries = c->d_entries;
     W.counters = c->d_counters;
     W.block_sums = (int32_t *)c->d_tiles;
 
@@ -324,7 +320,7 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     LFQ_TRY_HIP(hipEventRecord(c->ev[0], st));
     LFQ_TRY(lfq_launch_count(T, P, c->d_luts, d_counts, c->d_flags, c->d_counters, st));
     LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));
-    LFQ_TRY(lfq_launch_scan(tr->ncols, c->d_flags, W, st));
+    LFQ_TRY(lfq_launch_scan(T, c->d_flags, d_counts, W, st));
     LFQ_TRY_HIP(hipEventRecord(c->ev[2], st));
 
     /* big-column scratch: 2 doubles per observation (pass boundary) + K+1 log-probabilities per
@@ -337,7 +333,7 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
         max_depth = c->h_counters[LFQ_CNT_MAXDEPTH];
     }
     const int64_t per_block = 3 * max_depth + 72;
-    int n_big_blocks = c->n_cu / 2;                     /* leave half of the CUs to the light kernel */
+    int n_big_blocks = c->n_cu;                         /* 8-wave workgroups: one per CU beside the light kernel */
     const int64_t budget = (int64_t)1 << 29;            /* 4 GiB of doubles */
     if (per_block * n_big_blocks > budget) {
         n_big_blocks = (int)std::max<int64_t>(8, budget / per_block);
@@ -352,10 +348,17 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
         LFQ_TRY_HIP(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
         LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][0], c->side[i]));
     }
-    LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
-                              n_big_blocks, c->side[0]));
-    LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
-    LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, st));
+    const char *skip = getenv("LFQ_DEBUG_SKIP");   /* profiling aid: run the DP classes in isolation */
+    if (!skip || !strstr(skip, "big")) {
+        LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
+                                  n_big_blocks, c->side[0]));
+    }
+    if (!skip || !strstr(skip, "mid")) {
+        LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
+    }
+    if (!skip || !strstr(skip, "light")) {
+        LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, st));
+    }
     LFQ_TRY_HIP(hipEventRecord(c->ev_light_done, st));
     for (int i = 0; i < 2; i++) {
         LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][1], c->side[i]));

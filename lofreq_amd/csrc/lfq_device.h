@@ -22,7 +22,7 @@ __device__ __forceinline__ int lfq_lane() { return (int)(threadIdx.x & 63u); }
 /* lane i receives lane i-1's value, lane 0 receives 0 (DPP wave_shr:1, VALU, no LDS) */
 __device__ __forceinline__ int lfq_shr1_i32(int x)
 {
-    return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);   /* bound_ctrl: lane 0 reads 0 */
 }
 
 __device__ __forceinline__ double lfq_shr1_f64(double x)

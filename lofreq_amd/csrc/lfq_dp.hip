@@ -15,11 +15,11 @@
  *   lfq_dp_wave_kernel<1>  light columns, K < 64: one wavefront per column, one cell per lane.
  *   lfq_dp_wave_kernel<8>  mid columns, 64 <= K < 505: one wavefront per column, 8 cells per lane.
  *                        Both: persistent grid, static column striding, no strip exchange.
- *   lfq_dp_big_kernel    K >= 505: one 16-wave workgroup per column, C = 8, strip w on wave w.  Strips
+ *   lfq_dp_big_kernel    K >= 505: one 8-wave workgroup per column, C = 8, strip w on wave w.  Strips
  *                        run as a software pipeline over 64-row chunks (wave w works on chunk t-w at
  *                        step t); the boundary cell of strip w reaches strip w+1 through a
- *                        double-buffered LDS slab, one s_barrier per step.  More than 16 strips
- *                        (K > 8191) run in passes with the pass boundary in global scratch.
+ *                        double-buffered LDS slab, one s_barrier per step.  More than 8 strips
+ *                        (K > 4095) run in passes with the pass boundary in global scratch.
  *
  * The three kernels run concurrently on three HIP streams (lfq_api.hip).
  */
@@ -32,7 +32,7 @@
 #define LFQ_EXP_UNDERFLOW_X (-708.3964185322641)
 #define LFQ_DBL_EPS 2.220446049250313e-16
 
-#define LFQ_HEAVY_WAVES 16
+#define LFQ_HEAVY_WAVES 8
 #define LFQ_HEAVY_C 8
 
 struct LfqColCtx {
@@ -47,43 +47,87 @@ struct LfqColCtx {
     double sig_s;
 };
 
-__device__ __forceinline__ void lfq_col_setup(LfqColCtx &cx, int col, const LfqTracksDev &T, const LfqParams &P,
-                                              const lfq_col_counts &cnt, const LfqWork &W)
+__device__ __forceinline__ void lfq_col_setup(LfqColCtx &cx, const LfqEntry &en, const LfqParams &P)
 {
-    cx.col = col;
-    cx.off0 = T.col_off[col];
-    cx.n_obs = (int64_t)(T.col_off[col + 1] - cx.off0);
-    const uint32_t rb = T.ref_base[col];
-    cx.ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : 3;
-    cx.median_ref_bq = cnt.median_ref_bq;
-    cx.K = cnt.kmax;
+    cx.col = en.col;
+    cx.off0 = en.off0;
+    cx.n_obs = en.n_obs;
+    cx.ref_code = en.ref_code;
+    cx.median_ref_bq = en.median_ref_bq;
+    cx.K = en.kmax;
     /* running Bonferroni factor at this column (lofreq_call.c:794-800) */
     int64_t bonf = P.bonf_base;
     if (P.bonf_dynamic) {
-        bonf = ((P.bonf_base == 1) ? 0 : P.bonf_base) + 3 * (int64_t)W.tested_prefix[col];
+        bonf = ((P.bonf_base == 1) ? 0 : P.bonf_base) + 3 * (int64_t)en.prefix;
     }
     cx.bonf = bonf;
     cx.bonf_d = (double)bonf;
     cx.sig_s = P.sig * (1.0 + P.prune_slack);
 }
 
-/* evaluate the 64 observations of chunk `ch`: keep mask + effective p and 1-p per lane, with the
- * reference's guards against log(0) (snpcaller.c:872-881) expressed on the probabilities */
-__device__ __forceinline__ uint64_t lfq_eval_chunk(const LfqColCtx &cx, int64_t ch, const LfqTracksDev &T,
-                                                   const LfqParams &P, const LfqLuts *L, double *ps, double *qf)
+/* wave-uniform load of a work-list record (32 bytes) */
+__device__ __forceinline__ LfqEntry lfq_load_entry(const LfqEntry *list, int i)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(list + i);
+    const uint4 a = p[0], b = p[1];
+    LfqEntry e;
+    e.off0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.y) << 32)
+             | (uint32_t)__builtin_amdgcn_readfirstlane((int)a.x);
+    e.n_obs = __builtin_amdgcn_readfirstlane((int)a.z);
+    e.col = __builtin_amdgcn_readfirstlane((int)a.w);
+    e.prefix = __builtin_amdgcn_readfirstlane((int)b.x);
+    e.kmax = __builtin_amdgcn_readfirstlane((int)b.y);
+    const int m = __builtin_amdgcn_readfirstlane((int)b.z);
+    e.median_ref_bq = (int16_t)(m & 0xffff);
+    e.ref_code = (uint8_t)((m >> 16) & 0xff);
+    e.pad_ = 0;
+    e.pad2_ = 0;
+    return e;
+}
+
+/* the packed bytes of one observation per lane (chunk `ch` of the column); 0xffffffff = past the end */
+struct LfqRaw {
+    uint32_t w;      /* nt | bq << 8 | baq << 16 | mq << 24 */
+    uint32_t sq;
+};
+
+__device__ __forceinline__ LfqRaw lfq_load_chunk_at(uint64_t off0, int64_t n_obs, int64_t ch, const LfqTracksDev &T)
 {
     const int64_t idx = ch * 64 + lfq_lane();
-    LfqObs o;
-    o.keep = false;
-    o.p = 0.0;
-    if (idx < cx.n_obs) {
-        const uint64_t g = cx.off0 + (uint64_t)idx;
-        o = lfq_eval_obs(T.nt[g], T.bq[g], T.baq ? T.baq[g] : 255u, T.mq[g], T.sq ? T.sq[g] : 255u,
-                         cx.ref_code, cx.median_ref_bq, P, L);
+    LfqRaw r;
+    r.w = 0x00000004u;          /* N base: ignored */
+    r.sq = 255u;
+    if (idx < n_obs) {
+        const uint64_t g = off0 + (uint64_t)idx;
+        const uint32_t nt = T.nt[g], bq = T.bq[g], baq = T.baq ? T.baq[g] : 255u, mq = T.mq[g];
+        r.w = nt | (bq << 8) | (baq << 16) | (mq << 24);
+        r.sq = T.sq ? T.sq[g] : 255u;
     }
+    return r;
+}
+
+__device__ __forceinline__ LfqRaw lfq_load_chunk(const LfqColCtx &cx, int64_t ch, const LfqTracksDev &T)
+{
+    return lfq_load_chunk_at(cx.off0, cx.n_obs, ch, T);
+}
+
+/* evaluate the 64 observations of a chunk: keep mask + effective p and 1-p per lane, with the
+ * reference's guards against log(0) (snpcaller.c:872-881) expressed on the probabilities */
+__device__ __forceinline__ uint64_t lfq_eval_raw(const LfqColCtx &cx, const LfqRaw &r, const LfqParams &P,
+                                                 const LfqLuts *L, double *ps, double *qf)
+{
+    const LfqObs o = lfq_eval_obs(r.w & 0xffu, (r.w >> 8) & 0xffu, (r.w >> 16) & 0xffu, r.w >> 24, r.sq,
+                                  cx.ref_code, cx.median_ref_bq, P, L);
     *ps = (fabs(o.p) < LFQ_DBL_EPS) ? LFQ_DBL_EPS : o.p;
     *qf = (fabs(o.p - 1.0) < LFQ_DBL_EPS) ? 1.0 + (-o.p + LFQ_DBL_EPS) : 1.0 - o.p;
     return __ballot(o.keep);
+}
+
+__device__ __forceinline__ uint64_t lfq_eval_chunk(const LfqColCtx &cx, int64_t ch, const LfqTracksDev &T,
+                                                   const LfqParams &P, const LfqLuts *L, double *ps, double *qf)
+{
+    const LfqRaw r = lfq_load_chunk(cx, ch, T);
+    return lfq_eval_raw(cx, r, P, L, ps, qf);
 }
 
 template <int C>
@@ -105,98 +149,131 @@ __device__ __forceinline__ void lfq_strip_init(LfqStrip<C> &S, bool first_strip,
     S.all_zero = !first_strip;
 }
 
-/* Advance one strip over the kept rows of one chunk.  (bv,be): per-lane incoming boundary of row
- * `lane` (value, exponent) when has_in; (ov,oe): per-lane outgoing boundary when has_out.
- * Returns true when the pruning test fires (only evaluated on the strip that owns the tail). */
+/* one row of the chunk as the DP consumes it: effective p and 1-p.  Observations that do not
+ * contribute an error probability are stored as (0, 1): an exact identity row. */
+struct LfqRow {
+    double p, q;
+};
+
+/* Advance one strip over the 64 rows of one chunk, 8 rows at a time with no per-row branches.
+ *   rows     64 (p,q) pairs in LDS, read with a wave-uniform address (broadcast)
+ *   in_v/e   incoming boundary (value, exponent) per row in LDS when has_in (strip > 0)
+ *   out_v/e  outgoing boundary per row in LDS when has_out (strip is not the last one)
+ *   tflag    1.0 on the lane that owns the absorbing tail cell (at j = 0), else 0.0: its miss factor
+ *            becomes q + p instead of q (cells beyond the tail hold don't-care values that are never read)
+ * Returns true when the pruning test fires (evaluated every 8 rows on the strip that owns the tail). */
 template <int C>
-__device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, uint64_t km, double ps, double qf, bool has_in,
-                                                double bv, int be, bool has_out, double &ov, int &oe,
-                                                bool is_tail, bool owns_tail, int lt, double bonf_d, double sig_s)
+__device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *rows, uint64_t km, bool has_in,
+                                                const double *in_v, const int *in_e, bool has_out,
+                                                double *out_v, int *out_e, double tflag, bool owns_tail,
+                                                int lt, double bonf_d, double sig_s)
 {
     const int lane = lfq_lane();
-    while (km) {
-        const int i = __builtin_ctzll(km);
-        km &= km - 1;
-        const double p = lfq_rl_f64(ps, i);
-        const double q = lfq_rl_f64(qf, i);
-        double x = lfq_shr1_f64(S.v[C - 1]);
-        int dei = S.de;
-        if (has_in) {
-            const double xb = lfq_rl_f64(bv, i);
-            const int eb = lfq_rl_i32(be, i);
-            S.e_in = eb;
-            if (S.all_zero) {
-                S.e = eb;                   /* adopt the producer's scale while empty */
-                S.de = 0;
-                dei = 0;
-                if (xb == 0.0) {
-                    if (has_out && lane == i) {
-                        ov = 0.0;
-                        oe = eb;
-                    }
-                    S.rows++;
-                    continue;
+    constexpr int R = (C == 1) ? 8 : 4;     /* rows per unrolled group (register pressure vs. branch cost) */
+#pragma unroll 1
+    for (int g = 0; g < 64 / R; g++) {
+        const int r0 = g * R;
+        if (has_in && S.all_zero && (r0 & 7) == 0) {
+            /* nothing has reached this strip yet: skip whole groups whose incoming values are all zero */
+            const double xb = in_v[r0 + (lane & 7)];
+            const int eb_last = in_e[r0 + 7];
+            if (!__any(xb != 0.0)) {
+                if (has_out && lane < 8) {
+                    out_v[r0 + lane] = 0.0;
+                    out_e[r0 + lane] = in_e[r0 + lane];
                 }
-                S.all_zero = false;
+                S.e = eb_last;
+                S.e_in = eb_last;
+                g += 8 / R - 1;         /* the whole 8-row block */
+                continue;
             }
-            if (lane == 0) {
-                x = xb;
-                dei = eb - S.e;
-            }
+            S.all_zero = false;
+            S.e = in_e[r0];             /* adopt the producer's scale */
+            S.de = 0;
         }
-        if (has_out) {
-            const double v63 = lfq_rl_f64(S.v[C - 1], 63);
-            const int e63 = lfq_rl_i32(S.e, 63);
-            if (lane == i) {
-                ov = v63;
-                oe = e63;
-            }
-        }
-        const double xs = ldexp(x, dei);
-        const double ph = is_tail ? 0.0 : p;     /* nothing flows past the absorbing tail cell */
-        const double q0 = is_tail ? 1.0 : q;
 #pragma unroll
-        for (int j = C - 1; j >= 1; j--) {
-            S.v[j] = fma(S.v[j - 1], ph, S.v[j] * q);
+        for (int r = 0; r < R; r++) {
+            const LfqRow pq = rows[r0 + r];
+            double x = lfq_shr1_f64(S.v[C - 1]);
+            int dei = S.de;
+            if (has_in) {
+                const double xb = in_v[r0 + r];
+                const int eb = in_e[r0 + r];
+                S.e_in = eb;
+                if (lane == 0) {
+                    x = xb;
+                    dei = eb - S.e;
+                }
+            }
+            if (has_out && lane == 63) {
+                out_v[r0 + r] = S.v[C - 1];
+                out_e[r0 + r] = S.e;
+            }
+            const double pe = ldexp(pq.p, dei);             /* off the row-to-row dependency chain */
+            const double q0 = fma(tflag, pq.p, pq.q);
+#pragma unroll
+            for (int j = C - 1; j >= 1; j--) {
+                S.v[j] = fma(S.v[j - 1], pq.p, S.v[j] * pq.q);
+            }
+            S.v[0] = fma(x, pe, S.v[0] * q0);
         }
-        S.v[0] = fma(xs, p, S.v[0] * q0);
-        S.rows++;
+        if (((r0 + R) & 7) != 0) {
+            continue;
+        }
 
-        if ((S.rows & 7) == 0) {
-            /* renormalise: lane maximum to [0.5,1), exponent into e */
-            double m = S.v[0];
+        /* every 8 rows: renormalise (lane maximum to [0.5,1), exponent into e) ... */
+        double m = S.v[0];
 #pragma unroll
-            for (int j = 1; j < C; j++) {
-                m = fmax(m, S.v[j]);
-            }
-            const bool nzl = m > 0.0;
-            const uint64_t nz = __ballot(nzl);
-            if (nzl) {
-                const int ex = __builtin_amdgcn_frexp_exp(m);
+        for (int j = 1; j < C; j++) {
+            m = fmax(m, S.v[j]);
+        }
+        const bool nzl = m > 0.0;
+        const uint64_t nz = __ballot(nzl);
+        const int ex = nzl ? __builtin_amdgcn_frexp_exp(m) : 0;
 #pragma unroll
-                for (int j = 0; j < C; j++) {
-                    S.v[j] = ldexp(S.v[j], -ex);
-                }
-                S.e += ex;
+        for (int j = 0; j < C; j++) {
+            S.v[j] = ldexp(S.v[j], -ex);
+        }
+        S.e += ex;
+        /* ... empty lanes (always a suffix: every cell left of the frontier is positive) adopt the scale
+         * of the frontier lane, so the first value that reaches them is representable ... */
+        if (nz != ~0ull) {
+            if (nz) {
+                const int e_front = lfq_rl_i32(S.e, 63 - __builtin_clzll(nz));
+                S.e = nzl ? S.e : e_front;
+            } else if (has_in) {
+                S.e = S.e_in;
             }
-            /* empty lanes adopt the scale of the nearest non-empty lane to their left */
-            const uint64_t below = nz & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
-            const int src = below ? (63 - __builtin_clzll(below)) : lane;
-            const int e_src = __shfl(S.e, src, 64);
-            if (!nzl) {
-                S.e = below ? e_src : (has_in ? S.e_in : S.e);
-            }
-            S.de = lfq_shr1_i32(S.e) - S.e;
-            if (owns_tail) {
-                const double tv = lfq_rl_f64(S.v[0], lt);
-                const int te = lfq_rl_i32(S.e, lt);
-                if (ldexp(tv, te) * bonf_d > sig_s) {
-                    return true;
-                }
+        }
+        S.de = lfq_shr1_i32(S.e) - S.e;
+        /* ... and test the pruning condition on the tail cell */
+        if (owns_tail) {
+            const uint64_t over = __ballot(ldexp(S.v[0], S.e) * bonf_d > sig_s);
+            if ((over >> lt) & 1ull) {
+                S.rows = r0 + R;
+                return true;
             }
         }
     }
+    S.rows = 64;
     return false;
+}
+
+/* per-lane (p,q) of a chunk into the wave's LDS row buffer; returns the keep mask */
+__device__ __forceinline__ uint64_t lfq_stage_rows(const LfqColCtx &cx, const LfqRaw &raw, const LfqParams &P,
+                                                   const LfqLuts *L, LfqRow *rows)
+{
+    double ps, qf;
+    const uint64_t km = lfq_eval_raw(cx, raw, P, L, &ps, &qf);
+    const bool keep = (km >> lfq_lane()) & 1ull;
+    LfqRow r;
+    r.p = keep ? ps : 0.0;
+    r.q = keep ? qf : 1.0;
+    rows[lfq_lane()] = r;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return km;
 }
 
 template <int C>
@@ -323,6 +400,153 @@ __device__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, c
     }
 }
 
+/* ---- tail sums without transcendentals (wave-per-column kernels) ---------------------------------
+ * Values are (mantissa, binary exponent) pairs; sums align exponents with ldexp.  probvec_tailsum
+ * (snpcaller.c:730-741) becomes a prefix sum over the cells c..K held in registers; the exp()
+ * underflow inside the reference's log_sum chain (exp(min-max) < DBL_MIN) becomes
+ * "ratio of the smaller to the larger of (running sum, next cell) below 2^-1022". */
+struct LfqExt {
+    double v;
+    int e;
+};
+
+__device__ __forceinline__ LfqExt lfq_ext_add(LfqExt a, LfqExt b)
+{
+    if (a.v == 0.0) {
+        return b;
+    }
+    if (b.v == 0.0) {
+        return a;
+    }
+    LfqExt r;
+    r.e = max(a.e, b.e);
+    r.v = ldexp(a.v, a.e - r.e) + ldexp(b.v, b.e - r.e);
+    return r;
+}
+
+/* true if min(a,b)/max(a,b) < 2^-1022 */
+__device__ __forceinline__ bool lfq_ext_ratio_underflows(LfqExt a, LfqExt b)
+{
+    if (a.v == 0.0 || b.v == 0.0) {
+        return a.v != b.v;
+    }
+    /* compare a and b */
+    const int fa = __builtin_amdgcn_frexp_exp(a.v) + a.e, fb = __builtin_amdgcn_frexp_exp(b.v) + b.e;
+    const double ma = __builtin_amdgcn_frexp_mant(a.v), mb = __builtin_amdgcn_frexp_mant(b.v);
+    const bool a_small = (fa < fb) || (fa == fb && ma < mb);
+    const double ms = a_small ? ma : mb, ml = a_small ? mb : ma;
+    const int es = a_small ? fa : fb, el = a_small ? fb : fa;
+    /* (ms/ml) * 2^(es-el) < 2^-1022  <=>  ms/ml < 2^(-1022-es+el) */
+    const int d = es - el;                 /* <= 0 */
+    if (d > -1021) {
+        return false;
+    }
+    if (d < -1024) {
+        return true;
+    }
+    return (ms / ml) < ldexp(1.0, -1022 - d);
+}
+
+template <int C>
+__device__ void lfq_emit_linear(const LfqColCtx &cx, const lfq_col_counts &cnt, const LfqStrip<C> &S, int shift,
+                                int lt, const LfqWork &W, lfq_col_pvals *__restrict__ pvals,
+                                int64_t pvals_capacity)
+{
+    const int lane = lfq_lane();
+    const int K = cx.K;
+    double logp[3];
+    int status[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int c = cnt.alt_counts[a];
+        logp[a] = 0.0;
+        status[a] = LFQ_PV_NONE;
+        if (c == 0) {
+            continue;
+        }
+        LfqExt tot;
+        bool fe = false;
+        if (c == K) {
+            tot.v = lfq_rl_f64(S.v[0], lt);
+            tot.e = lfq_rl_i32(S.e, lt);
+        } else {
+            /* lane totals over the cells k in [c, K] (the tail cell k = K sits at j = 0 of lane lt) */
+            LfqExt mine;
+            mine.v = 0.0;
+            mine.e = S.e;
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const int k = lane * C + j - shift;
+                if (k >= c && (k < K || (k == K && j == 0))) {
+                    mine.v += S.v[j];
+                }
+            }
+            /* exclusive prefix across lanes */
+            LfqExt incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                LfqExt y;
+                y.v = __shfl_up(incl.v, d, 64);
+                y.e = __shfl_up(incl.e, d, 64);
+                if (lane >= d) {
+                    incl = lfq_ext_add(incl, y);
+                }
+            }
+            LfqExt run;
+            run.v = __shfl_up(incl.v, 1, 64);
+            run.e = __shfl_up(incl.e, 1, 64);
+            if (lane == 0) {
+                run.v = 0.0;
+                run.e = 0;
+            }
+            /* walk this lane's cells in k order: the reference's fold state before cell k is `run` */
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const int k = lane * C + j - shift;
+                if (k >= c && (k < K || (k == K && j == 0))) {
+                    LfqExt cell;
+                    cell.v = S.v[j];
+                    cell.e = S.e;
+                    if (k > c && lfq_ext_ratio_underflows(run, cell)) {
+                        fe = true;
+                    }
+                    run = lfq_ext_add(run, cell);
+                }
+            }
+            fe = __any(fe);
+            tot.v = lfq_rl_f64(incl.v, 63);
+            tot.e = lfq_rl_i32(incl.e, 63);
+        }
+        const double ed = (double)tot.e;
+        logp[a] = (tot.v > 0.0) ? (ed * LFQ_LN2_HI + (ed * LFQ_LN2_LO + log(tot.v))) : -INFINITY;
+        status[a] = fe ? LFQ_PV_LOG_FECLAMP : LFQ_PV_LOG;
+    }
+    if (lane == 0) {
+        const int slot = atomicAdd(&W.counters[LFQ_CNT_PVALS], 1);
+        if ((int64_t)slot < pvals_capacity) {
+            lfq_col_pvals r;
+            r.col = cx.col;
+            r.bonf = cx.bonf;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                r.logp[a] = logp[a];
+                r.status[a] = (uint8_t)status[a];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                r.pad_[i] = 0;
+            }
+            r.counts = cnt;
+            r.dp_rows = S.rows;
+            r.pad2_ = 0;
+            r.reserved_ = 0;
+            pvals[slot] = r;
+        } else {
+            W.counters[LFQ_CNT_OVERFLOW] = 1;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* wave-per-column kernel: light (K < 64, C = 1) and mid (64 <= K < 505, C = 8) columns          */
 /* ------------------------------------------------------------------------------------------ */
@@ -331,12 +555,17 @@ template <int C>
 __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqParams P,
                                                           const LfqLuts *__restrict__ g_luts,
                                                           const lfq_col_counts *__restrict__ counts, LfqWork W,
-                                                          const int32_t *__restrict__ queue, int count_idx,
+                                                          int base_idx, int count_idx,
                                                           lfq_col_pvals *__restrict__ pvals,
                                                           int64_t pvals_capacity, int n_waves)
 {
     __shared__ LfqLuts s_luts;
-    __shared__ double s_probvec[4][64 * C];
+    __shared__ LfqRow s_rows[4][64];
+    if (C > 1) {
+        /* few, long, latency-bound columns sharing SIMDs with the throughput-bound light kernel:
+         * win the issue arbitration (MI355X_MICROARCH "two waves per SIMD", item 2) */
+        __builtin_amdgcn_s_setprio(3);
+    }
     {
         const double *src = reinterpret_cast<const double *>(g_luts);
         double *dst = reinterpret_cast<double *>(&s_luts);
@@ -349,45 +578,82 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wave_id = (int)blockIdx.x * 4 + wave;
     const int n_work = W.counters[count_idx];
-    double *probvec = s_probvec[wave];
+    /* list layout [light | mid | big] */
+    const LfqEntry *list = W.entries + ((base_idx >= 0) ? W.counters[base_idx] : 0);
+    LfqRow *rows = s_rows[wave];
 
-    for (int w = wave_id; w < n_work; w += n_waves) {
-        const int col = __builtin_amdgcn_readfirstlane(queue[w]);
-        const lfq_col_counts cnt = counts[col];
+    /* software pipeline over columns: while column i runs its recurrence, the record of column i+2 and
+     * the first chunk of column i+1 are already in flight */
+    int w = wave_id;
+    if (w >= n_work) {
+        return;
+    }
+    LfqEntry en = lfq_load_entry(list, w);
+    LfqRaw raw = lfq_load_chunk_at(en.off0, en.n_obs, 0, T);
+    LfqEntry en_next = en;
+    bool have_next = (w + n_waves) < n_work;
+    if (have_next) {
+        en_next = lfq_load_entry(list, w + n_waves);
+    }
+    for (;;) {
+        LfqRaw raw_next = raw;
+        LfqEntry en_next2 = en_next;
+        const bool have_next2 = have_next && (w + 2 * n_waves) < n_work;
+        if (have_next) {
+            raw_next = lfq_load_chunk_at(en_next.off0, en_next.n_obs, 0, T);
+        }
+        if (have_next2) {
+            en_next2 = lfq_load_entry(list, w + 2 * n_waves);
+        }
+
         LfqColCtx cx;
-        lfq_col_setup(cx, col, T, P, cnt, W);
+        lfq_col_setup(cx, en, P);
         const int K = cx.K;
         const int shift = (C - K % C) % C;
         const int lt = (K + shift) / C;             /* lane that owns the tail cell (<= 63 by class) */
-        const bool is_tail = (lane == lt);
+        const double tflag = (lane == lt) ? 1.0 : 0.0;
         LfqStrip<C> S;
         lfq_strip_init<C>(S, true, shift);
         const int64_t n_chunks = (cx.n_obs + 63) / 64;
         bool pruned = false;
-        double ov = 0.0;
-        int oe = 0;
+        int n_rows = 0;
         for (int64_t ch = 0; ch < n_chunks; ch++) {
-            double ps, qf;
-            const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &s_luts, &ps, &qf);
-            if (lfq_strip_chunk<C>(S, km, ps, qf, false, 0.0, 0, false, ov, oe, is_tail, true, lt, cx.bonf_d,
-                                   cx.sig_s)) {
+            LfqRaw nxt = raw;
+            if (C > 1 && ch + 1 < n_chunks) {
+                nxt = lfq_load_chunk(cx, ch + 1, T);      /* long columns: hide the next chunk's latency */
+            }
+            const uint64_t km = lfq_stage_rows(cx, raw, P, &s_luts, rows);
+            const bool hit = lfq_strip_chunk<C>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
+                                                true, lt, cx.bonf_d, cx.sig_s);
+            n_rows += __popcll(S.rows >= 64 ? km : (km & ((1ull << S.rows) - 1ull)));
+            if (hit) {
                 pruned = true;
                 break;
             }
+            if (C > 1) {
+                raw = nxt;
+            } else if (ch + 1 < n_chunks) {
+                raw = lfq_load_chunk(cx, ch + 1, T);
+            }
         }
-        if (pruned || lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
-            continue;
+        if (!pruned && !lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
+            const lfq_col_counts cnt = counts[cx.col];
+            S.rows = n_rows;
+            lfq_emit_linear<C>(cx, cnt, S, shift, lt, W, pvals, pvals_capacity);
         }
-        lfq_strip_store_logs<C>(S, lane, shift, K, probvec);
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        lfq_emit_pvals(cx, cnt, probvec, K, true, 0u, nullptr, false, S.rows, W, pvals, pvals_capacity);
-        __builtin_amdgcn_wave_barrier();
+        if (!have_next) {
+            break;
+        }
+        w += n_waves;
+        en = en_next;
+        raw = raw_next;
+        en_next = en_next2;
+        have_next = have_next2;
     }
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* big columns: K >= 505, one 16-wave workgroup per column                                     */
+/* big columns: K >= 505, one 8-wave workgroup per column                                     */
 /* ------------------------------------------------------------------------------------------ */
 
 __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
@@ -398,10 +664,14 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
     constexpr int C = LFQ_HEAVY_C;
     constexpr int NW = LFQ_HEAVY_WAVES;
     __shared__ LfqLuts s_luts;
-    __shared__ double s_bv[2][NW][64];
+    __shared__ LfqRow s_rows[NW][64];
+    __shared__ double s_bv[2][NW][64];      /* strip boundary slabs, double-buffered across steps */
     __shared__ int s_be[2][NW][64];
+    __shared__ double s_gv[NW][64];         /* pass boundary staged from global scratch */
+    __shared__ int s_ge[NW][64];
     __shared__ int s_col, s_pruned;
     __shared__ double s_mu[NW];
+    __builtin_amdgcn_s_setprio(3);
     {
         const double *src = reinterpret_cast<const double *>(g_luts);
         double *dst = reinterpret_cast<double *>(&s_luts);
@@ -425,10 +695,10 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
         if (h >= n_big) {
             break;
         }
-        const int col = W.q_big[h];
-        const lfq_col_counts cnt = counts[col];
+        const LfqEntry en = lfq_load_entry(W.entries + W.counters[LFQ_CNT_LIGHT] + W.counters[LFQ_CNT_MID], h);
+        const lfq_col_counts cnt = counts[en.col];
         LfqColCtx cx;
-        lfq_col_setup(cx, col, T, P, cnt, W);
+        lfq_col_setup(cx, en, P);
         const int64_t n_chunks = (cx.n_obs + 63) / 64;
 
         /* Shortcut for p-values below the 80-bit range.  P(X >= c) <= e_c(p) <= mu^c / c!  (union
@@ -496,7 +766,7 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
             const int s = s0 + w;
             const bool active = w < nwp;
             const int gl = s * 64 + lane;
-            const bool is_tail = (gl == Lt);
+            const double tflag = (gl == Lt) ? 1.0 : 0.0;
             const bool owns_tail = active && (s == n_strips - 1);
             const bool has_in = (s > 0);
             const bool in_global = has_in && (w == 0);    /* first strip of a later pass */
@@ -506,38 +776,41 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
             lfq_strip_init<C>(S, s == 0, shift);
 
             const int64_t n_steps = n_chunks + nwp - 1;
+            LfqRaw raw = lfq_load_chunk(cx, 0, T);
             for (int64_t t = 0; t < n_steps; t++) {
                 const int64_t ch = t - w;
                 if (active && ch >= 0 && ch < n_chunks) {
-                    double ps, qf;
-                    const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &s_luts, &ps, &qf);
-                    double bv = 0.0, ov = 0.0;
-                    int be = 0, oe = 0;
+                    const LfqRaw cur = raw;
+                    if (ch + 1 < n_chunks) {
+                        raw = lfq_load_chunk(cx, ch + 1, T);   /* in flight across this step's rows */
+                    }
                     const int64_t idx = ch * 64 + lane;
+                    const double *in_v = nullptr;
+                    const int *in_e = nullptr;
                     if (has_in) {
                         if (in_global) {
-                            if (idx < cx.n_obs) {
-                                bv = bnd[2 * idx];
-                                be = (int)bnd[2 * idx + 1];
-                            }
+                            s_gv[w][lane] = (idx < cx.n_obs) ? bnd[2 * idx] : 0.0;
+                            s_ge[w][lane] = (idx < cx.n_obs) ? (int)bnd[2 * idx + 1] : 0;
+                            in_v = s_gv[w];
+                            in_e = s_ge[w];
                         } else {
-                            bv = s_bv[(t - 1) & 1][w - 1][lane];
-                            be = s_be[(t - 1) & 1][w - 1][lane];
+                            in_v = s_bv[(t - 1) & 1][w - 1];
+                            in_e = s_be[(t - 1) & 1][w - 1];
                         }
                     }
-                    if (lfq_strip_chunk<C>(S, km, ps, qf, has_in, bv, be, has_out, ov, oe, is_tail, owns_tail, lt,
-                                           cx.bonf_d, cx.sig_s)) {
+                    const uint64_t km = lfq_stage_rows(cx, cur, P, &s_luts, s_rows[w]);
+                    if (lfq_strip_chunk<C>(S, s_rows[w], km, has_in, in_v, in_e, has_out, s_bv[t & 1][w],
+                                           s_be[t & 1][w], tflag, owns_tail, lt, cx.bonf_d, cx.sig_s)) {
                         s_pruned = 1;
                     }
-                    if (has_out) {
-                        if (out_global) {
-                            if (idx < cx.n_obs) {
-                                bnd[2 * idx] = ov;
-                                bnd[2 * idx + 1] = (double)oe;
-                            }
-                        } else {
-                            s_bv[t & 1][w][lane] = ov;
-                            s_be[t & 1][w][lane] = oe;
+                    rows_tail += __popcll(km);
+                    if (out_global) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (idx < cx.n_obs) {
+                            bnd[2 * idx] = s_bv[t & 1][w][lane];
+                            bnd[2 * idx + 1] = (double)s_be[t & 1][w][lane];
                         }
                     }
                 }
@@ -551,7 +824,6 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
                 if (lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
                     s_pruned = 1;
                 }
-                rows_tail = S.rows;
             }
             __threadfence_block();
             __syncthreads();
@@ -585,7 +857,7 @@ int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
     hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                       d_counts, w, (const int32_t *)w.q_light, LFQ_CNT_LIGHT, d_pvals, pvals_capacity,
+                       d_counts, w, -1, LFQ_CNT_LIGHT, d_pvals, pvals_capacity,
                        (int)(blocks * 4));
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
@@ -599,7 +871,7 @@ int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
     hipLaunchKernelGGL(lfq_dp_wave_kernel<LFQ_HEAVY_C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,
-                       d_luts, d_counts, w, (const int32_t *)w.q_mid, LFQ_CNT_MID, d_pvals, pvals_capacity,
+                       d_luts, d_counts, w, LFQ_CNT_LIGHT, LFQ_CNT_MID, d_pvals, pvals_capacity,
                        (int)(blocks * 4));
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

@@ -45,12 +45,24 @@ struct LfqTracksDev {
     int64_t ncols;
 };
 
+/* one tested column, as the DP kernels consume it: everything a wavefront needs to start the column
+ * in a single 32-byte record, laid out in work-list order so that it can be prefetched */
+struct LfqEntry {
+    uint64_t off0;            /* first observation */
+    int32_t n_obs;
+    int32_t col;
+    int32_t prefix;           /* inclusive count of tested columns up to this one (running Bonferroni) */
+    int32_t kmax;
+    int16_t median_ref_bq;
+    uint8_t ref_code;         /* 0..3 */
+    uint8_t pad_;
+    int32_t pad2_;
+};
+
 /* work lists and counters produced by the scan kernels, consumed by the DP kernel */
 struct LfqWork {
     int32_t *tested_prefix;   /* [ncols] inclusive count of tested columns up to and incl. c */
-    int32_t *q_big;           /* [ncols] tested columns with kmax >= LFQ_BIG_K  (workgroup per column) */
-    int32_t *q_mid;           /* [ncols] LFQ_MID_K <= kmax < LFQ_BIG_K           (wave per column, 8 cells/lane) */
-    int32_t *q_light;         /* [ncols] kmax < LFQ_MID_K                        (wave per column, 1 cell/lane) */
+    LfqEntry *entries;        /* [ncols] work list: [light | mid | big] = [kmax < LFQ_MID_K | < LFQ_BIG_K | rest] */
     int32_t *counters;        /* [16], see LFQ_CNT_* */
     int32_t *block_sums;      /* scan scratch */
 };
@@ -70,7 +82,8 @@ struct LfqWork {
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
 int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, int32_t *d_counters, void *stream);
-int lfq_launch_scan(int64_t ncols, const uint8_t *d_flags, const LfqWork &w, void *stream);
+int lfq_launch_scan(const LfqTracksDev &t, const uint8_t *d_flags, const lfq_col_counts *d_counts,
+                    const LfqWork &w, void *stream);
 int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                         const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                         int64_t pvals_capacity, int n_waves, void *stream);

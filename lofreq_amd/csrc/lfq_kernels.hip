@@ -344,12 +344,14 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t
     }
 }
 
-__global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(int64_t ncols,
+__global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTracksDev T,
                                                                          const uint8_t *__restrict__ flags,
+                                                                         const lfq_col_counts *__restrict__ counts,
                                                                          const LfqTriple *__restrict__ tile_sums,
                                                                          LfqWork W)
 {
     __shared__ LfqTriple s_wave[16];
+    const int64_t ncols = T.ncols;
     const int64_t base = (int64_t)blockIdx.x * LFQ_SCAN_TILE + (int64_t)threadIdx.x * LFQ_SCAN_ITEMS;
     uint32_t f[LFQ_SCAN_ITEMS];
     LfqTriple x = {0, 0, 0};
@@ -360,21 +362,39 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(int64_
     LfqTriple total;
     LfqTriple ex = lfq_block_excl_scan(x, &total, s_wave);
     lfq_triple_add(ex, tile_sums[blockIdx.x]);
+    /* list layout [light | mid | big]; the class totals were published by lfq_scan_sums_kernel */
+    const uint32_t base_mid = (uint32_t)W.counters[LFQ_CNT_LIGHT];
+    const uint32_t base_big = base_mid + (uint32_t)W.counters[LFQ_CNT_MID];
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
-        if (base + i >= ncols) {
+        const int64_t c = base + i;
+        if (c >= ncols) {
             break;
         }
         if (f[i] & 1u) {
+            uint32_t pos;
             if (f[i] & 4u) {
-                W.q_big[ex.b++] = (int32_t)(base + i);
+                pos = base_big + ex.b++;
             } else if (f[i] & 2u) {
-                W.q_mid[ex.m++] = (int32_t)(base + i);
+                pos = base_mid + ex.m++;
             } else {
-                W.q_light[ex.t - ex.m - ex.b] = (int32_t)(base + i);
+                pos = ex.t - ex.m - ex.b;
             }
             ex.t++;
+            const lfq_col_counts *cn = &counts[c];
+            const uint32_t rb = T.ref_base[c];
+            LfqEntry e;
+            e.off0 = T.col_off[c];
+            e.n_obs = (int32_t)(T.col_off[c + 1] - e.off0);
+            e.col = (int32_t)c;
+            e.prefix = (int32_t)ex.t;                  /* inclusive */
+            e.kmax = cn->kmax;
+            e.median_ref_bq = (int16_t)cn->median_ref_bq;
+            e.ref_code = (uint8_t)((rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : 3);
+            e.pad_ = 0;
+            e.pad2_ = 0;
+            W.entries[pos] = e;
         }
-        W.tested_prefix[base + i] = (int32_t)ex.t;     /* inclusive */
+        W.tested_prefix[c] = (int32_t)ex.t;            /* inclusive */
     }
 }
 
@@ -448,8 +468,10 @@ int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d
     return LFQ_OK;
 }
 
-int lfq_launch_scan(int64_t ncols, const uint8_t *d_flags, const LfqWork &w, void *stream)
+int lfq_launch_scan(const LfqTracksDev &t, const uint8_t *d_flags, const lfq_col_counts *d_counts,
+                    const LfqWork &w, void *stream)
 {
+    const int64_t ncols = t.ncols;
     if (ncols <= 0) {
         return LFQ_OK;
     }
@@ -460,7 +482,7 @@ int lfq_launch_scan(int64_t ncols, const uint8_t *d_flags, const LfqWork &w, voi
     hipLaunchKernelGGL(lfq_scan_sums_kernel, dim3(1), dim3(LFQ_SCAN_THREADS), 0, (hipStream_t)stream, ntiles,
                        tile_sums, w.counters);
     hipLaunchKernelGGL(lfq_scan_apply_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
-                       (hipStream_t)stream, ncols, d_flags, (const LfqTriple *)tile_sums, w);
+                       (hipStream_t)stream, t, d_flags, d_counts, (const LfqTriple *)tile_sums, w);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }
