@@ -339,7 +339,7 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
         n_big_blocks = (int)std::max<int64_t>(8, budget / per_block);
     }
     LFQ_TRY(grow(&c->d_scratch, &c->scratch_doubles, per_block * n_big_blocks));
-    const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 32, std::max<int64_t>(tr->ncols, 4));
+    const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 28, std::max<int64_t>(tr->ncols / 8, 4));
     const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(tr->ncols, 4));
 
     /* fork: big and mid columns on side streams, light columns on the main stream */
@@ -393,6 +393,16 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
     if (c->h_counters[LFQ_CNT_OVERFLOW]) {
         return LFQ_ERR_CAPACITY;
     }
+    return LFQ_OK;
+}
+
+/* profiling aid (not part of the public header): raw device counters of the last batch */
+int lfq_debug_counters(lfq_ctx *c, int32_t *out16)
+{
+    if (!c || !out16) {
+        return LFQ_ERR_INVALID;
+    }
+    memcpy(out16, c->h_counters, LFQ_NCOUNTERS * sizeof(int32_t));
     return LFQ_OK;
 }
 
@@ -466,7 +476,13 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
     LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
     LFQ_TRY(lfq_snv_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
     lfq_batch_stats st;
+#ifdef LFQ_TRACE
+    fprintf(stderr, "[lfq] launched, waiting\n");
+#endif
     LFQ_TRY(lfq_batch_finish(c, &st));
+#ifdef LFQ_TRACE
+    fprintf(stderr, "[lfq] finished: tested %ld pvals %ld\n", (long)st.n_tested, (long)st.n_pvals);
+#endif
 
     std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
     if (st.n_pvals > 0) {
@@ -492,8 +508,14 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         }
         ref_host = h_ref.data();
     }
+#ifdef LFQ_TRACE
+    fprintf(stderr, "[lfq] finalizing\n");
+#endif
     int rc = lfq_finalize_pvals(conf, h_pv.data(), st.n_pvals, nullptr, ref_host, records, records_capacity,
                                 n_records);
+#ifdef LFQ_TRACE
+    fprintf(stderr, "[lfq] finalized rc=%d n=%ld\n", rc, (long)*n_records);
+#endif
     /* Bonferroni bookkeeping of the per-column loop (lofreq_call.c:794-801) */
     if (st.n_tested > 0) {
         if (conf->bonf_dynamic) {

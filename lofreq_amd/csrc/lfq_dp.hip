@@ -551,17 +551,126 @@ __device__ void lfq_emit_linear(const LfqColCtx &cx, const lfq_col_counts &cnt, 
 /* wave-per-column kernel: light (K < 64, C = 1) and mid (64 <= K < 505, C = 8) columns          */
 /* ------------------------------------------------------------------------------------------ */
 
-template <int C>
+/* Claim `n` consecutive work-list slots for this wavefront: one returning device-scope atomic from
+ * lane 0, result broadcast.  Written as inline asm on purpose: with ROCm 7.2's hipcc the plain
+ * `if (lane == 0) atomicAdd(head, 1)` form in this loop (next to the sparse-output atomicAdd) produced a
+ * kernel that never terminated; adding 2, or issuing the atomic from all lanes, did not. */
+__device__ __forceinline__ int lfq_claim(int32_t *head, int n)
+{
+    int old = 0;
+    if (lfq_lane() == 0) {
+        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(old)
+                     : "v"(head), "v"(n)
+                     : "memory");
+    }
+    return __builtin_amdgcn_readfirstlane(old);
+}
+
+/* what the column pipeline wants loaded while this column computes */
+struct LfqPrefetch {
+    bool want_raw, want_entry;
+    uint64_t off0;
+    int64_t n_obs;
+    const LfqEntry *entry_ptr;
+    LfqRaw *raw;
+    LfqEntry *entry;
+};
+
+/* one column on one wavefront: C cells per lane, single strip ((K + C) / C <= 64) */
+template <int C, bool PREFETCH>
+__device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw, const LfqTracksDev &T,
+                                                const LfqParams &P, const LfqLuts *L, LfqRow *rows,
+                                                const lfq_col_counts *__restrict__ counts, const LfqWork &W,
+                                                lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity,
+                                                const LfqPrefetch &pf)
+{
+    const int lane = lfq_lane();
+    const int K = cx.K;
+    const int shift = (C - K % C) % C;
+    const int lt = (K + shift) / C;             /* lane that owns the tail cell (<= 63 by class) */
+    const double tflag = (lane == lt) ? 1.0 : 0.0;
+    LfqStrip<C> S;
+    lfq_strip_init<C>(S, true, shift);
+    const int64_t n_chunks = (cx.n_obs + 63) / 64;
+    bool pruned = false;
+    int n_rows = 0;
+#ifdef LFQ_PROFILE
+    long long t_stage = 0, t_rows = 0, t_load = 0;
+#endif
+    for (int64_t ch = 0; ch < n_chunks; ch++) {
+#ifdef LFQ_PROFILE
+        const long long c0 = clock64();
+#endif
+        const uint64_t km = lfq_stage_rows(cx, raw, P, L, rows);
+#ifdef LFQ_PROFILE
+        const long long c1 = clock64();
+        t_stage += c1 - c0;
+#endif
+        if (ch == 0) {
+            /* next column's first chunk and the record of the column after it */
+            if (pf.want_raw) {
+                *pf.raw = lfq_load_chunk_at(pf.off0, pf.n_obs, 0, T);
+            }
+            if (pf.want_entry) {
+                *pf.entry = lfq_load_entry(pf.entry_ptr, 0);
+            }
+        }
+        /* the next chunk's loads are issued AFTER this chunk has been consumed into LDS and BEFORE its
+         * rows run: exactly one batch of loads is in flight, and it lands while the recurrence computes */
+        if (PREFETCH && ch + 1 < n_chunks) {
+            raw = lfq_load_chunk(cx, ch + 1, T);
+        }
+#ifdef LFQ_PROFILE
+        const long long c2 = clock64();
+        t_load += c2 - c1;
+#endif
+        const bool hit = lfq_strip_chunk<C>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
+                                            true, lt, cx.bonf_d, cx.sig_s);
+#ifdef LFQ_PROFILE
+        t_rows += clock64() - c2;
+#endif
+        n_rows += __popcll(S.rows >= 64 ? km : (km & ((1ull << S.rows) - 1ull)));
+        if (hit) {
+            pruned = true;
+            break;
+        }
+        if (!PREFETCH && ch + 1 < n_chunks) {
+            raw = lfq_load_chunk(cx, ch + 1, T);
+        }
+    }
+#ifdef LFQ_PROFILE
+    if (lane == 0) {
+        atomicAdd(&W.counters[8], (int)(t_stage >> 8));
+        atomicAdd(&W.counters[9], (int)(t_load >> 8));
+        atomicAdd(&W.counters[10], (int)(t_rows >> 8));
+        atomicAdd(&W.counters[11], n_rows);
+    }
+#endif
+#ifdef LFQ_TRACE
+    if (lane == 0) printf("col %d K %d C %d: rows done pruned=%d n_rows=%d\n", cx.col, K, C, (int)pruned, n_rows);
+#endif
+    if (!pruned && !lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
+#ifdef LFQ_TRACE
+        if (lane == 0) printf("col %d: emitting\n", cx.col);
+#endif
+        const lfq_col_counts cnt = counts[cx.col];
+        S.rows = n_rows;
+        lfq_emit_linear<C>(cx, cnt, S, shift, lt, W, pvals, pvals_capacity);
+    }
+}
+
+template <int MAXC>
 __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqParams P,
                                                           const LfqLuts *__restrict__ g_luts,
                                                           const lfq_col_counts *__restrict__ counts, LfqWork W,
                                                           int base_idx, int count_idx,
                                                           lfq_col_pvals *__restrict__ pvals,
-                                                          int64_t pvals_capacity, int n_waves)
+                                                          int64_t pvals_capacity, int batch)
 {
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
-    if (C > 1) {
+    if (MAXC > 1) {
         /* few, long, latency-bound columns sharing SIMDs with the throughput-bound light kernel:
          * win the issue arbitration (MI355X_MICROARCH "two waves per SIMD", item 2) */
         __builtin_amdgcn_s_setprio(3);
@@ -582,73 +691,59 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
     const LfqEntry *list = W.entries + ((base_idx >= 0) ? W.counters[base_idx] : 0);
     LfqRow *rows = s_rows[wave];
 
-    /* software pipeline over columns: while column i runs its recurrence, the record of column i+2 and
-     * the first chunk of column i+1 are already in flight */
-    int w = wave_id;
-    if (w >= n_work) {
-        return;
-    }
-    LfqEntry en = lfq_load_entry(list, w);
-    LfqRaw raw = lfq_load_chunk_at(en.off0, en.n_obs, 0, T);
-    LfqEntry en_next = en;
-    bool have_next = (w + n_waves) < n_work;
-    if (have_next) {
-        en_next = lfq_load_entry(list, w + n_waves);
-    }
+    /* Dynamic distribution: a wavefront claims BATCH consecutive work-list records at a time (so the
+     * kernel's duration does not depend on how many of its wavefronts are resident), and inside a batch
+     * runs a software pipeline over columns: while column i computes, the first chunk of column i+1 and
+     * the record of column i+2 are in flight. */
+    const int BATCH = batch;            /* run-time on purpose, see lfq_claim */
+    int32_t *head = &W.counters[(MAXC == 1) ? LFQ_CNT_HEAD_LIGHT : LFQ_CNT_HEAD_MID];
     for (;;) {
-        LfqRaw raw_next = raw;
-        LfqEntry en_next2 = en_next;
-        const bool have_next2 = have_next && (w + 2 * n_waves) < n_work;
-        if (have_next) {
-            raw_next = lfq_load_chunk_at(en_next.off0, en_next.n_obs, 0, T);
-        }
-        if (have_next2) {
-            en_next2 = lfq_load_entry(list, w + 2 * n_waves);
-        }
-
-        LfqColCtx cx;
-        lfq_col_setup(cx, en, P);
-        const int K = cx.K;
-        const int shift = (C - K % C) % C;
-        const int lt = (K + shift) / C;             /* lane that owns the tail cell (<= 63 by class) */
-        const double tflag = (lane == lt) ? 1.0 : 0.0;
-        LfqStrip<C> S;
-        lfq_strip_init<C>(S, true, shift);
-        const int64_t n_chunks = (cx.n_obs + 63) / 64;
-        bool pruned = false;
-        int n_rows = 0;
-        for (int64_t ch = 0; ch < n_chunks; ch++) {
-            LfqRaw nxt = raw;
-            if (C > 1 && ch + 1 < n_chunks) {
-                nxt = lfq_load_chunk(cx, ch + 1, T);      /* long columns: hide the next chunk's latency */
-            }
-            const uint64_t km = lfq_stage_rows(cx, raw, P, &s_luts, rows);
-            const bool hit = lfq_strip_chunk<C>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
-                                                true, lt, cx.bonf_d, cx.sig_s);
-            n_rows += __popcll(S.rows >= 64 ? km : (km & ((1ull << S.rows) - 1ull)));
-            if (hit) {
-                pruned = true;
-                break;
-            }
-            if (C > 1) {
-                raw = nxt;
-            } else if (ch + 1 < n_chunks) {
-                raw = lfq_load_chunk(cx, ch + 1, T);
-            }
-        }
-        if (!pruned && !lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
-            const lfq_col_counts cnt = counts[cx.col];
-            S.rows = n_rows;
-            lfq_emit_linear<C>(cx, cnt, S, shift, lt, W, pvals, pvals_capacity);
-        }
-        if (!have_next) {
+        int b0 = lfq_claim(head, BATCH);
+#ifdef LFQ_TRACE
+        if (lane == 0 && (b0 < n_work + 3)) printf("wave %d MAXC %d claimed %d of %d\n", wave_id, MAXC, b0, n_work);
+#endif
+        if (b0 >= n_work) {
             break;
         }
-        w += n_waves;
-        en = en_next;
-        raw = raw_next;
-        en_next = en_next2;
-        have_next = have_next2;
+        const int b1 = min(b0 + BATCH, n_work);
+        int w = b0;
+        LfqEntry en = lfq_load_entry(list, w);
+        LfqRaw raw = lfq_load_chunk_at(en.off0, en.n_obs, 0, T);
+        LfqEntry en_next = en;
+        bool have_next = (w + 1) < b1;
+        if (have_next) {
+            en_next = lfq_load_entry(list, w + 1);
+        }
+        for (;;) {
+            LfqColCtx cx;
+            lfq_col_setup(cx, en, P);
+            LfqRaw raw_next = raw;
+            LfqEntry en_next2 = en_next;
+            const bool have_next2 = have_next && (w + 2) < b1;
+            LfqPrefetch pf;
+            pf.want_raw = have_next;
+            pf.off0 = en_next.off0;
+            pf.n_obs = en_next.n_obs;
+            pf.want_entry = have_next2;
+            pf.entry_ptr = list + (have_next2 ? (w + 2) : w);
+            pf.raw = &raw_next;
+            pf.entry = &en_next2;
+            if (MAXC == 1 || cx.K < 64) {
+                lfq_wave_column<1, (MAXC > 1)>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
+            } else {
+                /* (more cells-per-lane variants were measured -- C = 2 and 4 are ~30 % faster per row for
+                 * K < 250 -- but four inlined variants push this kernel into SGPR spilling) */
+                lfq_wave_column<8, true>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
+            }
+            if (!have_next) {
+                break;
+            }
+            w += 1;
+            en = en_next;
+            raw = raw_next;
+            en_next = en_next2;
+            have_next = have_next2;
+        }
     }
 }
 
@@ -656,25 +751,131 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
 /* big columns: K >= 505, one 8-wave workgroup per column                                     */
 /* ------------------------------------------------------------------------------------------ */
 
+struct LfqBigShared {
+    LfqLuts luts;
+    LfqRow rows[LFQ_HEAVY_WAVES][64];
+    double bv[2][LFQ_HEAVY_WAVES][64];      /* strip boundary slabs, double-buffered across steps */
+    int be[2][LFQ_HEAVY_WAVES][64];
+    double gv[LFQ_HEAVY_WAVES][64];         /* pass boundary staged from global scratch */
+    int ge[LFQ_HEAVY_WAVES][64];
+    double mu[LFQ_HEAVY_WAVES];
+    int col, pruned;
+};
+
+/* the strip pipeline of one big column with C cells per lane (C chosen so that the strips fit the
+ * workgroup's wavefronts in one pass whenever possible: fewer cells per lane = shorter rows) */
+template <int C>
+__device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_counts &cnt, int kp, unsigned uf_mask,
+                                               const double *uf_bound, bool force_fe, double *bnd,
+                                               const LfqTracksDev &T, const LfqParams &P, LfqBigShared &sh,
+                                               const LfqWork &W, lfq_col_pvals *__restrict__ pvals,
+                                               int64_t pvals_capacity)
+{
+    constexpr int NW = LFQ_HEAVY_WAVES;
+    const int lane = lfq_lane();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_chunks = (cx.n_obs + 63) / 64;
+    const int K = kp;
+    const int shift = (C - K % C) % C;
+    const int Lt = (K + shift) / C;            /* global lane owning the tail cell at j = 0 */
+    const int n_strips = Lt / 64 + 1;
+    const int lt = Lt % 64;
+    double *probvec = bnd + 2 * cx.n_obs + 2;
+    bool pruned = false;
+    int rows_tail = 0;
+
+    for (int s0 = 0; s0 < n_strips && !pruned; s0 += NW) {
+        const int nwp = min(NW, n_strips - s0);       /* strips in this pass */
+        const int s = s0 + w;
+        const bool active = w < nwp;
+        const int gl = s * 64 + lane;
+        const double tflag = (gl == Lt) ? 1.0 : 0.0;
+        const bool owns_tail = active && (s == n_strips - 1);
+        const bool has_in = (s > 0);
+        const bool in_global = has_in && (w == 0);    /* first strip of a later pass */
+        const bool has_out = active && (s < n_strips - 1);
+        const bool out_global = has_out && (w == nwp - 1);
+        LfqStrip<C> S;
+        lfq_strip_init<C>(S, s == 0, shift);
+
+        const int64_t n_steps = n_chunks + nwp - 1;
+        LfqRaw raw = lfq_load_chunk(cx, 0, T);
+        for (int64_t t = 0; t < n_steps; t++) {
+            const int64_t ch = t - w;
+            if (active && ch >= 0 && ch < n_chunks) {
+                const int64_t idx = ch * 64 + lane;
+                const double *in_v = nullptr;
+                const int *in_e = nullptr;
+                if (has_in) {
+                    if (in_global) {
+                        sh.gv[w][lane] = (idx < cx.n_obs) ? bnd[2 * idx] : 0.0;
+                        sh.ge[w][lane] = (idx < cx.n_obs) ? (int)bnd[2 * idx + 1] : 0;
+                        in_v = sh.gv[w];
+                        in_e = sh.ge[w];
+                    } else {
+                        in_v = sh.bv[(t - 1) & 1][w - 1];
+                        in_e = sh.be[(t - 1) & 1][w - 1];
+                    }
+                }
+                const uint64_t km = lfq_stage_rows(cx, raw, P, &sh.luts, sh.rows[w]);
+                if (ch + 1 < n_chunks) {
+                    raw = lfq_load_chunk(cx, ch + 1, T);   /* lands while this step's rows run */
+                }
+                if (lfq_strip_chunk<C>(S, sh.rows[w], km, has_in, in_v, in_e, has_out, sh.bv[t & 1][w],
+                                       sh.be[t & 1][w], tflag, owns_tail, lt, cx.bonf_d, cx.sig_s)) {
+                    sh.pruned = 1;
+                }
+                rows_tail += __popcll(km);
+                if (out_global) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (idx < cx.n_obs) {
+                        bnd[2 * idx] = sh.bv[t & 1][w][lane];
+                        bnd[2 * idx + 1] = (double)sh.be[t & 1][w][lane];
+                    }
+                }
+            }
+            __syncthreads();
+            if (sh.pruned) {
+                pruned = true;
+                break;
+            }
+        }
+        if (!pruned && owns_tail) {
+            if (lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
+                sh.pruned = 1;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (sh.pruned) {
+            pruned = true;
+        }
+        if (!pruned && active) {
+            lfq_strip_store_logs<C>(S, gl, shift, K, probvec);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
+        /* the wave that owned the tail strip finishes the column */
+        lfq_emit_pvals(cx, cnt, probvec, K, !pruned, uf_mask, uf_bound, force_fe, rows_tail, W, pvals,
+                       pvals_capacity);
+    }
+}
+
 __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
     LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
     LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity, double *__restrict__ scratch,
     int64_t scratch_per_block)
 {
-    constexpr int C = LFQ_HEAVY_C;
     constexpr int NW = LFQ_HEAVY_WAVES;
-    __shared__ LfqLuts s_luts;
-    __shared__ LfqRow s_rows[NW][64];
-    __shared__ double s_bv[2][NW][64];      /* strip boundary slabs, double-buffered across steps */
-    __shared__ int s_be[2][NW][64];
-    __shared__ double s_gv[NW][64];         /* pass boundary staged from global scratch */
-    __shared__ int s_ge[NW][64];
-    __shared__ int s_col, s_pruned;
-    __shared__ double s_mu[NW];
+    __shared__ LfqBigShared sh;
     __builtin_amdgcn_s_setprio(3);
     {
         const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
+        double *dst = reinterpret_cast<double *>(&sh.luts);
         for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
             dst[i] = src[i];
         }
@@ -687,11 +888,11 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            s_col = atomicAdd(&W.counters[LFQ_CNT_HEAD], 1);
-            s_pruned = 0;
+            sh.col = atomicAdd(&W.counters[LFQ_CNT_HEAD], 1);
+            sh.pruned = 0;
         }
         __syncthreads();
-        const int h = s_col;
+        const int h = sh.col;
         if (h >= n_big) {
             break;
         }
@@ -711,7 +912,7 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
         double part = 0.0;
         for (int64_t ch = w; ch < n_chunks; ch += NW) {
             double ps, qf;
-            const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &s_luts, &ps, &qf);
+            const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &sh.luts, &ps, &qf);
             part += ((km >> lane) & 1ull) ? ps : 0.0;
         }
 #pragma unroll
@@ -719,12 +920,12 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
             part += __shfl_xor(part, d, 64);
         }
         if (lane == 0) {
-            s_mu[w] = part;
+            sh.mu[w] = part;
         }
         __syncthreads();
         double mu = 0.0;
         for (int i = 0; i < NW; i++) {
-            mu += s_mu[i];
+            mu += sh.mu[i];
         }
         const double lmu = log(mu);
         unsigned uf_mask = 0;
@@ -752,94 +953,10 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
             }
             continue;
         }
-        const int K = kp;
-        const int shift = (C - K % C) % C;
-        const int Lt = (K + shift) / C;            /* global lane owning the tail cell at j = 0 */
-        const int n_strips = Lt / 64 + 1;
-        const int lt = Lt % 64;
-        double *probvec = bnd + 2 * cx.n_obs + 2;
-        bool pruned = false;
-        int rows_tail = 0;
-
-        for (int s0 = 0; s0 < n_strips && !pruned; s0 += NW) {
-            const int nwp = min(NW, n_strips - s0);       /* strips in this pass */
-            const int s = s0 + w;
-            const bool active = w < nwp;
-            const int gl = s * 64 + lane;
-            const double tflag = (gl == Lt) ? 1.0 : 0.0;
-            const bool owns_tail = active && (s == n_strips - 1);
-            const bool has_in = (s > 0);
-            const bool in_global = has_in && (w == 0);    /* first strip of a later pass */
-            const bool has_out = active && (s < n_strips - 1);
-            const bool out_global = has_out && (w == nwp - 1);
-            LfqStrip<C> S;
-            lfq_strip_init<C>(S, s == 0, shift);
-
-            const int64_t n_steps = n_chunks + nwp - 1;
-            LfqRaw raw = lfq_load_chunk(cx, 0, T);
-            for (int64_t t = 0; t < n_steps; t++) {
-                const int64_t ch = t - w;
-                if (active && ch >= 0 && ch < n_chunks) {
-                    const LfqRaw cur = raw;
-                    if (ch + 1 < n_chunks) {
-                        raw = lfq_load_chunk(cx, ch + 1, T);   /* in flight across this step's rows */
-                    }
-                    const int64_t idx = ch * 64 + lane;
-                    const double *in_v = nullptr;
-                    const int *in_e = nullptr;
-                    if (has_in) {
-                        if (in_global) {
-                            s_gv[w][lane] = (idx < cx.n_obs) ? bnd[2 * idx] : 0.0;
-                            s_ge[w][lane] = (idx < cx.n_obs) ? (int)bnd[2 * idx + 1] : 0;
-                            in_v = s_gv[w];
-                            in_e = s_ge[w];
-                        } else {
-                            in_v = s_bv[(t - 1) & 1][w - 1];
-                            in_e = s_be[(t - 1) & 1][w - 1];
-                        }
-                    }
-                    const uint64_t km = lfq_stage_rows(cx, cur, P, &s_luts, s_rows[w]);
-                    if (lfq_strip_chunk<C>(S, s_rows[w], km, has_in, in_v, in_e, has_out, s_bv[t & 1][w],
-                                           s_be[t & 1][w], tflag, owns_tail, lt, cx.bonf_d, cx.sig_s)) {
-                        s_pruned = 1;
-                    }
-                    rows_tail += __popcll(km);
-                    if (out_global) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (idx < cx.n_obs) {
-                            bnd[2 * idx] = s_bv[t & 1][w][lane];
-                            bnd[2 * idx + 1] = (double)s_be[t & 1][w][lane];
-                        }
-                    }
-                }
-                __syncthreads();
-                if (s_pruned) {
-                    pruned = true;
-                    break;
-                }
-            }
-            if (!pruned && owns_tail) {
-                if (lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
-                    s_pruned = 1;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-            if (s_pruned) {
-                pruned = true;
-            }
-            if (!pruned && active) {
-                lfq_strip_store_logs<C>(S, gl, shift, K, probvec);
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-        if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
-            /* the wave that owned the tail strip finishes the column */
-            lfq_emit_pvals(cx, cnt, probvec, K, !pruned, uf_mask, uf_bound, force_fe, rows_tail, W, pvals,
-                           pvals_capacity);
+        if (kp < 128 * NW - 1) {
+            lfq_big_column<2>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
+        } else {
+            lfq_big_column<8>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
         }
     }
 }
@@ -857,8 +974,7 @@ int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
     hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                       d_counts, w, -1, LFQ_CNT_LIGHT, d_pvals, pvals_capacity,
-                       (int)(blocks * 4));
+                       d_counts, w, -1, LFQ_CNT_LIGHT, d_pvals, pvals_capacity, 32);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 
@@ -871,8 +987,7 @@ int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
     hipLaunchKernelGGL(lfq_dp_wave_kernel<LFQ_HEAVY_C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,
-                       d_luts, d_counts, w, LFQ_CNT_LIGHT, LFQ_CNT_MID, d_pvals, pvals_capacity,
-                       (int)(blocks * 4));
+                       d_luts, d_counts, w, LFQ_CNT_LIGHT, LFQ_CNT_MID, d_pvals, pvals_capacity, 1);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 

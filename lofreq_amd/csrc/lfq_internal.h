@@ -78,6 +78,8 @@ struct LfqWork {
 #define LFQ_CNT_PVALS 5
 #define LFQ_CNT_OVERFLOW 6
 #define LFQ_CNT_MAXDEPTH 7
+#define LFQ_CNT_HEAD_LIGHT 12  /* dynamic work distribution of the wave-per-column kernels */
+#define LFQ_CNT_HEAD_MID 13
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
 int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,

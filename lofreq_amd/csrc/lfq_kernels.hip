@@ -35,13 +35,6 @@
 /* count kernel                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 
-__device__ __forceinline__ uint32_t lfq_eq4(uint32_t code4, uint32_t x4)
-{
-    /* 0x80 in every byte where code == x (all bytes < 0x80) */
-    const uint32_t t = code4 ^ x4;
-    return ((t + 0x7F7F7F7Fu) & 0x80808080u) ^ 0x80808080u;
-}
-
 __device__ __forceinline__ uint32_t lfq_bytes_mask(int lo, int hi, int d)
 {
     /* 0x80 for bytes [lo,hi) of the 16-byte chunk that fall into dword d */
@@ -53,25 +46,85 @@ __device__ __forceinline__ uint32_t lfq_bytes_mask(int lo, int hi, int d)
     return below_h & ~below_l & 0x80808080u;
 }
 
+/* Per-lane partial counts as bit-plane popcounts.  With the nt4 code bits b0,b1 (b2 set = N) of the
+ * observations that are in range and not N ("valid"):
+ *     n[0] = #valid, n[1] = #(b0), n[2] = #(b1), n[3] = #(b0 & b1)
+ * so that  #T = n3, #C = n1 - n3, #G = n2 - n3, #A = n0 - n1 - n2 + n3.  The same four planes are
+ * counted again restricted to forward-strand reads (fw), to bq >= min_bq (ge) and, when the alt
+ * threshold differs, to bq >= max(min_bq, min_alt_bq) (ga). */
 struct LfqAcc {
-    uint32_t raw[4], fw[4], filt[4];
+    uint32_t raw[4], fw[4], ge[4], ga[4];
 };
 
+template <bool SAME_THR>
 __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_t bqw, uint32_t vm,
-                                                uint32_t minbq4, uint32_t minalt4, int ref_code)
+                                                uint32_t minbq4, uint32_t minalt4)
 {
-    const uint32_t code = ntw & 0x07070707u;
-    const uint32_t fwd = ~(ntw << 4);                             /* bit 7 set where forward strand */
+    /* everything lives in bit 7 of each byte; shifted words are "dirty" outside bit 7 and only ever
+     * ANDed with clean masks */
+    const uint32_t s0 = ntw << 7, s1 = ntw << 6, s2 = ntw << 5, s3 = ntw << 4;
+    const uint32_t p0 = vm & ~s2;                  /* valid: in range and not N */
+    const uint32_t p1 = p0 & s0;
+    const uint32_t p2 = p0 & s1;
+    const uint32_t p3 = p1 & s1;
+    a.raw[0] += __popc(p0);
+    a.raw[1] += __popc(p1);
+    a.raw[2] += __popc(p2);
+    a.raw[3] += __popc(p3);
+    a.fw[0] += __popc(p0 & ~s3);
+    a.fw[1] += __popc(p1 & ~s3);
+    a.fw[2] += __popc(p2 & ~s3);
+    a.fw[3] += __popc(p3 & ~s3);
     const uint32_t hi = bqw | 0x80808080u;
-    const uint32_t ge_min = (hi - minbq4) & vm;                   /* bit 7: bq >= min_bq */
-    const uint32_t ge_alt = (hi - minalt4) & ge_min;              /* ... and >= min_alt_bq */
-#pragma unroll
-    for (int x = 0; x < 4; x++) {
-        const uint32_t eq = lfq_eq4(code, 0x01010101u * (uint32_t)x) & vm;
-        a.raw[x] += __popc(eq);
-        a.fw[x] += __popc(eq & fwd);
-        a.filt[x] += __popc(eq & ((x == ref_code) ? ge_min : ge_alt));
+    const uint32_t g = hi - minbq4;                /* bit 7: bq >= min_bq (bq < 128) */
+    a.ge[0] += __popc(p0 & g);
+    a.ge[1] += __popc(p1 & g);
+    a.ge[2] += __popc(p2 & g);
+    a.ge[3] += __popc(p3 & g);
+    if (!SAME_THR) {
+        const uint32_t g2 = (hi - minalt4) & g;    /* ... and >= min_alt_bq */
+        a.ga[0] += __popc(p0 & g2);
+        a.ga[1] += __popc(p1 & g2);
+        a.ga[2] += __popc(p2 & g2);
+        a.ga[3] += __popc(p3 & g2);
     }
+}
+
+template <bool SAME_THR>
+__device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &T, uint64_t off0, uint64_t off1,
+                                                 uint32_t minbq4, uint32_t minalt4)
+{
+    const int lane = lfq_lane();
+    const uint4 *nt16 = reinterpret_cast<const uint4 *>(T.nt);
+    const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq);
+    const int64_t c0 = (int64_t)(off0 >> 4), c1 = (int64_t)((off1 + 15) >> 4);
+    for (int64_t ch = c0 + lane; ch < c1; ch += LFQ_WAVE) {
+        const uint4 n4 = nt16[ch];
+        const uint4 b4 = bq16[ch];
+        const int64_t base = ch << 4;
+        const int lo = (int64_t)off0 > base ? (int)((int64_t)off0 - base) : 0;
+        const int hi = (int64_t)off1 < base + 16 ? (int)((int64_t)off1 - base) : 16;
+        if (lo == 0 && hi == 16) {
+            lfq_count_dword<SAME_THR>(a, n4.x, b4.x, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR>(a, n4.y, b4.y, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR>(a, n4.z, b4.z, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR>(a, n4.w, b4.w, 0x80808080u, minbq4, minalt4);
+        } else {
+            lfq_count_dword<SAME_THR>(a, n4.x, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
+            lfq_count_dword<SAME_THR>(a, n4.y, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
+            lfq_count_dword<SAME_THR>(a, n4.z, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
+            lfq_count_dword<SAME_THR>(a, n4.w, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
+        }
+    }
+}
+
+/* bit-plane counts -> per-nucleotide counts (A,C,G,T) */
+__device__ __forceinline__ void lfq_planes_to_classes(const uint32_t n[4], uint32_t c[4])
+{
+    c[3] = n[3];
+    c[1] = n[1] - n[3];
+    c[2] = n[2] - n[3];
+    c[0] = n[0] - n[1] - n[2] + n[3];
 }
 
 __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
@@ -111,33 +164,20 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
     LfqAcc a;
 #pragma unroll
     for (int x = 0; x < 4; x++) {
-        a.raw[x] = a.fw[x] = a.filt[x] = 0;
+        a.raw[x] = a.fw[x] = a.ge[x] = a.ga[x] = 0;
     }
+    /* general path accumulates per-class counts directly */
+    uint32_t g_raw[4] = {0, 0, 0, 0}, g_fw[4] = {0, 0, 0, 0}, g_filt[4] = {0, 0, 0, 0};
+    const bool same_thr = (P.min_alt_bq4 == P.min_bq4);
 
     if (!r.gated && !P.general) {
         /* fast path: only the nt and bq tracks decide the counts */
         const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
         const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
-        const uint4 *nt16 = reinterpret_cast<const uint4 *>(T.nt);
-        const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq);
-        const int64_t c0 = (int64_t)(off0 >> 4), c1 = (int64_t)((off1 + 15) >> 4);
-        for (int64_t ch = c0 + lane; ch < c1; ch += LFQ_WAVE) {
-            const uint4 n4 = nt16[ch];
-            const uint4 b4 = bq16[ch];
-            const int64_t base = ch << 4;
-            const int lo = (int64_t)off0 > base ? (int)((int64_t)off0 - base) : 0;
-            const int hi = (int64_t)off1 < base + 16 ? (int)((int64_t)off1 - base) : 16;
-            if (lo == 0 && hi == 16) {
-                lfq_count_dword(a, n4.x, b4.x, 0x80808080u, minbq4, minalt4, ref_code);
-                lfq_count_dword(a, n4.y, b4.y, 0x80808080u, minbq4, minalt4, ref_code);
-                lfq_count_dword(a, n4.z, b4.z, 0x80808080u, minbq4, minalt4, ref_code);
-                lfq_count_dword(a, n4.w, b4.w, 0x80808080u, minbq4, minalt4, ref_code);
-            } else {
-                lfq_count_dword(a, n4.x, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4, ref_code);
-                lfq_count_dword(a, n4.y, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4, ref_code);
-                lfq_count_dword(a, n4.z, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4, ref_code);
-                lfq_count_dword(a, n4.w, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4, ref_code);
-            }
+        if (same_thr) {
+            lfq_count_chunks<true>(a, T, off0, off1, minbq4, minalt4);
+        } else {
+            lfq_count_chunks<false>(a, T, off0, off1, minbq4, minalt4);
         }
     } else if (!r.gated) {
         /* general path: merged-quality filters and/or the median-of-reference-BQ override
@@ -183,18 +223,40 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             const LfqObs o = lfq_eval_obs(ntb, T.bq[off0 + i], T.baq ? T.baq[off0 + i] : 255u,
                                           T.mq[off0 + i], T.sq ? T.sq[off0 + i] : 255u, ref_code, median,
                                           P, luts);
-            a.raw[code] += 1;
-            a.fw[code] += (ntb & 8u) ? 0u : 1u;
-            a.filt[code] += o.keep ? 1u : 0u;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                g_raw[x] += (code == (uint32_t)x) ? 1u : 0u;
+                g_fw[x] += (code == (uint32_t)x && !(ntb & 8u)) ? 1u : 0u;
+                g_filt[x] += (code == (uint32_t)x && o.keep) ? 1u : 0u;
+            }
         }
     }
 
     uint32_t raw[4], fw[4], filt[4];
+    if (!P.general) {
+        uint32_t n_raw[4], n_fw[4], n_ge[4], n_ga[4], c_ge[4], c_ga[4];
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
-        raw[x] = lfq_wave_sum_u32(a.raw[x]);
-        fw[x] = lfq_wave_sum_u32(a.fw[x]);
-        filt[x] = lfq_wave_sum_u32(a.filt[x]);
+        for (int x = 0; x < 4; x++) {
+            n_raw[x] = lfq_wave_sum_u32(a.raw[x]);
+            n_fw[x] = lfq_wave_sum_u32(a.fw[x]);
+            n_ge[x] = lfq_wave_sum_u32(a.ge[x]);
+            n_ga[x] = same_thr ? n_ge[x] : lfq_wave_sum_u32(a.ga[x]);
+        }
+        lfq_planes_to_classes(n_raw, raw);
+        lfq_planes_to_classes(n_fw, fw);
+        lfq_planes_to_classes(n_ge, c_ge);
+        lfq_planes_to_classes(n_ga, c_ga);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];     /* alt bases must pass both thresholds */
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            raw[x] = lfq_wave_sum_u32(g_raw[x]);
+            fw[x] = lfq_wave_sum_u32(g_fw[x]);
+            filt[x] = lfq_wave_sum_u32(g_filt[x]);
+        }
     }
 
     if (lane == 0) {
@@ -221,7 +283,12 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
             r.kmax = kmax;
             r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
-            flag = (uint8_t)((r.tested ? 1 : 0) | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K) ? 2 : 0));
+            /* scheduling class.  Columns whose alt count is far above what sequencing errors explain
+             * (~ n/1000 at Q30) almost surely run the full recurrence: they go to the long-column
+             * kernel even when K < 64, so that the light kernel only sees quick exits. */
+            const int suspicious = max(12, r.n_err_probs / 512 + 8);
+            flag = (uint8_t)((r.tested ? 1 : 0)
+                             | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
         }
         out[col] = r;
         flags[col] = flag;

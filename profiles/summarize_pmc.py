@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc runs (one sqlite db per counter pass) into profiles/*.md and
+profiles/pmc_traffic.json (HBM bytes per launch of each kernel, read by bench.py for roofline.traffic).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
+gfx950 reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read: the count kernel's
+reads are of that kind and are doubled; the other kernels' byte-granular loads are left uncorrected and
+flagged as uncalibrated."""
+import glob
+import json
+import sqlite3
+import sys
+
+
+def counters(db_path):
+    db = sqlite3.connect(db_path)
+    out = {}
+    for name, cname, val, n in db.execute(
+            "select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+            "group by kernel_name, counter_name"):
+        short = name.split("(")[0].replace("void ", "")
+        out.setdefault(short, {})[cname] = (val, n)
+    return out
+
+
+def main(root, tag):
+    allc = {}
+    for path in sorted(glob.glob(root + "/pmc_*/*.db")):
+        for k, d in counters(path).items():
+            allc.setdefault(k, {}).update(d)
+    lines = ["# PMC summary (%s)" % tag, "",
+             "Separate `rocprofv3 --pmc` passes of `bench.py --steps 1 --warmup 0` (C3, 1 MI355X).", "",
+             "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch (corrected) | SQ_INSTS_VALU | "
+             "SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE |", "|---|---|---|---|---|---|---|---|"]
+    traffic = {}
+    for k in sorted(allc):
+        if not k.startswith("lfq_"):
+            continue
+        d = allc[k]
+        f, n = d.get("FETCH_SIZE", (0, 1))
+        w, _ = d.get("WRITE_SIZE", (0, 1))
+        wide = k in ("lfq_count_kernel", "lfq_synth_kernel")
+        byt = ((2.0 if wide else 1.0) * f + w) * 1024.0 / max(n, 1)
+        traffic[k] = byt
+        lines.append("| %s | %d | %.0f | %.0f | %.4g %s | %.4g | %.4g | %.4g |" % (
+            k, n, f, w, byt, "(FETCH x2: wide coalesced reads)" if wide else "(uncalibrated)",
+            d.get("SQ_INSTS_VALU", (0, 1))[0], d.get("SQ_WAVE_CYCLES", (0, 1))[0],
+            d.get("GRBM_GUI_ACTIVE", (0, 1))[0]))
+    text = "\n".join(lines) + "\n"
+    open("profiles/%s_pmc.md" % tag, "w").write(text)
+    # bench.py looks kernels up by the names it uses
+    tj = {"lfq_count_kernel": traffic.get("lfq_count_kernel"),
+          "lfq_dp_wave_kernel<1>": traffic.get("lfq_dp_wave_kernel<1>"),
+          "lfq_dp_wave_kernel<8>": traffic.get("lfq_dp_wave_kernel<8>"),
+          "lfq_dp_big_kernel": traffic.get("lfq_dp_big_kernel")}
+    json.dump(tj, open("profiles/pmc_traffic.json", "w"), indent=1)
+    print(text)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -8,7 +8,7 @@ import pytest
 
 import util
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 
 
 def _compare_records(la, recs, ores, host, tol=util.PV_LOG_TOL):
