@@ -213,8 +213,12 @@ int lfq_synth_fill_device(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t 
 
 /* --- device timing of the last batch (HIP events on the stream the kernels ran on) --- */
 typedef struct lfq_kernel_times {
-    float ms_count, ms_scan, ms_dp, ms_total;   /* ms_dp = scan end -> all three DP kernels done */
-    float ms_dp_light, ms_dp_mid, ms_dp_big;    /* the concurrent DP kernels individually */
+    float ms_count;     /* sum over the batch's segments of the count kernel launches */
+    float ms_scan;      /* sum of the scan (prefix + work-list) kernels */
+    float ms_dp;        /* DP time not hidden under a count kernel: last count kernel end -> all done */
+    float ms_total;     /* first kernel start -> all done */
+    float ms_dp_light, ms_dp_mid, ms_dp_big;    /* sums of the concurrent DP kernels' own durations */
+    int32_t n_segments; /* count-kernel launches in this batch */
 } lfq_kernel_times;
 int lfq_last_kernel_times(lfq_ctx *ctx, lfq_kernel_times *t);
 

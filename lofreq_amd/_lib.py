@@ -46,7 +46,7 @@ class BatchStats(C.Structure):
 class KernelTimes(C.Structure):
     _fields_ = [("ms_count", C.c_float), ("ms_scan", C.c_float), ("ms_dp", C.c_float),
                 ("ms_total", C.c_float), ("ms_dp_light", C.c_float), ("ms_dp_mid", C.c_float),
-                ("ms_dp_big", C.c_float)]
+                ("ms_dp_big", C.c_float), ("n_segments", C.c_int32)]
 
 
 COL_COUNTS_DTYPE = np.dtype([

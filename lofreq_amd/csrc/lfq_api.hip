@@ -44,8 +44,14 @@ struct lfq_ctx {
     uint8_t *d_flags;
     int32_t *d_prefix, *d_counters;
     LfqEntry *d_entries;
-    hipStream_t side[2];       /* mid / big DP kernels run beside the light one */
-    hipEvent_t ev_fork, ev_light_done, ev_join[2], ev_side[2][2];
+    hipStream_t dps;           /* scan + light DP of a segment, beside the next segment's count kernel */
+    hipStream_t side[2];       /* big / mid DP kernels run beside the light one */
+    hipEvent_t ev_cnt[LFQ_MAX_SEGMENTS][2];    /* count kernel of segment s: start, stop (main stream) */
+    hipEvent_t ev_scan[LFQ_MAX_SEGMENTS];      /* work lists of segment s ready (dps) */
+    hipEvent_t ev_light[LFQ_MAX_SEGMENTS][2];  /* light kernel (dps) */
+    hipEvent_t ev_side[2][LFQ_MAX_SEGMENTS][2];/* big / mid kernels (side streams) */
+    hipEvent_t ev_join[3];
+    int cur_segments;
     uint64_t *d_tiles;
     double *d_scratch;
     int64_t scratch_doubles;
@@ -178,7 +184,7 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         cap = 0;
         LFQ_TRY(grow(&c->d_entries, &cap, want));
         cap = 0;
-        LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8)));
+        LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8 * (LFQ_MAX_SEGMENTS + 1))));
         c->ws_cols = want;
     }
     return LFQ_OK;
@@ -213,18 +219,29 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     }
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_counters, LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_counters, LFQ_NCOUNTERS * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    /* counter blocks: one per segment + one batch-wide */
+    ok = ok && hipMalloc((void **)&c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
+                             hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 4; i++) {
         ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     }
-    ok = ok && hipEventCreate(&c->ev_fork) == hipSuccess && hipEventCreate(&c->ev_light_done) == hipSuccess;
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    ok = ok && hipStreamCreateWithPriority(&c->dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
     for (int i = 0; ok && i < 2; i++) {
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
-        ok = ok && hipEventCreate(&c->ev_join[i]) == hipSuccess;
-        ok = ok && hipEventCreate(&c->ev_side[i][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][1]) == hipSuccess;
+    }
+    for (int i = 0; ok && i < 3; i++) {
+        ok = hipEventCreate(&c->ev_join[i]) == hipSuccess;
+    }
+    for (int s = 0; ok && s < LFQ_MAX_SEGMENTS; s++) {
+        ok = hipEventCreate(&c->ev_cnt[s][0]) == hipSuccess && hipEventCreate(&c->ev_cnt[s][1]) == hipSuccess;
+        ok = ok && hipEventCreate(&c->ev_scan[s]) == hipSuccess;
+        ok = ok && hipEventCreate(&c->ev_light[s][0]) == hipSuccess && hipEventCreate(&c->ev_light[s][1]) == hipSuccess;
+        for (int i = 0; ok && i < 2; i++) {
+            ok = hipEventCreate(&c->ev_side[i][s][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][s][1]) == hipSuccess;
+        }
     }
     if (ok) {
         LfqLuts h;
@@ -255,14 +272,20 @@ void lfq_destroy(lfq_ctx *c)
     for (int i = 0; i < 4; i++) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_light_done) (void)hipEventDestroy(c->ev_light_done);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-        if (c->ev_side[i][0]) (void)hipEventDestroy(c->ev_side[i][0]);
-        if (c->ev_side[i][1]) (void)hipEventDestroy(c->ev_side[i][1]);
+    }
+    for (int s = 0; s < LFQ_MAX_SEGMENTS; s++) {
+        hipEvent_t evs[] = {c->ev_cnt[s][0], c->ev_cnt[s][1], c->ev_scan[s], c->ev_light[s][0], c->ev_light[s][1],
+                            c->ev_side[0][s][0], c->ev_side[0][s][1], c->ev_side[1][s][0], c->ev_side[1][s][1]};
+        for (hipEvent_t e : evs) {
+            if (e) (void)hipEventDestroy(e);
+        }
+    }
+    for (int i = 0; i < 2; i++) {
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
     }
+    if (c->dps) (void)hipStreamDestroy(c->dps);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
@@ -307,30 +330,27 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     T.num_bases = tr->num_bases;
     T.ncols = tr->ncols;
 
-    LfqWork W;
-    W.tested_prefix = c->d_prefix;
-    W.entries = c->d_entries;
-    W.counters = c->d_counters;
-    W.block_sums = (int32_t *)c->d_tiles;
-
+    const int64_t ncols = tr->ncols;
+    int32_t *gcounters = c->d_counters + LFQ_MAX_SEGMENTS * LFQ_NCOUNTERS;
     c->cur_stream = st;
     c->cur_pvals_cap = pvals_capacity;
-    c->cur_ncols = tr->ncols;
-    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, LFQ_NCOUNTERS * sizeof(int32_t), st));
+    c->cur_ncols = ncols;
+    c->cur_segments = 0;
+    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
     LFQ_TRY_HIP(hipEventRecord(c->ev[0], st));
-    LFQ_TRY(lfq_launch_count(T, P, c->d_luts, d_counts, c->d_flags, c->d_counters, st));
-    LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));
-    LFQ_TRY(lfq_launch_scan(T, c->d_flags, d_counts, W, st));
-    LFQ_TRY_HIP(hipEventRecord(c->ev[2], st));
+    if (ncols == 0) {
+        LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
+        return LFQ_OK;
+    }
 
-    /* big-column scratch: 2 doubles per observation (pass boundary) + K+1 log-probabilities per
-     * resident workgroup; needs the deepest column of the batch */
+    /* big-column scratch: 2 doubles per observation (pass boundary) + K+1 log-probabilities per resident
+     * workgroup; needs the deepest column of the batch */
     int64_t max_depth = tr->max_col_obs;
-    if (max_depth <= 0 && tr->ncols > 0) {
-        LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, LFQ_NCOUNTERS * sizeof(int32_t),
-                                   hipMemcpyDeviceToHost, st));
+    if (max_depth <= 0) {
+        LFQ_TRY(lfq_launch_maxdepth(T, gcounters, st));
+        LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, gcounters, LFQ_NCOUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         LFQ_TRY_HIP(hipStreamSynchronize(st));
-        max_depth = c->h_counters[LFQ_CNT_MAXDEPTH];
+        max_depth = c->h_counters[LFQ_GC_MAXDEPTH];
     }
     const int64_t per_block = 3 * max_depth + 72;
     int n_big_blocks = c->n_cu;                         /* 8-wave workgroups: one per CU beside the light kernel */
@@ -339,30 +359,66 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
         n_big_blocks = (int)std::max<int64_t>(8, budget / per_block);
     }
     LFQ_TRY(grow(&c->d_scratch, &c->scratch_doubles, per_block * n_big_blocks));
-    const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 28, std::max<int64_t>(tr->ncols / 8, 4));
-    const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(tr->ncols, 4));
 
-    /* fork: big and mid columns on side streams, light columns on the main stream */
-    LFQ_TRY_HIP(hipEventRecord(c->ev_fork, st));
-    for (int i = 0; i < 2; i++) {
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][0], c->side[i]));
+    /* Segments: the count kernel is HBM-bound and leaves the VALUs mostly idle, the DP kernels are
+     * latency/issue-bound and touch little memory.  Cutting the batch into segments lets the DP of
+     * segment s run (on other streams) under the count kernel of segment s+1.  The running Bonferroni
+     * prefix is carried from segment to segment on the device (LFQ_GC_TESTED). */
+    int n_seg = 1;   /* measured on C3: with the current kernels overlapping count and DP loses (both want wave slots
+                      * and VALU issue); kept switchable for experiments via LFQ_SEGMENTS */
+    if (const char *e = getenv("LFQ_SEGMENTS")) {
+        n_seg = std::min(LFQ_MAX_SEGMENTS, std::max(1, atoi(e)));
     }
+    c->cur_segments = n_seg;
     const char *skip = getenv("LFQ_DEBUG_SKIP");   /* profiling aid: run the DP classes in isolation */
-    if (!skip || !strstr(skip, "big")) {
-        LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
-                                  n_big_blocks, c->side[0]));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], st));
+    LFQ_TRY_HIP(hipStreamWaitEvent(c->dps, c->ev_join[2], 0));   /* dps starts after the memset */
+
+    for (int s = 0; s < n_seg; s++) {
+        const int64_t c0 = ncols * s / n_seg, c1 = ncols * (s + 1) / n_seg;
+        LfqWork W;
+        W.tested_prefix = c->d_prefix;
+        W.entries = c->d_entries + c0;
+        W.counters = c->d_counters + s * LFQ_NCOUNTERS;
+        W.gcounters = gcounters;
+        W.block_sums = (int32_t *)(c->d_tiles + 2 * (c0 / 4096 + 8 * s));
+
+        LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
+        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, st));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
+
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->dps, c->ev_cnt[s][1], 0));
+        LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, c->dps));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], c->dps));
+        const int64_t seg_cols = c1 - c0;
+        const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 28, std::max<int64_t>(seg_cols / 8, 4));
+        const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(seg_cols, 4));
+        for (int i = 0; i < 2; i++) {
+            LFQ_TRY_HIP(hipStreamWaitEvent(c->side[i], c->ev_scan[s], 0));
+            LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][0], c->side[i]));
+        }
+        if (!skip || !strstr(skip, "big")) {
+            LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
+                                      n_big_blocks, c->side[0]));
+        }
+        if (!skip || !strstr(skip, "mid")) {
+            LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
+        }
+        LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], c->dps));
+        if (!skip || !strstr(skip, "light")) {
+            LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, c->dps));
+        }
+        LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], c->dps));
+        for (int i = 0; i < 2; i++) {
+            LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][1], c->side[i]));
+        }
     }
-    if (!skip || !strstr(skip, "mid")) {
-        LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
-    }
-    if (!skip || !strstr(skip, "light")) {
-        LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, st));
-    }
-    LFQ_TRY_HIP(hipEventRecord(c->ev_light_done, st));
-    for (int i = 0; i < 2; i++) {
-        LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][1], c->side[i]));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_join[i], c->side[i]));
+    /* join everything back into the caller's stream */
+    LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));                     /* all count kernels done */
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[0], c->side[0]));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[1], c->side[1]));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], c->dps));
+    for (int i = 0; i < 3; i++) {
         LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_join[i], 0));
     }
     LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
@@ -375,22 +431,32 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
         return LFQ_ERR_INVALID;
     }
     hipStream_t st = c->cur_stream ? c->cur_stream : c->stream;
-    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, LFQ_NCOUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, st));
     LFQ_TRY_HIP(hipStreamSynchronize(st));
+    const int32_t *g = c->h_counters + LFQ_MAX_SEGMENTS * LFQ_NCOUNTERS;
+    memset(&c->times, 0, sizeof(c->times));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->times.ms_count = ms;
-    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->times.ms_scan = ms;
-    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->times.ms_dp = ms;
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[3]) == hipSuccess) c->times.ms_total = ms;
-    if (hipEventElapsedTime(&ms, c->ev[2], c->ev_light_done) == hipSuccess) c->times.ms_dp_light = ms;
-    if (hipEventElapsedTime(&ms, c->ev_side[0][0], c->ev_side[0][1]) == hipSuccess) c->times.ms_dp_big = ms;
-    if (hipEventElapsedTime(&ms, c->ev_side[1][0], c->ev_side[1][1]) == hipSuccess) c->times.ms_dp_mid = ms;
+    float dp_end = 0.f;
+    for (int s = 0; s < c->cur_segments; s++) {
+        if (hipEventElapsedTime(&ms, c->ev_cnt[s][0], c->ev_cnt[s][1]) == hipSuccess) c->times.ms_count += ms;
+        if (hipEventElapsedTime(&ms, c->ev_cnt[s][1], c->ev_scan[s]) == hipSuccess) c->times.ms_scan += ms;
+        if (hipEventElapsedTime(&ms, c->ev_light[s][0], c->ev_light[s][1]) == hipSuccess) c->times.ms_dp_light += ms;
+        if (hipEventElapsedTime(&ms, c->ev_side[0][s][0], c->ev_side[0][s][1]) == hipSuccess) c->times.ms_dp_big += ms;
+        if (hipEventElapsedTime(&ms, c->ev_side[1][s][0], c->ev_side[1][s][1]) == hipSuccess) c->times.ms_dp_mid += ms;
+    }
+    /* DP time that is NOT hidden under a count kernel: last count kernel's end -> everything done */
+    if (c->cur_segments > 0 && hipEventElapsedTime(&dp_end, c->ev[1], c->ev[3]) == hipSuccess) {
+        c->times.ms_dp = dp_end;
+    }
+    c->times.n_segments = c->cur_segments;
     if (stats) {
-        stats->n_tested = c->h_counters[LFQ_CNT_TESTED];
-        stats->n_pvals = std::min<int64_t>(c->h_counters[LFQ_CNT_PVALS], c->cur_pvals_cap);
+        stats->n_tested = g[LFQ_GC_TESTED];
+        stats->n_pvals = std::min<int64_t>(g[LFQ_GC_PVALS], c->cur_pvals_cap);
         stats->n_obs = 0;
     }
-    if (c->h_counters[LFQ_CNT_OVERFLOW]) {
+    if (g[LFQ_GC_OVERFLOW]) {
         return LFQ_ERR_CAPACITY;
     }
     return LFQ_OK;
@@ -402,7 +468,7 @@ int lfq_debug_counters(lfq_ctx *c, int32_t *out16)
     if (!c || !out16) {
         return LFQ_ERR_INVALID;
     }
-    memcpy(out16, c->h_counters, LFQ_NCOUNTERS * sizeof(int32_t));
+    memcpy(out16, c->h_counters, LFQ_NCOUNTERS * sizeof(int32_t));   /* segment 0 */
     return LFQ_OK;
 }
 

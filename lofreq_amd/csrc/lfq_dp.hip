@@ -12,10 +12,11 @@
  * carries a binary exponent e for its C cells (value = v*2^e), renormalised every 8 rows, so the
  * 1e-4932-range tails the reference reaches in log space are representable.
  *
- *   lfq_dp_wave_kernel<1>  light columns, K < 64: one wavefront per column, one cell per lane.
- *   lfq_dp_wave_kernel<8>  mid columns, 64 <= K < 505: one wavefront per column, 8 cells per lane.
- *                        Both: persistent grid, static column striding, no strip exchange.
- *   lfq_dp_big_kernel    K >= 505: one 8-wave workgroup per column, C = 8, strip w on wave w.  Strips
+ *   lfq_dp_wave_kernel<1>  light columns (K < 64 and not suspicious): one wavefront per column, one cell
+ *                        per lane; almost all of them are pruned within the first few dozen rows.
+ *   lfq_dp_wave_kernel<4>  mid columns (K < 250): one wavefront per column, 1 or 4 cells per lane.
+ *                        Both: persistent grid, work claimed dynamically, no strip exchange.
+ *   lfq_dp_big_kernel    K >= 250: one 8-wave workgroup per column, 2 or 4 cells per lane, strip w on wave w.  Strips
  *                        run as a software pipeline over 64-row chunks (wave w works on chunk t-w at
  *                        step t); the boundary cell of strip w reaches strip w+1 through a
  *                        double-buffered LDS slab, one s_barrier per step.  More than 8 strips
@@ -33,7 +34,6 @@
 #define LFQ_DBL_EPS 2.220446049250313e-16
 
 #define LFQ_HEAVY_WAVES 8
-#define LFQ_HEAVY_C 8
 
 struct LfqColCtx {
     int col;
@@ -162,7 +162,7 @@ struct LfqRow {
  *   tflag    1.0 on the lane that owns the absorbing tail cell (at j = 0), else 0.0: its miss factor
  *            becomes q + p instead of q (cells beyond the tail hold don't-care values that are never read)
  * Returns true when the pruning test fires (evaluated every 8 rows on the strip that owns the tail). */
-template <int C>
+template <int C, bool IO>
 __device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *rows, uint64_t km, bool has_in,
                                                 const double *in_v, const int *in_e, bool has_out,
                                                 double *out_v, int *out_e, double tflag, bool owns_tail,
@@ -170,10 +170,18 @@ __device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *ro
 {
     const int lane = lfq_lane();
     constexpr int R = (C == 1) ? 8 : 4;     /* rows per unrolled group (register pressure vs. branch cost) */
+    /* boundary I/O without branches or EXEC changes inside the row loop (IO = strip pipeline only):
+     *   in : every lane reads the row's incoming (value, exponent) with a wave-uniform address; only lane 0
+     *        of a strip > 0 uses it (in_sel)
+     *   out: every lane stores its last cell; lane 63 of a strip that has a successor stores to the slab
+     *        slot of the row, all other lanes to a private dump slot (out_stride = 0) */
+    const bool in_sel = IO && has_in && lane == 0;
+    const int out_slot0 = (IO && has_out && lane == 63) ? 0 : 64 + lane;
+    const int out_stride = (IO && has_out && lane == 63) ? 1 : 0;
 #pragma unroll 1
     for (int g = 0; g < 64 / R; g++) {
         const int r0 = g * R;
-        if (has_in && S.all_zero && (r0 & 7) == 0) {
+        if (IO && has_in && S.all_zero && (r0 & 7) == 0) {
             /* nothing has reached this strip yet: skip whole groups whose incoming values are all zero */
             const double xb = in_v[r0 + (lane & 7)];
             const int eb_last = in_e[r0 + 7];
@@ -196,18 +204,14 @@ __device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *ro
             const LfqRow pq = rows[r0 + r];
             double x = lfq_shr1_f64(S.v[C - 1]);
             int dei = S.de;
-            if (has_in) {
+            if (IO) {
                 const double xb = in_v[r0 + r];
                 const int eb = in_e[r0 + r];
                 S.e_in = eb;
-                if (lane == 0) {
-                    x = xb;
-                    dei = eb - S.e;
-                }
-            }
-            if (has_out && lane == 63) {
-                out_v[r0 + r] = S.v[C - 1];
-                out_e[r0 + r] = S.e;
+                x = in_sel ? xb : x;
+                dei = in_sel ? (eb - S.e) : dei;
+                out_v[out_slot0 + (r0 + r) * out_stride] = S.v[C - 1];
+                out_e[out_slot0 + (r0 + r) * out_stride] = S.e;
             }
             const double pe = ldexp(pq.p, dei);             /* off the row-to-row dependency chain */
             const double q0 = fma(tflag, pq.p, pq.q);
@@ -241,7 +245,7 @@ __device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *ro
             if (nz) {
                 const int e_front = lfq_rl_i32(S.e, 63 - __builtin_clzll(nz));
                 S.e = nzl ? S.e : e_front;
-            } else if (has_in) {
+            } else if (IO && has_in) {
                 S.e = S.e_in;
             }
         }
@@ -345,7 +349,7 @@ __device__ double lfq_tailsum(const double *probvec, int start, int K, bool *fe_
  * is proven to be below the 80-bit underflow threshold (the reference returns LDBL_MIN for them);
  * `force_fe` marks every computed tail as "the reference's log_sum chain underflows" (see the shortcut
  * in lfq_dp_big_kernel); `have_probvec` is false when the kp-recurrence was pruned or not needed. */
-__device__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, const double *probvec, int kp,
+__device__ __noinline__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, const double *probvec, int kp,
                                bool have_probvec, unsigned uf_mask, const double *uf_bound, bool force_fe,
                                int rows, const LfqWork &W, lfq_col_pvals *__restrict__ pvals,
                                int64_t pvals_capacity)
@@ -375,7 +379,7 @@ __device__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, c
         }
     }
     if (lfq_lane() == 0) {
-        const int slot = atomicAdd(&W.counters[LFQ_CNT_PVALS], 1);
+        const int slot = atomicAdd(&W.gcounters[LFQ_GC_PVALS], 1);
         if ((int64_t)slot < pvals_capacity) {
             lfq_col_pvals r;
             r.col = cx.col;
@@ -395,7 +399,7 @@ __device__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, c
             r.reserved_ = 0;
             pvals[slot] = r;
         } else {
-            W.counters[LFQ_CNT_OVERFLOW] = 1;
+            W.gcounters[LFQ_GC_OVERFLOW] = 1;
         }
     }
 }
@@ -522,7 +526,7 @@ __device__ void lfq_emit_linear(const LfqColCtx &cx, const lfq_col_counts &cnt, 
         status[a] = fe ? LFQ_PV_LOG_FECLAMP : LFQ_PV_LOG;
     }
     if (lane == 0) {
-        const int slot = atomicAdd(&W.counters[LFQ_CNT_PVALS], 1);
+        const int slot = atomicAdd(&W.gcounters[LFQ_GC_PVALS], 1);
         if ((int64_t)slot < pvals_capacity) {
             lfq_col_pvals r;
             r.col = cx.col;
@@ -542,13 +546,13 @@ __device__ void lfq_emit_linear(const LfqColCtx &cx, const lfq_col_counts &cnt, 
             r.reserved_ = 0;
             pvals[slot] = r;
         } else {
-            W.counters[LFQ_CNT_OVERFLOW] = 1;
+            W.gcounters[LFQ_GC_OVERFLOW] = 1;
         }
     }
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* wave-per-column kernel: light (K < 64, C = 1) and mid (64 <= K < 505, C = 8) columns          */
+/* wave-per-column kernel: light (C = 1) and mid (K < 250, C = 1 or 4) columns                  */
 /* ------------------------------------------------------------------------------------------ */
 
 /* Claim `n` consecutive work-list slots for this wavefront: one returning device-scope atomic from
@@ -625,7 +629,7 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
         const long long c2 = clock64();
         t_load += c2 - c1;
 #endif
-        const bool hit = lfq_strip_chunk<C>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
+        const bool hit = lfq_strip_chunk<C, false>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
                                             true, lt, cx.bonf_d, cx.sig_s);
 #ifdef LFQ_PROFILE
         t_rows += clock64() - c2;
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
             } else {
                 /* (more cells-per-lane variants were measured -- C = 2 and 4 are ~30 % faster per row for
                  * K < 250 -- but four inlined variants push this kernel into SGPR spilling) */
-                lfq_wave_column<8, true>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
+                lfq_wave_column<4, true>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
             }
             if (!have_next) {
                 break;
@@ -748,19 +752,67 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* big columns: K >= 505, one 8-wave workgroup per column                                     */
+/* big columns: K >= 250, one 8-wave workgroup per column                                     */
 /* ------------------------------------------------------------------------------------------ */
 
 struct LfqBigShared {
     LfqLuts luts;
     LfqRow rows[LFQ_HEAVY_WAVES][64];
-    double bv[2][LFQ_HEAVY_WAVES][64];      /* strip boundary slabs, double-buffered across steps */
-    int be[2][LFQ_HEAVY_WAVES][64];
+    double bv[2][LFQ_HEAVY_WAVES][128];     /* strip boundary slabs, double-buffered across steps; entries */
+    int be[2][LFQ_HEAVY_WAVES][128];        /* 64..127 of each slab are per-lane dump slots (see lfq_strip_chunk) */
+    double zero_v[64];                      /* "no predecessor" input of the first strip */
+    int zero_e[64];
     double gv[LFQ_HEAVY_WAVES][64];         /* pass boundary staged from global scratch */
     int ge[LFQ_HEAVY_WAVES][64];
     double mu[LFQ_HEAVY_WAVES];
     int col, pruned;
 };
+
+/* mu = sum of the column's error probabilities (all wavefronts of the workgroup), then the per-allele
+ * upper bounds log(mu^c / c!) and the recurrence size kp that is still needed.  Kept out of line: its
+ * registers (log, lgamma) must not inflate the strip pipeline's allocation. */
+__device__ __noinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_counts &cnt, const LfqTracksDev &T,
+                                            const LfqParams &P, LfqBigShared &sh, unsigned *uf_mask_out,
+                                            double *uf_bound, int *kp_out)
+{
+    constexpr int NW = LFQ_HEAVY_WAVES;
+    const int lane = lfq_lane();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_chunks = (cx.n_obs + 63) / 64;
+    double part = 0.0;
+    for (int64_t ch = w; ch < n_chunks; ch += NW) {
+        double ps, qf;
+        const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &sh.luts, &ps, &qf);
+        part += ((km >> lane) & 1ull) ? ps : 0.0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        part += __shfl_xor(part, d, 64);
+    }
+    if (lane == 0) {
+        sh.mu[w] = part;
+    }
+    __syncthreads();
+    double mu = 0.0;
+    for (int i = 0; i < NW; i++) {
+        mu += sh.mu[i];
+    }
+    const double lmu = log(mu);
+    unsigned uf_mask = 0;
+    int kp = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int c = cnt.alt_counts[a];
+        uf_bound[a] = (c > 0) ? (double)c * lmu - lgamma((double)c + 1.0) : 0.0;
+        if (c > 0 && uf_bound[a] < -12200.0) {
+            uf_mask |= 1u << a;
+        } else if (c > kp) {
+            kp = c;
+        }
+    }
+    *uf_mask_out = uf_mask;
+    *kp_out = kp;
+}
 
 /* the strip pipeline of one big column with C cells per lane (C chosen so that the strips fit the
  * workgroup's wavefronts in one pass whenever possible: fewer cells per lane = shorter rows) */
@@ -799,13 +851,17 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
         lfq_strip_init<C>(S, s == 0, shift);
 
         const int64_t n_steps = n_chunks + nwp - 1;
+#ifdef LFQ_PROFILE
+        long long pt_stage = 0, pt_rows = 0, pt_bar = 0;
+        const long long pstart = clock64();
+#endif
         LfqRaw raw = lfq_load_chunk(cx, 0, T);
         for (int64_t t = 0; t < n_steps; t++) {
             const int64_t ch = t - w;
             if (active && ch >= 0 && ch < n_chunks) {
                 const int64_t idx = ch * 64 + lane;
-                const double *in_v = nullptr;
-                const int *in_e = nullptr;
+                const double *in_v = sh.zero_v;
+                const int *in_e = sh.zero_e;
                 if (has_in) {
                     if (in_global) {
                         sh.gv[w][lane] = (idx < cx.n_obs) ? bnd[2 * idx] : 0.0;
@@ -817,15 +873,25 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
                         in_e = sh.be[(t - 1) & 1][w - 1];
                     }
                 }
+#ifdef LFQ_PROFILE
+                const long long pc0 = clock64();
+#endif
                 const uint64_t km = lfq_stage_rows(cx, raw, P, &sh.luts, sh.rows[w]);
                 if (ch + 1 < n_chunks) {
                     raw = lfq_load_chunk(cx, ch + 1, T);   /* lands while this step's rows run */
                 }
-                if (lfq_strip_chunk<C>(S, sh.rows[w], km, has_in, in_v, in_e, has_out, sh.bv[t & 1][w],
+#ifdef LFQ_PROFILE
+                const long long pc1 = clock64();
+                pt_stage += pc1 - pc0;
+#endif
+                if (lfq_strip_chunk<C, true>(S, sh.rows[w], km, has_in, in_v, in_e, has_out, sh.bv[t & 1][w],
                                        sh.be[t & 1][w], tflag, owns_tail, lt, cx.bonf_d, cx.sig_s)) {
                     sh.pruned = 1;
                 }
                 rows_tail += __popcll(km);
+#ifdef LFQ_PROFILE
+                pt_rows += clock64() - pc1;
+#endif
                 if (out_global) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -836,12 +902,27 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
                     }
                 }
             }
+#ifdef LFQ_PROFILE
+            const long long pb0 = clock64();
+#endif
             __syncthreads();
+#ifdef LFQ_PROFILE
+            pt_bar += clock64() - pb0;
+#endif
             if (sh.pruned) {
                 pruned = true;
                 break;
             }
         }
+#ifdef LFQ_PROFILE
+        if (lane == 0 && w == 0) {
+            atomicAdd(&W.counters[8], (int)(pt_stage >> 8));
+            atomicAdd(&W.counters[9], (int)(pt_bar >> 8));
+            atomicAdd(&W.counters[10], (int)(pt_rows >> 8));
+            atomicAdd(&W.counters[11], (int)((clock64() - pstart) >> 8));
+            atomicAdd(&W.counters[14], (int)n_steps);
+        }
+#endif
         if (!pruned && owns_tail) {
             if (lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
                 sh.pruned = 1;
@@ -865,7 +946,7 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
     }
 }
 
-__global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
+__global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
     LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
     LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity, double *__restrict__ scratch,
     int64_t scratch_per_block)
@@ -879,6 +960,10 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
         for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
             dst[i] = src[i];
         }
+    }
+    if (threadIdx.x < 64) {
+        sh.zero_v[threadIdx.x] = 0.0;
+        sh.zero_e[threadIdx.x] = 0;
     }
     const int lane = lfq_lane();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -909,38 +994,10 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
          * reference's log_sum chain provably underflows too (the chain spans > 708 in log space), so
          * their p-values are clamped by value: they only need the recurrence up to the largest
          * non-underflowing count. */
-        double part = 0.0;
-        for (int64_t ch = w; ch < n_chunks; ch += NW) {
-            double ps, qf;
-            const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &sh.luts, &ps, &qf);
-            part += ((km >> lane) & 1ull) ? ps : 0.0;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            part += __shfl_xor(part, d, 64);
-        }
-        if (lane == 0) {
-            sh.mu[w] = part;
-        }
-        __syncthreads();
-        double mu = 0.0;
-        for (int i = 0; i < NW; i++) {
-            mu += sh.mu[i];
-        }
-        const double lmu = log(mu);
         unsigned uf_mask = 0;
         double uf_bound[3];
         int kp = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const int c = cnt.alt_counts[a];
-            uf_bound[a] = (c > 0) ? (double)c * lmu - lgamma((double)c + 1.0) : 0.0;
-            if (c > 0 && uf_bound[a] < -12200.0) {
-                uf_mask |= 1u << a;
-            } else if (c > kp) {
-                kp = c;
-            }
-        }
+        lfq_big_bounds(cx, cnt, T, P, sh, &uf_mask, uf_bound, &kp);
         const bool force_fe = uf_mask != 0;
         if (force_fe) {
             /* pruned alleles become LDBL_MAX; that equals the reference's clamp only while the pruning
@@ -956,7 +1013,10 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
         if (kp < 128 * NW - 1) {
             lfq_big_column<2>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
         } else {
-            lfq_big_column<8>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
+            /* 4 cells per lane: up to K = 2044 in one pass; deeper columns run in passes.  (8 cells per
+             * lane would halve the passes but doubles the kernel's register footprint, which decides
+             * whether these workgroups can be resident beside the light kernel.) */
+            lfq_big_column<4>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
         }
     }
 }
@@ -986,7 +1046,7 @@ int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
         return LFQ_OK;
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    hipLaunchKernelGGL(lfq_dp_wave_kernel<LFQ_HEAVY_C>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,
+    hipLaunchKernelGGL(lfq_dp_wave_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,
                        d_luts, d_counts, w, LFQ_CNT_LIGHT, LFQ_CNT_MID, d_pvals, pvals_capacity, 1);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

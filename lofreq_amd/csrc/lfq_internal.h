@@ -62,30 +62,35 @@ struct LfqEntry {
 /* work lists and counters produced by the scan kernels, consumed by the DP kernel */
 struct LfqWork {
     int32_t *tested_prefix;   /* [ncols] inclusive count of tested columns up to and incl. c */
-    LfqEntry *entries;        /* [ncols] work list: [light | mid | big] = [kmax < LFQ_MID_K | < LFQ_BIG_K | rest] */
-    int32_t *counters;        /* [16], see LFQ_CNT_* */
+    LfqEntry *entries;        /* this segment's work list: [light | mid | big] = [kmax < LFQ_MID_K | < LFQ_BIG_K | rest] */
+    int32_t *gcounters;       /* batch-wide counters shared by all segments, see LFQ_GC_* */
+    int32_t *counters;        /* [16] of this segment, see LFQ_CNT_* */
     int32_t *block_sums;      /* scan scratch */
 };
 
 #define LFQ_MID_K 64          /* K+1 cells no longer fit one cell per lane */
-#define LFQ_BIG_K 505         /* K+1 (+alignment) cells no longer fit one 64x8 strip */
+#define LFQ_BIG_K 250         /* K+1 (+alignment) cells no longer fit one 64x4 strip: strip pipeline */
 #define LFQ_NCOUNTERS 16
+#define LFQ_MAX_SEGMENTS 8      /* a batch is cut into segments so that the DP of one overlaps the count of the next */
+#define LFQ_GC_PVALS 0         /* records appended to the sparse output */
+#define LFQ_GC_OVERFLOW 1
+#define LFQ_GC_TESTED 2        /* running total of tested columns (carry between segments) */
+#define LFQ_GC_MAXDEPTH 3
 #define LFQ_CNT_TESTED 0
 #define LFQ_CNT_BIG 1
 #define LFQ_CNT_MID 2
 #define LFQ_CNT_LIGHT 3
 #define LFQ_CNT_HEAD 4        /* dequeue head of the big-column list */
-#define LFQ_CNT_PVALS 5
-#define LFQ_CNT_OVERFLOW 6
-#define LFQ_CNT_MAXDEPTH 7
+#define LFQ_CNT_CARRY_IN 15    /* tested columns in earlier segments of the batch */
 #define LFQ_CNT_HEAD_LIGHT 12  /* dynamic work distribution of the wave-per-column kernels */
 #define LFQ_CNT_HEAD_MID 13
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
-int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int32_t *d_counters, void *stream);
-int lfq_launch_scan(const LfqTracksDev &t, const uint8_t *d_flags, const lfq_col_counts *d_counts,
-                    const LfqWork &w, void *stream);
+int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);
+int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
+                     lfq_col_counts *d_counts, uint8_t *d_flags, void *stream);
+int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,
+                    const lfq_col_counts *d_counts, const LfqWork &w, void *stream);
 int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                         const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                         int64_t pvals_capacity, int n_waves, void *stream);

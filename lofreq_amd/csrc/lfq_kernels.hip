@@ -28,6 +28,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "lfq_device.h"
 #include "lofreq_synth.h"
 
@@ -130,14 +132,13 @@ __device__ __forceinline__ void lfq_planes_to_classes(const uint32_t n[4], uint3
 __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
                                                         const LfqLuts *__restrict__ luts,
                                                         lfq_col_counts *__restrict__ out,
-                                                        uint8_t *__restrict__ flags,
-                                                        int32_t *__restrict__ counters)
+                                                        uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
     __shared__ uint32_t s_hist[4][128];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
-    const int64_t col = (int64_t)blockIdx.x * 4 + wave;
-    if (col >= T.ncols) {
+    const int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave;
+    if (col >= c1) {
         return;
     }
     const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
@@ -292,9 +293,6 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         }
         out[col] = r;
         flags[col] = flag;
-        if (n_obs > (int64_t)counters[LFQ_CNT_MAXDEPTH]) {
-            atomicMax(&counters[LFQ_CNT_MAXDEPTH], (int)min(n_obs, (int64_t)0x7fffffff));
-        }
     }
 }
 
@@ -385,7 +383,8 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_tiles_kernel(int64_
 /* single block: exclusive scan over the tile sums, totals into the counters */
 __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t ntiles,
                                                                         LfqTriple *__restrict__ tile_sums,
-                                                                        int32_t *__restrict__ counters)
+                                                                        int32_t *__restrict__ counters,
+                                                                        int32_t *__restrict__ gcounters)
 {
     __shared__ LfqTriple s_wave[16];
     LfqTriple carry = {0, 0, 0};
@@ -408,18 +407,22 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t
         counters[LFQ_CNT_MID] = (int32_t)carry.m;
         counters[LFQ_CNT_BIG] = (int32_t)carry.b;
         counters[LFQ_CNT_LIGHT] = (int32_t)(carry.t - carry.m - carry.b);
+        /* running Bonferroni carry between the segments of a batch (stream-ordered) */
+        const int32_t before = gcounters[LFQ_GC_TESTED];
+        counters[LFQ_CNT_CARRY_IN] = before;
+        gcounters[LFQ_GC_TESTED] = before + (int32_t)carry.t;
     }
 }
 
-__global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTracksDev T,
+__global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTracksDev T, int64_t c0, int64_t c1,
                                                                          const uint8_t *__restrict__ flags,
                                                                          const lfq_col_counts *__restrict__ counts,
                                                                          const LfqTriple *__restrict__ tile_sums,
                                                                          LfqWork W)
 {
     __shared__ LfqTriple s_wave[16];
-    const int64_t ncols = T.ncols;
-    const int64_t base = (int64_t)blockIdx.x * LFQ_SCAN_TILE + (int64_t)threadIdx.x * LFQ_SCAN_ITEMS;
+    const int64_t ncols = c1;
+    const int64_t base = c0 + (int64_t)blockIdx.x * LFQ_SCAN_TILE + (int64_t)threadIdx.x * LFQ_SCAN_ITEMS;
     uint32_t f[LFQ_SCAN_ITEMS];
     LfqTriple x = {0, 0, 0};
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
     /* list layout [light | mid | big]; the class totals were published by lfq_scan_sums_kernel */
     const uint32_t base_mid = (uint32_t)W.counters[LFQ_CNT_LIGHT];
     const uint32_t base_big = base_mid + (uint32_t)W.counters[LFQ_CNT_MID];
+    const uint32_t carry_in = (uint32_t)W.counters[LFQ_CNT_CARRY_IN];
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
         const int64_t c = base + i;
         if (c >= ncols) {
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
             e.off0 = T.col_off[c];
             e.n_obs = (int32_t)(T.col_off[c + 1] - e.off0);
             e.col = (int32_t)c;
-            e.prefix = (int32_t)ex.t;                  /* inclusive */
+            e.prefix = (int32_t)(carry_in + ex.t);     /* inclusive, batch-wide */
             e.kmax = cn->kmax;
             e.median_ref_bq = (int16_t)cn->median_ref_bq;
             e.ref_code = (uint8_t)((rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : 3);
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
             e.pad2_ = 0;
             W.entries[pos] = e;
         }
-        W.tested_prefix[c] = (int32_t)ex.t;            /* inclusive */
+        W.tested_prefix[c] = (int32_t)(carry_in + ex.t);   /* inclusive, batch-wide */
     }
 }
 
@@ -522,34 +526,63 @@ __global__ __launch_bounds__(256) void lfq_synth_kernel(lfq_synth_spec S, int64_
         }                                \
     } while (0)
 
-int lfq_launch_count(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int32_t *d_counters, void *stream)
+__global__ __launch_bounds__(256) void lfq_maxdepth_kernel(const uint64_t *__restrict__ col_off, int64_t ncols,
+                                                           int32_t *__restrict__ gcounters)
+{
+    int best = 0;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = col_off[c + 1] - col_off[c];
+        best = max(best, (int)min(d, (uint64_t)0x7fffffff));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        best = max(best, __shfl_xor(best, d, 64));
+    }
+    if (lfq_lane() == 0) {
+        atomicMax(&gcounters[LFQ_GC_MAXDEPTH], best);
+    }
+}
+
+int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream)
 {
     if (t.ncols <= 0) {
         return LFQ_OK;
     }
-    const unsigned blocks = (unsigned)((t.ncols + 3) / 4);
-    hipLaunchKernelGGL(lfq_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                       d_counts, d_flags, d_counters);
+    const unsigned blocks = (unsigned)std::min<int64_t>((t.ncols + 255) / 256, 1024);
+    hipLaunchKernelGGL(lfq_maxdepth_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t.col_off, t.ncols,
+                       d_gcounters);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }
 
-int lfq_launch_scan(const LfqTracksDev &t, const uint8_t *d_flags, const lfq_col_counts *d_counts,
-                    const LfqWork &w, void *stream)
+int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
+                     lfq_col_counts *d_counts, uint8_t *d_flags, void *stream)
 {
-    const int64_t ncols = t.ncols;
+    if (c1 <= c0) {
+        return LFQ_OK;
+    }
+    const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
+    hipLaunchKernelGGL(lfq_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
+                       d_counts, d_flags, c0, c1);
+    LFQ_HIP_TRY(hipGetLastError());
+    return LFQ_OK;
+}
+
+int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,
+                    const lfq_col_counts *d_counts, const LfqWork &w, void *stream)
+{
+    const int64_t ncols = c1 - c0;
     if (ncols <= 0) {
         return LFQ_OK;
     }
     const int64_t ntiles = (ncols + LFQ_SCAN_TILE - 1) / LFQ_SCAN_TILE;
     LfqTriple *tile_sums = reinterpret_cast<LfqTriple *>(w.block_sums);
     hipLaunchKernelGGL(lfq_scan_tiles_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
-                       (hipStream_t)stream, ncols, d_flags, tile_sums);
+                       (hipStream_t)stream, ncols, d_flags + c0, tile_sums);
     hipLaunchKernelGGL(lfq_scan_sums_kernel, dim3(1), dim3(LFQ_SCAN_THREADS), 0, (hipStream_t)stream, ntiles,
-                       tile_sums, w.counters);
+                       tile_sums, w.counters, w.gcounters);
     hipLaunchKernelGGL(lfq_scan_apply_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
-                       (hipStream_t)stream, t, d_flags, d_counts, (const LfqTriple *)tile_sums, w);
+                       (hipStream_t)stream, t, c0, c1, d_flags, d_counts, (const LfqTriple *)tile_sums, w);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }

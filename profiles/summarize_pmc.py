@@ -51,7 +51,7 @@ def main(root, tag):
     # bench.py looks kernels up by the names it uses
     tj = {"lfq_count_kernel": traffic.get("lfq_count_kernel"),
           "lfq_dp_wave_kernel<1>": traffic.get("lfq_dp_wave_kernel<1>"),
-          "lfq_dp_wave_kernel<8>": traffic.get("lfq_dp_wave_kernel<8>"),
+          "lfq_dp_wave_kernel<4>": traffic.get("lfq_dp_wave_kernel<4>"),
           "lfq_dp_big_kernel": traffic.get("lfq_dp_big_kernel")}
     json.dump(tj, open("profiles/pmc_traffic.json", "w"), indent=1)
     print(text)

@@ -14,5 +14,5 @@ L=_lib.load(); L.lfq_debug_counters.argtypes=[C.c_void_p, C.POINTER(C.c_int32)]
 for it in range(2):
     conf=la.VarcallConf(); caller.snv_batch_device(batch, conf, d_counts, d_pvals, ncols); st=caller.batch_finish()
 cnt=(C.c_int32*16)(); L.lfq_debug_counters(caller.h, cnt); c=list(cnt)
-print("counters", c[:8]); print("stage %.1f Mticks, load-issue %.1f, rows %.1f, n_rows %d -> %.1f ticks/row; stage ticks/chunk ~ %.0f"%(c[8]*256/1e6,c[9]*256/1e6,c[10]*256/1e6,c[11], c[10]*256/max(c[11],1), c[8]*256/max(c[11]/64,1)))
+print("counters", c); print("stage %.1f Mticks, load-issue %.1f, rows %.1f, n_rows %d -> %.1f ticks/row; stage ticks/chunk ~ %.0f"%(c[8]*256/1e6,c[9]*256/1e6,c[10]*256/1e6,c[11], c[10]*256/max(c[11],1), c[8]*256/max(c[11]/64,1)))
 print(caller.kernel_times())
