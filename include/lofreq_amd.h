@@ -49,6 +49,7 @@ typedef enum lfq_status {
 #define LFQ_USE_BAQ 1
 #define LFQ_USE_MQ 2
 #define LFQ_USE_SQ 4
+#define LFQ_USE_IDAQ 8
 
 /* ---- packed column batch ------------------------------------------------------------------
  * Struct-of-arrays, one byte per observation per track, columns concatenated (CSR offsets).
@@ -88,6 +89,8 @@ typedef struct lfq_conf {
     float sig;                 /* float, like the reference */
     int32_t flag;
     int64_t num_snv_tests;     /* the global of lofreq_call.c:84; mutated */
+    int64_t bonf_indel;        /* running indel Bonferroni factor (snpcaller.h:52); mutated by the indel calls */
+    int64_t num_indel_tests;   /* the global of lofreq_call.c:85; mutated */
 } lfq_conf;
 
 /* dense per-column output of the counting kernel == plp_to_errprobs()'s integer outputs
@@ -179,6 +182,77 @@ int lfq_batch_finish(lfq_ctx *ctx, lfq_batch_stats *stats);
 int lfq_call_snvs_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_tracks *tracks, int tracks_on_device,
                         lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
                         lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats);
+
+/* --- indel tests (call_indels, lofreq_call.c:619-726) on the same kernels ------------------------------
+ * One "test" = one indel event of one column = snpcaller() on all reads of the column with
+ * counts = {event count, 0, 0} (lofreq_call.c:306-426).  The caller packs each test as a
+ * pseudo-column in the track format: bq = indel quality, baq = indel alignment quality of the tested
+ * event's reads (255 elsewhere or with IDAQ off), mq, sq; nt = 1 ('C') for the tested event's reads, 0 for
+ * every other read; ref_base = 'A'.  No base filters apply; the running factor is conf->bonf_indel, +1 per
+ * test (lofreq_call.c:693-696).  Returns the significant tests (p * bonf_indel < sig) in test order. */
+typedef struct lfq_indel_call {
+    int64_t test;              /* pseudo-column index within the batch */
+    int64_t bonf;              /* bonf_indel at this test */
+    long double pvalue;
+    int32_t qual;              /* PROB_TO_PHREDQUAL(pvalue) */
+    int32_t count;             /* event count (AF numerator, lofreq_call.c:334) */
+} lfq_indel_call;
+int lfq_indel_batch_device(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *tracks,
+                           lfq_col_counts *d_counts, lfq_col_pvals *d_pvals, int64_t pvals_capacity,
+                           void *stream);
+int lfq_call_indel_tests_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_tracks *tracks, int tracks_on_device,
+                               lfq_indel_call *calls, int64_t calls_capacity, int64_t *n_calls,
+                               lfq_batch_stats *stats);
+/* --- call_indels drop-in (lofreq_call.c:619-726): the indel fields of a batch of plp_col_t, flattened ----
+ * side[0] = insertions, side[1] = deletions.  Events of a column are listed in the order the reference
+ * iterates its uthash (insertion order = first occurrence in the pileup, utils.h:101-135).  "Non-event reads"
+ * are ins_quals/ins_map_quals (del_quals/del_map_quals): reads of the column carrying no event of that side
+ * (plp.c compile_plp_col).  Qualities are phred ints as in the reference; -1 = not available. */
+typedef struct lfq_indel_side {
+    const int32_t *non_fw, *non_rv;    /* [ncols]     non_ins_fw_rv / non_del_fw_rv (plp.h:127-128) */
+    const int64_t *ne_off;             /* [ncols+1]   non-event reads of each column */
+    const int16_t *ne_q, *ne_mq;       /*             ins_quals / ins_map_quals (plp.h:113-116) */
+    const int64_t *ev_off;             /* [ncols+1]   events of each column */
+    const int64_t *key_off;            /* [nevents+1] event key (inserted / deleted sequence) in key_chars */
+    const char *key_chars;
+    const int32_t *ev_fw, *ev_rv;      /* [nevents]   ins_event.fw_rv (utils.h:108) */
+    const int64_t *rd_off;             /* [nevents+1] reads of each event; count = rd_off[e+1]-rd_off[e] */
+    const int16_t *rd_q, *rd_aq, *rd_mq, *rd_sq;   /* ins_quals / ins_aln_quals / ins_map_quals / ins_source_quals */
+} lfq_indel_side;
+
+typedef struct lfq_indel_columns {
+    int64_t ncols;
+    const uint8_t *ref_base;
+    const int32_t *coverage_plp, *num_tails, *num_non_indels, *num_ins, *num_dels, *hrun;
+    lfq_indel_side side[2];
+} lfq_indel_columns;
+
+typedef struct lfq_indel_record {
+    int64_t col;
+    int32_t side;                      /* 0 insertion, 1 deletion */
+    int32_t event;                     /* index into side[side]'s event arrays */
+    int32_t qual, dp, sb;              /* report_var (lofreq_call.c:95-155) */
+    int32_t ref_fw, ref_rv, alt_fw, alt_rv;
+    int32_t hrun;
+    float af;
+    int32_t count;
+    int64_t bonf;
+    long double pvalue;
+} lfq_indel_record;
+
+/* call_indels over a batch of columns, in column/side/event order: gates (min_cov on non_indels+ins+dels,
+ * 'N' reference, the poly-AT 1-bp A/T rule of :649-681), packs every surviving event as a pseudo-column,
+ * runs them through lfq_call_indel_tests_batch and assembles the report_var fields.  conf->bonf_indel and
+ * conf->num_indel_tests are advanced exactly as the reference does. */
+int lfq_call_indels_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_indel_columns *cols,
+                          lfq_indel_record *records, int64_t records_capacity, int64_t *n_records,
+                          int64_t *n_tests);
+
+/* vcf_write_var + vcf_var_sprintf_info for an indel record (vcf.c:469-497, 608-629);
+ * af = count / ((float)coverage_plp - num_tails), dp = coverage_plp - num_tails (lofreq_call.c:132, 334) */
+int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t pos0, const char *ref,
+                            const char *alt, int qual, int dp, float af, int sb, int ref_fw, int ref_rv,
+                            int alt_fw, int alt_rv, int hrun, const char *filter_or_null);
 
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,

@@ -6,14 +6,16 @@ Bonferroni emit test, behind LoFreq's column interface.  Compute lives in hand-w
 mirror of the reference interface plus region sharding across GPUs.
 """
 from ._lib import (COL_COUNTS_DTYPE, COL_PVALS_DTYPE, SNV_RECORD_DTYPE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP,
-                   LFQ_PV_NONE, LFQ_PV_UNDERFLOW, LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ)
+                   LFQ_PV_NONE, LFQ_PV_UNDERFLOW, LFQ_USE_BAQ, LFQ_USE_IDAQ, LFQ_USE_MQ, LFQ_USE_SQ,
+                   INDEL_RECORD_DTYPE)
 from .caller import (PileupBatch, SnvCaller, VarcallConf, filter_records, finalize_pvals, format_vcf,
                      format_vcf_record,
                      pvalue_from_log, snvqual_thresh, write_vcf_header)
+from .indel import IndelColumns, call_indels, format_indel_record
 
 __all__ = [
     "COL_COUNTS_DTYPE", "COL_PVALS_DTYPE", "SNV_RECORD_DTYPE", "LFQ_PV_LOG", "LFQ_PV_LOG_FECLAMP",
     "LFQ_PV_NONE", "LFQ_PV_UNDERFLOW", "LFQ_USE_BAQ", "LFQ_USE_MQ", "LFQ_USE_SQ", "PileupBatch", "SnvCaller", "VarcallConf",
     "filter_records", "finalize_pvals", "format_vcf", "format_vcf_record", "pvalue_from_log", "snvqual_thresh",
-    "write_vcf_header",
+    "write_vcf_header", "LFQ_USE_IDAQ", "INDEL_RECORD_DTYPE", "IndelColumns", "call_indels", "format_indel_record",
 ]

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liblofreq_amd.so")
 
 LFQ_OK = 0
 LFQ_ERR_CAPACITY = -4
-LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ = 1, 2, 4
+LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ, LFQ_USE_IDAQ = 1, 2, 4, 8
 LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP, LFQ_PV_UNDERFLOW = 0, 1, 2, 3
 LFQ_Q_MISSING = 255
 
@@ -26,7 +26,7 @@ class Conf(C.Structure):
         ("min_jq", C.c_int32), ("min_alt_jq", C.c_int32), ("def_alt_jq", C.c_int32),
         ("bonf_dynamic", C.c_int32), ("min_cov", C.c_int32),
         ("bonf_subst", C.c_int64), ("sig", C.c_float), ("flag", C.c_int32),
-        ("num_snv_tests", C.c_int64),
+        ("num_snv_tests", C.c_int64), ("bonf_indel", C.c_int64), ("num_indel_tests", C.c_int64),
     ]
 
 
@@ -48,6 +48,28 @@ class KernelTimes(C.Structure):
                 ("ms_total", C.c_float), ("ms_dp_light", C.c_float), ("ms_dp_mid", C.c_float),
                 ("ms_dp_big", C.c_float), ("n_segments", C.c_int32)]
 
+
+class IndelSide(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "non_fw", "non_rv", "ne_off", "ne_q", "ne_mq", "ev_off", "key_off", "key_chars", "ev_fw", "ev_rv",
+        "rd_off", "rd_q", "rd_aq", "rd_mq", "rd_sq")]
+
+
+class IndelColumnsC(C.Structure):
+    _fields_ = [("ncols", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "ref_base", "coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun")] + [
+        ("side", IndelSide * 2)]
+
+
+INDEL_CALL_DTYPE = np.dtype([("test", "i8"), ("bonf", "i8"), ("pvalue", np.longdouble), ("qual", "i4"),
+                             ("count", "i4")], align=True)
+assert INDEL_CALL_DTYPE.itemsize == 48, INDEL_CALL_DTYPE.itemsize
+
+INDEL_RECORD_DTYPE = np.dtype([
+    ("col", "i8"), ("side", "i4"), ("event", "i4"), ("qual", "i4"), ("dp", "i4"), ("sb", "i4"),
+    ("ref_fw", "i4"), ("ref_rv", "i4"), ("alt_fw", "i4"), ("alt_rv", "i4"), ("hrun", "i4"), ("af", "f4"),
+    ("count", "i4"), ("bonf", "i8"), ("pvalue", np.longdouble)], align=True)
+assert INDEL_RECORD_DTYPE.itemsize == 80, INDEL_RECORD_DTYPE.itemsize
 
 COL_COUNTS_DTYPE = np.dtype([
     ("n_err_probs", "i4"), ("alt_counts", "i4", 3), ("alt_raw_counts", "i4", 3), ("alt_fw", "i4", 3),
@@ -73,6 +95,7 @@ EXPORTS = [
     "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_format_vcf", "lfq_snvqual_thresh", "lfq_sb_phred",
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_last_kernel_times",
+    "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
 ]
 
 _lib = None
@@ -128,6 +151,14 @@ def load():
     L.lfq_synth_fill_device.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64,
                                         vp, vp, vp, vp, vp, vp, vp]
     L.lfq_last_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+    L.lfq_indel_batch_device.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), vp, vp, C.c_int64, vp]
+    L.lfq_call_indel_tests_batch.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int, vp, C.c_int64,
+                                             C.POINTER(C.c_int64), C.POINTER(BatchStats)]
+    L.lfq_call_indels_batch.argtypes = [vp, C.POINTER(Conf), C.POINTER(IndelColumnsC), vp, C.c_int64,
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
+                                          C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_char_p]
     _lib = L
     return L
 

@@ -125,7 +125,7 @@ double jq_threshold(int m)
     return x;
 }
 
-int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P)
+int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bool indel_mode)
 {
     if (conf->def_alt_jq == -1) {
         return LFQ_ERR_UNSUPPORTED;     /* reference: LOG_FATAL + exit (snpcaller.c:482-484) */
@@ -146,6 +146,22 @@ int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P)
     P->bonf_base = conf->bonf_subst;
     P->sig = (double)conf->sig;
     P->prune_slack = 1e-6;
+    P->bonf_step = 3;
+    P->bonf_reset_first = 1;
+    if (indel_mode) {
+        /* call_indels: no base / merged-quality filters, every event is a test (lofreq_call.c:684-725);
+         * the alignment-quality track is "used" wherever the packer filled it in */
+        P->min_bq4 = P->min_alt_bq4 = 0;
+        P->def_alt_bq = 0;
+        P->jq_reject_above = P->alt_jq_reject_above = INFINITY;
+        P->def_alt_jp = -1.0;
+        P->general = 0;
+        P->min_cov = 0;
+        P->use_baq = tr->baq != nullptr;
+        P->bonf_base = conf->bonf_indel;
+        P->bonf_step = 1;
+        P->bonf_reset_first = 0;
+    }
     return LFQ_OK;
 }
 
@@ -299,8 +315,9 @@ int lfq_synchronize(lfq_ctx *c)
     return LFQ_OK;
 }
 
-int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
-                         lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null)
+static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
+                             lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null,
+                             bool indel_mode)
 {
     if (!c || !conf || !tr || tr->ncols < 0 || tr->ncols > 0x7ffffff0LL) {
         return LFQ_ERR_INVALID;
@@ -315,7 +332,7 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     LFQ_TRY_HIP(hipSetDevice(c->device));
     hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
     LfqParams P;
-    LFQ_TRY(make_params(conf, tr, &P));
+    LFQ_TRY(make_params(conf, tr, &P, indel_mode));
     LFQ_TRY(ensure_workspace(c, tr->ncols));
 
     LfqTracksDev T;
@@ -425,6 +442,18 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     return LFQ_OK;
 }
 
+int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
+                         lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null)
+{
+    return batch_device_impl(c, conf, tr, d_counts, d_pvals, pvals_capacity, stream_or_null, false);
+}
+
+int lfq_indel_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
+                           lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null)
+{
+    return batch_device_impl(c, conf, tr, d_counts, d_pvals, pvals_capacity, stream_or_null, true);
+}
+
 int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
 {
     if (!c) {
@@ -481,24 +510,11 @@ int lfq_last_kernel_times(lfq_ctx *c, lfq_kernel_times *t)
     return LFQ_OK;
 }
 
-int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
-                        lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
-                        lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+/* host tracks -> one padded device allocation (16-byte contract); device tracks pass through */
+static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, lfq_tracks *dev_out)
 {
-    if (!c || !conf || !tr || !n_records || tr->ncols < 0) {
-        return LFQ_ERR_INVALID;
-    }
-    *n_records = 0;
-    if (tr->ncols == 0) {
-        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
-        return LFQ_OK;
-    }
-    LFQ_TRY_HIP(hipSetDevice(c->device));
     const int64_t ncols = tr->ncols;
     lfq_tracks dev = *tr;
-    std::vector<uint8_t> h_ref;
-    std::vector<int32_t> h_cov;
-
     if (!tracks_on_device) {
         /* host buffers: stage them (padded to the 16-byte contract) in one device allocation */
         const uint64_t n_obs = tr->col_off[ncols];
@@ -537,6 +553,28 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
             dev.max_col_obs = (int64_t)md;
         }
     }
+
+    *dev_out = dev;
+    return LFQ_OK;
+}
+
+int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
+                        lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
+                        lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+{
+    if (!c || !conf || !tr || !n_records || tr->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_records = 0;
+    if (tr->ncols == 0) {
+        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    const int64_t ncols = tr->ncols;
+    lfq_tracks dev;
+    LFQ_TRY(stage_tracks(c, tr, tracks_on_device, &dev));
+    std::vector<uint8_t> h_ref;
 
     LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
     LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
@@ -594,6 +632,253 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         *stats_out = st;
     }
     return rc;
+}
+
+int lfq_call_indel_tests_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
+                               lfq_indel_call *calls, int64_t calls_capacity, int64_t *n_calls,
+                               lfq_batch_stats *stats_out)
+{
+    if (!c || !conf || !tr || !n_calls || tr->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_calls = 0;
+    if (tr->ncols == 0) {
+        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    const int64_t ncols = tr->ncols;
+    lfq_tracks dev;
+    LFQ_TRY(stage_tracks(c, tr, tracks_on_device, &dev));
+    LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
+    LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
+    LFQ_TRY(lfq_indel_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
+    lfq_batch_stats st;
+    LFQ_TRY(lfq_batch_finish(c, &st));
+    std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
+    if (st.n_pvals > 0) {
+        LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals),
+                              hipMemcpyDeviceToHost));
+    }
+    std::sort(h_pv.begin(), h_pv.end(), [](const lfq_col_pvals &a, const lfq_col_pvals &b) { return a.col < b.col; });
+    int64_t n_out = 0;
+    int rc = LFQ_OK;
+    for (const lfq_col_pvals &r : h_pv) {
+        const long double pv = lfq_pvalue_from_log(r.logp[0], r.status[0]);
+        if (pv * (long long)r.bonf < conf->sig) {                 /* lofreq_call.c:326 / :384 */
+            if (n_out >= calls_capacity) {
+                rc = LFQ_ERR_CAPACITY;
+                break;
+            }
+            lfq_indel_call &o = calls[n_out++];
+            o.test = r.col;
+            o.bonf = r.bonf;
+            o.pvalue = pv;
+            o.qual = (int)(-10.0 * log10l(pv));                   /* PROB_TO_PHREDQUAL, utils.h:45 */
+            o.count = r.counts.alt_counts[0];
+        }
+    }
+    *n_calls = n_out;
+    /* every pseudo-column is one test (lofreq_call.c:693-696, 715-718) */
+    if (conf->bonf_dynamic) {
+        conf->bonf_indel += st.n_tested;
+    }
+    conf->num_indel_tests += st.n_tested;
+    if (stats_out) {
+        *stats_out = st;
+    }
+    return rc;
+}
+
+namespace {
+
+/* pseudo-columns of a run of indel tests, host side */
+struct IndelPack {
+    std::vector<uint8_t> nt, bq, baq, mq, sq, ref;
+    std::vector<uint64_t> off{0};
+    struct Meta {
+        int64_t col;
+        int32_t side, event;
+    };
+    std::vector<Meta> meta;
+    int64_t max_obs = 0;
+    void clear()
+    {
+        nt.clear(); bq.clear(); baq.clear(); mq.clear(); sq.clear(); ref.clear();
+        off.assign(1, 0);
+        meta.clear();
+        max_obs = 0;
+    }
+};
+
+inline uint8_t q8(int q)            /* phred int -> track byte; -1 (n/a) -> 255 */
+{
+    return q < 0 ? (uint8_t)LFQ_Q_MISSING : (uint8_t)std::min(q, 254);
+}
+
+inline int nt4_of(char ch)          /* bam_nt4_table for the letters the poly-AT rule looks at */
+{
+    switch (ch) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return 4;
+    }
+}
+
+/* plp_to_ins_errprobs / plp_to_del_errprobs (snpcaller.c:502-623) as track bytes for one tested event */
+void pack_indel_test(IndelPack &pk, const lfq_indel_columns *b, const lfq_conf *conf, int sd, int64_t c, int64_t ev)
+{
+    const lfq_indel_side &S = b->side[sd];
+    const bool use_mq = (conf->flag & LFQ_USE_MQ) != 0;
+    const bool use_sq = (conf->flag & LFQ_USE_SQ) != 0 && S.rd_sq;
+    const bool use_aq = (conf->flag & LFQ_USE_IDAQ) != 0 && S.rd_aq;
+    for (int64_t i = S.ne_off[c]; i < S.ne_off[c + 1]; i++) {
+        pk.nt.push_back(0);
+        pk.bq.push_back((uint8_t)std::min(std::max((int)S.ne_q[i], 0), 254));
+        pk.baq.push_back(LFQ_Q_MISSING);
+        pk.mq.push_back(use_mq && S.ne_mq ? q8(S.ne_mq[i]) : (uint8_t)LFQ_Q_MISSING);
+        pk.sq.push_back(LFQ_Q_MISSING);
+    }
+    for (int64_t e = S.ev_off[c]; e < S.ev_off[c + 1]; e++) {
+        const bool me = e == ev;                     /* strcmp(it->key, key) == 0 (snpcaller.c:540) */
+        for (int64_t i = S.rd_off[e]; i < S.rd_off[e + 1]; i++) {
+            pk.nt.push_back(me ? 1 : 0);
+            pk.bq.push_back((uint8_t)std::min(std::max((int)S.rd_q[i], 0), 254));
+            pk.baq.push_back(me && use_aq ? q8(S.rd_aq[i]) : (uint8_t)LFQ_Q_MISSING);
+            pk.mq.push_back(use_mq && S.rd_mq ? q8(S.rd_mq[i]) : (uint8_t)LFQ_Q_MISSING);
+            pk.sq.push_back(use_sq ? q8(S.rd_sq[i]) : (uint8_t)LFQ_Q_MISSING);
+        }
+    }
+    const uint64_t end = pk.nt.size();
+    pk.max_obs = std::max<int64_t>(pk.max_obs, (int64_t)(end - pk.off.back()));
+    pk.off.push_back(end);
+    pk.ref.push_back('A');
+    pk.meta.push_back({c, sd, (int32_t)ev});
+}
+
+}  // namespace
+
+int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b, lfq_indel_record *recs,
+                          int64_t cap, int64_t *n_records, int64_t *n_tests_out)
+{
+    if (!c || !conf || !b || !n_records || b->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_records = 0;
+    int64_t n_tests = 0, n_out = 0;
+    IndelPack pk;
+    std::vector<lfq_indel_call> calls;
+    const uint64_t flush_obs = 256u << 20;            /* pseudo-column bytes per track per device batch */
+
+    auto flush = [&]() -> int {
+        if (pk.meta.empty()) {
+            return LFQ_OK;
+        }
+        const size_t pad = 32;
+        for (auto *v : {&pk.nt, &pk.bq, &pk.baq, &pk.mq, &pk.sq}) {
+            v->resize(v->size() + pad, 0);            /* 16-byte tail contract of the track format */
+        }
+        lfq_tracks tr;
+        memset(&tr, 0, sizeof(tr));
+        tr.nt = pk.nt.data();
+        tr.bq = pk.bq.data();
+        tr.baq = pk.baq.data();
+        tr.mq = pk.mq.data();
+        tr.sq = pk.sq.data();
+        tr.col_off = pk.off.data();
+        tr.ref_base = pk.ref.data();
+        tr.ncols = (int64_t)pk.meta.size();
+        tr.max_col_obs = pk.max_obs;
+        calls.resize(pk.meta.size());
+        int64_t nc = 0;
+        lfq_batch_stats st;
+        LFQ_TRY(lfq_call_indel_tests_batch(c, conf, &tr, 0, calls.data(), (int64_t)calls.size(), &nc, &st));
+        if (st.n_tested != (int64_t)pk.meta.size()) {
+            return LFQ_ERR_INVALID;                   /* every packed event must have been a test */
+        }
+        n_tests += st.n_tested;
+        for (int64_t i = 0; i < nc; i++) {
+            const IndelPack::Meta &m = pk.meta[(size_t)calls[i].test];
+            const lfq_indel_side &S = b->side[m.side];
+            if (n_out >= cap) {
+                return LFQ_ERR_CAPACITY;
+            }
+            lfq_indel_record &r = recs[n_out++];
+            memset(&r, 0, sizeof(r));
+            r.col = m.col;
+            r.side = m.side;
+            r.event = m.event;
+            r.qual = calls[i].qual;
+            r.count = calls[i].count;
+            r.bonf = calls[i].bonf;
+            r.pvalue = calls[i].pvalue;
+            r.af = r.count / ((float)b->coverage_plp[m.col] - b->num_tails[m.col]);   /* lofreq_call.c:334 */
+            r.dp = b->coverage_plp[m.col] - b->num_tails[m.col];                       /* lofreq_call.c:132 */
+            r.ref_fw = S.non_fw[m.col];
+            r.ref_rv = S.non_rv[m.col];
+            r.alt_fw = S.ev_fw[m.event];
+            r.alt_rv = S.ev_rv[m.event];
+            r.sb = lfq_sb_phred(r.ref_fw, r.ref_rv, r.alt_fw, r.alt_rv);
+            r.hrun = b->hrun ? b->hrun[m.col] : 0;
+        }
+        pk.clear();
+        return LFQ_OK;
+    };
+
+    for (int64_t col = 0; col < b->ncols; col++) {
+        if (b->ref_base[col] == 'N') {
+            continue;                                                        /* lofreq_call.c:892 */
+        }
+        if (b->num_non_indels[col] + b->num_ins[col] + b->num_dels[col] < conf->min_cov) {
+            continue;                                                        /* :626 */
+        }
+        /* low-AF 1-bp A/T insertion AND deletion of the same base at one column: skipped (:649-681) */
+        bool ign[5] = {false, false, false, false, false};
+        const int64_t ne_ins = b->side[0].ne_off[col + 1] - b->side[0].ne_off[col];
+        const int64_t ne_del = b->side[1].ne_off[col + 1] - b->side[1].ne_off[col];
+        if (b->num_ins[col] && ne_ins && b->num_dels[col] && ne_del) {
+            int cnt[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+            for (int sd = 0; sd < 2; sd++) {
+                const lfq_indel_side &S = b->side[sd];
+                for (int64_t e = S.ev_off[col]; e < S.ev_off[col + 1]; e++) {
+                    const char *key = S.key_chars + S.key_off[e];
+                    if (S.key_off[e + 1] - S.key_off[e] == 1 && (key[0] == 'A' || key[0] == 'T')) {
+                        cnt[sd][nt4_of(key[0])] = (int)(S.rd_off[e + 1] - S.rd_off[e]);
+                    }
+                }
+            }
+            const float denom = (float)(b->coverage_plp[col] - b->num_tails[col]);
+            for (int i = 0; i < 5; i++) {
+                if (cnt[0][i] && cnt[1][i] && cnt[0][i] / denom < 0.05f && cnt[1][i] / denom < 0.05f) {
+                    ign[i] = true;
+                }
+            }
+        }
+        for (int sd = 0; sd < 2; sd++) {
+            const lfq_indel_side &S = b->side[sd];
+            if (!(sd == 0 ? b->num_ins[col] : b->num_dels[col])) {
+                continue;                                                    /* :684 / :706 */
+            }
+            for (int64_t e = S.ev_off[col]; e < S.ev_off[col + 1]; e++) {
+                const char *key = S.key_chars + S.key_off[e];
+                if (S.key_off[e + 1] - S.key_off[e] == 1 && ign[nt4_of(key[0])]) {
+                    continue;                                                /* :687-689 / :709-711 */
+                }
+                pack_indel_test(pk, b, conf, sd, col, e);
+                if (pk.nt.size() >= flush_obs) {
+                    LFQ_TRY(flush());
+                }
+            }
+        }
+    }
+    LFQ_TRY(flush());
+    *n_records = n_out;
+    if (n_tests_out) {
+        *n_tests_out = n_tests;
+    }
+    return LFQ_OK;
 }
 
 int lfq_synth_fill_device(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t plant_period, int64_t col_begin,

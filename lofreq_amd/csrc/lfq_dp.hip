@@ -58,7 +58,7 @@ __device__ __forceinline__ void lfq_col_setup(LfqColCtx &cx, const LfqEntry &en,
     /* running Bonferroni factor at this column (lofreq_call.c:794-800) */
     int64_t bonf = P.bonf_base;
     if (P.bonf_dynamic) {
-        bonf = ((P.bonf_base == 1) ? 0 : P.bonf_base) + 3 * (int64_t)en.prefix;
+        bonf = ((P.bonf_reset_first && P.bonf_base == 1) ? 0 : P.bonf_base) + (int64_t)P.bonf_step * en.prefix;
     }
     cx.bonf = bonf;
     cx.bonf_d = (double)bonf;

@@ -141,6 +141,9 @@ void lfq_conf_init(lfq_conf *c)
     c->sig = 0.01;
     c->flag = LFQ_USE_MQ | LFQ_USE_BAQ;
     c->num_snv_tests = 0;
+    c->bonf_indel = 1;
+    c->num_indel_tests = 0;
+    c->flag |= LFQ_USE_IDAQ;
 }
 
 /* expl() with the reference's clamp (snpcaller.c:1047-1059 / 1169-1188).  For
@@ -368,6 +371,15 @@ int lfq_format_snv_record(char *buf, int buflen, const char *chrom, int64_t pos0
                     chrom, (long)(pos0 + 1), rec->ref, rec->alt, rec->qual,
                     filter_or_null ? filter_or_null : ".", rec->dp, af, rec->sb, rec->ref_fw, rec->ref_rv,
                     rec->alt_fw, rec->alt_rv, rec->hqa);
+}
+
+int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t pos0, const char *ref,
+                            const char *alt, int qual, int dp, float af, int sb, int ref_fw, int ref_rv,
+                            int alt_fw, int alt_rv, int hrun, const char *filter_or_null)
+{
+    return snprintf(buf, (size_t)buflen, "%s\t%ld\t.\t%s\t%s\t%d\t%s\tDP=%d;AF=%f;SB=%d;DP4=%d,%d,%d,%d;INDEL;HRUN=%d\n",
+                    chrom, (long)(pos0 + 1), ref, alt, qual, filter_or_null ? filter_or_null : ".", dp, af, sb,
+                    ref_fw, ref_rv, alt_fw, alt_rv, hrun);
 }
 
 /* many records at once; returns the number of bytes the full text needs (written if it fits) */

@@ -32,7 +32,9 @@ struct LfqParams {
     int32_t min_cov;
     int32_t use_baq, use_mq, use_sq;   /* track present AND enabled by conf->flag */
     int32_t bonf_dynamic;
-    int64_t bonf_base;        /* conf->bonf_subst before this batch */
+    int64_t bonf_base;        /* conf->bonf_subst (or bonf_indel) before this batch */
+    int32_t bonf_step;        /* tests added per tested column: 3 for SNVs (lofreq_call.c:798), 1 for indel tests (:694) */
+    int32_t bonf_reset_first; /* SNVs: the first tested column SETS the factor to 3 instead of adding (lofreq_call.c:795-796) */
     double sig;               /* (double)(float)conf->sig */
     double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
 };

@@ -51,6 +51,9 @@ void orc_conf_init(orc_conf *c)
     c->flag = ORC_USE_MQ | ORC_USE_BAQ;
     c->raw_counts_after_minbq = 0;
     c->num_snv_tests = 0;
+    c->bonf_indel = 1;      /* snpcaller.c:642 */
+    c->num_indel_tests = 0;
+    c->flag |= ORC_USE_IDAQ; /* snpcaller.c:647 */
 }
 
 /* utils.h:42  PHREDQUAL_TO_PROB */
@@ -532,6 +535,178 @@ int orc_call_batch(const uint8_t *nt, const uint8_t *bq, const uint8_t *baq, con
     }
     free(ep);
     return 0;
+}
+
+/* ---- indel path --------------------------------------------------------------------------- */
+
+static int orc_nt4(char c)      /* plp.c:71-88 bam_nt4_table for the letters that matter here */
+{
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return 4;
+    }
+}
+
+/* plp_to_ins_errprobs / plp_to_del_errprobs (snpcaller.c:502-561 / 565-623): all non-event reads
+ * (indel quality + mapping quality, no alignment quality), then the reads of EVERY event of this side;
+ * the alignment quality is only used for the event being tested. */
+static int orc_indel_errprobs(double *ep, const orc_indel_batch *b, int side, int64_t col, int64_t tested_ev,
+                              const orc_conf *conf)
+{
+    int n = 0;
+    int64_t i, e;
+    for (i = b->ne_off[side][col]; i < b->ne_off[side][col + 1]; i++) {
+        int q = b->ne_q[side][i], mq = -1;
+        if (conf->flag & ORC_USE_MQ) {
+            mq = b->ne_mq[side][i];                 /* no 255 -> -1 mapping here (snpcaller.c:523-526) */
+        }
+        ep[n++] = orc_merge_quals(-1, mq, -1, q);
+    }
+    for (e = b->ev_off[side][col]; e < b->ev_off[side][col + 1]; e++) {
+        for (i = b->rd_off[side][e]; i < b->rd_off[side][e + 1]; i++) {
+            int q = b->rd_q[side][i], aq = -1, mq = -1, sq = -1;
+            if ((conf->flag & ORC_USE_IDAQ) && e == tested_ev) {     /* strcmp(it->key, key) == 0 */
+                aq = b->rd_aq[side][i];
+            }
+            if (conf->flag & ORC_USE_MQ) {
+                mq = b->rd_mq[side][i];
+                if (mq == 255) {
+                    mq = -1;
+                }
+            }
+            if (conf->flag & ORC_USE_SQ) {
+                sq = b->rd_sq[side][i];
+            }
+            ep[n++] = orc_merge_quals(sq, mq, aq, q);
+        }
+    }
+    return n;
+}
+
+/* call_indels (lofreq_call.c:619-726) + call_alt_ins/del (:306-426) */
+int orc_call_indels_batch(const orc_indel_batch *b, orc_conf *conf, orc_indel_test *out, int64_t cap,
+                          int64_t *n_out)
+{
+    int64_t c, n_tests = 0, max_reads = 1;
+    double *ep;
+    for (c = 0; c < b->ncols; c++) {
+        int side;
+        for (side = 0; side < 2; side++) {
+            int64_t e0 = b->ev_off[side][c], e1 = b->ev_off[side][c + 1];
+            int64_t m = (b->ne_off[side][c + 1] - b->ne_off[side][c]) + (b->rd_off[side][e1] - b->rd_off[side][e0]);
+            if (m > max_reads) {
+                max_reads = m;
+            }
+        }
+    }
+    ep = malloc(sizeof(double) * (size_t)max_reads);
+    for (c = 0; c < b->ncols; c++) {
+        int ign[5] = {0, 0, 0, 0, 0};
+        int side;
+        const float denom = (float)b->coverage_plp[c] - b->num_tails[c];   /* lofreq_call.c:334, 391 */
+        if (b->ref_base[c] == 'N') {
+            continue;                                                       /* lofreq_call.c:892 */
+        }
+        if (b->num_non_indels[c] + b->num_ins[c] + b->num_dels[c] < conf->min_cov) {
+            continue;                                                       /* :626 */
+        }
+        /* multi-allelic low-AF 1-bp A/T indels next to poly-AT (:649-681) */
+        if (b->num_ins[c] && (b->ne_off[0][c + 1] - b->ne_off[0][c]) && b->num_dels[c]
+            && (b->ne_off[1][c + 1] - b->ne_off[1][c])) {
+            int dict[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+            int i;
+            for (side = 0; side < 2; side++) {
+                int64_t e;
+                for (e = b->ev_off[side][c]; e < b->ev_off[side][c + 1]; e++) {
+                    const char *key = b->key_chars[side] + b->key_off[side][e];
+                    int64_t len = b->key_off[side][e + 1] - b->key_off[side][e];
+                    if (len == 1 && (key[0] == 'A' || key[0] == 'T')) {
+                        dict[side][orc_nt4(key[0])] = (int)(b->rd_off[side][e + 1] - b->rd_off[side][e]);
+                    }
+                }
+            }
+            for (i = 0; i < 5; i++) {
+                if (dict[0][i] && dict[1][i]) {
+                    float ins_af = dict[0][i] / ((float)(b->coverage_plp[c] - b->num_tails[c]));
+                    float del_af = dict[1][i] / ((float)(b->coverage_plp[c] - b->num_tails[c]));
+                    if (ins_af < 0.05f && del_af < 0.05f) {
+                        ign[i] = 1;
+                    }
+                }
+            }
+        }
+        for (side = 0; side < 2; side++) {
+            int64_t e;
+            if (!(side == 0 ? b->num_ins[c] : b->num_dels[c])) {
+                continue;                                                   /* :684, :706 */
+            }
+            for (e = b->ev_off[side][c]; e < b->ev_off[side][c + 1]; e++) {
+                const char *key = b->key_chars[side] + b->key_off[side][e];
+                int64_t len = b->key_off[side][e + 1] - b->key_off[side][e];
+                int counts[3] = {0, 0, 0};
+                long double pv[3];
+                double lp[3];
+                int n, rows;
+                orc_indel_test *t;
+                if (len == 1 && ign[orc_nt4(key[0])]) {
+                    continue;                                               /* :687-689 */
+                }
+                n = orc_indel_errprobs(ep, b, side, c, e, conf);
+                qsort(ep, (size_t)n, sizeof(double), orc_dbl_cmp);         /* :692 */
+                if (conf->bonf_dynamic) {
+                    conf->bonf_indel += 1;                                  /* :693-695 */
+                }
+                conf->num_indel_tests += 1;
+                counts[0] = (int)(b->rd_off[side][e + 1] - b->rd_off[side][e]);   /* it->count */
+                if (orc_snpcaller(pv, lp, ep, n, counts, conf->bonf_indel, (double)conf->sig, &rows)) {
+                    free(ep);
+                    return -1;
+                }
+                if (n_tests >= cap) {
+                    free(ep);
+                    return -4;
+                }
+                t = &out[n_tests++];
+                memset(t, 0, sizeof(*t));
+                t->col = c;
+                t->side = side;
+                t->event = (int32_t)e;
+                t->n_err_probs = n;
+                t->count = counts[0];
+                t->bonf_used = conf->bonf_indel;
+                t->logp = lp[0];
+                t->pvalue = pv[0];
+                t->qual = -1;
+                if (pv[0] * conf->bonf_indel < conf->sig) {                 /* :326 / :384 */
+                    t->emitted = 1;
+                    t->qual = orc_prob_to_phred(pv[0]);
+                    t->af = counts[0] / denom;
+                    t->ref_fw = b->non_fw[side][c];
+                    t->ref_rv = b->non_rv[side][c];
+                    t->alt_fw = b->ev_fw[side][e];
+                    t->alt_rv = b->ev_rv[side][e];
+                    t->sb = orc_sb_phred(t->ref_fw, t->ref_rv, t->alt_fw, t->alt_rv);
+                    t->dp = b->coverage_plp[c] - b->num_tails[c];           /* lofreq_call.c:132 */
+                    t->hrun = b->hrun[c];
+                }
+            }
+        }
+    }
+    free(ep);
+    *n_out = n_tests;
+    return 0;
+}
+
+int orc_format_indel(char *buf, int buflen, const char *chrom, long pos0, const char *ref, const char *alt,
+                     int qual, int dp, float af, int sb, int ref_fw, int ref_rv, int alt_fw, int alt_rv, int hrun,
+                     const char *filter)
+{
+    return snprintf(buf, (size_t)buflen, "%s\t%ld\t.\t%s\t%s\t%d\t%s\tDP=%d;AF=%f;SB=%d;DP4=%d,%d,%d,%d;INDEL;HRUN=%d\n",
+                    chrom, pos0 + 1, ref, alt, qual, filter ? filter : ".", dp, af, sb, ref_fw, ref_rv, alt_fw,
+                    alt_rv, hrun);
 }
 
 /* ---- fet.c: Fisher's exact test (samtools 0.1.18 kfunc) ------------------ */

@@ -32,6 +32,7 @@ class Conf(C.Structure):
         ("bonf_dynamic", C.c_int32), ("min_cov", C.c_int32),
         ("bonf_subst", C.c_int64), ("sig", C.c_float), ("flag", C.c_int32),
         ("raw_counts_after_minbq", C.c_int32), ("num_snv_tests", C.c_int64),
+        ("bonf_indel", C.c_int64), ("num_indel_tests", C.c_int64),
     ]
 
 
@@ -56,6 +57,41 @@ assert COL_RESULT_DTYPE.itemsize == C.sizeof(ColResult), (COL_RESULT_DTYPE.items
 LDBL_MAX = np.finfo(np.longdouble).max
 LDBL_MIN = np.finfo(np.longdouble).tiny
 _ldp = C.POINTER(C.c_longdouble)
+
+
+_i32p, _i16p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int16), C.POINTER(C.c_int64)
+
+
+class IndelBatch(C.Structure):
+    _fields_ = [
+        ("ncols", C.c_int64), ("ref_base", C.POINTER(C.c_uint8)),
+        ("coverage_plp", _i32p), ("num_tails", _i32p), ("num_non_indels", _i32p), ("num_ins", _i32p),
+        ("num_dels", _i32p), ("hrun", _i32p),
+        ("non_fw", _i32p * 2), ("non_rv", _i32p * 2),
+        ("ne_off", _i64p * 2), ("ne_q", _i16p * 2), ("ne_mq", _i16p * 2),
+        ("ev_off", _i64p * 2), ("key_off", _i64p * 2), ("key_chars", C.c_char_p * 2),
+        ("ev_fw", _i32p * 2), ("ev_rv", _i32p * 2),
+        ("rd_off", _i64p * 2), ("rd_q", _i16p * 2), ("rd_aq", _i16p * 2), ("rd_mq", _i16p * 2),
+        ("rd_sq", _i16p * 2),
+    ]
+
+
+class IndelTest(C.Structure):
+    _fields_ = [
+        ("col", C.c_int64), ("side", C.c_int32), ("event", C.c_int32), ("n_err_probs", C.c_int32),
+        ("count", C.c_int32), ("bonf_used", C.c_int64), ("logp", C.c_double), ("pvalue", C.c_longdouble),
+        ("emitted", C.c_int32), ("qual", C.c_int32), ("dp", C.c_int32), ("sb", C.c_int32),
+        ("ref_fw", C.c_int32), ("ref_rv", C.c_int32), ("alt_fw", C.c_int32), ("alt_rv", C.c_int32),
+        ("hrun", C.c_int32), ("af", C.c_float),
+    ]
+
+
+INDEL_TEST_DTYPE = np.dtype([
+    ("col", "i8"), ("side", "i4"), ("event", "i4"), ("n_err_probs", "i4"), ("count", "i4"), ("bonf_used", "i8"),
+    ("logp", "f8"), ("pvalue", np.longdouble), ("emitted", "i4"), ("qual", "i4"), ("dp", "i4"), ("sb", "i4"),
+    ("ref_fw", "i4"), ("ref_rv", "i4"), ("alt_fw", "i4"), ("alt_rv", "i4"), ("hrun", "i4"), ("af", "f4")],
+    align=True)
+assert INDEL_TEST_DTYPE.itemsize == C.sizeof(IndelTest), (INDEL_TEST_DTYPE.itemsize, C.sizeof(IndelTest))
 
 
 class Timing(C.Structure):
@@ -118,6 +154,12 @@ def lib():
         L.orc_default_filter.restype = C.c_int
         L.orc_default_filter.argtypes = [C.POINTER(C.c_int)] * 5 + [C.c_long, C.c_int, C.c_int,
                                                                     C.POINTER(C.c_int)]
+        L.orc_call_indels_batch.restype = C.c_int
+        L.orc_call_indels_batch.argtypes = [C.POINTER(IndelBatch), C.POINTER(Conf), C.POINTER(IndelTest), C.c_int64,
+                                            C.POINTER(C.c_int64)]
+        L.orc_format_indel.restype = C.c_int
+        L.orc_format_indel.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long, C.c_char_p, C.c_char_p, C.c_int,
+                                       C.c_int, C.c_float] + [C.c_int] * 6 + [C.c_char_p]
         L.orc_synth_init_spec.argtypes = [C.POINTER(SynthSpec), C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_synth_fill.argtypes = [C.POINTER(SynthSpec), C.c_int64, C.c_int64, u8p, u8p, u8p, u8p,
                                      C.POINTER(C.c_uint64), u8p]
@@ -204,6 +246,61 @@ def call_batch(nt, bq, baq, mq, sq, col_off, ref_base, conf, coverage_plp=None, 
         raise RuntimeError("orc_call_batch failed: %d" % rc)
     res = np.frombuffer(out, dtype=COL_RESULT_DTYPE, count=max(ncols, 1))[:ncols].copy()
     return res, (tm if timing else None)
+
+
+def call_indels_batch(flat, conf):
+    """flat: dict of numpy arrays as produced by lofreq_amd.indel.IndelColumns.flat() (the flattened indel
+    fields of plp_col_t).  Returns the structured array of performed tests; conf is mutated."""
+    b = IndelBatch()
+    keep = []
+
+    def ptr(a, ct):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+
+    b.ncols = flat["ncols"]
+    b.ref_base = ptr(flat["ref_base"].astype(np.uint8), C.c_uint8)
+    for k in ("coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun"):
+        setattr(b, k, ptr(flat[k].astype(np.int32), C.c_int32))
+    n_ev = 0
+    for s in (0, 1):
+        b.non_fw[s] = ptr(flat["non_fw"][s].astype(np.int32), C.c_int32)
+        b.non_rv[s] = ptr(flat["non_rv"][s].astype(np.int32), C.c_int32)
+        b.ne_off[s] = ptr(flat["ne_off"][s].astype(np.int64), C.c_int64)
+        b.ne_q[s] = ptr(flat["ne_q"][s].astype(np.int16), C.c_int16)
+        b.ne_mq[s] = ptr(flat["ne_mq"][s].astype(np.int16), C.c_int16)
+        b.ev_off[s] = ptr(flat["ev_off"][s].astype(np.int64), C.c_int64)
+        b.key_off[s] = ptr(flat["key_off"][s].astype(np.int64), C.c_int64)
+        kb = bytes(flat["key_chars"][s]) + b"\0"
+        keep.append(kb)
+        b.key_chars[s] = kb
+        b.ev_fw[s] = ptr(flat["ev_fw"][s].astype(np.int32), C.c_int32)
+        b.ev_rv[s] = ptr(flat["ev_rv"][s].astype(np.int32), C.c_int32)
+        b.rd_off[s] = ptr(flat["rd_off"][s].astype(np.int64), C.c_int64)
+        for k in ("rd_q", "rd_aq", "rd_mq", "rd_sq"):
+            getattr(b, k)[s] = ptr(flat[k][s].astype(np.int16), C.c_int16)
+        n_ev += len(flat["rd_off"][s]) - 1
+    out = (IndelTest * max(n_ev, 1))()
+    n = C.c_int64(0)
+    rc = lib().orc_call_indels_batch(C.byref(b), C.byref(conf), out, max(n_ev, 1), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("orc_call_indels_batch failed: %d" % rc)
+    return np.frombuffer(out, dtype=INDEL_TEST_DTYPE, count=max(n_ev, 1))[: n.value].copy()
+
+
+def format_indel(chrom, pos0, ref, alt, t, filter_str=None):
+    """orc_format_indel on one emitted test record"""
+    L = lib()
+    L.orc_format_indel.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_long, C.c_char_p, C.c_char_p, C.c_int,
+                                   C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_char_p]
+    buf = C.create_string_buffer(1024 + len(ref) + len(alt))
+    L.orc_format_indel(buf, len(buf), chrom.encode(), int(pos0), ref.encode(), alt.encode(), int(t["qual"]),
+                       int(t["dp"]), C.c_float(float(t["af"])), int(t["sb"]), int(t["ref_fw"]), int(t["ref_rv"]),
+                       int(t["alt_fw"]), int(t["alt_rv"]), int(t["hrun"]),
+                       None if filter_str is None else filter_str.encode())
+    return buf.value.decode()
 
 
 def synth_fill(seed, depth, plant_period, col_begin, ncols):

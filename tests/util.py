@@ -157,3 +157,50 @@ def assert_pvalue_close(pv_gpu, pv_ref, tol=PV_LOG_TOL, ctx=""):
         return
     d = abs(log_of(pv_gpu) - log_of(pv_ref))
     assert d <= tol, "p-value mismatch %s: gpu=%r ref=%r |dlog|=%g" % (ctx, pv_gpu, pv_ref, d)
+
+
+def random_indel_columns(rng, ncols, depth_lo=20, depth_hi=400, p_event=0.5, polyat=False):
+    """Random indel fields of `ncols` pileup columns (dicts for lofreq_amd.indel.IndelColumns.from_columns)."""
+    cols = []
+    for _ in range(ncols):
+        depth = int(rng.integers(depth_lo, depth_hi + 1))
+        col = {"ref": str(rng.choice(list("ACGTN"), p=[0.24, 0.24, 0.24, 0.24, 0.04])), "hrun": int(rng.integers(0, 9))}
+        tails = int(rng.integers(0, 3))
+        tot_ev = [0, 0]
+        for sd, sn in enumerate(("ins", "dels")):
+            events = []
+            left = depth
+            if rng.random() < p_event:
+                n_ev = int(rng.integers(1, 4))
+                keys = set()
+                for _e in range(n_ev):
+                    klen = 1 if (polyat or rng.random() < 0.5) else int(rng.integers(2, 6))
+                    key = "".join(rng.choice(list("AT" if polyat else "ACGT"), klen))
+                    if key in keys:
+                        continue
+                    keys.add(key)
+                    frac = float(rng.choice([0.005, 0.02, 0.04, 0.1, 0.4]))
+                    cnt = max(1, min(left - 1, int(round(frac * depth * rng.uniform(0.5, 1.5)))))
+                    if cnt <= 0 or left - cnt < 1:
+                        continue
+                    left -= cnt
+                    fw = int(rng.integers(0, cnt + 1))
+                    events.append({
+                        "key": key, "fw": fw, "rv": cnt - fw,
+                        "q": rng.integers(20, 61, cnt).tolist(),
+                        "aq": rng.choice([-1, 10, 25, 40, 60], cnt).tolist(),
+                        "mq": rng.choice([0, 20, 42, 60, 255], cnt, p=[0.02, 0.08, 0.1, 0.78, 0.02]).tolist(),
+                        "sq": rng.choice([-1, 30, 50], cnt).tolist(),
+                    })
+            n_ne = left
+            nfw = int(rng.integers(0, n_ne + 1))
+            col[sn] = {"non_fw": nfw, "non_rv": n_ne - nfw,
+                       "ne_q": rng.integers(25, 61, n_ne).tolist(),
+                       "ne_mq": rng.choice([0, 20, 42, 60, 255], n_ne, p=[0.02, 0.08, 0.1, 0.78, 0.02]).tolist(),
+                       "events": events}
+            tot_ev[sd] = depth - left
+        col["coverage_plp"] = depth + tails
+        col["num_tails"] = tails
+        col["num_non_indels"] = max(depth - tot_ev[0] - tot_ev[1], 0)
+        cols.append(col)
+    return cols
