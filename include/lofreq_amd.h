@@ -248,6 +248,12 @@ int lfq_call_indels_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_indel_columns 
                           lfq_indel_record *records, int64_t records_capacity, int64_t *n_records,
                           int64_t *n_tests);
 
+/* `lofreq filter` as `lofreq call` invokes it, for indel records (lofreq_filter.c:325-335, 210-236, 599-601):
+ * QUAL >= indelqual_thresh (= lfq_snvqual_thresh(sig, bonf_indel), lofreq_call.c:1529-1534; 0 = off), and with
+ * the defaults on, DP >= 10.  The strand-bias filter skips indels by default. keep[i] = 1 for PASS. */
+int lfq_filter_indel_records(const lfq_indel_record *records, int64_t n, int indelqual_thresh, int apply_defaults,
+                             int32_t *keep);
+
 /* vcf_write_var + vcf_var_sprintf_info for an indel record (vcf.c:469-497, 608-629);
  * af = count / ((float)coverage_plp - num_tails), dp = coverage_plp - num_tails (lofreq_call.c:132, 334) */
 int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t pos0, const char *ref,

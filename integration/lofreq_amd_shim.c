@@ -14,8 +14,12 @@
  *   - VCF records reach conf->vcf_out in column order (flush order = arrival order);
  *   - conf->bonf_subst and the global num_snv_tests end up exactly as the per-column loop leaves them
  *     (lofreq_call.c:794-801), so main_call's epilogue (:1506-1564) is unchanged;
- *   - indels (call_indels, :896) are still called on the CPU, per column, as before.
+ *   - indels (call_indels, :896): the indel fields of each column are flattened into an lfq_indel_columns
+ *     batch and go through lfq_call_indels_batch at the same flush; indel records of a column are printed
+ *     before its SNV records, as call_vars does (:896 before :928); conf->bonf_indel, num_indel_tests and
+ *     indel_calls_wo_idaq end up as the per-column loop leaves them.
  */
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -25,10 +29,15 @@
 #include "snpcaller.h"
 #include "vcf.h"
 
+#include "uthash.h"
+#include "utils.h"
+
 extern long long int num_snv_tests;                       /* lofreq_call.c:84 */
-extern void call_indels(const plp_col_t *p, varcall_conf_t *conf);   /* lofreq_call.c:619 */
+extern long long int num_indel_tests;                     /* lofreq_call.c:85 */
+extern long int indel_calls_wo_idaq;                      /* lofreq_call.c:88 */
 
 #define LFQ_BATCH_COLS (1 << 20)        /* flush every 2^20 columns (or at the end) */
+#define LFQ_BATCH_INDEL_READS (1 << 28) /* ... or when the flattened indel columns hold this many reads */
 
 typedef struct {
     lfq_ctx *ctx;
@@ -43,9 +52,190 @@ typedef struct {
     /* per-column metadata needed to print records after the flush */
     char **target;
     int *pos;
+    int64_t *seq;                       /* arrival number of the column (merge key with the indel batch) */
 } lfq_batch;
 
 static lfq_batch B;
+static int64_t g_seq;
+
+/* ---- indel fields of the columns that carry indel events (lfq_indel_columns, flattened) ------------- */
+typedef struct { void *p; int64_t n, cap; size_t elt; } vec;
+#define VEC(T) {NULL, 0, 0, sizeof(T)}
+static void *vpush(vec *v, int64_t k)
+{
+    if (v->n + k > v->cap) {
+        while (v->n + k > v->cap) v->cap = v->cap ? 2 * v->cap : 1024;
+        v->p = realloc(v->p, (size_t)v->cap * v->elt);
+    }
+    v->n += k;
+    return (char *)v->p + (size_t)(v->n - k) * v->elt;
+}
+typedef struct {
+    vec non_fw, non_rv, ne_off, ne_q, ne_mq, ev_off, key_off, key_chars, ev_fw, ev_rv, rd_off, rd_q, rd_aq, rd_mq, rd_sq;
+} side_vecs;
+static struct {
+    vec ref_base, cov, tails, non_indels, num_ins, num_dels, hrun, seq, pos, has_aq;
+    vec target;
+    side_vecs sd[2];
+    int64_t ncols;
+    int init;
+} I;
+
+static void indel_init(void)
+{
+    int s;
+    vec i32 = VEC(int32_t), i64 = VEC(int64_t), i16 = VEC(int16_t), ch = VEC(char), u8 = VEC(uint8_t), ptr = VEC(char *);
+    I.ref_base = u8; I.cov = I.tails = I.non_indels = I.num_ins = I.num_dels = I.hrun = I.pos = I.has_aq = i32;
+    I.seq = i64; I.target = ptr;
+    for (s = 0; s < 2; s++) {
+        side_vecs *v = &I.sd[s];
+        v->non_fw = v->non_rv = v->ev_fw = v->ev_rv = i32;
+        v->ne_off = v->ev_off = v->key_off = v->rd_off = i64;
+        v->ne_q = v->ne_mq = v->rd_q = v->rd_aq = v->rd_mq = v->rd_sq = i16;
+        v->key_chars = ch;
+        *(int64_t *)vpush(&v->ne_off, 1) = 0;
+        *(int64_t *)vpush(&v->ev_off, 1) = 0;
+        *(int64_t *)vpush(&v->key_off, 1) = 0;
+        *(int64_t *)vpush(&v->rd_off, 1) = 0;
+    }
+    I.ncols = 0;
+    I.init = 1;
+}
+
+static void push_quals(vec *v, const int_varray_t *a)
+{
+    unsigned long j;
+    int16_t *d = vpush(v, (int64_t)a->n);
+    for (j = 0; j < a->n; j++) d[j] = (int16_t)a->data[j];
+}
+
+static void push_event(side_vecs *v, const char *key, const long fw_rv[2], const int_varray_t *q,
+                       const int_varray_t *aq, const int_varray_t *mq, const int_varray_t *sq)
+{
+    unsigned long j;
+    size_t kl = strlen(key);
+    int16_t *d;
+    memcpy(vpush(&v->key_chars, (int64_t)kl), key, kl);
+    *(int64_t *)vpush(&v->key_off, 1) = v->key_chars.n;
+    *(int32_t *)vpush(&v->ev_fw, 1) = (int32_t)fw_rv[0];
+    *(int32_t *)vpush(&v->ev_rv, 1) = (int32_t)fw_rv[1];
+    push_quals(&v->rd_q, q);
+    push_quals(&v->rd_mq, mq);
+    d = vpush(&v->rd_aq, (int64_t)q->n);                    /* -1 where the BAM carried no ai/ad tag */
+    for (j = 0; j < q->n; j++) d[j] = (int16_t)(j < aq->n ? aq->data[j] : -1);
+    d = vpush(&v->rd_sq, (int64_t)q->n);
+    for (j = 0; j < q->n; j++) d[j] = (int16_t)(j < sq->n ? sq->data[j] : -1);
+    *(int64_t *)vpush(&v->rd_off, 1) = v->rd_q.n;
+}
+
+/* copy the indel fields of one column (plp.h:113-130) */
+static void indel_add_column(const plp_col_t *p, int64_t seq)
+{
+    ins_event *ie, *ie_tmp;
+    del_event *de, *de_tmp;
+    if (!I.init) indel_init();
+    if (p->num_ins == 0 && p->num_dels == 0) return;        /* no event, no test (lofreq_call.c:684, :706) */
+    *(uint8_t *)vpush(&I.ref_base, 1) = (uint8_t)p->ref_base;
+    *(int32_t *)vpush(&I.cov, 1) = p->coverage_plp;
+    *(int32_t *)vpush(&I.tails, 1) = p->num_tails;
+    *(int32_t *)vpush(&I.non_indels, 1) = p->num_non_indels;
+    *(int32_t *)vpush(&I.num_ins, 1) = p->num_ins;
+    *(int32_t *)vpush(&I.num_dels, 1) = p->num_dels;
+    *(int32_t *)vpush(&I.hrun, 1) = p->hrun;
+    *(int32_t *)vpush(&I.pos, 1) = p->pos;
+    *(int32_t *)vpush(&I.has_aq, 1) = p->has_indel_aqs;
+    *(int64_t *)vpush(&I.seq, 1) = seq;
+    *(char **)vpush(&I.target, 1) = strdup(p->target);
+    *(int32_t *)vpush(&I.sd[0].non_fw, 1) = (int32_t)p->non_ins_fw_rv[0];
+    *(int32_t *)vpush(&I.sd[0].non_rv, 1) = (int32_t)p->non_ins_fw_rv[1];
+    *(int32_t *)vpush(&I.sd[1].non_fw, 1) = (int32_t)p->non_del_fw_rv[0];
+    *(int32_t *)vpush(&I.sd[1].non_rv, 1) = (int32_t)p->non_del_fw_rv[1];
+    push_quals(&I.sd[0].ne_q, &p->ins_quals);
+    push_quals(&I.sd[0].ne_mq, &p->ins_map_quals);
+    push_quals(&I.sd[1].ne_q, &p->del_quals);
+    push_quals(&I.sd[1].ne_mq, &p->del_map_quals);
+    *(int64_t *)vpush(&I.sd[0].ne_off, 1) = I.sd[0].ne_q.n;
+    *(int64_t *)vpush(&I.sd[1].ne_off, 1) = I.sd[1].ne_q.n;
+    HASH_ITER(hh_ins, p->ins_event_counts, ie, ie_tmp) {    /* uthash insertion order = reference order */
+        push_event(&I.sd[0], ie->key, ie->fw_rv, &ie->ins_quals, &ie->ins_aln_quals, &ie->ins_map_quals,
+                   &ie->ins_source_quals);
+    }
+    HASH_ITER(hh_del, p->del_event_counts, de, de_tmp) {
+        push_event(&I.sd[1], de->key, de->fw_rv, &de->del_quals, &de->del_aln_quals, &de->del_map_quals,
+                   &de->del_source_quals);
+    }
+    *(int64_t *)vpush(&I.sd[0].ev_off, 1) = I.sd[0].ev_fw.n;
+    *(int64_t *)vpush(&I.sd[1].ev_off, 1) = I.sd[1].ev_fw.n;
+    I.ncols++;
+}
+
+/* run the flattened indel columns; returns malloc'ed records */
+static lfq_indel_record *indel_flush(varcall_conf_t *conf, lfq_conf *lc, int64_t *n_rec)
+{
+    lfq_indel_columns c;
+    lfq_indel_record *rec;
+    int64_t nev, ntests = 0;
+    int s, rc;
+    *n_rec = 0;
+    if (!I.init || I.ncols == 0) return NULL;
+    memset(&c, 0, sizeof(c));
+    c.ncols = I.ncols;
+    c.ref_base = I.ref_base.p;  c.coverage_plp = I.cov.p;  c.num_tails = I.tails.p;
+    c.num_non_indels = I.non_indels.p;  c.num_ins = I.num_ins.p;  c.num_dels = I.num_dels.p;  c.hrun = I.hrun.p;
+    for (s = 0; s < 2; s++) {
+        side_vecs *v = &I.sd[s];
+        lfq_indel_side *o = &c.side[s];
+        o->non_fw = v->non_fw.p;  o->non_rv = v->non_rv.p;  o->ne_off = v->ne_off.p;  o->ne_q = v->ne_q.p;
+        o->ne_mq = v->ne_mq.p;  o->ev_off = v->ev_off.p;  o->key_off = v->key_off.p;  o->key_chars = v->key_chars.p;
+        o->ev_fw = v->ev_fw.p;  o->ev_rv = v->ev_rv.p;  o->rd_off = v->rd_off.p;  o->rd_q = v->rd_q.p;
+        o->rd_aq = v->rd_aq.p;  o->rd_mq = v->rd_mq.p;  o->rd_sq = v->rd_sq.p;
+    }
+    nev = I.sd[0].ev_fw.n + I.sd[1].ev_fw.n;
+    rec = malloc(sizeof(lfq_indel_record) * (size_t)(nev + 1));
+    rc = lfq_call_indels_batch(B.ctx, lc, &c, rec, nev, n_rec, &ntests);
+    if (rc != LFQ_OK) {
+        LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
+        exit(1);
+    }
+    conf->bonf_indel = lc->bonf_indel;       /* lofreq_call.c:693-695 */
+    num_indel_tests = lc->num_indel_tests;   /* :696 */
+    return rec;
+}
+
+static void indel_print(varcall_conf_t *conf, const lfq_indel_record *r)
+{
+    const side_vecs *v = &I.sd[r->side];
+    const int64_t *koff = v->key_off.p;
+    const int64_t kl = koff[r->event + 1] - koff[r->event];
+    const char rb = (char)((uint8_t *)I.ref_base.p)[r->col];
+    char *ref = malloc((size_t)kl + 2), *alt = malloc((size_t)kl + 2), *line = malloc((size_t)kl * 2 + 1024);
+    ref[0] = alt[0] = rb;                                    /* ins_to_str / del_to_str (lofreq_call.c:255-303) */
+    memcpy((r->side == 0 ? alt : ref) + 1, (const char *)v->key_chars.p + koff[r->event], (size_t)kl);
+    (r->side == 0 ? alt : ref)[kl + 1] = 0;
+    (r->side == 0 ? ref : alt)[1] = 0;
+    lfq_format_indel_record(line, (int)(kl * 2 + 1024), ((char **)I.target.p)[r->col], ((int32_t *)I.pos.p)[r->col],
+                            ref, alt, r->qual, r->dp, r->af, r->sb, r->ref_fw, r->ref_rv, r->alt_fw, r->alt_rv,
+                            r->hrun, NULL);
+    vcf_printf(&conf->vcf_out, "%s", line);
+    if (!((int32_t *)I.has_aq.p)[r->col]) indel_calls_wo_idaq += 1;   /* report_var, lofreq_call.c:109-111 */
+    free(ref); free(alt); free(line);
+}
+
+static void indel_reset(void)
+{
+    int64_t i;
+    int s;
+    for (i = 0; i < I.ncols; i++) free(((char **)I.target.p)[i]);
+    I.ref_base.n = I.cov.n = I.tails.n = I.non_indels.n = I.num_ins.n = I.num_dels.n = I.hrun.n = 0;
+    I.seq.n = I.pos.n = I.has_aq.n = I.target.n = 0;
+    for (s = 0; s < 2; s++) {
+        side_vecs *v = &I.sd[s];
+        v->non_fw.n = v->non_rv.n = v->ne_q.n = v->ne_mq.n = v->key_chars.n = v->ev_fw.n = v->ev_rv.n = 0;
+        v->rd_q.n = v->rd_aq.n = v->rd_mq.n = v->rd_sq.n = 0;
+        v->ne_off.n = v->ev_off.n = v->key_off.n = v->rd_off.n = 1;     /* keep the leading 0 */
+    }
+    I.ncols = 0;
+}
 
 static void grow_obs(int64_t need)
 {
@@ -66,6 +256,7 @@ static void grow_cols(int64_t need)
     B.nbases = realloc(B.nbases, B.cap_cols * sizeof(int32_t));
     B.target = realloc(B.target, B.cap_cols * sizeof(char *));
     B.pos = realloc(B.pos, B.cap_cols * sizeof(int));
+    B.seq = realloc(B.seq, B.cap_cols * sizeof(int64_t));
 }
 
 static void conf_to_lfq(const varcall_conf_t *c, lfq_conf *o)
@@ -74,8 +265,9 @@ static void conf_to_lfq(const varcall_conf_t *c, lfq_conf *o)
     o->min_bq = c->min_bq;       o->min_alt_bq = c->min_alt_bq;   o->def_alt_bq = c->def_alt_bq;
     o->min_jq = c->min_jq;       o->min_alt_jq = c->min_alt_jq;   o->def_alt_jq = c->def_alt_jq;
     o->bonf_dynamic = c->bonf_dynamic;  o->min_cov = c->min_cov;  o->bonf_subst = c->bonf_subst;
-    o->sig = c->sig;             o->flag = c->flag & (LFQ_USE_BAQ | LFQ_USE_MQ | LFQ_USE_SQ);
+    o->sig = c->sig;             o->flag = c->flag & (LFQ_USE_BAQ | LFQ_USE_MQ | LFQ_USE_SQ | LFQ_USE_IDAQ);
     o->num_snv_tests = num_snv_tests;
+    o->bonf_indel = c->bonf_indel;      o->num_indel_tests = num_indel_tests;
 }
 
 /* call after mpileup() returns, and whenever the batch is full */
@@ -83,17 +275,20 @@ void lfq_call_flush(varcall_conf_t *conf)
 {
     lfq_conf lc;
     lfq_tracks t;
-    lfq_snv_record *rec;
-    int64_t n_rec = 0, i;
+    lfq_snv_record *rec = NULL;
+    lfq_indel_record *irec;
+    int64_t n_rec = 0, n_irec = 0, i, k;
     int rc;
 
-    if (B.ncols == 0) return;
+    if (B.ncols == 0 && (!I.init || I.ncols == 0)) return;
     if (!B.ctx && lfq_create(&B.ctx, 0) != LFQ_OK) {
         LOG_FATAL("%s\n", "lofreq_amd: no usable MI355X / HIP device");
         exit(1);
     }
-    B.col_off[B.ncols] = (uint64_t)B.nobs;
     conf_to_lfq(conf, &lc);
+    irec = indel_flush(conf, &lc, &n_irec);
+    if (B.ncols == 0) goto print;
+    B.col_off[B.ncols] = (uint64_t)B.nobs;
     memset(&t, 0, sizeof(t));
     t.nt = B.nt; t.bq = B.bq; t.mq = B.mq;
     t.baq = B.use_baq ? B.baq : NULL;
@@ -108,14 +303,25 @@ void lfq_call_flush(varcall_conf_t *conf)
         LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
         exit(1);
     }
-    for (i = 0; i < n_rec; i++) {           /* vcf_write_var (vcf.c:469-497), FILTER '.' like report_var */
-        char line[512];
-        lfq_format_snv_record(line, sizeof(line), B.target[rec[i].col], B.pos[rec[i].col], &rec[i], NULL);
-        vcf_printf(&conf->vcf_out, "%s", line);
-    }
-    free(rec);
     conf->bonf_subst = lc.bonf_subst;        /* lofreq_call.c:794-800 */
     num_snv_tests = lc.num_snv_tests;        /* lofreq_call.c:801 */
+print:
+    /* merge by arrival number; a column's indel records precede its SNV records (call_vars :896 / :928) */
+    for (i = 0, k = 0; i < n_rec || k < n_irec;) {
+        const int64_t s_snv = i < n_rec ? B.seq[rec[i].col] : INT64_MAX;
+        const int64_t s_ind = k < n_irec ? ((int64_t *)I.seq.p)[irec[k].col] : INT64_MAX;
+        if (s_ind <= s_snv) {
+            indel_print(conf, &irec[k++]);
+        } else {                            /* vcf_write_var (vcf.c:469-497), FILTER '.' like report_var */
+            char line[512];
+            lfq_format_snv_record(line, sizeof(line), B.target[rec[i].col], B.pos[rec[i].col], &rec[i], NULL);
+            vcf_printf(&conf->vcf_out, "%s", line);
+            i++;
+        }
+    }
+    free(rec);
+    free(irec);
+    if (I.init) indel_reset();
     for (i = 0; i < B.ncols; i++) free(B.target[i]);
     B.ncols = 0; B.nobs = 0; B.max_depth = 0;
 }
@@ -129,9 +335,10 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
     int64_t depth = 0, c;
 
     if (p->ref_base == 'N') return;                                   /* lofreq_call.c:892 */
-    if (!conf->no_indels) call_indels(p, conf);                       /* :896, unchanged, CPU */
-    if (conf->only_indels) return;                                    /* :928 */
-    if (p->cons_base[0] == '+' || p->cons_base[0] == '-') return;     /* :929 */
+    g_seq++;
+    if (!conf->no_indels) indel_add_column(p, g_seq);                 /* :896 */
+    if (conf->only_indels) goto maybe_flush;                          /* :928 */
+    if (p->cons_base[0] == '+' || p->cons_base[0] == '-') goto maybe_flush;   /* :929 */
     /* the remaining gates (:930 num_bases*2 < coverage_plp, :747 min_cov, :754) run on the device */
 
     for (i = 0; i < NUM_NT4; i++) depth += p->base_quals[i].n;
@@ -144,6 +351,7 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
     B.nbases[c] = p->num_bases;
     B.target[c] = strdup(p->target);
     B.pos[c] = p->pos;
+    B.seq[c] = g_seq;
     for (i = 0; i < NUM_NT4; i++) {            /* plp_col_t keeps one int array per nucleotide (plp.h:88-91) */
         const long fw = p->fw_counts[i];       /* strand only matters as a count: forward reads first */
         for (j = 0; j < p->base_quals[i].n; j++) {
@@ -162,7 +370,10 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
     }
     if (depth > B.max_depth) B.max_depth = depth;
     B.ncols++;
-    if (B.ncols >= LFQ_BATCH_COLS) lfq_call_flush(conf);
+maybe_flush:
+    if (B.ncols >= LFQ_BATCH_COLS || (I.init && I.sd[0].ne_q.n + I.sd[1].ne_q.n >= LFQ_BATCH_INDEL_READS)) {
+        lfq_call_flush(conf);
+    }
 }
 
 void lfq_call_shutdown(void)

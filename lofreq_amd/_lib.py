@@ -96,6 +96,7 @@ EXPORTS = [
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
+    "lfq_filter_indel_records",
 ]
 
 _lib = None
@@ -156,6 +157,7 @@ def load():
                                              C.POINTER(C.c_int64), C.POINTER(BatchStats)]
     L.lfq_call_indels_batch.argtypes = [vp, C.POINTER(Conf), C.POINTER(IndelColumnsC), vp, C.c_int64,
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.lfq_filter_indel_records.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_char_p]

@@ -373,6 +373,25 @@ int lfq_format_snv_record(char *buf, int buflen, const char *chrom, int64_t pos0
                     rec->alt_fw, rec->alt_rv, rec->hqa);
 }
 
+int lfq_filter_indel_records(const lfq_indel_record *recs, int64_t n, int indelqual_thresh, int apply_defaults,
+                             int32_t *keep)
+{
+    if (n < 0 || (n > 0 && (!recs || !keep))) {
+        return LFQ_ERR_INVALID;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        bool ok = true;
+        if (indelqual_thresh > 0 && recs[i].qual > -1 && recs[i].qual < indelqual_thresh) {
+            ok = false;                                   /* apply_indelqual_threshold */
+        }
+        if (apply_defaults && recs[i].dp < 10) {
+            ok = false;                                   /* DEFAULT_MIN_COV, lofreq_filter.c:210-236 */
+        }
+        keep[i] = ok ? 1 : 0;
+    }
+    return LFQ_OK;
+}
+
 int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t pos0, const char *ref,
                             const char *alt, int qual, int dp, float af, int sb, int ref_fw, int ref_rv,
                             int alt_fw, int alt_rv, int hrun, const char *filter_or_null)

@@ -136,3 +136,13 @@ def format_indel_record(chrom, pos0, cols, r, filter_str=None):
                               int(r["ref_rv"]), int(r["alt_fw"]), int(r["alt_rv"]), int(r["hrun"]),
                               None if filter_str is None else filter_str.encode())
     return buf.value.decode()
+
+
+def filter_indel_records(recs, indelqual_thresh, apply_defaults=True):
+    """keep mask of `lofreq filter` as run by `lofreq call` on indel records"""
+    keep = np.zeros(len(recs), np.int32)
+    recs = np.ascontiguousarray(recs)
+    _lib.check(_lib.load().lfq_filter_indel_records(recs.ctypes.data, len(recs), int(indelqual_thresh),
+                                                    1 if apply_defaults else 0, keep.ctypes.data),
+               "lfq_filter_indel_records")
+    return keep.astype(bool)

@@ -114,7 +114,189 @@ def run(name, seed, glen, nreads, planted, mapqs, call_args):
                                                                     os.path.getsize(path)))
 
 
+# ---- indel fixtures ---------------------------------------------------------------------------------
+
+def write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.0008):
+    """sites: {pos0: [(kind, key_or_len, frac), ...]}; kind '+' inserts key after pos0, '-' deletes len
+    bases after pos0.  Per-base BI/BD indel qualities are random.  Returns (genome, reads)."""
+    rng = np.random.default_rng(seed)
+    genome = "".join(rng.choice(list("ACGT"), glen))
+    # a few homopolymer runs so that HRUN varies
+    g = list(genome)
+    for p0 in range(40, glen - 20, 55):
+        g[p0:p0 + 5] = g[p0] * 5
+    genome = "".join(g)
+    open(os.path.join(tmp, "t.fa"), "w").write(">chr1\n" + genome + "\n")
+    rl = 90
+    reads = []
+    for _ in range(nreads):
+        pos = int(rng.integers(0, glen - rl - 12))
+        seq, cigar, run, gp = [], [], 0, pos
+        while len(seq) < rl and gp < glen - 8:
+            seq.append(genome[gp])
+            run += 1
+            ev = None
+            if run > 4 and len(seq) < rl - 8:
+                for kind, k, frac in sites.get(gp, []):
+                    if rng.random() < frac:
+                        ev = (kind, k)
+                        break
+                if ev is None and rng.random() < noise:
+                    ev = ("+", str(rng.choice(list("ACGT")))) if rng.random() < 0.5 else ("-", 1)
+            if ev:
+                cigar.append("%dM" % run)
+                run = 0
+                if ev[0] == "+":
+                    seq.extend(ev[1])
+                    cigar.append("%dI" % len(ev[1]))
+                else:
+                    cigar.append("%dD" % ev[1])
+                    gp += ev[1]
+            gp += 1
+        if run == 0:
+            continue
+        cigar.append("%dM" % run)
+        n = len(seq)
+        qual = "".join(chr(33 + int(q)) for q in np.clip(np.round(rng.normal(35, 4, n)), 8, 41))
+        bi = "".join(chr(33 + int(q)) for q in rng.integers(25, 50, n))
+        bd = "".join(chr(33 + int(q)) for q in rng.integers(25, 50, n))
+        flag = 16 if rng.random() < 0.5 else 0
+        reads.append((pos, flag, int(rng.choice(mapqs)), "".join(cigar), "".join(seq), qual, bi, bd))
+    reads.sort()
+    with open(os.path.join(tmp, "t.sam"), "w") as f:
+        f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % glen)
+        for i, (pos, flag, mapq, cg, sq, q, bi, bd) in enumerate(reads):
+            f.write("r%d\t%d\tchr1\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tBI:Z:%s\tBD:Z:%s\n"
+                    % (i, flag, pos + 1, mapq, cg, sq, q, bi, bd))
+    return genome, reads
+
+
+def indel_strands(genome, reads):
+    """Independent of the reference: per column, strands of reads overlapping it and of reads carrying an
+    insertion / deletion right after it.  -> {pos0: {"cov": [fw, rv], "+": {key: [fw, rv]}, "-": {...}}}"""
+    import re
+    out = {}
+    for pos, flag, _mq, cg, seq, *_ in reads:
+        st = 1 if flag & 16 else 0
+        gp, qp, last = pos, 0, None
+        for n, op in re.findall(r"(\d+)([MID])", cg):
+            n = int(n)
+            if op == "M":
+                for k in range(n):
+                    out.setdefault(gp + k, {"cov": [0, 0], "+": {}, "-": {}})["cov"][st] += 1
+                gp += n
+                qp += n
+                last = gp - 1
+            elif op == "I":
+                out[last]["+"].setdefault(seq[qp:qp + n], [0, 0])[st] += 1
+                qp += n
+            else:
+                out[last]["-"].setdefault(genome[gp:gp + n], [0, 0])[st] += 1
+                for k in range(n):     # deleted bases still count as pileup coverage (is_del)
+                    out.setdefault(gp + k, {"cov": [0, 0], "+": {}, "-": {}})["cov"][st] += 1
+                gp += n
+    return out
+
+
+def parse_plpsummary_indels(text):
+    cols, cur = [], None
+    for line in text.splitlines():
+        if not line.strip():
+            continue
+        if not line.startswith(" "):
+            f = line.split("\t")
+            cur = {"pos0": int(f[1]) - 1, "ref": f[2]}
+            for tok in f[9:]:
+                k, v = tok.split(":")
+                cur[k] = int(v)
+            cur["ins"] = {"ne": {}, "events": []}
+            cur["dels"] = {"ne": {}, "events": []}
+            cols.append(cur)
+            continue
+        f = line.strip().split("\t")
+        key = f[0]
+        if key[0] not in "+-":
+            continue
+        side = cur["ins"] if key[0] == "+" else cur["dels"]
+        track = f[1].split("=")[0].strip()
+        vals = [int(x) for x in f[2].split()] if len(f) > 2 else []
+        if key[1:] == "0":
+            side["ne"][track] = vals
+        else:
+            if not side["events"] or side["events"][-1]["key"] != key[1:]:
+                side["events"].append({"key": key[1:]})
+            side["events"][-1][track] = vals
+    return cols
+
+
+def run_indel(name, seed, glen, nreads, sites, mapqs, call_args, alnqual=True):
+    with tempfile.TemporaryDirectory() as tmp:
+        genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        bam = "t.sam"
+        if alnqual:
+            with open(os.path.join(tmp, "t.aq.bam"), "wb") as f:
+                subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
+            bam = "t.aq.bam"
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", bam], cwd=tmp, check=True, capture_output=True,
+                             text=True).stdout
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
+        res = subprocess.run([LOFREQ, "call", "--call-indels", "--only-indels", "-f", "t.fa", "-o", "out.vcf"]
+                             + call_args + [bam], cwd=tmp, check=True, capture_output=True, text=True, env=env)
+        ntests = None
+        for line in res.stderr.splitlines():
+            if "Number of indel tests performed" in line:
+                ntests = int(line.split(":")[-1])
+        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+    strands = indel_strands(genome, reads)
+    packed = []
+    for c in parse_plpsummary_indels(plp):
+        if not (c["ins"]["events"] or c["dels"]["events"]):
+            continue
+        s = strands[c["pos0"]]
+        col = {"pos0": c["pos0"], "ref": c["ref"], "num_tails": c["tails"], "hrun": c["hrun"]}
+        n_ins = sum(len(e["IQ"]) for e in c["ins"]["events"])
+        n_del = sum(len(e["IDQ"]) for e in c["dels"]["events"])
+        col["num_ins"], col["num_dels"] = n_ins, n_del
+        col["coverage_plp"] = len(c["ins"]["ne"].get("IDQ", [])) + n_ins
+        assert col["coverage_plp"] == len(c["dels"]["ne"].get("IDQ", [])) + n_del == sum(s["cov"]), (c["pos0"],)
+        col["num_non_indels"] = col["coverage_plp"] - n_ins - n_del
+        for sn, sign, qk in (("ins", "+", "IQ"), ("dels", "-", "IDQ")):
+            ev_fw = sum(v[0] for v in s[sign].values())
+            ev_rv = sum(v[1] for v in s[sign].values())
+            side = {"non_fw": s["cov"][0] - ev_fw, "non_rv": s["cov"][1] - ev_rv,
+                    "ne_q": enc(c[sn]["ne"].get("IDQ", [])), "ne_mq": c[sn]["ne"].get("MQ", []), "events": []}
+            for e in c[sn]["events"]:
+                fw, rv = s[sign][e["key"]]
+                assert fw + rv == len(e[qk]), (c["pos0"], e["key"])
+                side["events"].append({"key": e["key"], "fw": fw, "rv": rv, "q": enc(e[qk]), "aq": enc(e["AQ"]),
+                                       "mq": e["MQ"], "sq": enc(e["SQ"])})
+            col[sn] = side
+        packed.append(col)
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "call_args": ["--call-indels", "--only-indels"] + call_args, "alnqual": alnqual, "columns": packed,
+           "vcf": vcf, "num_indel_tests": ntests}
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d indel columns, %d vcf records, %s tests, %d bytes" % (name, len(packed), len(vcf), ntests,
+                                                                          os.path.getsize(path)))
+
+
+def main_indels():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
+             160: [("-", 1, 0.02), ("+", "T", 0.02)], 190: [("+", "A", 0.5)], 215: [("-", 2, 0.01)],
+             240: [("-", 5, 0.3), ("+", "CCCC", 0.05)]}
+    run_indel("indel_default", 21, 330, 900, sites, mq_mix, ["--no-default-filter"])
+    run_indel("indel_fixedbonf_noidaq", 22, 330, 900, sites, mq_mix, ["--no-default-filter", "-b", "100", "-A"])
+    run_indel("indel_default_filter", 23, 330, 700, sites, [60] * 10 + [20], [])
+
+
 def main():
+    if "--indels-only" in sys.argv:
+        return main_indels()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
@@ -130,6 +312,7 @@ def main():
     run("snv_deep", 14, 160, 1800, planted_b, [60] * 12 + [50, 3], ["--no-default-filter", "-b", "480"])
     run("snv_minbq_sig", 15, 220, 600, planted_a, mq_mix, ["-q", "20", "-Q", "25", "-a", "0.001", "-b", "660",
                                                          "--no-default-filter"])
+    main_indels()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,28 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def fixtures():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "snv_*.json")))
+
+
+def indel_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "indel_*.json")))
+
+
+def load_indels(path):
+    """-> (fixture dict, column dicts for lofreq_amd.indel.IndelColumns.from_columns)"""
+    fx = json.load(open(path))
+    cols = []
+    for c in fx["columns"]:
+        d = {k: c[k] for k in ("ref", "coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun")}
+        for sn in ("ins", "dels"):
+            s = c[sn]
+            d[sn] = {"non_fw": s["non_fw"], "non_rv": s["non_rv"], "ne_q": dec(s["ne_q"]).tolist(),
+                     "ne_mq": s["ne_mq"],
+                     "events": [{"key": e["key"], "fw": e["fw"], "rv": e["rv"], "q": dec(e["q"]).tolist(),
+                                 "aq": dec(e["aq"]).tolist(), "mq": e["mq"], "sq": dec(e["sq"]).tolist()}
+                                for e in s["events"]]}
+        cols.append(d)
+    return fx, cols
 
 
 def dec(s):
@@ -56,6 +77,12 @@ def conf_kwargs(call_args):
     for a in it:
         if a == "--no-default-filter":
             no_default_filter = True
+        elif a == "--call-indels":
+            flag |= 8                       # VARCALL_USE_IDAQ stays on only when indels are called (:1325-1328)
+        elif a == "--only-indels":
+            pass
+        elif a == "-A":
+            flag &= ~8
         elif a == "-b":
             kw["bonf_dynamic"] = 0
             kw["bonf_subst"] = int(next(it))

@@ -59,3 +59,30 @@ def test_oracle_reproduces_reference_binary(oracle, path):
                              r["alt_rv"], r["hqa"], 0, filt.encode())
         lines.append(bytes(buf[:n]).decode().rstrip("\n"))
     assert lines == fx["vcf"]
+
+
+@pytest.mark.parametrize("path", gu.indel_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_oracle_reproduces_reference_binary_indels(oracle, path):
+    """call_indels restatement vs the 2.1.4 binary: indel VCF records byte-for-byte and the test count"""
+    from lofreq_amd.indel import IndelColumns
+    fx, dicts = gu.load_indels(path)
+    cols = IndelColumns.from_columns(dicts)
+    kw, no_default_filter = gu.conf_kwargs(fx["call_args"])
+    kw.pop("bonf_subst", None)                       # -b does not touch bonf_indel (lofreq_call.c, snpcaller.c:642)
+    conf = oracle.default_conf(**kw)
+    tests = oracle.call_indels_batch(cols.flat(), conf)
+    assert conf.num_indel_tests == fx["num_indel_tests"] == len(tests)
+    dynamic = bool(conf.bonf_dynamic)
+    direct = no_default_filter and not dynamic
+    thr = oracle.lib().orc_snvqual_thresh(conf.sig, conf.bonf_indel) if dynamic else 0
+    lines = []
+    for t in tests[tests["emitted"] == 1]:
+        if not direct:
+            if thr > 0 and t["qual"] < thr:
+                continue
+            if not no_default_filter and t["dp"] < 10:
+                continue
+        ref, alt = cols.ref_alt(int(t["col"]), int(t["side"]), int(t["event"]))
+        lines.append(oracle.format_indel("chr1", fx["columns"][int(t["col"])]["pos0"], ref, alt, t,
+                                         None if direct else "PASS").rstrip("\n"))
+    assert lines == fx["vcf"]

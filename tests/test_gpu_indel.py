@@ -88,3 +88,30 @@ def test_indel_empty(caller):
     conf = la.VarcallConf()
     recs, n = la.call_indels(caller, cols, conf)
     assert len(recs) == 0 and n == 0 and conf.bonf_indel == 1
+
+
+def test_indel_golden_reference_binary_vcf(caller):
+    """the HIP path alone against the VCFs the reference's own 2.1.4 binary wrote (tests/golden/indel_*.json)"""
+    import golden_util as gu
+    import lofreq_amd as la
+    paths = gu.indel_fixtures()
+    assert len(paths) >= 3
+    for path in paths:
+        fx, dicts = gu.load_indels(path)
+        cols = la.IndelColumns.from_columns(dicts)
+        kw, no_default_filter = gu.conf_kwargs(fx["call_args"])
+        kw.pop("bonf_subst", None)
+        conf = la.VarcallConf(**kw)
+        recs, ntests = la.call_indels(caller, cols, conf)
+        assert ntests == fx["num_indel_tests"] == conf.num_indel_tests, path
+        dynamic = bool(conf.bonf_dynamic)
+        direct = no_default_filter and not dynamic
+        if direct:
+            keep = np.ones(len(recs), bool)
+        else:
+            thr = la.snvqual_thresh(conf.sig, conf.bonf_indel) if dynamic else 0
+            keep = la.filter_indel_records(recs, thr, apply_defaults=not no_default_filter)
+        lines = [la.format_indel_record("chr1", fx["columns"][int(r["col"])]["pos0"], cols, r,
+                                        None if direct else "PASS").rstrip("\n")
+                 for r, k in zip(recs, keep) if k]
+        assert lines == fx["vcf"], path
