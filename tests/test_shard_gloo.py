@@ -93,3 +93,64 @@ def test_shard_ranges():
     from lofreq_amd import shard
     assert shard.shard_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
     assert shard.shard_ranges(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def _indel_scenario(la):
+    """emitted-candidate indel records of a 600-column run with their single-process running factors"""
+    rng = np.random.default_rng(77)
+    ncols = 600
+    tests_per_col = rng.choice([0, 0, 1, 2, 3], ncols)
+    first_test = np.concatenate([[0], np.cumsum(tests_per_col)])      # tests before column c
+    recs = []
+    for c in range(ncols):
+        for e in range(tests_per_col[c]):
+            if rng.random() < 0.5:
+                r = np.zeros(1, la.INDEL_RECORD_DTYPE)
+                r["col"], r["side"], r["event"] = c, e & 1, e
+                r["bonf"] = 1 + first_test[c] + e + 1                 # bonf_indel after this test's increment
+                # p-values straddling sig / bonf so that the exact factor matters
+                r["pvalue"] = np.longdouble(0.01) / np.longdouble(rng.uniform(0.2, 3.0) * (first_test[c] + 2))
+                r["qual"] = int(-10 * np.log10(float(r["pvalue"][0])))
+                recs.append(r)
+    return ncols, tests_per_col, first_test, np.concatenate(recs)
+
+
+def _indel_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    ncols, tpc, first, recs = _indel_scenario(la)
+    lo, hi = shard.shard_ranges(ncols, world)[rank]
+    mine = recs[(recs["col"] >= lo) & (recs["col"] < hi)].copy()
+    mine["col"] -= lo
+    mine["bonf"] -= int(first[lo])                  # the shard's local running factor
+    # what the local emit test (local factor) would have passed on to us
+    mine = mine[mine["pvalue"] * mine["bonf"].astype(np.longdouble) < np.float32(0.01)]
+    conf = la.VarcallConf()
+    n_local = int(tpc[lo:hi].sum())
+    conf.c.bonf_indel += n_local                    # as lfq_call_indels_batch leaves it
+    conf.c.num_indel_tests += n_local
+    got, total = shard.finish_indel_shard(conf, 1, mine, n_local, lo, dist, None)
+    if rank == 0:
+        np.save(out, got.view(np.uint8))
+        np.save(out + ".meta", np.array([total, conf.bonf_indel, conf.num_indel_tests]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_indels_equal_single_process(tmp_path, world):
+    import lofreq_amd as la
+    out = str(tmp_path / "irecs.npy")
+    mp.spawn(_indel_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out).view(la.INDEL_RECORD_DTYPE)
+    total, bonf, ntests = np.load(out + ".meta.npy")
+    ncols, tpc, first, recs = _indel_scenario(la)
+    exp = recs[recs["pvalue"] * recs["bonf"].astype(np.longdouble) < np.float32(0.01)]
+    assert total == ntests == int(tpc.sum()) and bonf == 1 + int(tpc.sum())
+    assert 5 < len(exp) < len(recs)
+    assert len(got) == len(exp)
+    for k in la.INDEL_RECORD_DTYPE.names:            # field-wise: the long double carries 6 padding bytes
+        assert (got[k] == exp[k]).all(), k
