@@ -46,6 +46,8 @@ struct lfq_ctx {
     LfqEntry *d_entries;
     hipStream_t dps;           /* scan + light DP of a segment, beside the next segment's count kernel */
     hipStream_t side[2];       /* big / mid DP kernels run beside the light one */
+    hipStream_t aux[2];        /* second row-segment class of each side stream */
+    hipEvent_t ev_aux[2], ev_mid;
     hipEvent_t ev_cnt[LFQ_MAX_SEGMENTS][2];    /* count kernel of segment s: start, stop (main stream) */
     hipEvent_t ev_scan[LFQ_MAX_SEGMENTS];      /* work lists of segment s ready (dps) */
     hipEvent_t ev_light[LFQ_MAX_SEGMENTS][2];  /* light kernel (dps) */
@@ -55,6 +57,11 @@ struct lfq_ctx {
     uint64_t *d_tiles;
     double *d_scratch;
     int64_t scratch_doubles;
+    LfqLong *d_longs;             /* row-split columns (lfq_internal.h) */
+    LfqSegCell *d_pool;
+    int32_t long_cap, pool_cells;
+    hipEvent_t ev_segw, ev_prep;
+    int32_t *d_unsplit;
     int32_t *h_counters;   /* pinned */
     /* layer-2 owned outputs / staging */
     lfq_col_counts *d_counts;
@@ -189,6 +196,8 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         if (c->d_prefix) (void)hipFree(c->d_prefix);
         if (c->d_entries) (void)hipFree(c->d_entries);
         if (c->d_tiles) (void)hipFree(c->d_tiles);
+        if (c->d_unsplit) (void)hipFree(c->d_unsplit);
+        c->d_unsplit = nullptr;
         c->d_flags = nullptr;
         c->d_prefix = nullptr;
         c->d_entries = nullptr;
@@ -201,6 +210,8 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         LFQ_TRY(grow(&c->d_entries, &cap, want));
         cap = 0;
         LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8 * (LFQ_MAX_SEGMENTS + 1))));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_unsplit, &cap, want));
         c->ws_cols = want;
     }
     return LFQ_OK;
@@ -246,7 +257,9 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     ok = ok && hipStreamCreateWithPriority(&c->dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
     for (int i = 0; ok && i < 2; i++) {
-        ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
+        ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess
+             && hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_hi) == hipSuccess
+             && hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) == hipSuccess;
     }
     for (int i = 0; ok && i < 3; i++) {
         ok = hipEventCreate(&c->ev_join[i]) == hipSuccess;
@@ -279,7 +292,7 @@ void lfq_destroy(lfq_ctx *c)
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_entries, c->d_counters, c->d_tiles,
+    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_entries, c->d_counters, c->d_tiles, c->d_longs, c->d_pool, c->d_unsplit,
                     c->d_scratch, c->d_counts, c->d_pvals, c->d_stage};
     for (void *b : bufs) {
         if (b) (void)hipFree(b);
@@ -290,6 +303,9 @@ void lfq_destroy(lfq_ctx *c)
     }
     for (int i = 0; i < 3; i++) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (i == 0 && c->ev_segw) (void)hipEventDestroy(c->ev_segw);
+        if (i == 0 && c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+        if (i == 0 && c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     }
     for (int s = 0; s < LFQ_MAX_SEGMENTS; s++) {
         hipEvent_t evs[] = {c->ev_cnt[s][0], c->ev_cnt[s][1], c->ev_scan[s], c->ev_light[s][0], c->ev_light[s][1],
@@ -300,6 +316,8 @@ void lfq_destroy(lfq_ctx *c)
     }
     for (int i = 0; i < 2; i++) {
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+        if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+        if (c->ev_aux[i]) (void)hipEventDestroy(c->ev_aux[i]);
     }
     if (c->dps) (void)hipStreamDestroy(c->dps);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -376,6 +394,20 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         n_big_blocks = (int)std::max<int64_t>(8, budget / per_block);
     }
     LFQ_TRY(grow(&c->d_scratch, &c->scratch_doubles, per_block * n_big_blocks));
+    if (!c->d_longs) {
+        /* row-split bookkeeping: 64 Ki column records, 8 Mi segment cells (128 MiB); a column that does not
+         * get its cells simply runs unsplit */
+        c->long_cap = 1 << 16;
+        c->pool_cells = 8 << 20;
+        if (const char *e = getenv("LFQ_SPLIT_POOL_CELLS")) {
+            c->pool_cells = std::max(0, atoi(e));               /* 0 disables row splitting */
+        }
+        LFQ_TRY_HIP(hipMalloc((void **)&c->d_longs, (size_t)c->long_cap * sizeof(LfqLong)));
+        LFQ_TRY_HIP(hipMalloc((void **)&c->d_pool, (size_t)std::max(c->pool_cells, 1) * sizeof(LfqSegCell)));
+        LFQ_TRY_HIP(hipEventCreateWithFlags(&c->ev_segw, hipEventDisableTiming));
+        LFQ_TRY_HIP(hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming));
+        LFQ_TRY_HIP(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+    }
 
     /* Segments: the count kernel is HBM-bound and leaves the VALUs mostly idle, the DP kernels are
      * latency/issue-bound and touch little memory.  Cutting the batch into segments lets the DP of
@@ -399,6 +431,11 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         W.counters = c->d_counters + s * LFQ_NCOUNTERS;
         W.gcounters = gcounters;
         W.block_sums = (int32_t *)(c->d_tiles + 2 * (c0 / 4096 + 8 * s));
+        W.long_cap = c->long_cap / n_seg;
+        W.pool_cells = c->pool_cells / n_seg;
+        W.longs = c->d_longs + (int64_t)s * W.long_cap;
+        W.pool = c->d_pool + (int64_t)s * W.pool_cells;
+        W.unsplit = c->d_unsplit + c0;
 
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
         LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, st));
@@ -408,19 +445,68 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, c->dps));
         LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], c->dps));
         const int64_t seg_cols = c1 - c0;
-        const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 28, std::max<int64_t>(seg_cols / 8, 4));
+        /* the light kernel is throughput work and persistent: it must leave wave slots for the short
+         * latency-bound kernels of the long columns, or they only start when it ends */
+        int light_waves_per_cu = 20;
+        if (const char *e = getenv("LFQ_LIGHT_WAVES_PER_CU")) {
+            light_waves_per_cu = std::max(4, atoi(e));
+        }
+        const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * light_waves_per_cu, std::max<int64_t>(seg_cols / 8, 4));
         const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(seg_cols, 4));
         for (int i = 0; i < 2; i++) {
             LFQ_TRY_HIP(hipStreamWaitEvent(c->side[i], c->ev_scan[s], 0));
             LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][0], c->side[i]));
         }
-        if (!skip || !strstr(skip, "big")) {
+        const bool run_big = !skip || !strstr(skip, "big"), run_mid = !skip || !strstr(skip, "mid");
+        const bool dbg_sync = getenv("LFQ_DEBUG_SYNC") != nullptr;    /* debugging aid: serialize and name the stages */
+#define LFQ_DBG_STAGE(name)                                                        \
+    do {                                                                           \
+        if (dbg_sync) {                                                            \
+            fprintf(stderr, "[lfq] %s launched\n", name);                          \
+            hipError_t e_ = hipDeviceSynchronize();                                \
+            fprintf(stderr, "[lfq] %s done (%d)\n", name, (int)e_);                \
+        }                                                                          \
+    } while (0)
+        /* big class: bounds + split decision, then the row segments of the wide classes, then whatever
+         * could not be split; mid class: first stretch of rows, then the row segments of the survivors;
+         * finally the fold + emission of every split column */
+        if (run_big) {
+            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[0]));
+            LFQ_DBG_STAGE("prep");
+        }
+        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, c->side[0]));
+        if (run_mid) {
+            LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
+            LFQ_DBG_STAGE("mid");
+        }
+        LFQ_TRY_HIP(hipEventRecord(c->ev_mid, c->side[1]));
+        /* the five row-segment classes: 2 on side[0], 3 and 4 on aux[0] (records from the prep kernel only);
+         * 1 on side[1], 0 on aux[1] (records from the mid kernel; K = 250..252 of the big class lands in 1) */
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->aux[0], c->ev_prep, 0));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->aux[1], c->ev_prep, 0));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->aux[1], c->ev_mid, 0));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[1], c->ev_prep, 0));
+        if (run_big) {
+            LFQ_TRY(lfq_launch_dp_seg(2, T, P, c->d_luts, W, c->n_cu * 8, c->side[0]));
+            LFQ_DBG_STAGE("seg2");
+            LFQ_TRY(lfq_launch_dp_seg(3, T, P, c->d_luts, W, c->n_cu * 8, c->aux[0]));
+            LFQ_TRY(lfq_launch_dp_seg(4, T, P, c->d_luts, W, c->n_cu * 4, c->aux[0]));
+            LFQ_DBG_STAGE("seg3+seg4");
             LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
                                       n_big_blocks, c->side[0]));
+            LFQ_DBG_STAGE("big");
         }
-        if (!skip || !strstr(skip, "mid")) {
-            LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
-        }
+        LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, c->side[1]));
+        LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, c->aux[1]));
+        LFQ_DBG_STAGE("seg0+seg1");
+        LFQ_TRY_HIP(hipEventRecord(c->ev_segw, c->side[1]));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_aux[0], c->aux[0]));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_aux[1], c->aux[1]));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_segw, 0));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_aux[0], 0));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_aux[1], 0));
+        LFQ_TRY(lfq_launch_dp_combine(P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[0]));
+        LFQ_DBG_STAGE("combine");
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], c->dps));
         if (!skip || !strstr(skip, "light")) {
             LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, c->dps));
@@ -497,7 +583,7 @@ int lfq_debug_counters(lfq_ctx *c, int32_t *out16)
     if (!c || !out16) {
         return LFQ_ERR_INVALID;
     }
-    memcpy(out16, c->h_counters, LFQ_NCOUNTERS * sizeof(int32_t));   /* segment 0 */
+    memcpy(out16, c->h_counters, 16 * sizeof(int32_t));   /* segment 0 */
     return LFQ_OK;
 }
 

@@ -303,6 +303,88 @@ __device__ __forceinline__ void lfq_strip_store_logs(const LfqStrip<C> &S, int g
     }
 }
 
+/* a strip's cells in (mantissa, exponent) form -> the segment pool (cells 0..K-1 and the tail cell K) */
+template <int C>
+__device__ __forceinline__ void lfq_strip_store_cells(const LfqStrip<C> &S, int gl, int shift, int K, LfqSegCell *out)
+{
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        const int k = gl * C + j - shift;
+        if (k >= 0 && k <= K && (k < K || j == 0)) {
+            const double v = S.v[j];
+            LfqSegCell c;
+            c.v = (v > 0.0) ? __builtin_amdgcn_frexp_mant(v) : 0.0;
+            c.e = (v > 0.0) ? S.e + __builtin_amdgcn_frexp_exp(v) : 0;
+            c.pad_ = 0;
+            out[k] = c;
+        }
+    }
+}
+
+/* How many NEW row segments to cut `rem_chunks` remaining chunks of a K-cell column into (0 = do not split).
+ * Bounds: LFQ_SEG_MAX segments in total, no segment shorter than LFQ_SEG_MIN_CHUNKS chunks, and the
+ * (segments - 1) convolutions of K^2/2 terms must stay below a quarter of the rows * K recurrence work. */
+__device__ __forceinline__ int lfq_split_plan(int K, int64_t rem_chunks, int phase1)
+{
+    if (K > LFQ_SPLIT_MAX_K) {
+        return 0;
+    }
+    int64_t n_new = LFQ_SEG_MAX - phase1;
+    n_new = min(n_new, rem_chunks / LFQ_SEG_MIN_CHUNKS);
+    n_new = min(n_new, rem_chunks * 64 / (2 * (int64_t)max(K, 1)) + 1 - phase1);
+    return n_new >= 2 ? (int)n_new : 0;
+}
+
+__device__ __forceinline__ int lfq_seg_class(int K)
+{
+    return K <= 63 ? 0 : (K <= 252 ? 1 : (K <= 504 ? 2 : (K <= 1008 ? 3 : 4)));
+}
+
+/* reserve pool cells and a record slot for a column that is about to be split; nullptr = run it unsplit.
+ * Called by one lane. */
+__device__ __forceinline__ LfqLong *lfq_long_reserve(const LfqWork &W, int K, int n_seg, int64_t *cell0)
+{
+    const int cells = n_seg * (K + 1);
+    const int c0 = atomicAdd(&W.counters[LFQ_CNT_POOL], cells);
+    if (c0 + cells > W.pool_cells) {
+        return nullptr;
+    }
+    const int cls = lfq_seg_class(K);
+    const int per_class = W.long_cap / LFQ_SEG_CLASSES;
+    const int slot = atomicAdd(&W.counters[LFQ_CNT_LONG0 + cls], 1);
+    if (slot >= per_class) {
+        return nullptr;
+    }
+    *cell0 = c0;
+    return W.longs + cls * per_class + slot;
+}
+
+__device__ __forceinline__ void lfq_ctx_from_long(LfqColCtx &cx, const LfqLong &r, const LfqParams &P)
+{
+    cx.col = r.col;
+    cx.off0 = r.off0;
+    cx.n_obs = r.n_obs;
+    cx.ref_code = r.ref_code;
+    cx.median_ref_bq = r.median_ref_bq;
+    cx.K = r.K;
+    cx.bonf = r.bonf;
+    cx.bonf_d = (double)r.bonf;
+    cx.sig_s = P.sig * (1.0 + P.prune_slack);
+    if (r.force_fe) {
+        cx.sig_s = fmax(cx.sig_s, 4.5e-16 * cx.bonf_d);     /* see lfq_dp_big_kernel */
+    }
+}
+
+/* chunk range [c0, c1) of new segment `r` (r >= phase1) of a row-split column */
+__device__ __forceinline__ void lfq_seg_range(const LfqLong &rec, int r, int64_t *c0, int64_t *c1)
+{
+    const int64_t n_chunks = ((int64_t)rec.n_obs + 63) / 64;
+    const int64_t rem = n_chunks - rec.ch_begin;
+    const int n_new = rec.n_seg - rec.phase1;
+    *c0 = rec.ch_begin + rem * (r - rec.phase1) / n_new;
+    *c1 = rec.ch_begin + rem * (r - rec.phase1 + 1) / n_new;
+}
+
 __device__ __forceinline__ double lfq_logaddexp(double a, double b)
 {
     const double hi = fmax(a, b), lo = fmin(a, b);
@@ -571,6 +653,12 @@ __device__ __forceinline__ int lfq_claim(int32_t *head, int n)
     return __builtin_amdgcn_readfirstlane(old);
 }
 
+/* fire-and-forget device-scope add from the calling lane (same reason for inline asm as lfq_claim) */
+__device__ __forceinline__ void lfq_atomic_add_noret(int32_t *p, int v)
+{
+    asm volatile("global_atomic_add %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
 /* what the column pipeline wants loaded while this column computes */
 struct LfqPrefetch {
     bool want_raw, want_entry;
@@ -582,7 +670,7 @@ struct LfqPrefetch {
 };
 
 /* one column on one wavefront: C cells per lane, single strip ((K + C) / C <= 64) */
-template <int C, bool PREFETCH>
+template <int C, bool PREFETCH, bool SPLIT>
 __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw, const LfqTracksDev &T,
                                                 const LfqParams &P, const LfqLuts *L, LfqRow *rows,
                                                 const lfq_col_counts *__restrict__ counts, const LfqWork &W,
@@ -638,6 +726,48 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
         if (hit) {
             pruned = true;
             break;
+        }
+        if (SPLIT && ch + 1 == LFQ_PHASE1_CHUNKS) {
+            /* still alive after the first stretch of rows: cut the rest into concurrent row segments;
+             * the state reached here becomes segment 0 (lfq_dp_segw_kernel, lfq_dp_combine_kernel) */
+            const int n_new = lfq_split_plan(K, n_chunks - (ch + 1), 1);
+            if (n_new > 0) {
+                const int n_seg = n_new + 1;
+                const int cells = n_seg * (K + 1);
+                const int cls = lfq_seg_class(K);
+                const int per_class = W.long_cap / LFQ_SEG_CLASSES;
+                const int c0 = lfq_claim(&W.counters[LFQ_CNT_POOL], cells);
+                if (c0 + cells <= W.pool_cells) {
+                    const int slot = lfq_claim(&W.counters[LFQ_CNT_LONG0 + cls], 1);
+                    if (slot < per_class) {
+                        lfq_strip_store_cells<C>(S, lane, shift, K, W.pool + c0);
+                        if (lane == 0) {
+                            LfqLong r;
+                            r.off0 = cx.off0;
+                            r.bonf = cx.bonf;
+                            r.cell0 = c0;
+                            r.n_obs = (int32_t)cx.n_obs;
+                            r.col = cx.col;
+                            r.K = K;
+                            r.n_seg = n_seg;
+                            r.ch_begin = (int32_t)(ch + 1);
+                            r.phase1 = 1;
+                            r.uf_mask = 0;
+                            r.force_fe = 0;
+                            r.pruned = 0;
+                            r.rows = n_rows;
+                            r.median_ref_bq = (int16_t)cx.median_ref_bq;
+                            r.ref_code = (uint8_t)cx.ref_code;
+                            r.pad0_ = 0;
+                            r.pad1_ = 0;
+                            r.uf_bound[0] = r.uf_bound[1] = r.uf_bound[2] = 0.0;
+                            r.pad_[0] = r.pad_[1] = r.pad_[2] = r.pad_[3] = 0;
+                            W.longs[cls * per_class + slot] = r;
+                        }
+                        return;
+                    }
+                }
+            }
         }
         if (!PREFETCH && ch + 1 < n_chunks) {
             raw = lfq_load_chunk(cx, ch + 1, T);
@@ -733,11 +863,11 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
             pf.raw = &raw_next;
             pf.entry = &en_next2;
             if (MAXC == 1 || cx.K < 64) {
-                lfq_wave_column<1, (MAXC > 1)>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
+                lfq_wave_column<1, (MAXC > 1), (MAXC > 1)>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
             } else {
                 /* (more cells-per-lane variants were measured -- C = 2 and 4 are ~30 % faster per row for
                  * K < 250 -- but four inlined variants push this kernel into SGPR spilling) */
-                lfq_wave_column<4, true>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
+                lfq_wave_column<4, true, true>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
             }
             if (!have_next) {
                 break;
@@ -765,37 +895,46 @@ struct LfqBigShared {
     double gv[LFQ_HEAVY_WAVES][64];         /* pass boundary staged from global scratch */
     int ge[LFQ_HEAVY_WAVES][64];
     double mu[LFQ_HEAVY_WAVES];
-    int col, pruned;
+    int col, pruned, split;
 };
 
 /* mu = sum of the column's error probabilities (all wavefronts of the workgroup), then the per-allele
  * upper bounds log(mu^c / c!) and the recurrence size kp that is still needed.  Kept out of line: its
  * registers (log, lgamma) must not inflate the strip pipeline's allocation. */
-__device__ __noinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_counts &cnt, const LfqTracksDev &T,
-                                            const LfqParams &P, LfqBigShared &sh, unsigned *uf_mask_out,
-                                            double *uf_bound, int *kp_out)
+__device__ __forceinline__ void lfq_big_bounds_impl(const LfqColCtx &cx, const lfq_col_counts &cnt,
+                                                    const LfqTracksDev &T, const LfqParams &P, const LfqLuts *luts,
+                                                    double *mu_sh, int NW, unsigned *uf_mask_out, double *uf_bound,
+                                                    int *kp_out)
 {
-    constexpr int NW = LFQ_HEAVY_WAVES;
     const int lane = lfq_lane();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n_chunks = (cx.n_obs + 63) / 64;
     double part = 0.0;
-    for (int64_t ch = w; ch < n_chunks; ch += NW) {
-        double ps, qf;
-        const uint64_t km = lfq_eval_chunk(cx, ch, T, P, &sh.luts, &ps, &qf);
-        part += ((km >> lane) & 1ull) ? ps : 0.0;
+    /* four chunks of loads in flight per wavefront: this loop is pure memory latency otherwise */
+    for (int64_t ch = w; ch < n_chunks; ch += 4 * NW) {
+        LfqRaw r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            r[u] = lfq_load_chunk(cx, ch + u * NW, T);      /* past the end = ignored observations */
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double ps, qf;
+            const uint64_t km = lfq_eval_raw(cx, r[u], P, luts, &ps, &qf);
+            part += ((km >> lane) & 1ull) ? ps : 0.0;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         part += __shfl_xor(part, d, 64);
     }
     if (lane == 0) {
-        sh.mu[w] = part;
+        mu_sh[w] = part;
     }
     __syncthreads();
     double mu = 0.0;
     for (int i = 0; i < NW; i++) {
-        mu += sh.mu[i];
+        mu += mu_sh[i];
     }
     const double lmu = log(mu);
     unsigned uf_mask = 0;
@@ -814,19 +953,30 @@ __device__ __noinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_c
     *kp_out = kp;
 }
 
+__device__ __noinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_counts &cnt, const LfqTracksDev &T,
+                                            const LfqParams &P, const LfqLuts *luts, double *mu_sh, int NW,
+                                            unsigned *uf_mask_out, double *uf_bound, int *kp_out)
+{
+    lfq_big_bounds_impl(cx, cnt, T, P, luts, mu_sh, NW, uf_mask_out, uf_bound, kp_out);
+}
+
 /* the strip pipeline of one big column with C cells per lane (C chosen so that the strips fit the
  * workgroup's wavefronts in one pass whenever possible: fewer cells per lane = shorter rows) */
-template <int C>
-__device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_counts &cnt, int kp, unsigned uf_mask,
+/* ch0..ch1: the chunk range to run (the whole column, or one row segment of a split column starting from
+ * the identity distribution).  seg_out != nullptr: segment mode -- the final cells go to the pool and
+ * nothing is emitted; `rec` receives the pruned flag and the row count. */
+template <int C, bool SEG>
+__device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_counts *cntp, int kp, unsigned uf_mask,
                                                const double *uf_bound, bool force_fe, double *bnd,
                                                const LfqTracksDev &T, const LfqParams &P, LfqBigShared &sh,
                                                const LfqWork &W, lfq_col_pvals *__restrict__ pvals,
-                                               int64_t pvals_capacity)
+                                               int64_t pvals_capacity, int64_t ch0, int64_t ch1,
+                                               LfqSegCell *seg_out, LfqLong *rec)
 {
     constexpr int NW = LFQ_HEAVY_WAVES;
     const int lane = lfq_lane();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t n_chunks = (cx.n_obs + 63) / 64;
+    const int64_t n_chunks = ch1 - ch0;
     const int K = kp;
     const int shift = (C - K % C) % C;
     const int Lt = (K + shift) / C;            /* global lane owning the tail cell at j = 0 */
@@ -855,10 +1005,10 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
         long long pt_stage = 0, pt_rows = 0, pt_bar = 0;
         const long long pstart = clock64();
 #endif
-        LfqRaw raw = lfq_load_chunk(cx, 0, T);
+        LfqRaw raw = lfq_load_chunk(cx, ch0, T);
         for (int64_t t = 0; t < n_steps; t++) {
-            const int64_t ch = t - w;
-            if (active && ch >= 0 && ch < n_chunks) {
+            const int64_t ch = ch0 + t - w;
+            if (active && ch >= ch0 && ch < ch1) {
                 const int64_t idx = ch * 64 + lane;
                 const double *in_v = sh.zero_v;
                 const int *in_e = sh.zero_e;
@@ -877,7 +1027,7 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
                 const long long pc0 = clock64();
 #endif
                 const uint64_t km = lfq_stage_rows(cx, raw, P, &sh.luts, sh.rows[w]);
-                if (ch + 1 < n_chunks) {
+                if (ch + 1 < ch1) {
                     raw = lfq_load_chunk(cx, ch + 1, T);   /* lands while this step's rows run */
                 }
 #ifdef LFQ_PROFILE
@@ -934,14 +1084,25 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
             pruned = true;
         }
         if (!pruned && active) {
-            lfq_strip_store_logs<C>(S, gl, shift, K, probvec);
+            if (SEG) {
+                lfq_strip_store_cells<C>(S, gl, shift, K, seg_out);
+            } else {
+                lfq_strip_store_logs<C>(S, gl, shift, K, probvec);
+            }
         }
         __threadfence_block();
         __syncthreads();
     }
-    if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
+    if (SEG) {
+        if (w == ((n_strips - 1) % NW) && lane == 0) {
+            if (pruned) {
+                rec->pruned = 1;
+            }
+            lfq_atomic_add_noret(&rec->rows, rows_tail);
+        }
+    } else if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
         /* the wave that owned the tail strip finishes the column */
-        lfq_emit_pvals(cx, cnt, probvec, K, !pruned, uf_mask, uf_bound, force_fe, rows_tail, W, pvals,
+        lfq_emit_pvals(cx, *cntp, probvec, K, !pruned, uf_mask, uf_bound, force_fe, rows_tail, W, pvals,
                        pvals_capacity);
     }
 }
@@ -967,7 +1128,7 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
     }
     const int lane = lfq_lane();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_big = W.counters[LFQ_CNT_BIG];
+    const int n_unsplit = W.counters[LFQ_CNT_UNSPLIT];
     double *bnd = scratch + (int64_t)blockIdx.x * scratch_per_block;   /* pass boundary: 2 doubles / obs */
 
     for (;;) {
@@ -977,7 +1138,81 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
             sh.pruned = 0;
         }
         __syncthreads();
-        const int h = sh.col;
+        if (sh.col >= n_unsplit) {
+            break;
+        }
+        /* the columns lfq_dp_big_prep_kernel could not (or need not) cut into row segments */
+        const int h = W.unsplit[sh.col];
+        const LfqEntry en = lfq_load_entry(W.entries + W.counters[LFQ_CNT_LIGHT] + W.counters[LFQ_CNT_MID], h);
+        const lfq_col_counts cnt = counts[en.col];
+        LfqColCtx cx;
+        lfq_col_setup(cx, en, P);
+        const int64_t n_chunks = (cx.n_obs + 63) / 64;
+        unsigned uf_mask = 0;
+        double uf_bound[3];
+        int kp = 0;
+        lfq_big_bounds(cx, cnt, T, P, &sh.luts, sh.mu, NW, &uf_mask, uf_bound, &kp);     /* see the prep kernel */
+        const bool force_fe = uf_mask != 0;
+        if (force_fe) {
+            cx.sig_s = fmax(cx.sig_s, 4.5e-16 * cx.bonf_d);
+        }
+        if (kp == 0) {
+            continue;                   /* already emitted by the prep kernel */
+        }
+        if (kp < 128 * NW - 1) {
+            lfq_big_column<2, false>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
+                              n_chunks, nullptr, nullptr);
+        } else {
+            /* 4 cells per lane: up to K = 2044 in one pass; deeper columns run in passes.  (8 cells per
+             * lane would halve the passes but doubles the kernel's register footprint, which decides
+             * whether these workgroups can be resident beside the light kernel.) */
+            lfq_big_column<4, false>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
+                              n_chunks, nullptr, nullptr);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* big columns, step 1: bounds, shortcut, and the decision to split                            */
+/* ------------------------------------------------------------------------------------------ */
+
+#define LFQ_PREP_WAVES 8
+
+/* One 4-wave workgroup per big column (K >= LFQ_BIG_K).
+ *
+ * Shortcut for p-values below the 80-bit range.  P(X >= c) <= e_c(p) <= mu^c / c!  (union bound +
+ * Maclaurin), mu = sum of the error probabilities.  If that bound is below e^-12200 the reference's
+ * expl() underflows and it reports LDBL_MIN (snpcaller.c:1047-1059) whatever the exact
+ * value is.  For the remaining alleles of such a column the reference's log_sum chain provably underflows
+ * too (the chain spans > 708 in log space), so their p-values are clamped by value: they only need the
+ * recurrence up to the largest non-underflowing count kp.
+ *
+ * kp == 0: the record is emitted here.  Otherwise the column is cut into row segments (a record in the
+ * class list of its kp) or, if it is too short / too wide / the pool is full, queued for the unsplit
+ * strip-pipeline kernel. */
+__global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
+    LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
+    LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity)
+{
+    __shared__ LfqLuts s_luts;
+    __shared__ double s_mu[LFQ_PREP_WAVES];
+    __shared__ int s_col;
+    {
+        const double *src = reinterpret_cast<const double *>(g_luts);
+        double *dst = reinterpret_cast<double *>(&s_luts);
+        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
+            dst[i] = src[i];
+        }
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int n_big = W.counters[LFQ_CNT_BIG];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_col = atomicAdd(&W.counters[LFQ_CNT_HEAD_PREP], 1);
+        }
+        __syncthreads();
+        const int h = s_col;
         if (h >= n_big) {
             break;
         }
@@ -986,18 +1221,10 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
         LfqColCtx cx;
         lfq_col_setup(cx, en, P);
         const int64_t n_chunks = (cx.n_obs + 63) / 64;
-
-        /* Shortcut for p-values below the 80-bit range.  P(X >= c) <= e_c(p) <= mu^c / c!  (union
-         * bound + Maclaurin), mu = sum of the error probabilities.  If that bound is below e^-12200
-         * the reference's expl() underflows and it reports LDBL_MIN (snpcaller.c:1047-1059, SURVEY
-         * App. A.6) whatever the exact value is.  For the remaining alleles of such a column the
-         * reference's log_sum chain provably underflows too (the chain spans > 708 in log space), so
-         * their p-values are clamped by value: they only need the recurrence up to the largest
-         * non-underflowing count. */
         unsigned uf_mask = 0;
         double uf_bound[3];
         int kp = 0;
-        lfq_big_bounds(cx, cnt, T, P, sh, &uf_mask, uf_bound, &kp);
+        lfq_big_bounds_impl(cx, cnt, T, P, &s_luts, s_mu, LFQ_PREP_WAVES, &uf_mask, uf_bound, &kp);
         const bool force_fe = uf_mask != 0;
         if (force_fe) {
             /* pruned alleles become LDBL_MAX; that equals the reference's clamp only while the pruning
@@ -1005,18 +1232,376 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
             cx.sig_s = fmax(cx.sig_s, 4.5e-16 * cx.bonf_d);
         }
         if (kp == 0) {
-            if (w == 0) {
-                lfq_emit_pvals(cx, cnt, nullptr, 0, false, uf_mask, uf_bound, true, 0, W, pvals, pvals_capacity);
+            /* every allele is an 80-bit underflow: the record is complete (same layout as lfq_emit_pvals) */
+            if (threadIdx.x == 0) {
+                const int slot = atomicAdd(&W.gcounters[LFQ_GC_PVALS], 1);
+                if ((int64_t)slot < pvals_capacity) {
+                    lfq_col_pvals r;
+                    r.col = cx.col;
+                    r.bonf = cx.bonf;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const bool uf = (uf_mask >> a) & 1u;
+                        r.logp[a] = uf ? uf_bound[a] : 0.0;
+                        r.status[a] = (uint8_t)(uf ? LFQ_PV_UNDERFLOW : LFQ_PV_NONE);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        r.pad_[i] = 0;
+                    }
+                    r.counts = cnt;
+                    r.dp_rows = 0;
+                    r.pad2_ = 0;
+                    r.reserved_ = 0;
+                    pvals[slot] = r;
+                } else {
+                    W.gcounters[LFQ_GC_OVERFLOW] = 1;
+                }
             }
             continue;
         }
-        if (kp < 128 * NW - 1) {
-            lfq_big_column<2>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
-        } else {
-            /* 4 cells per lane: up to K = 2044 in one pass; deeper columns run in passes.  (8 cells per
-             * lane would halve the passes but doubles the kernel's register footprint, which decides
-             * whether these workgroups can be resident beside the light kernel.) */
-            lfq_big_column<4>(cx, cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity);
+        if (threadIdx.x == 0) {
+            const int n_new = lfq_split_plan(kp, n_chunks, 0);
+            int64_t cell0 = 0;
+            LfqLong *slot = (n_new > 0) ? lfq_long_reserve(W, kp, n_new, &cell0) : nullptr;
+            if (slot) {
+                LfqLong r;
+                r.off0 = cx.off0;
+                r.bonf = cx.bonf;
+                r.cell0 = cell0;
+                r.n_obs = (int32_t)cx.n_obs;
+                r.col = cx.col;
+                r.K = kp;
+                r.n_seg = n_new;
+                r.ch_begin = 0;
+                r.phase1 = 0;
+                r.uf_mask = uf_mask;
+                r.force_fe = force_fe ? 1 : 0;
+                r.pruned = 0;
+                r.rows = 0;
+                r.median_ref_bq = (int16_t)cx.median_ref_bq;
+                r.ref_code = (uint8_t)cx.ref_code;
+                r.pad0_ = 0;
+                r.pad1_ = 0;
+                r.uf_bound[0] = uf_bound[0];
+                r.uf_bound[1] = uf_bound[1];
+                r.uf_bound[2] = uf_bound[2];
+                r.pad_[0] = r.pad_[1] = r.pad_[2] = r.pad_[3] = 0;
+                *slot = r;
+            } else {
+                W.unsplit[atomicAdd(&W.counters[LFQ_CNT_UNSPLIT], 1)] = h;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* row segments of split columns: one wavefront each                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* chunks [ch0, ch1) of a column from the identity distribution, C cells per lane ((K + C) / C <= 64) */
+template <int C>
+__device__ __forceinline__ void lfq_wave_segment(const LfqColCtx &cx, int64_t ch0, int64_t ch1, const LfqTracksDev &T,
+                                                 const LfqParams &P, const LfqLuts *L, LfqRow *rows,
+                                                 LfqSegCell *out)
+{
+    const int lane = lfq_lane();
+    const int K = cx.K;
+    const int shift = (C - K % C) % C;
+    const int lt = (K + shift) / C;
+    const double tflag = (lane == lt) ? 1.0 : 0.0;
+    LfqStrip<C> S;
+    lfq_strip_init<C>(S, true, shift);
+    bool pruned = false;
+    int n_rows = 0;
+    LfqRaw raw = lfq_load_chunk(cx, ch0, T);
+    for (int64_t ch = ch0; ch < ch1; ch++) {
+        const uint64_t km = lfq_stage_rows(cx, raw, P, L, rows);
+        if (ch + 1 < ch1) {
+            raw = lfq_load_chunk(cx, ch + 1, T);
+        }
+        const bool hit = lfq_strip_chunk<C, false>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
+                                                   true, lt, cx.bonf_d, cx.sig_s);
+        n_rows += __popcll(S.rows >= 64 ? km : (km & ((1ull << S.rows) - 1ull)));
+        if (hit) {
+            pruned = true;
+            break;
+        }
+    }
+    if (!pruned && lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
+        pruned = true;
+    }
+    /* a segment's own tail is a lower bound of the column's: pruned here = pruned for good.  The flag and
+     * the row count travel in the pad field of the segment's cell 0 (read by the combine kernel). */
+    lfq_strip_store_cells<C>(S, lane, shift, K, out);
+    if (lane == 0) {
+        __builtin_nontemporal_store(n_rows | (pruned ? (int)0x40000000 : 0), &out[0].pad_);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqParams P,
+                                                         const LfqLuts *__restrict__ g_luts, LfqWork W, int cls)
+{
+    __shared__ LfqLuts s_luts;
+    __shared__ LfqRow s_rows[4][64];
+    __builtin_amdgcn_s_setprio(3);
+    {
+        const double *src = reinterpret_cast<const double *>(g_luts);
+        double *dst = reinterpret_cast<double *>(&s_luts);
+        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
+            dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int per_class = W.long_cap / LFQ_SEG_CLASSES;
+    const int n_long = min(W.counters[LFQ_CNT_LONG0 + cls], per_class);
+    const int n_items = n_long * LFQ_SEG_MAX;
+    const LfqLong *list = W.longs + cls * per_class;
+    LfqRow *rows = s_rows[wave];
+    /* the segments of a class cost about the same: a static stride over (record, segment) is balanced, and
+     * the loop stays free of atomics (n_waves_total wavefronts; item idx = record * LFQ_SEG_MAX + segment) */
+    const int n_waves_total = (int)gridDim.x * 4;
+    for (int idx = (int)blockIdx.x * 4 + wave; idx < n_items; idx += n_waves_total) {
+        const int r = idx % LFQ_SEG_MAX;
+        const LfqLong R = list[idx / LFQ_SEG_MAX];
+        if (r < R.phase1 || r >= R.n_seg) {
+            continue;
+        }
+        LfqColCtx cx;
+        lfq_ctx_from_long(cx, R, P);
+        int64_t c0, c1;
+        lfq_seg_range(R, r, &c0, &c1);
+        lfq_wave_segment<C>(cx, c0, c1, T, P, &s_luts, rows, W.pool + R.cell0 + (int64_t)r * (R.K + 1));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* combine: fold the segment distributions of a split column, then finish it like the big kernel */
+/* ------------------------------------------------------------------------------------------ */
+
+#define LFQ_COMB_THREADS 512
+#define LFQ_COMB_CELLS 2048
+#define LFQ_COMB_PER_THREAD (LFQ_COMB_CELLS / LFQ_COMB_THREADS)
+#define LFQ_EXT_ZERO_E (-(1 << 28))
+
+struct LfqCombShared {
+    double av[LFQ_COMB_CELLS];
+    double bv[LFQ_COMB_CELLS];
+    int ae[LFQ_COMB_CELLS];
+    int be[LFQ_COMB_CELLS];
+    double rv[LFQ_COMB_THREADS / 64];
+    int re[LFQ_COMB_THREADS / 64];
+    double tot_v;
+    int tot_e;
+    int idx, pruned;
+};
+
+__device__ __forceinline__ LfqExt lfq_ext_norm(double v, int e)
+{
+    LfqExt r;
+    r.v = (v > 0.0) ? __builtin_amdgcn_frexp_mant(v) : 0.0;
+    r.e = (v > 0.0) ? e + __builtin_amdgcn_frexp_exp(v) : 0;
+    return r;
+}
+
+__global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqParams P,
+                                                                          const lfq_col_counts *__restrict__ counts,
+                                                                          LfqWork W, lfq_col_pvals *__restrict__ pvals,
+                                                                          int64_t pvals_capacity)
+{
+    __shared__ LfqCombShared sh;
+    const int tid = threadIdx.x;
+    const int lane = lfq_lane();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int per_class = W.long_cap / LFQ_SEG_CLASSES;
+    int n_cls[LFQ_SEG_CLASSES], n_all = 0;
+#pragma unroll
+    for (int c = 0; c < LFQ_SEG_CLASSES; c++) {
+        n_cls[c] = min(W.counters[LFQ_CNT_LONG0 + c], per_class);
+        n_all += n_cls[c];
+    }
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            sh.idx = atomicAdd(&W.counters[LFQ_CNT_HEAD_COMB], 1);
+        }
+        __syncthreads();
+        int h = sh.idx;
+        if (h >= n_all) {
+            break;
+        }
+        int cls = LFQ_SEG_CLASSES - 1;            /* widest class first: its folds take longest */
+        while (h >= n_cls[cls]) {
+            h -= n_cls[cls];
+            cls--;
+        }
+        const LfqLong R = W.longs[cls * per_class + h];
+        const int K = R.K;
+        LfqColCtx cx;
+        lfq_ctx_from_long(cx, R, P);
+        /* row counts and pruned flags of the segments the segment kernels wrote (pad of their cell 0) */
+        int rows_total = R.rows;
+        bool pruned = R.pruned != 0;
+        for (int sgi = R.phase1; sgi < R.n_seg; sgi++) {
+            const int f = W.pool[R.cell0 + (int64_t)sgi * (K + 1)].pad_;
+            rows_total += f & 0x3fffffff;
+            pruned = pruned || (f & 0x40000000) != 0;
+        }
+        if (!pruned) {
+            const LfqSegCell *seg = W.pool + R.cell0;
+            for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
+                const LfqSegCell c = seg[k];
+                sh.av[k] = c.v;
+                sh.ae[k] = c.e;
+            }
+            for (int s = 1; s < R.n_seg; s++) {
+                seg += K + 1;
+                for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
+                    const LfqSegCell c = seg[k];
+                    sh.bv[k] = c.v;
+                    sh.be[k] = c.e;
+                }
+                __syncthreads();
+                /* c_k = sum_i a_i b_(k-i), k < K: aligned to a running maximum exponent */
+                LfqExt out[LFQ_COMB_PER_THREAD];
+#pragma unroll
+                for (int m = 0; m < LFQ_COMB_PER_THREAD; m++) {
+                    const int k = tid + m * LFQ_COMB_THREADS;
+                    /* four independent accumulators: the LDS reads and the ldexp/add chains of consecutive
+                     * terms overlap instead of serialising */
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                    int me[4] = {LFQ_EXT_ZERO_E, LFQ_EXT_ZERO_E, LFQ_EXT_ZERO_E, LFQ_EXT_ZERO_E};
+                    if (k < K) {
+                        int i = 0;
+                        for (; i + 3 <= k; i += 4) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const double t = sh.av[i + u] * sh.bv[k - i - u];
+                                int x = sh.ae[i + u] + sh.be[k - i - u];
+                                x = (t != 0.0) ? x : LFQ_EXT_ZERO_E;
+                                const int nm = max(me[u], x);
+                                acc[u] = ldexp(acc[u], me[u] - nm) + ldexp(t, x - nm);
+                                me[u] = nm;
+                            }
+                        }
+                        for (; i <= k; i++) {
+                            const double t = sh.av[i] * sh.bv[k - i];
+                            int x = sh.ae[i] + sh.be[k - i];
+                            x = (t != 0.0) ? x : LFQ_EXT_ZERO_E;
+                            const int nm = max(me[0], x);
+                            acc[0] = ldexp(acc[0], me[0] - nm) + ldexp(t, x - nm);
+                            me[0] = nm;
+                        }
+                    }
+                    LfqExt s01, s23;
+                    s01.e = max(me[0], me[1]);
+                    s01.v = ldexp(acc[0], me[0] - s01.e) + ldexp(acc[1], me[1] - s01.e);
+                    s23.e = max(me[2], me[3]);
+                    s23.v = ldexp(acc[2], me[2] - s23.e) + ldexp(acc[3], me[3] - s23.e);
+                    const int se = max(s01.e, s23.e);
+                    out[m] = lfq_ext_norm(ldexp(s01.v, s01.e - se) + ldexp(s23.v, s23.e - se), se);
+                }
+                __syncthreads();
+                /* in place: b[j] <- S_B(j) = b[j] + ... + b[K-1] + tail_B  (wave 0, suffix scan from the top) */
+                if (w == 0) {
+                    LfqExt carry;
+                    carry.v = 0.0;
+                    carry.e = 0;
+                    for (int base = K; base >= 0; base -= 64) {
+                        const int j = base - lane;
+                        LfqExt incl;
+                        incl.v = (j >= 0) ? sh.bv[j] : 0.0;
+                        incl.e = (j >= 0) ? sh.be[j] : 0;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            LfqExt y;
+                            y.v = __shfl_up(incl.v, d, 64);
+                            y.e = __shfl_up(incl.e, d, 64);
+                            if (lane >= d) {
+                                incl = lfq_ext_add(incl, y);
+                            }
+                        }
+                        const LfqExt tot = lfq_ext_add(carry, incl);
+                        if (j >= 0) {
+                            sh.bv[j] = tot.v;
+                            sh.be[j] = tot.e;
+                        }
+                        carry.v = lfq_rl_f64(tot.v, 63);
+                        carry.e = lfq_rl_i32(tot.e, 63);
+                    }
+                }
+                __syncthreads();
+                /* tail_C = tail_A + sum_(i<K) a_i S_B(K-i) */
+                LfqExt part;
+                part.v = 0.0;
+                part.e = 0;
+                for (int i = tid; i < K; i += LFQ_COMB_THREADS) {
+                    LfqExt t;
+                    t.v = sh.av[i] * sh.bv[K - i];
+                    t.e = sh.ae[i] + sh.be[K - i];
+                    part = lfq_ext_add(part, t);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    LfqExt y;
+                    y.v = __shfl_xor(part.v, d, 64);
+                    y.e = __shfl_xor(part.e, d, 64);
+                    part = lfq_ext_add(part, y);
+                }
+                if (lane == 0) {
+                    sh.rv[w] = part.v;
+                    sh.re[w] = part.e;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    LfqExt tot;
+                    tot.v = sh.av[K];
+                    tot.e = sh.ae[K];
+                    for (int i = 0; i < LFQ_COMB_THREADS / 64; i++) {
+                        LfqExt y;
+                        y.v = sh.rv[i];
+                        y.e = sh.re[i];
+                        tot = lfq_ext_add(tot, y);
+                    }
+                    tot = lfq_ext_norm(tot.v, tot.e);
+                    sh.tot_v = tot.v;
+                    sh.tot_e = tot.e;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < LFQ_COMB_PER_THREAD; m++) {
+                    const int k = tid + m * LFQ_COMB_THREADS;
+                    if (k < K) {
+                        sh.av[k] = out[m].v;
+                        sh.ae[k] = out[m].e;
+                    }
+                }
+                if (tid == 0) {
+                    sh.av[K] = sh.tot_v;
+                    sh.ae[K] = sh.tot_e;
+                }
+                __syncthreads();
+            }
+            if (R.n_seg <= 1) {
+                __syncthreads();
+            }
+            pruned = ldexp(sh.av[K], sh.ae[K]) * cx.bonf_d > cx.sig_s;
+        }
+        if (!pruned) {
+            /* natural logs in poissbin()'s probvec layout, into the b arrays */
+            for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
+                const double ed = (double)sh.ae[k];
+                const double v = sh.av[k];
+                sh.bv[k] = (v > 0.0) ? (ed * LFQ_LN2_HI + (ed * LFQ_LN2_LO + log(v))) : -INFINITY;
+            }
+        }
+        __syncthreads();
+        if ((!pruned || R.uf_mask) && w == 0) {
+            const lfq_col_counts cnt = counts[R.col];
+            lfq_emit_pvals(cx, cnt, sh.bv, K, !pruned, R.uf_mask, R.uf_bound, R.force_fe != 0, rows_total, W, pvals,
+                           pvals_capacity);
         }
     }
 }
@@ -1062,5 +1647,48 @@ int lfq_launch_dp_big(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
     hipLaunchKernelGGL(lfq_dp_big_kernel, dim3((unsigned)n_blocks), dim3(LFQ_HEAVY_WAVES * 64), 0,
                        (hipStream_t)stream, t, p, d_luts, d_counts, w, d_pvals, pvals_capacity, d_scratch,
                        scratch_doubles_per_block);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+
+int lfq_launch_dp_big_prep(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                           const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
+                           int64_t pvals_capacity, int n_blocks, void *stream)
+{
+    if (t.ncols <= 0 || n_blocks <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_dp_big_prep_kernel, dim3((unsigned)n_blocks), dim3(LFQ_PREP_WAVES * 64), 0,
+                       (hipStream_t)stream, t, p, d_luts, d_counts, w, d_pvals, pvals_capacity);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+int lfq_launch_dp_seg(int seg_class, const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                      const LfqWork &w, int n_waves, void *stream)
+{
+    if (t.ncols <= 0 || n_waves <= 0) {
+        return LFQ_OK;
+    }
+    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (seg_class) {
+    case 0: hipLaunchKernelGGL(lfq_dp_seg_kernel<1>, grid, block, 0, st, t, p, d_luts, w, 0); break;
+    case 1: hipLaunchKernelGGL(lfq_dp_seg_kernel<4>, grid, block, 0, st, t, p, d_luts, w, 1); break;
+    case 2: hipLaunchKernelGGL(lfq_dp_seg_kernel<8>, grid, block, 0, st, t, p, d_luts, w, 2); break;
+    case 3: hipLaunchKernelGGL(lfq_dp_seg_kernel<16>, grid, block, 0, st, t, p, d_luts, w, 3); break;
+    case 4: hipLaunchKernelGGL(lfq_dp_seg_kernel<32>, grid, block, 0, st, t, p, d_luts, w, 4); break;
+    default: return LFQ_ERR_INVALID;
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+int lfq_launch_dp_combine(const LfqParams &p, const lfq_col_counts *d_counts, const LfqWork &w,
+                          lfq_col_pvals *d_pvals, int64_t pvals_capacity, int n_blocks, void *stream)
+{
+    if (n_blocks <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_dp_combine_kernel, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
+                       (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

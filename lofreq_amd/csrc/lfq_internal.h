@@ -61,6 +61,51 @@ struct LfqEntry {
     int32_t pad2_;
 };
 
+/* ---- row-split ("long") columns ------------------------------------------------------------------
+ * The rows of a column are independent Bernoulli trials, so the count distribution of the whole column is
+ * the convolution of the distributions of disjoint row ranges.  A column that is still alive after a
+ * first stretch of rows (or is known to be long: the big class) is cut into up to LFQ_SEG_MAX row
+ * segments that run concurrently from the identity distribution; a combine step folds the segment
+ * distributions (cells 0..K-1 plus the absorbing tail cell K) back together.  This turns one
+ * N-row latency chain into N/R rows + (R-1) K^2/2-term convolutions. */
+struct LfqSegCell {
+    double v;                 /* mantissa in [0.5, 1) or 0 */
+    int32_t e;                /* binary exponent: value = v * 2^e */
+    int32_t pad_;
+};
+
+struct LfqLong {              /* 128 bytes */
+    uint64_t off0;            /* the column, as in its LfqEntry */
+    int64_t bonf;             /* running Bonferroni factor at this column */
+    int64_t cell0;            /* segment r, cell k lives at pool[cell0 + r * (K + 1) + k] */
+    int32_t n_obs, col;
+    int32_t K;                /* recurrence size (largest allele count that is not an 80-bit underflow) */
+    int32_t n_seg;            /* segments incl. segment 0 */
+    int32_t ch_begin;         /* first chunk of the split range */
+    int32_t phase1;           /* 1: segment 0 is the state the wave kernel had reached at ch_begin */
+    uint32_t uf_mask;
+    int32_t force_fe;
+    int32_t pruned;           /* set by any segment whose own tail already exceeds the pruning threshold */
+    int32_t rows;             /* kept rows processed so far (diagnostic, lfq_col_pvals.dp_rows) */
+    int16_t median_ref_bq;
+    uint8_t ref_code;
+    uint8_t pad0_;
+    int32_t pad1_;
+    double uf_bound[3];
+    int64_t pad_[4];
+};
+
+#define LFQ_SEG_MAX 8
+/* a row segment always runs on ONE wavefront, with as many cells per lane as its K needs: the classes are
+ * K <= 63 (1 cell per lane), <= 252 (4), <= 504 (8), <= 1008 (16), <= 2016 (32) -- (K + C) / C <= 64 lanes
+ * incl. alignment.  More cells per lane = fewer instructions
+ * per cell (the per-row overhead is shared), which is what counts once the segments provide the parallelism. */
+#define LFQ_SEG_CLASSES 5
+#define LFQ_SEG_MIN_CHUNKS 16     /* no segment shorter than this many 64-row chunks */
+#define LFQ_PHASE1_CHUNKS 32      /* mid class: rows run unsplit before a surviving column is cut up */
+#define LFQ_SPLIT_MAX_K 2016      /* 63 * 32: one wavefront at 32 cells per lane; the combine kernel keeps two
+                                   * (K+1)-cell distributions in LDS */
+
 /* work lists and counters produced by the scan kernels, consumed by the DP kernel */
 struct LfqWork {
     int32_t *tested_prefix;   /* [ncols] inclusive count of tested columns up to and incl. c */
@@ -68,11 +113,16 @@ struct LfqWork {
     int32_t *gcounters;       /* batch-wide counters shared by all segments, see LFQ_GC_* */
     int32_t *counters;        /* [16] of this segment, see LFQ_CNT_* */
     int32_t *block_sums;      /* scan scratch */
+    LfqLong *longs;           /* [long_cap]: LFQ_SEG_CLASSES lists of long_cap / LFQ_SEG_CLASSES records each */
+    int32_t *unsplit;         /* big-list indices of the big columns that run unsplit (lfq_dp_big_kernel) */
+    LfqSegCell *pool;         /* [pool_cells] segment distributions, bump-allocated (LFQ_CNT_POOL) */
+    int32_t long_cap;
+    int32_t pool_cells;
 };
 
 #define LFQ_MID_K 64          /* K+1 cells no longer fit one cell per lane */
 #define LFQ_BIG_K 250         /* K+1 (+alignment) cells no longer fit one 64x4 strip: strip pipeline */
-#define LFQ_NCOUNTERS 16
+#define LFQ_NCOUNTERS 32
 #define LFQ_MAX_SEGMENTS 8      /* a batch is cut into segments so that the DP of one overlaps the count of the next */
 #define LFQ_GC_PVALS 0         /* records appended to the sparse output */
 #define LFQ_GC_OVERFLOW 1
@@ -86,6 +136,11 @@ struct LfqWork {
 #define LFQ_CNT_CARRY_IN 15    /* tested columns in earlier segments of the batch */
 #define LFQ_CNT_HEAD_LIGHT 12  /* dynamic work distribution of the wave-per-column kernels */
 #define LFQ_CNT_HEAD_MID 13
+#define LFQ_CNT_UNSPLIT 5       /* big columns left to lfq_dp_big_kernel */
+#define LFQ_CNT_HEAD_PREP 6
+#define LFQ_CNT_POOL 7         /* cells handed out from LfqWork::pool */
+#define LFQ_CNT_HEAD_COMB 24
+#define LFQ_CNT_LONG0 16       /* +class: row-split columns per cells-per-lane class (LFQ_SEG_CLASSES) */
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
 int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);
@@ -103,6 +158,13 @@ int lfq_launch_dp_big(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
                       const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                       int64_t pvals_capacity, double *d_scratch, int64_t scratch_doubles_per_block,
                       int n_blocks, void *stream);
+int lfq_launch_dp_big_prep(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                           const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
+                           int64_t pvals_capacity, int n_blocks, void *stream);
+int lfq_launch_dp_seg(int seg_class, const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                      const LfqWork &w, int n_waves, void *stream);
+int lfq_launch_dp_combine(const LfqParams &p, const lfq_col_counts *d_counts, const LfqWork &w,
+                          lfq_col_pvals *d_pvals, int64_t pvals_capacity, int n_blocks, void *stream);
 int lfq_launch_synth(const struct lfq_synth_spec *d_spec_host, int64_t col_begin, int64_t ncols,
                      uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off,
                      uint8_t *d_ref_base, void *stream);

@@ -234,3 +234,42 @@ def test_golden_reference_binary_vcf(caller, oracle):
             a = [bytes([int(x)]) for x in ores["alt_base"][c]].index(r["alt"])
             if int(r["alt_raw_count"]) == int(ores["alt_raw_counts"][c, a]):
                 assert g == e, (path, g, e)
+
+
+def test_row_split_long_columns(caller, oracle):
+    """Deep columns take the row-split route (segments from the identity distribution + convolution fold,
+    lfq_dp_segw/segb/combine kernels): K from ~40 to ~2400 at depth 6000..10000, every allele compared."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(31)
+    afs = [0.004, 0.008, 0.012, 0.02, 0.03, 0.05, 0.08, 0.12, 0.2, 0.24, 0.0, 0.0]
+    planted = {c: af for c, af in enumerate(afs * 3) if af > 0}
+    host = util.random_batch(rng, len(afs) * 3, 6000, 10000, planted=planted)
+    for kw in (dict(bonf_dynamic=0, bonf_subst=1, sig=1.0), dict()):
+        ores, oconf = util.run_oracle(oracle, host, **kw)
+        conf = la.VarcallConf(**kw)
+        counts, pvals, st = util.run_layer1(la, caller, host, conf)
+        util.assert_counts_equal(counts, ores, host)
+        got = {int(p["col"]): p for p in pvals}
+        ncmp = 0
+        for c in range(len(ores)):
+            if not ores["tested"][c]:
+                continue
+            bonf = int(ores["bonf_used"][c])
+            for a in range(3):
+                pv = ores["pvalue"][c, a]
+                if ores["alt_counts"][c, a] == 0 or pv == util.LDBL_MAX:
+                    continue
+                if not kw and not (pv * bonf < np.float32(conf.sig)):
+                    continue            # not significant: the device may have pruned it
+                assert c in got, (c, a)
+                p = got[c]
+                gpv = la.pvalue_from_log(p["logp"][a], int(p["status"][a]))
+                util.assert_pvalue_close(gpv, pv, 1e-9 if pv < 1e-600 else util.PV_LOG_TOL, ctx="col %d allele %d" % (c, a))
+                ncmp += 1
+        assert ncmp >= (60 if kw else 20), ncmp
+    # and through layer 2 (records, QUAL, dynamic Bonferroni)
+    ores, oconf = util.run_oracle(oracle, host)
+    conf = la.VarcallConf()
+    recs, _, _ = caller.call_snvs(util.to_pileup_batch(la, host), conf)
+    _compare_records(la, recs, ores, host, tol=1e-9)
+    assert conf.bonf_subst == oconf.bonf_subst
