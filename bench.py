@@ -99,8 +99,7 @@ def main():
         caller.snv_batch_device(batch, conf, d_counts, d_pvals, pv_cap)
         st = caller.batch_finish()
         pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
-        ref = batch.ref_base[:ncols].cpu().numpy()
-        recs, total = shard.finish_shard(conf, pv, st.n_tested, ref, col_begin,
+        recs, total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin,      # records carry their ref base
                                          dist if world > 1 else None, dev)
         text = None
         if rank == 0:

@@ -126,7 +126,8 @@ typedef struct lfq_col_pvals {
     int64_t bonf;              /* running Bonferroni factor at this column */
     double logp[3];            /* natural-log p-values, same allele order as the counts */
     uint8_t status[3];
-    uint8_t pad_[5];
+    uint8_t ref_base;          /* 'A','C','G','T': the column's reference base, so that the host needs no track */
+    uint8_t pad_[4];
     lfq_col_counts counts;     /* copy of the dense entry, so the host needs nothing else */
     int32_t dp_rows;           /* DP rows processed (diagnostic) */
     int32_t pad2_;

@@ -78,7 +78,7 @@ COL_COUNTS_DTYPE = np.dtype([
 assert COL_COUNTS_DTYPE.itemsize == 64
 
 COL_PVALS_DTYPE = np.dtype([
-    ("col", "i8"), ("bonf", "i8"), ("logp", "f8", 3), ("status", "u1", 3), ("pad_", "u1", 5),
+    ("col", "i8"), ("bonf", "i8"), ("logp", "f8", 3), ("status", "u1", 3), ("ref_base", "u1"), ("pad_", "u1", 4),
     ("counts", COL_COUNTS_DTYPE), ("dp_rows", "i4"), ("pad2_", "i4"), ("reserved_", "i8")], align=True)
 assert COL_PVALS_DTYPE.itemsize == 128
 

@@ -203,23 +203,26 @@ def pvalue_from_log(logp, status):
     n = C.c_int64(0)
     ref = np.frombuffer(b"A", dtype=np.uint8)
     _lib.check(_lib.load().lfq_finalize_pvals(C.byref(conf.c), C.c_void_p(pv.ctypes.data), 1, None,
-                                              C.c_void_p(ref.ctypes.data), C.c_void_p(rec.ctypes.data), 4,
+                                              C.c_void_p(ref.ctypes.data) if ref is not None else None,
+                                              C.c_void_p(rec.ctypes.data), 4,
                                               C.byref(n)))
     if n.value == 0:
         return np.finfo(np.longdouble).max
     return rec["pvalue"][0]
 
 
-def finalize_pvals(conf, pvals, ref_base, coverage_plp=None):
-    """Host finishing step on sparse device records -> reported SNVs (column order)."""
+def finalize_pvals(conf, pvals, ref_base=None, coverage_plp=None):
+    """Host finishing step on sparse device records -> reported SNVs (column order).  `ref_base` may be None:
+    every record carries its column's reference base."""
     pvals = np.ascontiguousarray(pvals, dtype=_lib.COL_PVALS_DTYPE)
     rec = np.zeros(max(3 * len(pvals), 4), dtype=_lib.SNV_RECORD_DTYPE)
     n = C.c_int64(0)
-    ref = np.ascontiguousarray(ref_base, dtype=np.uint8)
+    ref = None if ref_base is None else np.ascontiguousarray(ref_base, dtype=np.uint8)
     cov = None if coverage_plp is None else np.ascontiguousarray(coverage_plp, dtype=np.int32)
     _lib.check(_lib.load().lfq_finalize_pvals(C.byref(conf.c), C.c_void_p(pvals.ctypes.data), len(pvals),
                                               C.c_void_p(cov.ctypes.data) if cov is not None else None,
-                                              C.c_void_p(ref.ctypes.data), C.c_void_p(rec.ctypes.data),
+                                              C.c_void_p(ref.ctypes.data) if ref is not None else None,
+                                              C.c_void_p(rec.ctypes.data),
                                               len(rec), C.byref(n)))
     return rec[: n.value].copy()
 

@@ -14,6 +14,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "lfq_internal.h"
@@ -46,8 +49,7 @@ struct lfq_ctx {
     LfqEntry *d_entries;
     hipStream_t dps;           /* scan + light DP of a segment, beside the next segment's count kernel */
     hipStream_t side[2];       /* big / mid DP kernels run beside the light one */
-    hipStream_t aux[2];        /* second row-segment class of each side stream */
-    hipEvent_t ev_aux[2], ev_mid;
+    hipEvent_t ev_mid;
     hipEvent_t ev_cnt[LFQ_MAX_SEGMENTS][2];    /* count kernel of segment s: start, stop (main stream) */
     hipEvent_t ev_scan[LFQ_MAX_SEGMENTS];      /* work lists of segment s ready (dps) */
     hipEvent_t ev_light[LFQ_MAX_SEGMENTS][2];  /* light kernel (dps) */
@@ -62,6 +64,7 @@ struct lfq_ctx {
     int32_t long_cap, pool_cells;
     hipEvent_t ev_segw, ev_prep;
     int32_t *d_unsplit;
+    uint8_t *d_retry;          /* light columns the quad kernel hands to the one-column-per-wave kernel */
     int32_t *h_counters;   /* pinned */
     /* layer-2 owned outputs / staging */
     lfq_col_counts *d_counts;
@@ -77,6 +80,16 @@ struct lfq_ctx {
     hipEvent_t ev[4];
     lfq_kernel_times times;
     int n_cu;
+    /* strand-bias precompute (lfq_internal.h): DP4 tuples land in host-mapped memory right after the scan;
+     * a leader thread waits for that and runs the Fisher tests on the host pool while the DP kernels run */
+    int32_t *h_tuples, *d_tuples_mapped;      /* [3 * heavy_cap][4] */
+    int32_t *h_nheavy, *d_nheavy_mapped;
+    int heavy_cap;
+    hipEvent_t ev_heavy;
+    std::thread *leader;
+    std::mutex *lm;
+    std::condition_variable *lcv;
+    int leader_go, leader_stop;
 };
 
 namespace {
@@ -155,6 +168,10 @@ int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bool i
     P->prune_slack = 1e-6;
     P->bonf_step = 3;
     P->bonf_reset_first = 1;
+    P->seg_max = LFQ_SEG_MAX;
+    if (const char *e = getenv("LFQ_SEG_MAX")) {                 /* experiments: fewer, longer row segments */
+        P->seg_max = std::min(LFQ_SEG_MAX, std::max(2, atoi(e)));
+    }
     if (indel_mode) {
         /* call_indels: no base / merged-quality filters, every event is a test (lofreq_call.c:684-725);
          * the alignment-quality track is "used" wherever the packer filled it in */
@@ -187,6 +204,26 @@ void fill_luts(LfqLuts *L)
     L->mq[0] = 0.5;         /* MQ0_ERRPROB (snpcaller.c:64, 315-316) */
 }
 
+void leader_main(lfq_ctx *c)
+{
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(*c->lm);
+            c->lcv->wait(lk, [&] { return c->leader_go > 0 || c->leader_stop; });
+            if (c->leader_stop) {
+                return;
+            }
+            c->leader_go--;
+        }
+        int64_t n = 0;
+        if (hipEventSynchronize(c->ev_heavy) == hipSuccess) {
+            n = std::min<int64_t>(std::max<int64_t>(*(volatile int32_t *)c->h_nheavy, 0), c->heavy_cap);
+        }
+        lfq_sb_precompute(c->h_tuples, 3 * n);        /* ends the begin() bracket even when n == 0 */
+    }
+}
+
 int ensure_workspace(lfq_ctx *c, int64_t ncols)
 {
     if (ncols > c->ws_cols) {
@@ -197,7 +234,9 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         if (c->d_entries) (void)hipFree(c->d_entries);
         if (c->d_tiles) (void)hipFree(c->d_tiles);
         if (c->d_unsplit) (void)hipFree(c->d_unsplit);
+        if (c->d_retry) (void)hipFree(c->d_retry);
         c->d_unsplit = nullptr;
+        c->d_retry = nullptr;
         c->d_flags = nullptr;
         c->d_prefix = nullptr;
         c->d_entries = nullptr;
@@ -212,6 +251,8 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8 * (LFQ_MAX_SEGMENTS + 1))));
         cap = 0;
         LFQ_TRY(grow(&c->d_unsplit, &cap, want));
+        cap = 0;
+        LFQ_TRY(grow(&c->d_retry, &cap, want));
         c->ws_cols = want;
     }
     return LFQ_OK;
@@ -257,9 +298,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     ok = ok && hipStreamCreateWithPriority(&c->dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
     for (int i = 0; ok && i < 2; i++) {
-        ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess
-             && hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_hi) == hipSuccess
-             && hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming) == hipSuccess;
+        ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
     }
     for (int i = 0; ok && i < 3; i++) {
         ok = hipEventCreate(&c->ev_join[i]) == hipSuccess;
@@ -270,6 +309,20 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
         ok = ok && hipEventCreate(&c->ev_light[s][0]) == hipSuccess && hipEventCreate(&c->ev_light[s][1]) == hipSuccess;
         for (int i = 0; ok && i < 2; i++) {
             ok = hipEventCreate(&c->ev_side[i][s][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][s][1]) == hipSuccess;
+        }
+    }
+    if (ok) {
+        c->heavy_cap = 1 << 16;
+        ok = hipHostMalloc((void **)&c->h_tuples, (size_t)c->heavy_cap * 3 * 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess
+             && hipHostMalloc((void **)&c->h_nheavy, 64, hipHostMallocMapped) == hipSuccess
+             && hipHostGetDevicePointer((void **)&c->d_tuples_mapped, c->h_tuples, 0) == hipSuccess
+             && hipHostGetDevicePointer((void **)&c->d_nheavy_mapped, c->h_nheavy, 0) == hipSuccess
+             && hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            *c->h_nheavy = 0;
+            c->lm = new std::mutex();
+            c->lcv = new std::condition_variable();
+            c->leader = new std::thread(leader_main, c);
         }
     }
     if (ok) {
@@ -287,12 +340,29 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
 
 void lfq_destroy(lfq_ctx *c)
 {
+    if (c && c->leader) {
+        {
+            std::lock_guard<std::mutex> lk(*c->lm);
+            c->leader_stop = 1;
+        }
+        c->lcv->notify_all();
+        c->leader->join();
+        delete c->leader;
+        delete c->lm;
+        delete c->lcv;
+        c->leader = nullptr;
+    }
+    if (c) {
+        if (c->h_tuples) (void)hipHostFree(c->h_tuples);
+        if (c->h_nheavy) (void)hipHostFree(c->h_nheavy);
+        if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
+    }
     if (!c) {
         return;
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_entries, c->d_counters, c->d_tiles, c->d_longs, c->d_pool, c->d_unsplit,
+    void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_entries, c->d_counters, c->d_tiles, c->d_longs, c->d_pool, c->d_unsplit, c->d_retry,
                     c->d_scratch, c->d_counts, c->d_pvals, c->d_stage};
     for (void *b : bufs) {
         if (b) (void)hipFree(b);
@@ -316,8 +386,6 @@ void lfq_destroy(lfq_ctx *c)
     }
     for (int i = 0; i < 2; i++) {
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
-        if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
-        if (c->ev_aux[i]) (void)hipEventDestroy(c->ev_aux[i]);
     }
     if (c->dps) (void)hipStreamDestroy(c->dps);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -372,6 +440,9 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     c->cur_ncols = ncols;
     c->cur_segments = 0;
     LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
+    if (ncols > 0) {
+        LFQ_TRY_HIP(hipMemsetAsync(c->d_retry, 0, (size_t)ncols, st));
+    }
     LFQ_TRY_HIP(hipEventRecord(c->ev[0], st));
     if (ncols == 0) {
         LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
@@ -444,6 +515,17 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         LFQ_TRY_HIP(hipStreamWaitEvent(c->dps, c->ev_cnt[s][1], 0));
         LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, c->dps));
         LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], c->dps));
+        if (n_seg == 1 && !indel_mode && c->leader && !getenv("LFQ_NO_SB_PRECOMPUTE")) {
+            /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start now */
+            LFQ_TRY(lfq_launch_gather_heavy(W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, c->dps));
+            LFQ_TRY_HIP(hipEventRecord(c->ev_heavy, c->dps));
+            lfq_sb_precompute_begin();
+            {
+                std::lock_guard<std::mutex> lk(*c->lm);
+                c->leader_go++;
+            }
+            c->lcv->notify_one();
+        }
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
          * latency-bound kernels of the long columns, or they only start when it ends */
@@ -453,10 +535,6 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         }
         const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * light_waves_per_cu, std::max<int64_t>(seg_cols / 8, 4));
         const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(seg_cols, 4));
-        for (int i = 0; i < 2; i++) {
-            LFQ_TRY_HIP(hipStreamWaitEvent(c->side[i], c->ev_scan[s], 0));
-            LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][0], c->side[i]));
-        }
         const bool run_big = !skip || !strstr(skip, "big"), run_mid = !skip || !strstr(skip, "mid");
         const bool dbg_sync = getenv("LFQ_DEBUG_SYNC") != nullptr;    /* debugging aid: serialize and name the stages */
 #define LFQ_DBG_STAGE(name)                                                        \
@@ -467,49 +545,48 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
             fprintf(stderr, "[lfq] %s done (%d)\n", name, (int)e_);                \
         }                                                                          \
     } while (0)
-        /* big class: bounds + split decision, then the row segments of the wide classes, then whatever
-         * could not be split; mid class: first stretch of rows, then the row segments of the survivors;
-         * finally the fold + emission of every split column */
+        /* Stream plan (4 streams = the 4 hardware queues; more streams would share queues and serialise):
+         *   dps     scan -> big prep -> quad (light columns) -> retry
+         *   side[0] [prep] -> row segments of the big class -> unsplit big columns -> [side[1]] -> fold + emission
+         *   side[1] [scan] -> mid kernel (first stretch of rows) -> [prep] -> row segments of the mid class
+         * The prep kernel is short but latency-bound; beside the quad kernel it starves, and everything behind
+         * it on the critical path with it, so it runs BEFORE the quad kernel. */
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[1], c->ev_scan[s], 0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[1][s][0], c->side[1]));
         if (run_big) {
-            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[0]));
+            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu * 2, c->dps));
             LFQ_DBG_STAGE("prep");
         }
-        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, c->side[0]));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, c->dps));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_prep, 0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[0][s][0], c->side[0]));
         if (run_mid) {
             LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
             LFQ_DBG_STAGE("mid");
         }
-        LFQ_TRY_HIP(hipEventRecord(c->ev_mid, c->side[1]));
-        /* the five row-segment classes: 2 on side[0], 3 and 4 on aux[0] (records from the prep kernel only);
-         * 1 on side[1], 0 on aux[1] (records from the mid kernel; K = 250..252 of the big class lands in 1) */
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->aux[0], c->ev_prep, 0));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->aux[1], c->ev_prep, 0));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->aux[1], c->ev_mid, 0));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[1], c->ev_prep, 0));
         if (run_big) {
-            LFQ_TRY(lfq_launch_dp_seg(2, T, P, c->d_luts, W, c->n_cu * 8, c->side[0]));
-            LFQ_DBG_STAGE("seg2");
-            LFQ_TRY(lfq_launch_dp_seg(3, T, P, c->d_luts, W, c->n_cu * 8, c->aux[0]));
-            LFQ_TRY(lfq_launch_dp_seg(4, T, P, c->d_luts, W, c->n_cu * 4, c->aux[0]));
-            LFQ_DBG_STAGE("seg3+seg4");
+            LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, c->side[0]));
+            LFQ_DBG_STAGE("seg big");
+            LFQ_TRY(lfq_launch_dp_combine(1, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[0]));
+            LFQ_DBG_STAGE("combine big");
             LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
                                       n_big_blocks, c->side[0]));
             LFQ_DBG_STAGE("big");
         }
-        LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, c->side[1]));
-        LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, c->aux[1]));
-        LFQ_DBG_STAGE("seg0+seg1");
-        LFQ_TRY_HIP(hipEventRecord(c->ev_segw, c->side[1]));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_aux[0], c->aux[0]));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_aux[1], c->aux[1]));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_segw, 0));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_aux[0], 0));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_aux[1], 0));
-        LFQ_TRY(lfq_launch_dp_combine(P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[0]));
-        LFQ_DBG_STAGE("combine");
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[1], c->ev_prep, 0));     /* K = 250..252 of the big class lands in class 1 */
+        LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, c->side[1]));
+        LFQ_DBG_STAGE("seg mid");
+        LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[1]));
+        LFQ_DBG_STAGE("combine mid");
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], c->dps));
         if (!skip || !strstr(skip, "light")) {
-            LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, c->dps));
+            const char *lk = getenv("LFQ_LIGHT_KERNEL");
+            if (lk && !strcmp(lk, "wave")) {            /* A/B switch: the one-column-per-wavefront kernel */
+                LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, c->dps));
+            } else {
+                LFQ_TRY(lfq_launch_dp_quad(T, P, c->d_luts, d_counts, W, c->d_retry + c0, d_pvals, pvals_capacity,
+                                           n_light_waves, c->dps));
+            }
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], c->dps));
         for (int i = 0; i < 2; i++) {
@@ -660,8 +737,6 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
     const int64_t ncols = tr->ncols;
     lfq_tracks dev;
     LFQ_TRY(stage_tracks(c, tr, tracks_on_device, &dev));
-    std::vector<uint8_t> h_ref;
-
     LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
     LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
     LFQ_TRY(lfq_snv_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
@@ -683,21 +758,8 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         LFQ_TRY_HIP(hipMemcpy(h_counts_or_null, c->d_counts, (size_t)ncols * sizeof(lfq_col_counts),
                               hipMemcpyDeviceToHost));
     }
-    /* reference bases of the surviving columns (a handful of bytes when tracks live in HBM) */
-    const uint8_t *ref_host = nullptr;
-    if (!tracks_on_device) {
-        ref_host = tr->ref_base;
-    } else {
-        h_ref.assign((size_t)ncols, 'N');
-        if (st.n_pvals * 64 > ncols) {
-            LFQ_TRY_HIP(hipMemcpy(h_ref.data(), dev.ref_base, (size_t)ncols, hipMemcpyDeviceToHost));
-        } else {
-            for (const lfq_col_pvals &r : h_pv) {
-                LFQ_TRY_HIP(hipMemcpy(&h_ref[(size_t)r.col], dev.ref_base + r.col, 1, hipMemcpyDeviceToHost));
-            }
-        }
-        ref_host = h_ref.data();
-    }
+    /* the reference base of a surviving column travels in its record (lfq_col_pvals.ref_base) */
+    const uint8_t *ref_host = tracks_on_device ? nullptr : tr->ref_base;
 #ifdef LFQ_TRACE
     fprintf(stderr, "[lfq] finalizing\n");
 #endif

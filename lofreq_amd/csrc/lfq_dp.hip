@@ -303,6 +303,10 @@ __device__ __forceinline__ void lfq_strip_store_logs(const LfqStrip<C> &S, int g
     }
 }
 
+/* exponent stored with a zero mantissa: sums of two of them stay far below any real exponent, so the fold's
+ * running-maximum alignment needs no special case for empty cells */
+#define LFQ_EXT_ZERO_E (-(1 << 24))
+
 /* a strip's cells in (mantissa, exponent) form -> the segment pool (cells 0..K-1 and the tail cell K) */
 template <int C>
 __device__ __forceinline__ void lfq_strip_store_cells(const LfqStrip<C> &S, int gl, int shift, int K, LfqSegCell *out)
@@ -314,7 +318,7 @@ __device__ __forceinline__ void lfq_strip_store_cells(const LfqStrip<C> &S, int 
             const double v = S.v[j];
             LfqSegCell c;
             c.v = (v > 0.0) ? __builtin_amdgcn_frexp_mant(v) : 0.0;
-            c.e = (v > 0.0) ? S.e + __builtin_amdgcn_frexp_exp(v) : 0;
+            c.e = (v > 0.0) ? S.e + __builtin_amdgcn_frexp_exp(v) : LFQ_EXT_ZERO_E;   /* 0 = 0 * 2^(very small) */
             c.pad_ = 0;
             out[k] = c;
         }
@@ -324,12 +328,12 @@ __device__ __forceinline__ void lfq_strip_store_cells(const LfqStrip<C> &S, int 
 /* How many NEW row segments to cut `rem_chunks` remaining chunks of a K-cell column into (0 = do not split).
  * Bounds: LFQ_SEG_MAX segments in total, no segment shorter than LFQ_SEG_MIN_CHUNKS chunks, and the
  * (segments - 1) convolutions of K^2/2 terms must stay below a quarter of the rows * K recurrence work. */
-__device__ __forceinline__ int lfq_split_plan(int K, int64_t rem_chunks, int phase1)
+__device__ __forceinline__ int lfq_split_plan(int K, int64_t rem_chunks, int phase1, int seg_max)
 {
     if (K > LFQ_SPLIT_MAX_K) {
         return 0;
     }
-    int64_t n_new = LFQ_SEG_MAX - phase1;
+    int64_t n_new = seg_max - phase1;
     n_new = min(n_new, rem_chunks / LFQ_SEG_MIN_CHUNKS);
     n_new = min(n_new, rem_chunks * 64 / (2 * (int64_t)max(K, 1)) + 1 - phase1);
     return n_new >= 2 ? (int)n_new : 0;
@@ -471,8 +475,9 @@ __device__ __noinline__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_c
                 r.logp[a] = logp[a];
                 r.status[a] = (uint8_t)status[a];
             }
+            r.ref_base = (uint8_t)"ACGT"[cx.ref_code & 3];
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
+            for (int i = 0; i < 4; i++) {
                 r.pad_[i] = 0;
             }
             r.counts = cnt;
@@ -618,8 +623,9 @@ __device__ void lfq_emit_linear(const LfqColCtx &cx, const lfq_col_counts &cnt, 
                 r.logp[a] = logp[a];
                 r.status[a] = (uint8_t)status[a];
             }
+            r.ref_base = (uint8_t)"ACGT"[cx.ref_code & 3];
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
+            for (int i = 0; i < 4; i++) {
                 r.pad_[i] = 0;
             }
             r.counts = cnt;
@@ -730,7 +736,9 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
         if (SPLIT && ch + 1 == LFQ_PHASE1_CHUNKS) {
             /* still alive after the first stretch of rows: cut the rest into concurrent row segments;
              * the state reached here becomes segment 0 (lfq_dp_segw_kernel, lfq_dp_combine_kernel) */
-            const int n_new = lfq_split_plan(K, n_chunks - (ch + 1), 1);
+            /* fewer, longer segments when many columns are long anyway: the fold costs (segments - 1) convolutions */
+            const int n_new = lfq_split_plan(K, n_chunks - (ch + 1), 1,
+                                             min(P.seg_max, max(2, 4096 / max(W.counters[LFQ_CNT_MID], 1))));
             if (n_new > 0) {
                 const int n_seg = n_new + 1;
                 const int cells = n_seg * (K + 1);
@@ -877,6 +885,240 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
             raw = raw_next;
             en_next = en_next2;
             have_next = have_next2;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* light columns, four at a time                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Almost every column of a deep pileup is "light": a handful of mismatches (K <= 15) whose tail
+ * probability crosses the pruning threshold within a few dozen rows.  One column per wavefront leaves
+ * 60 of 64 lanes idle in the recurrence, so this kernel runs FOUR columns per wavefront, one per 16-lane
+ * DPP row: cell k of a column on lane k of its row (row_shr:1 brings the left neighbour, bound_ctrl feeds
+ * 0 into cell 0), 16 observations of each column evaluated per step (one per lane), 16 rows of the
+ * recurrence per step, pruning test every 8 rows.  A row group whose column is pruned takes the next
+ * column from the wavefront's claimed batch.  The kernel only PRUNES: a column that survives
+ * LFQ_Q_MAX_STEPS steps or reaches its end, or has K > 15, is flagged in `retry` and done from scratch by
+ * lfq_dp_retry_kernel (one wavefront per column, emission included) -- about 0.1 % of the columns. */
+#define LFQ_Q_MAXK 15
+#define LFQ_Q_MAX_STEPS 64
+
+__device__ __forceinline__ int lfq_rowshr1_i32(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    /* row_shr:1, 0 into lane 0 of each row */
+}
+
+__device__ __forceinline__ double lfq_rowshr1_f64(double x)
+{
+    const int lo = lfq_rowshr1_i32(__double2loint(x));
+    const int hi = lfq_rowshr1_i32(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqParams P,
+                                                          const LfqLuts *__restrict__ g_luts, LfqWork W,
+                                                          uint8_t *__restrict__ retry, int batch)
+{
+    __shared__ LfqLuts s_luts;
+    __shared__ LfqRow s_rows[4][64];
+    {
+        const double *src = reinterpret_cast<const double *>(g_luts);
+        double *dst = reinterpret_cast<double *>(&s_luts);
+        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
+            dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const int lane = lfq_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = lane >> 4, l = lane & 15;
+    const int n_work = W.counters[LFQ_CNT_LIGHT];
+    const LfqEntry *list = W.entries;               /* the light class leads the work list */
+    LfqRow *rows = s_rows[wave];
+    const double sig_s = P.sig * (1.0 + P.prune_slack);
+
+    int q_next = 0, q_end = 0;                      /* this wavefront's claimed batch (wave-uniform) */
+    bool exhausted = false;
+    /* state of the row group's column, replicated on its 16 lanes */
+    bool active = false;
+    uint64_t off0 = 0;
+    int n_obs = 0, cursor = 0, K = 0, ref_code = 0, med = 0, steps = 0, list_idx = 0;
+    double bonf_d = 1.0, tflag = 0.0;
+    double v = 0.0;
+    int e = 0, de = 0;
+    uint32_t raw_w = 4u, raw_sq = 255u;             /* the observation this lane evaluates in the next step */
+
+    for (;;) {
+        /* ---- hand new columns to the row groups that have none ---- */
+        uint64_t need = __ballot(!active);
+        while (need != 0ull && !exhausted) {
+            if (q_next >= q_end) {
+                const int b0 = lfq_claim(&W.counters[LFQ_CNT_HEAD_LIGHT], batch);
+                if (b0 >= n_work) {
+                    exhausted = true;
+                    break;
+                }
+                q_next = b0;
+                q_end = min(b0 + batch, n_work);
+            }
+            const unsigned gm = (unsigned)((need & 1ull) | ((need >> 15) & 2ull) | ((need >> 30) & 4ull) | ((need >> 45) & 8ull));
+            const int take = min(__popc(gm), q_end - q_next);
+            const int rank = __popc(gm & ((1u << g) - 1u));
+            const bool mine = !active && rank < take;
+            const int idx = q_next + rank;
+            q_next += take;
+            if (mine) {
+                const uint4 *ep = reinterpret_cast<const uint4 *>(list + idx);
+                const uint4 a = ep[0], b = ep[1];
+                K = (int)b.y;
+                if (K > LFQ_Q_MAXK) {
+                    if (l == 0) {
+                        retry[idx] = 1;             /* needs more than one DPP row: one-column-per-wave kernel */
+                    }
+                } else {
+                    active = true;
+                    off0 = ((uint64_t)a.y << 32) | a.x;
+                    n_obs = (int)a.z;
+                    int64_t bonf = P.bonf_base;
+                    if (P.bonf_dynamic) {           /* lfq_col_setup */
+                        bonf = ((P.bonf_reset_first && P.bonf_base == 1) ? 0 : P.bonf_base)
+                               + (int64_t)P.bonf_step * (int)b.x;
+                    }
+                    bonf_d = (double)bonf;
+                    med = (int)(int16_t)(b.z & 0xffffu);
+                    ref_code = (int)((b.z >> 16) & 0xffu);
+                    cursor = 0;
+                    steps = 0;
+                    list_idx = idx;
+                    v = (l == 0) ? 1.0 : 0.0;
+                    e = 0;
+                    de = 0;
+                    tflag = (l == K) ? 1.0 : 0.0;
+                    raw_w = 4u;
+                    raw_sq = 255u;
+                    if (l < n_obs) {
+                        const uint64_t o = off0 + (uint64_t)l;
+                        raw_w = (uint32_t)T.nt[o] | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
+                                | ((uint32_t)T.mq[o] << 24);
+                        raw_sq = T.sq ? T.sq[o] : 255u;
+                    }
+                }
+            }
+            need = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) {
+            break;
+        }
+
+        /* ---- 16 observations per column: (p, 1-p) rows into LDS ---- */
+        {
+            const LfqObs o = lfq_eval_obs(raw_w & 0xffu, (raw_w >> 8) & 0xffu, (raw_w >> 16) & 0xffu, raw_w >> 24, raw_sq,
+                                          ref_code, med, P, &s_luts);
+            const bool keep = active && o.keep;
+            const double ps = (fabs(o.p) < LFQ_DBL_EPS) ? LFQ_DBL_EPS : o.p;                       /* lfq_eval_raw */
+            const double qf = (fabs(o.p - 1.0) < LFQ_DBL_EPS) ? 1.0 + (-o.p + LFQ_DBL_EPS) : 1.0 - o.p;
+            LfqRow r;
+            r.p = keep ? ps : 0.0;
+            r.q = keep ? qf : 1.0;
+            rows[lane] = r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        cursor += 16;
+        raw_w = 4u;                                  /* an N base: ignored */
+        raw_sq = 255u;
+        if (active && cursor + l < n_obs) {          /* lands while the rows below run */
+            const uint64_t o = off0 + (uint64_t)(cursor + l);
+            raw_w = (uint32_t)T.nt[o] | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
+                    | ((uint32_t)T.mq[o] << 24);
+            raw_sq = T.sq ? T.sq[o] : 255u;
+        }
+
+        /* ---- 16 rows, renormalisation + pruning test after each 8 ---- */
+        bool pruned = false;
+        const LfqRow *grow = rows + (g << 4);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const LfqRow pq = grow[half * 8 + r];
+                const double x = lfq_rowshr1_f64(v);
+                const double pe = ldexp(pq.p, de);
+                const double q0 = fma(tflag, pq.p, pq.q);
+                v = fma(x, pe, v * q0);
+            }
+            const bool nzl = v > 0.0;
+            const uint64_t nz = __ballot(nzl);
+            const int ex = nzl ? __builtin_amdgcn_frexp_exp(v) : 0;
+            v = ldexp(v, -ex);
+            e += ex;
+            /* empty cells (a suffix of the row group) adopt the scale of the frontier cell */
+            const unsigned field = (unsigned)(nz >> (g << 4)) & 0xffffu;
+            const int front = (g << 4) + (field ? 31 - __clz((int)field) : l);
+            const int e_front = __shfl(e, nzl ? lane : front, 64);
+            e = nzl ? e : e_front;
+            de = lfq_rowshr1_i32(e) - e;
+            const uint64_t over = __ballot(ldexp(v, e) * bonf_d > sig_s);
+            pruned = pruned || ((over >> ((g << 4) + K)) & 1ull) != 0ull;
+        }
+        steps += 1;
+        if (active) {
+            if (pruned) {
+                active = false;                     /* p * bonf > sig for good: nothing to report */
+            } else if (cursor >= n_obs || steps >= LFQ_Q_MAX_STEPS) {
+                if (l == 0) {
+                    retry[list_idx] = 1;            /* survivor (or a long one): finish it on a whole wavefront */
+                }
+                active = false;
+            }
+        }
+    }
+}
+
+/* the columns the quad kernel flagged: static partition of the light list over the wavefronts */
+__global__ __launch_bounds__(256) void lfq_dp_retry_kernel(LfqTracksDev T, LfqParams P,
+                                                           const LfqLuts *__restrict__ g_luts,
+                                                           const lfq_col_counts *__restrict__ counts, LfqWork W,
+                                                           const uint8_t *__restrict__ retry,
+                                                           lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity)
+{
+    __shared__ LfqLuts s_luts;
+    __shared__ LfqRow s_rows[4][64];
+    {
+        const double *src = reinterpret_cast<const double *>(g_luts);
+        double *dst = reinterpret_cast<double *>(&s_luts);
+        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
+            dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const int lane = lfq_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_work = W.counters[LFQ_CNT_LIGHT];
+    const int n_waves_total = (int)gridDim.x * 4;
+    LfqRow *rows = s_rows[wave];
+    for (int base = ((int)blockIdx.x * 4 + wave) * 64; base < n_work; base += n_waves_total * 64) {
+        const int i = base + lane;
+        uint64_t m = __ballot(i < n_work && retry[i] != 0);
+        while (m != 0ull) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const LfqEntry en = lfq_load_entry(W.entries, base + j);
+            LfqColCtx cx;
+            lfq_col_setup(cx, en, P);
+            const LfqRaw raw = lfq_load_chunk_at(en.off0, en.n_obs, 0, T);
+            LfqPrefetch pf;
+            pf.want_raw = false;
+            pf.want_entry = false;
+            pf.off0 = 0;
+            pf.n_obs = 0;
+            pf.entry_ptr = nullptr;
+            pf.raw = nullptr;
+            pf.entry = nullptr;
+            lfq_wave_column<1, true, false>(cx, raw, T, P, &s_luts, rows, counts, W, pvals, pvals_capacity, pf);
         }
     }
 }
@@ -1245,8 +1487,9 @@ __global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
                         r.logp[a] = uf ? uf_bound[a] : 0.0;
                         r.status[a] = (uint8_t)(uf ? LFQ_PV_UNDERFLOW : LFQ_PV_NONE);
                     }
+                    r.ref_base = (uint8_t)"ACGT"[cx.ref_code & 3];
 #pragma unroll
-                    for (int i = 0; i < 5; i++) {
+                    for (int i = 0; i < 4; i++) {
                         r.pad_[i] = 0;
                     }
                     r.counts = cnt;
@@ -1261,7 +1504,7 @@ __global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
             continue;
         }
         if (threadIdx.x == 0) {
-            const int n_new = lfq_split_plan(kp, n_chunks, 0);
+            const int n_new = lfq_split_plan(kp, n_chunks, 0, min(P.seg_max, max(2, 2048 / max(n_big, 1))));
             int64_t cell0 = 0;
             LfqLong *slot = (n_new > 0) ? lfq_long_reserve(W, kp, n_new, &cell0) : nullptr;
             if (slot) {
@@ -1339,9 +1582,12 @@ __device__ __forceinline__ void lfq_wave_segment(const LfqColCtx &cx, int64_t ch
     }
 }
 
-template <int C>
+/* MODE 0: the classes fed by the mid kernel (1 and 4 cells per lane); MODE 1: the classes fed by the big
+ * prep kernel (8, 16, 32).  Items = (record, segment) pairs, class-major, static stride over the
+ * wavefronts: the loop is free of atomics. */
+template <int MODE>
 __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqParams P,
-                                                         const LfqLuts *__restrict__ g_luts, LfqWork W, int cls)
+                                                         const LfqLuts *__restrict__ g_luts, LfqWork W)
 {
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
@@ -1354,18 +1600,28 @@ __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqPara
         }
     }
     __syncthreads();
+    constexpr int C_LO = MODE ? 2 : 0, C_N = MODE ? 3 : 2;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int per_class = W.long_cap / LFQ_SEG_CLASSES;
-    const int n_long = min(W.counters[LFQ_CNT_LONG0 + cls], per_class);
-    const int n_items = n_long * LFQ_SEG_MAX;
-    const LfqLong *list = W.longs + cls * per_class;
+    int n_items[C_N], total = 0;
+#pragma unroll
+    for (int c = 0; c < C_N; c++) {
+        n_items[c] = min(W.counters[LFQ_CNT_LONG0 + C_LO + c], per_class) * LFQ_SEG_MAX;
+        total += n_items[c];
+    }
     LfqRow *rows = s_rows[wave];
-    /* the segments of a class cost about the same: a static stride over (record, segment) is balanced, and
-     * the loop stays free of atomics (n_waves_total wavefronts; item idx = record * LFQ_SEG_MAX + segment) */
     const int n_waves_total = (int)gridDim.x * 4;
-    for (int idx = (int)blockIdx.x * 4 + wave; idx < n_items; idx += n_waves_total) {
-        const int r = idx % LFQ_SEG_MAX;
-        const LfqLong R = list[idx / LFQ_SEG_MAX];
+    for (int idx = (int)blockIdx.x * 4 + wave; idx < total; idx += n_waves_total) {
+        int c = 0, i = idx;
+#pragma unroll
+        for (int k = 0; k < C_N - 1; k++) {
+            if (c == k && i >= n_items[k]) {
+                i -= n_items[k];
+                c = k + 1;
+            }
+        }
+        const int r = i % LFQ_SEG_MAX;
+        const LfqLong R = W.longs[(C_LO + c) * per_class + i / LFQ_SEG_MAX];
         if (r < R.phase1 || r >= R.n_seg) {
             continue;
         }
@@ -1373,7 +1629,22 @@ __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqPara
         lfq_ctx_from_long(cx, R, P);
         int64_t c0, c1;
         lfq_seg_range(R, r, &c0, &c1);
-        lfq_wave_segment<C>(cx, c0, c1, T, P, &s_luts, rows, W.pool + R.cell0 + (int64_t)r * (R.K + 1));
+        LfqSegCell *out = W.pool + R.cell0 + (int64_t)r * (R.K + 1);
+        if (MODE == 0) {
+            if (c == 0) {
+                lfq_wave_segment<1>(cx, c0, c1, T, P, &s_luts, rows, out);
+            } else {
+                lfq_wave_segment<4>(cx, c0, c1, T, P, &s_luts, rows, out);
+            }
+        } else {
+            if (c == 0) {
+                lfq_wave_segment<8>(cx, c0, c1, T, P, &s_luts, rows, out);
+            } else if (c == 1) {
+                lfq_wave_segment<16>(cx, c0, c1, T, P, &s_luts, rows, out);
+            } else {
+                lfq_wave_segment<32>(cx, c0, c1, T, P, &s_luts, rows, out);
+            }
+        }
     }
 }
 
@@ -1384,7 +1655,6 @@ __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqPara
 #define LFQ_COMB_THREADS 512
 #define LFQ_COMB_CELLS 2048
 #define LFQ_COMB_PER_THREAD (LFQ_COMB_CELLS / LFQ_COMB_THREADS)
-#define LFQ_EXT_ZERO_E (-(1 << 28))
 
 struct LfqCombShared {
     double av[LFQ_COMB_CELLS];
@@ -1393,6 +1663,8 @@ struct LfqCombShared {
     int be[LFQ_COMB_CELLS];
     double rv[LFQ_COMB_THREADS / 64];
     int re[LFQ_COMB_THREADS / 64];
+    double cv[LFQ_COMB_CELLS / 64 + 1];     /* chunk totals of the suffix scan */
+    int ce[LFQ_COMB_CELLS / 64 + 1];
     double tot_v;
     int tot_e;
     int idx, pruned;
@@ -1402,10 +1674,11 @@ __device__ __forceinline__ LfqExt lfq_ext_norm(double v, int e)
 {
     LfqExt r;
     r.v = (v > 0.0) ? __builtin_amdgcn_frexp_mant(v) : 0.0;
-    r.e = (v > 0.0) ? e + __builtin_amdgcn_frexp_exp(v) : 0;
+    r.e = (v > 0.0) ? e + __builtin_amdgcn_frexp_exp(v) : LFQ_EXT_ZERO_E;
     return r;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqParams P,
                                                                           const lfq_col_counts *__restrict__ counts,
                                                                           LfqWork W, lfq_col_pvals *__restrict__ pvals,
@@ -1415,17 +1688,19 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
     const int tid = threadIdx.x;
     const int lane = lfq_lane();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    /* MODE as in lfq_dp_seg_kernel: 0 = classes 0..1 (mid kernel's columns), 1 = classes 2..4 (big class) */
+    constexpr int C_LO = MODE ? 2 : 0, C_HI = MODE ? LFQ_SEG_CLASSES : 2;
     const int per_class = W.long_cap / LFQ_SEG_CLASSES;
     int n_cls[LFQ_SEG_CLASSES], n_all = 0;
 #pragma unroll
     for (int c = 0; c < LFQ_SEG_CLASSES; c++) {
-        n_cls[c] = min(W.counters[LFQ_CNT_LONG0 + c], per_class);
+        n_cls[c] = (c >= C_LO && c < C_HI) ? min(W.counters[LFQ_CNT_LONG0 + c], per_class) : 0;
         n_all += n_cls[c];
     }
     for (;;) {
         __syncthreads();
         if (tid == 0) {
-            sh.idx = atomicAdd(&W.counters[LFQ_CNT_HEAD_COMB], 1);
+            sh.idx = atomicAdd(&W.counters[LFQ_CNT_HEAD_COMB + MODE], 1);
         }
         __syncthreads();
         int h = sh.idx;
@@ -1439,6 +1714,9 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
         }
         const LfqLong R = W.longs[cls * per_class + h];
         const int K = R.K;
+#ifdef LFQ_PROFILE
+        const long long pw_rec = wall_clock64();
+#endif
         LfqColCtx cx;
         lfq_ctx_from_long(cx, R, P);
         /* row counts and pruned flags of the segments the segment kernels wrote (pad of their cell 0) */
@@ -1456,6 +1734,15 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                 sh.av[k] = c.v;
                 sh.ae[k] = c.e;
             }
+#ifdef LFQ_PROFILE
+            long long pt[6] = {0, 0, 0, 0, 0, 0};
+            const long long pc_start = clock64();
+            const long long pw_start = wall_clock64();
+#define LFQ_PT(i) do { const long long t_ = wall_clock64(); pt[i] += t_ - pt_last; pt_last = t_; } while (0)
+            long long pt_last = pw_start;
+#else
+#define LFQ_PT(i)
+#endif
             for (int s = 1; s < R.n_seg; s++) {
                 seg += K + 1;
                 for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
@@ -1464,6 +1751,7 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                     sh.be[k] = c.e;
                 }
                 __syncthreads();
+                LFQ_PT(0);
                 /* c_k = sum_i a_i b_(k-i), k < K: aligned to a running maximum exponent */
                 LfqExt out[LFQ_COMB_PER_THREAD];
 #pragma unroll
@@ -1472,15 +1760,14 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                     /* four independent accumulators: the LDS reads and the ldexp/add chains of consecutive
                      * terms overlap instead of serialising */
                     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                    int me[4] = {LFQ_EXT_ZERO_E, LFQ_EXT_ZERO_E, LFQ_EXT_ZERO_E, LFQ_EXT_ZERO_E};
+                    int me[4] = {4 * LFQ_EXT_ZERO_E, 4 * LFQ_EXT_ZERO_E, 4 * LFQ_EXT_ZERO_E, 4 * LFQ_EXT_ZERO_E};
                     if (k < K) {
                         int i = 0;
                         for (; i + 3 <= k; i += 4) {
 #pragma unroll
                             for (int u = 0; u < 4; u++) {
                                 const double t = sh.av[i + u] * sh.bv[k - i - u];
-                                int x = sh.ae[i + u] + sh.be[k - i - u];
-                                x = (t != 0.0) ? x : LFQ_EXT_ZERO_E;
+                                const int x = sh.ae[i + u] + sh.be[k - i - u];
                                 const int nm = max(me[u], x);
                                 acc[u] = ldexp(acc[u], me[u] - nm) + ldexp(t, x - nm);
                                 me[u] = nm;
@@ -1488,8 +1775,7 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                         }
                         for (; i <= k; i++) {
                             const double t = sh.av[i] * sh.bv[k - i];
-                            int x = sh.ae[i] + sh.be[k - i];
-                            x = (t != 0.0) ? x : LFQ_EXT_ZERO_E;
+                            const int x = sh.ae[i] + sh.be[k - i];
                             const int nm = max(me[0], x);
                             acc[0] = ldexp(acc[0], me[0] - nm) + ldexp(t, x - nm);
                             me[0] = nm;
@@ -1504,35 +1790,76 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                     out[m] = lfq_ext_norm(ldexp(s01.v, s01.e - se) + ldexp(s23.v, s23.e - se), se);
                 }
                 __syncthreads();
-                /* in place: b[j] <- S_B(j) = b[j] + ... + b[K-1] + tail_B  (wave 0, suffix scan from the top) */
-                if (w == 0) {
-                    LfqExt carry;
-                    carry.v = 0.0;
-                    carry.e = 0;
-                    for (int base = K; base >= 0; base -= 64) {
-                        const int j = base - lane;
-                        LfqExt incl;
-                        incl.v = (j >= 0) ? sh.bv[j] : 0.0;
-                        incl.e = (j >= 0) ? sh.be[j] : 0;
+                LFQ_PT(1);
+                /* in place: b[j] <- S_B(j) = b[j] + ... + b[K-1] + tail_B.  Two levels: every wavefront
+                 * suffix-scans 64-cell chunks (chunk c = cells K-64c-63 .. K-64c, lane 0 = highest index), the chunk
+                 * totals are suffix-combined by wave 0, then added back. */
+                const int n_chunks_b = (K + 64) / 64;
+                for (int c = w; c < n_chunks_b; c += LFQ_COMB_THREADS / 64) {
+                    const int j = K - 64 * c - lane;
+                    LfqExt incl;
+                    incl.v = (j >= 0) ? sh.bv[j] : 0.0;
+                    incl.e = (j >= 0) ? sh.be[j] : LFQ_EXT_ZERO_E;
 #pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            LfqExt y;
-                            y.v = __shfl_up(incl.v, d, 64);
-                            y.e = __shfl_up(incl.e, d, 64);
-                            if (lane >= d) {
-                                incl = lfq_ext_add(incl, y);
-                            }
+                    for (int d = 1; d < 64; d <<= 1) {
+                        LfqExt y;
+                        y.v = __shfl_up(incl.v, d, 64);
+                        y.e = __shfl_up(incl.e, d, 64);
+                        if (lane >= d) {
+                            incl = lfq_ext_add(incl, y);
                         }
-                        const LfqExt tot = lfq_ext_add(carry, incl);
-                        if (j >= 0) {
-                            sh.bv[j] = tot.v;
-                            sh.be[j] = tot.e;
-                        }
-                        carry.v = lfq_rl_f64(tot.v, 63);
-                        carry.e = lfq_rl_i32(tot.e, 63);
+                    }
+                    if (j >= 0) {
+                        sh.bv[j] = incl.v;
+                        sh.be[j] = incl.e;
+                    }
+                    if (lane == 63) {
+                        sh.cv[c] = incl.v;              /* chunk total */
+                        sh.ce[c] = incl.e;
                     }
                 }
                 __syncthreads();
+                if (w == 0) {
+                    /* exclusive suffix over the chunk totals: carry[c] = sum of chunks 0..c-1 (the higher cells) */
+                    LfqExt t;
+                    t.v = (lane < n_chunks_b) ? sh.cv[lane] : 0.0;
+                    t.e = (lane < n_chunks_b) ? sh.ce[lane] : LFQ_EXT_ZERO_E;
+                    LfqExt incl = t;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        LfqExt y;
+                        y.v = __shfl_up(incl.v, d, 64);
+                        y.e = __shfl_up(incl.e, d, 64);
+                        if (lane >= d) {
+                            incl = lfq_ext_add(incl, y);
+                        }
+                    }
+                    LfqExt ex;
+                    ex.v = __shfl_up(incl.v, 1, 64);
+                    ex.e = __shfl_up(incl.e, 1, 64);
+                    if (lane == 0) {
+                        ex.v = 0.0;
+                        ex.e = LFQ_EXT_ZERO_E;
+                    }
+                    if (lane < n_chunks_b) {
+                        sh.cv[lane] = ex.v;
+                        sh.ce[lane] = ex.e;
+                    }
+                }
+                __syncthreads();
+                for (int j = tid; j <= K; j += LFQ_COMB_THREADS) {
+                    const int c = (K - j) >> 6;
+                    LfqExt a, b;
+                    a.v = sh.bv[j];
+                    a.e = sh.be[j];
+                    b.v = sh.cv[c];
+                    b.e = sh.ce[c];
+                    a = lfq_ext_add(a, b);
+                    sh.bv[j] = a.v;
+                    sh.be[j] = a.e;
+                }
+                __syncthreads();
+                LFQ_PT(2);
                 /* tail_C = tail_A + sum_(i<K) a_i S_B(K-i) */
                 LfqExt part;
                 part.v = 0.0;
@@ -1583,7 +1910,19 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                     sh.ae[K] = sh.tot_e;
                 }
                 __syncthreads();
+                LFQ_PT(3);
             }
+#ifdef LFQ_PROFILE
+            if (tid == 0) {
+                atomicAdd(&W.counters[8], (int)pt[0]);
+                atomicAdd(&W.counters[9], (int)pt[1]);
+                atomicAdd(&W.counters[10], (int)pt[2]);
+                atomicAdd(&W.counters[11], (int)pt[3]);
+                atomicAdd(&W.counters[12], (int)((clock64() - pc_start) >> 8));
+                atomicAdd(&W.counters[13], (int)(wall_clock64() - pw_start));
+                atomicAdd(&W.counters[14], 1);
+            }
+#endif
             if (R.n_seg <= 1) {
                 __syncthreads();
             }
@@ -1598,11 +1937,20 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
             }
         }
         __syncthreads();
+#ifdef LFQ_PROFILE
+        const long long pw_emit = wall_clock64();
+#endif
         if ((!pruned || R.uf_mask) && w == 0) {
             const lfq_col_counts cnt = counts[R.col];
             lfq_emit_pvals(cx, cnt, sh.bv, K, !pruned, R.uf_mask, R.uf_bound, R.force_fe != 0, rows_total, W, pvals,
                            pvals_capacity);
         }
+#ifdef LFQ_PROFILE
+        if (tid == 0) {
+            atomicAdd(&W.counters[25], (int)(wall_clock64() - pw_emit));      /* emit */
+            atomicAdd(&W.counters[26], (int)(wall_clock64() - pw_rec));       /* whole record */
+        }
+#endif
     }
 }
 
@@ -1663,32 +2011,48 @@ int lfq_launch_dp_big_prep(const LfqTracksDev &t, const LfqParams &p, const LfqL
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 
-int lfq_launch_dp_seg(int seg_class, const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+int lfq_launch_dp_seg(int mode, const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                       const LfqWork &w, int n_waves, void *stream)
 {
     if (t.ncols <= 0 || n_waves <= 0) {
         return LFQ_OK;
     }
     const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (seg_class) {
-    case 0: hipLaunchKernelGGL(lfq_dp_seg_kernel<1>, grid, block, 0, st, t, p, d_luts, w, 0); break;
-    case 1: hipLaunchKernelGGL(lfq_dp_seg_kernel<4>, grid, block, 0, st, t, p, d_luts, w, 1); break;
-    case 2: hipLaunchKernelGGL(lfq_dp_seg_kernel<8>, grid, block, 0, st, t, p, d_luts, w, 2); break;
-    case 3: hipLaunchKernelGGL(lfq_dp_seg_kernel<16>, grid, block, 0, st, t, p, d_luts, w, 3); break;
-    case 4: hipLaunchKernelGGL(lfq_dp_seg_kernel<32>, grid, block, 0, st, t, p, d_luts, w, 4); break;
-    default: return LFQ_ERR_INVALID;
+    if (mode == 0) {
+        hipLaunchKernelGGL(lfq_dp_seg_kernel<0>, grid, block, 0, (hipStream_t)stream, t, p, d_luts, w);
+    } else {
+        hipLaunchKernelGGL(lfq_dp_seg_kernel<1>, grid, block, 0, (hipStream_t)stream, t, p, d_luts, w);
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 
-int lfq_launch_dp_combine(const LfqParams &p, const lfq_col_counts *d_counts, const LfqWork &w,
+int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_counts, const LfqWork &w,
                           lfq_col_pvals *d_pvals, int64_t pvals_capacity, int n_blocks, void *stream)
 {
     if (n_blocks <= 0) {
         return LFQ_OK;
     }
-    hipLaunchKernelGGL(lfq_dp_combine_kernel, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
-                       (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+    if (mode == 0) {
+        hipLaunchKernelGGL(lfq_dp_combine_kernel<0>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+    } else {
+        hipLaunchKernelGGL(lfq_dp_combine_kernel<1>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                       const lfq_col_counts *d_counts, const LfqWork &w, uint8_t *d_retry, lfq_col_pvals *d_pvals,
+                       int64_t pvals_capacity, int n_waves, void *stream)
+{
+    if (t.ncols <= 0 || n_waves <= 0) {
+        return LFQ_OK;
+    }
+    const unsigned blocks = (unsigned)((n_waves + 3) / 4);
+    hipLaunchKernelGGL(lfq_dp_quad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, w, d_retry,
+                       32);
+    hipLaunchKernelGGL(lfq_dp_retry_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, d_counts,
+                       w, d_retry, d_pvals, pvals_capacity);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

@@ -17,10 +17,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "lofreq_amd.h"
+#include "lfq_internal.h"
 
 namespace {
 
@@ -106,6 +111,199 @@ double hypergeom_next(int n11, int n1_, int n_1, int n, HyperAcc &s)
 }
 
 }  // namespace
+
+namespace {
+
+/* A small persistent pool for the host finishing step (strand-bias Fisher tests): spawning threads per
+ * batch costs more than the work.  Threads are created on first use and parked on a condition variable. */
+class LfqPool {
+public:
+    static LfqPool &instance()
+    {
+        static LfqPool p;
+        return p;
+    }
+    int size() const { return (int)threads_.size(); }
+    /* run `f` on `helpers` pool threads and on the caller; returns when all of them are done */
+    void run(const std::function<void()> &f, int helpers)
+    {
+        helpers = std::max(0, std::min(helpers, size()));
+        if (helpers == 0) {
+            f();
+            return;
+        }
+        std::unique_lock<std::mutex> call_lock(call_m_);      /* one batch at a time */
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &f;
+            want_ = helpers;
+            pending_ = helpers;
+            generation_++;
+        }
+        cv_start_.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    LfqPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, 63u);
+        if (const char *e = getenv("LFQ_HOST_THREADS")) {
+            n = std::max(0, std::min(atoi(e) - 1, 255));
+        }
+        for (int i = 0; i < n; i++) {
+            threads_.emplace_back([this, i] { loop(i); });
+        }
+    }
+    ~LfqPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            generation_++;
+        }
+        cv_start_.notify_all();
+        for (auto &t : threads_) {
+            t.join();
+        }
+    }
+    void loop(int idx)
+    {
+        int seen = 0;
+        for (;;) {
+            const std::function<void()> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_start_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) {
+                    return;
+                }
+                if (idx >= want_) {
+                    continue;           /* not needed for this batch */
+                }
+                job = job_;
+            }
+            (*job)();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                pending_--;
+            }
+            cv_done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_, call_m_;
+    std::condition_variable cv_start_, cv_done_;
+    const std::function<void()> *job_ = nullptr;
+    int generation_ = 0, want_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace
+
+namespace {
+
+struct SbKey {
+    int32_t a, b, c, d;
+    bool operator==(const SbKey &o) const { return a == o.a && b == o.b && c == o.c && d == o.d; }
+};
+struct SbKeyHash {
+    size_t operator()(const SbKey &k) const
+    {
+        uint64_t h = (uint64_t)(uint32_t)k.a * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)(uint32_t)k.b + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+        h ^= ((uint64_t)(uint32_t)k.c + 0x165667B1ull) * 0x9E3779B97F4A7C15ull + (h << 6);
+        h ^= ((uint64_t)(uint32_t)k.d + 0x27D4EB2Full) * 0xC2B2AE3D27D4EB4Full + (h >> 3);
+        return (size_t)h;
+    }
+};
+
+class LfqSbCache {
+public:
+    static LfqSbCache &instance()
+    {
+        static LfqSbCache c;
+        return c;
+    }
+    void begin()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        inflight_++;
+    }
+    void publish_and_end(std::vector<std::pair<SbKey, int>> &items)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            map_.clear();                       /* one batch's worth: the cache never grows without bound */
+            map_.reserve(items.size() * 2);
+            for (auto &it : items) {
+                map_.emplace(it.first, it.second);
+            }
+            inflight_--;
+        }
+        cv_.notify_all();
+    }
+    void wait_idle()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return inflight_ == 0; });
+    }
+    bool lookup(const SbKey &k, int *sb)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        auto it = map_.find(k);
+        if (it == map_.end()) {
+            return false;
+        }
+        *sb = it->second;
+        return true;
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    int inflight_ = 0;
+    std::unordered_map<SbKey, int, SbKeyHash> map_;
+};
+
+}  // namespace
+
+void lfq_sb_precompute_begin(void) { LfqSbCache::instance().begin(); }
+
+void lfq_sb_precompute(const int32_t *tuples, int64_t n)
+{
+    std::vector<std::pair<SbKey, int>> items;
+    items.reserve((size_t)std::max<int64_t>(n, 0));
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t *t = tuples + 4 * i;
+        if (t[0] | t[1] | t[2] | t[3]) {
+            items.push_back({SbKey{t[0], t[1], t[2], t[3]}, 0});
+        }
+    }
+    /* most expensive first (cost ~ range of the hypergeometric sum), one item at a time */
+    std::sort(items.begin(), items.end(), [](const std::pair<SbKey, int> &x, const std::pair<SbKey, int> &y) {
+        return (int64_t)x.first.c + x.first.d > (int64_t)y.first.c + y.first.d;
+    });
+    std::atomic<int64_t> next(0);
+    const int64_t m = (int64_t)items.size();
+    auto work = [&]() {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= m) {
+                break;
+            }
+            const SbKey &k = items[(size_t)i].first;
+            items[(size_t)i].second = lfq_sb_phred(k.a, k.b, k.c, k.d);
+        }
+    };
+    LfqPool::instance().run(work, (int)std::min<int64_t>(LfqPool::instance().size(), m / 2));
+    LfqSbCache::instance().publish_and_end(items);
+}
 
 extern "C" {
 
@@ -285,7 +483,7 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
         if (!main_ok) {
             continue;
         }
-        char refc = ref_base ? (char)ref_base[r.col] : 'N';
+        char refc = ref_base ? (char)ref_base[r.col] : (char)r.ref_base;      /* the record carries it */
         int ref_code = -1;
         for (int x = 0; x < 4; x++) {
             if (acgt[x] == refc) {
@@ -330,33 +528,35 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
      * the columns themselves run on the GPU.  Records are independent: spread them over host threads. */
     {
         const int64_t n = n_out;
-        unsigned hw = std::thread::hardware_concurrency();
-        int nthreads = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 32u), (n + 15) / 16);
         std::atomic<int64_t> next(0);
-        auto work = [&]() {
-            for (;;) {
-                const int64_t i0 = next.fetch_add(8);
-                if (i0 >= n) {
-                    break;
-                }
-                for (int64_t i = i0; i < std::min(n, i0 + 8); i++) {
-                    lfq_snv_record &o = records[i];
-                    o.sb = lfq_sb_phred(o.ref_fw, o.ref_rv, o.alt_fw, o.alt_rv);
-                }
-            }
-        };
-        if (nthreads <= 1) {
-            work();
-        } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads - 1; t++) {
-                pool.emplace_back(work);
-            }
-            work();
-            for (auto &t : pool) {
-                t.join();
+        /* expensive tables were precomputed while the DP kernels ran (lfq_sb_precompute); the rest here */
+        LfqSbCache &cache = LfqSbCache::instance();
+        cache.wait_idle();
+        std::vector<int64_t> miss;
+        for (int64_t i = 0; i < n; i++) {
+            lfq_snv_record &o = records[i];
+            if (!cache.lookup(SbKey{o.ref_fw, o.ref_rv, o.alt_fw, o.alt_rv}, &o.sb)) {
+                miss.push_back(i);
             }
         }
+        const int64_t nm = (int64_t)miss.size();
+        auto work = [&]() {
+            for (;;) {
+                const int64_t j = next.fetch_add(1);    /* one record at a time: their costs differ by 100x */
+                if (j >= nm) {
+                    break;
+                }
+                lfq_snv_record &o = records[miss[(size_t)j]];
+                o.sb = lfq_sb_phred(o.ref_fw, o.ref_rv, o.alt_fw, o.alt_rv);
+            }
+        };
+        int64_t cost = 0;
+        for (int64_t j = 0; j < nm; j++) {
+            cost += records[miss[(size_t)j]].alt_fw + records[miss[(size_t)j]].alt_rv;
+        }
+        /* waking the pool costs more than a few cheap tables */
+        const int helpers = cost < 20000 ? 0 : (int)std::min<int64_t>(LfqPool::instance().size(), nm / 4);
+        LfqPool::instance().run(work, helpers);
     }
     *n_records = n_out;
     return LFQ_OK;

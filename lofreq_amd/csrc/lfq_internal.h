@@ -37,6 +37,8 @@ struct LfqParams {
     int32_t bonf_reset_first; /* SNVs: the first tested column SETS the factor to 3 instead of adding (lofreq_call.c:795-796) */
     double sig;               /* (double)(float)conf->sig */
     double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
+    int32_t seg_max;          /* row segments per split column, 2..LFQ_SEG_MAX */
+    int32_t pad_;
 };
 
 struct LfqTracksDev {
@@ -142,7 +144,18 @@ struct LfqWork {
 #define LFQ_CNT_HEAD_COMB 24
 #define LFQ_CNT_LONG0 16       /* +class: row-split columns per cells-per-lane class (LFQ_SEG_CLASSES) */
 
+/* ---- strand-bias precompute (host, lfq_host.cpp) ---------------------------------------------------
+ * report_var's Fisher test (lofreq_call.c:117-129) depends only on the DP4 counts, which are final after
+ * the count kernel.  While the DP kernels run, a host thread computes it for the columns with many alt
+ * bases (the expensive ones) into a process-wide content-addressed cache that lfq_finalize_pvals consults.
+ * Purely an optimisation: a miss is computed on the spot, bit-identically. */
+void lfq_sb_precompute_begin(void);
+/* tuples: n x {ref_fw, ref_rv, alt_fw, alt_rv}; all-zero tuples are skipped.  Ends the begin() bracket. */
+void lfq_sb_precompute(const int32_t *tuples, int64_t n);
+
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
+int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, int32_t *tuples_mapped,
+                            int32_t *n_mapped, int cap_entries, int min_alt, void *stream);
 int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, void *stream);
@@ -151,6 +164,9 @@ int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t
 int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                         const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                         int64_t pvals_capacity, int n_waves, void *stream);
+int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+                       const lfq_col_counts *d_counts, const LfqWork &w, uint8_t *d_retry, lfq_col_pvals *d_pvals,
+                       int64_t pvals_capacity, int n_waves, void *stream);
 int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                       const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                       int64_t pvals_capacity, int n_waves, void *stream);
@@ -161,9 +177,9 @@ int lfq_launch_dp_big(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
 int lfq_launch_dp_big_prep(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                            const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                            int64_t pvals_capacity, int n_blocks, void *stream);
-int lfq_launch_dp_seg(int seg_class, const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
+int lfq_launch_dp_seg(int mode, const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                       const LfqWork &w, int n_waves, void *stream);
-int lfq_launch_dp_combine(const LfqParams &p, const lfq_col_counts *d_counts, const LfqWork &w,
+int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_counts, const LfqWork &w,
                           lfq_col_pvals *d_pvals, int64_t pvals_capacity, int n_blocks, void *stream);
 int lfq_launch_synth(const struct lfq_synth_spec *d_spec_host, int64_t col_begin, int64_t ncols,
                      uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off,

@@ -607,3 +607,42 @@ int lfq_launch_synth(const lfq_synth_spec *spec, int64_t col_begin, int64_t ncol
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* DP4 tuples of the columns with many alt bases -> host-mapped memory (strand-bias precompute) */
+/* ------------------------------------------------------------------------------------------ */
+
+__global__ __launch_bounds__(256) void lfq_gather_heavy_kernel(LfqWork W, const lfq_col_counts *__restrict__ counts,
+                                                               int32_t *__restrict__ tuples, int32_t *__restrict__ n_out,
+                                                               int cap_entries, int min_alt)
+{
+    const int n_light = W.counters[LFQ_CNT_LIGHT];
+    const int n_heavy = min(W.counters[LFQ_CNT_MID] + W.counters[LFQ_CNT_BIG], cap_entries);
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i == 0) {
+        __hip_atomic_store(n_out, n_heavy, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (i >= n_heavy) {
+        return;
+    }
+    const LfqEntry en = W.entries[n_light + i];
+    const lfq_col_counts c = counts[en.col];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int4 t = make_int4(0, 0, 0, 0);
+        if (c.alt_raw_counts[a] >= min_alt) {
+            t = make_int4(c.ref_fw, c.ref_rv, c.alt_fw[a], c.alt_raw_counts[a] - c.alt_fw[a]);
+        }
+        reinterpret_cast<int4 *>(tuples)[3 * i + a] = t;
+    }
+}
+
+int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, int32_t *tuples_mapped,
+                            int32_t *n_mapped, int cap_entries, int min_alt, void *stream)
+{
+    const unsigned blocks = (unsigned)((cap_entries + 255) / 256);
+    hipLaunchKernelGGL(lfq_gather_heavy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, d_counts,
+                       tuples_mapped, n_mapped, cap_entries, min_alt);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
