@@ -897,13 +897,12 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
  * probability crosses the pruning threshold within a few dozen rows.  One column per wavefront leaves
  * 60 of 64 lanes idle in the recurrence, so this kernel runs FOUR columns per wavefront, one per 16-lane
  * DPP row: cell k of a column on lane k of its row (row_shr:1 brings the left neighbour, bound_ctrl feeds
- * 0 into cell 0), 16 observations of each column evaluated per step (one per lane), 16 rows of the
- * recurrence per step, pruning test every 8 rows.  A row group whose column is pruned takes the next
+ * 0 into cell 0), GL observations of each column evaluated per step (one per lane), GL rows of the
+ * recurrence per step, pruning test every 8 rows.  A lane group whose column is pruned takes the next
  * column from the wavefront's claimed batch.  The kernel only PRUNES: a column that survives
- * LFQ_Q_MAX_STEPS steps or reaches its end, or has K > 15, is flagged in `retry` and done from scratch by
- * lfq_dp_retry_kernel (one wavefront per column, emission included) -- about 0.1 % of the columns. */
-#define LFQ_Q_MAXK 15
-#define LFQ_Q_MAX_STEPS 64
+ * LFQ_Q_MAX_ROWS rows or reaches its end, or has K >= GL, is flagged in `retry` and done from scratch by
+ * lfq_dp_retry_kernel (one wavefront per column, emission included) -- under 1 % of the columns. */
+#define LFQ_Q_MAX_ROWS 1024
 
 __device__ __forceinline__ int lfq_rowshr1_i32(int x)
 {
@@ -917,10 +916,16 @@ __device__ __forceinline__ double lfq_rowshr1_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
+/* GL = lanes per column: 16 (four columns per wavefront, K <= 15) or 8 (eight columns, K <= 7: half a DPP
+ * row each; the neighbour that row_shr:1 drags across the middle of a row is multiplied by 2^-4000 = 0). */
+template <int GL>
 __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqParams P,
                                                           const LfqLuts *__restrict__ g_luts, LfqWork W,
                                                           uint8_t *__restrict__ retry, int batch)
 {
+    constexpr int NG = 64 / GL;                     /* columns in flight per wavefront */
+    constexpr int MAXK = GL - 1;
+    constexpr int MAX_STEPS = LFQ_Q_MAX_ROWS / GL;
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
     {
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
     __syncthreads();
     const int lane = lfq_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g = lane >> 4, l = lane & 15;
+    const int g = lane / GL, l = lane % GL;
     const int n_work = W.counters[LFQ_CNT_LIGHT];
     const LfqEntry *list = W.entries;               /* the light class leads the work list */
     LfqRow *rows = s_rows[wave];
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
 
     int q_next = 0, q_end = 0;                      /* this wavefront's claimed batch (wave-uniform) */
     bool exhausted = false;
-    /* state of the row group's column, replicated on its 16 lanes */
+    /* state of the lane group's column, replicated on its GL lanes */
     bool active = false;
     uint64_t off0 = 0;
     int n_obs = 0, cursor = 0, K = 0, ref_code = 0, med = 0, steps = 0, list_idx = 0;
@@ -951,7 +956,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
     uint32_t raw_w = 4u, raw_sq = 255u;             /* the observation this lane evaluates in the next step */
 
     for (;;) {
-        /* ---- hand new columns to the row groups that have none ---- */
+        /* ---- hand new columns to the lane groups that have none ---- */
         uint64_t need = __ballot(!active);
         while (need != 0ull && !exhausted) {
             if (q_next >= q_end) {
@@ -963,7 +968,11 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
                 q_next = b0;
                 q_end = min(b0 + batch, n_work);
             }
-            const unsigned gm = (unsigned)((need & 1ull) | ((need >> 15) & 2ull) | ((need >> 30) & 4ull) | ((need >> 45) & 8ull));
+            unsigned gm = 0;
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                gm |= (unsigned)((need >> (gi * GL)) & 1ull) << gi;
+            }
             const int take = min(__popc(gm), q_end - q_next);
             const int rank = __popc(gm & ((1u << g) - 1u));
             const bool mine = !active && rank < take;
@@ -973,9 +982,9 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
                 const uint4 *ep = reinterpret_cast<const uint4 *>(list + idx);
                 const uint4 a = ep[0], b = ep[1];
                 K = (int)b.y;
-                if (K > LFQ_Q_MAXK) {
+                if (K > MAXK) {
                     if (l == 0) {
-                        retry[idx] = 1;             /* needs more than one DPP row: one-column-per-wave kernel */
+                        retry[idx] = 1;             /* needs more lanes: one-column-per-wave kernel */
                     }
                 } else {
                     active = true;
@@ -994,7 +1003,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
                     list_idx = idx;
                     v = (l == 0) ? 1.0 : 0.0;
                     e = 0;
-                    de = 0;
+                    de = (l == 0) ? -4000 : 0;
                     tflag = (l == K) ? 1.0 : 0.0;
                     raw_w = 4u;
                     raw_sq = 255u;
@@ -1012,7 +1021,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
             break;
         }
 
-        /* ---- 16 observations per column: (p, 1-p) rows into LDS ---- */
+        /* ---- GL observations per column: (p, 1-p) rows into LDS ---- */
         {
             const LfqObs o = lfq_eval_obs(raw_w & 0xffu, (raw_w >> 8) & 0xffu, (raw_w >> 16) & 0xffu, raw_w >> 24, raw_sq,
                                           ref_code, med, P, &s_luts);
@@ -1027,7 +1036,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        cursor += 16;
+        cursor += GL;
         raw_w = 4u;                                  /* an N base: ignored */
         raw_sq = 255u;
         if (active && cursor + l < n_obs) {          /* lands while the rows below run */
@@ -1037,14 +1046,14 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
             raw_sq = T.sq ? T.sq[o] : 255u;
         }
 
-        /* ---- 16 rows, renormalisation + pruning test after each 8 ---- */
+        /* ---- GL rows, renormalisation + pruning test after each 8 ---- */
         bool pruned = false;
-        const LfqRow *grow = rows + (g << 4);
+        const LfqRow *grow = rows + g * GL;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
+        for (int part = 0; part < GL / 8; part++) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const LfqRow pq = grow[half * 8 + r];
+                const LfqRow pq = grow[part * 8 + r];
                 const double x = lfq_rowshr1_f64(v);
                 const double pe = ldexp(pq.p, de);
                 const double q0 = fma(tflag, pq.p, pq.q);
@@ -1055,20 +1064,24 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
             const int ex = nzl ? __builtin_amdgcn_frexp_exp(v) : 0;
             v = ldexp(v, -ex);
             e += ex;
-            /* empty cells (a suffix of the row group) adopt the scale of the frontier cell */
-            const unsigned field = (unsigned)(nz >> (g << 4)) & 0xffffu;
-            const int front = (g << 4) + (field ? 31 - __clz((int)field) : l);
+            /* empty cells (a suffix of the lane group) adopt the scale of the frontier cell */
+            const unsigned field = (unsigned)(nz >> (g * GL)) & ((1u << GL) - 1u);
+            const int front = g * GL + (field ? 31 - __clz((int)field) : l);
             const int e_front = __shfl(e, nzl ? lane : front, 64);
             e = nzl ? e : e_front;
-            de = lfq_rowshr1_i32(e) - e;
+            const int e_left = lfq_rowshr1_i32(e);               /* all lanes: a DPP read of a masked-off lane is 0 */
+            de = (l == 0) ? -4000 : e_left - e;                  /* nothing enters cell 0 */
             const uint64_t over = __ballot(ldexp(v, e) * bonf_d > sig_s);
-            pruned = pruned || ((over >> ((g << 4) + K)) & 1ull) != 0ull;
+            pruned = pruned || ((over >> (g * GL + K)) & 1ull) != 0ull;
         }
         steps += 1;
         if (active) {
             if (pruned) {
+#ifdef LFQ_TRACE
+                if (l == K) printf("quad prune: lane %d g %d K %d v %g e %d tail %g bonf %g sig %g steps %d idx %d\n", lane, g, K, v, e, ldexp(v, e), bonf_d, sig_s, steps, list_idx);
+#endif
                 active = false;                     /* p * bonf > sig for good: nothing to report */
-            } else if (cursor >= n_obs || steps >= LFQ_Q_MAX_STEPS) {
+            } else if (cursor >= n_obs || steps >= MAX_STEPS) {
                 if (l == 0) {
                     retry[list_idx] = 1;            /* survivor (or a long one): finish it on a whole wavefront */
                 }
@@ -2050,8 +2063,13 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
         return LFQ_OK;
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    hipLaunchKernelGGL(lfq_dp_quad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, w, d_retry,
-                       32);
+    if (getenv("LFQ_QUAD16")) {                      /* A/B: four columns per wavefront instead of eight */
+        hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, w,
+                           d_retry, 32);
+    } else {
+        hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, w,
+                           d_retry, 64);
+    }
     hipLaunchKernelGGL(lfq_dp_retry_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, d_counts,
                        w, d_retry, d_pvals, pvals_capacity);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
