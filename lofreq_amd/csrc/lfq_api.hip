@@ -529,7 +529,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
          * latency-bound kernels of the long columns, or they only start when it ends */
-        int light_waves_per_cu = 20;
+        int light_waves_per_cu = 10;
         if (const char *e = getenv("LFQ_LIGHT_WAVES_PER_CU")) {
             light_waves_per_cu = std::max(4, atoi(e));
         }

@@ -459,16 +459,42 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
     }
     std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return pvals[a].col < pvals[b].col; });
 
+    /* expl() / log10l() on 80-bit values are the cost of this loop: p-values and QUALs first, in parallel */
+    struct PvQ {
+        long double pv[3];
+        int qual[3];
+    };
+    std::vector<PvQ> pvq((size_t)n_pvals);
+    {
+        std::atomic<int64_t> nextp(0);
+        auto workp = [&]() {
+            for (;;) {
+                const int64_t i0 = nextp.fetch_add(64);
+                if (i0 >= n_pvals) {
+                    break;
+                }
+                for (int64_t i = i0; i < std::min(n_pvals, i0 + 64); i++) {
+                    const lfq_col_pvals &r = pvals[i];
+                    for (int a = 0; a < 3; a++) {
+                        pvq[(size_t)i].pv[a] = lfq_pvalue_from_log(r.logp[a], r.status[a]);
+                        pvq[(size_t)i].qual[a] = (r.status[a] != LFQ_PV_NONE) ? prob_to_phred(pvq[(size_t)i].pv[a]) : 0;
+                    }
+                }
+            }
+        };
+        LfqPool::instance().run(workp, n_pvals >= 256 ? std::min(LfqPool::instance().size(), 8) : 0);
+    }
+
     static const char acgt[4] = {'A', 'C', 'G', 'T'};
     int64_t n_out = 0;
     for (int64_t oi = 0; oi < n_pvals; oi++) {
         const lfq_col_pvals &r = pvals[order[(size_t)oi]];
         const lfq_col_counts &cn = r.counts;
         const double bonf = (double)r.bonf;
-        long double pv[3];
+        const long double *pv = pvq[(size_t)order[(size_t)oi]].pv;
+        const int *quals = pvq[(size_t)order[(size_t)oi]].qual;
         int kmax = 0;
         for (int a = 0; a < 3; a++) {
-            pv[a] = lfq_pvalue_from_log(r.logp[a], r.status[a]);
             kmax = std::max(kmax, cn.alt_counts[a]);
         }
         /* snpcaller() returns all-LDBL_MAX if the most frequent allele is not significant
@@ -509,7 +535,7 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
                 memset(&o, 0, sizeof(o));
                 o.col = r.col;
                 o.pvalue = pv[a];
-                o.qual = prob_to_phred(pv[a]);              /* lofreq_call.c:863 */
+                o.qual = quals[a];                          /* lofreq_call.c:863 */
                 o.dp = cov;
                 o.alt_raw_count = cn.alt_raw_counts[a];     /* lofreq_call.c:835 */
                 o.ref_fw = cn.ref_fw;                       /* lofreq_call.c:853-857 */
@@ -606,6 +632,46 @@ int64_t lfq_format_vcf(char *buf, int64_t buflen, const char *chrom, const int64
                        const lfq_snv_record *recs, int64_t n, const uint8_t *keep_or_null,
                        const char *filter_or_null)
 {
+    if (n >= 256) {
+        /* text in parallel into fixed slots, then one compaction pass (snprintf with %f is the cost) */
+        constexpr int SLOT = 320;
+        std::vector<char> slots((size_t)n * SLOT);
+        std::vector<int32_t> lens((size_t)n, 0);
+        std::atomic<int64_t> next(0);
+        std::atomic<int> bad(0);
+        auto work = [&]() {
+            for (;;) {
+                const int64_t i0 = next.fetch_add(32);
+                if (i0 >= n) {
+                    break;
+                }
+                for (int64_t i = i0; i < std::min(n, i0 + 32); i++) {
+                    if (keep_or_null && !keep_or_null[i]) {
+                        continue;
+                    }
+                    const int64_t pos0 = pos0_or_null ? pos0_or_null[i] : recs[i].col;
+                    const int len = lfq_format_snv_record(&slots[(size_t)i * SLOT], SLOT, chrom, pos0, &recs[i], filter_or_null);
+                    if (len < 0 || len >= SLOT) {
+                        bad.store(1);
+                    }
+                    lens[(size_t)i] = len;
+                }
+            }
+        };
+        LfqPool::instance().run(work, std::min(LfqPool::instance().size(), 8));
+        if (!bad.load()) {
+            int64_t used = 0;
+            for (int64_t i = 0; i < n; i++) {
+                const int len = lens[(size_t)i];
+                if (buf && len > 0 && used + len <= buflen) {
+                    memcpy(buf + used, &slots[(size_t)i * SLOT], (size_t)len);
+                }
+                used += len;
+            }
+            return used;
+        }
+        /* a line did not fit its slot (very long contig name): fall through to the serial path */
+    }
     int64_t used = 0;
     char line[512];
     for (int64_t i = 0; i < n; i++) {
