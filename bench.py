@@ -141,8 +141,10 @@ def main():
         # CONCURRENTLY with each other; their individual durations overlap and are not additive.)
         # Algorithmic bytes per SURVEY 8(d): 4*depth + 80 per column; one launch covers ncols/n_launch columns.
         alg_bytes = ncols * (4.0 * depth + 80.0) / n_launch
-        cands = {"lfq_count_kernel": kt["ms_count"] / n_launch, "lfq_dp_wave_kernel<1>": kt["ms_dp_light"] / n_launch,
-                 "lfq_dp_wave_kernel<4>": kt["ms_dp_mid"] / n_launch, "lfq_dp_big_kernel": kt["ms_dp_big"] / n_launch}
+        # ms_dp_light/mid/big are the spans of the three DP stream chains (quad+retry | mid+segments+fold |
+        # prep+segments+fold), which overlap; the count kernel is one launch on its own.
+        cands = {"lfq_count_kernel": kt["ms_count"] / n_launch, "dp chain: lfq_dp_quad_kernel<8>+retry": kt["ms_dp_light"] / n_launch,
+                 "dp chain: mid class": kt["ms_dp_mid"] / n_launch, "dp chain: big class": kt["ms_dp_big"] / n_launch}
         dom = max(cands, key=cands.get)
         dom_ms = cands[dom]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

@@ -101,7 +101,7 @@ __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &
     const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq);
     const int64_t c0 = (int64_t)(off0 >> 4), c1 = (int64_t)((off1 + 15) >> 4);
     for (int64_t ch = c0 + lane; ch < c1; ch += LFQ_WAVE) {
-        const uint4 n4 = nt16[ch];
+        const uint4 n4 = nt16[ch];      /* (non-temporal loads were measured: no difference at 6.0 TB/s) */
         const uint4 b4 = bq16[ch];
         const int64_t base = ch << 4;
         const int lo = (int64_t)off0 > base ? (int)((int64_t)off0 - base) : 0;
