@@ -96,11 +96,16 @@ def main():
     def step():
         """One pass: kernels, sparse results to the host, exact emit test, exchange, VCF text."""
         conf = la.VarcallConf()                   # default sig, dynamic Bonferroni from 1
-        caller.snv_batch_device(batch, conf, d_counts, d_pvals, pv_cap)
-        st = caller.batch_finish()
-        pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
-        recs, total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin,      # records carry their ref base
-                                         dist if world > 1 else None, dev)
+        if world == 1:
+            # layer 2 of the C ABI (lfq_call_snvs_batch): the whole call_snvs loop over the batch in one call
+            recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
+        else:
+            # layer 1 + the shard exchange: the running Bonferroni factor needs every rank's tested-column count
+            caller.snv_batch_device(batch, conf, d_counts, d_pvals, pv_cap)
+            st = caller.batch_finish()
+            pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
+            recs, total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin,      # records carry their ref base
+                                             dist, dev)
         text = None
         if rank == 0:
             # --no-default-filter + dynamic Bonferroni: QUAL threshold from the final factor

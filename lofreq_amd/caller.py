@@ -134,7 +134,7 @@ class SnvCaller:
         Mutates conf.bonf_subst / conf.num_snv_tests like the reference's per-column loop."""
         t = batch._tracks()
         cap = int(records_capacity if records_capacity is not None else max(3 * batch.ncols, 16))
-        rec = np.zeros(cap, dtype=_lib.SNV_RECORD_DTYPE)
+        rec = np.empty(cap, dtype=_lib.SNV_RECORD_DTYPE)      # the library zero-fills what it writes
         n = C.c_int64(0)
         counts = np.zeros(batch.ncols, dtype=_lib.COL_COUNTS_DTYPE) if want_counts else None
         st = _lib.BatchStats()
