@@ -417,6 +417,12 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
     hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
+    /* LFQ_SINGLE_STREAM: every kernel on the caller's stream, in dependency order (counter collection with
+     * rocprofv3 --pmc serialises dispatches and does not get along with the cross-stream waits) */
+    const bool single_stream = getenv("LFQ_SINGLE_STREAM") != nullptr;
+    hipStream_t dps = single_stream ? st : c->dps;
+    hipStream_t side0 = single_stream ? st : c->side[0], side1 = single_stream ? st : c->side[1];
+    hipStream_t side_i[2] = {side0, side1};
     LfqParams P;
     LFQ_TRY(make_params(conf, tr, &P, indel_mode));
     LFQ_TRY(ensure_workspace(c, tr->ncols));
@@ -492,7 +498,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     c->cur_segments = n_seg;
     const char *skip = getenv("LFQ_DEBUG_SKIP");   /* profiling aid: run the DP classes in isolation */
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], st));
-    LFQ_TRY_HIP(hipStreamWaitEvent(c->dps, c->ev_join[2], 0));   /* dps starts after the memset */
+    LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_join[2], 0));   /* dps starts after the memset */
 
     for (int s = 0; s < n_seg; s++) {
         const int64_t c0 = ncols * s / n_seg, c1 = ncols * (s + 1) / n_seg;
@@ -512,13 +518,13 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, st));
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
 
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->dps, c->ev_cnt[s][1], 0));
-        LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, c->dps));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], c->dps));
+        LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_cnt[s][1], 0));
+        LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, dps));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], dps));
         if (n_seg == 1 && !indel_mode && c->leader && !getenv("LFQ_NO_SB_PRECOMPUTE")) {
             /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start now */
-            LFQ_TRY(lfq_launch_gather_heavy(W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, c->dps));
-            LFQ_TRY_HIP(hipEventRecord(c->ev_heavy, c->dps));
+            LFQ_TRY(lfq_launch_gather_heavy(W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
+            LFQ_TRY_HIP(hipEventRecord(c->ev_heavy, dps));
             lfq_sb_precompute_begin();
             {
                 std::lock_guard<std::mutex> lk(*c->lm);
@@ -551,53 +557,53 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
          *   side[1] [scan] -> mid kernel (first stretch of rows) -> [prep] -> row segments of the mid class
          * The prep kernel is short but latency-bound; beside the quad kernel it starves, and everything behind
          * it on the critical path with it, so it runs BEFORE the quad kernel. */
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[1], c->ev_scan[s], 0));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_side[1][s][0], c->side[1]));
+        LFQ_TRY_HIP(hipStreamWaitEvent(side1, c->ev_scan[s], 0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[1][s][0], side1));
         if (run_big) {
-            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu * 2, c->dps));
+            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu * 2, dps));
             LFQ_DBG_STAGE("prep");
         }
-        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, c->dps));
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[0], c->ev_prep, 0));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_side[0][s][0], c->side[0]));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, dps));
+        LFQ_TRY_HIP(hipStreamWaitEvent(side0, c->ev_prep, 0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[0][s][0], side0));
         if (run_mid) {
-            LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, c->side[1]));
+            LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, side1));
             LFQ_DBG_STAGE("mid");
         }
         if (run_big) {
-            LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, c->side[0]));
+            LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, side0));
             LFQ_DBG_STAGE("seg big");
-            LFQ_TRY(lfq_launch_dp_combine(1, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[0]));
+            LFQ_TRY(lfq_launch_dp_combine(1, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side0));
             LFQ_DBG_STAGE("combine big");
             LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
-                                      n_big_blocks, c->side[0]));
+                                      n_big_blocks, side0));
             LFQ_DBG_STAGE("big");
         }
-        LFQ_TRY_HIP(hipStreamWaitEvent(c->side[1], c->ev_prep, 0));     /* K = 250..252 of the big class lands in class 1 */
-        LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, c->side[1]));
+        LFQ_TRY_HIP(hipStreamWaitEvent(side1, c->ev_prep, 0));     /* K = 250..252 of the big class lands in class 1 */
+        LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, side1));
         LFQ_DBG_STAGE("seg mid");
-        LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, c->side[1]));
+        LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side1));
         LFQ_DBG_STAGE("combine mid");
-        LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], c->dps));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], dps));
         if (!skip || !strstr(skip, "light")) {
             const char *lk = getenv("LFQ_LIGHT_KERNEL");
             if (lk && !strcmp(lk, "wave")) {            /* A/B switch: the one-column-per-wavefront kernel */
-                LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, c->dps));
+                LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, dps));
             } else {
                 LFQ_TRY(lfq_launch_dp_quad(T, P, c->d_luts, d_counts, W, c->d_retry + c0, d_pvals, pvals_capacity,
-                                           n_light_waves, c->dps));
+                                           n_light_waves, dps));
             }
         }
-        LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], c->dps));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], dps));
         for (int i = 0; i < 2; i++) {
-            LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][1], c->side[i]));
+            LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][1], side_i[i]));
         }
     }
     /* join everything back into the caller's stream */
     LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));                     /* all count kernels done */
-    LFQ_TRY_HIP(hipEventRecord(c->ev_join[0], c->side[0]));
-    LFQ_TRY_HIP(hipEventRecord(c->ev_join[1], c->side[1]));
-    LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], c->dps));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[0], side0));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[1], side1));
+    LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], dps));
     for (int i = 0; i < 3; i++) {
         LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_join[i], 0));
     }
