@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--plant-period", type=int, default=997)
     ap.add_argument("--cpu-sample-cols", type=int, default=8000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-path", action="store_true",
+                    help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
     return ap.parse_args()
 
 
@@ -96,7 +98,7 @@ def main():
     def step():
         """One pass: kernels, sparse results to the host, exact emit test, exchange, VCF text."""
         conf = la.VarcallConf()                   # default sig, dynamic Bonferroni from 1
-        if world == 1:
+        if world == 1 and not args.shard_path:
             # layer 2 of the C ABI (lfq_call_snvs_batch): the whole call_snvs loop over the batch in one call
             recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
         else:
@@ -105,7 +107,7 @@ def main():
             st = caller.batch_finish()
             pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
             recs, total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin,      # records carry their ref base
-                                             dist, dev)
+                                             dist if world > 1 else None, dev)
         text = None
         if rank == 0:
             # --no-default-filter + dynamic Bonferroni: QUAL threshold from the final factor

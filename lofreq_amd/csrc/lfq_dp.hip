@@ -8,21 +8,23 @@
  * and the pruning test tail*bonf > sig (snpcaller.c:950, 1155).
  *
  * Mapping: cells across lanes, C consecutive cells per lane (blocked), 64*C cells per strip.  The
- * left neighbour arrives by DPP wave_shr:1, the row's p by v_readlane (SGPR broadcast).  Every lane
- * carries a binary exponent e for its C cells (value = v*2^e), renormalised every 8 rows, so the
+ * left neighbour arrives by DPP (wave_shr:1 / row_shr:1), the row's (p, 1-p) from an LDS broadcast.  Every
+ * lane carries a binary exponent e for its C cells (value = v*2^e), renormalised every 8 rows, so the
  * 1e-4932-range tails the reference reaches in log space are representable.
  *
- *   lfq_dp_wave_kernel<1>  light columns (K < 64 and not suspicious): one wavefront per column, one cell
- *                        per lane; almost all of them are pruned within the first few dozen rows.
- *   lfq_dp_wave_kernel<4>  mid columns (K < 250): one wavefront per column, 1 or 4 cells per lane.
- *                        Both: persistent grid, work claimed dynamically, no strip exchange.
- *   lfq_dp_big_kernel    K >= 250: one 8-wave workgroup per column, 2 or 4 cells per lane, strip w on wave w.  Strips
- *                        run as a software pipeline over 64-row chunks (wave w works on chunk t-w at
- *                        step t); the boundary cell of strip w reaches strip w+1 through a
- *                        double-buffered LDS slab, one s_barrier per step.  More than 8 strips
- *                        (K > 4095) run in passes with the pass boundary in global scratch.
- *
- * The three kernels run concurrently on three HIP streams (lfq_api.hip).
+ * Kernels, three chains on three streams after the scan:
+ *   light class   lfq_dp_quad_kernel<8>   eight columns per wavefront (8-lane groups, K <= 7); prunes only
+ *                 lfq_dp_retry_kernel     the <1 % the quad kernel could not finish: one wavefront per column
+ *   mid class     lfq_dp_wave_kernel<4>   one wavefront per column, 1 or 4 cells per lane, first 2048 rows
+ *                 lfq_dp_seg_kernel<0>    row segments of the survivors (one wavefront each, from the identity)
+ *                 lfq_dp_combine_kernel<0> convolution fold of the segments + emission
+ *   big class     lfq_dp_big_prep_kernel  bounds / underflow shortcut / split decision
+ *                 lfq_dp_seg_kernel<1>    row segments at 8, 16 or 32 cells per lane
+ *                 lfq_dp_combine_kernel<1>
+ *                 lfq_dp_big_kernel       what cannot be split: 8-wave strip pipeline over 64-row chunks,
+ *                                         boundary cell through a double-buffered LDS slab, passes through
+ *                                         global scratch beyond 8 strips
+ *   lfq_dp_wave_kernel<1> (one light column per wavefront) is kept as the A/B reference of the quad kernel.
  */
 #include "lfq_device.h"
 

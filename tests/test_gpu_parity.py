@@ -273,3 +273,23 @@ def test_row_split_long_columns(caller, oracle):
     recs, _, _ = caller.call_snvs(util.to_pileup_batch(la, host), conf)
     _compare_records(la, recs, ores, host, tol=1e-9)
     assert conf.bonf_subst == oconf.bonf_subst
+
+
+def test_ragged_deep_mix(caller, oracle):
+    """Very different depths in one batch (1 .. 40000), every DP class and route at once: quad kernel, retry,
+    mid kernel with and without row split, split and unsplit big columns (K > 2016 and short-but-wide)."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(77)
+    parts = []
+    specs = [(40, 1, 60, {}), (6, 30000, 40000, {0: 0.004, 1: 0.02, 2: 0.1}), (20, 2000, 2600, {3: 0.3, 7: 0.9, 11: 0.05}),
+             (30, 100, 700, {5: 0.6, 6: 0.95}), (4, 9000, 11000, {1: 0.3})]
+    for ncols, lo, hi, planted in specs:
+        parts.append(util.random_batch(rng, ncols, lo, hi, planted=planted, ref_n_frac=0.03))
+    host = util.concat_batches(parts)
+    ores, oconf = util.run_oracle(oracle, host)
+    conf = la.VarcallConf()
+    recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
+    util.assert_counts_equal(counts, ores, host)
+    assert conf.bonf_subst == oconf.bonf_subst and conf.num_snv_tests == oconf.num_snv_tests
+    _compare_records(la, recs, ores, host, tol=1e-9)
+    assert len(recs) >= 8
