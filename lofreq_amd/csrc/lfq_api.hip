@@ -168,6 +168,10 @@ int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bool i
     P->prune_slack = 1e-6;
     P->bonf_step = 3;
     P->bonf_reset_first = 1;
+    P->phase1_chunks = LFQ_PHASE1_CHUNKS;
+    if (const char *e = getenv("LFQ_PHASE1_CHUNKS")) {
+        P->phase1_chunks = std::max(1, atoi(e));
+    }
     P->seg_max = LFQ_SEG_MAX;
     if (const char *e = getenv("LFQ_SEG_MAX")) {                 /* experiments: fewer, longer row segments */
         P->seg_max = std::min(LFQ_SEG_MAX, std::max(2, atoi(e)));

@@ -667,6 +667,25 @@ __device__ __forceinline__ void lfq_atomic_add_noret(int32_t *p, int v)
     asm volatile("global_atomic_add %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
+/* lanes per light column for this batch: the smallest group that fits 90 % of the light columns (the rest go
+ * to the retry kernel); 64 = one column per wavefront (lfq_dp_wave_kernel<1>).  Deep pileups have K ~ depth / 7000
+ * per alt base from sequencing errors alone, so the best group size is a property of the batch. */
+__device__ __forceinline__ int lfq_light_group_lanes(const LfqWork &W)
+{
+    const int64_t n = W.counters[LFQ_CNT_LIGHT];
+    const int64_t need = n - n / 10;
+    if (W.counters[LFQ_CNT_KLE7] >= need) {
+        return 8;
+    }
+    if (W.counters[LFQ_CNT_KLE15] >= need) {
+        return 16;
+    }
+    if (W.counters[LFQ_CNT_KLE31] >= need) {
+        return 32;
+    }
+    return 64;
+}
+
 /* what the column pipeline wants loaded while this column computes */
 struct LfqPrefetch {
     bool want_raw, want_entry;
@@ -735,7 +754,7 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
             pruned = true;
             break;
         }
-        if (SPLIT && ch + 1 == LFQ_PHASE1_CHUNKS) {
+        if (SPLIT && ch + 1 == P.phase1_chunks) {
             /* still alive after the first stretch of rows: cut the rest into concurrent row segments;
              * the state reached here becomes segment 0 (lfq_dp_segw_kernel, lfq_dp_combine_kernel) */
             /* fewer, longer segments when many columns are long anyway: the fold costs (segments - 1) convolutions */
@@ -810,10 +829,13 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
                                                           const lfq_col_counts *__restrict__ counts, LfqWork W,
                                                           int base_idx, int count_idx,
                                                           lfq_col_pvals *__restrict__ pvals,
-                                                          int64_t pvals_capacity, int batch)
+                                                          int64_t pvals_capacity, int batch, int only_if_gl64)
 {
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
+    if (only_if_gl64 && lfq_light_group_lanes(W) != 64) {
+        return;                                     /* the quad kernel serves this batch's light class */
+    }
     if (MAXC > 1) {
         /* few, long, latency-bound columns sharing SIMDs with the throughput-bound light kernel:
          * win the issue arbitration (MI355X_MICROARCH "two waves per SIMD", item 2) */
@@ -901,10 +923,11 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
  * DPP row: cell k of a column on lane k of its row (row_shr:1 brings the left neighbour, bound_ctrl feeds
  * 0 into cell 0), GL observations of each column evaluated per step (one per lane), GL rows of the
  * recurrence per step, pruning test every 8 rows.  A lane group whose column is pruned takes the next
- * column from the wavefront's claimed batch.  The kernel only PRUNES: a column that survives
- * LFQ_Q_MAX_ROWS rows or reaches its end, or has K >= GL, is flagged in `retry` and done from scratch by
+ * column from the wavefront's claimed batch.  The kernel only PRUNES: a column that reaches its end
+ * unpruned, or has K >= GL, is flagged in `retry` and done from scratch by
  * lfq_dp_retry_kernel (one wavefront per column, emission included) -- under 1 % of the columns. */
-#define LFQ_Q_MAX_ROWS 1024
+#define LFQ_Q_MAX_ROWS (1 << 20)     /* effectively none: a deep column may need thousands of rows before its tail crosses
+                                      * the threshold, and running it twice costs more than keeping its lane group */
 
 __device__ __forceinline__ int lfq_rowshr1_i32(int x)
 {
@@ -918,18 +941,34 @@ __device__ __forceinline__ double lfq_rowshr1_f64(double x)
     return __hiloint2double(hi, lo);
 }
 
-/* GL = lanes per column: 16 (four columns per wavefront, K <= 15) or 8 (eight columns, K <= 7: half a DPP
- * row each; the neighbour that row_shr:1 drags across the middle of a row is multiplied by 2^-4000 = 0). */
+/* left neighbour within a GL-lane group: row_shr:1 inside a 16-lane DPP row, wave_shr:1 for 32-lane groups;
+ * what is dragged in at the first lane of a group is multiplied by 2^-4000 = 0 by the caller */
+template <int GL>
+__device__ __forceinline__ int lfq_grpshr1_i32(int x)
+{
+    return GL <= 16 ? lfq_rowshr1_i32(x) : lfq_shr1_i32(x);
+}
+
+template <int GL>
+__device__ __forceinline__ double lfq_grpshr1_f64(double x)
+{
+    return GL <= 16 ? lfq_rowshr1_f64(x) : lfq_shr1_f64(x);
+}
+
+/* GL = lanes per column: 8 (eight columns per wavefront, K <= 7), 16 (four, K <= 15) or 32 (two, K <= 31). */
 template <int GL>
 __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqParams P,
                                                           const LfqLuts *__restrict__ g_luts, LfqWork W,
-                                                          uint8_t *__restrict__ retry, int batch)
+                                                          uint8_t *__restrict__ retry, int batch, int force_gl)
 {
     constexpr int NG = 64 / GL;                     /* columns in flight per wavefront */
     constexpr int MAXK = GL - 1;
     constexpr int MAX_STEPS = LFQ_Q_MAX_ROWS / GL;
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
+    if (force_gl ? (force_gl != GL) : (lfq_light_group_lanes(W) != GL)) {
+        return;                                     /* another group size serves this batch */
+    }
     {
         const double *src = reinterpret_cast<const double *>(g_luts);
         double *dst = reinterpret_cast<double *>(&s_luts);
@@ -1056,7 +1095,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const LfqRow pq = grow[part * 8 + r];
-                const double x = lfq_rowshr1_f64(v);
+                const double x = lfq_grpshr1_f64<GL>(v);
                 const double pe = ldexp(pq.p, de);
                 const double q0 = fma(tflag, pq.p, pq.q);
                 v = fma(x, pe, v * q0);
@@ -1067,11 +1106,11 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
             v = ldexp(v, -ex);
             e += ex;
             /* empty cells (a suffix of the lane group) adopt the scale of the frontier cell */
-            const unsigned field = (unsigned)(nz >> (g * GL)) & ((1u << GL) - 1u);
+            const unsigned field = (unsigned)(nz >> (g * GL)) & (unsigned)((1ull << GL) - 1ull);
             const int front = g * GL + (field ? 31 - __clz((int)field) : l);
             const int e_front = __shfl(e, nzl ? lane : front, 64);
             e = nzl ? e : e_front;
-            const int e_left = lfq_rowshr1_i32(e);               /* all lanes: a DPP read of a masked-off lane is 0 */
+            const int e_left = lfq_grpshr1_i32<GL>(e);           /* all lanes: a DPP read of a masked-off lane is 0 */
             de = (l == 0) ? -4000 : e_left - e;                  /* nothing enters cell 0 */
             const uint64_t over = __ballot(ldexp(v, e) * bonf_d > sig_s);
             pruned = pruned || ((over >> (g * GL + K)) & 1ull) != 0ull;
@@ -1962,8 +2001,8 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
         }
 #ifdef LFQ_PROFILE
         if (tid == 0) {
-            atomicAdd(&W.counters[25], (int)(wall_clock64() - pw_emit));      /* emit */
-            atomicAdd(&W.counters[26], (int)(wall_clock64() - pw_rec));       /* whole record */
+            atomicAdd(&W.counters[29], (int)(wall_clock64() - pw_emit));      /* emit */
+            atomicAdd(&W.counters[30], (int)(wall_clock64() - pw_rec));       /* whole record */
         }
 #endif
     }
@@ -1982,7 +2021,7 @@ int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
     hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                       d_counts, w, -1, LFQ_CNT_LIGHT, d_pvals, pvals_capacity, 32);
+                       d_counts, w, -1, LFQ_CNT_LIGHT, d_pvals, pvals_capacity, 32, 0);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 
@@ -1995,7 +2034,7 @@ int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *
     }
     const unsigned blocks = (unsigned)((n_waves + 3) / 4);
     hipLaunchKernelGGL(lfq_dp_wave_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,
-                       d_luts, d_counts, w, LFQ_CNT_LIGHT, LFQ_CNT_MID, d_pvals, pvals_capacity, 1);
+                       d_luts, d_counts, w, LFQ_CNT_LIGHT, LFQ_CNT_MID, d_pvals, pvals_capacity, 1, 0);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 
@@ -2064,15 +2103,22 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
     if (t.ncols <= 0 || n_waves <= 0) {
         return LFQ_OK;
     }
-    const unsigned blocks = (unsigned)((n_waves + 3) / 4);
-    if (getenv("LFQ_QUAD16")) {                      /* A/B: four columns per wavefront instead of eight */
-        hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, w,
-                           d_retry, 32);
-    } else {
-        hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, w,
-                           d_retry, 64);
+    const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    int force = 0;                                   /* A/B: LFQ_QUAD_LANES = 8, 16, 32 or 64 */
+    if (const char *e = getenv("LFQ_QUAD_LANES")) {
+        force = atoi(e);
     }
-    hipLaunchKernelGGL(lfq_dp_retry_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, d_counts,
-                       w, d_retry, d_pvals, pvals_capacity);
+    /* one of the four serves the batch (lfq_light_group_lanes, decided on the device from the K histogram of
+     * the scan); the others return at once */
+    hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, 64, force);
+    hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, 32, force);
+    hipLaunchKernelGGL(lfq_dp_quad_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 16, force);
+    if (force == 0 || force == 64) {
+        hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
+                           d_pvals, pvals_capacity, 32, force == 64 ? 0 : 1);
+    }
+    hipLaunchKernelGGL(lfq_dp_retry_kernel, grid, block, 0, st, t, p, d_luts, d_counts, w, d_retry, d_pvals,
+                       pvals_capacity);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

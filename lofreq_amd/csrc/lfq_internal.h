@@ -38,7 +38,7 @@ struct LfqParams {
     double sig;               /* (double)(float)conf->sig */
     double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
     int32_t seg_max;          /* row segments per split column, 2..LFQ_SEG_MAX */
-    int32_t pad_;
+    int32_t phase1_chunks;    /* mid class: 64-row chunks run unsplit before a surviving column is cut up */
 };
 
 struct LfqTracksDev {
@@ -104,7 +104,7 @@ struct LfqLong {              /* 128 bytes */
  * per cell (the per-row overhead is shared), which is what counts once the segments provide the parallelism. */
 #define LFQ_SEG_CLASSES 5
 #define LFQ_SEG_MIN_CHUNKS 16     /* no segment shorter than this many 64-row chunks */
-#define LFQ_PHASE1_CHUNKS 32      /* mid class: rows run unsplit before a surviving column is cut up */
+#define LFQ_PHASE1_CHUNKS 8       /* mid class: rows run unsplit before a surviving column is cut up (measured: 4..8 best) */
 #define LFQ_SPLIT_MAX_K 2016      /* 63 * 32: one wavefront at 32 cells per lane; the combine kernel keeps two
                                    * (K+1)-cell distributions in LDS */
 
@@ -141,7 +141,10 @@ struct LfqWork {
 #define LFQ_CNT_UNSPLIT 5       /* big columns left to lfq_dp_big_kernel */
 #define LFQ_CNT_HEAD_PREP 6
 #define LFQ_CNT_POOL 7         /* cells handed out from LfqWork::pool */
-#define LFQ_CNT_HEAD_COMB 24
+#define LFQ_CNT_HEAD_COMB 24        /* and 25: one head per fold kernel mode */
+#define LFQ_CNT_KLE7 26             /* light columns with K <= 7 / <= 15 / <= 31: picks the lanes-per-column of the */
+#define LFQ_CNT_KLE15 27            /* quad kernel for this batch (lfq_light_group_lanes) */
+#define LFQ_CNT_KLE31 28
 #define LFQ_CNT_LONG0 16       /* +class: row-split columns per cells-per-lane class (LFQ_SEG_CLASSES) */
 
 /* ---- strand-bias precompute (host, lfq_host.cpp) ---------------------------------------------------

@@ -137,10 +137,10 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
     __shared__ uint32_t s_hist[4][128];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
-    const int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave;
-    if (col >= c1) {
-        return;
-    }
+    /* one column per wavefront; with a grid smaller than the batch (persistent launch, lfq_launch_count) a
+     * wavefront walks the columns with the grid's stride */
+    const int64_t col_stride = (int64_t)gridDim.x * 4;
+    for (int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave; col < c1; col += col_stride) {
     const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
     const int64_t n_obs = (int64_t)(off1 - off0);
     const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         out[col] = r;
         flags[col] = flag;
     }
+    }   /* column loop */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
     const uint32_t base_mid = (uint32_t)W.counters[LFQ_CNT_LIGHT];
     const uint32_t base_big = base_mid + (uint32_t)W.counters[LFQ_CNT_MID];
     const uint32_t carry_in = (uint32_t)W.counters[LFQ_CNT_CARRY_IN];
+    uint32_t kle7 = 0, kle15 = 0, kle31 = 0;       /* K histogram of the light class (lfq_light_group_lanes) */
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
         const int64_t c = base + i;
         if (c >= ncols) {
@@ -443,15 +445,18 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
         }
         if (f[i] & 1u) {
             uint32_t pos;
+            const lfq_col_counts *cn = &counts[c];
             if (f[i] & 4u) {
                 pos = base_big + ex.b++;
             } else if (f[i] & 2u) {
                 pos = base_mid + ex.m++;
             } else {
                 pos = ex.t - ex.m - ex.b;
+                kle7 += cn->kmax <= 7;
+                kle15 += cn->kmax <= 15;
+                kle31 += cn->kmax <= 31;
             }
             ex.t++;
-            const lfq_col_counts *cn = &counts[c];
             const uint32_t rb = T.ref_base[c];
             LfqEntry e;
             e.off0 = T.col_off[c];
@@ -466,6 +471,14 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
             W.entries[pos] = e;
         }
         W.tested_prefix[c] = (int32_t)(carry_in + ex.t);   /* inclusive, batch-wide */
+    }
+    kle7 = lfq_wave_sum_u32(kle7);
+    kle15 = lfq_wave_sum_u32(kle15);
+    kle31 = lfq_wave_sum_u32(kle31);
+    if (lfq_lane() == 0 && kle31) {
+        atomicAdd(&W.counters[LFQ_CNT_KLE7], (int)kle7);
+        atomicAdd(&W.counters[LFQ_CNT_KLE15], (int)kle15);
+        atomicAdd(&W.counters[LFQ_CNT_KLE31], (int)kle31);
     }
 }
 
@@ -561,7 +574,13 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
     if (c1 <= c0) {
         return LFQ_OK;
     }
-    const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
+    unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
+    if (const char *e = getenv("LFQ_COUNT_BLOCKS")) {           /* experiments: persistent launch of that many workgroups */
+        const long b = atol(e);
+        if (b > 0 && (unsigned long)b < blocks) {
+            blocks = (unsigned)b;
+        }
+    }
     hipLaunchKernelGGL(lfq_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
                        d_counts, d_flags, c0, c1);
     LFQ_HIP_TRY(hipGetLastError());
