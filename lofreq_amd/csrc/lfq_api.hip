@@ -519,7 +519,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         W.unsplit = c->d_unsplit + c0;
 
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
-        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, st));
+        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st));
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
 
         LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_cnt[s][1], 0));

@@ -94,13 +94,14 @@ __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_
 
 template <bool SAME_THR>
 __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &T, uint64_t off0, uint64_t off1,
-                                                 uint32_t minbq4, uint32_t minalt4)
+                                                 uint32_t minbq4, uint32_t minalt4, int lane = lfq_lane(),
+                                                 int lanes = LFQ_WAVE)
 {
-    const int lane = lfq_lane();
+    /* `lanes` lanes (a wavefront, or a 16-lane group of lfq_count_multi_kernel) stride over the column */
     const uint4 *nt16 = reinterpret_cast<const uint4 *>(T.nt);
     const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq);
     const int64_t c0 = (int64_t)(off0 >> 4), c1 = (int64_t)((off1 + 15) >> 4);
-    for (int64_t ch = c0 + lane; ch < c1; ch += LFQ_WAVE) {
+    for (int64_t ch = c0 + lane; ch < c1; ch += lanes) {
         const uint4 n4 = nt16[ch];      /* (non-temporal loads were measured: no difference at 6.0 TB/s) */
         const uint4 b4 = bq16[ch];
         const int64_t base = ch << 4;
@@ -127,6 +128,130 @@ __device__ __forceinline__ void lfq_planes_to_classes(const uint32_t n[4], uint3
     c[1] = n[1] - n[3];
     c[2] = n[2] - n[3];
     c[0] = n[0] - n[1] - n[2] + n[3];
+}
+
+/* counts per nucleotide -> the column record + class flag (one lane) */
+__device__ __forceinline__ void lfq_count_emit(lfq_col_counts &r, const uint32_t raw[4], const uint32_t fw[4],
+                                               const uint32_t filt[4], int ref_code,
+                                               lfq_col_counts *__restrict__ out, uint8_t *__restrict__ flags,
+                                               int64_t col)
+{
+    {
+        uint8_t flag = 0;
+        if (!r.gated) {
+            /* the three non-reference nucleotides in A,C,G,T order (snpcaller.c:391-397) */
+            const int x0 = (ref_code == 0) ? 1 : 0;
+            const int x1 = (ref_code <= 1) ? 2 : 1;
+            const int x2 = (ref_code <= 2) ? 3 : 2;
+#define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
+            r.ref_fw = (int)LFQ_PICK(fw, ref_code);
+            r.ref_rv = (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code));
+            r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
+            r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
+            r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
+            r.alt_raw_counts[0] = (int)LFQ_PICK(raw, x0);
+            r.alt_raw_counts[1] = (int)LFQ_PICK(raw, x1);
+            r.alt_raw_counts[2] = (int)LFQ_PICK(raw, x2);
+            r.alt_fw[0] = (int)LFQ_PICK(fw, x0);
+            r.alt_fw[1] = (int)LFQ_PICK(fw, x1);
+            r.alt_fw[2] = (int)LFQ_PICK(fw, x2);
+#undef LFQ_PICK
+            r.n_err_probs = (int)(filt[0] + filt[1] + filt[2] + filt[3]);
+            const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
+            r.kmax = kmax;
+            r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
+            /* scheduling class.  Columns whose alt count is far above what sequencing errors explain
+             * (~ n/1000 at Q30) almost surely run the full recurrence: they go to the long-column
+             * kernel even when K < 64, so that the light kernel only sees quick exits. */
+            const int suspicious = max(12, r.n_err_probs / 512 + 8);
+            flag = (uint8_t)((r.tested ? 1 : 0)
+                             | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
+        }
+        out[col] = r;
+        flags[col] = flag;
+    }
+}
+
+/* Shallow columns (depth up to a few thousand): the per-column epilogue (12 reductions + the record) costs more
+ * than the loads, so FOUR columns share a wavefront, 16 lanes each: 4-step reductions inside the DPP row, four
+ * records built at once.  Fast path only (nt + bq tracks); everything else runs lfq_count_kernel. */
+__global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, LfqParams P,
+                                                              lfq_col_counts *__restrict__ out,
+                                                              uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = lfq_lane();
+    const int g = lane >> 4, l = lane & 15;
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    const bool same_thr = (P.min_alt_bq4 == P.min_bq4);
+    const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
+    const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
+    for (int64_t colb = c0 + ((int64_t)blockIdx.x * 4 + wave) * 4; colb < c1; colb += stride) {
+        const int64_t col = colb + g;
+        const bool valid = col < c1;
+        const uint64_t off0 = valid ? T.col_off[col] : 0, off1 = valid ? T.col_off[col + 1] : 0;
+        const int64_t n_obs = (int64_t)(off1 - off0);
+        const int cov = (valid && T.coverage_plp) ? T.coverage_plp[col] : (int)n_obs;
+        const int nb = (valid && T.num_bases) ? T.num_bases[col] : (int)n_obs;
+        const uint32_t rb = valid ? T.ref_base[col] : 'N';
+        const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
+        lfq_col_counts r;
+        r.n_err_probs = 0;
+        for (int i = 0; i < 3; i++) {
+            r.alt_counts[i] = r.alt_raw_counts[i] = r.alt_fw[i] = 0;
+        }
+        r.ref_fw = r.ref_rv = 0;
+        r.kmax = 0;
+        r.tested = 0;
+        r.pad_[0] = r.pad_[1] = 0;
+        r.median_ref_bq = -1;
+        r.coverage = cov;
+        r.gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov);
+        LfqAcc a;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            a.raw[x] = a.fw[x] = a.ge[x] = a.ga[x] = 0;
+        }
+        if (valid && !r.gated) {
+            if (same_thr) {
+                lfq_count_chunks<true>(a, T, off0, off1, minbq4, minalt4, l, 16);
+            } else {
+                lfq_count_chunks<false>(a, T, off0, off1, minbq4, minalt4, l, 16);
+            }
+        }
+        /* sums over the 16 lanes of the group (every lane of the wavefront takes part) */
+        uint32_t n_raw[4], n_fw[4], n_ge[4], n_ga[4], raw[4], fw[4], c_ge[4], c_ga[4], filt[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            n_raw[x] = a.raw[x];
+            n_fw[x] = a.fw[x];
+            n_ge[x] = a.ge[x];
+            n_ga[x] = a.ga[x];
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) {
+                n_raw[x] += (uint32_t)__shfl_xor((int)n_raw[x], d, 64);
+                n_fw[x] += (uint32_t)__shfl_xor((int)n_fw[x], d, 64);
+                n_ge[x] += (uint32_t)__shfl_xor((int)n_ge[x], d, 64);
+                if (!same_thr) {
+                    n_ga[x] += (uint32_t)__shfl_xor((int)n_ga[x], d, 64);
+                }
+            }
+            if (same_thr) {
+                n_ga[x] = n_ge[x];
+            }
+        }
+        lfq_planes_to_classes(n_raw, raw);
+        lfq_planes_to_classes(n_fw, fw);
+        lfq_planes_to_classes(n_ge, c_ge);
+        lfq_planes_to_classes(n_ga, c_ga);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];
+        }
+        if (l == 0 && valid) {
+            lfq_count_emit(r, raw, fw, filt, ref_code, out, flags, col);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
@@ -261,38 +386,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
     }
 
     if (lane == 0) {
-        uint8_t flag = 0;
-        if (!r.gated) {
-            /* the three non-reference nucleotides in A,C,G,T order (snpcaller.c:391-397) */
-            const int x0 = (ref_code == 0) ? 1 : 0;
-            const int x1 = (ref_code <= 1) ? 2 : 1;
-            const int x2 = (ref_code <= 2) ? 3 : 2;
-#define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
-            r.ref_fw = (int)LFQ_PICK(fw, ref_code);
-            r.ref_rv = (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code));
-            r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
-            r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
-            r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
-            r.alt_raw_counts[0] = (int)LFQ_PICK(raw, x0);
-            r.alt_raw_counts[1] = (int)LFQ_PICK(raw, x1);
-            r.alt_raw_counts[2] = (int)LFQ_PICK(raw, x2);
-            r.alt_fw[0] = (int)LFQ_PICK(fw, x0);
-            r.alt_fw[1] = (int)LFQ_PICK(fw, x1);
-            r.alt_fw[2] = (int)LFQ_PICK(fw, x2);
-#undef LFQ_PICK
-            r.n_err_probs = (int)(filt[0] + filt[1] + filt[2] + filt[3]);
-            const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
-            r.kmax = kmax;
-            r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
-            /* scheduling class.  Columns whose alt count is far above what sequencing errors explain
-             * (~ n/1000 at Q30) almost surely run the full recurrence: they go to the long-column
-             * kernel even when K < 64, so that the light kernel only sees quick exits. */
-            const int suspicious = max(12, r.n_err_probs / 512 + 8);
-            flag = (uint8_t)((r.tested ? 1 : 0)
-                             | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
-        }
-        out[col] = r;
-        flags[col] = flag;
+        lfq_count_emit(r, raw, fw, filt, ref_code, out, flags, col);
     }
     }   /* column loop */
 }
@@ -569,9 +663,20 @@ int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *strea
 }
 
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, void *stream)
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream)
 {
     if (c1 <= c0) {
+        return LFQ_OK;
+    }
+    int64_t multi_below = 4096;                    /* deepest column of the batch below this: four columns per wavefront */
+    if (const char *e = getenv("LFQ_COUNT_MULTI_BELOW")) {
+        multi_below = atol(e);
+    }
+    if (!p.general && max_col_obs > 0 && max_col_obs < multi_below) {
+        const unsigned blocks = (unsigned)((c1 - c0 + 15) / 16);
+        hipLaunchKernelGGL(lfq_count_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
+                           d_flags, c0, c1);
+        LFQ_HIP_TRY(hipGetLastError());
         return LFQ_OK;
     }
     unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
