@@ -151,6 +151,12 @@ private:
     LfqPool()
     {
         unsigned hw = std::thread::hardware_concurrency();
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) {       /* one process per GPU (torchrun): share the cores */
+            const int lws = atoi(e);
+            if (lws > 1) {
+                hw = std::max(1u, hw / (unsigned)lws);
+            }
+        }
         int n = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, 63u);
         if (const char *e = getenv("LFQ_HOST_THREADS")) {
             n = std::max(0, std::min(atoi(e) - 1, 255));
