@@ -972,3 +972,256 @@ int orc_default_filter(const int *qual, const int *dp, const int *sb, const int 
     }
     return 0;
 }
+
+/* ---- base alignment quality (BAQ) ------------------------------------------------------------
+ * SURVEY 8(f) rank 1.  orc_kpa_glocal restates kpa_ext_glocal (kprobaln_ext.c:80-270, samtools 0.1.19
+ * kprobaln with LoFreq's posterior-matrix extension left out: pd == NULL), the banded profile-HMM
+ * forward/backward in scaled doubles; orc_baq_read restates the BAQ half of bam_prob_realn_core_ext
+ * (bam_md_ext.c:260-491).  Pinned bitwise against the reference's own kprobaln_ext.c compiled unmodified into
+ * oracle/_ref/libref_parts.so (tests/test_baq.py) and against `lb` tags written by the 2.1.4 binary's
+ * `lofreq alnqual` (tests/golden/baq_*.json).  htslib's seq_nt16_table / seq_nt16_int (absent here; hts.c)
+ * are used by the reference only to map bases to 0..3 / 4: A,C,G,T (either case) -> 0..3, anything else -> 4. */
+
+#define ORC_EI .25
+#define ORC_EM .33333333333
+
+static inline int orc_band_u(int bw, int i, int k)      /* set_u, kprobaln_ext.c:46 */
+{
+    int x = i - bw;
+    x = x > 0 ? x : 0;
+    return (k - x + 1) * 3;
+}
+
+static inline double orc_emit(int r, int qy, double ql) /* the emission term of kprobaln_ext.c:143, 163, 222 */
+{
+    return (r > 3 || qy > 3) ? 1. : (r == qy ? 1. - ql : ql * ORC_EM);
+}
+
+int orc_kpa_glocal(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_query, const uint8_t *iqual,
+                   float par_d, float par_e, int par_bw, int *state, uint8_t *q)
+{
+    static float qual2prob[256];
+    const uint8_t *ref = ref0 - 1, *query = query0 - 1;         /* 1-based, :98 */
+    double *F, *B, *s, m[9], sI, sM, bI, bM;
+    float *qual;
+    int bw, bw2, W, i, k, Pr;
+    if (l_ref <= 0 || l_query <= 0) {
+        return 0;                                               /* :89 */
+    }
+    bw = l_ref > l_query ? l_ref : l_query;                     /* :99-101 */
+    if (bw > par_bw) bw = par_bw;
+    if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
+    bw2 = bw * 2 + 1;
+    W = bw2 * 3 + 6;
+    F = calloc((size_t)(l_query + 1) * W, sizeof(double));
+    B = calloc((size_t)(l_query + 1) * W, sizeof(double));
+    s = calloc((size_t)l_query + 2, sizeof(double));
+    qual = calloc((size_t)l_query + 1, sizeof(float));
+    if (qual2prob[0] == 0) {
+        for (i = 0; i < 256; ++i) qual2prob[i] = pow(10, -i / 10.);   /* float table, :121-123 */
+    }
+    for (i = 1; i <= l_query; ++i) qual[i] = qual2prob[iqual ? iqual[i - 1] : 30];
+    sM = sI = 1. / (2 * l_query + 2);                           /* :127-132; par_d / par_e are floats */
+    m[0] = (1 - par_d - par_d) * (1 - sM); m[1] = m[2] = par_d * (1 - sM);
+    m[3] = (1 - par_e) * (1 - sI); m[4] = par_e * (1 - sI); m[5] = 0.;
+    m[6] = 1 - par_e; m[7] = 0.; m[8] = par_e;
+    bM = (1 - par_d) / l_ref; bI = par_d / l_ref;
+#define FI(i_) (F + (size_t)(i_) * W)
+#define BI(i_) (B + (size_t)(i_) * W)
+    /* forward, :134-190 */
+    FI(0)[orc_band_u(bw, 0, 0)] = s[0] = 1.;
+    {
+        double *fi = FI(1), sum = 0.;
+        int end = l_ref < bw + 1 ? l_ref : bw + 1, b_, e_;
+        for (k = 1; k <= end; ++k) {
+            const int u = orc_band_u(bw, 1, k);
+            const double e = orc_emit(ref[k], query[1], qual[1]);
+            fi[u + 0] = e * bM; fi[u + 1] = ORC_EI * bI;
+            sum += fi[u] + fi[u + 1];
+        }
+        s[1] = sum;
+        b_ = orc_band_u(bw, 1, 1); e_ = orc_band_u(bw, 1, end) + 2;
+        for (k = b_; k <= e_; ++k) fi[k] /= sum;
+    }
+    for (i = 2; i <= l_query; ++i) {
+        double *fi = FI(i), *fi1 = FI(i - 1), sum = 0., qli = qual[i];
+        int beg = 1, end = l_ref, x, b_, e_;
+        const int qyi = query[i];
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        for (k = beg; k <= end; ++k) {
+            const int u = orc_band_u(bw, i, k), v11 = orc_band_u(bw, i - 1, k - 1), v10 = orc_band_u(bw, i - 1, k),
+                      v01 = orc_band_u(bw, i, k - 1);
+            const double e = orc_emit(ref[k], qyi, qli);
+            fi[u + 0] = e * (m[0] * fi1[v11 + 0] + m[3] * fi1[v11 + 1] + m[6] * fi1[v11 + 2]);
+            fi[u + 1] = ORC_EI * (m[1] * fi1[v10 + 0] + m[4] * fi1[v10 + 1]);
+            fi[u + 2] = m[2] * fi[v01 + 0] + m[8] * fi[v01 + 2];
+            sum += fi[u] + fi[u + 1] + fi[u + 2];
+        }
+        s[i] = sum;
+        b_ = orc_band_u(bw, i, beg); e_ = orc_band_u(bw, i, end) + 2;
+        for (k = b_, sum = 1. / sum; k <= e_; ++k) fi[k] *= sum;
+    }
+    {
+        double sum = 0.;
+        for (k = 1; k <= l_ref; ++k) {
+            const int u = orc_band_u(bw, l_query, k);
+            if (u < 3 || u >= bw2 * 3 + 3) continue;
+            sum += FI(l_query)[u + 0] * sM + FI(l_query)[u + 1] * sI;
+        }
+        s[l_query + 1] = sum;
+    }
+    {   /* likelihood, :191-205 */
+        double p = 1., Pr1 = 0.;
+        for (i = 0; i <= l_query + 1; ++i) {
+            p *= s[i];
+            if (p < 1e-100) Pr1 += -4.343 * log(p), p = 1.;
+        }
+        Pr1 += -4.343 * log(p * l_ref * l_query);
+        Pr = (int)(Pr1 + .499);
+    }
+    /* backward, :206-238 */
+    for (k = 1; k <= l_ref; ++k) {
+        const int u = orc_band_u(bw, l_query, k);
+        double *bi = BI(l_query);
+        if (u < 3 || u >= bw2 * 3 + 3) continue;
+        bi[u + 0] = sM / s[l_query] / s[l_query + 1]; bi[u + 1] = sI / s[l_query] / s[l_query + 1];
+    }
+    for (i = l_query - 1; i >= 1; --i) {
+        int beg = 1, end = l_ref, x, b_, e_;
+        double *bi = BI(i), *bi1 = BI(i + 1), y = (i > 1), qli1 = qual[i + 1];
+        const int qyi1 = query[i + 1];
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        for (k = end; k >= beg; --k) {
+            const int u = orc_band_u(bw, i, k), v11 = orc_band_u(bw, i + 1, k + 1), v10 = orc_band_u(bw, i + 1, k),
+                      v01 = orc_band_u(bw, i, k + 1);
+            const double e = (k >= l_ref ? 0 : orc_emit(ref[k + 1], qyi1, qli1)) * bi1[v11];
+            bi[u + 0] = e * m[0] + ORC_EI * m[1] * bi1[v10 + 1] + m[2] * bi[v01 + 2];
+            bi[u + 1] = e * m[3] + ORC_EI * m[4] * bi1[v10 + 1];
+            bi[u + 2] = (e * m[6] + m[8] * bi[v01 + 2]) * y;
+        }
+        b_ = orc_band_u(bw, i, beg); e_ = orc_band_u(bw, i, end) + 2;
+        for (k = b_, y = 1. / s[i]; k <= e_; ++k) bi[k] *= y;
+    }
+    /* MAP, :254-281 */
+    for (i = 1; i <= l_query; ++i) {
+        double sum = 0., *fi = FI(i), *bi = BI(i), max = 0.;
+        int beg = 1, end = l_ref, x, max_k = -1;
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        for (k = beg; k <= end; ++k) {
+            const int u = orc_band_u(bw, i, k);
+            double z;
+            z = fi[u + 0] * bi[u + 0]; if (z > max) max = z, max_k = (k - 1) << 2 | 0; sum += z;
+            z = fi[u + 1] * bi[u + 1]; if (z > max) max = z, max_k = (k - 1) << 2 | 1; sum += z;
+        }
+        max /= sum;
+        if (state) state[i - 1] = max_k;
+        if (q) { k = (int)(-4.343 * log(1. - max) + .499); q[i - 1] = k > 100 ? 99 : k; }
+    }
+#undef FI
+#undef BI
+    free(F); free(B); free(s); free(qual);
+    return Pr;
+}
+
+static inline int orc_base_code(int ch)         /* seq_nt16_int[seq_nt16_table[ch]] */
+{
+    switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+/* BAQ of one read: bam_prob_realn_core_ext with baq_flag = 1, idaq_flag = 0, no pre-existing tags
+ * (bam_md_ext.c:330-470).  cigar: BAM encoding (len << 4 | op; M0 I1 D2 N3 S4 H5 P6 =7 X8).  seq: 0..4.
+ * out[l_qseq]: the bytes of the `lb` tag (BAQ + 33).  Returns 1 if a tag was computed, 0 if the read is
+ * skipped. */
+int orc_baq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, const uint8_t *qual, int l_qseq,
+                 const char *ref, int64_t ref_len, int baq_extended, uint8_t *out)
+{
+    int k, i, bw, x, y, yb, ye, xb, xe;
+    uint8_t *r, *q, *bq;
+    int *state;
+    if (l_qseq == 0) {
+        return 0;
+    }
+    x = pos; y = 0; yb = ye = xb = xe = -1;                     /* :312-340 */
+    for (k = 0; k < n_cigar; ++k) {
+        const int op = cigar[k] & 0xf, l = cigar[k] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            if (yb < 0) yb = y;
+            if (xb < 0) xb = x;
+            ye = y + l; xe = x + l;
+            x += l; y += l;
+        } else if (op == 4 || op == 1) {
+            y += l;
+        } else if (op == 2 || op == 3) {
+            x += l;
+        }
+    }
+    bw = 7;                                                     /* :372-380 */
+    if (abs((xe - xb) - (ye - yb)) > bw) bw = abs((xe - xb) - (ye - yb)) + 3;
+    xb -= yb + bw / 2; if (xb < 0) xb = 0;
+    xe += l_qseq - ye + bw / 2;
+    if (xe - xb - l_qseq > bw) {
+        xb += (xe - xb - l_qseq - bw) / 2, xe -= (xe - xb - l_qseq - bw) / 2;
+    }
+    bq = calloc((size_t)l_qseq + 1, 1);
+    memcpy(bq, qual, (size_t)l_qseq);                           /* :391-392: bases outside match blocks keep their BQ */
+    r = calloc((size_t)(xe - xb > 0 ? xe - xb : 1), 1);
+    for (i = xb; i < xe; ++i) {                                 /* :396-399; ref[] ends with NUL */
+        if (i >= ref_len || ref[i] == 0) { xe = i; break; }
+        r[i - xb] = (uint8_t)orc_base_code((unsigned char)ref[i]);
+    }
+    state = calloc((size_t)l_qseq, sizeof(int));
+    q = calloc((size_t)l_qseq, 1);
+    orc_kpa_glocal(r, xe - xb, seq, l_qseq, qual, 0.00001f, 0.4f, bw, state, q);   /* kpa_ext_par_lofreq_illumina */
+    if (!baq_extended) {                                        /* :409-426 */
+        for (k = 0, x = pos, y = 0; k < n_cigar; ++k) {
+            const int op = cigar[k] & 0xf, l = cigar[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                for (i = y; i < y + l; ++i) {
+                    if ((state[i] & 3) != 0 || state[i] >> 2 != x - xb + (i - y)) bq[i] = 0;
+                    bq[i] = q[i];
+                }
+                x += l; y += l;
+            } else if (op == 4 || op == 1) {
+                y += l;
+            } else if (op == 2) {
+                x += l;
+            }
+        }
+    } else {                                                    /* :431-451 */
+        uint8_t *left = calloc((size_t)l_qseq, 1), *rght = calloc((size_t)l_qseq, 1);
+        for (k = 0, x = pos, y = 0; k < n_cigar; ++k) {
+            const int op = cigar[k] & 0xf, l = cigar[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                for (i = y; i < y + l; ++i) {
+                    bq[i] = ((state[i] & 3) != 0 || state[i] >> 2 != x - xb + (i - y)) ? 0 : q[i];
+                }
+                for (left[y] = bq[y], i = y + 1; i < y + l; ++i) left[i] = bq[i] > left[i - 1] ? bq[i] : left[i - 1];
+                for (rght[y + l - 1] = bq[y + l - 1], i = y + l - 2; i >= y; --i) {
+                    rght[i] = bq[i] > rght[i + 1] ? bq[i] : rght[i + 1];
+                }
+                for (i = y; i < y + l; ++i) bq[i] = left[i] < rght[i] ? left[i] : rght[i];
+                x += l; y += l;
+            } else if (op == 4 || op == 1) {
+                y += l;
+            } else if (op == 2) {
+                x += l;
+            }
+        }
+        free(left); free(rght);
+    }
+    for (i = 0; i < l_qseq; ++i) {                              /* :456-462 */
+        if (bq[i] > 93) bq[i] = 93;
+        out[i] = (uint8_t)(bq[i] + 33);
+    }
+    free(bq); free(r); free(q); free(state);
+    return 1;
+}

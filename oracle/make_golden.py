@@ -294,9 +294,44 @@ def main_indels():
     run_indel("indel_default_filter", 23, 330, 700, sites, [60] * 10 + [20], [])
 
 
+# ---- BAQ fixtures -------------------------------------------------------------------
+
+def run_baq(name, seed, glen, nreads, sites, mapqs, extra=()):
+    """reads with and without indels -> `lofreq alnqual` (SAM out) -> the lb:Z tag of every read"""
+    with tempfile.TemporaryDirectory() as tmp:
+        genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        sam = subprocess.run([LOFREQ, "alnqual"] + list(extra) + ["t.sam", "t.fa"], cwd=tmp, check=True,
+                             capture_output=True, text=True).stdout
+    out = []
+    for line in sam.splitlines():
+        if line.startswith("@"):
+            continue
+        f = line.split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        out.append({"pos0": int(f[3]) - 1, "flag": int(f[1]), "cigar": f[5], "seq": f[9], "qual": f[10],
+                    "lb": tags.get("lb"), "ai": tags.get("ai"), "ad": tags.get("ad")})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "alnqual_args": list(extra), "genome": genome, "reads": out}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d reads, %d with lb, %d bytes" % (name, len(out), sum(1 for r in out if r["lb"]), os.path.getsize(path)))
+
+
+def main_baq():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
+             160: [("-", 1, 0.02), ("+", "T", 0.02)], 190: [("+", "A", 0.5)], 215: [("-", 2, 0.01)],
+             240: [("-", 12, 0.3), ("+", "CCCCCCCCCC", 0.05)]}
+    run_baq("baq_extended", 31, 330, 250, sites, mq_mix)
+    run_baq("baq_plain", 32, 330, 250, sites, mq_mix, extra=("-e",))
+
+
 def main():
     if "--indels-only" in sys.argv:
         return main_indels()
+    if "--baq-only" in sys.argv:
+        return main_baq()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
@@ -313,6 +348,7 @@ def main():
     run("snv_minbq_sig", 15, 220, 600, planted_a, mq_mix, ["-q", "20", "-Q", "25", "-a", "0.001", "-b", "660",
                                                          "--no-default-filter"])
     main_indels()
+    main_baq()
 
 
 if __name__ == "__main__":

@@ -338,4 +338,51 @@ def ref_parts():
     L.int_median.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.dbl_cmp.restype = C.c_int
     L.dbl_cmp.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(L, "kpa_ext_glocal"):
+        L.kpa_ext_glocal.restype = C.c_int
+        L.kpa_ext_glocal.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(KpaPar),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
+
+
+class KpaPar(C.Structure):
+    _fields_ = [("d", C.c_float), ("e", C.c_float), ("bw", C.c_int)]
+
+
+def kpa_glocal(ref, query, qual, d=0.00001, e=0.4, bw=7, use_reference=False):
+    """The banded profile-HMM of BAQ on one read: -> (Pr, state[int32], q[uint8]).  use_reference=True runs the
+    reference's own kpa_ext_glocal object (oracle/_ref/libref_parts.so) instead of the restatement."""
+    ref = np.ascontiguousarray(ref, np.uint8)
+    query = np.ascontiguousarray(query, np.uint8)
+    qual = np.ascontiguousarray(qual, np.uint8)
+    state = np.zeros(len(query), np.int32)
+    q = np.zeros(len(query), np.uint8)
+    if use_reference:
+        R = ref_parts()
+        par = KpaPar(d, e, bw)
+        pr = R.kpa_ext_glocal(ref.ctypes.data, len(ref), query.ctypes.data, len(query), qual.ctypes.data, C.byref(par),
+                              state.ctypes.data, q.ctypes.data, None, None)
+    else:
+        L = lib()
+        L.orc_kpa_glocal.restype = C.c_int
+        L.orc_kpa_glocal.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float,
+                                     C.c_int, C.c_void_p, C.c_void_p]
+        pr = L.orc_kpa_glocal(ref.ctypes.data, len(ref), query.ctypes.data, len(query), qual.ctypes.data, d, e, bw,
+                              state.ctypes.data, q.ctypes.data)
+    return pr, state, q
+
+
+def baq_read(pos, cigar, seq, qual, ref_bytes, extended=True):
+    """orc_baq_read: cigar = list of (op_char, len); seq = codes 0..4; -> lb tag bytes (BAQ + 33) or None"""
+    ops = "MIDNSHP=X"
+    cg = np.asarray([(l << 4) | ops.index(o) for o, l in cigar], np.uint32)
+    seq = np.ascontiguousarray(seq, np.uint8)
+    qual = np.ascontiguousarray(qual, np.uint8)
+    out = np.zeros(len(seq), np.uint8)
+    L = lib()
+    L.orc_baq_read.restype = C.c_int
+    L.orc_baq_read.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int64,
+                               C.c_int, C.c_void_p]
+    rc = L.orc_baq_read(int(pos), cg.ctypes.data, len(cg), seq.ctypes.data, qual.ctypes.data, len(seq), ref_bytes,
+                        len(ref_bytes), 1 if extended else 0, out.ctypes.data)
+    return out if rc else None

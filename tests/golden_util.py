@@ -102,3 +102,25 @@ def conf_kwargs(call_args):
 
 def strip_hqa(line):
     return line.split(";HQA=")[0]
+
+
+def baq_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "baq_*.json")))
+
+
+def parse_cigar(s):
+    import re
+    return [(op, int(n)) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", s)]
+
+
+def load_baq(path):
+    """-> (fixture, list of reads as dicts: pos0, cigar [(op, len)], seq codes 0..4, qual phred, lb bytes or None)"""
+    fx = json.load(open(path))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    reads = []
+    for r in fx["reads"]:
+        reads.append({"pos0": r["pos0"], "cigar": parse_cigar(r["cigar"]),
+                      "seq": np.array([code.get(c, 4) for c in r["seq"].upper()], np.uint8),
+                      "qual": np.array([ord(c) - 33 for c in r["qual"]], np.uint8),
+                      "lb": None if r["lb"] is None else np.frombuffer(r["lb"].encode(), np.uint8)})
+    return fx, reads
