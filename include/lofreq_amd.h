@@ -261,6 +261,26 @@ int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t po
                             const char *alt, int qual, int dp, float af, int sb, int ref_fw, int ref_rv,
                             int alt_fw, int alt_rv, int hrun, const char *filter_or_null);
 
+/* --- base alignment quality: the per-read pre-step -----------------------------------
+ * bam_prob_realn_core_ext (bam_md_ext.c:260-491) with baq_flag = 1 for reads without a pre-existing `lb` tag:
+ * alignment window and band from the CIGAR, kpa_ext_glocal (kprobaln_ext.c:80-270, kpa_ext_par_lofreq_illumina),
+ * then the plain or extended BAQ of every base.  One call = a batch of reads of ONE contig.  The caller
+ *  skips unmapped / zero-length reads like the reference (:287-289) and appends
+ * lb_out[seq_off[r] .. seq_off[r+1]) as the read's `lb:Z` tag (bytes are BAQ + 33, capped at '~').
+ * Indel alignment qualities (idaq, :73-248) are not computed here yet. */
+typedef struct lfq_baq_reads {
+    int64_t n_reads;
+    const int32_t *pos;        /* [n]   bam1_core_t.pos (0-based leftmost reference coordinate) */
+    const int64_t *cigar_off;  /* [n+1] into cigar */
+    const uint32_t *cigar;     /*       BAM encoding: len << 4 | op (M0 I1 D2 N3 S4 H5 P6 =7 X8) */
+    const int64_t *seq_off;    /* [n+1] into seq / qual / lb_out */
+    const uint8_t *seq;        /*       0..3 = A,C,G,T, 4 = anything else (seq_nt16_int of the BAM base) */
+    const uint8_t *qual;       /*       phred base qualities */
+    const char *ref;           /*       the contig's sequence (faidx_fetch_seq), ASCII */
+    int64_t ref_len;
+} lfq_baq_reads;
+int lfq_baq_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int baq_extended, uint8_t *lb_out);
+
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,
                        const int32_t *coverage_plp_or_null, const uint8_t *ref_base,

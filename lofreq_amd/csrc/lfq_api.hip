@@ -1039,6 +1039,137 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
     return LFQ_OK;
 }
 
+int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t *lb_out)
+{
+    if (!c || !rd || rd->n_reads < 0 || (rd->n_reads > 0 && (!rd->pos || !rd->cigar_off || !rd->cigar || !rd->seq_off
+                                                              || !rd->seq || !rd->qual || !rd->ref || !lb_out))) {
+        return LFQ_ERR_INVALID;
+    }
+    const int64_t n = rd->n_reads;
+    if (n == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    /* geometry of every read: alignment window and band width (bam_md_ext.c:312-380, :396-399) */
+    std::vector<LfqBaqRead> h((size_t)n);
+    int max_lq = 0, max_w = 0;
+    for (int64_t r = 0; r < n; r++) {
+        LfqBaqRead &o = h[(size_t)r];
+        const int l_qseq = (int)(rd->seq_off[r + 1] - rd->seq_off[r]);
+        const uint32_t *cg = rd->cigar + rd->cigar_off[r];
+        const int n_cigar = (int)(rd->cigar_off[r + 1] - rd->cigar_off[r]);
+        int x = rd->pos[r], y = 0, yb = -1, ye = -1, xb = -1, xe = -1;
+        for (int k = 0; k < n_cigar; ++k) {
+            const int op = cg[k] & 0xf, l = cg[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                if (yb < 0) yb = y;
+                if (xb < 0) xb = x;
+                ye = y + l; xe = x + l;
+                x += l; y += l;
+            } else if (op == 4 || op == 1) {
+                y += l;
+            } else if (op == 2 || op == 3) {
+                x += l;
+            }
+        }
+        int bw = 7;
+        if (abs((xe - xb) - (ye - yb)) > bw) bw = abs((xe - xb) - (ye - yb)) + 3;
+        xb -= yb + bw / 2; if (xb < 0) xb = 0;
+        xe += l_qseq - ye + bw / 2;
+        if (xe - xb - l_qseq > bw) {
+            xb += (xe - xb - l_qseq - bw) / 2, xe -= (xe - xb - l_qseq - bw) / 2;
+        }
+        if (xe > rd->ref_len) xe = (int)rd->ref_len;      /* the reference stops at the string's NUL */
+        o.pos = rd->pos[r];
+        o.l_qseq = l_qseq;
+        o.xb = xb;
+        o.l_ref = xe - xb;
+        o.bw = bw;
+        o.n_cigar = n_cigar;
+        o.cigar_off = rd->cigar_off[r];
+        if (l_qseq > 0 && o.l_ref > 0) {
+            int b2 = std::max(o.l_ref, l_qseq);
+            if (b2 > bw) b2 = bw;
+            if (b2 < abs(o.l_ref - l_qseq)) b2 = abs(o.l_ref - l_qseq);
+            max_lq = std::max(max_lq, l_qseq);
+            max_w = std::max(max_w, (b2 * 2 + 1) * 3 + 6);
+        }
+    }
+    const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
+    float h_q2p[256];
+    for (int i = 0; i < 256; i++) {
+        h_q2p[i] = (float)pow(10, -i / 10.);                 /* kprobaln_ext.c:121-123 */
+    }
+    /* device copies (one allocation) */
+    uint8_t *d_blob = nullptr;
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    const int64_t o_reads = 0, o_soff = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_cig = o_soff + al((n + 1) * 8),
+                  o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_ref = o_qual + al(n_bases),
+                  o_out = o_ref + al(rd->ref_len + 1), o_q2p = o_out + al(n_bases), total = o_q2p + al(1024);
+    LFQ_TRY_HIP(hipMalloc((void **)&d_blob, (size_t)total));
+    int rc = LFQ_OK;
+    auto up = [&](int64_t off, const void *src, int64_t bytes) {
+        if (rc == LFQ_OK && bytes > 0 && hipMemcpyAsync(d_blob + off, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
+    };
+    up(o_reads, h.data(), n * (int64_t)sizeof(LfqBaqRead));
+    up(o_soff, rd->seq_off, (n + 1) * 8);
+    up(o_cig, rd->cigar, n_cig * 4);
+    up(o_seq, rd->seq, n_bases);
+    up(o_qual, rd->qual, n_bases);
+    up(o_ref, rd->ref, rd->ref_len);
+    up(o_q2p, h_q2p, 1024);
+    if (rc == LFQ_OK && hipMemsetAsync(d_blob + o_out, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess) {
+        rc = LFQ_ERR_HIP;
+    }
+    double *d_scr = nullptr;
+    int32_t *d_expect = nullptr;
+    uint8_t *d_tmp8 = nullptr;
+    if (rc == LFQ_OK && max_lq > 0) {
+        LfqBaqArgs A;
+        memset(&A, 0, sizeof(A));
+        A.reads = (const LfqBaqRead *)(d_blob + o_reads);
+        A.seq_off = (const int64_t *)(d_blob + o_soff);
+        A.cigar = (const uint32_t *)(d_blob + o_cig);
+        A.seq = d_blob + o_seq;
+        A.qual = d_blob + o_qual;
+        A.ref = d_blob + o_ref;
+        A.lb_out = d_blob + o_out;
+        A.qual2prob = (const float *)(d_blob + o_q2p);
+        A.n_reads = n;
+        A.rows = max_lq + 1;
+        A.W = max_w;
+        A.baq_extended = baq_extended ? 1 : 0;
+        /* waves per launch from a 4 GiB scratch budget */
+        const int64_t per_wave = ((int64_t)A.rows * A.W + 2 * (int64_t)A.W + A.rows + 2) * 64 * 8;
+        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, ((int64_t)4 << 30) / per_wave));
+        if (hipMalloc((void **)&d_scr, (size_t)(waves * per_wave)) != hipSuccess
+            || hipMalloc((void **)&d_expect, (size_t)(waves * A.rows * 64 * 4)) != hipSuccess
+            || hipMalloc((void **)&d_tmp8, (size_t)(waves * 2 * A.rows * 64)) != hipSuccess) {
+            rc = LFQ_ERR_NOMEM;
+        }
+        A.scratch = d_scr;
+        A.expect = d_expect;
+        A.tmp8 = d_tmp8;
+        for (int64_t first = 0; rc == LFQ_OK && first < n; first += waves * 64) {
+            A.first_read = (int32_t)first;
+            rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), c->stream);
+        }
+    }
+    if (rc == LFQ_OK && hipMemcpyAsync(lb_out, d_blob + o_out, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+        rc = LFQ_ERR_HIP;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
+        rc = LFQ_ERR_HIP;
+    }
+    (void)hipFree(d_blob);
+    if (d_scr) (void)hipFree(d_scr);
+    if (d_expect) (void)hipFree(d_expect);
+    if (d_tmp8) (void)hipFree(d_tmp8);
+    return rc;
+}
+
 int lfq_synth_fill_device(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t plant_period, int64_t col_begin,
                           int64_t ncols, uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq,
                           uint64_t *d_col_off, uint8_t *d_ref_base, void *stream_or_null)

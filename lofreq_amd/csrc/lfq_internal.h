@@ -156,6 +156,34 @@ void lfq_sb_precompute_begin(void);
 /* tuples: n x {ref_fw, ref_rv, alt_fw, alt_rv}; all-zero tuples are skipped.  Ends the begin() bracket. */
 void lfq_sb_precompute(const int32_t *tuples, int64_t n);
 
+/* ---- BAQ (lfq_baq.hip) ----------------------------------------------------------------------------------- */
+struct LfqBaqRead {            /* 32 bytes, built on the host from the CIGAR (bam_md_ext.c:312-380) */
+    int32_t pos;               /* bam1_core_t.pos */
+    int32_t l_qseq;
+    int32_t xb, l_ref;         /* reference window [xb, xb + l_ref) */
+    int32_t bw;                /* band width handed to the HMM */
+    int32_t n_cigar;
+    int64_t cigar_off;
+};
+
+struct LfqBaqArgs {
+    const LfqBaqRead *reads;
+    const int64_t *seq_off;    /* [n+1] */
+    const uint32_t *cigar;
+    const uint8_t *seq, *qual; /* 0..4 / phred */
+    const uint8_t *ref;        /* contig, ASCII */
+    uint8_t *lb_out;           /* [seq_off[n]] */
+    double *scratch;           /* per wavefront: F[rows][W][64], B[2][W][64], S[rows + 2][64] */
+    int32_t *expect;           /* per wavefront: [rows][64] expected reference offset of a matched base, INT32_MIN otherwise */
+    uint8_t *tmp8;             /* per wavefront: [2][rows][64] running maxima of the extended BAQ */
+    const float *qual2prob;    /* [256] pow(10, -q/10.) as float, computed on the host (kprobaln_ext.c:121-123) */
+    int64_t n_reads;
+    int32_t rows, W;           /* scratch geometry: rows >= max l_qseq + 1, W >= max (2 bw + 1) * 3 + 6 */
+    int32_t baq_extended;
+    int32_t first_read;        /* reads [first_read, first_read + n_launch) of the arrays */
+};
+int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, void *stream);
+
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
 int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, int32_t *tuples_mapped,
                             int32_t *n_mapped, int cap_entries, int min_alt, void *stream);

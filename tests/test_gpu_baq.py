@@ -1,0 +1,78 @@
+"""-m gpu parity of the BAQ kernel (lfq_baq_batch): bit-exact against the oracle (itself bit-identical to the
+reference's kprobaln_ext.c object) and against the `lb` tags the reference's 2.1.4 binary wrote."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+
+
+@pytest.mark.parametrize("path", gu.baq_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_baq_golden_alnqual_tags(caller, path):
+    import lofreq_amd as la
+    fx, reads = gu.load_baq(path)
+    extended = "-e" not in fx["alnqual_args"]
+    out = la.baq_batch(caller, reads, fx["genome"].encode(), extended=extended)
+    assert len(out) == len(reads)
+    for r, o in zip(reads, out):
+        assert o.tobytes() == r["lb"].tobytes(), (r["pos0"], r["cigar"])
+
+
+def _random_reads(rng, genome, n, rl_lo, rl_hi):
+    reads = []
+    glen = len(genome)
+    for _ in range(n):
+        rl = int(rng.integers(rl_lo, rl_hi + 1))
+        pos = int(rng.integers(0, glen - rl - 20))
+        seq, cigar, gp, run = [], [], pos, 0
+        if rng.random() < 0.2:
+            k = int(rng.integers(1, 6))
+            seq.extend(rng.choice(list("ACGT"), k))
+            cigar.append(("S", k))
+        while len(seq) < rl and gp < glen - 1:
+            seq.append(genome[gp] if rng.random() > 0.02 else str(rng.choice(list("ACGTN"))))
+            run += 1
+            gp += 1
+            u = rng.random()
+            if run > 3 and len(seq) < rl - 4 and u < 0.01:
+                cigar.append(("M", run)); run = 0
+                k = int(rng.integers(1, 14))
+                seq.extend(rng.choice(list("ACGT"), k)); cigar.append(("I", k))
+            elif run > 3 and len(seq) < rl - 4 and u < 0.02:
+                cigar.append(("M", run)); run = 0
+                k = int(rng.integers(1, 14))
+                cigar.append(("D", k)); gp += k
+        if run:
+            cigar.append(("M", run))
+        if cigar[-1][0] != "M":
+            continue
+        import lofreq_amd as la
+        reads.append({"pos0": pos, "cigar": cigar, "seq": la.encode_seq("".join(seq)),
+                      "qual": np.clip(np.round(rng.normal(32, 8, len(seq))), 0, 60).astype(np.uint8)})
+    return reads
+
+
+@pytest.mark.parametrize("extended", [True, False])
+def test_baq_random_reads_vs_oracle(caller, oracle, extended):
+    """ragged read lengths (more than one wavefront, lanes of a wavefront with different lengths and bands),
+    soft clips, insertions and deletions up to 13 bp, N bases, reads at the contig ends"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(5)
+    genome = "".join(rng.choice(list("ACGT"), 3000))
+    reads = _random_reads(rng, genome, 400, 20, 160)
+    # reads hanging over both contig ends
+    reads.append({"pos0": 0, "cigar": [("M", 50)], "seq": la.encode_seq(genome[:50]), "qual": np.full(50, 30, np.uint8)})
+    reads.append({"pos0": 2950, "cigar": [("M", 50)], "seq": la.encode_seq(genome[2950:]), "qual": np.full(50, 30, np.uint8)})
+    out = la.baq_batch(caller, reads, genome.encode(), extended=extended)
+    nb = 0
+    for r, o in zip(reads, out):
+        exp = oracle.baq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), extended=extended)
+        assert o.tobytes() == exp.tobytes(), (r["pos0"], r["cigar"])
+        nb += len(o)
+    assert nb > 20000
+
+
+def test_baq_empty(caller):
+    import lofreq_amd as la
+    assert la.baq_batch(caller, [], b"ACGT") == []
