@@ -86,6 +86,11 @@ struct lfq_ctx {
     int32_t *h_nheavy, *d_nheavy_mapped;
     int heavy_cap;
     hipEvent_t ev_heavy;
+    /* BAQ scratch (lfq_baq_batch), kept between calls */
+    double *d_baq_scr;
+    int32_t *d_baq_expect;
+    uint8_t *d_baq_tmp8;
+    int64_t baq_scr_bytes, baq_expect_bytes, baq_tmp8_bytes;
     std::thread *leader;
     std::mutex *lm;
     std::condition_variable *lcv;
@@ -357,6 +362,9 @@ void lfq_destroy(lfq_ctx *c)
         c->leader = nullptr;
     }
     if (c) {
+        if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
+        if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
+        if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);
         if (c->h_tuples) (void)hipHostFree(c->h_tuples);
         if (c->h_nheavy) (void)hipHostFree(c->h_nheavy);
         if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
@@ -1142,13 +1150,34 @@ int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t
         A.W = max_w;
         A.baq_extended = baq_extended ? 1 : 0;
         /* waves per launch from a 4 GiB scratch budget */
-        const int64_t per_wave = ((int64_t)A.rows * A.W + 2 * (int64_t)A.W + A.rows + 2) * 64 * 8;
-        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, ((int64_t)4 << 30) / per_wave));
-        if (hipMalloc((void **)&d_scr, (size_t)(waves * per_wave)) != hipSuccess
-            || hipMalloc((void **)&d_expect, (size_t)(waves * A.rows * 64 * 4)) != hipSuccess
-            || hipMalloc((void **)&d_tmp8, (size_t)(waves * 2 * A.rows * 64)) != hipSuccess) {
-            rc = LFQ_ERR_NOMEM;
+        const int64_t per_wave = ((int64_t)A.rows * A.W + 2 * (int64_t)A.W + 2 * ((int64_t)A.rows + 2)) * 64 * 8;
+        /* the kernel is a chain of dependent HBM accesses per lane: it needs several wavefronts per SIMD in
+         * flight, i.e. scratch for them -- up to half of the free HBM, at most 32 GiB */
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        int64_t budget_b = std::min<int64_t>((int64_t)32 << 30, (int64_t)(free_b / 2));
+        if (const char *e = getenv("LFQ_BAQ_SCRATCH_MB")) {
+            budget_b = (int64_t)atol(e) << 20;
         }
+        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, budget_b / per_wave));
+        auto keep = [&](auto **slot, int64_t *have, int64_t need) {
+            if (need > *have) {
+                if (*slot) (void)hipFree(*slot);
+                *slot = nullptr;
+                *have = 0;
+                if (hipMalloc((void **)slot, (size_t)need) != hipSuccess) {
+                    rc = LFQ_ERR_NOMEM;
+                    return;
+                }
+                *have = need;
+            }
+        };
+        keep(&c->d_baq_scr, &c->baq_scr_bytes, waves * per_wave);
+        keep(&c->d_baq_expect, &c->baq_expect_bytes, waves * A.rows * 64 * 4);
+        keep(&c->d_baq_tmp8, &c->baq_tmp8_bytes, waves * 2 * A.rows * 64);
+        d_scr = c->d_baq_scr;
+        d_expect = c->d_baq_expect;
+        d_tmp8 = c->d_baq_tmp8;
         A.scratch = d_scr;
         A.expect = d_expect;
         A.tmp8 = d_tmp8;
@@ -1164,9 +1193,6 @@ int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t
         rc = LFQ_ERR_HIP;
     }
     (void)hipFree(d_blob);
-    if (d_scr) (void)hipFree(d_scr);
-    if (d_expect) (void)hipFree(d_expect);
-    if (d_tmp8) (void)hipFree(d_tmp8);
     return rc;
 }
 

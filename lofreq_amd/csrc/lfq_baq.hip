@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     const LfqBaqRead R = A.reads[A.first_read + (live ? ridx : 0)];
     const int W = A.W, rows = A.rows;
     /* this wavefront's scratch */
-    double *F = A.scratch + (size_t)blockIdx.x * ((size_t)rows * W + 2 * (size_t)W + rows + 2) * 64;
+    double *F = A.scratch + (size_t)blockIdx.x * ((size_t)rows * W + 2 * (size_t)W + 2 * ((size_t)rows + 2)) * 64;
     double *B = F + (size_t)rows * W * 64;
     double *S = B + 2 * (size_t)W * 64;
     int32_t *expect = A.expect + (size_t)blockIdx.x * rows * 64;
@@ -85,13 +85,20 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     m[6] = 1 - par_e; m[7] = 0.; m[8] = par_e;
     const double bM = (1 - par_d) / l_ref, bI = par_d / l_ref;
 
-    /* ---- forward (:134-190) ---- */
+    /* ---- forward (:134-190) ----
+     * Rows >= 2 are stored UNSCALED; the reference's `fi[k] *= 1/sum` (:181) is applied by whoever reads the
+     * cell (the same multiplication of the same two doubles: identical value), which saves one read + write
+     * pass over the matrix.  SQ(i) keeps s[i], RQ(i) the reciprocal the reference multiplies with.
+     * Only the cells next to the band are zeroed (the reference reads them from calloc'ed memory). */
+#define RQ(i_) S[(size_t)(rows + 2 + (i_)) * 64 + lane]
     for (int u = 0; u < Wr; u++) {
         FQ(0, u) = 0.;
         FQ(1, u) = 0.;
     }
     FQ(0, lfq_baq_u(bw, 0, 0)) = 1.;
     SQ(0) = 1.;
+    RQ(0) = 1.;
+    RQ(1) = 1.;                                                          /* row 1 is rescaled in place (division, :154) */
     {
         double sum = 0.;
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
@@ -111,40 +118,46 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         }
     }
     for (int i = 2; i <= l_query; ++i) {
-        for (int u = 0; u < Wr; u++) {
-            FQ(i, u) = 0.;
-        }
         double sum = 0.;
         const double qli = A.qual2prob[iqual[i]];
+        const double rs = RQ(i - 1);                 /* pending scale of row i-1 */
         const int qyi = query[i];
         int beg = 1, end = l_ref, x;
         x = i - bw; beg = beg > x ? beg : x;
         x = i + bw; end = end < x ? end : x;
+        const int b_ = lfq_baq_u(bw, i, beg), e_ = lfq_baq_u(bw, i, end) + 2;
+        for (int u = (b_ >= 3 ? b_ - 3 : 0); u < b_; u++) {
+            FQ(i, u) = 0.;
+        }
+        for (int u = e_ + 1; u < Wr && u <= e_ + 3; u++) {
+            FQ(i, u) = 0.;
+        }
+        double m_prev = 0., d_prev = 0.;             /* cell k-1 of this row (unscaled, like the reference at that point) */
         for (int k = beg; k <= end; ++k) {
-            const int u = lfq_baq_u(bw, i, k), v11 = lfq_baq_u(bw, i - 1, k - 1), v10 = lfq_baq_u(bw, i - 1, k),
-                      v01 = lfq_baq_u(bw, i, k - 1);
+            const int u = lfq_baq_u(bw, i, k), v11 = lfq_baq_u(bw, i - 1, k - 1), v10 = lfq_baq_u(bw, i - 1, k);
             const double e = lfq_baq_emit(lfq_baq_code(refw[k]), qyi, qli);
-            const double f0 = e * (m[0] * FQ(i - 1, v11 + 0) + m[3] * FQ(i - 1, v11 + 1) + m[6] * FQ(i - 1, v11 + 2));
-            const double f1 = LFQ_BAQ_EI * (m[1] * FQ(i - 1, v10 + 0) + m[4] * FQ(i - 1, v10 + 1));
-            const double f2 = m[2] * FQ(i, v01 + 0) + m[8] * FQ(i, v01 + 2);
+            const double a0 = FQ(i - 1, v11 + 0) * rs, a1 = FQ(i - 1, v11 + 1) * rs, a2 = FQ(i - 1, v11 + 2) * rs;
+            const double c0 = FQ(i - 1, v10 + 0) * rs, c1 = FQ(i - 1, v10 + 1) * rs;
+            const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
+            const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
+            const double f2 = m[2] * m_prev + m[8] * d_prev;
             FQ(i, u + 0) = f0;
             FQ(i, u + 1) = f1;
             FQ(i, u + 2) = f2;
+            m_prev = f0;
+            d_prev = f2;
             sum += f0 + f1 + f2;
         }
         SQ(i) = sum;
-        const int b_ = lfq_baq_u(bw, i, beg), e_ = lfq_baq_u(bw, i, end) + 2;
-        sum = 1. / sum;
-        for (int k = b_; k <= e_; ++k) {
-            FQ(i, k) = FQ(i, k) * sum;
-        }
+        RQ(i) = 1. / sum;
     }
     {
         double sum = 0.;
+        const double rs = RQ(l_query);
         for (int k = 1; k <= l_ref; ++k) {
             const int u = lfq_baq_u(bw, l_query, k);
             if (u < 3 || u >= bw2 * 3 + 3) continue;
-            sum += FQ(l_query, u + 0) * sM + FQ(l_query, u + 1) * sI;
+            sum += (FQ(l_query, u + 0) * rs) * sM + (FQ(l_query, u + 1) * rs) * sI;
         }
         SQ(l_query + 1) = sum;
     }
@@ -217,14 +230,15 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         }
         /* MAP of row i */
         double sum = 0., max = 0.;
+        const double rsi = RQ(i);
         int beg = 1, end = l_ref, x, max_k = -1;
         x = i - bw; beg = beg > x ? beg : x;
         x = i + bw; end = end < x ? end : x;
         for (int k = beg; k <= end; ++k) {
             const int u = lfq_baq_u(bw, i, k);
             double z;
-            z = FQ(i, u + 0) * BQ(cur, u + 0); if (z > max) max = z, max_k = (k - 1) << 2 | 0; sum += z;
-            z = FQ(i, u + 1) * BQ(cur, u + 1); if (z > max) max = z, max_k = (k - 1) << 2 | 1; sum += z;
+            z = (FQ(i, u + 0) * rsi) * BQ(cur, u + 0); if (z > max) max = z, max_k = (k - 1) << 2 | 0; sum += z;
+            z = (FQ(i, u + 1) * rsi) * BQ(cur, u + 1); if (z > max) max = z, max_k = (k - 1) << 2 | 1; sum += z;
         }
         max /= sum;
         int qk = (int)(-4.343 * log(1. - max) + .499);
@@ -281,6 +295,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
 #undef FQ
 #undef BQ
 #undef SQ
+#undef RQ
 }
 
 int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, void *stream)

@@ -173,7 +173,7 @@ struct LfqBaqArgs {
     const uint8_t *seq, *qual; /* 0..4 / phred */
     const uint8_t *ref;        /* contig, ASCII */
     uint8_t *lb_out;           /* [seq_off[n]] */
-    double *scratch;           /* per wavefront: F[rows][W][64], B[2][W][64], S[rows + 2][64] */
+    double *scratch;           /* per wavefront: F[rows][W][64], B[2][W][64], S[rows + 2][64], 1/S[rows + 2][64] */
     int32_t *expect;           /* per wavefront: [rows][64] expected reference offset of a matched base, INT32_MIN otherwise */
     uint8_t *tmp8;             /* per wavefront: [2][rows][64] running maxima of the extended BAQ */
     const float *qual2prob;    /* [256] pow(10, -q/10.) as float, computed on the host (kprobaln_ext.c:121-123) */

@@ -1,0 +1,37 @@
+import sys, os, time
+root=os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, root); sys.path.insert(0, os.path.join(root,"oracle"))
+import numpy as np, ctypes as C
+import lofreq_amd as la
+from lofreq_amd import _lib
+import pyoracle as orc
+n=int(sys.argv[1]) if len(sys.argv)>1 else 400000
+rl=150
+rng=np.random.default_rng(1)
+glen=2_000_000
+genome=rng.integers(0,4,glen).astype(np.uint8)
+gen_ascii=np.frombuffer(b"ACGT",np.uint8)[genome].tobytes()
+pos=np.sort(rng.integers(0,glen-rl-10,n)).astype(np.int32)
+seq=genome[(pos[:,None]+np.arange(rl)[None,:])].astype(np.uint8)
+mism=rng.random(seq.shape)<0.005
+seq[mism]=(seq[mism]+1)%4
+qual=np.clip(np.round(rng.normal(33,6,seq.shape)),2,41).astype(np.uint8)
+cig=np.full(n,(rl<<4)|0,np.uint32)
+cig_off=np.arange(n+1,dtype=np.int64); seq_off=np.arange(n+1,dtype=np.int64)*rl
+out=np.zeros(n*rl,np.uint8)
+caller=la.SnvCaller(0)
+rd=_lib.BaqReads(); rd.n_reads=n; rd.pos=pos.ctypes.data; rd.cigar_off=cig_off.ctypes.data; rd.cigar=cig.ctypes.data
+rd.seq_off=seq_off.ctypes.data; seqf=np.ascontiguousarray(seq.reshape(-1)); qualf=np.ascontiguousarray(qual.reshape(-1))
+rd.seq=seqf.ctypes.data; rd.qual=qualf.ctypes.data; rd.ref=C.cast(C.c_char_p(gen_ascii),C.c_void_p); rd.ref_len=glen
+L=_lib.load()
+for it in range(3):
+    t0=time.perf_counter(); rc=L.lfq_baq_batch(caller.h, C.byref(rd), 1, out.ctypes.data); dt=time.perf_counter()-t0
+    print("gpu: %d reads x %d bp in %.3f s -> %.2f M reads/s (host buffers in and out, allocations included), rc %d"%(n,rl,dt,n/dt/1e6,rc))
+# cpu oracle on a sample
+m=2000
+t0=time.perf_counter()
+for i in range(m):
+    o=orc.baq_read(int(pos[i]), [("M",rl)], seq[i], qual[i], gen_ascii, True)
+dt=time.perf_counter()-t0
+print("cpu oracle (1 thread, via ctypes): %d reads in %.2f s -> %.0f reads/s"%(m,dt,m/dt))
+assert o.tobytes()==out[(m-1)*rl:m*rl].tobytes()
+print("last sample read identical to the GPU result")
