@@ -997,8 +997,10 @@ static inline double orc_emit(int r, int qy, double ql) /* the emission term of 
     return (r > 3 || qy > 3) ? 1. : (r == qy ? 1. - ql : ql * ORC_EM);
 }
 
-int orc_kpa_glocal(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_query, const uint8_t *iqual,
-                   float par_d, float par_e, int par_bw, int *state, uint8_t *q)
+/* pd (optional): posterior matrix, (l_query + 1) rows of (2 bw + 1) * 3 + 6 doubles with bw = *ret_bw
+ * (kprobaln_ext.c:266-270); the caller sizes it for the largest possible band */
+int orc_kpa_glocal_pd(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_query, const uint8_t *iqual,
+                      float par_d, float par_e, int par_bw, int *state, uint8_t *q, double *pd, int *ret_bw)
 {
     static float qual2prob[256];
     const uint8_t *ref = ref0 - 1, *query = query0 - 1;         /* 1-based, :98 */
@@ -1011,6 +1013,7 @@ int orc_kpa_glocal(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_
     bw = l_ref > l_query ? l_ref : l_query;                     /* :99-101 */
     if (bw > par_bw) bw = par_bw;
     if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
+    if (ret_bw) *ret_bw = bw;
     bw2 = bw * 2 + 1;
     W = bw2 * 3 + 6;
     F = calloc((size_t)(l_query + 1) * W, sizeof(double));
@@ -1115,6 +1118,12 @@ int orc_kpa_glocal(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_
             double z;
             z = fi[u + 0] * bi[u + 0]; if (z > max) max = z, max_k = (k - 1) << 2 | 0; sum += z;
             z = fi[u + 1] * bi[u + 1]; if (z > max) max = z, max_k = (k - 1) << 2 | 1; sum += z;
+            if (pd) {
+                double *pdi = pd + (size_t)i * W;
+                pdi[u + 0] = fi[u + 0] * bi[u + 0] * s[i];
+                pdi[u + 1] = fi[u + 1] * bi[u + 1] * s[i];
+                pdi[u + 2] = fi[u + 2] * bi[u + 2] * s[i];
+            }
         }
         max /= sum;
         if (state) state[i - 1] = max_k;
@@ -1124,6 +1133,12 @@ int orc_kpa_glocal(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_
 #undef BI
     free(F); free(B); free(s); free(qual);
     return Pr;
+}
+
+int orc_kpa_glocal(const uint8_t *ref0, int l_ref, const uint8_t *query0, int l_query, const uint8_t *iqual,
+                   float par_d, float par_e, int par_bw, int *state, uint8_t *q)
+{
+    return orc_kpa_glocal_pd(ref0, l_ref, query0, l_query, iqual, par_d, par_e, par_bw, state, q, NULL, NULL);
 }
 
 static inline int orc_base_code(int ch)         /* seq_nt16_int[seq_nt16_table[ch]] */
@@ -1141,12 +1156,106 @@ static inline int orc_base_code(int ch)         /* seq_nt16_int[seq_nt16_table[c
  * (bam_md_ext.c:330-470).  cigar: BAM encoding (len << 4 | op; M0 I1 D2 N3 S4 H5 P6 =7 X8).  seq: 0..4.
  * out[l_qseq]: the bytes of the `lb` tag (BAQ + 33).  Returns 1 if a tag was computed, 0 if the read is
  * skipped. */
+/* prob_to_sangerq + encode_q, bam_md_ext.c:55-56 */
+static inline uint8_t orc_ap_to_char(double p)
+{
+    const int q = (p < 0.0 + DBL_EPSILON) ? 126 + 1 : ((int)(-10 * log10(p)) + 33);
+    return (uint8_t)(q < 33 ? '!' : (q > 126 ? '~' : q));
+}
+
+/* idaq (bam_md_ext.c:73-248): indel alignment qualities from the posterior matrix.  iaq / daq: l_qseq bytes
+ * ('~' = nothing); returns bit 0 = an `ai` tag is written (n_ins > 0), bit 1 = an `ad` tag (n_del > 0).
+ * The read's bases are "ACGTN"[code]: ambiguity codes other than N are not representable (they would compare
+ * unequal to a same-coded reference base in the repeat scan, :197). */
+static int orc_idaq(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, int l_qseq, const char *ref,
+                    const double *pd, int W, int xe, int xb, int bw, uint8_t *iaq, uint8_t *daq)
+{
+    int k, x, y, n_ins = 0, n_del = 0;
+    const int bw2 = bw * 2 + 1;
+    memset(iaq, '~', (size_t)l_qseq);
+    memset(daq, '~', (size_t)l_qseq);
+    for (k = 0, x = pos, y = 0; k < n_cigar; ++k) {
+        int j;
+        const int op = cigar[k] & 0xf, oplen = cigar[k] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            x += oplen; y += oplen;
+        } else if (op == 2) {                               /* :107-171; note: the skips do not advance x */
+            const int rpos = x, qpos = y;
+            int ref_i, del_rep = 0, rep_i = 0;
+            double ap = 0;
+            const char *del_seq;
+            if (qpos == 0) continue;
+            if (oplen > 16) continue;
+            n_del += 1;
+            del_seq = ref + x;
+            x += oplen;
+            ref_i = x;
+            while (ref_i < xe) {
+                if (ref[ref_i] != del_seq[rep_i]) break;
+                del_rep += 1; ref_i += 1; rep_i += 1;
+                if (rep_i >= oplen) rep_i = 0;
+            }
+            for (j = 0; j < del_rep + 1; j++) {
+                int u;
+                if (qpos + j > l_qseq) break;
+                u = orc_band_u(bw, qpos + j, rpos - xb + 1 + j);
+                if (u < 3 || u >= bw2 * 3 + 3) continue;
+                ap += pd[(size_t)(qpos + j) * W + u + 2];
+            }
+            ap = 1 - ap;
+            daq[qpos - 1] = orc_ap_to_char(ap);
+        } else if (op == 1) {                               /* :172-233; note: the skips do not advance y */
+            const int rpos = x, qpos = y;
+            int ref_i, ins_rep = 0, rep_i = 0;
+            double ap = 0;
+            char ins_seq[17];
+            if (oplen > 16) continue;
+            n_ins += 1;
+            if (qpos == 0) continue;
+            for (j = 0; j < oplen; j++) {
+                ins_seq[j] = "ACGTN"[seq[y] > 4 ? 4 : seq[y]];
+                y++;
+            }
+            ref_i = x;
+            while (ref_i < xe) {
+                if (ref[ref_i] != ins_seq[rep_i]) break;
+                ins_rep += 1; ref_i += 1; rep_i += 1;
+                if (rep_i >= oplen) rep_i = 0;
+            }
+            for (j = 0; j < ins_rep + 1; j++) {
+                int u;
+                if (qpos + j + 1 > l_qseq) break;
+                u = orc_band_u(bw, qpos + j + 1, rpos - xb + j);
+                if (u < 3 || u >= bw2 * 3 + 3) continue;
+                ap += pd[(size_t)(qpos + j + 1) * W + u + 1];
+            }
+            ap = 1 - ap;
+            iaq[qpos - 1] = orc_ap_to_char(ap);
+        } else if (op == 4) {
+            y += oplen;
+        }
+    }
+    return (n_ins ? 1 : 0) | (n_del ? 2 : 0);
+}
+
+/* BAQ + IDAQ of one read; iaq / daq may be NULL (then only the lb tag is computed).  Returns bit 0 = lb computed,
+ * bit 1 = ai tag present, bit 2 = ad tag present. */
+int orc_baq_idaq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, const uint8_t *qual, int l_qseq,
+                      const char *ref, int64_t ref_len, int baq_extended, uint8_t *out, uint8_t *iaq, uint8_t *daq);
+
 int orc_baq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, const uint8_t *qual, int l_qseq,
                  const char *ref, int64_t ref_len, int baq_extended, uint8_t *out)
 {
-    int k, i, bw, x, y, yb, ye, xb, xe;
+    return orc_baq_idaq_read(pos, cigar, n_cigar, seq, qual, l_qseq, ref, ref_len, baq_extended, out, NULL, NULL) & 1;
+}
+
+int orc_baq_idaq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, const uint8_t *qual, int l_qseq,
+                      const char *ref, int64_t ref_len, int baq_extended, uint8_t *out, uint8_t *iaq, uint8_t *daq)
+{
+    int k, i, bw, x, y, yb, ye, xb, xe, has_indel = 0, hmm_bw = 0, rc = 1;
     uint8_t *r, *q, *bq;
     int *state;
+    double *pd = NULL;
     if (l_qseq == 0) {
         return 0;
     }
@@ -1160,8 +1269,10 @@ int orc_baq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq
             x += l; y += l;
         } else if (op == 4 || op == 1) {
             y += l;
+            if (op == 1) has_indel = 1;
         } else if (op == 2 || op == 3) {
             x += l;
+            if (op == 2) has_indel = 1;
         }
     }
     bw = 7;                                                     /* :372-380 */
@@ -1180,7 +1291,11 @@ int orc_baq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq
     }
     state = calloc((size_t)l_qseq, sizeof(int));
     q = calloc((size_t)l_qseq, 1);
-    orc_kpa_glocal(r, xe - xb, seq, l_qseq, qual, 0.00001f, 0.4f, bw, state, q);   /* kpa_ext_par_lofreq_illumina */
+    if (iaq && daq && has_indel) {
+        const int lr = xe - xb, bmax = (lr > l_qseq ? lr : l_qseq) + abs(lr - l_qseq) + bw;
+        pd = calloc((size_t)(l_qseq + 1) * ((size_t)(2 * bmax + 1) * 3 + 6), sizeof(double));
+    }
+    orc_kpa_glocal_pd(r, xe - xb, seq, l_qseq, qual, 0.00001f, 0.4f, bw, state, q, pd, &hmm_bw);   /* kpa_ext_par_lofreq_illumina */
     if (!baq_extended) {                                        /* :409-426 */
         for (k = 0, x = pos, y = 0; k < n_cigar; ++k) {
             const int op = cigar[k] & 0xf, l = cigar[k] >> 4;
@@ -1222,6 +1337,10 @@ int orc_baq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq
         if (bq[i] > 93) bq[i] = 93;
         out[i] = (uint8_t)(bq[i] + 33);
     }
+    if (pd) {                                                   /* :476-478 */
+        rc |= orc_idaq(pos, cigar, n_cigar, seq, l_qseq, ref, pd, (hmm_bw * 2 + 1) * 3 + 6, xe, xb, hmm_bw, iaq, daq) << 1;
+        free(pd);
+    }
     free(bq); free(r); free(q); free(state);
-    return 1;
+    return rc;
 }

@@ -386,3 +386,21 @@ def baq_read(pos, cigar, seq, qual, ref_bytes, extended=True):
     rc = L.orc_baq_read(int(pos), cg.ctypes.data, len(cg), seq.ctypes.data, qual.ctypes.data, len(seq), ref_bytes,
                         len(ref_bytes), 1 if extended else 0, out.ctypes.data)
     return out if rc else None
+
+
+def baq_idaq_read(pos, cigar, seq, qual, ref_bytes, extended=True):
+    """orc_baq_idaq_read -> (lb bytes, ai bytes or None, ad bytes or None)"""
+    ops = "MIDNSHP=X"
+    cg = np.asarray([(l << 4) | ops.index(o) for o, l in cigar], np.uint32)
+    seq = np.ascontiguousarray(seq, np.uint8)
+    qual = np.ascontiguousarray(qual, np.uint8)
+    out = np.zeros(len(seq), np.uint8)
+    iaq = np.zeros(len(seq), np.uint8)
+    daq = np.zeros(len(seq), np.uint8)
+    L = lib()
+    L.orc_baq_idaq_read.restype = C.c_int
+    L.orc_baq_idaq_read.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int64,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_baq_idaq_read(int(pos), cg.ctypes.data, len(cg), seq.ctypes.data, qual.ctypes.data, len(seq), ref_bytes,
+                             len(ref_bytes), 1 if extended else 0, out.ctypes.data, iaq.ctypes.data, daq.ctypes.data)
+    return out, (iaq if rc & 2 else None), (daq if rc & 4 else None)

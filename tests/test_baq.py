@@ -80,3 +80,26 @@ def test_oracle_reproduces_alnqual_lb_tags(oracle, path):
         assert out.tobytes() == r["lb"].tobytes(), (r["pos0"], r["cigar"])
         nbytes += len(out)
     assert nbytes > 10000
+
+
+@pytest.mark.parametrize("path", __import__("golden_util").baq_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_oracle_reproduces_alnqual_ai_ad_tags(oracle, path):
+    """the indel alignment qualities (idaq, bam_md_ext.c:73-248) vs the ai / ad tags of the 2.1.4 binary"""
+    import json
+    import golden_util as gu
+    fx, reads = gu.load_baq(path)
+    raw = json.load(open(path))["reads"]
+    extended = "-e" not in fx["alnqual_args"]
+    genome = fx["genome"].encode()
+    n_tags = 0
+    for r, rr in zip(reads, raw):
+        lb, ai, ad = oracle.baq_idaq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome, extended=extended)
+        assert lb.tobytes() == r["lb"].tobytes()
+        assert (ai is None) == (rr["ai"] is None) and (ad is None) == (rr["ad"] is None), (r["pos0"], r["cigar"])
+        if ai is not None:
+            assert ai.tobytes() == rr["ai"].encode(), (r["pos0"], r["cigar"])
+            n_tags += 1
+        if ad is not None:
+            assert ad.tobytes() == rr["ad"].encode(), (r["pos0"], r["cigar"])
+            n_tags += 1
+    assert n_tags >= 80
