@@ -267,7 +267,10 @@ int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t po
  * then the plain or extended BAQ of every base.  One call = a batch of reads of ONE contig.  The caller
  *  skips unmapped / zero-length reads like the reference (:287-289) and appends
  * lb_out[seq_off[r] .. seq_off[r+1]) as the read's `lb:Z` tag (bytes are BAQ + 33, capped at '~').
- * Indel alignment qualities (idaq, :73-248) are not computed here yet. */
+ * lfq_baq_idaq_batch additionally computes the indel alignment qualities (idaq, :73-248): ai_out / ad_out get the
+ * bytes of the `ai` / `ad` tags ('~' where there is nothing), tag_flags[r] bit 0 / bit 1 say whether read r gets an
+ * ai / ad tag at all (n_ins / n_del > 0, :238-243).  Reads whose bases carry IUPAC ambiguity codes other than N
+ * compare as N in the repeat scan (:197); more than 64 indels or 1024 repeat cells per read are not tracked. */
 typedef struct lfq_baq_reads {
     int64_t n_reads;
     const int32_t *pos;        /* [n]   bam1_core_t.pos (0-based leftmost reference coordinate) */
@@ -280,6 +283,8 @@ typedef struct lfq_baq_reads {
     int64_t ref_len;
 } lfq_baq_reads;
 int lfq_baq_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int baq_extended, uint8_t *lb_out);
+int lfq_baq_idaq_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int baq_extended, uint8_t *lb_out,
+                       uint8_t *ai_out, uint8_t *ad_out, uint8_t *tag_flags);
 
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,

@@ -101,7 +101,7 @@ EXPORTS = [
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
-    "lfq_filter_indel_records", "lfq_baq_batch",
+    "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch",
 ]
 
 _lib = None
@@ -164,6 +164,7 @@ def load():
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.lfq_filter_indel_records.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
     L.lfq_baq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp]
+    L.lfq_baq_idaq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp, vp, vp, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_char_p]

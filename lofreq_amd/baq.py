@@ -19,9 +19,10 @@ def encode_seq(s):
     return _CODE[np.frombuffer(s.encode() if isinstance(s, str) else s, np.uint8)]
 
 
-def baq_batch(caller, reads, ref, extended=True):
+def baq_batch(caller, reads, ref, extended=True, idaq=False):
     """reads: list of dicts {pos0, cigar [(op, len)], seq (codes 0..4), qual (phred)}; ref: the contig (bytes).
-    -> list of uint8 arrays: the `lb` tag bytes (BAQ + 33) of every read."""
+    -> list of uint8 arrays: the `lb` tag bytes (BAQ + 33) of every read; with idaq=True a list of
+    (lb, ai or None, ad or None) per read (indel alignment qualities, `lfq_baq_idaq_batch`)."""
     n = len(reads)
     pos = np.asarray([r["pos0"] for r in reads], np.int32)
     cig_off = np.zeros(n + 1, np.int64)
@@ -48,6 +49,17 @@ def baq_batch(caller, reads, ref, extended=True):
     rd.qual = qual.ctypes.data
     rd.ref = C.cast(C.c_char_p(ref), C.c_void_p)
     rd.ref_len = len(ref)
-    _lib.check(_lib.load().lfq_baq_batch(caller.h, C.byref(rd), 1 if extended else 0, out.ctypes.data),
-               "lfq_baq_batch")
-    return [out[seq_off[i]:seq_off[i + 1]].copy() for i in range(n)]
+    if not idaq:
+        _lib.check(_lib.load().lfq_baq_batch(caller.h, C.byref(rd), 1 if extended else 0, out.ctypes.data),
+                   "lfq_baq_batch")
+        return [out[seq_off[i]:seq_off[i + 1]].copy() for i in range(n)]
+    ai = np.zeros_like(out)
+    ad = np.zeros_like(out)
+    fl = np.zeros(max(n, 1), np.uint8)
+    _lib.check(_lib.load().lfq_baq_idaq_batch(caller.h, C.byref(rd), 1 if extended else 0, out.ctypes.data,
+                                              ai.ctypes.data, ad.ctypes.data, fl.ctypes.data), "lfq_baq_idaq_batch")
+    res = []
+    for i in range(n):
+        a, b = seq_off[i], seq_off[i + 1]
+        res.append((out[a:b].copy(), ai[a:b].copy() if fl[i] & 1 else None, ad[a:b].copy() if fl[i] & 2 else None))
+    return res

@@ -90,7 +90,9 @@ struct lfq_ctx {
     double *d_baq_scr;
     int32_t *d_baq_expect;
     uint8_t *d_baq_tmp8;
-    int64_t baq_scr_bytes, baq_expect_bytes, baq_tmp8_bytes;
+    int32_t *d_baq_itab;
+    double *d_baq_terms;
+    int64_t baq_scr_bytes, baq_expect_bytes, baq_tmp8_bytes, baq_itab_bytes, baq_terms_bytes;
     std::thread *leader;
     std::mutex *lm;
     std::condition_variable *lcv;
@@ -365,6 +367,8 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
         if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);
+        if (c->d_baq_itab) (void)hipFree(c->d_baq_itab);
+        if (c->d_baq_terms) (void)hipFree(c->d_baq_terms);
         if (c->h_tuples) (void)hipHostFree(c->h_tuples);
         if (c->h_nheavy) (void)hipHostFree(c->h_nheavy);
         if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
@@ -1049,6 +1053,13 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
 
 int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t *lb_out)
 {
+    return lfq_baq_idaq_batch(c, rd, baq_extended, lb_out, nullptr, nullptr, nullptr);
+}
+
+int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t *lb_out, uint8_t *ai_out,
+                       uint8_t *ad_out, uint8_t *tag_flags)
+{
+    const bool want_idaq = ai_out && ad_out && tag_flags;
     if (!c || !rd || rd->n_reads < 0 || (rd->n_reads > 0 && (!rd->pos || !rd->cigar_off || !rd->cigar || !rd->seq_off
                                                               || !rd->seq || !rd->qual || !rd->ref || !lb_out))) {
         return LFQ_ERR_INVALID;
@@ -1113,7 +1124,8 @@ int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
     const int64_t o_reads = 0, o_soff = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_cig = o_soff + al((n + 1) * 8),
                   o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_ref = o_qual + al(n_bases),
-                  o_out = o_ref + al(rd->ref_len + 1), o_q2p = o_out + al(n_bases), total = o_q2p + al(1024);
+                  o_out = o_ref + al(rd->ref_len + 1), o_q2p = o_out + al(n_bases), o_ai = o_q2p + al(1024),
+                  o_ad = o_ai + al(n_bases), o_fl = o_ad + al(n_bases), total = o_fl + al(n);
     LFQ_TRY_HIP(hipMalloc((void **)&d_blob, (size_t)total));
     int rc = LFQ_OK;
     auto up = [&](int64_t off, const void *src, int64_t bytes) {
@@ -1128,7 +1140,9 @@ int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t
     up(o_qual, rd->qual, n_bases);
     up(o_ref, rd->ref, rd->ref_len);
     up(o_q2p, h_q2p, 1024);
-    if (rc == LFQ_OK && hipMemsetAsync(d_blob + o_out, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess) {
+    if (rc == LFQ_OK && (hipMemsetAsync(d_blob + o_out, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
+                         || hipMemsetAsync(d_blob + o_ai, '~', (size_t)(o_fl - o_ai), c->stream) != hipSuccess
+                         || hipMemsetAsync(d_blob + o_fl, 0, (size_t)al(n), c->stream) != hipSuccess)) {
         rc = LFQ_ERR_HIP;
     }
     double *d_scr = nullptr;
@@ -1175,6 +1189,15 @@ int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t
         keep(&c->d_baq_scr, &c->baq_scr_bytes, waves * per_wave);
         keep(&c->d_baq_expect, &c->baq_expect_bytes, waves * A.rows * 64 * 4);
         keep(&c->d_baq_tmp8, &c->baq_tmp8_bytes, waves * 2 * A.rows * 64);
+        if (want_idaq) {
+            keep(&c->d_baq_itab, &c->baq_itab_bytes, waves * LFQ_BAQ_MAX_INDELS * 4 * 64 * 4);
+            keep(&c->d_baq_terms, &c->baq_terms_bytes, waves * (int64_t)LFQ_BAQ_MAX_TERMS * 64 * 8);
+            A.itab = c->d_baq_itab;
+            A.terms = c->d_baq_terms;
+            A.ai_out = d_blob + o_ai;
+            A.ad_out = d_blob + o_ad;
+            A.tag_flags = d_blob + o_fl;
+        }
         d_scr = c->d_baq_scr;
         d_expect = c->d_baq_expect;
         d_tmp8 = c->d_baq_tmp8;
@@ -1187,6 +1210,12 @@ int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t
         }
     }
     if (rc == LFQ_OK && hipMemcpyAsync(lb_out, d_blob + o_out, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+        rc = LFQ_ERR_HIP;
+    }
+    if (rc == LFQ_OK && want_idaq
+        && (hipMemcpyAsync(ai_out, d_blob + o_ai, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+            || hipMemcpyAsync(ad_out, d_blob + o_ad, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+            || hipMemcpyAsync(tag_flags, d_blob + o_fl, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) {
         rc = LFQ_ERR_HIP;
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {

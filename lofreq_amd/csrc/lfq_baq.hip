@@ -184,6 +184,84 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         }
     }
 
+    /* ---- indel table for idaq (bam_md_ext.c:95-234): which posterior cells each indel needs ---- */
+    int n_tab = 0, n_ins = 0, n_del = 0;
+    int32_t *itab = A.itab ? A.itab + (size_t)blockIdx.x * LFQ_BAQ_MAX_INDELS * 4 * 64 : nullptr;
+    double *terms = A.terms ? A.terms + (size_t)blockIdx.x * LFQ_BAQ_MAX_TERMS * 64 : nullptr;
+#define IT(e_, f_) itab[((size_t)(e_) * 4 + (f_)) * 64 + lane]
+#define TM(t_) terms[(size_t)(t_) * 64 + lane]
+    uint8_t *ai = A.ai_out ? A.ai_out + s0 : nullptr, *ad = A.ad_out ? A.ad_out + s0 : nullptr;
+    if (itab) {
+        const uint32_t *cg = A.cigar + R.cigar_off;
+        const int xe = R.xb + l_ref;
+        int x = R.pos, y = 0, n_terms = 0;
+        for (int i = 0; i < l_query; i++) {
+            ai[i] = '~';
+            ad[i] = '~';
+        }
+        for (int k = 0; k < R.n_cigar; ++k) {
+            const int op = cg[k] & 0xf, oplen = cg[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                x += oplen; y += oplen;
+            } else if (op == 2) {                   /* deletion; the reference's skips do not advance x (:112-114) */
+                const int rpos = x, qpos = y;
+                if (qpos == 0) continue;
+                if (oplen > 16) continue;
+                n_del += 1;
+                x += oplen;
+                int ref_i = x, rep = 0, rep_i = 0;
+                while (ref_i < xe) {
+                    if (A.ref[ref_i] != A.ref[rpos + rep_i]) break;
+                    rep += 1; ref_i += 1; rep_i += 1;
+                    if (rep_i >= oplen) rep_i = 0;
+                }
+                int nt = rep + 1;
+                if (qpos + nt - 1 > l_query) nt = l_query - qpos + 1;          /* `if (qpos+j > l_qseq) break` */
+                if (n_tab < LFQ_BAQ_MAX_INDELS && n_terms + nt <= LFQ_BAQ_MAX_TERMS) {
+                    IT(n_tab, 0) = (qpos << 1) | 1;                            /* bit 0: deletion */
+                    IT(n_tab, 1) = rpos - R.xb + 1;
+                    IT(n_tab, 2) = nt;
+                    IT(n_tab, 3) = n_terms;
+                    for (int j = 0; j < nt; j++) {
+                        TM(n_terms + j) = -1.;                                 /* "not added" */
+                    }
+                    n_terms += nt;
+                    n_tab += 1;
+                }
+            } else if (op == 1) {                   /* insertion; the skips do not advance y (:181-183) */
+                const int rpos = x, qpos = y;
+                if (oplen > 16) continue;
+                n_ins += 1;
+                if (qpos == 0) continue;
+                y += oplen;
+                int ref_i = x, rep = 0, rep_i = 0;
+                while (ref_i < xe) {
+                    const int b = query[1 + qpos + rep_i];                     /* 0..4 -> seq_nt16_str letter */
+                    if (A.ref[ref_i] != (uint8_t)"ACGTN"[b > 4 ? 4 : b]) break;
+                    rep += 1; ref_i += 1; rep_i += 1;
+                    if (rep_i >= oplen) rep_i = 0;
+                }
+                int nt = rep + 1;
+                if (qpos + nt > l_query) nt = l_query - qpos;                  /* `if (qpos+j+1 > l_qseq) break` */
+                if (nt < 0) nt = 0;
+                if (n_tab < LFQ_BAQ_MAX_INDELS && n_terms + nt <= LFQ_BAQ_MAX_TERMS) {
+                    IT(n_tab, 0) = qpos << 1;
+                    IT(n_tab, 1) = rpos - R.xb;
+                    IT(n_tab, 2) = nt;
+                    IT(n_tab, 3) = n_terms;
+                    for (int j = 0; j < nt; j++) {
+                        TM(n_terms + j) = -1.;
+                    }
+                    n_terms += nt;
+                    n_tab += 1;
+                }
+            } else if (op == 4) {
+                y += oplen;
+            }
+        }
+        A.tag_flags[A.first_read + ridx] = (uint8_t)((n_ins ? 1 : 0) | (n_del ? 2 : 0));
+    }
+
     /* ---- backward (:206-238), with the MAP step of a row (:254-281) as soon as the row exists ---- */
     int cur = 0;
     for (int u = 0; u < Wr; u++) {
@@ -240,6 +318,15 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
             z = (FQ(i, u + 0) * rsi) * BQ(cur, u + 0); if (z > max) max = z, max_k = (k - 1) << 2 | 0; sum += z;
             z = (FQ(i, u + 1) * rsi) * BQ(cur, u + 1); if (z > max) max = z, max_k = (k - 1) << 2 | 1; sum += z;
         }
+        for (int e = 0; e < n_tab; e++) {           /* pd cells of this row that an indel needs (:147-163, :207-224) */
+            const int t0 = IT(e, 0), is_del = t0 & 1, qpos = t0 >> 1;
+            const int j = is_del ? i - qpos : i - qpos - 1;
+            if (j < 0 || j >= IT(e, 2)) continue;
+            const int u = lfq_baq_u(bw, i, IT(e, 1) + j);
+            if (u < 3 || u >= bw2 * 3 + 3) continue;                           /* u_within_limits */
+            const int st = is_del ? 2 : 1;
+            TM(IT(e, 3) + j) = (FQ(i, u + st) * rsi) * BQ(cur, u + st) * SQ(i);
+        }
         max /= sum;
         int qk = (int)(-4.343 * log(1. - max) + .499);
         qk = qk > 100 ? 99 : qk;
@@ -292,6 +379,23 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         const int v = out[i] > 93 ? 93 : out[i];
         out[i] = (uint8_t)(v + 33);
     }
+    /* ---- idaq: sum each indel's terms in the reference's order (j ascending), 1 - sum -> phred char ---- */
+    for (int e = 0; e < n_tab; e++) {
+        const int t0 = IT(e, 0), is_del = t0 & 1, qpos = t0 >> 1, nt = IT(e, 2), off = IT(e, 3);
+        double ap = 0;
+        for (int j = 0; j < nt; j++) {
+            const double t = TM(off + j);
+            if (t >= 0.) {
+                ap += t;
+            }
+        }
+        ap = 1 - ap;
+        const int qv = (ap < 0.0 + 2.220446049250313e-16) ? 126 + 1 : ((int)(-10 * log10(ap)) + 33);   /* :55-56 */
+        const uint8_t ch = (uint8_t)(qv < 33 ? '!' : (qv > 126 ? '~' : qv));
+        (is_del ? ad : ai)[qpos - 1] = ch;
+    }
+#undef IT
+#undef TM
 #undef FQ
 #undef BQ
 #undef SQ

@@ -181,7 +181,14 @@ struct LfqBaqArgs {
     int32_t rows, W;           /* scratch geometry: rows >= max l_qseq + 1, W >= max (2 bw + 1) * 3 + 6 */
     int32_t baq_extended;
     int32_t first_read;        /* reads [first_read, first_read + n_launch) of the arrays */
+    /* indel alignment qualities (idaq, bam_md_ext.c:73-248); all null / 0 = not requested */
+    uint8_t *ai_out, *ad_out;  /* [seq_off[n]] bytes of the ai / ad tags ('~' = nothing) */
+    uint8_t *tag_flags;        /* [n] bit 0: the read gets an ai tag, bit 1: an ad tag */
+    int32_t *itab;             /* per wavefront: [LFQ_BAQ_MAX_INDELS][4][64] kept indels: type|qpos, k0, rep, term offset */
+    double *terms;             /* per wavefront: [LFQ_BAQ_MAX_TERMS][64] posterior terms, summed in the reference's order */
 };
+#define LFQ_BAQ_MAX_INDELS 64
+#define LFQ_BAQ_MAX_TERMS 1024
 int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, void *stream);
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */

@@ -76,3 +76,50 @@ def test_baq_random_reads_vs_oracle(caller, oracle, extended):
 def test_baq_empty(caller):
     import lofreq_amd as la
     assert la.baq_batch(caller, [], b"ACGT") == []
+
+
+@pytest.mark.parametrize("path", gu.baq_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_idaq_golden_ai_ad_tags(caller, path):
+    """indel alignment qualities against the ai / ad tags of the reference's 2.1.4 binary"""
+    import json
+    import lofreq_amd as la
+    fx, reads = gu.load_baq(path)
+    raw = json.load(open(path))["reads"]
+    extended = "-e" not in fx["alnqual_args"]
+    out = la.baq_batch(caller, reads, fx["genome"].encode(), extended=extended, idaq=True)
+    n_tags = 0
+    for r, rr, (lb, ai, ad) in zip(reads, raw, out):
+        assert lb.tobytes() == r["lb"].tobytes()
+        assert (ai is None) == (rr["ai"] is None) and (ad is None) == (rr["ad"] is None), (r["pos0"], r["cigar"])
+        if ai is not None:
+            assert ai.tobytes() == rr["ai"].encode(), (r["pos0"], r["cigar"])
+            n_tags += 1
+        if ad is not None:
+            assert ad.tobytes() == rr["ad"].encode(), (r["pos0"], r["cigar"])
+            n_tags += 1
+    assert n_tags >= 80
+
+
+def test_idaq_random_reads_vs_oracle(caller, oracle):
+    import lofreq_amd as la
+    rng = np.random.default_rng(6)
+    # homopolymer-rich genome so that the repeat scan of idaq (bam_md_ext.c:132-145, 192-205) has work to do
+    genome = "".join(rng.choice(list("ACGT"), 3000))
+    g = list(genome)
+    for p0 in range(30, 2900, 41):
+        g[p0:p0 + int(rng.integers(3, 9))] = g[p0] * 8
+    genome = "".join(g[:3000])
+    reads = _random_reads(rng, genome, 300, 30, 160)
+    out = la.baq_batch(caller, reads, genome.encode(), extended=True, idaq=True)
+    n_tags = 0
+    for r, (lb, ai, ad) in zip(reads, out):
+        elb, eai, ead = oracle.baq_idaq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), True)
+        assert lb.tobytes() == elb.tobytes(), (r["pos0"], r["cigar"])
+        assert (ai is None) == (eai is None) and (ad is None) == (ead is None), (r["pos0"], r["cigar"])
+        if ai is not None:
+            assert ai.tobytes() == eai.tobytes(), (r["pos0"], r["cigar"])
+            n_tags += 1
+        if ad is not None:
+            assert ad.tobytes() == ead.tobytes(), (r["pos0"], r["cigar"])
+            n_tags += 1
+    assert n_tags > 100
