@@ -322,7 +322,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
             ok = hipEventCreate(&c->ev_side[i][s][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][s][1]) == hipSuccess;
         }
     }
-    if (ok) {
+    if (ok && !getenv("LFQ_NO_SB_PRECOMPUTE")) {
         c->heavy_cap = 1 << 16;
         ok = hipHostMalloc((void **)&c->h_tuples, (size_t)c->heavy_cap * 3 * 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess
              && hipHostMalloc((void **)&c->h_nheavy, 64, hipHostMallocMapped) == hipSuccess
@@ -596,10 +596,12 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
             LFQ_DBG_STAGE("big");
         }
         LFQ_TRY_HIP(hipStreamWaitEvent(side1, c->ev_prep, 0));     /* K = 250..252 of the big class lands in class 1 */
-        LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, side1));
-        LFQ_DBG_STAGE("seg mid");
-        LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side1));
-        LFQ_DBG_STAGE("combine mid");
+        if (run_mid || run_big) {
+            LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, side1));
+            LFQ_DBG_STAGE("seg mid");
+            LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side1));
+            LFQ_DBG_STAGE("combine mid");
+        }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], dps));
         if (!skip || !strstr(skip, "light")) {
             const char *lk = getenv("LFQ_LIGHT_KERNEL");

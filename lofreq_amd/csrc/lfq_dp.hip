@@ -661,12 +661,6 @@ __device__ __forceinline__ int lfq_claim(int32_t *head, int n)
     return __builtin_amdgcn_readfirstlane(old);
 }
 
-/* fire-and-forget device-scope add from the calling lane (same reason for inline asm as lfq_claim) */
-__device__ __forceinline__ void lfq_atomic_add_noret(int32_t *p, int v)
-{
-    asm volatile("global_atomic_add %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
-
 /* lanes per light column for this batch: the smallest group that fits 90 % of the light columns (the rest go
  * to the retry kernel); 64 = one column per wavefront (lfq_dp_wave_kernel<1>).  Deep pileups have K ~ depth / 7000
  * per alt base from sequencing errors alone, so the best group size is a property of the batch. */
@@ -849,9 +843,7 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
         }
     }
     __syncthreads();
-    const int lane = lfq_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wave_id = (int)blockIdx.x * 4 + wave;
     const int n_work = W.counters[count_idx];
     /* list layout [light | mid | big] */
     const LfqEntry *list = W.entries + ((base_idx >= 0) ? W.counters[base_idx] : 0);
@@ -865,9 +857,6 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
     int32_t *head = &W.counters[(MAXC == 1) ? LFQ_CNT_HEAD_LIGHT : LFQ_CNT_HEAD_MID];
     for (;;) {
         int b0 = lfq_claim(head, BATCH);
-#ifdef LFQ_TRACE
-        if (lane == 0 && (b0 < n_work + 3)) printf("wave %d MAXC %d claimed %d of %d\n", wave_id, MAXC, b0, n_work);
-#endif
         if (b0 >= n_work) {
             break;
         }
@@ -1258,16 +1247,13 @@ __device__ __noinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_c
 
 /* the strip pipeline of one big column with C cells per lane (C chosen so that the strips fit the
  * workgroup's wavefronts in one pass whenever possible: fewer cells per lane = shorter rows) */
-/* ch0..ch1: the chunk range to run (the whole column, or one row segment of a split column starting from
- * the identity distribution).  seg_out != nullptr: segment mode -- the final cells go to the pool and
- * nothing is emitted; `rec` receives the pruned flag and the row count. */
-template <int C, bool SEG>
+/* ch0..ch1: the chunk range to run (the whole column) */
+template <int C>
 __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_counts *cntp, int kp, unsigned uf_mask,
                                                const double *uf_bound, bool force_fe, double *bnd,
                                                const LfqTracksDev &T, const LfqParams &P, LfqBigShared &sh,
                                                const LfqWork &W, lfq_col_pvals *__restrict__ pvals,
-                                               int64_t pvals_capacity, int64_t ch0, int64_t ch1,
-                                               LfqSegCell *seg_out, LfqLong *rec)
+                                               int64_t pvals_capacity, int64_t ch0, int64_t ch1)
 {
     constexpr int NW = LFQ_HEAVY_WAVES;
     const int lane = lfq_lane();
@@ -1380,30 +1366,19 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
             pruned = true;
         }
         if (!pruned && active) {
-            if (SEG) {
-                lfq_strip_store_cells<C>(S, gl, shift, K, seg_out);
-            } else {
-                lfq_strip_store_logs<C>(S, gl, shift, K, probvec);
-            }
+            lfq_strip_store_logs<C>(S, gl, shift, K, probvec);
         }
         __threadfence_block();
         __syncthreads();
     }
-    if (SEG) {
-        if (w == ((n_strips - 1) % NW) && lane == 0) {
-            if (pruned) {
-                rec->pruned = 1;
-            }
-            lfq_atomic_add_noret(&rec->rows, rows_tail);
-        }
-    } else if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
+    if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
         /* the wave that owned the tail strip finishes the column */
         lfq_emit_pvals(cx, *cntp, probvec, K, !pruned, uf_mask, uf_bound, force_fe, rows_tail, W, pvals,
                        pvals_capacity);
     }
 }
 
-__global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
+__global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
     LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
     LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity, double *__restrict__ scratch,
     int64_t scratch_per_block)
@@ -1422,8 +1397,6 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
         sh.zero_v[threadIdx.x] = 0.0;
         sh.zero_e[threadIdx.x] = 0;
     }
-    const int lane = lfq_lane();
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_unsplit = W.counters[LFQ_CNT_UNSPLIT];
     double *bnd = scratch + (int64_t)blockIdx.x * scratch_per_block;   /* pass boundary: 2 doubles / obs */
 
@@ -1456,14 +1429,14 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, 4) void lfq_dp_big_kernel(
             continue;                   /* already emitted by the prep kernel */
         }
         if (kp < 128 * NW - 1) {
-            lfq_big_column<2, false>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
-                              n_chunks, nullptr, nullptr);
+            lfq_big_column<2>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
+                              n_chunks);
         } else {
             /* 4 cells per lane: up to K = 2044 in one pass; deeper columns run in passes.  (8 cells per
              * lane would halve the passes but doubles the kernel's register footprint, which decides
              * whether these workgroups can be resident beside the light kernel.) */
-            lfq_big_column<4, false>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
-                              n_chunks, nullptr, nullptr);
+            lfq_big_column<4>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
+                              n_chunks);
         }
     }
 }
