@@ -1143,9 +1143,11 @@ __global__ __launch_bounds__(256) void lfq_dp_retry_kernel(LfqTracksDev T, LfqPa
     const int n_work = W.counters[LFQ_CNT_LIGHT];
     const int n_waves_total = (int)gridDim.x * 4;
     LfqRow *rows = s_rows[wave];
-    for (int base = ((int)blockIdx.x * 4 + wave) * 64; base < n_work; base += n_waves_total * 64) {
+    /* 16 list entries per wavefront and pass: flagged columns cluster (deep or noisy stretches), so a fine
+     * interleave balances better than 64-entry blocks */
+    for (int base = ((int)blockIdx.x * 4 + wave) * 16; base < n_work; base += n_waves_total * 16) {
         const int i = base + lane;
-        uint64_t m = __ballot(i < n_work && retry[i] != 0);
+        uint64_t m = __ballot(lane < 16 && i < n_work && retry[i] != 0);
         while (m != 0ull) {
             const int j = __builtin_ctzll(m);
             m &= m - 1ull;
