@@ -318,6 +318,45 @@ def run_baq(name, seed, glen, nreads, sites, mapqs, extra=()):
     print("%s: %d reads, %d with lb, %d bytes" % (name, len(out), sum(1 for r in out if r["lb"]), os.path.getsize(path)))
 
 
+# ---- reads -> VCF chain fixtures: BAQ computed by `lofreq call` itself ---------------------------------------
+
+def run_chain(name, seed, glen, nreads, planted, mapqs, call_args):
+    """all-M reads (base qualities >= 6 so that the 2.1.4 / HEAD raw-count delta cannot show) -> `lofreq call`
+    with its on-the-fly BAQ -> VCF.  The fixture holds the READS, not the columns: the test has to run BAQ,
+    build the pileup and call."""
+    with tempfile.TemporaryDirectory() as tmp:
+        genome = write_fixture(tmp, seed, glen, nreads, planted, mapqs, min_q=6)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
+        res = subprocess.run([LOFREQ, "call", "-f", "t.fa", "-o", "out.vcf"] + call_args + ["t.sam"], cwd=tmp,
+                             check=True, capture_output=True, text=True, env=env)
+        ntests = None
+        for line in res.stderr.splitlines():
+            if "Number of substitution tests performed" in line:
+                ntests = int(line.split(":")[-1])
+        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+        reads = []
+        for line in open(os.path.join(tmp, "t.sam")):
+            if line.startswith("@"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            reads.append([int(f[3]) - 1, int(f[1]), int(f[4]), f[5], f[9], f[10]])
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "call_args": call_args, "genome": genome, "reads": reads, "vcf": vcf, "num_snv_tests": ntests}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d reads, %d vcf records, %s tests, %d bytes" % (name, len(reads), len(vcf), ntests, os.path.getsize(path)))
+
+
+def main_chain():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    planted = {60: ("A", 0.05), 61: ("C", 0.05), 90: ("C", 0.10), 120: ("G", 0.03), 150: ("T", 0.5), 180: ("C", 1.0),
+               200: ("T", 0.07), 230: ("A", 0.02)}
+    run_chain("chain_default", 41, 300, 700, planted, mq_mix, [])
+    run_chain("chain_nofilter", 42, 300, 700, planted, mq_mix, ["--no-default-filter"])
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -332,6 +371,8 @@ def main():
         return main_indels()
     if "--baq-only" in sys.argv:
         return main_baq()
+    if "--chain-only" in sys.argv:
+        return main_chain()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
@@ -349,6 +390,7 @@ def main():
                                                          "--no-default-filter"])
     main_indels()
     main_baq()
+    main_chain()
 
 
 if __name__ == "__main__":

@@ -124,3 +124,7 @@ def load_baq(path):
                       "qual": np.array([ord(c) - 33 for c in r["qual"]], np.uint8),
                       "lb": None if r["lb"] is None else np.frombuffer(r["lb"].encode(), np.uint8)})
     return fx, reads
+
+
+def chain_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "chain_*.json")))
