@@ -286,6 +286,30 @@ int lfq_baq_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int baq_extended, ui
 int lfq_baq_idaq_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int baq_extended, uint8_t *lb_out,
                        uint8_t *ai_out, uint8_t *ad_out, uint8_t *tag_flags);
 
+/* --- device-side pileup: reads -> the packed SNV tracks of a region -------------------------
+ * What compile_plp_col (plp.c:797-1017) builds per column, for all columns of [region_begin, region_end) at once,
+ * directly in HBM in the lfq_tracks layout.  The host has done what mplp_func does per read (plp.c:600-700): flag /
+ * MAPQ filtering, and BAQ (lfq_baq_batch) if wanted.  Columns = the covered positions in order (mpileup yields no
+ * column for a position without alignments); col_pos_out[c] is the reference position of column c.
+ * The returned tracks point into memory owned by the context, valid until the next lfq_pileup_snv_tracks call;
+ * they can be handed straight to lfq_call_snvs_batch(..., tracks_on_device = 1, ...). */
+typedef struct lfq_pileup_reads {
+    int64_t n_reads;
+    const int32_t *pos;        /* [n]   bam1_core_t.pos */
+    const int64_t *cigar_off;  /* [n+1] */
+    const uint32_t *cigar;     /*       BAM encoding */
+    const int64_t *seq_off;    /* [n+1] into seq / qual / baq */
+    const uint8_t *seq;        /*       0..4 */
+    const uint8_t *qual;       /*       phred */
+    const uint8_t *baq;        /*       lb tag bytes (BAQ + 33), or NULL (every BAQ missing) */
+    const uint8_t *mapq;       /* [n]   bam1_core_t.qual */
+    const uint8_t *reverse;    /* [n]   bam_is_rev */
+    const char *ref;           /*       the contig */
+    int64_t ref_len;
+} lfq_pileup_reads;
+int lfq_pileup_snv_tracks(lfq_ctx *ctx, const lfq_pileup_reads *reads, int64_t region_begin, int64_t region_end,
+                          int min_plp_bq, lfq_tracks *tracks_out, int64_t *col_pos_out);
+
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,
                        const int32_t *coverage_plp_or_null, const uint8_t *ref_base,

@@ -54,6 +54,11 @@ class BaqReads(C.Structure):
         "pos", "cigar_off", "cigar", "seq_off", "seq", "qual", "ref")] + [("ref_len", C.c_int64)]
 
 
+class PileupReads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "pos", "cigar_off", "cigar", "seq_off", "seq", "qual", "baq", "mapq", "reverse", "ref")] + [("ref_len", C.c_int64)]
+
+
 class IndelSide(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "non_fw", "non_rv", "ne_off", "ne_q", "ne_mq", "ev_off", "key_off", "key_chars", "ev_fw", "ev_rv",
@@ -101,7 +106,7 @@ EXPORTS = [
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
-    "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch",
+    "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
 ]
 
 _lib = None
@@ -165,6 +170,7 @@ def load():
     L.lfq_filter_indel_records.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
     L.lfq_baq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp]
     L.lfq_baq_idaq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp, vp, vp, vp]
+    L.lfq_pileup_snv_tracks.argtypes = [vp, C.POINTER(PileupReads), C.c_int64, C.c_int64, C.c_int, C.POINTER(Tracks), vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_char_p]

@@ -86,6 +86,7 @@ struct lfq_ctx {
     int32_t *h_nheavy, *d_nheavy_mapped;
     int heavy_cap;
     hipEvent_t ev_heavy;
+    uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     /* BAQ scratch (lfq_baq_batch), kept between calls */
     double *d_baq_scr;
     int32_t *d_baq_expect;
@@ -364,6 +365,8 @@ void lfq_destroy(lfq_ctx *c)
         c->leader = nullptr;
     }
     if (c) {
+        if (c->d_plp_in) (void)hipFree(c->d_plp_in);
+        if (c->d_plp_out) (void)hipFree(c->d_plp_out);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
         if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);
@@ -1225,6 +1228,129 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
     }
     (void)hipFree(d_blob);
     return rc;
+}
+
+int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region_begin, int64_t region_end,
+                          int min_plp_bq, lfq_tracks *out, int64_t *col_pos_out)
+{
+    if (!c || !rd || !out || region_end < region_begin || rd->n_reads < 0
+        || (rd->n_reads > 0 && (!rd->pos || !rd->cigar_off || !rd->cigar || !rd->seq_off || !rd->seq || !rd->qual
+                                || !rd->mapq || !rd->reverse || !rd->ref))) {
+        return LFQ_ERR_INVALID;
+    }
+    memset(out, 0, sizeof(*out));
+    const int64_t n = rd->n_reads, width = region_end - region_begin;
+    if (n == 0 || width == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    /* inputs + per-position counters in one allocation (kept until the next call) */
+    const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
+                  o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_baq = o_qual + al(n_bases),
+                  o_mq = o_baq + al(n_bases), o_rev = o_mq + al(n), o_cov = o_rev + al(n), o_nb = o_cov + al(width * 4),
+                  o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4), total = o_cidx + al(width * 4);
+    if (c->d_plp_in) (void)hipFree(c->d_plp_in);
+    c->d_plp_in = nullptr;
+    LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_in, (size_t)total));
+    uint8_t *d = c->d_plp_in;
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_pos, rd->pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_coff, rd->cigar_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_soff, rd->seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_cig, rd->cigar, (size_t)n_cig * 4, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_seq, rd->seq, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_qual, rd->qual, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
+    if (rd->baq) {
+        LFQ_TRY_HIP(hipMemcpyAsync(d + o_baq, rd->baq, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
+    }
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_mq, rd->mapq, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_rev, rd->reverse, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), c->stream));
+    LfqPileupArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n_reads = n;
+    A.pos = (const int32_t *)(d + o_pos);
+    A.cigar_off = (const int64_t *)(d + o_coff);
+    A.seq_off = (const int64_t *)(d + o_soff);
+    A.cigar = (const uint32_t *)(d + o_cig);
+    A.seq = d + o_seq;
+    A.qual = d + o_qual;
+    A.baq = rd->baq ? d + o_baq : nullptr;
+    A.mapq = d + o_mq;
+    A.reverse = d + o_rev;
+    A.begin = region_begin;
+    A.width = width;
+    A.min_plp_bq = min_plp_bq;
+    A.cov = (int32_t *)(d + o_cov);
+    A.nb = (int32_t *)(d + o_nb);
+    A.cursor = (int32_t *)(d + o_cur);
+    LFQ_TRY(lfq_launch_pileup_count(A, c->stream));
+    /* prefix sums on the host: 8 bytes per reference position of the region, once per region */
+    std::vector<int32_t> cov((size_t)width), nb((size_t)width), cidx((size_t)width, -1);
+    LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(nb.data(), A.nb, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> off(1, 0);
+    std::vector<int32_t> h_cov, h_nb;
+    std::vector<uint8_t> h_ref;
+    int64_t max_obs = 0;
+    for (int64_t p = 0; p < width; p++) {
+        if (cov[(size_t)p] <= 0) {
+            continue;
+        }
+        cidx[(size_t)p] = (int32_t)h_cov.size();
+        if (col_pos_out) {
+            col_pos_out[h_cov.size()] = region_begin + p;
+        }
+        h_cov.push_back(cov[(size_t)p]);
+        h_nb.push_back(nb[(size_t)p]);
+        const int64_t gp = region_begin + p;
+        char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';           /* plp.c:818-823 */
+        if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
+            rb = 'N';
+        }
+        h_ref.push_back((uint8_t)rb);
+        off.push_back(off.back() + (uint64_t)nb[(size_t)p]);
+        max_obs = std::max<int64_t>(max_obs, nb[(size_t)p]);
+    }
+    const int64_t ncols = (int64_t)h_cov.size();
+    const int64_t n_obs = (int64_t)off.back(), trk = al(n_obs + 32);
+    const int64_t t_off = 0, t_ref = t_off + al((ncols + 1) * 8), t_cov = t_ref + al(ncols + 16), t_nb = t_cov + al(ncols * 4 + 16),
+                  t_nt = t_nb + al(ncols * 4 + 16), t_bq = t_nt + trk, t_baq = t_bq + trk, t_mq = t_baq + trk,
+                  t_total = t_mq + trk;
+    if (c->d_plp_out) (void)hipFree(c->d_plp_out);
+    c->d_plp_out = nullptr;
+    LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_out, (size_t)t_total));
+    uint8_t *t = c->d_plp_out;
+    LFQ_TRY_HIP(hipMemsetAsync(t + t_nt, 0, (size_t)(t_total - t_nt), c->stream));     /* the 16-byte tails are read */
+    LFQ_TRY_HIP(hipMemcpyAsync(t + t_off, off.data(), (size_t)(ncols + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (ncols > 0) {
+        LFQ_TRY_HIP(hipMemcpyAsync(t + t_ref, h_ref.data(), (size_t)ncols, hipMemcpyHostToDevice, c->stream));
+        LFQ_TRY_HIP(hipMemcpyAsync(t + t_cov, h_cov.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
+        LFQ_TRY_HIP(hipMemcpyAsync(t + t_nb, h_nb.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_cidx, cidx.data(), (size_t)width * 4, hipMemcpyHostToDevice, c->stream));
+    A.col_index = (const int32_t *)(d + o_cidx);
+    A.col_off = (const uint64_t *)(t + t_off);
+    A.t_nt = t + t_nt;
+    A.t_bq = t + t_bq;
+    A.t_baq = t + t_baq;
+    A.t_mq = t + t_mq;
+    LFQ_TRY(lfq_launch_pileup_scatter(A, c->stream));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    out->nt = t + t_nt;
+    out->bq = t + t_bq;
+    out->baq = t + t_baq;
+    out->mq = t + t_mq;
+    out->sq = nullptr;
+    out->col_off = (const uint64_t *)(t + t_off);
+    out->ref_base = t + t_ref;
+    out->coverage_plp = (const int32_t *)(t + t_cov);
+    out->num_bases = (const int32_t *)(t + t_nb);
+    out->ncols = ncols;
+    out->max_col_obs = max_obs;
+    return LFQ_OK;
 }
 
 int lfq_synth_fill_device(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t plant_period, int64_t col_begin,

@@ -191,6 +191,24 @@ struct LfqBaqArgs {
 #define LFQ_BAQ_MAX_TERMS 1024
 int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, void *stream);
 
+/* ---- device-side pileup (lfq_pileup.hip) ------------------------------------------------------------------ */
+struct LfqPileupArgs {
+    int64_t n_reads;
+    const int32_t *pos;
+    const int64_t *cigar_off, *seq_off;
+    const uint32_t *cigar;
+    const uint8_t *seq, *qual, *baq;      /* baq: lb tag bytes (BAQ + 33) or null */
+    const uint8_t *mapq, *reverse;        /* [n] */
+    int64_t begin, width;                 /* region [begin, begin + width) */
+    int32_t min_plp_bq;
+    int32_t *cov, *nb, *cursor;           /* [width] per reference position */
+    const int32_t *col_index;             /* [width] position -> column (covered positions only) */
+    const uint64_t *col_off;              /* [ncols + 1] */
+    uint8_t *t_nt, *t_bq, *t_baq, *t_mq;  /* packed tracks */
+};
+int lfq_launch_pileup_count(const LfqPileupArgs &a, void *stream);
+int lfq_launch_pileup_scatter(const LfqPileupArgs &a, void *stream);
+
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
 int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, int32_t *tuples_mapped,
                             int32_t *n_mapped, int cap_entries, int min_alt, void *stream);

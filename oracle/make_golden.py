@@ -77,8 +77,8 @@ def parse_plpsummary(text):
 
 
 def enc(vals):
-    """phred list -> compact ASCII (value+33; -1 -> '~')"""
-    return "".join("~" if v < 0 else chr(33 + v) for v in vals)
+    """phred list -> compact ASCII (value + 33; -1 -> ' ', which no value maps to: 93 + 33 is '~')"""
+    return "".join(" " if v < 0 else chr(33 + v) for v in vals)
 
 
 def run(name, seed, glen, nreads, planted, mapqs, call_args):
@@ -357,6 +357,44 @@ def main_chain():
     run_chain("chain_nofilter", 42, 300, 700, planted, mq_mix, ["--no-default-filter"])
 
 
+def run_pileup(name, seed, glen, nreads, sites, mapqs):
+    """reads with indels + their lb tags (alnqual) and the binary's own column dump (plpsummary) of the same BAM"""
+    with tempfile.TemporaryDirectory() as tmp:
+        genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        with open(os.path.join(tmp, "t.aq.bam"), "wb") as f:
+            subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
+        sam = subprocess.run([LOFREQ, "alnqual", "t.sam", "t.fa"], cwd=tmp, check=True, capture_output=True,
+                             text=True).stdout
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", "t.aq.bam"], cwd=tmp, check=True, capture_output=True,
+                             text=True).stdout
+    out = []
+    for line in sam.splitlines():
+        if line.startswith("@"):
+            continue
+        f = line.split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        out.append([int(f[3]) - 1, int(f[1]), int(f[4]), f[5], f[9], f[10], tags.get("lb")])
+    cols = []
+    for c in parse_plpsummary(plp):
+        o = {}
+        for nt, tr in c["obs"].items():
+            o[nt] = {"bq": enc(tr.get("BQ", [])), "baq": enc(tr["BAQ"]) if "BAQ" in tr else None, "mq": tr.get("MQ", [])}
+        cols.append({"pos0": c["pos0"], "ref": c["ref"], "fwrv": c["fwrv"], "obs": o})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "genome": genome, "reads": out, "columns": cols}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d reads, %d columns, %d bytes" % (name, len(out), len(cols), os.path.getsize(path)))
+
+
+def main_pileup():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
+             190: [("+", "A", 0.5)], 240: [("-", 12, 0.3)]}
+    run_pileup("pileup_indels", 51, 330, 300, sites, mq_mix)
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -373,6 +411,8 @@ def main():
         return main_baq()
     if "--chain-only" in sys.argv:
         return main_chain()
+    if "--pileup-only" in sys.argv:
+        return main_pileup()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
@@ -391,6 +431,7 @@ def main():
     main_indels()
     main_baq()
     main_chain()
+    main_pileup()
 
 
 if __name__ == "__main__":

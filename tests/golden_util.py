@@ -35,7 +35,7 @@ def load_indels(path):
 
 
 def dec(s):
-    return np.array([(-1 if ch == "~" else ord(ch) - 33) for ch in s], dtype=np.int64)
+    return np.array([(-1 if ch == " " else ord(ch) - 33) for ch in s], dtype=np.int64)
 
 
 def load(path):
@@ -128,3 +128,7 @@ def load_baq(path):
 
 def chain_fixtures():
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, "chain_*.json")))
+
+
+def pileup_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "pileup_*.json")))

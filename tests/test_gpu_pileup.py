@@ -1,0 +1,81 @@
+"""-m gpu: the device-side pileup (lfq_pileup_snv_tracks) against the reference binary's own column dump
+(`lofreq plpsummary`) of the same reads, incl. insertions, deletions and low base qualities."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+
+
+def _fetch(ptr, nbytes):
+    """device memory at a raw pointer -> numpy (through torch's allocator-free path: hipMemcpy via ctypes)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    out = np.zeros(nbytes, np.uint8)
+    assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0   # DeviceToHost
+    return out
+
+
+@pytest.mark.parametrize("path", gu.pileup_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_pileup_matches_plpsummary(caller, path):
+    import lofreq_amd as la
+    fx = json.load(open(path))
+    reads = [{"pos0": r[0], "cigar": gu.parse_cigar(r[3]), "seq": la.encode_seq(r[4]),
+              "qual": np.array([ord(c) - 33 for c in r[5]], np.uint8), "mapq": r[2], "reverse": bool(r[1] & 16)}
+             for r in fx["reads"]]
+    lb = [np.frombuffer(r[6].encode(), np.uint8) for r in fx["reads"]]
+    glen = len(fx["genome"])
+    dt = la.pileup_snv_tracks(caller, reads, fx["genome"].encode(), 0, glen, lb=lb, min_plp_bq=3)
+    t = dt._tracks()
+    ncols = dt.ncols
+    off = _fetch(t.col_off, (ncols + 1) * 8).view(np.uint64)
+    n_obs = int(off[-1])
+    nt, bq, baq, mq = (_fetch(p, n_obs) for p in (t.nt, t.bq, t.baq, t.mq))
+    ref = _fetch(t.ref_base, ncols)
+    exp = {c["pos0"]: c for c in fx["columns"]}
+    assert ncols >= len(exp)
+    checked = 0
+    for ci in range(ncols):
+        p0 = int(dt.col_pos[ci])
+        a, b = int(off[ci]), int(off[ci + 1])
+        e = exp.get(p0)
+        if e is None:               # plpsummary prints nothing for columns without a single base (all deleted)
+            assert a == b
+            continue
+        assert chr(ref[ci]) == e["ref"]
+        for code, letter in enumerate("ACGTN"):
+            sel = (nt[a:b] & 7) == code
+            o = e["obs"].get(letter)
+            got = sorted(zip(bq[a:b][sel].tolist(), baq[a:b][sel].tolist(), mq[a:b][sel].tolist()))
+            want = [] if not o else sorted(zip(gu.dec(o["bq"]).tolist(),
+                                               [(255 if v < 0 else v) for v in gu.dec(o["baq"]).tolist()], o["mq"]))
+            assert got == want, (p0, letter)
+            fw = int((sel & ((nt[a:b] & 8) == 0)).sum())
+            assert [fw, int(sel.sum()) - fw] == e["fwrv"][letter], (p0, letter)
+            checked += len(got)
+    assert checked > 20000
+
+
+def test_pileup_then_call_device_resident(caller, oracle):
+    """the tracks stay in HBM: pileup -> lfq_call_snvs_batch(tracks_on_device) gives the same records as packing
+    the same columns on the host"""
+    import lofreq_amd as la
+    import util
+    fx = json.load(open(gu.chain_fixtures()[0]))
+    reads = [{"pos0": r[0], "cigar": gu.parse_cigar(r[3]), "seq": la.encode_seq(r[4]),
+              "qual": np.array([ord(c) - 33 for c in r[5]], np.uint8), "mapq": r[2], "reverse": bool(r[1] & 16)}
+             for r in fx["reads"]]
+    lb = la.baq_batch(caller, reads, fx["genome"].encode(), extended=True)
+    dt = la.pileup_snv_tracks(caller, reads, fx["genome"].encode(), 0, len(fx["genome"]), lb=lb)
+    conf = la.VarcallConf()
+    recs, _, st = caller.call_snvs(dt, conf)
+    assert conf.num_snv_tests == fx["num_snv_tests"]
+    thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
+    keep = la.filter_records(recs, thr, apply_defaults=True)
+    pos0 = np.array([dt.col_pos[int(r["col"])] for r in recs], np.int64)
+    text = la.format_vcf(recs, "chr1", pos0=pos0, keep=keep, filter_str="PASS")
+    assert [gu.strip_hqa(l) for l in text.splitlines()] == fx["vcf"]
