@@ -35,3 +35,19 @@ dt=time.perf_counter()-t0
 print("cpu oracle (1 thread, via ctypes): %d reads in %.2f s -> %.0f reads/s"%(m,dt,m/dt))
 assert o.tobytes()==out[(m-1)*rl:m*rl].tobytes()
 print("last sample read identical to the GPU result")
+
+# ---- device-side pileup of the same reads (lb from the GPU BAQ), then the call, tracks resident in HBM
+lb = out
+mapq = np.full(n, 60, np.uint8); rev = (rng.random(n) < 0.5).astype(np.uint8)
+pr = _lib.PileupReads(); pr.n_reads = n; pr.pos = pos.ctypes.data; pr.cigar_off = cig_off.ctypes.data; pr.cigar = cig.ctypes.data
+pr.seq_off = seq_off.ctypes.data; pr.seq = seqf.ctypes.data; pr.qual = qualf.ctypes.data; pr.baq = lb.ctypes.data
+pr.mapq = mapq.ctypes.data; pr.reverse = rev.ctypes.data; pr.ref = C.cast(C.c_char_p(gen_ascii), C.c_void_p); pr.ref_len = glen
+t = _lib.Tracks(); col_pos = np.zeros(glen, np.int64)
+for it in range(3):
+    t0 = time.perf_counter(); rc = L.lfq_pileup_snv_tracks(caller.h, C.byref(pr), 0, glen, 3, C.byref(t), col_pos.ctypes.data); dt = time.perf_counter() - t0
+    print("pileup: %d reads -> %d columns, %.1f M observations in %.3f s (%.1f M reads/s, host buffers in), rc %d" % (n, t.ncols, n * rl / 1e6, dt, n / dt / 1e6, rc))
+from lofreq_amd.pileup import DeviceTracks
+dtk = DeviceTracks(t, col_pos[: t.ncols].copy())
+conf = la.VarcallConf()
+t0 = time.perf_counter(); recs, _, st = caller.call_snvs(dtk, conf, records_capacity=1 << 16); dt = time.perf_counter() - t0
+print("call on the resident tracks: %d columns, %d tested, %d records in %.4f s" % (dtk.ncols, st.n_tested, len(recs), dt))
