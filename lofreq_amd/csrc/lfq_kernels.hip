@@ -262,10 +262,11 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
     __shared__ uint32_t s_hist[4][128];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
-    /* one column per wavefront; with a grid smaller than the batch (persistent launch, lfq_launch_count) a
-     * wavefront walks the columns with the grid's stride */
-    const int64_t col_stride = (int64_t)gridDim.x * 4;
-    for (int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave; col < c1; col += col_stride) {
+    /* one column per wavefront (a persistent, looping form was measured: fewer waves in flight, slower) */
+    const int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave;
+    if (col >= c1) {
+        return;
+    }
     const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
     const int64_t n_obs = (int64_t)(off1 - off0);
     const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
@@ -385,10 +386,40 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         }
     }
 
-    if (lane == 0) {
-        lfq_count_emit(r, raw, fw, filt, ref_code, out, flags, col);
+    if (lane == 0) {        /* (same block as lfq_count_emit; a call with array arguments costs this kernel registers and LDS) */
+        uint8_t flag = 0;
+        if (!r.gated) {
+            /* the three non-reference nucleotides in A,C,G,T order (snpcaller.c:391-397) */
+            const int x0 = (ref_code == 0) ? 1 : 0;
+            const int x1 = (ref_code <= 1) ? 2 : 1;
+            const int x2 = (ref_code <= 2) ? 3 : 2;
+#define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
+            r.ref_fw = (int)LFQ_PICK(fw, ref_code);
+            r.ref_rv = (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code));
+            r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
+            r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
+            r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
+            r.alt_raw_counts[0] = (int)LFQ_PICK(raw, x0);
+            r.alt_raw_counts[1] = (int)LFQ_PICK(raw, x1);
+            r.alt_raw_counts[2] = (int)LFQ_PICK(raw, x2);
+            r.alt_fw[0] = (int)LFQ_PICK(fw, x0);
+            r.alt_fw[1] = (int)LFQ_PICK(fw, x1);
+            r.alt_fw[2] = (int)LFQ_PICK(fw, x2);
+#undef LFQ_PICK
+            r.n_err_probs = (int)(filt[0] + filt[1] + filt[2] + filt[3]);
+            const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
+            r.kmax = kmax;
+            r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
+            /* scheduling class.  Columns whose alt count is far above what sequencing errors explain
+             * (~ n/1000 at Q30) almost surely run the full recurrence: they go to the long-column
+             * kernel even when K < 64, so that the light kernel only sees quick exits. */
+            const int suspicious = max(12, r.n_err_probs / 512 + 8);
+            flag = (uint8_t)((r.tested ? 1 : 0)
+                             | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
+        }
+        out[col] = r;
+        flags[col] = flag;
     }
-    }   /* column loop */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -566,13 +597,23 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
         }
         W.tested_prefix[c] = (int32_t)(carry_in + ex.t);   /* inclusive, batch-wide */
     }
+    /* one set of global atomics per workgroup (per wavefront they contend: +0.1 ms on a 1 M column batch) */
+    __shared__ uint32_t s_k[3];
+    if (threadIdx.x < 3) {
+        s_k[threadIdx.x] = 0;
+    }
+    __syncthreads();
     kle7 = lfq_wave_sum_u32(kle7);
     kle15 = lfq_wave_sum_u32(kle15);
     kle31 = lfq_wave_sum_u32(kle31);
     if (lfq_lane() == 0 && kle31) {
-        atomicAdd(&W.counters[LFQ_CNT_KLE7], (int)kle7);
-        atomicAdd(&W.counters[LFQ_CNT_KLE15], (int)kle15);
-        atomicAdd(&W.counters[LFQ_CNT_KLE31], (int)kle31);
+        atomicAdd(&s_k[0], kle7);
+        atomicAdd(&s_k[1], kle15);
+        atomicAdd(&s_k[2], kle31);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_k[2]) {
+        atomicAdd(&W.counters[LFQ_CNT_KLE7 + (int)threadIdx.x], (int)s_k[threadIdx.x]);
     }
 }
 
@@ -679,13 +720,7 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         LFQ_HIP_TRY(hipGetLastError());
         return LFQ_OK;
     }
-    unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
-    if (const char *e = getenv("LFQ_COUNT_BLOCKS")) {           /* experiments: persistent launch of that many workgroups */
-        const long b = atol(e);
-        if (b > 0 && (unsigned long)b < blocks) {
-            blocks = (unsigned)b;
-        }
-    }
+    const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
     hipLaunchKernelGGL(lfq_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
                        d_counts, d_flags, c0, c1);
     LFQ_HIP_TRY(hipGetLastError());
