@@ -179,6 +179,9 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                # frac prices SURVEY 8(d)'s 4 bytes per observation; the kernel only has to READ 2 of them, so
+                # frac can exceed 1.  traffic_frac is the real HBM utilisation: measured bytes / duration / peak.
+                "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and dom_ms > 0 else None,
                 "count_kernel": {
                     "avg_launch_ms": kt["ms_count"] / n_launch,
                     "achieved": alg_bytes / (kt["ms_count"] / n_launch * 1e-3) / 1e9 if kt["ms_count"] > 0 else 0.0,

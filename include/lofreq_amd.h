@@ -59,7 +59,8 @@ typedef enum lfq_status {
  *   bq   base quality, 0..93 (plp.c:937-953)
  *   baq  base alignment quality 0..93; 255 = missing (-1, plp.c:956-962).  NULL track = BAQ off.
  *   mq   mapping quality as in the BAM record, 0..255 (255 = NA is handled as snpcaller.c:451 does)
- *   sq   source quality 0..254; 255 = missing (-1).  NULL track = no source quality.
+ *   sq   source quality 0..253; 254 = anything larger (source_qual's 49314: probability 0.0); 255 = missing (-1).
+ *        NULL track = no source quality.
  * Track base pointers must be 16-byte aligned and readable up to the next multiple of 16 bytes
  * past col_off[ncols]; col_off itself may be arbitrary (columns need not be aligned).
  */
@@ -306,9 +307,24 @@ typedef struct lfq_pileup_reads {
     const uint8_t *reverse;    /* [n]   bam_is_rev */
     const char *ref;           /*       the contig */
     int64_t ref_len;
+    const uint8_t *sq;         /* [n]   source quality byte of the read (lfq_source_qual_batch), or NULL: no sq track */
 } lfq_pileup_reads;
 int lfq_pileup_snv_tracks(lfq_ctx *ctx, const lfq_pileup_reads *reads, int64_t region_begin, int64_t region_end,
                           int min_plp_bq, lfq_tracks *tracks_out, int64_t *col_pos_out);
+
+/* --- source quality: the per-read pre-step of `lofreq call -s` -------------------------
+ * source_qual (plp.c:427-593) over count_cigar_ops (samutils.c:437-614) for a batch of reads of one contig (same
+ * read layout as lfq_baq_batch; the reference letters are compared as given, the caller upper-cases the contig
+ * like mplp_func does, plp.c:652).  def_nm_q: -T/--def-nm-q (>= 0 replaces EVERY operation's quality, :500-504;
+ * -1 = off); min_bq: the reference passes DEFAULT_MIN_BQ = 6 (plp.c:728); ign_or_null: one byte per reference
+ * position, != 0 where the -S/--ign-vcf list has a variant (var_in_ign_list, plp.c:305-323).
+ * sq_out[r] = what source_qual returns: -1 (nothing to count), 49314 (at most one non-match) or
+ * (int)(-10 log10l(1 - P)) (INT32_MIN when P rounds to 1, as the x86-64 build yields); mplp_func stores
+ * max(sq, 0) in the read's `sq` tag (plp.c:731-734).  sq_byte_or_null[r] gets the byte the packed sq track takes:
+ * min(max(sq, 0), 254) -- every value above 3240 is the probability 0.0 in PHREDQUAL_TO_PROB, and source_qual
+ * yields nothing between 160 and 49314. */
+int lfq_source_qual_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int def_nm_q, int min_bq,
+                          const uint8_t *ign_or_null, int32_t *sq_out, uint8_t *sq_byte_or_null);
 
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,

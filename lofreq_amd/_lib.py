@@ -56,7 +56,8 @@ class BaqReads(C.Structure):
 
 class PileupReads(C.Structure):
     _fields_ = [("n_reads", C.c_int64)] + [(n, C.c_void_p) for n in (
-        "pos", "cigar_off", "cigar", "seq_off", "seq", "qual", "baq", "mapq", "reverse", "ref")] + [("ref_len", C.c_int64)]
+        "pos", "cigar_off", "cigar", "seq_off", "seq", "qual", "baq", "mapq", "reverse", "ref")] + [("ref_len", C.c_int64),
+                                                                                              ("sq", C.c_void_p)]
 
 
 class IndelSide(C.Structure):
@@ -107,6 +108,7 @@ EXPORTS = [
     "lfq_synth_fill_device", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
+    "lfq_source_qual_batch",
 ]
 
 _lib = None
@@ -171,6 +173,7 @@ def load():
     L.lfq_baq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp]
     L.lfq_baq_idaq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp, vp, vp, vp]
     L.lfq_pileup_snv_tracks.argtypes = [vp, C.POINTER(PileupReads), C.c_int64, C.c_int64, C.c_int, C.POINTER(Tracks), vp]
+    L.lfq_source_qual_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, C.c_int, vp, vp, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_char_p]

@@ -212,6 +212,7 @@ void fill_luts(LfqLuts *L)
     }
     L->baq[255] = 0.0;      /* -1: missing (snpcaller.c:321-322) */
     L->sq[255] = 0.0;       /* snpcaller.c:307-308 */
+    L->sq[254] = 0.0;       /* source_qual's PROB_TO_PHREDQUAL(LDBL_MIN) = 49314 (plp.c:521): pow(10, -4931.4) == 0.0 */
     L->mq[255] = 0.0;       /* MQ 255 = NA -> -1 (snpcaller.c:451-453, 313-314) */
     L->mq[0] = 0.5;         /* MQ0_ERRPROB (snpcaller.c:64, 315-316) */
 }
@@ -1249,7 +1250,8 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     /* inputs + per-position counters in one allocation (kept until the next call) */
     const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
                   o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_baq = o_qual + al(n_bases),
-                  o_mq = o_baq + al(n_bases), o_rev = o_mq + al(n), o_cov = o_rev + al(n), o_nb = o_cov + al(width * 4),
+                  o_mq = o_baq + al(n_bases), o_rev = o_mq + al(n), o_sq = o_rev + al(n), o_cov = o_sq + al(n),
+                  o_nb = o_cov + al(width * 4),
                   o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4), total = o_cidx + al(width * 4);
     if (c->d_plp_in) (void)hipFree(c->d_plp_in);
     c->d_plp_in = nullptr;
@@ -1266,6 +1268,9 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     }
     LFQ_TRY_HIP(hipMemcpyAsync(d + o_mq, rd->mapq, (size_t)n, hipMemcpyHostToDevice, c->stream));
     LFQ_TRY_HIP(hipMemcpyAsync(d + o_rev, rd->reverse, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (rd->sq) {
+        LFQ_TRY_HIP(hipMemcpyAsync(d + o_sq, rd->sq, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
     LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), c->stream));
     LfqPileupArgs A;
     memset(&A, 0, sizeof(A));
@@ -1279,6 +1284,7 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     A.baq = rd->baq ? d + o_baq : nullptr;
     A.mapq = d + o_mq;
     A.reverse = d + o_rev;
+    A.sq = rd->sq ? d + o_sq : nullptr;
     A.begin = region_begin;
     A.width = width;
     A.min_plp_bq = min_plp_bq;
@@ -1318,7 +1324,7 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     const int64_t n_obs = (int64_t)off.back(), trk = al(n_obs + 32);
     const int64_t t_off = 0, t_ref = t_off + al((ncols + 1) * 8), t_cov = t_ref + al(ncols + 16), t_nb = t_cov + al(ncols * 4 + 16),
                   t_nt = t_nb + al(ncols * 4 + 16), t_bq = t_nt + trk, t_baq = t_bq + trk, t_mq = t_baq + trk,
-                  t_total = t_mq + trk;
+                  t_sq = t_mq + trk, t_total = t_sq + (rd->sq ? trk : 0);
     if (c->d_plp_out) (void)hipFree(c->d_plp_out);
     c->d_plp_out = nullptr;
     LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_out, (size_t)t_total));
@@ -1337,19 +1343,122 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     A.t_bq = t + t_bq;
     A.t_baq = t + t_baq;
     A.t_mq = t + t_mq;
+    A.t_sq = rd->sq ? t + t_sq : nullptr;
     LFQ_TRY(lfq_launch_pileup_scatter(A, c->stream));
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
     out->nt = t + t_nt;
     out->bq = t + t_bq;
     out->baq = t + t_baq;
     out->mq = t + t_mq;
-    out->sq = nullptr;
+    out->sq = rd->sq ? t + t_sq : nullptr;
     out->col_off = (const uint64_t *)(t + t_off);
     out->ref_base = t + t_ref;
     out->coverage_plp = (const int32_t *)(t + t_cov);
     out->num_bases = (const int32_t *)(t + t_nb);
     out->ncols = ncols;
     out->max_col_obs = max_obs;
+    return LFQ_OK;
+}
+
+/* source_qual for a batch of reads (plp.c:427-593): counting + DP on the device, phred conversion here */
+int lfq_source_qual_batch(lfq_ctx *c, const lfq_baq_reads *rd, int def_nm_q, int min_bq, const uint8_t *ign,
+                          int32_t *sq_out, uint8_t *sq_byte)
+{
+    if (!c || !rd || !sq_out || rd->n_reads < 0 || def_nm_q > 255
+        || (rd->n_reads > 0 && (!rd->pos || !rd->cigar_off || !rd->cigar || !rd->seq_off || !rd->seq || !rd->qual
+                                || !rd->ref))) {
+        return LFQ_ERR_INVALID;
+    }
+    const int64_t n = rd->n_reads;
+    if (n == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
+    int64_t max_ops = 0;                                /* bound of K: one operation per base or CIGAR element */
+    for (int64_t r = 0; r < n; r++) {
+        max_ops = std::max<int64_t>(max_ops, (rd->seq_off[r + 1] - rd->seq_off[r]) + (rd->cigar_off[r + 1] - rd->cigar_off[r]));
+    }
+    const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)c->n_cu * 2));
+    const int64_t scratch_cells = max_ops + 1 > LFQ_SRCQ_LDS_CELLS ? max_ops + 1 : 0;
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
+                  o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_ref = o_qual + al(n_bases),
+                  o_ign = o_ref + al(rd->ref_len), o_prob = o_ign + (ign ? al(rd->ref_len) : 0), o_st = o_prob + al(n * 8),
+                  o_scr = o_st + al(n), total = o_scr + (int64_t)n_blocks * 4 * 2 * scratch_cells * 8;
+    uint8_t *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)total) != hipSuccess) {
+        return LFQ_ERR_NOMEM;
+    }
+    int rc = LFQ_OK;
+    std::vector<double> prob((size_t)n);
+    std::vector<uint8_t> st((size_t)n);
+    auto up = [&](int64_t off, const void *src, int64_t bytes) {
+        if (rc == LFQ_OK && bytes > 0 && hipMemcpyAsync(d + off, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
+    };
+    up(o_pos, rd->pos, n * 4);
+    up(o_coff, rd->cigar_off, (n + 1) * 8);
+    up(o_soff, rd->seq_off, (n + 1) * 8);
+    up(o_cig, rd->cigar, n_cig * 4);
+    up(o_seq, rd->seq, n_bases);
+    up(o_qual, rd->qual, n_bases);
+    up(o_ref, rd->ref, rd->ref_len);
+    if (ign) {
+        up(o_ign, ign, rd->ref_len);
+    }
+    if (rc == LFQ_OK) {
+        LfqSrcqArgs A;
+        memset(&A, 0, sizeof(A));
+        A.n_reads = n;
+        A.pos = (const int32_t *)(d + o_pos);
+        A.cigar_off = (const int64_t *)(d + o_coff);
+        A.seq_off = (const int64_t *)(d + o_soff);
+        A.cigar = (const uint32_t *)(d + o_cig);
+        A.seq = d + o_seq;
+        A.qual = d + o_qual;
+        A.ref = (const char *)(d + o_ref);
+        A.ref_len = rd->ref_len;
+        A.ign = ign ? d + o_ign : nullptr;
+        A.nonmatch_qual = def_nm_q;
+        A.min_bq = min_bq;
+        A.scratch = scratch_cells ? (double *)(d + o_scr) : nullptr;
+        A.scratch_cells = scratch_cells;
+        A.prob = (double *)(d + o_prob);
+        A.status = d + o_st;
+        rc = lfq_launch_srcq(A, c->d_luts, n_blocks, c->stream);
+    }
+    if (rc == LFQ_OK
+        && (hipMemcpyAsync(prob.data(), d + o_prob, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+            || hipMemcpyAsync(st.data(), d + o_st, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) {
+        rc = LFQ_ERR_HIP;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
+        rc = LFQ_ERR_HIP;
+    }
+    (void)hipFree(d);
+    if (rc != LFQ_OK) {
+        return rc;
+    }
+    const int perfect = (int)(-10.0L * log10l(LDBL_MIN));       /* PROB_TO_PHREDQUAL(LDBL_MIN) = 49314, plp.c:521 */
+    for (int64_t r = 0; r < n; r++) {
+        int q;
+        if (st[(size_t)r] == LFQ_SRCQ_NA) {
+            q = -1;
+        } else if (st[(size_t)r] == LFQ_SRCQ_PERFECT) {
+            q = perfect;
+        } else {
+            const double x = 1.0 - prob[(size_t)r];             /* PROB_TO_PHREDQUAL(1.0 - src_prob), plp.c:567 */
+            /* log10l(0) = -inf and a negative argument gives NaN: the x86-64 long double -> int conversion
+             * of either is INT_MIN ("integer indefinite"); mplp_func then stores 0 */
+            q = (x > 0.0) ? (int)(-10.0L * log10l((long double)x)) : INT32_MIN;
+        }
+        sq_out[r] = q;
+        if (sq_byte) {
+            sq_byte[r] = (uint8_t)(q < 0 ? 0 : (q > 254 ? 254 : q));
+        }
+    }
     return LFQ_OK;
 }
 

@@ -205,8 +205,33 @@ struct LfqPileupArgs {
     const int32_t *col_index;             /* [width] position -> column (covered positions only) */
     const uint64_t *col_off;              /* [ncols + 1] */
     uint8_t *t_nt, *t_bq, *t_baq, *t_mq;  /* packed tracks */
+    const uint8_t *sq;                    /* [n] per-read source quality byte or null */
+    uint8_t *t_sq;
 };
 int lfq_launch_pileup_count(const LfqPileupArgs &a, void *stream);
+
+/* source quality (lfq_srcq.hip) */
+#define LFQ_DBL_EPSILON 2.220446049250313e-16
+#define LFQ_SRCQ_LDS_CELLS 768      /* K below this: the DP cells of a read live in LDS, else in its scratch slice */
+#define LFQ_SRCQ_NA 0               /* count_cigar_ops found nothing: source_qual returns -1 */
+#define LFQ_SRCQ_PERFECT 1          /* at most one non-match: PROB_TO_PHREDQUAL(LDBL_MIN) */
+#define LFQ_SRCQ_VALUE 2            /* prob[r] = P(X = K - 1) of the row poissbin stopped at */
+struct LfqSrcqArgs {
+    int64_t n_reads;
+    const int32_t *pos;
+    const int64_t *cigar_off, *seq_off;
+    const uint32_t *cigar;
+    const uint8_t *seq, *qual;
+    const char *ref;
+    int64_t ref_len;
+    const uint8_t *ign;                 /* [ref_len] or null */
+    int32_t nonmatch_qual, min_bq;
+    double *scratch;                    /* 2 * scratch_cells doubles per wavefront of the launch, or null */
+    int64_t scratch_cells;
+    double *prob;                       /* [n] */
+    uint8_t *status;                    /* [n] */
+};
+int lfq_launch_srcq(const LfqSrcqArgs &a, const LfqLuts *d_luts, int n_blocks, void *stream);
 int lfq_launch_pileup_scatter(const LfqPileupArgs &a, void *stream);
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(256) void lfq_pileup_scatter_kernel(LfqPileupArgs A
                     A.t_bq[slot] = (uint8_t)(bq > 93 ? 93 : bq);                       /* plp.c:948-952 */
                     A.t_baq[slot] = lb ? (uint8_t)(lb[y + j] >= 33 ? lb[y + j] - 33 : 255) : (uint8_t)255;
                     A.t_mq[slot] = (uint8_t)mq;
+                    if (A.t_sq) {
+                        A.t_sq[slot] = A.sq[r];                                         /* plp.c:975-977 */
+                    }
                 }
             }
             x += l; y += l;

@@ -23,9 +23,10 @@ class DeviceTracks:
         return self._t
 
 
-def pileup_snv_tracks(caller, reads, ref, begin, end, lb=None, min_plp_bq=3):
+def pileup_snv_tracks(caller, reads, ref, begin, end, lb=None, min_plp_bq=3, sq=None):
     """reads: list of dicts {pos0, cigar [(op, len)], seq (codes 0..4), qual (phred), mapq, reverse};
-    lb: list of the reads' lb tag bytes (from baq_batch) or None.  -> DeviceTracks"""
+    lb: list of the reads' lb tag bytes (from baq_batch) or None; sq: the reads' source-quality bytes (second
+    result of source_qual_batch) or None.  -> DeviceTracks"""
     n = len(reads)
     pos = np.asarray([r["pos0"] for r in reads], np.int32)
     cig_off = np.zeros(n + 1, np.int64)
@@ -57,6 +58,10 @@ def pileup_snv_tracks(caller, reads, ref, begin, end, lb=None, min_plp_bq=3):
     rd.reverse = rev.ctypes.data
     rd.ref = C.cast(C.c_char_p(ref), C.c_void_p)
     rd.ref_len = len(ref)
+    if sq is not None:
+        sq = np.ascontiguousarray(sq, np.uint8)
+        assert len(sq) == n
+        rd.sq = sq.ctypes.data
     t = _lib.Tracks()
     col_pos = np.zeros(max(end - begin, 1), np.int64)
     _lib.check(_lib.load().lfq_pileup_snv_tracks(caller.h, C.byref(rd), int(begin), int(end), int(min_plp_bq),

@@ -395,6 +395,9 @@ int orc_col_errprobs(double *ep, int *n_ep, int alt_base[3], int alt_counts[3], 
             }
             if ((conf->flag & ORC_USE_SQ) && sq) {          /* :461-463 */
                 q_src = orc_unpack_q(sq[j]);
+                if (q_src == 254) {                         /* packed track: 254 = source_qual's 49314 (plp.c:521) */
+                    q_src = 49314;
+                }
             }
             p_joint = orc_merge_quals(q_src, q_map, q_aln, q_base);   /* :465 */
             q_joint = orc_prob_to_phred_safe(p_joint);                /* :466 */
@@ -1343,4 +1346,127 @@ int orc_baq_idaq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t
     }
     free(bq); free(r); free(q); free(state);
     return rc;
+}
+
+/* ---- source quality ---------------------------------------------------------------------
+ * orc_count_cigar_ops restates count_cigar_ops (samutils.c:437-614), orc_source_qual restates source_qual
+ * (plp.c:427-593) as mplp_func calls it (plp.c:727-730; the caller then stores max(sq, 0) in the `sq` tag).
+ * Pinned against the SQ track printed by the 2.1.4 binary's `lofreq plpsummary -s` (tests/golden/srcq_*.json).
+ * seq holds codes 0..4 (A,C,G,T, anything else): seq_nt16_str of the BAM base is compared with the reference
+ * letter as is (:486-489), so an N base matches an N reference; other IUPAC letters are taken as N here.
+ * ign (optional): one byte per reference position, != 0 where the -S/--ign-vcf list holds a variant
+ * (var_in_ign_list, plp.c:305-323, keyed by chrom and pos only). */
+#define ORC_INDEL_QUAL_DEFAULT 45                                   /* samutils.c:51 */
+
+int orc_count_cigar_ops(int counts[4], int *quals[4], int pos, const uint32_t *cigar, int n_cigar,
+                        const uint8_t *seq, const uint8_t *qual, const char *ref, int64_t ref_len, int min_bq,
+                        const uint8_t *ign)
+{
+    int64_t tpos = pos;
+    int qpos = 0, k, i, num_ops = 0;
+    memset(counts, 0, 4 * sizeof(int));
+    for (k = 0; k < n_cigar; ++k) {                                 /* :472 */
+        const int op = cigar[k] & 0xf;
+        const int64_t l = cigar[k] >> 4;
+        if (op == 0 || op == 8) {                                   /* BAM_CMATCH, BAM_CDIFF :481 */
+            int64_t t;
+            for (t = tpos; t < tpos + l; t++) {
+                const char ref_nt = (t >= 0 && t < ref_len) ? ref[t] : '\0';
+                const char read_nt = "ACGTN"[seq[qpos] > 4 ? 4 : seq[qpos]];
+                const int bq = qual[qpos];
+                const int actual = (ref_nt != read_nt || op == 8) ? 1 : 0;      /* :489-493 */
+                if (bq < min_bq) {                                  /* :496-502 */
+                    qpos += 1;
+                    continue;
+                }
+                if (ign && actual == 1 && t >= 0 && t < ref_len && ign[t]) {    /* :505-519 */
+                    qpos += 1;
+                    continue;
+                }
+                counts[actual] += 1;
+                if (quals) {
+                    quals[actual][counts[actual] - 1] = bq;
+                }
+                qpos += 1;
+            }
+            tpos += l;
+        } else if (op == 1 || op == 2) {                            /* BAM_CINS, BAM_CDEL :533 */
+            const int64_t vpos = op == 1 ? tpos - 1 : tpos;         /* :542-545 */
+            if (ign && vpos >= 0 && vpos < ref_len && ign[vpos]) {  /* :547-555 */
+                if (op == 1) {
+                    qpos += (int)l;
+                }
+                continue;                                           /* NB a skipped deletion does not advance tpos */
+            }
+            if (op == 1) {
+                counts[2] += 1;                                     /* one operation per indel :563 */
+                if (quals) {
+                    quals[2][counts[2] - 1] = ORC_INDEL_QUAL_DEFAULT;
+                }
+                qpos += (int)l;
+            } else {
+                counts[3] += 1;
+                if (quals) {
+                    quals[3][counts[3] - 1] = ORC_INDEL_QUAL_DEFAULT;
+                }
+                tpos += l;
+            }
+        } else if (op == 3) {                                       /* BAM_CREF_SKIP :581 */
+            tpos += l;
+        } else if (op == 4) {                                       /* BAM_CSOFT_CLIP :584 */
+            qpos += (int)l;
+        }                                                           /* H, P, =: nothing moves (:590-593) */
+    }
+    for (i = 0; i < 4; i++) {
+        num_ops += counts[i];
+    }
+    return num_ops;
+}
+
+int orc_source_qual(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, const uint8_t *qual, int l_qseq,
+                    const char *ref, int64_t ref_len, int nonmatch_qual, int min_bq, const uint8_t *ign)
+{
+    int counts[4], *quals[4], i, j, n_ep, idx = 0, nonmatch = 0, src_qual = -1;
+    double *ep = NULL, *probvec, src_prob;
+    long double unused;
+    for (i = 0; i < 4; i++) {
+        quals[i] = (int *)malloc((size_t)(l_qseq + n_cigar + 1) * sizeof(int));
+    }
+    n_ep = orc_count_cigar_ops(counts, quals, pos, cigar, n_cigar, seq, qual, ref, ref_len, min_bq, ign);
+    if (n_ep < 1) {                                                 /* :468-474 */
+        goto done;
+    }
+    ep = (double *)malloc((size_t)n_ep * sizeof(double));
+    for (i = 0; i < 4; i++) {                                       /* :486-509 */
+        if (i != 0) {
+            nonmatch += counts[i];
+        }
+        for (j = 0; j < counts[i]; j++) {
+            const int q = nonmatch_qual >= 0 ? nonmatch_qual : quals[i][j];     /* every category, :500-504 */
+            ep[idx++] = orc_phred_to_prob(q);
+        }
+    }
+    if (nonmatch > 0) {                                             /* :514-516 */
+        nonmatch -= 1;
+    }
+    if (nonmatch == 0) {                                            /* :517-524 */
+        src_qual = orc_prob_to_phred(LDBL_MIN);
+        goto done;
+    }
+    qsort(ep, (size_t)n_ep, sizeof(double), orc_dbl_cmp);           /* :551 */
+    probvec = orc_poissbin(&unused, ep, n_ep, nonmatch, 1, 0.05, NULL);         /* :552-553, bonf 1.0 -> 1 */
+    errno = 0;                                                      /* :555-564 */
+    feclearexcept(FE_ALL_EXCEPT);
+    src_prob = exp(probvec[nonmatch - 1]);
+    if (errno || fetestexcept(FE_INVALID | FE_DIVBYZERO | FE_OVERFLOW | FE_UNDERFLOW)) {
+        src_prob = src_prob < DBL_EPSILON ? DBL_MIN : DBL_MAX;
+    }
+    free(probvec);
+    src_qual = orc_prob_to_phred(1.0 - src_prob);                   /* :567 */
+done:
+    for (i = 0; i < 4; i++) {
+        free(quals[i]);
+    }
+    free(ep);
+    return src_qual;
 }

@@ -395,6 +395,104 @@ def main_pileup():
     run_pileup("pileup_indels", 51, 330, 300, sites, mq_mix)
 
 
+# ---- source quality fixtures: per-read sq as seen through the binary's own column dump (plpsummary -s) -----
+
+def write_srcq_fixture(tmp, seed, glen, nreads, sites, mapqs):
+    """the indel reads of write_indel_fixture with read-specific mismatch rates (0 .. 25 %), base qualities down to
+    2 (below source_qual's min_bq 6), occasional soft clips and N bases"""
+    genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.004)
+    rng = np.random.default_rng(seed + 1000)
+    out = []
+    for (pos, flag, mapq, cg, sq, q, bi, bd) in reads:
+        rate = float(rng.choice([0.0] * 14 + [0.01, 0.03, 0.08, 0.25]))
+        seq = list(sq)
+        qual = [ord(c) - 33 for c in q]
+        if "I" not in cg and "D" not in cg:         # planted SNVs (reads without indels: offsets are direct)
+            for p0, alt, frac in ((50, "A", 0.3), (85, "C", 0.4), (120, "G", 0.5), (160, "T", 0.3), (210, "C", 0.2),
+                                  (211, "G", 0.2), (275, "A", 0.6)):
+                if pos <= p0 < pos + len(seq) and rng.random() < frac:
+                    seq[p0 - pos] = alt if genome[p0] != alt else "T"
+        for j in range(len(seq)):
+            if rng.random() < rate:
+                seq[j] = str(rng.choice([c for c in "ACGTN" if c != seq[j]]))
+            if rng.random() < 0.1:
+                qual[j] = int(rng.integers(2, 20))
+        if rng.random() < 0.2:
+            k = int(rng.integers(1, 6))
+            seq = list(rng.choice(list("ACGT"), k)) + seq
+            qual = [int(x) for x in rng.integers(10, 40, k)] + qual
+            cg = "%dS" % k + cg
+        if rng.random() < 0.2:
+            k = int(rng.integers(1, 6))
+            seq = seq + list(rng.choice(list("ACGT"), k))
+            qual = qual + [int(x) for x in rng.integers(10, 40, k)]
+            cg = cg + "%dS" % k
+        out.append((pos, flag, mapq, cg, "".join(seq), "".join(chr(33 + x) for x in qual)))
+    with open(os.path.join(tmp, "t.sam"), "w") as f:
+        f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % glen)
+        for i, (pos, flag, mapq, cg, sq, q) in enumerate(out):
+            f.write("r%d\t%d\tchr1\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\n" % (i, flag, pos + 1, mapq, cg, sq, q))
+    return genome, out
+
+
+def enc_mq(vals):
+    return "".join("%02x" % v for v in vals)
+
+
+def run_srcq(name, seed, glen, nreads, sites, mapqs, extra=(), ign=()):
+    """`lofreq plpsummary -s -B`: BQ / MQ / SQ of every column; `lofreq call -s -B`: the VCF with the source
+    quality merged in (snpcaller.c:303-341).  ign: 0-based positions written to a VCF for -S/--ign-vcf."""
+    with tempfile.TemporaryDirectory() as tmp:
+        genome, reads = write_srcq_fixture(tmp, seed, glen, nreads, sites, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        sargs = ["-s"] + list(extra)
+        if ign:
+            with open(os.path.join(tmp, "ign.vcf"), "w") as f:
+                f.write("##fileformat=VCFv4.0\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+                for p0 in ign:
+                    f.write("chr1\t%d\t.\t%s\t%s\t100\tPASS\tDP=10\n" % (p0 + 1, genome[p0], "A" if genome[p0] != "A" else "C"))
+            sargs += ["-S", "ign.vcf"]
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", "-B"] + sargs + ["t.sam"], cwd=tmp, check=True,
+                             capture_output=True, text=True).stdout
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
+        # source quality is harsh (every read with two or more non-matches counts as a near-certain error), so
+        # that nothing is significant at the defaults: fixed Bonferroni factor 1 and sig 0.9 give records to compare
+        call_args = ["--no-default-filter", "-b", "1", "-a", "0.9"]
+        res = subprocess.run([LOFREQ, "call", "-f", "t.fa", "-B", "-o", "out.vcf"] + call_args + sargs + ["t.sam"],
+                             cwd=tmp, check=True, capture_output=True, text=True, env=env)
+        ntests = None
+        for line in res.stderr.splitlines():
+            if "Number of substitution tests performed" in line:
+                ntests = int(line.split(":")[-1])
+        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+    cols = []
+    for c in parse_plpsummary(plp):
+        o = {}
+        for nt, tr in c["obs"].items():
+            o[nt] = {"bq": enc(tr.get("BQ", [])), "mq": enc_mq(tr.get("MQ", [])),
+                     "sq": enc([-1 if v > 253 else v for v in tr.get("SQ", [])])}
+        cols.append({"pos0": c["pos0"], "ref": c["ref"], "fwrv": c["fwrv"], "obs": o})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "args": sargs, "call_args": call_args, "ign": list(ign), "genome": genome,
+           "encoding": "bq / sq: chr(33 + value), sq ' ' = 49314 (PROB_TO_PHREDQUAL(LDBL_MIN)); mq: 2 hex digits",
+           "reads": [[r[0], r[1], r[2], r[3], r[4], r[5]] for r in reads], "columns": cols, "vcf": vcf,
+           "num_snv_tests": ntests}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    nsq = sorted({v for c in cols for o in c["obs"].values() for v in o["sq"]})
+    print("%s: %d reads, %d columns, %d vcf records, %d bytes; distinct SQ: %s" % (name, len(reads), len(cols), len(vcf),
+                                                                                   os.path.getsize(path), nsq[:40]))
+
+
+def main_srcq():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
+             190: [("+", "A", 0.5)], 240: [("-", 12, 0.3)]}
+    run_srcq("srcq_default", 61, 330, 220, sites, mq_mix)
+    run_srcq("srcq_ign_nmq", 62, 330, 220, sites, mq_mix, extra=("-T", "20"), ign=(70, 99, 100, 150, 189, 190, 240))
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -413,6 +511,8 @@ def main():
         return main_chain()
     if "--pileup-only" in sys.argv:
         return main_pileup()
+    if "--srcq-only" in sys.argv:
+        return main_srcq()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]

@@ -404,3 +404,21 @@ def baq_idaq_read(pos, cigar, seq, qual, ref_bytes, extended=True):
     rc = L.orc_baq_idaq_read(int(pos), cg.ctypes.data, len(cg), seq.ctypes.data, qual.ctypes.data, len(seq), ref_bytes,
                              len(ref_bytes), 1 if extended else 0, out.ctypes.data, iaq.ctypes.data, daq.ctypes.data)
     return out, (iaq if rc & 2 else None), (daq if rc & 4 else None)
+
+
+def source_qual(pos, cigar, seq, qual, ref_bytes, nonmatch_qual=-1, min_bq=6, ign=None):
+    """orc_source_qual (plp.c:427-593): cigar = list of (op_char, len); seq = codes 0..4; ign = uint8 mask over
+    the reference or None -> what source_qual() returns (mplp_func stores max(., 0) in the sq tag)"""
+    ops = "MIDNSHP=X"
+    cg = np.asarray([(l << 4) | ops.index(o) for o, l in cigar], np.uint32)
+    seq = np.ascontiguousarray(seq, np.uint8)
+    qual = np.ascontiguousarray(qual, np.uint8)
+    L = lib()
+    L.orc_source_qual.restype = C.c_int
+    L.orc_source_qual.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int64,
+                                  C.c_int, C.c_int, C.c_void_p]
+    if ign is not None:
+        ign = np.ascontiguousarray(ign, np.uint8)
+    return L.orc_source_qual(int(pos), cg.ctypes.data, len(cg), seq.ctypes.data, qual.ctypes.data, len(seq),
+                             ref_bytes, len(ref_bytes), int(nonmatch_qual), int(min_bq),
+                             ign.ctypes.data if ign is not None else None)

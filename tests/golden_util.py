@@ -94,6 +94,12 @@ def conf_kwargs(call_args):
             kw["min_alt_bq"] = int(next(it))
         elif a == "-a":
             kw["sig"] = float(next(it))
+        elif a == "-s":
+            flag |= 4
+        elif a == "-T":
+            next(it)                        # def_nm_q belongs to the per-read source quality, not to varcall_conf
+        elif a == "-S":
+            next(it)
         else:
             raise ValueError(a)
     kw["flag"] = flag
@@ -132,3 +138,42 @@ def chain_fixtures():
 
 def pileup_fixtures():
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, "pileup_*.json")))
+
+
+def srcq_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "srcq_*.json")))
+
+
+def load_srcq(path):
+    """-> (fixture, reads as dicts for the batch APIs, def_nm_q, ign mask over the genome or None)"""
+    fx = json.load(open(path))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    reads = [{"pos0": r[0], "cigar": parse_cigar(r[3]), "seq": np.array([code.get(c, 4) for c in r[4]], np.uint8),
+              "qual": np.array([ord(c) - 33 for c in r[5]], np.uint8), "mapq": r[2], "reverse": bool(r[1] & 16)}
+             for r in fx["reads"]]
+    nmq = int(fx["args"][fx["args"].index("-T") + 1]) if "-T" in fx["args"] else -1
+    ign = None
+    if fx["ign"]:
+        ign = np.zeros(len(fx["genome"]), np.uint8)
+        ign[fx["ign"]] = 1
+    return fx, reads, nmq, ign
+
+
+def py_pileup(reads, min_plp_bq=3):
+    """plain restatement of which (read, qpos) land in which column / nucleotide list, in pileup order
+    (compile_plp_col, plp.c:905-960): -> {pos0: {letter: [(read index, qpos), ...]}}"""
+    cols = {}
+    for ri, r in enumerate(reads):
+        x, y = r["pos0"], 0
+        for op, l in r["cigar"]:
+            if op in "M=X":
+                for i in range(l):
+                    if r["qual"][y + i] >= min_plp_bq:
+                        cols.setdefault(x + i, {}).setdefault("ACGTN"[r["seq"][y + i]], []).append((ri, y + i))
+                x += l
+                y += l
+            elif op in "IS":
+                y += l
+            elif op in "DN":
+                x += l
+    return cols
