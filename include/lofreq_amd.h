@@ -312,6 +312,26 @@ typedef struct lfq_pileup_reads {
 int lfq_pileup_snv_tracks(lfq_ctx *ctx, const lfq_pileup_reads *reads, int64_t region_begin, int64_t region_end,
                           int min_plp_bq, lfq_tracks *tracks_out, int64_t *col_pos_out);
 
+/* The indel fields of compile_plp_col (plp.c:1019-1192) for the same reads: per column (= covered position, the
+ * same column numbering as lfq_pileup_snv_tracks) coverage_plp, num_tails, num_non_indels / num_ins / num_dels,
+ * hrun (get_hrun, plp.c:744-787), per side the strand counts and -- at columns with at least one event, the only
+ * ones call_indels reads them for -- the ins_quals / del_quals arrays of the reads without such an event, and
+ * the event tables (key, strands, per-read qualities) in the reference's order (first appearance; reads in pileup
+ * order).  Pileup entries follow htslib's resolve_cigar2: an entry inside a deletion / reference skip takes the
+ * qualities at the query position of the next base; the indel of an entry is the I / D operation following the
+ * last position of its CIGAR operation.  Entries with BI or BD below min_plp_idq are ignored (plp.c:1062).
+ * *cols_out points into memory owned by the context, valid until the next lfq_pileup_indel_columns call; it goes
+ * straight into lfq_call_indels_batch. */
+typedef struct lfq_pileup_indel_tags {
+    const uint8_t *bi, *bd;    /* per base (seq_off layout): BI / BD tag bytes (quality + 33); NULL = tag absent (quality 0) */
+    const uint8_t *ai, *ad;    /* per base: ai / ad tag bytes (lfq_baq_idaq_batch); NULL = absent (-1) */
+    const uint8_t *tag_flags;  /* [n] bit 0..3: read has BI / BD / ai / ad; NULL = every read has every non-NULL array */
+    const int32_t *sq;         /* [n] source quality of the read or NULL (-1) */
+} lfq_pileup_indel_tags;
+int lfq_pileup_indel_columns(lfq_ctx *ctx, const lfq_pileup_reads *reads, const lfq_pileup_indel_tags *tags_or_null,
+                             int64_t region_begin, int64_t region_end, int min_plp_idq,
+                             const lfq_indel_columns **cols_out, int64_t *col_pos_out);
+
 /* --- source quality: the per-read pre-step of `lofreq call -s` -------------------------
  * source_qual (plp.c:427-593) over count_cigar_ops (samutils.c:437-614) for a batch of reads of one contig (same
  * read layout as lfq_baq_batch; the reference letters are compared as given, the caller upper-cases the contig

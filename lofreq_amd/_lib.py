@@ -60,6 +60,10 @@ class PileupReads(C.Structure):
                                                                                               ("sq", C.c_void_p)]
 
 
+class PileupIndelTags(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("bi", "bd", "ai", "ad", "tag_flags", "sq")]
+
+
 class IndelSide(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "non_fw", "non_rv", "ne_off", "ne_q", "ne_mq", "ev_off", "key_off", "key_chars", "ev_fw", "ev_rv",
@@ -108,7 +112,7 @@ EXPORTS = [
     "lfq_synth_fill_device", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
-    "lfq_source_qual_batch",
+    "lfq_source_qual_batch", "lfq_pileup_indel_columns",
 ]
 
 _lib = None
@@ -173,6 +177,8 @@ def load():
     L.lfq_baq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp]
     L.lfq_baq_idaq_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, vp, vp, vp, vp]
     L.lfq_pileup_snv_tracks.argtypes = [vp, C.POINTER(PileupReads), C.c_int64, C.c_int64, C.c_int, C.POINTER(Tracks), vp]
+    L.lfq_pileup_indel_columns.argtypes = [vp, C.POINTER(PileupReads), C.POINTER(PileupIndelTags), C.c_int64, C.c_int64,
+                                           C.c_int, C.POINTER(C.POINTER(IndelColumnsC)), vp]
     L.lfq_source_qual_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, C.c_int, vp, vp, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -7,6 +7,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <ctype.h>
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -16,6 +17,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -37,6 +39,19 @@
             return rc_;             \
         }                           \
     } while (0)
+
+/* the columns handed out by lfq_pileup_indel_columns live here until the next call */
+struct LfqIndelColsOwned {
+    lfq_indel_columns cols;
+    std::vector<uint8_t> ref_base;
+    std::vector<int32_t> cov, tails, non_indels, n_ins, n_dels, hrun;
+    struct Side {
+        std::vector<int32_t> non_fw, non_rv, ev_fw, ev_rv;
+        std::vector<int64_t> ne_off, ev_off, key_off, rd_off;
+        std::vector<int16_t> ne_q, ne_mq, rd_q, rd_aq, rd_mq, rd_sq;
+        std::vector<char> key_chars;
+    } side[2];
+};
 
 struct lfq_ctx {
     int device;
@@ -87,6 +102,7 @@ struct lfq_ctx {
     int heavy_cap;
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
+    LfqIndelColsOwned *plp_indel;
     /* BAQ scratch (lfq_baq_batch), kept between calls */
     double *d_baq_scr;
     int32_t *d_baq_expect;
@@ -368,6 +384,7 @@ void lfq_destroy(lfq_ctx *c)
     if (c) {
         if (c->d_plp_in) (void)hipFree(c->d_plp_in);
         if (c->d_plp_out) (void)hipFree(c->d_plp_out);
+        delete c->plp_indel;
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
         if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);
@@ -1357,6 +1374,366 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     out->num_bases = (const int32_t *)(t + t_nb);
     out->ncols = ncols;
     out->max_col_obs = max_obs;
+    return LFQ_OK;
+}
+
+/* compile_plp_col's indel fields for the reads of a region (plp.c:1019-1192): the sparse part (which read carries
+ * which insertion / deletion where: straight from the CIGARs) is assembled here, the dense part (counts over all
+ * pileup entries and the quality arrays of the reads WITHOUT an event at the event columns) by lfq_plp_indel_kernel */
+int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_indel_tags *tg,
+                             int64_t region_begin, int64_t region_end, int min_plp_idq,
+                             const lfq_indel_columns **cols_out, int64_t *col_pos_out)
+{
+    if (!c || !rd || !cols_out || region_end < region_begin || rd->n_reads < 0
+        || (rd->n_reads > 0 && (!rd->pos || !rd->cigar_off || !rd->cigar || !rd->seq_off || !rd->seq || !rd->mapq
+                                || !rd->reverse || !rd->ref))) {
+        return LFQ_ERR_INVALID;
+    }
+    delete c->plp_indel;
+    c->plp_indel = new LfqIndelColsOwned();
+    LfqIndelColsOwned &O = *c->plp_indel;
+    memset(&O.cols, 0, sizeof(O.cols));
+    *cols_out = &O.cols;
+    const int64_t n = rd->n_reads, width = region_end - region_begin;
+    const uint8_t *t_bi = tg ? tg->bi : nullptr, *t_bd = tg ? tg->bd : nullptr, *t_ai = tg ? tg->ai : nullptr,
+                  *t_ad = tg ? tg->ad : nullptr, *t_fl = tg ? tg->tag_flags : nullptr;
+    const int32_t *t_sq = tg ? tg->sq : nullptr;
+
+    /* 1. events from the CIGARs, in read (= pileup) order */
+    struct Ev { int64_t pos; int64_t read; int32_t qpos, indel; };
+    std::vector<Ev> evs;
+    for (int64_t r = 0; r < n; r++) {
+        const uint32_t *cg = rd->cigar + rd->cigar_off[r];
+        const int n_cigar = (int)(rd->cigar_off[r + 1] - rd->cigar_off[r]);
+        const int64_t s0 = rd->seq_off[r];
+        const int l_qseq = (int)(rd->seq_off[r + 1] - s0);
+        const uint32_t fl = t_fl ? t_fl[r] : 15u;
+        int64_t x = rd->pos[r];
+        int y = 0;
+        for (int k = 0; k < n_cigar; ++k) {
+            const int op = cg[k] & 0xf, l = cg[k] >> 4;
+            if (op == 0 || op == 7 || op == 8 || op == 2 || op == 3) {
+                const bool is_del = op == 2 || op == 3;
+                int indel = 0;                                      /* htslib resolve_cigar2: peek at the next operation */
+                if (l > 0 && k + 1 < n_cigar) {
+                    const int op2 = cg[k + 1] & 0xf, l2 = cg[k + 1] >> 4;
+                    if (op2 == 2) {
+                        indel = -l2;
+                    } else if (op2 == 1) {
+                        indel = l2;
+                    } else if (op2 == 6 && k + 2 < n_cigar) {
+                        int l3 = 0;
+                        for (int kk = k + 2; kk < n_cigar; ++kk) {
+                            const int o3 = cg[kk] & 0xf;
+                            if (o3 == 1) {
+                                l3 += cg[kk] >> 4;
+                            } else if (o3 == 2 || o3 == 0 || o3 == 3 || o3 == 7 || o3 == 8) {
+                                break;
+                            }
+                        }
+                        indel = l3 > 0 ? l3 : 0;
+                    }
+                }
+                const int64_t p = x + l - 1;
+                if (indel != 0 && p >= region_begin && p < region_end) {
+                    int qpos = is_del ? y : y + l - 1;
+                    qpos = qpos < l_qseq ? qpos : l_qseq - 1;
+                    const int iq = (t_bi && (fl & 1u) && qpos >= 0) ? (int)t_bi[s0 + qpos] - 33 : 0;
+                    const int dq = (t_bd && (fl & 2u) && qpos >= 0) ? (int)t_bd[s0 + qpos] - 33 : 0;
+                    if (!(iq < min_plp_idq || dq < min_plp_idq)) {      /* plp.c:1062 */
+                        evs.push_back({p, r, qpos, indel});
+                    }
+                }
+                x += l;
+                if (!is_del) {
+                    y += l;
+                }
+            } else if (op == 1 || op == 4) {
+                y += l;
+            }
+        }
+    }
+    std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
+
+    if (n == 0 || width == 0) {
+        for (int sd = 0; sd < 2; sd++) {
+            O.side[sd].ne_off.assign(1, 0);
+            O.side[sd].ev_off.assign(1, 0);
+            O.side[sd].key_off.assign(1, 0);
+            O.side[sd].rd_off.assign(1, 0);
+        }
+    } else {
+        /* 2. dense counters on the device */
+        LFQ_TRY_HIP(hipSetDevice(c->device));
+        const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
+        auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+        const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
+                      o_bi = o_cig + al(n_cig * 4), o_bd = o_bi + al(n_bases), o_fl = o_bd + al(n_bases), o_mq = o_fl + al(n),
+                      o_rev = o_mq + al(n), o_cnt = o_rev + al(n), o_cur = o_cnt + 7 * al(width * 4),
+                      o_off = o_cur + 2 * al(width * 4), total = o_off + 2 * al(width * 8);
+        uint8_t *d = nullptr;
+        if (hipMalloc((void **)&d, (size_t)total) != hipSuccess) {
+            return LFQ_ERR_NOMEM;
+        }
+        int16_t *d_ne = nullptr;
+        int rc = LFQ_OK;
+        auto up = [&](int64_t off, const void *src, int64_t bytes) {
+            if (rc == LFQ_OK && src && bytes > 0
+                && hipMemcpyAsync(d + off, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        };
+        up(o_pos, rd->pos, n * 4);
+        up(o_coff, rd->cigar_off, (n + 1) * 8);
+        up(o_soff, rd->seq_off, (n + 1) * 8);
+        up(o_cig, rd->cigar, n_cig * 4);
+        up(o_bi, t_bi, n_bases);
+        up(o_bd, t_bd, n_bases);
+        up(o_fl, t_fl, n);
+        up(o_mq, rd->mapq, n);
+        up(o_rev, rd->reverse, n);
+        if (rc == LFQ_OK && hipMemsetAsync(d + o_cnt, 0, (size_t)(o_off - o_cnt), c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
+        LfqPlpIndelArgs A;
+        memset(&A, 0, sizeof(A));
+        A.n_reads = n;
+        A.pos = (const int32_t *)(d + o_pos);
+        A.cigar_off = (const int64_t *)(d + o_coff);
+        A.seq_off = (const int64_t *)(d + o_soff);
+        A.cigar = (const uint32_t *)(d + o_cig);
+        A.bi = t_bi ? d + o_bi : nullptr;
+        A.bd = t_bd ? d + o_bd : nullptr;
+        A.tag_flags = t_fl ? d + o_fl : nullptr;
+        A.mapq = d + o_mq;
+        A.reverse = d + o_rev;
+        A.begin = region_begin;
+        A.width = width;
+        A.min_plp_idq = min_plp_idq;
+        int32_t **cnt[7] = {&A.cov, &A.tails, &A.non_indels, &A.n_ins, &A.n_dels, &A.non_ins_fw, &A.non_del_fw};
+        for (int i = 0; i < 7; i++) {
+            *cnt[i] = (int32_t *)(d + o_cnt + i * al(width * 4));
+        }
+        std::vector<int32_t> h[7];
+        if (rc == LFQ_OK) {
+            rc = lfq_launch_plp_indel(A, 0, c->stream);
+        }
+        for (int i = 0; i < 7 && rc == LFQ_OK; i++) {
+            h[i].resize((size_t)width);
+            if (hipMemcpyAsync(h[i].data(), *cnt[i], (size_t)width * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        }
+        if (rc == LFQ_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
+        /* 3. columns = covered positions; quality arrays of the reads without an event at the event positions */
+        std::vector<int64_t> pos_off[2];
+        int64_t ne_total[2] = {0, 0};
+        if (rc == LFQ_OK) {
+            pos_off[0].assign((size_t)width, -1);
+            pos_off[1].assign((size_t)width, -1);
+            std::vector<uint8_t> has_ev((size_t)width, 0);
+            for (const Ev &e : evs) {
+                has_ev[(size_t)(e.pos - region_begin)] = 1;
+            }
+            for (int sd = 0; sd < 2; sd++) {
+                O.side[sd].ne_off.push_back(0);
+            }
+            for (int64_t p = 0; p < width; p++) {
+                if (h[0][(size_t)p] <= 0) {
+                    continue;
+                }
+                const int64_t gp = region_begin + p;
+                if (col_pos_out) {
+                    col_pos_out[O.cov.size()] = gp;
+                }
+                char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';       /* plp.c:818-823 */
+                if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
+                    rb = 'N';
+                }
+                O.ref_base.push_back((uint8_t)rb);
+                O.cov.push_back(h[0][(size_t)p]);
+                O.tails.push_back(h[1][(size_t)p]);
+                O.non_indels.push_back(h[2][(size_t)p]);
+                O.n_ins.push_back(h[3][(size_t)p]);
+                O.n_dels.push_back(h[4][(size_t)p]);
+                int hr = 1;                                             /* get_hrun, plp.c:744-787 */
+                if (gp + 1 < rd->ref_len) {
+                    const int ch = toupper((unsigned char)rd->ref[gp + 1]);
+                    for (int64_t i = gp + 2; i < rd->ref_len && toupper((unsigned char)rd->ref[i]) == ch; i++) {
+                        hr++;
+                    }
+                    for (int64_t i = gp; i >= 0 && toupper((unsigned char)rd->ref[i]) == ch; i--) {
+                        hr++;
+                    }
+                }
+                O.hrun.push_back(hr);
+                const int32_t ne_cnt[2] = {h[2][(size_t)p] + h[4][(size_t)p], h[2][(size_t)p] + h[3][(size_t)p]};
+                const int32_t fw[2] = {h[5][(size_t)p], h[6][(size_t)p]};
+                for (int sd = 0; sd < 2; sd++) {
+                    O.side[sd].non_fw.push_back(fw[sd]);
+                    O.side[sd].non_rv.push_back(ne_cnt[sd] - fw[sd]);
+                    if (has_ev[(size_t)p]) {
+                        pos_off[sd][(size_t)p] = ne_total[sd];
+                        ne_total[sd] += ne_cnt[sd];
+                    }
+                    O.side[sd].ne_off.push_back(ne_total[sd]);
+                }
+            }
+            const int64_t ne_all = ne_total[0] + ne_total[1];
+            if (ne_all > 0 && hipMalloc((void **)&d_ne, (size_t)ne_all * 4) != hipSuccess) {
+                rc = LFQ_ERR_NOMEM;
+            }
+            if (rc == LFQ_OK && ne_all > 0) {
+                for (int sd = 0; sd < 2; sd++) {
+                    up(o_off + sd * al(width * 8), pos_off[sd].data(), width * 8);
+                    A.ne_off[sd] = (const int64_t *)(d + o_off + sd * al(width * 8));
+                    A.cursor[sd] = (int32_t *)(d + o_cur + sd * al(width * 4));
+                }
+                A.ne_q[0] = d_ne;
+                A.ne_mq[0] = d_ne + ne_total[0];
+                A.ne_q[1] = d_ne + 2 * ne_total[0];
+                A.ne_mq[1] = d_ne + 2 * ne_total[0] + ne_total[1];
+                if (rc == LFQ_OK) {
+                    rc = lfq_launch_plp_indel(A, 1, c->stream);
+                }
+                for (int sd = 0; sd < 2 && rc == LFQ_OK; sd++) {
+                    O.side[sd].ne_q.resize((size_t)ne_total[sd]);
+                    O.side[sd].ne_mq.resize((size_t)ne_total[sd]);
+                    if (ne_total[sd] > 0
+                        && (hipMemcpyAsync(O.side[sd].ne_q.data(), A.ne_q[sd], (size_t)ne_total[sd] * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+                            || hipMemcpyAsync(O.side[sd].ne_mq.data(), A.ne_mq[sd], (size_t)ne_total[sd] * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) {
+                        rc = LFQ_ERR_HIP;
+                    }
+                }
+                if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
+                    rc = LFQ_ERR_HIP;
+                }
+            }
+        }
+        (void)hipFree(d);
+        if (d_ne) (void)hipFree(d_ne);
+        if (rc != LFQ_OK) {
+            return rc;
+        }
+        /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
+         * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */
+        std::vector<int64_t> col_of((size_t)width, -1);
+        {
+            int64_t ci = 0;
+            for (int64_t p = 0; p < width; p++) {
+                if (h[0][(size_t)p] > 0) {
+                    col_of[(size_t)p] = ci++;
+                }
+            }
+        }
+        for (int sd = 0; sd < 2; sd++) {
+            LfqIndelColsOwned::Side &S = O.side[sd];
+            S.ev_off.push_back(0);
+            S.key_off.push_back(0);
+            S.rd_off.push_back(0);
+        }
+        const int64_t ncols = (int64_t)O.cov.size();
+        size_t ei = 0;
+        for (int64_t col = 0; col < ncols; col++) {
+            size_t e1 = ei;
+            while (e1 < evs.size() && col_of[(size_t)(evs[e1].pos - region_begin)] == col) {
+                e1++;
+            }
+            for (int sd = 0; sd < 2; sd++) {
+                LfqIndelColsOwned::Side &S = O.side[sd];
+                std::vector<std::string> keys;
+                std::vector<std::vector<size_t>> members;
+                for (size_t i = ei; i < e1; i++) {
+                    const Ev &e = evs[i];
+                    if ((e.indel > 0) != (sd == 0)) {
+                        continue;
+                    }
+                    std::string key;
+                    if (sd == 0) {                                      /* inserted bases, plp.c:1082-1086 */
+                        const int64_t s0 = rd->seq_off[e.read], lq = rd->seq_off[e.read + 1] - s0;
+                        for (int j = 1; j <= e.indel; j++) {
+                            const int64_t q = e.qpos + j;
+                            const uint8_t code = q < lq ? rd->seq[s0 + q] : 4;
+                            key.push_back("ACGTN"[code > 4 ? 4 : code]);
+                        }
+                    } else {                                            /* deleted reference bases, :1127-1131 */
+                        for (int j = 1; j <= -e.indel; j++) {
+                            const int64_t g = e.pos + j;
+                            key.push_back(g < rd->ref_len ? (char)toupper((unsigned char)rd->ref[g]) : 'N');
+                        }
+                    }
+                    size_t ki = 0;
+                    while (ki < keys.size() && keys[ki] != key) {
+                        ki++;
+                    }
+                    if (ki == keys.size()) {
+                        keys.push_back(key);
+                        members.emplace_back();
+                    }
+                    members[ki].push_back(i);
+                }
+                for (size_t ki = 0; ki < keys.size(); ki++) {
+                    int fw = 0, rv = 0;
+                    for (size_t i : members[ki]) {
+                        const Ev &e = evs[i];
+                        const int64_t s0 = rd->seq_off[e.read];
+                        const uint32_t fl = t_fl ? t_fl[e.read] : 15u;
+                        const uint8_t *qa = sd == 0 ? t_bi : t_bd, *aa = sd == 0 ? t_ai : t_ad;
+                        const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u)), has_a = aa && (fl & (sd == 0 ? 4u : 8u));
+                        S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
+                        S.rd_aq.push_back((int16_t)(has_a ? (int)aa[s0 + e.qpos] - 33 : -1));     /* :1069-1073, 1113-1117 */
+                        S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
+                        const int32_t sq = t_sq ? t_sq[e.read] : -1;
+                        S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
+                        if (rd->reverse[e.read]) {
+                            rv++;
+                        } else {
+                            fw++;
+                        }
+                    }
+                    S.ev_fw.push_back(fw);
+                    S.ev_rv.push_back(rv);
+                    S.key_chars.insert(S.key_chars.end(), keys[ki].begin(), keys[ki].end());
+                    S.key_off.push_back((int64_t)S.key_chars.size());
+                    S.rd_off.push_back((int64_t)S.rd_q.size());
+                }
+                S.ev_off.push_back((int64_t)S.ev_fw.size());
+            }
+            ei = e1;
+        }
+    }
+    /* 5. publish */
+    lfq_indel_columns &C = O.cols;
+    C.ncols = (int64_t)O.cov.size();
+    C.ref_base = O.ref_base.data();
+    C.coverage_plp = O.cov.data();
+    C.num_tails = O.tails.data();
+    C.num_non_indels = O.non_indels.data();
+    C.num_ins = O.n_ins.data();
+    C.num_dels = O.n_dels.data();
+    C.hrun = O.hrun.data();
+    for (int sd = 0; sd < 2; sd++) {
+        LfqIndelColsOwned::Side &S = O.side[sd];
+        S.key_chars.push_back('\0');
+        lfq_indel_side &T = C.side[sd];
+        T.non_fw = S.non_fw.data();
+        T.non_rv = S.non_rv.data();
+        T.ne_off = S.ne_off.data();
+        T.ne_q = S.ne_q.data();
+        T.ne_mq = S.ne_mq.data();
+        T.ev_off = S.ev_off.data();
+        T.key_off = S.key_off.data();
+        T.key_chars = S.key_chars.data();
+        T.ev_fw = S.ev_fw.data();
+        T.ev_rv = S.ev_rv.data();
+        T.rd_off = S.rd_off.data();
+        T.rd_q = S.rd_q.data();
+        T.rd_aq = S.rd_aq.data();
+        T.rd_mq = S.rd_mq.data();
+        T.rd_sq = S.rd_sq.data();
+    }
     return LFQ_OK;
 }
 

@@ -210,6 +210,26 @@ struct LfqPileupArgs {
 };
 int lfq_launch_pileup_count(const LfqPileupArgs &a, void *stream);
 
+/* the indel fields of compile_plp_col (plp.c:1019-1192), dense part on the device */
+struct LfqPlpIndelArgs {
+    int64_t n_reads;
+    const int32_t *pos;
+    const int64_t *cigar_off, *seq_off;
+    const uint32_t *cigar;
+    const uint8_t *bi, *bd;               /* per base tag bytes (quality + 33) or null */
+    const uint8_t *tag_flags;             /* [n] bit 0: read has BI, bit 1: BD; null = wherever the array exists */
+    const uint8_t *mapq, *reverse;        /* [n] */
+    int64_t begin, width;
+    int32_t min_plp_idq;
+    /* per reference position of the region */
+    int32_t *cov, *tails, *non_indels, *n_ins, *n_dels, *non_ins_fw, *non_del_fw;
+    /* scatter pass: positions with at least one event get the (quality, MAPQ) of their non-event reads */
+    const int64_t *ne_off[2];             /* [width] start of the position's slice per side, -1 = not wanted */
+    int32_t *cursor[2];                   /* [width] */
+    int16_t *ne_q[2], *ne_mq[2];
+};
+int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream);
+
 /* source quality (lfq_srcq.hip) */
 #define LFQ_DBL_EPSILON 2.220446049250313e-16
 #define LFQ_SRCQ_LDS_CELLS 768      /* K below this: the DP cells of a read live in LDS, else in its scratch slice */

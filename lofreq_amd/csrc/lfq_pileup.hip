@@ -114,3 +114,127 @@ int lfq_launch_pileup_scatter(const LfqPileupArgs &a, void *stream)
                        (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
+
+
+/* ---- indel fields of the pileup (plp.c:1019-1192) ------------------------------------------------------------
+ * Every pileup entry of a read (a base of an M/=/X operation, or a position inside a D/N operation) carries the
+ * read's BI / BD quality at the entry's query position and, at the last position of an operation, the indel
+ * that follows (htslib resolve_cigar2: +len for I, -len for D).  Entries passing min_plp_idq are counted
+ * (num_non_indels / num_ins / num_dels, the strand counts of the reads without an insertion resp. deletion) and
+ * their (quality, MAPQ) go to the column's ins_quals / del_quals arrays -- those are only materialised for
+ * positions that have an event (the host knows them from the CIGARs), the only ones call_indels reads. */
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void lfq_plp_indel_kernel(LfqPlpIndelArgs A)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n_reads) {
+        return;
+    }
+    const uint32_t *cg = A.cigar + A.cigar_off[r];
+    const int n_cigar = (int)(A.cigar_off[r + 1] - A.cigar_off[r]);
+    const int64_t s0 = A.seq_off[r];
+    const int l_qseq = (int)(A.seq_off[r + 1] - s0);
+    const uint32_t fl = A.tag_flags ? A.tag_flags[r] : 3u;
+    const uint8_t *bi = (A.bi && (fl & 1u)) ? A.bi + s0 : nullptr, *bd = (A.bd && (fl & 2u)) ? A.bd + s0 : nullptr;
+    const int rev = A.reverse[r] ? 1 : 0;
+    const int16_t mq = (int16_t)A.mapq[r];
+    int64_t end = A.pos[r];                                 /* bam_endpos - 1: is_tail */
+    for (int k = 0; k < n_cigar; ++k) {
+        const int op = cg[k] & 0xf;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) {
+            end += cg[k] >> 4;
+        }
+    }
+    end -= 1;
+    int64_t x = A.pos[r];
+    int y = 0;
+    for (int k = 0; k < n_cigar; ++k) {
+        const int op = cg[k] & 0xf, l = cg[k] >> 4;
+        if (op == 0 || op == 7 || op == 8 || op == 2 || op == 3) {
+            const bool is_del = op == 2 || op == 3;
+            int indel_last = 0;                             /* the peek of resolve_cigar2 at the operation's last position */
+            if (k + 1 < n_cigar) {
+                const int op2 = cg[k + 1] & 0xf, l2 = cg[k + 1] >> 4;
+                if (op2 == 2) {
+                    indel_last = -l2;
+                } else if (op2 == 1) {
+                    indel_last = l2;
+                } else if (op2 == 6 && k + 2 < n_cigar) {
+                    int l3 = 0;
+                    for (int kk = k + 2; kk < n_cigar; ++kk) {
+                        const int o3 = cg[kk] & 0xf;
+                        if (o3 == 1) {
+                            l3 += cg[kk] >> 4;
+                        } else if (o3 == 2 || o3 == 0 || o3 == 3 || o3 == 7 || o3 == 8) {
+                            break;
+                        }
+                    }
+                    if (l3 > 0) {
+                        indel_last = l3;
+                    }
+                }
+            }
+            for (int j = 0; j < l; j++) {
+                const int64_t c = x + j - A.begin;
+                if (c < 0 || c >= A.width) {
+                    continue;
+                }
+                int qpos = is_del ? y : y + j;
+                qpos = qpos < l_qseq ? qpos : l_qseq - 1;
+                const int iq = (bi && qpos >= 0) ? (int)bi[qpos] - 33 : 0, dq = (bd && qpos >= 0) ? (int)bd[qpos] - 33 : 0;   /* plp.c:1023-1059 */
+                const int indel = (j == l - 1) ? indel_last : 0;
+                const bool pass = !(iq < A.min_plp_idq || dq < A.min_plp_idq);                    /* :1062 */
+                if (!SCATTER) {
+                    atomicAdd(&A.cov[c], 1);
+                    if (!is_del && x + j == end) {
+                        atomicAdd(&A.tails[c], 1);                                              /* :920-922 */
+                    }
+                    if (pass) {
+                        if (indel > 0) {
+                            atomicAdd(&A.n_ins[c], 1);
+                            atomicAdd(&A.non_del_fw[c], rev ? 0 : 1);                           /* :1100-1104 */
+                        } else if (indel < 0) {
+                            atomicAdd(&A.n_dels[c], 1);
+                            atomicAdd(&A.non_ins_fw[c], rev ? 0 : 1);                           /* :1151-1155 */
+                        } else {
+                            atomicAdd(&A.non_indels[c], 1);
+                            atomicAdd(&A.non_ins_fw[c], rev ? 0 : 1);
+                            atomicAdd(&A.non_del_fw[c], rev ? 0 : 1);
+                        }
+                    }
+                } else if (pass) {
+                    if (indel <= 0 && A.ne_off[0][c] >= 0) {            /* no insertion here: ins_quals (:1147, 1162) */
+                        const int64_t slot = A.ne_off[0][c] + atomicAdd(&A.cursor[0][c], 1);
+                        A.ne_q[0][slot] = (int16_t)iq;
+                        A.ne_mq[0][slot] = mq;
+                    }
+                    if (indel >= 0 && A.ne_off[1][c] >= 0) {            /* no deletion here: del_quals (:1096, 1173) */
+                        const int64_t slot = A.ne_off[1][c] + atomicAdd(&A.cursor[1][c], 1);
+                        A.ne_q[1][slot] = (int16_t)dq;
+                        A.ne_mq[1][slot] = mq;
+                    }
+                }
+            }
+            x += l;
+            if (!is_del) {
+                y += l;
+            }
+        } else if (op == 1 || op == 4) {
+            y += l;
+        }
+    }
+}
+
+int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream)
+{
+    if (a.n_reads <= 0) {
+        return LFQ_OK;
+    }
+    const dim3 grid((unsigned)((a.n_reads + 255) / 256)), block(256);
+    if (scatter) {
+        hipLaunchKernelGGL(lfq_plp_indel_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(lfq_plp_indel_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}

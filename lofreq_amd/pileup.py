@@ -67,3 +67,101 @@ def pileup_snv_tracks(caller, reads, ref, begin, end, lb=None, min_plp_bq=3, sq=
     _lib.check(_lib.load().lfq_pileup_snv_tracks(caller.h, C.byref(rd), int(begin), int(end), int(min_plp_bq),
                                                  C.byref(t), col_pos.ctypes.data), "lfq_pileup_snv_tracks")
     return DeviceTracks(t, col_pos[: int(t.ncols)].copy())
+
+
+def _pack_reads(reads, ref, lb=None, sq=None):
+    n = len(reads)
+    keep = {"pos": np.asarray([r["pos0"] for r in reads] or [0], np.int32)}
+    cig_off = np.zeros(n + 1, np.int64)
+    seq_off = np.zeros(n + 1, np.int64)
+    cig, seqs, quals = [], [], []
+    for i, r in enumerate(reads):
+        cig.extend((l << 4) | _OPS.index(o) for o, l in r["cigar"])
+        cig_off[i + 1] = len(cig)
+        seqs.append(np.asarray(r["seq"], np.uint8))
+        quals.append(np.asarray(r["qual"], np.uint8))
+        seq_off[i + 1] = seq_off[i] + len(seqs[-1])
+    keep["cig_off"], keep["seq_off"] = cig_off, seq_off
+    keep["cig"] = np.asarray(cig if cig else [0], np.uint32)
+    keep["seq"] = np.concatenate(seqs) if seqs else np.zeros(1, np.uint8)
+    keep["qual"] = np.concatenate(quals) if quals else np.zeros(1, np.uint8)
+    keep["mapq"] = np.asarray([r["mapq"] for r in reads] or [0], np.uint8)
+    keep["rev"] = np.asarray([1 if r["reverse"] else 0 for r in reads] or [0], np.uint8)
+    keep["ref"] = bytes(ref)
+    rd = _lib.PileupReads()
+    rd.n_reads = n
+    rd.pos = keep["pos"].ctypes.data
+    rd.cigar_off = cig_off.ctypes.data
+    rd.cigar = keep["cig"].ctypes.data
+    rd.seq_off = seq_off.ctypes.data
+    rd.seq = keep["seq"].ctypes.data
+    rd.qual = keep["qual"].ctypes.data
+    rd.mapq = keep["mapq"].ctypes.data
+    rd.reverse = keep["rev"].ctypes.data
+    rd.ref = C.cast(C.c_char_p(keep["ref"]), C.c_void_p)
+    rd.ref_len = len(keep["ref"])
+    return rd, keep
+
+
+def pileup_indel_columns(caller, reads, ref, begin, end, min_plp_idq=0):
+    """The indel fields of the pileup (`lfq_pileup_indel_columns`).  reads: as for pileup_snv_tracks, plus the
+    optional per-read entries "bi", "bd", "ai", "ad" (tag bytes, uint8 arrays of the read's length, or None) and
+    "sq" (int).  -> (IndelColumns for call_indels / format_indel_record, positions of the columns)"""
+    from .indel import IndelColumns, _I32
+    n = len(reads)
+    rd, keep = _pack_reads(reads, ref)
+    n_bases = int(keep["seq_off"][-1])
+    tags = _lib.PileupIndelTags()
+    flags = np.zeros(max(n, 1), np.uint8)
+    for bit, name in enumerate(("bi", "bd", "ai", "ad")):
+        if any(r.get(name) is not None for r in reads):
+            arr = np.full(max(n_bases, 1), 33, np.uint8)
+            for i, r in enumerate(reads):
+                if r.get(name) is not None:
+                    arr[keep["seq_off"][i]:keep["seq_off"][i + 1]] = np.asarray(r[name], np.uint8)
+                    flags[i] |= 1 << bit
+            keep[name] = arr
+            setattr(tags, name, arr.ctypes.data)
+    keep["flags"] = flags
+    tags.tag_flags = flags.ctypes.data
+    if any(r.get("sq") is not None for r in reads):
+        keep["sq"] = np.asarray([(-1 if r.get("sq") is None else r["sq"]) for r in reads], np.int32)
+        tags.sq = keep["sq"].ctypes.data
+    out = C.POINTER(_lib.IndelColumnsC)()
+    col_pos = np.zeros(max(end - begin, 1), np.int64)
+    _lib.check(_lib.load().lfq_pileup_indel_columns(caller.h, C.byref(rd), C.byref(tags), int(begin), int(end),
+                                                    int(min_plp_idq), C.byref(out), col_pos.ctypes.data),
+               "lfq_pileup_indel_columns")
+    cs = out.contents
+    ncols = int(cs.ncols)
+
+    def arr(ptr, count, dt):
+        if count == 0 or not ptr:
+            return np.zeros(0, dt)
+        return np.frombuffer(C.string_at(ptr, count * np.dtype(dt).itemsize), dtype=dt).copy()
+
+    o = IndelColumns()
+    o.ncols = ncols
+    o.ref_base = arr(cs.ref_base, ncols, np.uint8)
+    for name in _I32:
+        setattr(o, name, arr(getattr(cs, name), ncols, np.int32))
+    for sd in range(2):
+        S = cs.side[sd]
+        ne_off = arr(S.ne_off, ncols + 1, np.int64)
+        ev_off = arr(S.ev_off, ncols + 1, np.int64)
+        nev = int(ev_off[-1]) if ncols else 0
+        key_off = arr(S.key_off, nev + 1, np.int64)
+        rd_off = arr(S.rd_off, nev + 1, np.int64)
+        nrd = int(rd_off[-1]) if nev else 0
+        nne = int(ne_off[-1]) if ncols else 0
+        key_chars = arr(S.key_chars, (int(key_off[-1]) if nev else 0) + 1, np.uint8)
+        o.sides[sd] = {
+            "non_fw": arr(S.non_fw, ncols, np.int32), "non_rv": arr(S.non_rv, ncols, np.int32), "ne_off": ne_off,
+            "ne_q": arr(S.ne_q, nne, np.int16), "ne_mq": arr(S.ne_mq, nne, np.int16), "ev_off": ev_off,
+            "key_off": key_off, "key_chars": key_chars, "ev_fw": arr(S.ev_fw, nev, np.int32),
+            "ev_rv": arr(S.ev_rv, nev, np.int32), "rd_off": rd_off, "rd_q": arr(S.rd_q, nrd, np.int16),
+            "rd_aq": arr(S.rd_aq, nrd, np.int16), "rd_mq": arr(S.rd_mq, nrd, np.int16),
+            "rd_sq": arr(S.rd_sq, nrd, np.int16)}
+        kc = key_chars.tobytes()
+        o.keys[sd] = [kc[key_off[e]:key_off[e + 1]].decode() for e in range(nev)]
+    return o, col_pos[:ncols].copy()

@@ -116,7 +116,7 @@ def run(name, seed, glen, nreads, planted, mapqs, call_args):
 
 # ---- indel fixtures ---------------------------------------------------------------------------------
 
-def write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.0008):
+def write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.0008, planted_snvs=None):
     """sites: {pos0: [(kind, key_or_len, frac), ...]}; kind '+' inserts key after pos0, '-' deletes len
     bases after pos0.  Per-base BI/BD indel qualities are random.  Returns (genome, reads)."""
     rng = np.random.default_rng(seed)
@@ -131,9 +131,10 @@ def write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.0008):
     reads = []
     for _ in range(nreads):
         pos = int(rng.integers(0, glen - rl - 12))
-        seq, cigar, run, gp = [], [], 0, pos
+        seq, cigar, run, gp, gpos = [], [], 0, pos, []
         while len(seq) < rl and gp < glen - 8:
             seq.append(genome[gp])
+            gpos.append(gp)
             run += 1
             ev = None
             if run > 4 and len(seq) < rl - 8:
@@ -148,6 +149,7 @@ def write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.0008):
                 run = 0
                 if ev[0] == "+":
                     seq.extend(ev[1])
+                    gpos.extend([None] * len(ev[1]))
                     cigar.append("%dI" % len(ev[1]))
                 else:
                     cigar.append("%dD" % ev[1])
@@ -158,6 +160,13 @@ def write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, noise=0.0008):
         cigar.append("%dM" % run)
         n = len(seq)
         qual = "".join(chr(33 + int(q)) for q in np.clip(np.round(rng.normal(35, 4, n)), 8, 41))
+        if planted_snvs is not None:        # base errors by quality + planted SNVs (only when asked: keeps older fixtures)
+            for j in range(n):
+                if rng.random() < 10 ** (-(ord(qual[j]) - 33) / 10.0):
+                    seq[j] = str(rng.choice([c for c in "ACGT" if c != seq[j]]))
+                p = planted_snvs.get(gpos[j])
+                if p and rng.random() < p[1]:
+                    seq[j] = p[0] if p[0] != genome[gpos[j]] else "ACGT"[("ACGT".index(p[0]) + 1) % 4]
         bi = "".join(chr(33 + int(q)) for q in rng.integers(25, 50, n))
         bd = "".join(chr(33 + int(q)) for q in rng.integers(25, 50, n))
         flag = 16 if rng.random() < 0.5 else 0
@@ -229,26 +238,7 @@ def parse_plpsummary_indels(text):
     return cols
 
 
-def run_indel(name, seed, glen, nreads, sites, mapqs, call_args, alnqual=True):
-    with tempfile.TemporaryDirectory() as tmp:
-        genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs)
-        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
-        bam = "t.sam"
-        if alnqual:
-            with open(os.path.join(tmp, "t.aq.bam"), "wb") as f:
-                subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
-            bam = "t.aq.bam"
-        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", bam], cwd=tmp, check=True, capture_output=True,
-                             text=True).stdout
-        env = dict(os.environ)
-        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
-        res = subprocess.run([LOFREQ, "call", "--call-indels", "--only-indels", "-f", "t.fa", "-o", "out.vcf"]
-                             + call_args + [bam], cwd=tmp, check=True, capture_output=True, text=True, env=env)
-        ntests = None
-        for line in res.stderr.splitlines():
-            if "Number of indel tests performed" in line:
-                ntests = int(line.split(":")[-1])
-        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+def pack_indel_cols(plp, genome, reads):
     strands = indel_strands(genome, reads)
     packed = []
     for c in parse_plpsummary_indels(plp):
@@ -274,6 +264,30 @@ def run_indel(name, seed, glen, nreads, sites, mapqs, call_args, alnqual=True):
                                        "mq": e["MQ"], "sq": enc(e["SQ"])})
             col[sn] = side
         packed.append(col)
+    return packed
+
+
+def run_indel(name, seed, glen, nreads, sites, mapqs, call_args, alnqual=True):
+    with tempfile.TemporaryDirectory() as tmp:
+        genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        bam = "t.sam"
+        if alnqual:
+            with open(os.path.join(tmp, "t.aq.bam"), "wb") as f:
+                subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
+            bam = "t.aq.bam"
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", bam], cwd=tmp, check=True, capture_output=True,
+                             text=True).stdout
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
+        res = subprocess.run([LOFREQ, "call", "--call-indels", "--only-indels", "-f", "t.fa", "-o", "out.vcf"]
+                             + call_args + [bam], cwd=tmp, check=True, capture_output=True, text=True, env=env)
+        ntests = None
+        for line in res.stderr.splitlines():
+            if "Number of indel tests performed" in line:
+                ntests = int(line.split(":")[-1])
+        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+    packed = pack_indel_cols(plp, genome, reads)
     fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
            "call_args": ["--call-indels", "--only-indels"] + call_args, "alnqual": alnqual, "columns": packed,
            "vcf": vcf, "num_indel_tests": ntests}
@@ -493,6 +507,61 @@ def main_srcq():
     run_srcq("srcq_ign_nmq", 62, 330, 220, sites, mq_mix, extra=("-T", "20"), ign=(70, 99, 100, 150, 189, 190, 240))
 
 
+# ---- reads -> indel columns -> indel (and SNV) calls: the pileup's indel fields ------------------------------
+
+def run_plpindel(name, seed, glen, nreads, sites, mapqs, call_args):
+    """reads with BI / BD (+ lb / ai / ad from `lofreq alnqual`), the binary's indel column dump (plpsummary) and
+    the VCFs of `lofreq call --call-indels` with and without --only-indels"""
+    with tempfile.TemporaryDirectory() as tmp:
+        planted = {50: ("A", 0.3), 120: ("G", 0.08), 121: ("T", 0.05), 205: ("C", 0.02), 260: ("A", 0.5)}
+        genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, planted_snvs=planted)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        with open(os.path.join(tmp, "t.aq.bam"), "wb") as f:
+            subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
+        sam = subprocess.run([LOFREQ, "alnqual", "t.sam", "t.fa"], cwd=tmp, check=True, capture_output=True,
+                             text=True).stdout
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", "t.aq.bam"], cwd=tmp, check=True,
+                             capture_output=True, text=True).stdout
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.realpath(LOFREQ)) + ":" + env["PATH"]
+        out = {}
+        for tag, extra in (("indels", ["--only-indels"]), ("all", [])):
+            res = subprocess.run([LOFREQ, "call", "--call-indels", "-f", "t.fa", "-o", "out_%s.vcf" % tag] + extra
+                                 + call_args + ["t.aq.bam"], cwd=tmp, check=True, capture_output=True, text=True, env=env)
+            nt = {}
+            for line in res.stderr.splitlines():
+                if "tests performed" in line:
+                    nt["indel" if "indel" in line else "snv"] = int(line.split(":")[-1])
+            vcf = [l for l in open(os.path.join(tmp, "out_%s.vcf" % tag)).read().splitlines() if not l.startswith("#")]
+            out[tag] = {"vcf": vcf, "num_tests": nt}
+    rd = []
+    for line in sam.splitlines():
+        if line.startswith("@"):
+            continue
+        f = line.split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        rd.append([int(f[3]) - 1, int(f[1]), int(f[4]), f[5], f[9], f[10], tags.get("BI"), tags.get("BD"),
+                   tags.get("lb"), tags.get("ai"), tags.get("ad")])
+    packed = pack_indel_cols(plp, genome, reads)
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "call_args": ["--call-indels"] + call_args, "genome": genome,
+           "read_fields": "pos0, flag, mapq, cigar, seq, qual, BI, BD, lb, ai, ad", "reads": rd, "columns": packed,
+           "only_indels": out["indels"], "all": out["all"]}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d reads, %d indel columns, %d / %d vcf records, tests %s / %s, %d bytes"
+          % (name, len(rd), len(packed), len(out["indels"]["vcf"]), len(out["all"]["vcf"]), out["indels"]["num_tests"],
+             out["all"]["num_tests"], os.path.getsize(path)))
+
+
+def main_plpindel():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
+             160: [("-", 1, 0.02), ("+", "T", 0.02)], 190: [("+", "A", 0.5)], 215: [("-", 2, 0.01)],
+             240: [("-", 5, 0.3), ("+", "CCCC", 0.05)]}
+    run_plpindel("plpindel_default", 71, 330, 350, sites, mq_mix, ["--no-default-filter"])
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -513,6 +582,8 @@ def main():
         return main_pileup()
     if "--srcq-only" in sys.argv:
         return main_srcq()
+    if "--plpindel-only" in sys.argv:
+        return main_plpindel()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]

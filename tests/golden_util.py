@@ -177,3 +177,23 @@ def py_pileup(reads, min_plp_bq=3):
             elif op in "DN":
                 x += l
     return cols
+
+
+def plpindel_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "plpindel_*.json")))
+
+
+def load_plpindel(path, with_alnqual_tags=True):
+    """-> (fixture, reads as dicts incl. bi / bd and, if wanted, the lb / ai / ad tags `lofreq alnqual` wrote)"""
+    fx = json.load(open(path))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    tag = lambda t: None if t is None else np.frombuffer(t.encode(), np.uint8)
+    reads = []
+    for r in fx["reads"]:
+        d = {"pos0": r[0], "cigar": parse_cigar(r[3]), "seq": np.array([code.get(c, 4) for c in r[4]], np.uint8),
+             "qual": np.array([ord(c) - 33 for c in r[5]], np.uint8), "mapq": r[2], "reverse": bool(r[1] & 16),
+             "bi": tag(r[6]), "bd": tag(r[7])}
+        if with_alnqual_tags:
+            d.update(lb=tag(r[8]), ai=tag(r[9]), ad=tag(r[10]))
+        reads.append(d)
+    return fx, reads

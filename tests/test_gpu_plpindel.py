@@ -1,0 +1,100 @@
+"""-m gpu: the indel fields of the pileup on the device (lfq_pileup_indel_columns) against the
+reference binary's own column dump (`lofreq plpsummary`), then reads -> columns -> indel calls against
+`lofreq call --call-indels --only-indels`, and the whole chain reads -> BAQ/IDAQ -> both pileups -> SNV + indel calls
+against `lofreq call --call-indels` (tests/golden/plpindel_*.json)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def _indel_lines(la, caller, cols, col_pos, conf):
+    recs, ntests = la.call_indels(caller, cols, conf)
+    thr = la.snvqual_thresh(conf.sig, conf.bonf_indel)                  # lofreq_call.c:1529-1534
+    keep = la.filter_indel_records(recs, thr, apply_defaults=False)
+    lines = [(int(col_pos[int(r["col"])]), 0, la.format_indel_record("chr1", int(col_pos[int(r["col"])]), cols, r,
+                                                                      "PASS").rstrip("\n"))
+             for r, k in zip(recs, keep) if k]
+    return lines, ntests
+
+
+@pytest.mark.parametrize("path", gu.plpindel_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_indel_columns_match_plpsummary(caller, path):
+    import lofreq_amd as la
+    fx, reads = gu.load_plpindel(path)
+    ref = fx["genome"].encode()
+    cols, col_pos = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+    col_of = {int(p): i for i, p in enumerate(col_pos)}
+    n_ev = 0
+    for e in fx["columns"]:
+        c = col_of[e["pos0"]]
+        ctx = "pos0 %d" % e["pos0"]
+        assert chr(cols.ref_base[c]) == e["ref"], ctx
+        for k in ("coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun"):
+            assert int(getattr(cols, k)[c]) == e[k], (ctx, k)
+        for sd, sn in enumerate(("ins", "dels")):
+            S, E = cols.sides[sd], e[sn]
+            assert int(S["non_fw"][c]) == E["non_fw"] and int(S["non_rv"][c]) == E["non_rv"], (ctx, sn)
+            a, b = int(S["ne_off"][c]), int(S["ne_off"][c + 1])
+            got = sorted(zip(S["ne_q"][a:b].tolist(), S["ne_mq"][a:b].tolist()))
+            assert got == sorted(zip(gu.dec(E["ne_q"]).tolist(), E["ne_mq"])), (ctx, sn)
+            e0, e1 = int(S["ev_off"][c]), int(S["ev_off"][c + 1])
+            assert [cols.keys[sd][i] for i in range(e0, e1)] == [ev["key"] for ev in E["events"]], (ctx, sn)
+            for i, ev in zip(range(e0, e1), E["events"]):
+                assert int(S["ev_fw"][i]) == ev["fw"] and int(S["ev_rv"][i]) == ev["rv"], (ctx, ev["key"])
+                r0, r1 = int(S["rd_off"][i]), int(S["rd_off"][i + 1])
+                for name, want in (("rd_q", gu.dec(ev["q"]).tolist()), ("rd_aq", gu.dec(ev["aq"]).tolist()),
+                                   ("rd_mq", ev["mq"]), ("rd_sq", gu.dec(ev["sq"]).tolist())):
+                    assert S[name][r0:r1].tolist() == want, (ctx, ev["key"], name)
+                n_ev += 1
+    assert n_ev >= 25
+    # columns the binary printed no event for have none here either
+    with_ev = {e["pos0"] for e in fx["columns"]}
+    for c, p in enumerate(col_pos):
+        if int(p) not in with_ev:
+            assert cols.sides[0]["ev_off"][c] == cols.sides[0]["ev_off"][c + 1]
+            assert cols.sides[1]["ev_off"][c] == cols.sides[1]["ev_off"][c + 1]
+
+
+@pytest.mark.parametrize("path", gu.plpindel_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_reads_to_indel_vcf(caller, path):
+    import lofreq_amd as la
+    fx, reads = gu.load_plpindel(path)
+    ref = fx["genome"].encode()
+    cols, col_pos = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+    kw, _ = gu.conf_kwargs(fx["call_args"])
+    conf = la.VarcallConf(**kw)
+    lines, ntests = _indel_lines(la, caller, cols, col_pos, conf)
+    assert ntests == fx["only_indels"]["num_tests"]["indel"]
+    assert [l[2] for l in lines] == fx["only_indels"]["vcf"]
+
+
+@pytest.mark.parametrize("path", gu.plpindel_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_reads_to_full_vcf_device_chain(caller, path):
+    """nothing taken from `lofreq alnqual`: lb / ai / ad come from lfq_baq_idaq_batch, both pileups from the device"""
+    import lofreq_amd as la
+    fx, reads = gu.load_plpindel(path, with_alnqual_tags=False)
+    ref = fx["genome"].encode()
+    tags = la.baq_batch(caller, reads, ref, extended=True, idaq=True)
+    for r, (lb, ai, ad) in zip(reads, tags):
+        r["ai"], r["ad"] = ai, ad
+    kw, _ = gu.conf_kwargs(fx["call_args"])
+    conf = la.VarcallConf(**kw)
+    cols, col_pos = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+    ilines, ntests = _indel_lines(la, caller, cols, col_pos, conf)
+    dt = la.pileup_snv_tracks(caller, reads, ref, 0, len(ref), lb=[t[0] for t in tags])
+    assert dt.col_pos.tolist() == col_pos.tolist()
+    # call_vars skips the SNVs of a column whose consensus is an indel (lofreq_call.c:928-931); none in this fixture
+    recs, _, st = caller.call_snvs(dt, conf)
+    assert conf.num_snv_tests == fx["all"]["num_tests"]["snv"] and ntests == fx["all"]["num_tests"]["indel"]
+    keep = la.filter_records(recs, la.snvqual_thresh(conf.sig, conf.bonf_subst), apply_defaults=False)
+    slines = []
+    for r, k in zip(recs, keep):
+        if k:
+            p0 = int(dt.col_pos[int(r["col"])])
+            slines.append((p0, 1, gu.strip_hqa(la.format_vcf(np.array([r]), "chr1", pos0=np.array([p0]),
+                                                             filter_str="PASS").rstrip("\n"))))
+    merged = [l[2] for l in sorted(ilines + slines, key=lambda t: (t[0], t[1]))]     # indels first within a column (:896)
+    assert merged == fx["all"]["vcf"]
