@@ -227,6 +227,10 @@ typedef struct lfq_indel_columns {
     const uint8_t *ref_base;
     const int32_t *coverage_plp, *num_tails, *num_non_indels, *num_ins, *num_dels, *hrun;
     lfq_indel_side side[2];
+    /* optional (NULL when unknown; not read by lfq_call_indels_batch): 1 where the column's consensus is an
+     * insertion or deletion, cons_base[0] == '+' / '-' (plp.c:1236-1270) -- call_vars does not call SNVs there
+     * (lofreq_call.c:928-931), see lfq_pileup_skip_snv_columns */
+    const uint8_t *cons_indel;
 } lfq_indel_columns;
 
 typedef struct lfq_indel_record {
@@ -331,6 +335,11 @@ typedef struct lfq_pileup_indel_tags {
 int lfq_pileup_indel_columns(lfq_ctx *ctx, const lfq_pileup_reads *reads, const lfq_pileup_indel_tags *tags_or_null,
                              int64_t region_begin, int64_t region_end, int min_plp_idq,
                              const lfq_indel_columns **cols_out, int64_t *col_pos_out);
+
+/* call_vars' gate for SNVs (lofreq_call.c:928-931): columns with skip[col] != 0 (e.g. lfq_indel_columns.cons_indel)
+ * of the tracks last returned by lfq_pileup_snv_tracks are taken out of the SNV path -- their num_bases becomes
+ * 0, which is the other half of the same gate (num_bases * 2 < coverage_plp): no test, no Bonferroni step. */
+int lfq_pileup_skip_snv_columns(lfq_ctx *ctx, const uint8_t *skip, int64_t ncols);
 
 /* --- source quality: the per-read pre-step of `lofreq call -s` -------------------------
  * source_qual (plp.c:427-593) over count_cigar_ops (samutils.c:437-614) for a batch of reads of one contig (same

@@ -73,7 +73,7 @@ class IndelSide(C.Structure):
 class IndelColumnsC(C.Structure):
     _fields_ = [("ncols", C.c_int64)] + [(n, C.c_void_p) for n in (
         "ref_base", "coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun")] + [
-        ("side", IndelSide * 2)]
+        ("side", IndelSide * 2), ("cons_indel", C.c_void_p)]
 
 
 INDEL_CALL_DTYPE = np.dtype([("test", "i8"), ("bonf", "i8"), ("pvalue", np.longdouble), ("qual", "i4"),
@@ -112,7 +112,7 @@ EXPORTS = [
     "lfq_synth_fill_device", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
-    "lfq_source_qual_batch", "lfq_pileup_indel_columns",
+    "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
 ]
 
 _lib = None
@@ -179,6 +179,7 @@ def load():
     L.lfq_pileup_snv_tracks.argtypes = [vp, C.POINTER(PileupReads), C.c_int64, C.c_int64, C.c_int, C.POINTER(Tracks), vp]
     L.lfq_pileup_indel_columns.argtypes = [vp, C.POINTER(PileupReads), C.POINTER(PileupIndelTags), C.c_int64, C.c_int64,
                                            C.c_int, C.POINTER(C.POINTER(IndelColumnsC)), vp]
+    L.lfq_pileup_skip_snv_columns.argtypes = [vp, vp, C.c_int64]
     L.lfq_source_qual_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, C.c_int, vp, vp, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

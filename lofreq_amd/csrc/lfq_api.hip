@@ -43,7 +43,7 @@
 /* the columns handed out by lfq_pileup_indel_columns live here until the next call */
 struct LfqIndelColsOwned {
     lfq_indel_columns cols;
-    std::vector<uint8_t> ref_base;
+    std::vector<uint8_t> ref_base, cons_indel;
     std::vector<int32_t> cov, tails, non_indels, n_ins, n_dels, hrun;
     struct Side {
         std::vector<int32_t> non_fw, non_rv, ev_fw, ev_rv;
@@ -103,6 +103,8 @@ struct lfq_ctx {
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     LfqIndelColsOwned *plp_indel;
+    int32_t *d_plp_nb;               /* num_bases of the tracks last handed out, and their column count */
+    int64_t plp_ncols;
     /* BAQ scratch (lfq_baq_batch), kept between calls */
     double *d_baq_scr;
     int32_t *d_baq_expect;
@@ -1372,6 +1374,8 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     out->ref_base = t + t_ref;
     out->coverage_plp = (const int32_t *)(t + t_cov);
     out->num_bases = (const int32_t *)(t + t_nb);
+    c->d_plp_nb = (int32_t *)(t + t_nb);
+    c->plp_ncols = ncols;
     out->ncols = ncols;
     out->max_col_obs = max_obs;
     return LFQ_OK;
@@ -1704,8 +1708,31 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
             ei = e1;
         }
     }
-    /* 5. publish */
+    /* 5. consensus indel (plp.c:1236-1270): the largest sum of qualities of one event against the sum over the
+     * reads without an event of that side */
+    O.cons_indel.assign(O.cov.size(), 0);
+    for (int64_t col = 0; col < (int64_t)O.cov.size(); col++) {
+        for (int sd = 0; sd < 2; sd++) {
+            const LfqIndelColsOwned::Side &S = O.side[sd];
+            int64_t best = 0, non = 0;
+            for (int64_t e = S.ev_off[(size_t)col]; e < S.ev_off[(size_t)col + 1]; e++) {
+                int64_t sum = 0;
+                for (int64_t i = S.rd_off[(size_t)e]; i < S.rd_off[(size_t)e + 1]; i++) {
+                    sum += S.rd_q[(size_t)i];
+                }
+                best = std::max(best, sum);
+            }
+            for (int64_t i = S.ne_off[(size_t)col]; i < S.ne_off[(size_t)col + 1]; i++) {
+                non += S.ne_q[(size_t)i];
+            }
+            if (best > non) {
+                O.cons_indel[(size_t)col] = 1;
+            }
+        }
+    }
+    /* 6. publish */
     lfq_indel_columns &C = O.cols;
+    C.cons_indel = O.cons_indel.data();
     C.ncols = (int64_t)O.cov.size();
     C.ref_base = O.ref_base.data();
     C.coverage_plp = O.cov.data();
@@ -1733,6 +1760,30 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
         T.rd_aq = S.rd_aq.data();
         T.rd_mq = S.rd_mq.data();
         T.rd_sq = S.rd_sq.data();
+    }
+    return LFQ_OK;
+}
+
+int lfq_pileup_skip_snv_columns(lfq_ctx *c, const uint8_t *skip, int64_t ncols)
+{
+    if (!c || !skip || ncols < 0 || !c->d_plp_out || ncols != c->plp_ncols) {
+        return LFQ_ERR_INVALID;
+    }
+    if (ncols == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    std::vector<int32_t> nb((size_t)ncols);
+    LFQ_TRY_HIP(hipMemcpy(nb.data(), c->d_plp_nb, (size_t)ncols * 4, hipMemcpyDeviceToHost));
+    bool any = false;
+    for (int64_t i = 0; i < ncols; i++) {
+        if (skip[i]) {
+            nb[(size_t)i] = 0;
+            any = true;
+        }
+    }
+    if (any) {
+        LFQ_TRY_HIP(hipMemcpy(c->d_plp_nb, nb.data(), (size_t)ncols * 4, hipMemcpyHostToDevice));
     }
     return LFQ_OK;
 }

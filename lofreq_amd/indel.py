@@ -32,6 +32,7 @@ class IndelColumns:
             setattr(self, n, np.zeros(0, np.int32))
         self.sides = [None, None]
         self.keys = [[], []]
+        self.cons_indel = None          # uint8 per column when known (pileup_indel_columns)
 
     @staticmethod
     def from_columns(cols):

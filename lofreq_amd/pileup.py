@@ -164,4 +164,13 @@ def pileup_indel_columns(caller, reads, ref, begin, end, min_plp_idq=0):
             "rd_sq": arr(S.rd_sq, nrd, np.int16)}
         kc = key_chars.tobytes()
         o.keys[sd] = [kc[key_off[e]:key_off[e + 1]].decode() for e in range(nev)]
+    o.cons_indel = arr(cs.cons_indel, ncols, np.uint8)
     return o, col_pos[:ncols].copy()
+
+
+def skip_snv_columns(caller, skip):
+    """call_vars' gate (lofreq_call.c:928-931): take the columns with skip[col] != 0 (IndelColumns.cons_indel) out of
+    the SNV tracks last returned by pileup_snv_tracks"""
+    skip = np.ascontiguousarray(skip, np.uint8)
+    _lib.check(_lib.load().lfq_pileup_skip_snv_columns(caller.h, skip.ctypes.data, len(skip)),
+               "lfq_pileup_skip_snv_columns")

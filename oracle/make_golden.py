@@ -214,7 +214,7 @@ def parse_plpsummary_indels(text):
             continue
         if not line.startswith(" "):
             f = line.split("\t")
-            cur = {"pos0": int(f[1]) - 1, "ref": f[2]}
+            cur = {"pos0": int(f[1]) - 1, "ref": f[2], "cons": f[3]}
             for tok in f[9:]:
                 k, v = tok.split(":")
                 cur[k] = int(v)
@@ -509,11 +509,11 @@ def main_srcq():
 
 # ---- reads -> indel columns -> indel (and SNV) calls: the pileup's indel fields ------------------------------
 
-def run_plpindel(name, seed, glen, nreads, sites, mapqs, call_args):
+def run_plpindel(name, seed, glen, nreads, sites, mapqs, call_args, planted=None):
     """reads with BI / BD (+ lb / ai / ad from `lofreq alnqual`), the binary's indel column dump (plpsummary) and
     the VCFs of `lofreq call --call-indels` with and without --only-indels"""
     with tempfile.TemporaryDirectory() as tmp:
-        planted = {50: ("A", 0.3), 120: ("G", 0.08), 121: ("T", 0.05), 205: ("C", 0.02), 260: ("A", 0.5)}
+        planted = planted or {50: ("A", 0.3), 120: ("G", 0.08), 121: ("T", 0.05), 205: ("C", 0.02), 260: ("A", 0.5)}
         genome, reads = write_indel_fixture(tmp, seed, glen, nreads, sites, mapqs, planted_snvs=planted)
         subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
         with open(os.path.join(tmp, "t.aq.bam"), "wb") as f:
@@ -543,6 +543,9 @@ def run_plpindel(name, seed, glen, nreads, sites, mapqs, call_args):
         rd.append([int(f[3]) - 1, int(f[1]), int(f[4]), f[5], f[9], f[10], tags.get("BI"), tags.get("BD"),
                    tags.get("lb"), tags.get("ai"), tags.get("ad")])
     packed = pack_indel_cols(plp, genome, reads)
+    cons = {c["pos0"]: c["cons"] for c in parse_plpsummary_indels(plp)}
+    for col in packed:
+        col["cons"] = cons[col["pos0"]]
     fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
            "call_args": ["--call-indels"] + call_args, "genome": genome,
            "read_fields": "pos0, flag, mapq, cigar, seq, qual, BI, BD, lb, ai, ad", "reads": rd, "columns": packed,
@@ -560,6 +563,10 @@ def main_plpindel():
              160: [("-", 1, 0.02), ("+", "T", 0.02)], 190: [("+", "A", 0.5)], 215: [("-", 2, 0.01)],
              240: [("-", 5, 0.3), ("+", "CCCC", 0.05)]}
     run_plpindel("plpindel_default", 71, 330, 350, sites, mq_mix, ["--no-default-filter"])
+    # consensus indels: SNVs planted at (and next to) columns where most reads carry an insertion / deletion
+    sites2 = {70: [("+", "AC", 0.85)], 100: [("-", 3, 0.9)], 160: [("-", 1, 0.55), ("+", "T", 0.1)], 230: [("+", "G", 0.6)]}
+    planted2 = {70: ("A", 0.3), 71: ("C", 0.3), 100: ("G", 0.3), 160: ("T", 0.4), 230: ("C", 0.35), 280: ("A", 0.2)}
+    run_plpindel("plpindel_consindel", 72, 330, 300, sites2, mq_mix, ["--no-default-filter"], planted=planted2)
 
 
 def main_baq():

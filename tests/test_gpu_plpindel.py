@@ -32,6 +32,7 @@ def test_indel_columns_match_plpsummary(caller, path):
         c = col_of[e["pos0"]]
         ctx = "pos0 %d" % e["pos0"]
         assert chr(cols.ref_base[c]) == e["ref"], ctx
+        assert bool(cols.cons_indel[c]) == (e["cons"][0] in "+-"), (ctx, e["cons"])        # plp.c:1236-1270
         for k in ("coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun"):
             assert int(getattr(cols, k)[c]) == e[k], (ctx, k)
         for sd, sn in enumerate(("ins", "dels")):
@@ -49,11 +50,12 @@ def test_indel_columns_match_plpsummary(caller, path):
                                    ("rd_mq", ev["mq"]), ("rd_sq", gu.dec(ev["sq"]).tolist())):
                     assert S[name][r0:r1].tolist() == want, (ctx, ev["key"], name)
                 n_ev += 1
-    assert n_ev >= 25
+    assert n_ev >= 20
     # columns the binary printed no event for have none here either
     with_ev = {e["pos0"] for e in fx["columns"]}
     for c, p in enumerate(col_pos):
         if int(p) not in with_ev:
+            assert not cols.cons_indel[c]
             assert cols.sides[0]["ev_off"][c] == cols.sides[0]["ev_off"][c + 1]
             assert cols.sides[1]["ev_off"][c] == cols.sides[1]["ev_off"][c + 1]
 
@@ -86,7 +88,7 @@ def test_reads_to_full_vcf_device_chain(caller, path):
     ilines, ntests = _indel_lines(la, caller, cols, col_pos, conf)
     dt = la.pileup_snv_tracks(caller, reads, ref, 0, len(ref), lb=[t[0] for t in tags])
     assert dt.col_pos.tolist() == col_pos.tolist()
-    # call_vars skips the SNVs of a column whose consensus is an indel (lofreq_call.c:928-931); none in this fixture
+    la.skip_snv_columns(caller, cols.cons_indel)    # call_vars: no SNVs where the consensus is an indel (:928-931)
     recs, _, st = caller.call_snvs(dt, conf)
     assert conf.num_snv_tests == fx["all"]["num_tests"]["snv"] and ntests == fx["all"]["num_tests"]["indel"]
     keep = la.filter_records(recs, la.snvqual_thresh(conf.sig, conf.bonf_subst), apply_defaults=False)
