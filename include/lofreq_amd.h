@@ -380,6 +380,17 @@ void lfq_holm_bonf_corr(double *pvals, int64_t n, double alpha, int64_t num_test
 int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thresh,
                        int apply_defaults, uint8_t *keep);
 
+/* --- `lofreq uniq --use-det-lim` (uniq_snv, lofreq_uniq.c:222-333): the second consumer of the
+ * column boundary.  For every column (the pileup of the OTHER sample at a variant's position, built with uniq's
+ * own mpileup settings: no BAQ, MAPQ >= 1, lofreq_uniq.c:461-465) and the variant's allele frequency af[col]:
+ * would the variant have been detectable here?  The default varcall_conf (init_varcall_conf), the first alt count
+ * replaced by (int)(af * n_err_probs) (float product, truncated), snpcaller(bonf 1, alpha 0.01f);
+ * detectable[col] = pvalue * 1 < 0.01f, the condition under which uniq_snv adds the UNIQ flag.  Only the 'N'
+ * reference gate applies (uniq_snv does not go through call_snvs).  pvalue_or_null[col] gets snpcaller's value for
+ * the columns that were emitted (LDBL_MAX elsewhere: K = 0, or pruned as not significant). */
+int lfq_uniq_detlim_batch(lfq_ctx *ctx, const lfq_tracks *tracks, int tracks_on_device, const float *af,
+                          uint8_t *detectable, long double *pvalue_or_null);
+
 /* --- synthetic workload (bench / tests): fills device tracks per include/lofreq_synth.h --- */
 int lfq_synth_fill_device(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t plant_period,
                           int64_t col_begin, int64_t ncols, uint8_t *d_nt, uint8_t *d_bq,

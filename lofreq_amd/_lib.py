@@ -113,6 +113,7 @@ EXPORTS = [
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
+    "lfq_uniq_detlim_batch",
 ]
 
 _lib = None
@@ -180,6 +181,7 @@ def load():
     L.lfq_pileup_indel_columns.argtypes = [vp, C.POINTER(PileupReads), C.POINTER(PileupIndelTags), C.c_int64, C.c_int64,
                                            C.c_int, C.POINTER(C.POINTER(IndelColumnsC)), vp]
     L.lfq_pileup_skip_snv_columns.argtypes = [vp, vp, C.c_int64]
+    L.lfq_uniq_detlim_batch.argtypes = [vp, C.POINTER(Tracks), C.c_int, vp, vp, vp]
     L.lfq_source_qual_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, C.c_int, vp, vp, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

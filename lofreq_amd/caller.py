@@ -144,6 +144,19 @@ class SnvCaller:
         _lib.check(rc, "lfq_call_snvs_batch")
         return rec[: n.value].copy(), counts, st
 
+    def uniq_detlim(self, batch, af):
+        """`lofreq uniq --use-det-lim` (uniq_snv, lofreq_uniq.c:274-333) over a batch of columns: af[col] = the
+        variant's allele frequency -> (detectable uint8 per column: the UNIQ condition, p-values longdouble)"""
+        t = batch._tracks()
+        af = np.ascontiguousarray(af, np.float32)
+        assert len(af) == batch.ncols
+        det = np.zeros(max(batch.ncols, 1), np.uint8)
+        pv = np.zeros(max(batch.ncols, 1), np.longdouble)
+        rc = self.L.lfq_uniq_detlim_batch(self.h, C.byref(t), 1 if batch.on_device else 0, C.c_void_p(af.ctypes.data),
+                                          C.c_void_p(det.ctypes.data), C.c_void_p(pv.ctypes.data))
+        _lib.check(rc, "lfq_uniq_detlim_batch")
+        return det[: batch.ncols], pv[: batch.ncols]
+
     # -- layer 1: kernels only, device-resident in and out --------------------------------------
     def snv_batch_device(self, batch, conf, d_counts, d_pvals, pvals_capacity, stream=None):
         assert batch.on_device

@@ -103,6 +103,9 @@ struct lfq_ctx {
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     LfqIndelColsOwned *plp_indel;
+    const float *detlim_af;          /* device: per-column allele frequency while lfq_uniq_detlim_batch runs, else null */
+    float *d_detlim;
+    int64_t detlim_cap;
     int32_t *d_plp_nb;               /* num_bases of the tracks last handed out, and their column count */
     int64_t plp_ncols;
     /* BAQ scratch (lfq_baq_batch), kept between calls */
@@ -387,6 +390,7 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_plp_in) (void)hipFree(c->d_plp_in);
         if (c->d_plp_out) (void)hipFree(c->d_plp_out);
         delete c->plp_indel;
+        if (c->d_detlim) (void)hipFree(c->d_detlim);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
         if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);
@@ -464,6 +468,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     hipStream_t side_i[2] = {side0, side1};
     LfqParams P;
     LFQ_TRY(make_params(conf, tr, &P, indel_mode));
+    P.detlim_af = indel_mode ? nullptr : c->detlim_af;      /* set only inside lfq_uniq_detlim_batch */
     LFQ_TRY(ensure_workspace(c, tr->ncols));
 
     LfqTracksDev T;
@@ -1760,6 +1765,66 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
         T.rd_aq = S.rd_aq.data();
         T.rd_mq = S.rd_mq.data();
         T.rd_sq = S.rd_sq.data();
+    }
+    return LFQ_OK;
+}
+
+/* uniq_snv with --use-det-lim (lofreq_uniq.c:274-333) for a batch of columns: the default varcall_conf
+ * (init_varcall_conf), alt_counts = {(int)(af * n_err_probs), 0, 0}, snpcaller(bonf 1, alpha 0.01f) */
+int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, const float *af,
+                          uint8_t *detectable, long double *pvalue_or_null)
+{
+    if (!c || !tr || !af || !detectable || tr->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    const int64_t ncols = tr->ncols;
+    if (ncols == 0) {
+        return LFQ_OK;
+    }
+    for (int64_t i = 0; i < ncols; i++) {
+        if (!(af[i] >= 0.0f && af[i] <= 1.0f)) {
+            return LFQ_ERR_INVALID;                     /* the reference rejects such an AF too (:262-268) */
+        }
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    lfq_conf conf;
+    lfq_conf_init(&conf);
+    conf.bonf_dynamic = 0;
+    conf.bonf_subst = 1;                                /* int bonf = 1 (:286) */
+    conf.sig = 0.01f;                                   /* float alpha = 0.01 (:287) */
+    lfq_tracks dev;
+    LFQ_TRY(stage_tracks(c, tr, tracks_on_device, &dev));
+    LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
+    LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
+    LFQ_TRY(grow(&c->d_detlim, &c->detlim_cap, ncols));
+    LFQ_TRY_HIP(hipMemcpyAsync(c->d_detlim, af, (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
+    c->detlim_af = c->d_detlim;
+    int rc = lfq_snv_batch_device(c, &conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream);
+    c->detlim_af = nullptr;
+    LFQ_TRY(rc);
+    lfq_batch_stats st;
+    LFQ_TRY(lfq_batch_finish(c, &st));
+    std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
+    if (st.n_pvals > 0) {
+        LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals), hipMemcpyDeviceToHost));
+    }
+    memset(detectable, 0, (size_t)ncols);
+    if (pvalue_or_null) {
+        for (int64_t i = 0; i < ncols; i++) {
+            pvalue_or_null[i] = LDBL_MAX;               /* snpcaller's "not computed" (snpcaller.c:1100-1103) */
+        }
+    }
+    const int bonf = 1;
+    const float alpha = 0.01f;
+    for (const lfq_col_pvals &p : h_pv) {
+        if (p.col < 0 || p.col >= ncols || p.status[0] == LFQ_PV_NONE) {
+            continue;
+        }
+        const long double pv = lfq_pvalue_from_log(p.logp[0], p.status[0]);
+        if (pvalue_or_null) {
+            pvalue_or_null[p.col] = pv;
+        }
+        detectable[p.col] = (pv * (float)bonf < alpha) ? 1 : 0;         /* :314 */
     }
     return LFQ_OK;
 }

@@ -39,6 +39,9 @@ struct LfqParams {
     double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
     int32_t seg_max;          /* row segments per split column, 2..LFQ_SEG_MAX */
     int32_t phase1_chunks;    /* mid class: 64-row chunks run unsplit before a surviving column is cut up */
+    /* `lofreq uniq --use-det-lim` (lofreq_uniq.c:274-333): per column the assumed allele frequency; the first alt
+     * count becomes (int)(af * n_err_probs), the others 0, and only the 'N' reference gate applies.  null = off */
+    const float *detlim_af;
 };
 
 struct LfqTracksDev {

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
         r.pad_[0] = r.pad_[1] = 0;
         r.median_ref_bq = -1;
         r.coverage = cov;
-        r.gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov);
+        r.gated = (ref_code < 0) || (!P.detlim_af && (((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov)));
         LfqAcc a;
 #pragma unroll
         for (int x = 0; x < 4; x++) {
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
     r.median_ref_bq = -1;
     r.coverage = cov;
     /* gates: lofreq_call.c:892/754 (ref N; non-ACGT refs are N, plp.c:819-823), :930, :747 */
-    r.gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov);
+    r.gated = (ref_code < 0) || (!P.detlim_af && (((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov)));
 
     LfqAcc a;
 #pragma unroll
@@ -407,6 +407,10 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             r.alt_fw[2] = (int)LFQ_PICK(fw, x2);
 #undef LFQ_PICK
             r.n_err_probs = (int)(filt[0] + filt[1] + filt[2] + filt[3]);
+            if (P.detlim_af) {                       /* lofreq_uniq.c:297-301: float product, truncated */
+                r.alt_counts[0] = (int)(P.detlim_af[col] * (float)r.n_err_probs);
+                r.alt_counts[1] = r.alt_counts[2] = 0;
+            }
             const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
             r.kmax = kmax;
             r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
@@ -713,7 +717,7 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
     if (const char *e = getenv("LFQ_COUNT_MULTI_BELOW")) {
         multi_below = atol(e);
     }
-    if (!p.general && max_col_obs > 0 && max_col_obs < multi_below) {
+    if (!p.general && !p.detlim_af && max_col_obs > 0 && max_col_obs < multi_below) {
         const unsigned blocks = (unsigned)((c1 - c0 + 15) / 16);
         hipLaunchKernelGGL(lfq_count_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
                            d_flags, c0, c1);

@@ -1470,3 +1470,49 @@ done:
     free(ep);
     return src_qual;
 }
+
+/* ---- `lofreq uniq --use-det-lim`: uniq_snv, lofreq_uniq.c:222-333 ------------------------
+ * per column: default varcall_conf, plp_to_errprobs, alt_counts = {af * num_err_probs (float product, truncated),
+ * 0, 0}, snpcaller(bonf 1, alpha (double)0.01f, -1); flag[col] = pvalues[0] * (float)bonf < alpha (:314), the
+ * condition for the UNIQ tag.  Pinned against `lofreq uniq --use-det-lim --output-all` of the 2.1.4 binary
+ * (tests/golden/uniq_*.json). */
+int orc_uniq_detlim_batch(const uint8_t *nt, const uint8_t *bq, const uint8_t *baq, const uint8_t *mq,
+                          const uint8_t *sq, const uint64_t *col_off, const uint8_t *ref_base, int64_t ncols,
+                          const float *af, uint8_t *flag, long double *pvalue)
+{
+    int64_t c;
+    for (c = 0; c < ncols; c++) {
+        const uint64_t o0 = col_off[c];
+        const int64_t n_obs = (int64_t)(col_off[c + 1] - o0);
+        orc_conf conf;
+        double *ep;
+        int n_ep = 0, alt_base[3], alt_counts[3], alt_raw[3];
+        long double pv[3];
+        const int bonf = 1;
+        const float alpha = 0.01;                                   /* :286-287 */
+        flag[c] = 0;
+        if (pvalue) {
+            pvalue[c] = LDBL_MAX;
+        }
+        if (n_obs < 1 || ref_base[c] == 'N') {                      /* :254-256; an 'N' reference has no variant */
+            continue;
+        }
+        orc_conf_init(&conf);                                       /* init_varcall_conf, :289 */
+        ep = (double *)malloc((size_t)n_obs * sizeof(double));
+        if (orc_col_errprobs(ep, &n_ep, alt_base, alt_counts, alt_raw, nt + o0, bq + o0, baq ? baq + o0 : NULL,
+                             mq + o0, sq ? sq + o0 : NULL, n_obs, (char)ref_base[c], &conf)) {
+            free(ep);
+            return -1;
+        }
+        /* NB no qsort here: uniq_snv hands the probabilities to snpcaller in plp_to_errprobs order (:293-305) */
+        alt_counts[0] = af[c] * n_ep;                               /* :300 */
+        alt_counts[1] = alt_counts[2] = 0;
+        orc_snpcaller(pv, NULL, ep, n_ep, alt_counts, bonf, alpha, NULL);       /* :303 */
+        if (pvalue) {
+            pvalue[c] = pv[0];
+        }
+        flag[c] = (pv[0] * (float)bonf < alpha) ? 1 : 0;            /* :314 */
+        free(ep);
+    }
+    return 0;
+}

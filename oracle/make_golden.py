@@ -569,6 +569,60 @@ def main_plpindel():
     run_plpindel("plpindel_consindel", 72, 330, 300, sites2, mq_mix, ["--no-default-filter"], planted=planted2)
 
 
+# ---- lofreq uniq --use-det-lim -------------------------------------------------------------
+
+def run_uniq(name, seed, glen, nreads, mapqs):
+    """variants with assorted AFs against a BAM: `lofreq uniq --use-det-lim --output-all` says which ones would
+    have been detectable (UNIQ flag); the columns are what uniq's own mpileup sees (no BAQ, MAPQ >= 1,
+    lofreq_uniq.c:461-465) = `plpsummary -B -m 1`"""
+    with tempfile.TemporaryDirectory() as tmp:
+        genome = write_fixture(tmp, seed, glen, nreads, {}, mapqs)
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        with open(os.path.join(tmp, "t.bam"), "wb") as f:      # alnqual -b: the handiest SAM -> BAM converter here
+            subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
+        subprocess.check_call([LOFREQ, "index", "t.bam"], cwd=tmp)
+        rng = np.random.default_rng(seed + 5)
+        afs = [0.001, 0.004, 0.008, 0.012, 0.02, 0.03, 0.05, 0.08, 0.15, 0.3, 0.6, 1.0]
+        var = []
+        for p0 in range(5, glen - 5, 3):
+            ref = genome[p0]
+            alt = str(rng.choice([c for c in "ACGT" if c != ref]))
+            var.append((p0, ref, alt, float(rng.choice(afs))))
+        with open(os.path.join(tmp, "v.vcf"), "w") as f:
+            f.write("##fileformat=VCFv4.0\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+            for p0, ref, alt, af in var:
+                f.write("chr1\t%d\t.\t%s\t%s\t100\tPASS\tDP=100;AF=%f\n" % (p0 + 1, ref, alt, af))
+        res = subprocess.run([LOFREQ, "uniq", "--use-det-lim", "--output-all", "-v", "v.vcf", "-o", "-", "t.bam"],
+                             cwd=tmp, check=True, capture_output=True, text=True).stdout
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", "-B", "-m", "1", "t.bam"], cwd=tmp, check=True,
+                             capture_output=True, text=True).stdout
+    uniq = {}
+    for line in res.splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split("\t")
+        uniq[int(f[1]) - 1] = "UNIQ" in f[7].split(";")
+    cols = {c["pos0"]: c for c in parse_plpsummary(plp)}
+    out = []
+    for p0, ref, alt, af in var:
+        c = cols.get(p0)
+        if c is None or p0 not in uniq:
+            continue
+        o = {nt: {"bq": enc(tr.get("BQ", [])), "mq": enc_mq(tr.get("MQ", []))} for nt, tr in c["obs"].items()}
+        out.append({"pos0": p0, "ref": ref, "alt": alt, "af": "%f" % af, "fwrv": c["fwrv"], "obs": o, "uniq": uniq[p0]})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "encoding": "bq: chr(33 + value); mq: 2 hex digits; af: the string written to the VCF (strtof)",
+           "variants": out}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d variants, %d UNIQ, %d bytes" % (name, len(out), sum(v["uniq"] for v in out), os.path.getsize(path)))
+
+
+def main_uniq():
+    mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
+    run_uniq("uniq_detlim", 81, 400, 700, mq_mix)
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -591,6 +645,8 @@ def main():
         return main_srcq()
     if "--plpindel-only" in sys.argv:
         return main_plpindel()
+    if "--uniq-only" in sys.argv:
+        return main_uniq()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]

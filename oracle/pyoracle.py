@@ -422,3 +422,30 @@ def source_qual(pos, cigar, seq, qual, ref_bytes, nonmatch_qual=-1, min_bq=6, ig
     return L.orc_source_qual(int(pos), cg.ctypes.data, len(cg), seq.ctypes.data, qual.ctypes.data, len(seq),
                              ref_bytes, len(ref_bytes), int(nonmatch_qual), int(min_bq),
                              ign.ctypes.data if ign is not None else None)
+
+
+def uniq_detlim_batch(nt, bq, baq, mq, sq, col_off, ref_base, af):
+    """orc_uniq_detlim_batch (uniq_snv with --use-det-lim, lofreq_uniq.c:222-333) -> (flags uint8, pvalues longdouble)"""
+    col_off = np.ascontiguousarray(col_off, dtype=np.uint64)
+    ncols = len(col_off) - 1
+    keep, ptrs = [], []
+    for a in (nt, bq, baq, mq, sq):
+        if a is None:
+            ptrs.append(None)
+        else:
+            arr = np.ascontiguousarray(a, np.uint8)
+            keep.append(arr)
+            ptrs.append(arr.ctypes.data)
+    rb = np.ascontiguousarray(np.frombuffer(ref_base, np.uint8) if isinstance(ref_base, (bytes, bytearray)) else ref_base,
+                              np.uint8)
+    af = np.ascontiguousarray(af, np.float32)
+    flag = np.zeros(max(ncols, 1), np.uint8)
+    pv = np.zeros(max(ncols, 1), np.longdouble)
+    L = lib()
+    L.orc_uniq_detlim_batch.restype = C.c_int
+    L.orc_uniq_detlim_batch.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_uniq_detlim_batch(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], col_off.ctypes.data, rb.ctypes.data, ncols,
+                                 af.ctypes.data, flag.ctypes.data, pv.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("orc_uniq_detlim_batch failed: %d" % rc)
+    return flag[:ncols], pv[:ncols]

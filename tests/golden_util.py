@@ -197,3 +197,33 @@ def load_plpindel(path, with_alnqual_tags=True):
             d.update(lb=tag(r[8]), ai=tag(r[9]), ad=tag(r[10]))
         reads.append(d)
     return fx, reads
+
+
+def uniq_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "uniq_*.json")))
+
+
+def load_uniq(path):
+    """-> (fixture, packed host tracks of the variants' columns (no BAQ: uniq's mpileup), af float32 per column)"""
+    fx = json.load(open(path))
+    nts, bqs, mqs, off, refs, af = [], [], [], [0], [], []
+    for v in fx["variants"]:
+        n_col = 0
+        for code, nt in enumerate("ACGTN"):
+            o = v["obs"].get(nt)
+            if not o:
+                continue
+            bq = dec(o["bq"])
+            n = len(bq)
+            fw = v["fwrv"][nt][0]
+            strand = (np.arange(n) >= fw).astype(np.uint8)
+            nts.append(np.full(n, code, np.uint8) | (strand << 3))
+            bqs.append(bq.astype(np.uint8))
+            mqs.append(np.array([int(o["mq"][2 * i:2 * i + 2], 16) for i in range(n)], np.uint8))
+            n_col += n
+        off.append(off[-1] + n_col)
+        refs.append(ord(v["ref"]))
+        af.append(np.float32(v["af"]))          # strtof of the VCF's AF string (lofreq_uniq.c:262)
+    host = dict(nt=np.concatenate(nts), bq=np.concatenate(bqs), baq=None, mq=np.concatenate(mqs), sq=None,
+                col_off=np.asarray(off, np.uint64), ref_base=np.asarray(refs, np.uint8))
+    return fx, host, np.asarray(af, np.float32)
