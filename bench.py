@@ -35,8 +35,8 @@ SEED = 0x9E3779B97F4A7C15 ^ (3 << 32)   # SURVEY 8d seed formula, config id 3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--depth", type=int, default=10000)
     ap.add_argument("--cols", type=int, default=1000000, help="columns per GPU (region shard)")
     ap.add_argument("--plant-period", type=int, default=997)

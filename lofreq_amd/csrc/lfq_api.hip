@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -785,6 +786,10 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
         return LFQ_OK;
     }
+    static const bool timing = getenv("LFQ_TIMING") != nullptr;     /* host phases of one call to stderr */
+    double tp[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    tp[0] = now();
     LFQ_TRY_HIP(hipSetDevice(c->device));
     const int64_t ncols = tr->ncols;
     lfq_tracks dev;
@@ -792,6 +797,7 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
     LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
     LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
     LFQ_TRY(lfq_snv_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
+    tp[1] = now();
     lfq_batch_stats st;
 #ifdef LFQ_TRACE
     fprintf(stderr, "[lfq] launched, waiting\n");
@@ -801,6 +807,7 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
     fprintf(stderr, "[lfq] finished: tested %ld pvals %ld\n", (long)st.n_tested, (long)st.n_pvals);
 #endif
 
+    tp[2] = now();
     std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
     if (st.n_pvals > 0) {
         LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals),
@@ -810,6 +817,7 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         LFQ_TRY_HIP(hipMemcpy(h_counts_or_null, c->d_counts, (size_t)ncols * sizeof(lfq_col_counts),
                               hipMemcpyDeviceToHost));
     }
+    tp[3] = now();
     /* the reference base of a surviving column travels in its record (lfq_col_pvals.ref_base) */
     const uint8_t *ref_host = tracks_on_device ? nullptr : tr->ref_base;
 #ifdef LFQ_TRACE
@@ -820,6 +828,11 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
 #ifdef LFQ_TRACE
     fprintf(stderr, "[lfq] finalized rc=%d n=%ld\n", rc, (long)*n_records);
 #endif
+    tp[4] = now();
+    if (timing) {
+        fprintf(stderr, "[lfq timing] launch %.3f  wait %.3f  d2h %.3f  finalize %.3f ms (kernels %.3f ms, %ld records)\n",
+                tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], (double)c->times.ms_total, (long)st.n_pvals);
+    }
     /* Bonferroni bookkeeping of the per-column loop (lofreq_call.c:794-801) */
     if (st.n_tested > 0) {
         if (conf->bonf_dynamic) {
@@ -1546,7 +1559,19 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
             for (const Ev &e : evs) {
                 has_ev[(size_t)(e.pos - region_begin)] = 1;
             }
+            size_t n_cov = 0;
+            for (int64_t p = 0; p < width; p++) {
+                n_cov += h[0][(size_t)p] > 0;
+            }
+            for (auto *v : {&O.cov, &O.tails, &O.non_indels, &O.n_ins, &O.n_dels, &O.hrun}) {
+                v->reserve(n_cov);
+            }
+            O.ref_base.reserve(n_cov);
             for (int sd = 0; sd < 2; sd++) {
+                O.side[sd].non_fw.reserve(n_cov);
+                O.side[sd].non_rv.reserve(n_cov);
+                O.side[sd].ne_off.reserve(n_cov + 1);
+                O.side[sd].ev_off.reserve(n_cov + 1);
                 O.side[sd].ne_off.push_back(0);
             }
             for (int64_t p = 0; p < width; p++) {

@@ -51,3 +51,22 @@ dtk = DeviceTracks(t, col_pos[: t.ncols].copy())
 conf = la.VarcallConf()
 t0 = time.perf_counter(); recs, _, st = caller.call_snvs(dtk, conf, records_capacity=1 << 16); dt = time.perf_counter() - t0
 print("call on the resident tracks: %d columns, %d tested, %d records in %.4f s" % (dtk.ncols, st.n_tested, len(recs), dt))
+
+# ---- source quality of the same reads (lofreq call -s), then the indel fields of the pileup
+sq = np.zeros(n, np.int32); sqb = np.zeros(n, np.uint8)
+for it in range(3):
+    t0 = time.perf_counter(); rc = L.lfq_source_qual_batch(caller.h, C.byref(rd), -1, 6, None, sq.ctypes.data, sqb.ctypes.data); dt = time.perf_counter() - t0
+    print("source quality: %d reads in %.3f s (%.1f M reads/s, host buffers in and out), rc %d; %d reads ran the DP" % (n, dt, n / dt / 1e6, rc, int(((sq >= 0) & (sq < 49314)).sum())))
+m = 3000
+t0 = time.perf_counter()
+for i in range(m):
+    o = orc.source_qual(int(pos[i]), [("M", rl)], seq[i], qual[i], gen_ascii)
+    assert o == sq[i], (i, o, sq[i])
+dt = time.perf_counter() - t0
+print("cpu oracle source quality (1 thread, via ctypes): %d reads in %.2f s -> %.0f reads/s, identical" % (m, dt, m / dt))
+bi = rng.integers(33 + 25, 33 + 50, n * rl).astype(np.uint8); bd = rng.integers(33 + 25, 33 + 50, n * rl).astype(np.uint8)
+tg = _lib.PileupIndelTags(); tg.bi = bi.ctypes.data; tg.bd = bd.ctypes.data
+outp = C.POINTER(_lib.IndelColumnsC)()
+for it in range(3):
+    t0 = time.perf_counter(); rc = L.lfq_pileup_indel_columns(caller.h, C.byref(pr), C.byref(tg), 0, glen, 0, C.byref(outp), col_pos.ctypes.data); dt = time.perf_counter() - t0
+    print("indel fields of the pileup: %d reads -> %d columns in %.3f s (%.1f M reads/s), rc %d" % (n, outp.contents.ncols, dt, n / dt / 1e6, rc))
