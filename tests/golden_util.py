@@ -227,3 +227,76 @@ def load_uniq(path):
     host = dict(nt=np.concatenate(nts), bq=np.concatenate(bqs), baq=None, mq=np.concatenate(mqs), sq=None,
                 col_off=np.asarray(off, np.uint64), ref_base=np.asarray(refs, np.uint8))
     return fx, host, np.asarray(af, np.float32)
+
+
+def py_indel_pileup(reads, ref, min_plp_idq=0):
+    """Plain restatement of the indel part of compile_plp_col (plp.c:1019-1192) over htslib's pileup entries
+    (resolve_cigar2): -> {pos0: dict(cov, tails, non_indels, n_ins, n_dels, non_fw[2], non_rv[2], ne[2] = [(q, mq)],
+    ev[2] = ordered {key: [(q, aq, mq, sq, rev)]})} -- the independent check of lfq_pileup_indel_columns."""
+    cols = {}
+
+    def col(p):
+        return cols.setdefault(p, dict(cov=0, tails=0, non_indels=0, n_ins=0, n_dels=0, non_fw=[0, 0], non_rv=[0, 0],
+                                       ne=[[], []], ev=[{}, {}]))
+    for r in reads:
+        cig = r["cigar"]
+        end = r["pos0"] + sum(l for o, l in cig if o in "MDN=X") - 1
+        x, y = r["pos0"], 0
+        lq = len(r["seq"])
+        rev = 1 if r["reverse"] else 0
+        for k, (op, l) in enumerate(cig):
+            if op in "M=XDN":
+                is_del = op in "DN"
+                indel_last = 0
+                if k + 1 < len(cig):
+                    o2, l2 = cig[k + 1]
+                    if o2 == "D":
+                        indel_last = -l2
+                    elif o2 == "I":
+                        indel_last = l2
+                    elif o2 == "P" and k + 2 < len(cig):
+                        l3 = 0
+                        for o3, ll in cig[k + 2:]:
+                            if o3 == "I":
+                                l3 += ll
+                            elif o3 in "DMN=X":
+                                break
+                        indel_last = l3
+                for j in range(l):
+                    c = col(x + j)
+                    qpos = min(y if is_del else y + j, lq - 1)
+                    iq = int(r["bi"][qpos]) - 33 if r.get("bi") is not None else 0
+                    dq = int(r["bd"][qpos]) - 33 if r.get("bd") is not None else 0
+                    indel = indel_last if j == l - 1 else 0
+                    c["cov"] += 1
+                    if not is_del and x + j == end:
+                        c["tails"] += 1
+                    if iq < min_plp_idq or dq < min_plp_idq:
+                        continue
+                    mq, sq = r["mapq"], (-1 if r.get("sq") is None else r["sq"])
+                    if indel > 0:
+                        key = "".join("ACGTN"[b] for b in r["seq"][qpos + 1:qpos + 1 + indel])
+                        aq = int(r["ai"][qpos]) - 33 if r.get("ai") is not None else -1
+                        c["ev"][0].setdefault(key, []).append((iq, aq, mq, sq, rev))
+                        c["n_ins"] += 1
+                        c["ne"][1].append((dq, mq))
+                        c["non_rv" if rev else "non_fw"][1] += 1
+                    elif indel < 0:
+                        key = "".join((ref[g] if g < len(ref) else "N") for g in range(x + j + 1, x + j + 1 - indel)).upper()
+                        aq = int(r["ad"][qpos]) - 33 if r.get("ad") is not None else -1
+                        c["ev"][1].setdefault(key, []).append((dq, aq, mq, sq, rev))
+                        c["n_dels"] += 1
+                        c["ne"][0].append((iq, mq))
+                        c["non_rv" if rev else "non_fw"][0] += 1
+                    else:
+                        c["non_indels"] += 1
+                        c["ne"][0].append((iq, mq))
+                        c["ne"][1].append((dq, mq))
+                        for sd in range(2):
+                            c["non_rv" if rev else "non_fw"][sd] += 1
+                x += l
+                if not is_del:
+                    y += l
+            elif op in "IS":
+                y += l
+    return cols

@@ -100,3 +100,100 @@ def test_reads_to_full_vcf_device_chain(caller, path):
                                                              filter_str="PASS").rstrip("\n"))))
     merged = [l[2] for l in sorted(ilines + slines, key=lambda t: (t[0], t[1]))]     # indels first within a column (:896)
     assert merged == fx["all"]["vcf"]
+
+
+def _random_indel_reads(rng, n, glen, genome):
+    reads = []
+    for i in range(n):
+        pos = int(rng.integers(0, glen - 400))
+        cigar, seq, x = [], [], pos
+        if rng.random() < 0.2:
+            k = int(rng.integers(1, 6)); cigar.append(("S", k)); seq.extend(rng.integers(0, 4, k).tolist())
+        nops = int(rng.integers(1, 6))
+        for j in range(nops):
+            l = int(rng.integers(1, 40))
+            cigar.append((str(rng.choice(["M", "M", "M", "=", "X"])), l))
+            seq.extend(int(genome[x + t]) if rng.random() > 0.02 else int(rng.integers(0, 5)) for t in range(l))
+            x += l
+            if j + 1 < nops:
+                u = rng.random()
+                if u < 0.35:
+                    k = int(rng.integers(1, 4)); cigar.append(("I", k)); seq.extend(rng.integers(0, 4, k).tolist())
+                elif u < 0.7:
+                    k = int(rng.integers(1, 4)); cigar.append(("D", k)); x += k
+                    if rng.random() < 0.15:        # a deletion directly followed by an insertion
+                        k = int(rng.integers(1, 3)); cigar.append(("I", k)); seq.extend(rng.integers(0, 4, k).tolist())
+                elif u < 0.8:
+                    k = int(rng.integers(5, 30)); cigar.append(("N", k)); x += k
+                elif u < 0.85:
+                    cigar.append(("P", 1)); k = int(rng.integers(1, 3)); cigar.append(("I", k))
+                    seq.extend(rng.integers(0, 4, k).tolist())
+        if rng.random() < 0.2:
+            k = int(rng.integers(1, 6)); cigar.append(("S", k)); seq.extend(rng.integers(0, 4, k).tolist())
+        if rng.random() < 0.1:
+            cigar.append(("H", 2))
+        m = len(seq)
+        tag = lambda lo, hi: rng.integers(33 + lo, 33 + hi, m).astype(np.uint8)
+        reads.append({"pos0": pos, "cigar": cigar, "seq": np.asarray(seq, np.uint8),
+                      "qual": rng.integers(2, 42, m).astype(np.uint8), "mapq": int(rng.choice([60, 60, 30, 0, 255])),
+                      "reverse": bool(rng.random() < 0.5),
+                      "bi": tag(10, 50) if rng.random() < 0.9 else None, "bd": tag(10, 50) if rng.random() < 0.9 else None,
+                      "ai": tag(0, 60) if rng.random() < 0.7 else None, "ad": tag(0, 60) if rng.random() < 0.7 else None,
+                      "sq": int(rng.choice([0, 3, 12, 49314])) if rng.random() < 0.5 else None})
+    reads.sort(key=lambda r: r["pos0"])
+    return reads
+
+
+@pytest.mark.parametrize("min_idq,begin,end", [(0, 0, 3000), (25, 0, 3000), (0, 700, 1900)])
+def test_indel_columns_random_reads_vs_plain_restatement(caller, min_idq, begin, end):
+    """every CIGAR operation incl. N, P and D followed by I, missing tags, the min_plp_idq gate, a sub-region:
+    all fields against the pure-Python restatement of compile_plp_col's indel part (tests/golden_util.py)"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(5)
+    glen = 3000
+    genome = rng.integers(0, 4, glen).astype(np.uint8)
+    genome[1000:1012] = 2                                   # a homopolymer for hrun
+    ref = "".join("ACGT"[c] for c in genome)
+    reads = _random_indel_reads(rng, 1500, glen, genome)
+    want = gu.py_indel_pileup(reads, ref, min_plp_idq=min_idq)
+    cols, col_pos = la.pileup_indel_columns(caller, reads, ref.encode(), begin, end, min_plp_idq=min_idq)
+    assert col_pos.tolist() == sorted(p for p in want if begin <= p < end)
+    n_ev = 0
+    for c, p in enumerate(col_pos.tolist()):
+        w = want[p]
+        got = {k: int(getattr(cols, k)[c]) for k in ("coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels")}
+        assert got == {"coverage_plp": w["cov"], "num_tails": w["tails"], "num_non_indels": w["non_indels"],
+                       "num_ins": w["n_ins"], "num_dels": w["n_dels"]}, p
+        for sd in range(2):
+            S = cols.sides[sd]
+            assert (int(S["non_fw"][c]), int(S["non_rv"][c])) == (w["non_fw"][sd], w["non_rv"][sd]), (p, sd)
+            e0, e1 = int(S["ev_off"][c]), int(S["ev_off"][c + 1])
+            assert [cols.keys[sd][i] for i in range(e0, e1)] == list(w["ev"][sd].keys()), (p, sd)
+            a, b = int(S["ne_off"][c]), int(S["ne_off"][c + 1])
+            if w["ev"][0] or w["ev"][1]:
+                assert sorted(zip(S["ne_q"][a:b].tolist(), S["ne_mq"][a:b].tolist())) == sorted(w["ne"][sd]), (p, sd)
+            else:
+                assert a == b
+            for i, key in zip(range(e0, e1), w["ev"][sd]):
+                r0, r1 = int(S["rd_off"][i]), int(S["rd_off"][i + 1])
+                members = w["ev"][sd][key]
+                assert S["rd_q"][r0:r1].tolist() == [m[0] for m in members], (p, key)
+                assert S["rd_aq"][r0:r1].tolist() == [m[1] for m in members], (p, key)
+                assert S["rd_mq"][r0:r1].tolist() == [m[2] for m in members], (p, key)
+                assert S["rd_sq"][r0:r1].tolist() == [min(m[3], 32767) for m in members], (p, key)
+                assert int(S["ev_rv"][i]) == sum(m[4] for m in members) and int(S["ev_fw"][i]) == len(members) - int(S["ev_rv"][i])
+                n_ev += 1
+    assert n_ev > 300
+
+
+def test_indel_columns_empty_inputs(caller):
+    import lofreq_amd as la
+    cols, col_pos = la.pileup_indel_columns(caller, [], b"ACGT", 0, 4)
+    assert cols.ncols == 0 and len(col_pos) == 0
+    r = [{"pos0": 1, "cigar": [("M", 2)], "seq": np.array([1, 2], np.uint8), "qual": np.array([30, 30], np.uint8),
+          "mapq": 60, "reverse": False}]
+    cols, col_pos = la.pileup_indel_columns(caller, r, b"ACGT", 2, 2)          # empty region
+    assert cols.ncols == 0
+    cols, col_pos = la.pileup_indel_columns(caller, r, b"ACGT", 0, 4)          # no tags at all, no events
+    assert col_pos.tolist() == [1, 2] and cols.num_non_indels.tolist() == [1, 1] and cols.num_tails.tolist() == [0, 1]
+    assert len(cols.keys[0]) == len(cols.keys[1]) == 0 and not cols.cons_indel.any()
