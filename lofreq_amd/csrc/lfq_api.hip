@@ -1114,6 +1114,7 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
     LFQ_TRY_HIP(hipSetDevice(c->device));
     /* geometry of every read: alignment window and band width (bam_md_ext.c:312-380, :396-399) */
     std::vector<LfqBaqRead> h((size_t)n);
+    std::vector<int32_t> width((size_t)n, 0);
     int max_lq = 0, max_w = 0;
     for (int64_t r = 0; r < n; r++) {
         LfqBaqRead &o = h[(size_t)r];
@@ -1155,6 +1156,26 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
             if (b2 < abs(o.l_ref - l_qseq)) b2 = abs(o.l_ref - l_qseq);
             max_lq = std::max(max_lq, l_qseq);
             max_w = std::max(max_w, (b2 * 2 + 1) * 3 + 6);
+            width[(size_t)r] = (b2 * 2 + 1) * 3 + 6;
+        }
+    }
+    /* narrow-band reads (rows of at most LFQ_BAQ_LDS_CELLS cells) first: they run in the LDS variant */
+    static const bool use_lds = !(getenv("LFQ_BAQ_LDS") && atoi(getenv("LFQ_BAQ_LDS")) == 0);
+    std::vector<int32_t> order((size_t)n);
+    int64_t n_narrow = 0;
+    int max_lref_narrow = 0;
+    {
+        int64_t wi = n;
+        for (int64_t r = 0; r < n; r++) {
+            if (use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
+                order[(size_t)n_narrow++] = (int32_t)r;
+                max_lref_narrow = std::max(max_lref_narrow, h[(size_t)r].l_ref);
+            }
+        }
+        for (int64_t r = n - 1; r >= 0; r--) {
+            if (!(use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF)) {
+                order[(size_t)--wi] = (int32_t)r;
+            }
         }
     }
     const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
@@ -1168,7 +1189,7 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
     const int64_t o_reads = 0, o_soff = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_cig = o_soff + al((n + 1) * 8),
                   o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_ref = o_qual + al(n_bases),
                   o_out = o_ref + al(rd->ref_len + 1), o_q2p = o_out + al(n_bases), o_ai = o_q2p + al(1024),
-                  o_ad = o_ai + al(n_bases), o_fl = o_ad + al(n_bases), total = o_fl + al(n);
+                  o_ad = o_ai + al(n_bases), o_fl = o_ad + al(n_bases), o_ord = o_fl + al(n), total = o_ord + al(n * 4);
     LFQ_TRY_HIP(hipMalloc((void **)&d_blob, (size_t)total));
     int rc = LFQ_OK;
     auto up = [&](int64_t off, const void *src, int64_t bytes) {
@@ -1183,6 +1204,7 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
     up(o_qual, rd->qual, n_bases);
     up(o_ref, rd->ref, rd->ref_len);
     up(o_q2p, h_q2p, 1024);
+    up(o_ord, order.data(), n * 4);
     if (rc == LFQ_OK && (hipMemsetAsync(d_blob + o_out, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
                          || hipMemsetAsync(d_blob + o_ai, '~', (size_t)(o_fl - o_ai), c->stream) != hipSuccess
                          || hipMemsetAsync(d_blob + o_fl, 0, (size_t)al(n), c->stream) != hipSuccess)) {
@@ -1247,9 +1269,15 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
         A.scratch = d_scr;
         A.expect = d_expect;
         A.tmp8 = d_tmp8;
-        for (int64_t first = 0; rc == LFQ_OK && first < n; first += waves * 64) {
+        A.order = (const int32_t *)(d_blob + o_ord);
+        A.max_lref = max_lref_narrow;
+        for (int64_t first = 0; rc == LFQ_OK && first < n_narrow; first += waves * 64) {
             A.first_read = (int32_t)first;
-            rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), c->stream);
+            rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n_narrow - first), 1, c->stream);
+        }
+        for (int64_t first = n_narrow; rc == LFQ_OK && first < n; first += waves * 64) {
+            A.first_read = (int32_t)first;
+            rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
         }
     }
     if (rc == LFQ_OK && hipMemcpyAsync(lb_out, d_blob + o_out, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
