@@ -1,0 +1,66 @@
+"""-m gpu: repeated calls of every batch entry point leave the device memory where it was (no leak in the per-call
+staging), results stay identical from call to call, and invalid arguments come back as error codes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import util
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def _free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_repeated_calls_no_leak_and_deterministic(caller, oracle):
+    import lofreq_amd as la
+    fx, reads = gu.load_plpindel(gu.plpindel_fixtures()[0])
+    ref = fx["genome"].encode()
+    rng = np.random.default_rng(3)
+    host = util.random_batch(rng, 400, 50, 600)
+    first = None
+    base = None
+    for it in range(12):
+        tags = la.baq_batch(caller, reads, ref, extended=True, idaq=True)
+        sq, sqb = la.source_qual_batch(caller, reads, ref)
+        cols, col_pos = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+        dt = la.pileup_snv_tracks(caller, reads, ref, 0, len(ref), lb=[t[0] for t in tags], sq=sqb)
+        conf = la.VarcallConf()
+        recs, _, st = caller.call_snvs(dt, conf)
+        irecs, nt = la.call_indels(caller, cols, la.VarcallConf())
+        recs2, _, _ = caller.call_snvs(util.to_pileup_batch(la, host), la.VarcallConf())
+        det, _ = caller.uniq_detlim(util.to_pileup_batch(la, host), np.full(400, 0.05, np.float32))
+        sig = (b"".join(t[0].tobytes() for t in tags), sq.tobytes(), recs.tobytes(), irecs["qual"].tobytes(),
+               recs2.tobytes(), det.tobytes(), cols.sides[0]["rd_q"].tobytes())
+        if first is None:
+            first = sig
+        assert sig == first, "call %d differs from the first" % it
+        if it == 1:
+            base = _free_bytes()            # after the pools have grown to this workload
+    assert abs(_free_bytes() - base) < (64 << 20)
+
+
+def test_invalid_arguments_are_error_codes(caller):
+    from lofreq_amd import _lib
+    L = _lib.load()
+    vp = C.c_void_p
+    assert L.lfq_source_qual_batch(caller.h, None, -1, 6, None, None, None) < 0
+    assert L.lfq_pileup_indel_columns(caller.h, None, None, 0, 10, 0, None, None) < 0
+    assert L.lfq_pileup_skip_snv_columns(caller.h, None, 5) < 0
+    assert L.lfq_uniq_detlim_batch(caller.h, None, 0, None, None, None) < 0
+    rd = _lib.PileupReads()
+    rd.n_reads = -1
+    out = C.POINTER(_lib.IndelColumnsC)()
+    assert L.lfq_pileup_indel_columns(caller.h, C.byref(rd), None, 0, 10, 0, C.byref(out), None) < 0
+    rd.n_reads = 0
+    assert L.lfq_pileup_indel_columns(caller.h, C.byref(rd), None, 10, 0, 0, C.byref(out), None) < 0   # end < begin
+    t = _lib.Tracks()
+    t.ncols = 3
+    af = np.array([0.1, 2.0, 0.1], np.float32)                  # AF out of range (lofreq_uniq.c:262-268)
+    det = np.zeros(3, np.uint8)
+    assert L.lfq_uniq_detlim_batch(caller.h, C.byref(t), 0, vp(af.ctypes.data), vp(det.ctypes.data), None) < 0
