@@ -341,6 +341,31 @@ int lfq_pileup_indel_columns(lfq_ctx *ctx, const lfq_pileup_reads *reads, const 
  * 0, which is the other half of the same gate (num_bases * 2 < coverage_plp): no test, no Bonferroni step. */
 int lfq_pileup_skip_snv_columns(lfq_ctx *ctx, const uint8_t *skip, int64_t ncols);
 
+/* --- resident read set: the device-side chain of the steps above ---------------------------------------------
+ * lfq_readset_create uploads the reads of one contig region once (reads->baq / reads->sq and the BI / BD bytes of
+ * `tags` go along when given); the steps below then work on the device copy and leave their per-base results in
+ * HBM for the next one -- BAQ / IDAQ -> source quality -> both pileups -> calls -- so that only VCF-sized data
+ * comes back.  The host arrays handed to lfq_readset_create must outlive the read set (the sparse host-side
+ * steps -- geometry from the CIGARs, the indel event tables -- read them in place).  The host-buffer entry points
+ * above (lfq_baq_idaq_batch, lfq_source_qual_batch, lfq_pileup_snv_tracks, lfq_pileup_indel_columns) are these
+ * functions around a temporary read set. */
+typedef struct lfq_readset lfq_readset;
+int lfq_readset_create(lfq_ctx *ctx, const lfq_pileup_reads *reads, const lfq_pileup_indel_tags *tags_or_null,
+                       lfq_readset **out);
+void lfq_readset_destroy(lfq_readset *rs);
+/* lb (and, with want_idaq, ai / ad) of every read, kept on the device; needs reads->qual */
+int lfq_readset_baq(lfq_ctx *ctx, lfq_readset *rs, int baq_extended, int want_idaq);
+/* source quality; the per-read byte for the sq track stays on the device, sq_out_or_null gets source_qual()'s value */
+int lfq_readset_source_qual(lfq_ctx *ctx, lfq_readset *rs, int def_nm_q, int min_bq, const uint8_t *ign_or_null,
+                            int32_t *sq_out_or_null);
+int lfq_readset_pileup_snv(lfq_ctx *ctx, lfq_readset *rs, int64_t region_begin, int64_t region_end, int min_plp_bq,
+                           lfq_tracks *tracks_out, int64_t *col_pos_out);
+int lfq_readset_pileup_indels(lfq_ctx *ctx, lfq_readset *rs, int64_t region_begin, int64_t region_end, int min_plp_idq,
+                              const lfq_indel_columns **cols_out, int64_t *col_pos_out);
+/* copies of the resident tags for writing them back to the BAM; NULL = not wanted.  tag_flags as lfq_baq_idaq_batch */
+int lfq_readset_fetch_tags(lfq_ctx *ctx, lfq_readset *rs, uint8_t *lb_out, uint8_t *ai_out, uint8_t *ad_out,
+                           uint8_t *tag_flags);
+
 /* --- source quality: the per-read pre-step of `lofreq call -s` -------------------------
  * source_qual (plp.c:427-593) over count_cigar_ops (samutils.c:437-614) for a batch of reads of one contig (same
  * read layout as lfq_baq_batch; the reference letters are compared as given, the caller upper-cases the contig

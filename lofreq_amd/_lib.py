@@ -114,6 +114,8 @@ EXPORTS = [
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
     "lfq_uniq_detlim_batch",
+    "lfq_readset_create", "lfq_readset_destroy", "lfq_readset_baq", "lfq_readset_source_qual",
+    "lfq_readset_pileup_snv", "lfq_readset_pileup_indels", "lfq_readset_fetch_tags",
 ]
 
 _lib = None
@@ -182,6 +184,14 @@ def load():
                                            C.c_int, C.POINTER(C.POINTER(IndelColumnsC)), vp]
     L.lfq_pileup_skip_snv_columns.argtypes = [vp, vp, C.c_int64]
     L.lfq_uniq_detlim_batch.argtypes = [vp, C.POINTER(Tracks), C.c_int, vp, vp, vp]
+    L.lfq_readset_create.argtypes = [vp, C.POINTER(PileupReads), C.POINTER(PileupIndelTags), C.POINTER(vp)]
+    L.lfq_readset_destroy.argtypes = [vp]
+    L.lfq_readset_destroy.restype = None
+    L.lfq_readset_baq.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.lfq_readset_source_qual.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lfq_readset_pileup_snv.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(Tracks), vp]
+    L.lfq_readset_pileup_indels.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.POINTER(IndelColumnsC)), vp]
+    L.lfq_readset_fetch_tags.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lfq_source_qual_batch.argtypes = [vp, C.POINTER(BaqReads), C.c_int, C.c_int, vp, vp, vp]
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -1094,6 +1094,155 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
     return LFQ_OK;
 }
 
+/* ---- resident read set ------------------------------------------------------------------------------------
+ * The reads of one contig region, uploaded once; BAQ / IDAQ, source quality and both pileups work on the device
+ * copy and leave their per-base results (lb, ai, ad, sq) there for the next stage.  The host arrays handed to
+ * lfq_readset_create stay the caller's and must outlive the read set: the sparse host-side steps (geometry from the
+ * CIGARs, the indel event tables) read them in place. */
+struct lfq_readset {
+    lfq_ctx *c;
+    int64_t n, n_bases, n_cig, ref_len;
+    const int32_t *pos;
+    const int64_t *cigar_off, *seq_off;
+    const uint32_t *cigar;
+    const uint8_t *seq, *qual, *mapq, *reverse;
+    const char *ref;
+    const uint8_t *h_bi, *h_bd, *h_ai, *h_ad, *h_flags;     /* tag bytes on the host, as given (may be null) */
+    const int32_t *h_sq;
+    uint8_t *blob;
+    uint8_t *d_pos, *d_coff, *d_soff, *d_cig, *d_seq, *d_qual, *d_ref, *d_mapq, *d_rev, *d_bi, *d_bd, *d_lb, *d_ai,
+            *d_ad, *d_fl, *d_sqb;
+    bool has_lb, has_idaq, has_sqb, has_bi, has_bd;
+    std::vector<uint8_t> fl;            /* per read: bit 0..3 = has BI / BD / ai / ad (host flags or from the device BAQ) */
+    std::vector<int32_t> sq32;          /* source quality per read once computed */
+};
+
+void lfq_readset_destroy(lfq_readset *rs)
+{
+    if (rs) {
+        if (rs->blob) (void)hipFree(rs->blob);
+        delete rs;
+    }
+}
+
+int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_indel_tags *tg, lfq_readset **out)
+{
+    if (!c || !rd || !out || rd->n_reads < 0
+        || (rd->n_reads > 0 && (!rd->pos || !rd->cigar_off || !rd->cigar || !rd->seq_off || !rd->seq || !rd->ref))) {
+        return LFQ_ERR_INVALID;
+    }
+    *out = nullptr;
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    lfq_readset *rs = new lfq_readset();
+    rs->c = c;
+    rs->n = rd->n_reads;
+    rs->n_bases = rs->n > 0 ? rd->seq_off[rs->n] : 0;
+    rs->n_cig = rs->n > 0 ? rd->cigar_off[rs->n] : 0;
+    rs->ref_len = rd->ref_len;
+    rs->pos = rd->pos; rs->cigar_off = rd->cigar_off; rs->seq_off = rd->seq_off; rs->cigar = rd->cigar;
+    rs->seq = rd->seq; rs->qual = rd->qual; rs->mapq = rd->mapq; rs->reverse = rd->reverse; rs->ref = rd->ref;
+    rs->h_bi = tg ? tg->bi : nullptr; rs->h_bd = tg ? tg->bd : nullptr;
+    rs->h_ai = tg ? tg->ai : nullptr; rs->h_ad = tg ? tg->ad : nullptr;
+    rs->h_flags = tg ? tg->tag_flags : nullptr;
+    rs->h_sq = tg ? tg->sq : nullptr;
+    rs->blob = nullptr;
+    rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
+    const int64_t n = rs->n, nb = rs->n_bases;
+    rs->fl.assign((size_t)std::max<int64_t>(n, 1), 0);
+    for (int64_t r = 0; r < n; r++) {
+        const uint32_t f = rs->h_flags ? rs->h_flags[r] : 15u;
+        rs->fl[(size_t)r] = (uint8_t)((rs->h_bi && (f & 1u) ? 1 : 0) | (rs->h_bd && (f & 2u) ? 2 : 0)
+                                      | (rs->h_ai && (f & 4u) ? 4 : 0) | (rs->h_ad && (f & 8u) ? 8 : 0));
+    }
+    if (n == 0) {
+        *out = rs;
+        return LFQ_OK;
+    }
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { const int64_t o = off; off += al(bytes); return o; };
+    const int64_t o_pos = take(n * 4), o_coff = take((n + 1) * 8), o_soff = take((n + 1) * 8), o_cig = take(rs->n_cig * 4),
+                  o_seq = take(nb + 16), o_qual = take(nb + 16), o_ref = take(rs->ref_len + 1), o_mapq = take(n), o_rev = take(n),
+                  o_bi = take(nb + 16), o_bd = take(nb + 16), o_lb = take(nb + 16), o_ai = take(nb + 16), o_ad = take(nb + 16),
+                  o_fl = take(n), o_sqb = take(n);
+    if (hipMalloc((void **)&rs->blob, (size_t)off) != hipSuccess) {
+        delete rs;
+        return LFQ_ERR_NOMEM;
+    }
+    uint8_t *d = rs->blob;
+    rs->d_pos = d + o_pos; rs->d_coff = d + o_coff; rs->d_soff = d + o_soff; rs->d_cig = d + o_cig; rs->d_seq = d + o_seq;
+    rs->d_qual = d + o_qual; rs->d_ref = d + o_ref; rs->d_mapq = d + o_mapq; rs->d_rev = d + o_rev; rs->d_bi = d + o_bi;
+    rs->d_bd = d + o_bd; rs->d_lb = d + o_lb; rs->d_ai = d + o_ai; rs->d_ad = d + o_ad; rs->d_fl = d + o_fl;
+    rs->d_sqb = d + o_sqb;
+    int rc = LFQ_OK;
+    auto up = [&](uint8_t *dst, const void *src, int64_t bytes) {
+        if (rc == LFQ_OK && src && bytes > 0 && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
+    };
+    up(rs->d_pos, rd->pos, n * 4);
+    up(rs->d_coff, rd->cigar_off, (n + 1) * 8);
+    up(rs->d_soff, rd->seq_off, (n + 1) * 8);
+    up(rs->d_cig, rd->cigar, rs->n_cig * 4);
+    up(rs->d_seq, rd->seq, nb);
+    up(rs->d_qual, rd->qual, nb);
+    up(rs->d_ref, rd->ref, rs->ref_len);
+    up(rs->d_mapq, rd->mapq, n);
+    up(rs->d_rev, rd->reverse, n);
+    up(rs->d_bi, rs->h_bi, nb);
+    up(rs->d_bd, rs->h_bd, nb);
+    up(rs->d_lb, rd->baq, nb);
+    up(rs->d_sqb, rd->sq, n);
+    up(rs->d_fl, rs->fl.data(), n);
+    rs->has_bi = rs->h_bi != nullptr;
+    rs->has_bd = rs->h_bd != nullptr;
+    rs->has_lb = rd->baq != nullptr;
+    rs->has_sqb = rd->sq != nullptr;
+    if (rc == LFQ_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+        rc = LFQ_ERR_HIP;
+    }
+    if (rc != LFQ_OK) {
+        lfq_readset_destroy(rs);
+        return rc;
+    }
+    *out = rs;
+    return LFQ_OK;
+}
+
+int lfq_readset_fetch_tags(lfq_ctx *c, lfq_readset *rs, uint8_t *lb_out, uint8_t *ai_out, uint8_t *ad_out, uint8_t *tag_flags)
+{
+    if (!c || !rs || rs->c != c) {
+        return LFQ_ERR_INVALID;
+    }
+    if (rs->n == 0) {
+        return LFQ_OK;
+    }
+    if ((lb_out && !rs->has_lb) || ((ai_out || ad_out || tag_flags) && !rs->has_idaq)) {
+        return LFQ_ERR_INVALID;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    if (lb_out) LFQ_TRY_HIP(hipMemcpyAsync(lb_out, rs->d_lb, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
+    if (ai_out) LFQ_TRY_HIP(hipMemcpyAsync(ai_out, rs->d_ai, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
+    if (ad_out) LFQ_TRY_HIP(hipMemcpyAsync(ad_out, rs->d_ad, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    if (tag_flags) {
+        for (int64_t r = 0; r < rs->n; r++) {
+            tag_flags[r] = (uint8_t)((rs->fl[(size_t)r] >> 2) & 3u);       /* bit 0: ai, bit 1: ad (lfq_baq_idaq_batch) */
+        }
+    }
+    return LFQ_OK;
+}
+
+static int readset_from_baq_reads(lfq_ctx *c, const lfq_baq_reads *rd, lfq_readset **rs)
+{
+    lfq_pileup_reads pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.n_reads = rd->n_reads;
+    pr.pos = rd->pos; pr.cigar_off = rd->cigar_off; pr.cigar = rd->cigar; pr.seq_off = rd->seq_off;
+    pr.seq = rd->seq; pr.qual = rd->qual; pr.ref = rd->ref; pr.ref_len = rd->ref_len;
+    return lfq_readset_create(c, &pr, nullptr, rs);
+}
+
 int lfq_baq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, uint8_t *lb_out)
 {
     return lfq_baq_idaq_batch(c, rd, baq_extended, lb_out, nullptr, nullptr, nullptr);
@@ -1107,7 +1256,29 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
                                                               || !rd->seq || !rd->qual || !rd->ref || !lb_out))) {
         return LFQ_ERR_INVALID;
     }
-    const int64_t n = rd->n_reads;
+    if (rd->n_reads == 0) {
+        return LFQ_OK;
+    }
+    lfq_readset *rs = nullptr;
+    LFQ_TRY(readset_from_baq_reads(c, rd, &rs));
+    int rc = lfq_readset_baq(c, rs, baq_extended, want_idaq ? 1 : 0);
+    if (rc == LFQ_OK) {
+        rc = lfq_readset_fetch_tags(c, rs, lb_out, want_idaq ? ai_out : nullptr, want_idaq ? ad_out : nullptr,
+                                    want_idaq ? tag_flags : nullptr);
+    }
+    lfq_readset_destroy(rs);
+    return rc;
+}
+
+/* bam_prob_realn_core_ext for every read of the set: lb (and ai / ad) stay on the device */
+int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq_i)
+{
+    if (!c || !rs || rs->c != c || (rs->n > 0 && !rs->qual)) {
+        return LFQ_ERR_INVALID;
+    }
+    const bool want_idaq = want_idaq_i != 0;
+    const lfq_readset *rd = rs;             /* the host views carry the names the geometry code below uses */
+    const int64_t n = rs->n;
     if (n == 0) {
         return LFQ_OK;
     }
@@ -1178,18 +1349,16 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
             }
         }
     }
-    const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
+    const int64_t n_bases = rs->n_bases;
     float h_q2p[256];
     for (int i = 0; i < 256; i++) {
         h_q2p[i] = (float)pow(10, -i / 10.);                 /* kprobaln_ext.c:121-123 */
     }
-    /* device copies (one allocation) */
+    /* per-call device data: geometry, launch order, the quality table (the reads themselves are resident) */
     uint8_t *d_blob = nullptr;
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    const int64_t o_reads = 0, o_soff = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_cig = o_soff + al((n + 1) * 8),
-                  o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_ref = o_qual + al(n_bases),
-                  o_out = o_ref + al(rd->ref_len + 1), o_q2p = o_out + al(n_bases), o_ai = o_q2p + al(1024),
-                  o_ad = o_ai + al(n_bases), o_fl = o_ad + al(n_bases), o_ord = o_fl + al(n), total = o_ord + al(n * 4);
+    const int64_t o_reads = 0, o_q2p = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_ord = o_q2p + al(1024),
+                  total = o_ord + al(n * 4);
     LFQ_TRY_HIP(hipMalloc((void **)&d_blob, (size_t)total));
     int rc = LFQ_OK;
     auto up = [&](int64_t off, const void *src, int64_t bytes) {
@@ -1198,16 +1367,12 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
         }
     };
     up(o_reads, h.data(), n * (int64_t)sizeof(LfqBaqRead));
-    up(o_soff, rd->seq_off, (n + 1) * 8);
-    up(o_cig, rd->cigar, n_cig * 4);
-    up(o_seq, rd->seq, n_bases);
-    up(o_qual, rd->qual, n_bases);
-    up(o_ref, rd->ref, rd->ref_len);
     up(o_q2p, h_q2p, 1024);
     up(o_ord, order.data(), n * 4);
-    if (rc == LFQ_OK && (hipMemsetAsync(d_blob + o_out, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
-                         || hipMemsetAsync(d_blob + o_ai, '~', (size_t)(o_fl - o_ai), c->stream) != hipSuccess
-                         || hipMemsetAsync(d_blob + o_fl, 0, (size_t)al(n), c->stream) != hipSuccess)) {
+    if (rc == LFQ_OK && (hipMemsetAsync(rs->d_lb, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
+                         || (want_idaq && (hipMemsetAsync(rs->d_ai, '~', (size_t)n_bases, c->stream) != hipSuccess
+                                           || hipMemsetAsync(rs->d_ad, '~', (size_t)n_bases, c->stream) != hipSuccess
+                                           || hipMemsetAsync(rs->d_fl, 0, (size_t)n, c->stream) != hipSuccess)))) {
         rc = LFQ_ERR_HIP;
     }
     double *d_scr = nullptr;
@@ -1217,12 +1382,12 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
         LfqBaqArgs A;
         memset(&A, 0, sizeof(A));
         A.reads = (const LfqBaqRead *)(d_blob + o_reads);
-        A.seq_off = (const int64_t *)(d_blob + o_soff);
-        A.cigar = (const uint32_t *)(d_blob + o_cig);
-        A.seq = d_blob + o_seq;
-        A.qual = d_blob + o_qual;
-        A.ref = d_blob + o_ref;
-        A.lb_out = d_blob + o_out;
+        A.seq_off = (const int64_t *)rs->d_soff;
+        A.cigar = (const uint32_t *)rs->d_cig;
+        A.seq = rs->d_seq;
+        A.qual = rs->d_qual;
+        A.ref = rs->d_ref;
+        A.lb_out = rs->d_lb;
         A.qual2prob = (const float *)(d_blob + o_q2p);
         A.n_reads = n;
         A.rows = max_lq + 1;
@@ -1259,9 +1424,9 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
             keep(&c->d_baq_terms, &c->baq_terms_bytes, waves * (int64_t)LFQ_BAQ_MAX_TERMS * 64 * 8);
             A.itab = c->d_baq_itab;
             A.terms = c->d_baq_terms;
-            A.ai_out = d_blob + o_ai;
-            A.ad_out = d_blob + o_ad;
-            A.tag_flags = d_blob + o_fl;
+            A.ai_out = rs->d_ai;
+            A.ad_out = rs->d_ad;
+            A.tag_flags = rs->d_fl;
         }
         d_scr = c->d_baq_scr;
         d_expect = c->d_baq_expect;
@@ -1280,19 +1445,31 @@ int lfq_baq_idaq_batch(lfq_ctx *c, const lfq_baq_reads *rd, int baq_extended, ui
             rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
         }
     }
-    if (rc == LFQ_OK && hipMemcpyAsync(lb_out, d_blob + o_out, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
-        rc = LFQ_ERR_HIP;
-    }
-    if (rc == LFQ_OK && want_idaq
-        && (hipMemcpyAsync(ai_out, d_blob + o_ai, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess
-            || hipMemcpyAsync(ad_out, d_blob + o_ad, (size_t)n_bases, hipMemcpyDeviceToHost, c->stream) != hipSuccess
-            || hipMemcpyAsync(tag_flags, d_blob + o_fl, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) {
-        rc = LFQ_ERR_HIP;
+    std::vector<uint8_t> dfl;
+    if (rc == LFQ_OK && want_idaq) {            /* which reads got an ai / ad tag (bam_md_ext.c:238-243): bits 2, 3 */
+        dfl.resize((size_t)n);
+        if (hipMemcpyAsync(dfl.data(), rs->d_fl, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
         rc = LFQ_ERR_HIP;
     }
     (void)hipFree(d_blob);
+    if (rc == LFQ_OK) {
+        rs->has_lb = true;
+        if (want_idaq) {
+            rs->has_idaq = true;
+            rs->h_ai = rs->h_ad = nullptr;      /* superseded by the device result */
+            for (int64_t r = 0; r < n; r++) {
+                rs->fl[(size_t)r] = (uint8_t)((rs->fl[(size_t)r] & 3u) | ((dfl[(size_t)r] & 3u) << 2));
+            }
+            /* the resident flags follow the host layout (bit 0 BI, 1 BD, 2 ai, 3 ad) again */
+            if (hipMemcpy(rs->d_fl, rs->fl.data(), (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        }
+    }
     return rc;
 }
 
@@ -1304,52 +1481,49 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
                                 || !rd->mapq || !rd->reverse || !rd->ref))) {
         return LFQ_ERR_INVALID;
     }
+    lfq_readset *rs = nullptr;
+    LFQ_TRY(lfq_readset_create(c, rd, nullptr, &rs));
+    const int rc = lfq_readset_pileup_snv(c, rs, region_begin, region_end, min_plp_bq, out, col_pos_out);
+    lfq_readset_destroy(rs);            /* the tracks live in the context, not in the read set */
+    return rc;
+}
+
+int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, int64_t region_end, int min_plp_bq,
+                           lfq_tracks *out, int64_t *col_pos_out)
+{
+    if (!c || !rs || rs->c != c || !out || region_end < region_begin
+        || (rs->n > 0 && (!rs->qual || !rs->mapq || !rs->reverse))) {
+        return LFQ_ERR_INVALID;
+    }
+    const lfq_readset *rd = rs;
     memset(out, 0, sizeof(*out));
-    const int64_t n = rd->n_reads, width = region_end - region_begin;
+    const int64_t n = rs->n, width = region_end - region_begin;
     if (n == 0 || width == 0) {
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
-    const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    /* inputs + per-position counters in one allocation (kept until the next call) */
-    const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
-                  o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_baq = o_qual + al(n_bases),
-                  o_mq = o_baq + al(n_bases), o_rev = o_mq + al(n), o_sq = o_rev + al(n), o_cov = o_sq + al(n),
-                  o_nb = o_cov + al(width * 4),
-                  o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4), total = o_cidx + al(width * 4);
+    /* per-position counters (kept until the next call) */
+    const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
+                  total = o_cidx + al(width * 4);
     if (c->d_plp_in) (void)hipFree(c->d_plp_in);
     c->d_plp_in = nullptr;
     LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_in, (size_t)total));
     uint8_t *d = c->d_plp_in;
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_pos, rd->pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_coff, rd->cigar_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_soff, rd->seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_cig, rd->cigar, (size_t)n_cig * 4, hipMemcpyHostToDevice, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_seq, rd->seq, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_qual, rd->qual, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
-    if (rd->baq) {
-        LFQ_TRY_HIP(hipMemcpyAsync(d + o_baq, rd->baq, (size_t)n_bases, hipMemcpyHostToDevice, c->stream));
-    }
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_mq, rd->mapq, (size_t)n, hipMemcpyHostToDevice, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_rev, rd->reverse, (size_t)n, hipMemcpyHostToDevice, c->stream));
-    if (rd->sq) {
-        LFQ_TRY_HIP(hipMemcpyAsync(d + o_sq, rd->sq, (size_t)n, hipMemcpyHostToDevice, c->stream));
-    }
     LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), c->stream));
     LfqPileupArgs A;
     memset(&A, 0, sizeof(A));
     A.n_reads = n;
-    A.pos = (const int32_t *)(d + o_pos);
-    A.cigar_off = (const int64_t *)(d + o_coff);
-    A.seq_off = (const int64_t *)(d + o_soff);
-    A.cigar = (const uint32_t *)(d + o_cig);
-    A.seq = d + o_seq;
-    A.qual = d + o_qual;
-    A.baq = rd->baq ? d + o_baq : nullptr;
-    A.mapq = d + o_mq;
-    A.reverse = d + o_rev;
-    A.sq = rd->sq ? d + o_sq : nullptr;
+    A.pos = (const int32_t *)rs->d_pos;
+    A.cigar_off = (const int64_t *)rs->d_coff;
+    A.seq_off = (const int64_t *)rs->d_soff;
+    A.cigar = (const uint32_t *)rs->d_cig;
+    A.seq = rs->d_seq;
+    A.qual = rs->d_qual;
+    A.baq = rs->has_lb ? rs->d_lb : nullptr;
+    A.mapq = rs->d_mapq;
+    A.reverse = rs->d_rev;
+    A.sq = rs->has_sqb ? rs->d_sqb : nullptr;
     A.begin = region_begin;
     A.width = width;
     A.min_plp_bq = min_plp_bq;
@@ -1389,7 +1563,7 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     const int64_t n_obs = (int64_t)off.back(), trk = al(n_obs + 32);
     const int64_t t_off = 0, t_ref = t_off + al((ncols + 1) * 8), t_cov = t_ref + al(ncols + 16), t_nb = t_cov + al(ncols * 4 + 16),
                   t_nt = t_nb + al(ncols * 4 + 16), t_bq = t_nt + trk, t_baq = t_bq + trk, t_mq = t_baq + trk,
-                  t_sq = t_mq + trk, t_total = t_sq + (rd->sq ? trk : 0);
+                  t_sq = t_mq + trk, t_total = t_sq + (rs->has_sqb ? trk : 0);
     if (c->d_plp_out) (void)hipFree(c->d_plp_out);
     c->d_plp_out = nullptr;
     LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_out, (size_t)t_total));
@@ -1408,14 +1582,14 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     A.t_bq = t + t_bq;
     A.t_baq = t + t_baq;
     A.t_mq = t + t_mq;
-    A.t_sq = rd->sq ? t + t_sq : nullptr;
+    A.t_sq = rs->has_sqb ? t + t_sq : nullptr;
     LFQ_TRY(lfq_launch_pileup_scatter(A, c->stream));
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
     out->nt = t + t_nt;
     out->bq = t + t_bq;
     out->baq = t + t_baq;
     out->mq = t + t_mq;
-    out->sq = rd->sq ? t + t_sq : nullptr;
+    out->sq = rs->has_sqb ? t + t_sq : nullptr;
     out->col_off = (const uint64_t *)(t + t_off);
     out->ref_base = t + t_ref;
     out->coverage_plp = (const int32_t *)(t + t_cov);
@@ -1439,15 +1613,29 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
                                 || !rd->reverse || !rd->ref))) {
         return LFQ_ERR_INVALID;
     }
+    lfq_readset *rs = nullptr;
+    LFQ_TRY(lfq_readset_create(c, rd, tg, &rs));
+    const int rc = lfq_readset_pileup_indels(c, rs, region_begin, region_end, min_plp_idq, cols_out, col_pos_out);
+    lfq_readset_destroy(rs);            /* the columns live in the context */
+    return rc;
+}
+
+int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, int64_t region_end, int min_plp_idq,
+                              const lfq_indel_columns **cols_out, int64_t *col_pos_out)
+{
+    if (!c || !rs || rs->c != c || !cols_out || region_end < region_begin || (rs->n > 0 && (!rs->mapq || !rs->reverse))) {
+        return LFQ_ERR_INVALID;
+    }
+    const lfq_readset *rd = rs;
     delete c->plp_indel;
     c->plp_indel = new LfqIndelColsOwned();
     LfqIndelColsOwned &O = *c->plp_indel;
     memset(&O.cols, 0, sizeof(O.cols));
     *cols_out = &O.cols;
-    const int64_t n = rd->n_reads, width = region_end - region_begin;
-    const uint8_t *t_bi = tg ? tg->bi : nullptr, *t_bd = tg ? tg->bd : nullptr, *t_ai = tg ? tg->ai : nullptr,
-                  *t_ad = tg ? tg->ad : nullptr, *t_fl = tg ? tg->tag_flags : nullptr;
-    const int32_t *t_sq = tg ? tg->sq : nullptr;
+    const int64_t n = rs->n, width = region_end - region_begin;
+    /* tag bytes on the host where the caller gave them; ai / ad computed by lfq_readset_baq are fetched per event */
+    const uint8_t *t_bi = rs->h_bi, *t_bd = rs->h_bd, *t_ai = rs->h_ai, *t_ad = rs->h_ad, *t_fl = rs->fl.data();
+    const int32_t *t_sq = rs->h_sq ? rs->h_sq : (rs->sq32.empty() ? nullptr : rs->sq32.data());
 
     /* 1. events from the CIGARs, in read (= pileup) order */
     struct Ev { int64_t pos; int64_t read; int32_t qpos, indel; };
@@ -1457,7 +1645,7 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
         const int n_cigar = (int)(rd->cigar_off[r + 1] - rd->cigar_off[r]);
         const int64_t s0 = rd->seq_off[r];
         const int l_qseq = (int)(rd->seq_off[r + 1] - s0);
-        const uint32_t fl = t_fl ? t_fl[r] : 15u;
+        const uint32_t fl = t_fl[r];
         int64_t x = rd->pos[r];
         int y = 0;
         for (int k = 0; k < n_cigar; ++k) {
@@ -1504,6 +1692,7 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
         }
     }
     std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
+    std::vector<uint8_t> g_ai, g_ad;        /* per event, when the qualities come from the device */
 
     if (n == 0 || width == 0) {
         for (int sd = 0; sd < 2; sd++) {
@@ -1515,12 +1704,9 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
     } else {
         /* 2. dense counters on the device */
         LFQ_TRY_HIP(hipSetDevice(c->device));
-        const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
         auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-        const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
-                      o_bi = o_cig + al(n_cig * 4), o_bd = o_bi + al(n_bases), o_fl = o_bd + al(n_bases), o_mq = o_fl + al(n),
-                      o_rev = o_mq + al(n), o_cnt = o_rev + al(n), o_cur = o_cnt + 7 * al(width * 4),
-                      o_off = o_cur + 2 * al(width * 4), total = o_off + 2 * al(width * 8);
+        const int64_t o_cnt = 0, o_cur = o_cnt + 7 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
+                      total = o_off + 2 * al(width * 8);
         uint8_t *d = nullptr;
         if (hipMalloc((void **)&d, (size_t)total) != hipSuccess) {
             return LFQ_ERR_NOMEM;
@@ -1533,30 +1719,21 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
                 rc = LFQ_ERR_HIP;
             }
         };
-        up(o_pos, rd->pos, n * 4);
-        up(o_coff, rd->cigar_off, (n + 1) * 8);
-        up(o_soff, rd->seq_off, (n + 1) * 8);
-        up(o_cig, rd->cigar, n_cig * 4);
-        up(o_bi, t_bi, n_bases);
-        up(o_bd, t_bd, n_bases);
-        up(o_fl, t_fl, n);
-        up(o_mq, rd->mapq, n);
-        up(o_rev, rd->reverse, n);
         if (rc == LFQ_OK && hipMemsetAsync(d + o_cnt, 0, (size_t)(o_off - o_cnt), c->stream) != hipSuccess) {
             rc = LFQ_ERR_HIP;
         }
         LfqPlpIndelArgs A;
         memset(&A, 0, sizeof(A));
         A.n_reads = n;
-        A.pos = (const int32_t *)(d + o_pos);
-        A.cigar_off = (const int64_t *)(d + o_coff);
-        A.seq_off = (const int64_t *)(d + o_soff);
-        A.cigar = (const uint32_t *)(d + o_cig);
-        A.bi = t_bi ? d + o_bi : nullptr;
-        A.bd = t_bd ? d + o_bd : nullptr;
-        A.tag_flags = t_fl ? d + o_fl : nullptr;
-        A.mapq = d + o_mq;
-        A.reverse = d + o_rev;
+        A.pos = (const int32_t *)rs->d_pos;
+        A.cigar_off = (const int64_t *)rs->d_coff;
+        A.seq_off = (const int64_t *)rs->d_soff;
+        A.cigar = (const uint32_t *)rs->d_cig;
+        A.bi = rs->has_bi ? rs->d_bi : nullptr;
+        A.bd = rs->has_bd ? rs->d_bd : nullptr;
+        A.tag_flags = rs->d_fl;
+        A.mapq = rs->d_mapq;
+        A.reverse = rs->d_rev;
         A.begin = region_begin;
         A.width = width;
         A.min_plp_idq = min_plp_idq;
@@ -1674,6 +1851,29 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
                 }
             }
         }
+        /* ai / ad of the event reads when lfq_readset_baq left them on the device */
+        if (rc == LFQ_OK && rs->has_idaq && !evs.empty()) {
+            std::vector<int64_t> idx(evs.size());
+            for (size_t i = 0; i < evs.size(); i++) {
+                idx[i] = rd->seq_off[evs[i].read] + evs[i].qpos;
+            }
+            uint8_t *dg = nullptr;
+            const int64_t ne = (int64_t)evs.size();
+            if (hipMalloc((void **)&dg, (size_t)(ne * 10)) != hipSuccess) {
+                rc = LFQ_ERR_NOMEM;
+            } else {
+                g_ai.resize(evs.size());
+                g_ad.resize(evs.size());
+                if (hipMemcpyAsync(dg, idx.data(), (size_t)ne * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess
+                    || lfq_launch_gather2(rs->d_ai, rs->d_ad, (const int64_t *)dg, ne, dg + ne * 8, dg + ne * 9, c->stream) != LFQ_OK
+                    || hipMemcpyAsync(g_ai.data(), dg + ne * 8, (size_t)ne, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+                    || hipMemcpyAsync(g_ad.data(), dg + ne * 9, (size_t)ne, hipMemcpyDeviceToHost, c->stream) != hipSuccess
+                    || hipStreamSynchronize(c->stream) != hipSuccess) {
+                    rc = LFQ_ERR_HIP;
+                }
+                (void)hipFree(dg);
+            }
+        }
         (void)hipFree(d);
         if (d_ne) (void)hipFree(d_ne);
         if (rc != LFQ_OK) {
@@ -1741,11 +1941,17 @@ int lfq_pileup_indel_columns(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_p
                     for (size_t i : members[ki]) {
                         const Ev &e = evs[i];
                         const int64_t s0 = rd->seq_off[e.read];
-                        const uint32_t fl = t_fl ? t_fl[e.read] : 15u;
+                        const uint32_t fl = t_fl[e.read];
                         const uint8_t *qa = sd == 0 ? t_bi : t_bd, *aa = sd == 0 ? t_ai : t_ad;
-                        const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u)), has_a = aa && (fl & (sd == 0 ? 4u : 8u));
+                        const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u)), tagged = (fl & (sd == 0 ? 4u : 8u)) != 0;
                         S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
-                        S.rd_aq.push_back((int16_t)(has_a ? (int)aa[s0 + e.qpos] - 33 : -1));     /* :1069-1073, 1113-1117 */
+                        int aq = -1;                                                     /* :1069-1073, 1113-1117 */
+                        if (tagged && !g_ai.empty()) {
+                            aq = (int)(sd == 0 ? g_ai[i] : g_ad[i]) - 33;
+                        } else if (tagged && aa) {
+                            aq = (int)aa[s0 + e.qpos] - 33;
+                        }
+                        S.rd_aq.push_back((int16_t)aq);
                         S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
                         const int32_t sq = t_sq ? t_sq[e.read] : -1;
                         S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
@@ -1915,12 +2121,33 @@ int lfq_source_qual_batch(lfq_ctx *c, const lfq_baq_reads *rd, int def_nm_q, int
                                 || !rd->ref))) {
         return LFQ_ERR_INVALID;
     }
-    const int64_t n = rd->n_reads;
+    if (rd->n_reads == 0) {
+        return LFQ_OK;
+    }
+    lfq_readset *rs = nullptr;
+    LFQ_TRY(readset_from_baq_reads(c, rd, &rs));
+    const int rc = lfq_readset_source_qual(c, rs, def_nm_q, min_bq, ign, sq_out);
+    if (rc == LFQ_OK && sq_byte) {
+        for (int64_t r = 0; r < rd->n_reads; r++) {
+            const int q = sq_out[r];
+            sq_byte[r] = (uint8_t)(q < 0 ? 0 : (q > 254 ? 254 : q));
+        }
+    }
+    lfq_readset_destroy(rs);
+    return rc;
+}
+
+int lfq_readset_source_qual(lfq_ctx *c, lfq_readset *rs, int def_nm_q, int min_bq, const uint8_t *ign, int32_t *sq_out)
+{
+    if (!c || !rs || rs->c != c || def_nm_q > 255 || (rs->n > 0 && !rs->qual)) {
+        return LFQ_ERR_INVALID;
+    }
+    const lfq_readset *rd = rs;
+    const int64_t n = rs->n;
     if (n == 0) {
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
-    const int64_t n_bases = rd->seq_off[n], n_cig = rd->cigar_off[n];
     int64_t max_ops = 0;                                /* bound of K: one operation per base or CIGAR element */
     for (int64_t r = 0; r < n; r++) {
         max_ops = std::max<int64_t>(max_ops, (rd->seq_off[r + 1] - rd->seq_off[r]) + (rd->cigar_off[r + 1] - rd->cigar_off[r]));
@@ -1928,10 +2155,8 @@ int lfq_source_qual_batch(lfq_ctx *c, const lfq_baq_reads *rd, int def_nm_q, int
     const int n_blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)c->n_cu * 2));
     const int64_t scratch_cells = max_ops + 1 > LFQ_SRCQ_LDS_CELLS ? max_ops + 1 : 0;
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    const int64_t o_pos = 0, o_coff = o_pos + al(n * 4), o_soff = o_coff + al((n + 1) * 8), o_cig = o_soff + al((n + 1) * 8),
-                  o_seq = o_cig + al(n_cig * 4), o_qual = o_seq + al(n_bases), o_ref = o_qual + al(n_bases),
-                  o_ign = o_ref + al(rd->ref_len), o_prob = o_ign + (ign ? al(rd->ref_len) : 0), o_st = o_prob + al(n * 8),
-                  o_scr = o_st + al(n), total = o_scr + (int64_t)n_blocks * 4 * 2 * scratch_cells * 8;
+    const int64_t o_ign = 0, o_prob = o_ign + (ign ? al(rd->ref_len) : 0), o_st = o_prob + al(n * 8), o_scr = o_st + al(n),
+                  total = o_scr + (int64_t)n_blocks * 4 * 2 * scratch_cells * 8;
     uint8_t *d = nullptr;
     if (hipMalloc((void **)&d, (size_t)total) != hipSuccess) {
         return LFQ_ERR_NOMEM;
@@ -1939,32 +2164,20 @@ int lfq_source_qual_batch(lfq_ctx *c, const lfq_baq_reads *rd, int def_nm_q, int
     int rc = LFQ_OK;
     std::vector<double> prob((size_t)n);
     std::vector<uint8_t> st((size_t)n);
-    auto up = [&](int64_t off, const void *src, int64_t bytes) {
-        if (rc == LFQ_OK && bytes > 0 && hipMemcpyAsync(d + off, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-            rc = LFQ_ERR_HIP;
-        }
-    };
-    up(o_pos, rd->pos, n * 4);
-    up(o_coff, rd->cigar_off, (n + 1) * 8);
-    up(o_soff, rd->seq_off, (n + 1) * 8);
-    up(o_cig, rd->cigar, n_cig * 4);
-    up(o_seq, rd->seq, n_bases);
-    up(o_qual, rd->qual, n_bases);
-    up(o_ref, rd->ref, rd->ref_len);
-    if (ign) {
-        up(o_ign, ign, rd->ref_len);
+    if (ign && hipMemcpyAsync(d + o_ign, ign, (size_t)rd->ref_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        rc = LFQ_ERR_HIP;
     }
     if (rc == LFQ_OK) {
         LfqSrcqArgs A;
         memset(&A, 0, sizeof(A));
         A.n_reads = n;
-        A.pos = (const int32_t *)(d + o_pos);
-        A.cigar_off = (const int64_t *)(d + o_coff);
-        A.seq_off = (const int64_t *)(d + o_soff);
-        A.cigar = (const uint32_t *)(d + o_cig);
-        A.seq = d + o_seq;
-        A.qual = d + o_qual;
-        A.ref = (const char *)(d + o_ref);
+        A.pos = (const int32_t *)rs->d_pos;
+        A.cigar_off = (const int64_t *)rs->d_coff;
+        A.seq_off = (const int64_t *)rs->d_soff;
+        A.cigar = (const uint32_t *)rs->d_cig;
+        A.seq = rs->d_seq;
+        A.qual = rs->d_qual;
+        A.ref = (const char *)rs->d_ref;
         A.ref_len = rd->ref_len;
         A.ign = ign ? d + o_ign : nullptr;
         A.nonmatch_qual = def_nm_q;
@@ -1988,6 +2201,8 @@ int lfq_source_qual_batch(lfq_ctx *c, const lfq_baq_reads *rd, int def_nm_q, int
         return rc;
     }
     const int perfect = (int)(-10.0L * log10l(LDBL_MIN));       /* PROB_TO_PHREDQUAL(LDBL_MIN) = 49314, plp.c:521 */
+    rs->sq32.resize((size_t)n);
+    std::vector<uint8_t> sqb((size_t)n);
     for (int64_t r = 0; r < n; r++) {
         int q;
         if (st[(size_t)r] == LFQ_SRCQ_NA) {
@@ -2000,11 +2215,15 @@ int lfq_source_qual_batch(lfq_ctx *c, const lfq_baq_reads *rd, int def_nm_q, int
              * of either is INT_MIN ("integer indefinite"); mplp_func then stores 0 */
             q = (x > 0.0) ? (int)(-10.0L * log10l((long double)x)) : INT32_MIN;
         }
-        sq_out[r] = q;
-        if (sq_byte) {
-            sq_byte[r] = (uint8_t)(q < 0 ? 0 : (q > 254 ? 254 : q));
+        if (sq_out) {
+            sq_out[r] = q;
         }
+        rs->sq32[(size_t)r] = q < 0 ? 0 : q;                    /* what the sq tag holds (plp.c:731-734) */
+        sqb[(size_t)r] = (uint8_t)(q < 0 ? 0 : (q > 254 ? 254 : q));
     }
+    /* the byte of the packed sq track, resident for lfq_readset_pileup_snv */
+    LFQ_TRY_HIP(hipMemcpy(rs->d_sqb, sqb.data(), (size_t)n, hipMemcpyHostToDevice));
+    rs->has_sqb = true;
     return LFQ_OK;
 }
 

@@ -237,6 +237,7 @@ struct LfqPlpIndelArgs {
     int16_t *ne_q[2], *ne_mq[2];
 };
 int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream);
+int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n, uint8_t *oa, uint8_t *ob, void *stream);
 
 /* source quality (lfq_srcq.hip) */
 #define LFQ_DBL_EPSILON 2.220446049250313e-16

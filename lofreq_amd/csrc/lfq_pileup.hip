@@ -238,3 +238,24 @@ int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream)
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
+
+
+/* two byte arrays at a list of positions (the ai / ad qualities of the reads that carry an indel event) */
+__global__ __launch_bounds__(256) void lfq_gather2_kernel(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n,
+                                                          uint8_t *oa, uint8_t *ob)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        oa[i] = a[idx[i]];
+        ob[i] = b[idx[i]];
+    }
+}
+
+int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n, uint8_t *oa, uint8_t *ob, void *stream)
+{
+    if (n <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_gather2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, idx, n, oa, ob);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}

@@ -132,6 +132,12 @@ def pileup_indel_columns(caller, reads, ref, begin, end, min_plp_idq=0):
     _lib.check(_lib.load().lfq_pileup_indel_columns(caller.h, C.byref(rd), C.byref(tags), int(begin), int(end),
                                                     int(min_plp_idq), C.byref(out), col_pos.ctypes.data),
                "lfq_pileup_indel_columns")
+    return _indel_columns_from_c(out, col_pos)
+
+
+def _indel_columns_from_c(out, col_pos):
+    """copy a context-owned lfq_indel_columns into an IndelColumns"""
+    from .indel import IndelColumns, _I32
     cs = out.contents
     ncols = int(cs.ncols)
 
@@ -167,10 +173,95 @@ def pileup_indel_columns(caller, reads, ref, begin, end, min_plp_idq=0):
     o.cons_indel = arr(cs.cons_indel, ncols, np.uint8)
     return o, col_pos[:ncols].copy()
 
-
 def skip_snv_columns(caller, skip):
     """call_vars' gate (lofreq_call.c:928-931): take the columns with skip[col] != 0 (IndelColumns.cons_indel) out of
     the SNV tracks last returned by pileup_snv_tracks"""
     skip = np.ascontiguousarray(skip, np.uint8)
     _lib.check(_lib.load().lfq_pileup_skip_snv_columns(caller.h, skip.ctypes.data, len(skip)),
                "lfq_pileup_skip_snv_columns")
+
+
+class ReadSet:
+    """The reads of one contig region resident on the device (`lfq_readset`): upload once, then BAQ / IDAQ, source
+    quality, both pileups and the calls without the per-base arrays leaving HBM.
+
+        rs = ReadSet(caller, reads, ref)          # reads: dicts as for pileup_snv_tracks (+ "bi", "bd")
+        rs.baq(idaq=True); rs.source_qual()       # optional steps, results stay resident
+        tracks = rs.pileup_snv(0, len(ref)); cols, col_pos = rs.pileup_indels(0, len(ref))
+    """
+
+    def __init__(self, caller, reads, ref):
+        self.caller = caller
+        self.L = _lib.load()
+        n = len(reads)
+        self.n = n
+        rd, keep = _pack_reads(reads, ref)
+        n_bases = int(keep["seq_off"][-1])
+        tags = _lib.PileupIndelTags()
+        flags = np.zeros(max(n, 1), np.uint8)
+        for bit, name in enumerate(("bi", "bd", "ai", "ad")):
+            if any(r.get(name) is not None for r in reads):
+                arr = np.full(max(n_bases, 1), 33, np.uint8)
+                for i, r in enumerate(reads):
+                    if r.get(name) is not None:
+                        arr[keep["seq_off"][i]:keep["seq_off"][i + 1]] = np.asarray(r[name], np.uint8)
+                        flags[i] |= 1 << bit
+                keep[name] = arr
+                setattr(tags, name, arr.ctypes.data)
+        keep["flags"] = flags
+        tags.tag_flags = flags.ctypes.data
+        if any(r.get("lb") is not None for r in reads):
+            keep["lb"] = np.concatenate([np.asarray(r["lb"], np.uint8) for r in reads])
+            rd.baq = keep["lb"].ctypes.data
+        self._keep = keep                           # the host arrays must outlive the read set
+        self.seq_off = keep["seq_off"]
+        h = C.c_void_p()
+        _lib.check(self.L.lfq_readset_create(caller.h, C.byref(rd), C.byref(tags), C.byref(h)), "lfq_readset_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lfq_readset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def baq(self, extended=True, idaq=False):
+        _lib.check(self.L.lfq_readset_baq(self.caller.h, self.h, 1 if extended else 0, 1 if idaq else 0), "lfq_readset_baq")
+
+    def source_qual(self, def_nm_q=-1, min_bq=6, ign=None):
+        sq = np.zeros(max(self.n, 1), np.int32)
+        if ign is not None:
+            ign = np.ascontiguousarray(ign, np.uint8)
+        _lib.check(self.L.lfq_readset_source_qual(self.caller.h, self.h, int(def_nm_q), int(min_bq),
+                                                  ign.ctypes.data if ign is not None else None, sq.ctypes.data),
+                   "lfq_readset_source_qual")
+        return sq[: self.n]
+
+    def fetch_tags(self, idaq=False):
+        nb = max(int(self.seq_off[-1]), 1)
+        lb = np.zeros(nb, np.uint8)
+        ai = np.zeros(nb, np.uint8) if idaq else None
+        ad = np.zeros(nb, np.uint8) if idaq else None
+        fl = np.zeros(max(self.n, 1), np.uint8) if idaq else None
+        p = lambda a: a.ctypes.data if a is not None else None
+        _lib.check(self.L.lfq_readset_fetch_tags(self.caller.h, self.h, p(lb), p(ai), p(ad), p(fl)), "lfq_readset_fetch_tags")
+        return lb, ai, ad, fl
+
+    def pileup_snv(self, begin, end, min_plp_bq=3):
+        t = _lib.Tracks()
+        col_pos = np.zeros(max(end - begin, 1), np.int64)
+        _lib.check(self.L.lfq_readset_pileup_snv(self.caller.h, self.h, int(begin), int(end), int(min_plp_bq), C.byref(t),
+                                                 col_pos.ctypes.data), "lfq_readset_pileup_snv")
+        return DeviceTracks(t, col_pos[: int(t.ncols)].copy())
+
+    def pileup_indels(self, begin, end, min_plp_idq=0):
+        out = C.POINTER(_lib.IndelColumnsC)()
+        col_pos = np.zeros(max(end - begin, 1), np.int64)
+        _lib.check(self.L.lfq_readset_pileup_indels(self.caller.h, self.h, int(begin), int(end), int(min_plp_idq),
+                                                    C.byref(out), col_pos.ctypes.data), "lfq_readset_pileup_indels")
+        return _indel_columns_from_c(out, col_pos)

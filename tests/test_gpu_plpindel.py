@@ -197,3 +197,54 @@ def test_indel_columns_empty_inputs(caller):
     cols, col_pos = la.pileup_indel_columns(caller, r, b"ACGT", 0, 4)          # no tags at all, no events
     assert col_pos.tolist() == [1, 2] and cols.num_non_indels.tolist() == [1, 1] and cols.num_tails.tolist() == [0, 1]
     assert len(cols.keys[0]) == len(cols.keys[1]) == 0 and not cols.cons_indel.any()
+
+
+@pytest.mark.parametrize("path", gu.plpindel_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_resident_readset_chain(caller, path):
+    """the same chain on a resident read set (lfq_readset_*): one upload, BAQ / IDAQ -> both pileups -> calls with the
+    per-base arrays staying in HBM; identical VCF, and the fetched tags equal the host-buffer entry point's"""
+    import lofreq_amd as la
+    fx, reads = gu.load_plpindel(path, with_alnqual_tags=False)
+    ref = fx["genome"].encode()
+    rs = la.ReadSet(caller, reads, ref)
+    rs.baq(extended=True, idaq=True)
+    kw, _ = gu.conf_kwargs(fx["call_args"])
+    conf = la.VarcallConf(**kw)
+    cols, col_pos = rs.pileup_indels(0, len(ref))
+    ilines, ntests = _indel_lines(la, caller, cols, col_pos, conf)
+    dt = rs.pileup_snv(0, len(ref))
+    la.skip_snv_columns(caller, cols.cons_indel)
+    recs, _, st = caller.call_snvs(dt, conf)
+    assert conf.num_snv_tests == fx["all"]["num_tests"]["snv"] and ntests == fx["all"]["num_tests"]["indel"]
+    keep = la.filter_records(recs, la.snvqual_thresh(conf.sig, conf.bonf_subst), apply_defaults=False)
+    slines = [(int(dt.col_pos[int(r["col"])]), 1,
+               gu.strip_hqa(la.format_vcf(np.array([r]), "chr1", pos0=np.array([int(dt.col_pos[int(r["col"])])]),
+                                          filter_str="PASS").rstrip("\n"))) for r, k in zip(recs, keep) if k]
+    assert [l[2] for l in sorted(ilines + slines, key=lambda t: (t[0], t[1]))] == fx["all"]["vcf"]
+    lb, ai, ad, fl = rs.fetch_tags(idaq=True)
+    tags = la.baq_batch(caller, reads, ref, extended=True, idaq=True)
+    for i, (tlb, tai, tad) in enumerate(tags):
+        a, b = int(rs.seq_off[i]), int(rs.seq_off[i + 1])
+        assert lb[a:b].tobytes() == tlb.tobytes()
+        assert (tai is None) == (not fl[i] & 1) and (tad is None) == (not fl[i] & 2)
+        if tai is not None:
+            assert ai[a:b].tobytes() == tai.tobytes()
+        if tad is not None:
+            assert ad[a:b].tobytes() == tad.tobytes()
+    rs.close()
+
+
+def test_resident_readset_source_quality(caller):
+    """sq computed on the read set feeds the sq track of its SNV pileup: same calls as the host-buffer route"""
+    import lofreq_amd as la
+    fx, reads, nmq, ign = gu.load_srcq(gu.srcq_fixtures()[0])
+    ref = fx["genome"].encode()
+    rs = la.ReadSet(caller, reads, ref)
+    sq = rs.source_qual(def_nm_q=nmq, min_bq=6, ign=ign)
+    sq2, sqb = la.source_qual_batch(caller, reads, ref, def_nm_q=nmq, min_bq=6, ign=ign)
+    assert sq.tolist() == sq2.tolist()
+    kw, _ = gu.conf_kwargs(fx["call_args"] + ["-B"] + fx["args"])
+    recs, _, _ = caller.call_snvs(rs.pileup_snv(0, len(ref)), la.VarcallConf(**kw))
+    dt = la.pileup_snv_tracks(caller, reads, ref, 0, len(ref), lb=None, sq=sqb)
+    recs2, _, _ = caller.call_snvs(dt, la.VarcallConf(**kw))
+    assert recs.tobytes() == recs2.tobytes() and len(recs) >= 3
