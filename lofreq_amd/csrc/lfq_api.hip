@@ -42,6 +42,12 @@
     } while (0)
 
 /* the columns handed out by lfq_pileup_indel_columns live here until the next call */
+static inline double lfq_now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static const bool lfq_timing_on = getenv("LFQ_TIMING") != nullptr;
+
 struct LfqIndelColsOwned {
     lfq_indel_columns cols;
     std::vector<uint8_t> ref_base, cons_indel;
@@ -1637,6 +1643,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     const uint8_t *t_bi = rs->h_bi, *t_bd = rs->h_bd, *t_ai = rs->h_ai, *t_ad = rs->h_ad, *t_fl = rs->fl.data();
     const int32_t *t_sq = rs->h_sq ? rs->h_sq : (rs->sq32.empty() ? nullptr : rs->sq32.data());
 
+    double tm[8] = {lfq_now_ms(), 0, 0, 0, 0, 0, 0, 0};
     /* 1. events from the CIGARs, in read (= pileup) order */
     struct Ev { int64_t pos; int64_t read; int32_t qpos, indel; };
     std::vector<Ev> evs;
@@ -1692,6 +1699,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         }
     }
     std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
+    tm[1] = lfq_now_ms();
     std::vector<uint8_t> g_ai, g_ad;        /* per event, when the qualities come from the device */
 
     if (n == 0 || width == 0) {
@@ -1754,6 +1762,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         if (rc == LFQ_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
             rc = LFQ_ERR_HIP;
         }
+        tm[2] = lfq_now_ms();
         /* 3. columns = covered positions; quality arrays of the reads without an event at the event positions */
         std::vector<int64_t> pos_off[2];
         int64_t ne_total[2] = {0, 0};
@@ -1851,6 +1860,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 }
             }
         }
+        tm[3] = lfq_now_ms();
         /* ai / ad of the event reads when lfq_readset_baq left them on the device */
         if (rc == LFQ_OK && rs->has_idaq && !evs.empty()) {
             std::vector<int64_t> idx(evs.size());
@@ -1879,6 +1889,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         if (rc != LFQ_OK) {
             return rc;
         }
+        tm[4] = lfq_now_ms();
         /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
          * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */
         std::vector<int64_t> col_of((size_t)width, -1);
@@ -1902,6 +1913,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             size_t e1 = ei;
             while (e1 < evs.size() && col_of[(size_t)(evs[e1].pos - region_begin)] == col) {
                 e1++;
+            }
+            if (e1 == ei) {                             /* the common case: a column without events */
+                O.side[0].ev_off.push_back((int64_t)O.side[0].ev_fw.size());
+                O.side[1].ev_off.push_back((int64_t)O.side[1].ev_fw.size());
+                continue;
             }
             for (int sd = 0; sd < 2; sd++) {
                 LfqIndelColsOwned::Side &S = O.side[sd];
@@ -1972,12 +1988,16 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             ei = e1;
         }
     }
+    tm[5] = lfq_now_ms();
     /* 5. consensus indel (plp.c:1236-1270): the largest sum of qualities of one event against the sum over the
      * reads without an event of that side */
     O.cons_indel.assign(O.cov.size(), 0);
     for (int64_t col = 0; col < (int64_t)O.cov.size(); col++) {
         for (int sd = 0; sd < 2; sd++) {
             const LfqIndelColsOwned::Side &S = O.side[sd];
+            if (S.ev_off[(size_t)col] == S.ev_off[(size_t)col + 1]) {
+                continue;                               /* no event of this side: nothing can exceed the non-event sum */
+            }
             int64_t best = 0, non = 0;
             for (int64_t e = S.ev_off[(size_t)col]; e < S.ev_off[(size_t)col + 1]; e++) {
                 int64_t sum = 0;
@@ -1993,6 +2013,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 O.cons_indel[(size_t)col] = 1;
             }
         }
+    }
+    tm[6] = lfq_now_ms();
+    if (lfq_timing_on) {
+        fprintf(stderr, "[lfq timing] indel pileup: events %.1f  device counts %.1f  columns+scatter %.1f  gather %.1f  tables %.1f  consensus %.1f ms\n",
+                tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);
     }
     /* 6. publish */
     lfq_indel_columns &C = O.cols;
