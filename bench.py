@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--plant-period", type=int, default=997)
     ap.add_argument("--cpu-sample-cols", type=int, default=8000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="N=1 only: two contexts, batch k+1 is submitted (lfq_call_snvs_submit) before batch k is "
+                         "collected; every step still does all of its work inside the timed region")
     ap.add_argument("--shard-path", action="store_true",
                     help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
     return ap.parse_args()
@@ -116,6 +119,22 @@ def main():
             text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
         return conf, st, recs, text, caller.kernel_times()
 
+    pipelined = args.pipeline and world == 1 and not args.shard_path
+    if pipelined:
+        callers = [caller, la.SnvCaller(local_rank)]
+
+        def submit(k):
+            conf = la.VarcallConf()
+            callers[k % 2].call_snvs_submit(batch, conf)
+            return conf
+
+        def collect(k, conf):
+            recs, st = callers[k % 2].call_snvs_collect(conf, records_capacity=1 << 16)
+            thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
+            keep = la.filter_records(recs, thr, apply_defaults=False)
+            text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
+            return conf, st, recs, text, callers[k % 2].kernel_times()
+
     for _ in range(args.warmup):
         step()
 
@@ -127,9 +146,17 @@ def main():
     kt_acc = None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        conf, st, recs, text, kt = step()
-        kt_acc = kt if kt_acc is None else {k: kt_acc[k] + kt[k] for k in kt}
+    if pipelined:
+        pending = submit(0)
+        for k in range(1, args.steps + 1):
+            nxt = submit(k) if k < args.steps else None
+            conf, st, recs, text, kt = collect(k - 1, pending)
+            kt_acc = kt if kt_acc is None else {x: kt_acc[x] + kt[x] for x in kt}
+            pending = nxt
+    else:
+        for _ in range(args.steps):
+            conf, st, recs, text, kt = step()
+            kt_acc = kt if kt_acc is None else {k: kt_acc[k] + kt[k] for k in kt}
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -173,6 +200,7 @@ def main():
                 "columns_per_gpu": ncols, "depth": depth, "planted_snv_period": args.plant_period,
                 "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
+                "pipeline_depth": 2 if pipelined else 1,
                 "kernel_ms": kt,
             },
             "roofline": {

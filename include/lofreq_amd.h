@@ -380,6 +380,16 @@ int lfq_readset_fetch_tags(lfq_ctx *ctx, lfq_readset *rs, uint8_t *lb_out, uint8
 int lfq_source_qual_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int def_nm_q, int min_bq,
                           const uint8_t *ign_or_null, int32_t *sq_out, uint8_t *sq_byte_or_null);
 
+/* lfq_call_snvs_batch in two halves, for callers that keep more than one batch in flight (one context per batch in
+ * flight): submit launches the kernels and returns; collect waits, fetches the sparse records and finishes them on
+ * the host.  While batch k is collected, the kernels of batch k+1 (submitted on another context) run.  conf's
+ * running Bonferroni factor is read at submit and advanced at collect, so batches in flight at the same time
+ * need confs of their own -- independent regions, as call-parallel's bins are.  Host tracks handed to submit
+ * (tracks_on_device = 0) must stay valid until collect. */
+int lfq_call_snvs_submit(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *tracks, int tracks_on_device);
+int lfq_call_snvs_collect(lfq_ctx *ctx, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
+                          int64_t *n_records, lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out);
+
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,
                        const int32_t *coverage_plp_or_null, const uint8_t *ref_base,

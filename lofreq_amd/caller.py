@@ -144,6 +144,25 @@ class SnvCaller:
         _lib.check(rc, "lfq_call_snvs_batch")
         return rec[: n.value].copy(), counts, st
 
+    def call_snvs_submit(self, batch, conf):
+        """first half of call_snvs: launch the kernels of the batch and return (one batch in flight per context)"""
+        t = batch._tracks()
+        self._sub = (batch, t)                   # keep the arrays alive until collect
+        _lib.check(self.L.lfq_call_snvs_submit(self.h, C.byref(conf.c), C.byref(t), 1 if batch.on_device else 0),
+                   "lfq_call_snvs_submit")
+
+    def call_snvs_collect(self, conf, records_capacity=1 << 16):
+        """second half: wait, finish on the host -> (records, BatchStats); mutates conf like call_snvs"""
+        cap = int(records_capacity)
+        rec = np.empty(cap, dtype=_lib.SNV_RECORD_DTYPE)
+        n = C.c_int64(0)
+        st = _lib.BatchStats()
+        rc = self.L.lfq_call_snvs_collect(self.h, C.byref(conf.c), C.c_void_p(rec.ctypes.data), cap, C.byref(n), None,
+                                          C.byref(st))
+        self._sub = None
+        _lib.check(rc, "lfq_call_snvs_collect")
+        return rec[: n.value].copy(), st
+
     def uniq_detlim(self, batch, af):
         """`lofreq uniq --use-det-lim` (uniq_snv, lofreq_uniq.c:274-333) over a batch of columns: af[col] = the
         variant's allele frequency -> (detectable uint8 per column: the UNIQ condition, p-values longdouble)"""

@@ -110,6 +110,9 @@ struct lfq_ctx {
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     LfqIndelColsOwned *plp_indel;
+    int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */
+    const uint8_t *sub_ref_host;
+    double sub_t0, sub_t1;
     const float *detlim_af;          /* device: per-column allele frequency while lfq_uniq_detlim_batch runs, else null */
     float *d_detlim;
     int64_t detlim_cap;
@@ -321,6 +324,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
         return LFQ_ERR_NOMEM;
     }
     c->device = device_ordinal;
+    c->sub_ncols = -1;
     hipDeviceProp_t prop;
     c->n_cu = 256;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -780,22 +784,18 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
     return LFQ_OK;
 }
 
-int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
-                        lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
-                        lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+/* layer 2, asynchronous half: stage the tracks if they are host buffers and launch the kernels of the batch */
+int lfq_call_snvs_submit(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device)
 {
-    if (!c || !conf || !tr || !n_records || tr->ncols < 0) {
+    if (!c || !conf || !tr || tr->ncols < 0) {
         return LFQ_ERR_INVALID;
     }
-    *n_records = 0;
+    c->sub_ncols = -1;
+    c->sub_t0 = lfq_now_ms();
     if (tr->ncols == 0) {
-        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        c->sub_ncols = 0;
         return LFQ_OK;
     }
-    static const bool timing = getenv("LFQ_TIMING") != nullptr;     /* host phases of one call to stderr */
-    double tp[6] = {0, 0, 0, 0, 0, 0};
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    tp[0] = now();
     LFQ_TRY_HIP(hipSetDevice(c->device));
     const int64_t ncols = tr->ncols;
     lfq_tracks dev;
@@ -803,17 +803,33 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
     LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
     LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
     LFQ_TRY(lfq_snv_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
-    tp[1] = now();
-    lfq_batch_stats st;
-#ifdef LFQ_TRACE
-    fprintf(stderr, "[lfq] launched, waiting\n");
-#endif
-    LFQ_TRY(lfq_batch_finish(c, &st));
-#ifdef LFQ_TRACE
-    fprintf(stderr, "[lfq] finished: tested %ld pvals %ld\n", (long)st.n_tested, (long)st.n_pvals);
-#endif
+    c->sub_ncols = ncols;
+    c->sub_ref_host = tracks_on_device ? nullptr : tr->ref_base;
+    c->sub_t1 = lfq_now_ms();
+    return LFQ_OK;
+}
 
-    tp[2] = now();
+/* layer 2, second half: wait for the batch submitted on this context, fetch the sparse records, exact emit test,
+ * strand bias, records; conf's Bonferroni bookkeeping as the per-column loop does it */
+int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
+                          int64_t *n_records, lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+{
+    if (!c || !conf || !n_records || c->sub_ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_records = 0;
+    const int64_t ncols = c->sub_ncols;
+    c->sub_ncols = -1;
+    if (ncols == 0) {
+        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    double tp[4];
+    tp[0] = lfq_now_ms();
+    lfq_batch_stats st;
+    LFQ_TRY(lfq_batch_finish(c, &st));
+    tp[1] = lfq_now_ms();
     std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
     if (st.n_pvals > 0) {
         LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals),
@@ -823,21 +839,14 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         LFQ_TRY_HIP(hipMemcpy(h_counts_or_null, c->d_counts, (size_t)ncols * sizeof(lfq_col_counts),
                               hipMemcpyDeviceToHost));
     }
-    tp[3] = now();
+    tp[2] = lfq_now_ms();
     /* the reference base of a surviving column travels in its record (lfq_col_pvals.ref_base) */
-    const uint8_t *ref_host = tracks_on_device ? nullptr : tr->ref_base;
-#ifdef LFQ_TRACE
-    fprintf(stderr, "[lfq] finalizing\n");
-#endif
-    int rc = lfq_finalize_pvals(conf, h_pv.data(), st.n_pvals, nullptr, ref_host, records, records_capacity,
+    int rc = lfq_finalize_pvals(conf, h_pv.data(), st.n_pvals, nullptr, c->sub_ref_host, records, records_capacity,
                                 n_records);
-#ifdef LFQ_TRACE
-    fprintf(stderr, "[lfq] finalized rc=%d n=%ld\n", rc, (long)*n_records);
-#endif
-    tp[4] = now();
-    if (timing) {
+    tp[3] = lfq_now_ms();
+    if (lfq_timing_on) {
         fprintf(stderr, "[lfq timing] launch %.3f  wait %.3f  d2h %.3f  finalize %.3f ms (kernels %.3f ms, %ld records)\n",
-                tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], (double)c->times.ms_total, (long)st.n_pvals);
+                c->sub_t1 - c->sub_t0, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], (double)c->times.ms_total, (long)st.n_pvals);
     }
     /* Bonferroni bookkeeping of the per-column loop (lofreq_call.c:794-801) */
     if (st.n_tested > 0) {
@@ -851,6 +860,18 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         *stats_out = st;
     }
     return rc;
+}
+
+int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
+                        lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
+                        lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+{
+    if (!c || !conf || !tr || !n_records || tr->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_records = 0;
+    LFQ_TRY(lfq_call_snvs_submit(c, conf, tr, tracks_on_device));
+    return lfq_call_snvs_collect(c, conf, records, records_capacity, n_records, h_counts_or_null, stats_out);
 }
 
 int lfq_call_indel_tests_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,

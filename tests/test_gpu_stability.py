@@ -64,3 +64,32 @@ def test_invalid_arguments_are_error_codes(caller):
     af = np.array([0.1, 2.0, 0.1], np.float32)                  # AF out of range (lofreq_uniq.c:262-268)
     det = np.zeros(3, np.uint8)
     assert L.lfq_uniq_detlim_batch(caller.h, C.byref(t), 0, vp(af.ctypes.data), vp(det.ctypes.data), None) < 0
+
+
+def test_submit_collect_two_batches_in_flight(caller, oracle):
+    """lfq_call_snvs_submit / _collect on two contexts: batch k+1 launched before batch k is finished on the host;
+    records identical to the one-call route"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(11)
+    hosts = [util.random_batch(rng, 300, 300, 900, planted={7: 0.3, 100: 0.5, 200: 0.2}) for _ in range(4)]
+    batches = [util.to_pileup_batch(la, h) for h in hosts]
+    want = [caller.call_snvs(b, la.VarcallConf())[0] for b in batches]
+    other = la.SnvCaller(0)
+    ctx = [caller, other]
+    confs = [la.VarcallConf() for _ in batches]
+    got = [None] * len(batches)
+    ctx[0].call_snvs_submit(batches[0], confs[0])
+    for k in range(1, len(batches) + 1):
+        if k < len(batches):
+            ctx[k % 2].call_snvs_submit(batches[k], confs[k])
+        got[k - 1], st = ctx[(k - 1) % 2].call_snvs_collect(confs[k - 1])
+    for g, w, cf in zip(got, want, confs):
+        assert g.tobytes() == w.tobytes()
+        assert cf.num_snv_tests > 0
+    assert sum(len(w) for w in want) > 0
+    # collect without a submitted batch is an error, not a hang
+    from lofreq_amd import _lib
+    n = __import__("ctypes").c_int64(0)
+    assert _lib.load().lfq_call_snvs_collect(caller.h, __import__("ctypes").byref(confs[0].c), None, 0,
+                                             __import__("ctypes").byref(n), None, None) < 0
+    other.close()
