@@ -974,21 +974,42 @@ void pack_indel_test(IndelPack &pk, const lfq_indel_columns *b, const lfq_conf *
     const bool use_mq = (conf->flag & LFQ_USE_MQ) != 0;
     const bool use_sq = (conf->flag & LFQ_USE_SQ) != 0 && S.rd_sq;
     const bool use_aq = (conf->flag & LFQ_USE_IDAQ) != 0 && S.rd_aq;
-    for (int64_t i = S.ne_off[c]; i < S.ne_off[c + 1]; i++) {
-        pk.nt.push_back(0);
-        pk.bq.push_back((uint8_t)std::min(std::max((int)S.ne_q[i], 0), 254));
-        pk.baq.push_back(LFQ_Q_MISSING);
-        pk.mq.push_back(use_mq && S.ne_mq ? q8(S.ne_mq[i]) : (uint8_t)LFQ_Q_MISSING);
-        pk.sq.push_back(LFQ_Q_MISSING);
+    /* sized once, filled through raw pointers: this loop moves every read of every tested column */
+    const int64_t n_ne = S.ne_off[c + 1] - S.ne_off[c];
+    const int64_t n_rd = S.rd_off[S.ev_off[c + 1]] - S.rd_off[S.ev_off[c]];
+    const size_t base = pk.nt.size(), total = base + (size_t)(n_ne + n_rd);
+    pk.nt.resize(total);
+    pk.bq.resize(total);
+    pk.baq.resize(total);
+    pk.mq.resize(total);
+    pk.sq.resize(total);
+    uint8_t *p_nt = pk.nt.data() + base, *p_bq = pk.bq.data() + base, *p_baq = pk.baq.data() + base,
+            *p_mq = pk.mq.data() + base, *p_sq = pk.sq.data() + base;
+    {
+        const int16_t *q = S.ne_q + S.ne_off[c], *m = (use_mq && S.ne_mq) ? S.ne_mq + S.ne_off[c] : nullptr;
+        memset(p_nt, 0, (size_t)n_ne);
+        memset(p_baq, LFQ_Q_MISSING, (size_t)n_ne);
+        memset(p_sq, LFQ_Q_MISSING, (size_t)n_ne);
+        for (int64_t i = 0; i < n_ne; i++) {
+            p_bq[i] = (uint8_t)std::min(std::max((int)q[i], 0), 254);
+        }
+        if (m) {
+            for (int64_t i = 0; i < n_ne; i++) {
+                p_mq[i] = q8(m[i]);
+            }
+        } else {
+            memset(p_mq, LFQ_Q_MISSING, (size_t)n_ne);
+        }
     }
+    int64_t w = n_ne;
     for (int64_t e = S.ev_off[c]; e < S.ev_off[c + 1]; e++) {
         const bool me = e == ev;                     /* strcmp(it->key, key) == 0 (snpcaller.c:540) */
-        for (int64_t i = S.rd_off[e]; i < S.rd_off[e + 1]; i++) {
-            pk.nt.push_back(me ? 1 : 0);
-            pk.bq.push_back((uint8_t)std::min(std::max((int)S.rd_q[i], 0), 254));
-            pk.baq.push_back(me && use_aq ? q8(S.rd_aq[i]) : (uint8_t)LFQ_Q_MISSING);
-            pk.mq.push_back(use_mq && S.rd_mq ? q8(S.rd_mq[i]) : (uint8_t)LFQ_Q_MISSING);
-            pk.sq.push_back(use_sq ? q8(S.rd_sq[i]) : (uint8_t)LFQ_Q_MISSING);
+        for (int64_t i = S.rd_off[e]; i < S.rd_off[e + 1]; i++, w++) {
+            p_nt[w] = me ? 1 : 0;
+            p_bq[w] = (uint8_t)std::min(std::max((int)S.rd_q[i], 0), 254);
+            p_baq[w] = me && use_aq ? q8(S.rd_aq[i]) : (uint8_t)LFQ_Q_MISSING;
+            p_mq[w] = use_mq && S.rd_mq ? q8(S.rd_mq[i]) : (uint8_t)LFQ_Q_MISSING;
+            p_sq[w] = use_sq ? q8(S.rd_sq[i]) : (uint8_t)LFQ_Q_MISSING;
         }
     }
     const uint64_t end = pk.nt.size();
@@ -1929,6 +1950,9 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             S.rd_off.push_back(0);
         }
         const int64_t ncols = (int64_t)O.cov.size();
+        std::vector<std::string> keys;
+        std::vector<std::vector<size_t>> members;
+        std::string key;
         size_t ei = 0;
         for (int64_t col = 0; col < ncols; col++) {
             size_t e1 = ei;
@@ -1942,14 +1966,17 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
             for (int sd = 0; sd < 2; sd++) {
                 LfqIndelColsOwned::Side &S = O.side[sd];
-                std::vector<std::string> keys;
-                std::vector<std::vector<size_t>> members;
+                keys.clear();                           /* (reused across columns: no allocation in the common case) */
+                for (auto &m : members) {
+                    m.clear();
+                }
+                size_t n_keys = 0;
                 for (size_t i = ei; i < e1; i++) {
                     const Ev &e = evs[i];
                     if ((e.indel > 0) != (sd == 0)) {
                         continue;
                     }
-                    std::string key;
+                    key.clear();
                     if (sd == 0) {                                      /* inserted bases, plp.c:1082-1086 */
                         const int64_t s0 = rd->seq_off[e.read], lq = rd->seq_off[e.read + 1] - s0;
                         for (int j = 1; j <= e.indel; j++) {
@@ -1964,16 +1991,19 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                         }
                     }
                     size_t ki = 0;
-                    while (ki < keys.size() && keys[ki] != key) {
+                    while (ki < n_keys && keys[ki] != key) {
                         ki++;
                     }
-                    if (ki == keys.size()) {
+                    if (ki == n_keys) {
                         keys.push_back(key);
-                        members.emplace_back();
+                        if (members.size() <= n_keys) {
+                            members.emplace_back();
+                        }
+                        n_keys++;
                     }
                     members[ki].push_back(i);
                 }
-                for (size_t ki = 0; ki < keys.size(); ki++) {
+                for (size_t ki = 0; ki < n_keys; ki++) {
                     int fw = 0, rv = 0;
                     for (size_t i : members[ki]) {
                         const Ev &e = evs[i];
