@@ -254,11 +254,20 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
     }
 }
 
+/* VPAD: the highest VGPR the kernel claims (0 = what it needs, 72 -> 7 wavefronts per SIMD).  96 / 128 cap the
+ * residency at 5 / 4 wavefronts per SIMD, which leaves registers for the DP kernels of the previous batch segment
+ * to run beside it (LFQ_COUNT_VGPRS, with LFQ_SEGMENTS > 1). */
+template <int VPAD>
 __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
                                                         const LfqLuts *__restrict__ luts,
                                                         lfq_col_counts *__restrict__ out,
                                                         uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
+    if (VPAD == 96) {
+        asm volatile("; claim v95" ::: "v95");
+    } else if (VPAD == 128) {
+        asm volatile("; claim v127" ::: "v127");
+    }
     __shared__ uint32_t s_hist[4][128];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
@@ -725,7 +734,18 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         return LFQ_OK;
     }
     const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
-    hipLaunchKernelGGL(lfq_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
+    static const int vpad = getenv("LFQ_COUNT_VGPRS") ? atoi(getenv("LFQ_COUNT_VGPRS")) : 0;
+    if (vpad == 96) {
+        hipLaunchKernelGGL(lfq_count_kernel<96>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
+                           d_counts, d_flags, c0, c1);
+        return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+    }
+    if (vpad == 128) {
+        hipLaunchKernelGGL(lfq_count_kernel<128>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
+                           d_counts, d_flags, c0, c1);
+        return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+    }
+    hipLaunchKernelGGL(lfq_count_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
                        d_counts, d_flags, c0, c1);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
