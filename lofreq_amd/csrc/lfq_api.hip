@@ -1163,12 +1163,15 @@ struct lfq_readset {
     bool has_lb, has_idaq, has_sqb, has_bi, has_bd;
     std::vector<uint8_t> fl;            /* per read: bit 0..3 = has BI / BD / ai / ad (host flags or from the device BAQ) */
     std::vector<int32_t> sq32;          /* source quality per read once computed */
+    int32_t *d_pmax;                    /* position-sorted reads: running maximum of the end coordinates (lazily) */
+    int pmax_state;                     /* 0 unknown, 1 sorted (d_pmax valid), 2 unsorted */
 };
 
 void lfq_readset_destroy(lfq_readset *rs)
 {
     if (rs) {
         if (rs->blob) (void)hipFree(rs->blob);
+        if (rs->d_pmax) (void)hipFree(rs->d_pmax);
         delete rs;
     }
 }
@@ -1194,6 +1197,8 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->h_flags = tg ? tg->tag_flags : nullptr;
     rs->h_sq = tg ? tg->sq : nullptr;
     rs->blob = nullptr;
+    rs->d_pmax = nullptr;
+    rs->pmax_state = 0;
     rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
     const int64_t n = rs->n, nb = rs->n_bases;
     rs->fl.assign((size_t)std::max<int64_t>(n, 1), 0);
@@ -1255,6 +1260,45 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     }
     *out = rs;
     return LFQ_OK;
+}
+
+/* position-sorted reads (what mpileup requires) take the column-major pileup kernels, which find the reads that can
+ * overlap a position by binary search: they need the running maximum of the end coordinates.  -> device array or null */
+static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
+{
+    if (rs->pmax_state == 0) {
+        rs->pmax_state = 2;
+        const int64_t n = rs->n;
+        bool sorted = getenv("LFQ_PILEUP_ATOMIC") == nullptr;
+        for (int64_t r = 1; sorted && r < n; r++) {
+            sorted = rs->pos[r] >= rs->pos[r - 1];
+        }
+        if (sorted && n > 0) {
+            std::vector<int32_t> pmax((size_t)n);
+            int32_t run = INT32_MIN;
+            for (int64_t r = 0; r < n; r++) {
+                const uint32_t *cg = rs->cigar + rs->cigar_off[r];
+                const int nc = (int)(rs->cigar_off[r + 1] - rs->cigar_off[r]);
+                int64_t e = rs->pos[r];
+                for (int k = 0; k < nc; k++) {
+                    const int op = cg[k] & 0xf;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) {
+                        e += cg[k] >> 4;
+                    }
+                }
+                run = std::max<int32_t>(run, (int32_t)std::min<int64_t>(e, INT32_MAX));
+                pmax[(size_t)r] = run;
+            }
+            if (hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
+                && hipMemcpy(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) {
+                rs->pmax_state = 1;
+            } else if (rs->d_pmax) {
+                (void)hipFree(rs->d_pmax);
+                rs->d_pmax = nullptr;
+            }
+        }
+    }
+    return rs->pmax_state == 1 ? rs->d_pmax : nullptr;
 }
 
 int lfq_readset_fetch_tags(lfq_ctx *c, lfq_readset *rs, uint8_t *lb_out, uint8_t *ai_out, uint8_t *ad_out, uint8_t *tag_flags)
@@ -1578,7 +1622,10 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.cov = (int32_t *)(d + o_cov);
     A.nb = (int32_t *)(d + o_nb);
     A.cursor = (int32_t *)(d + o_cur);
-    LFQ_TRY(lfq_launch_pileup_count(A, c->stream));
+    /* position-sorted reads (the normal case): the column-major kernels; otherwise one thread per read + atomics */
+    A.pmax_end = readset_pmax(c, rs);
+    const bool sorted = A.pmax_end != nullptr;
+    LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, c->stream) : lfq_launch_pileup_count(A, c->stream));
     /* prefix sums on the host: 8 bytes per reference position of the region, once per region */
     std::vector<int32_t> cov((size_t)width), nb((size_t)width), cidx((size_t)width, -1);
     LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1631,7 +1678,7 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.t_baq = t + t_baq;
     A.t_mq = t + t_mq;
     A.t_sq = rs->has_sqb ? t + t_sq : nullptr;
-    LFQ_TRY(lfq_launch_pileup_scatter(A, c->stream));
+    LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 1, c->stream) : lfq_launch_pileup_scatter(A, c->stream));
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
     out->nt = t + t_nt;
     out->bq = t + t_bq;
@@ -1793,7 +1840,8 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         }
         std::vector<int32_t> h[7];
         if (rc == LFQ_OK) {
-            rc = lfq_launch_plp_indel(A, 0, c->stream);
+            A.pmax_end = readset_pmax(c, rs);
+            rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 0, c->stream) : lfq_launch_plp_indel(A, 0, c->stream);
         }
         for (int i = 0; i < 7 && rc == LFQ_OK; i++) {
             h[i].resize((size_t)width);
@@ -1886,7 +1934,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 A.ne_q[1] = d_ne + 2 * ne_total[0];
                 A.ne_mq[1] = d_ne + 2 * ne_total[0] + ne_total[1];
                 if (rc == LFQ_OK) {
-                    rc = lfq_launch_plp_indel(A, 1, c->stream);
+                    rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 1, c->stream) : lfq_launch_plp_indel(A, 1, c->stream);
                 }
                 for (int sd = 0; sd < 2 && rc == LFQ_OK; sd++) {
                     O.side[sd].ne_q.resize((size_t)ne_total[sd]);

@@ -215,8 +215,10 @@ struct LfqPileupArgs {
     uint8_t *t_nt, *t_bq, *t_baq, *t_mq;  /* packed tracks */
     const uint8_t *sq;                    /* [n] per-read source quality byte or null */
     uint8_t *t_sq;
+    const int32_t *pmax_end;              /* [n] sorted reads: max over reads 0..r of the end coordinate (exclusive); null = unsorted input */
 };
 int lfq_launch_pileup_count(const LfqPileupArgs &a, void *stream);
+int lfq_launch_pileup_columns(const LfqPileupArgs &a, int scatter, void *stream);
 
 /* the indel fields of compile_plp_col (plp.c:1019-1192), dense part on the device */
 struct LfqPlpIndelArgs {
@@ -235,8 +237,10 @@ struct LfqPlpIndelArgs {
     const int64_t *ne_off[2];             /* [width] start of the position's slice per side, -1 = not wanted */
     int32_t *cursor[2];                   /* [width] */
     int16_t *ne_q[2], *ne_mq[2];
+    const int32_t *pmax_end;              /* sorted reads: see LfqPileupArgs; selects the column-major kernel */
 };
 int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream);
+int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *stream);
 int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n, uint8_t *oa, uint8_t *ob, void *stream);
 
 /* source quality (lfq_srcq.hip) */

@@ -259,3 +259,276 @@ int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, i
     hipLaunchKernelGGL(lfq_gather2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, idx, n, oa, ob);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
+
+
+/* ---- column-major pileup for position-sorted reads (what mpileup requires anyway) ----------------------------
+ * One wavefront per reference position: the reads that can overlap it are a window of the sorted read list --
+ * from the first read whose running maximum of end coordinates exceeds the position to the last read starting at
+ * or before it (two binary searches).  The lanes walk the window 64 reads at a time, each lane resolving its read's
+ * CIGAR at the position (resolve_cigar2: a base, a deleted / skipped position, or no overlap).  Pass 0 counts
+ * coverage_plp and num_bases with wave reductions; pass 1 writes the kept bases to the column's slice at
+ * base + rank (ballot + mbcnt): no atomics, coalesced stores, and the observations of a column come out in pileup
+ * order.  The read bytes are fetched from L2: neighbouring positions share their window. */
+__device__ __forceinline__ int lfq_plp_locate(const uint32_t *cg, int n_cigar, int64_t x, int64_t p, int *qpos)
+{
+    int y = 0;                                   /* -> 1: base at *qpos, 2: deleted / skipped, 0: no overlap */
+    for (int k = 0; k < n_cigar; ++k) {
+        const int op = cg[k] & 0xf, l = cg[k] >> 4;
+        if (op == 0 || op == 7 || op == 8) {
+            if (p < x + l) {
+                *qpos = y + (int)(p - x);
+                return p >= x ? 1 : 0;
+            }
+            x += l; y += l;
+        } else if (op == 2 || op == 3) {
+            if (p < x + l) {
+                return p >= x ? 2 : 0;
+            }
+            x += l;
+        } else if (op == 1 || op == 4) {
+            y += l;
+        }
+    }
+    return 0;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void lfq_pileup_columns_kernel(LfqPileupArgs A)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= A.width) {
+        return;
+    }
+    const int64_t p = A.begin + c;
+    int ci = 0;
+    uint64_t base = 0;
+    if (SCATTER) {
+        ci = A.col_index[c];
+        if (ci < 0) {
+            return;
+        }
+        base = A.col_off[ci];
+    }
+    /* window [lo, hi): lo = first read with pmax_end > p, hi = first read with pos > p (wave-uniform searches) */
+    int64_t lo = 0, hi = A.n_reads;
+    {
+        int64_t a = 0, b = A.n_reads;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if ((int64_t)A.pmax_end[m] > p) b = m; else a = m + 1;
+        }
+        lo = a;
+        a = lo; b = A.n_reads;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if ((int64_t)A.pos[m] > p) b = m; else a = m + 1;
+        }
+        hi = a;
+    }
+    uint32_t n_cov = 0, n_kept = 0;
+    for (int64_t r0 = lo; r0 < hi; r0 += 64) {
+        const int64_t r = r0 + lane;
+        int kind = 0, qpos = 0;
+        if (r < hi) {
+            const int64_t co = A.cigar_off[r];
+            kind = lfq_plp_locate(A.cigar + co, (int)(A.cigar_off[r + 1] - co), A.pos[r], p, &qpos);
+        }
+        int bq = 0;
+        int64_t s0 = 0;
+        if (kind == 1) {
+            s0 = A.seq_off[r];
+            bq = A.qual[s0 + qpos];
+        }
+        const bool kept = kind == 1 && bq >= A.min_plp_bq;
+        const uint64_t mk = __ballot(kept);
+        if (!SCATTER) {
+            n_cov += (uint32_t)__popcll(__ballot(kind != 0));
+            n_kept += (uint32_t)__popcll(mk);
+        } else {
+            if (kept) {
+                const uint64_t slot = base + n_kept + (uint64_t)__popcll(mk & ((1ull << lane) - 1ull));
+                const uint32_t code = A.seq[s0 + qpos];
+                A.t_nt[slot] = (uint8_t)((code > 4 ? 4u : code) | (A.reverse[r] ? 8u : 0u));
+                A.t_bq[slot] = (uint8_t)(bq > 93 ? 93 : bq);                                   /* plp.c:948-952 */
+                const uint32_t lb = A.baq ? A.baq[s0 + qpos] : 0u;
+                A.t_baq[slot] = A.baq ? (uint8_t)(lb >= 33 ? lb - 33 : 255) : (uint8_t)255;
+                A.t_mq[slot] = A.mapq[r];
+                if (A.t_sq) {
+                    A.t_sq[slot] = A.sq[r];
+                }
+            }
+            n_kept += (uint32_t)__popcll(mk);
+        }
+    }
+    if (!SCATTER && lane == 0) {
+        A.cov[c] = (int32_t)n_cov;
+        A.nb[c] = (int32_t)n_kept;
+    }
+}
+
+int lfq_launch_pileup_columns(const LfqPileupArgs &a, int scatter, void *stream)
+{
+    if (a.n_reads <= 0 || a.width <= 0) {
+        return LFQ_OK;
+    }
+    const dim3 grid((unsigned)((a.width + 3) / 4)), block(256);
+    if (scatter) {
+        hipLaunchKernelGGL(lfq_pileup_columns_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(lfq_pileup_columns_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+
+/* ---- the indel fields, column-major (position-sorted reads): same window walk as lfq_pileup_columns_kernel ------
+ * Per read and position: the pileup entry (base or deleted / skipped position), its query position (htslib: the
+ * next base for an entry inside a deletion), the indel that follows if this is the last position of its CIGAR
+ * operation, whether it is the read's last aligned position (is_tail).  Pass 0: the seven per-position counts by
+ * ballots; pass 1: the (quality, MAPQ) of the reads without an insertion resp. deletion, in pileup order. */
+__device__ __forceinline__ int lfq_plp_locate_indel(const uint32_t *cg, int n_cigar, int64_t x, int64_t p, int l_qseq,
+                                                    int *qpos, int *indel, bool *tail)
+{
+    int y = 0, kind = 0;
+    *indel = 0;
+    for (int k = 0; k < n_cigar; ++k) {
+        const int op = cg[k] & 0xf, l = cg[k] >> 4;
+        const bool m = op == 0 || op == 7 || op == 8, d = op == 2 || op == 3;
+        if ((m || d) && kind == 0 && p >= x && p < x + l) {
+            kind = m ? 1 : 2;
+            int q = m ? y + (int)(p - x) : y;
+            *qpos = q < l_qseq ? q : l_qseq - 1;
+            if (p == x + l - 1 && k + 1 < n_cigar) {            /* resolve_cigar2: peek at the next operation */
+                const int op2 = cg[k + 1] & 0xf, l2 = cg[k + 1] >> 4;
+                if (op2 == 2) {
+                    *indel = -l2;
+                } else if (op2 == 1) {
+                    *indel = l2;
+                } else if (op2 == 6 && k + 2 < n_cigar) {
+                    int l3 = 0;
+                    for (int kk = k + 2; kk < n_cigar; ++kk) {
+                        const int o3 = cg[kk] & 0xf;
+                        if (o3 == 1) {
+                            l3 += cg[kk] >> 4;
+                        } else if (o3 == 2 || o3 == 0 || o3 == 3 || o3 == 7 || o3 == 8) {
+                            break;
+                        }
+                    }
+                    *indel = l3 > 0 ? l3 : 0;
+                }
+            }
+        }
+        if (m) {
+            x += l; y += l;
+        } else if (d) {
+            x += l;
+        } else if (op == 1 || op == 4) {
+            y += l;
+        }
+    }
+    *tail = (p == x - 1);                        /* x is now bam_endpos */
+    return kind;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void lfq_plp_indel_columns_kernel(LfqPlpIndelArgs A)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= A.width) {
+        return;
+    }
+    const int64_t p = A.begin + c;
+    int64_t off0 = -1, off1 = -1;
+    if (SCATTER) {
+        off0 = A.ne_off[0][c];
+        off1 = A.ne_off[1][c];
+        if (off0 < 0 && off1 < 0) {
+            return;
+        }
+    }
+    int64_t lo, hi;
+    {
+        int64_t a = 0, b = A.n_reads;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if ((int64_t)A.pmax_end[m] > p) b = m; else a = m + 1;
+        }
+        lo = a;
+        b = A.n_reads;
+        while (a < b) {
+            const int64_t m = (a + b) >> 1;
+            if ((int64_t)A.pos[m] > p) b = m; else a = m + 1;
+        }
+        hi = a;
+    }
+    uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};      /* cov, tails, non_indels, n_ins, n_dels, non_ins_fw, non_del_fw */
+    uint32_t w0 = 0, w1 = 0;                      /* scatter cursors of the two sides */
+    for (int64_t r0 = lo; r0 < hi; r0 += 64) {
+        const int64_t r = r0 + lane;
+        int kind = 0, qpos = 0, indel = 0, iq = 0, dq = 0, rev = 0;
+        bool tail = false;
+        int16_t mq = 0;
+        if (r < hi) {
+            const int64_t co = A.cigar_off[r], s0 = A.seq_off[r];
+            const int l_qseq = (int)(A.seq_off[r + 1] - s0);
+            kind = lfq_plp_locate_indel(A.cigar + co, (int)(A.cigar_off[r + 1] - co), A.pos[r], p, l_qseq, &qpos, &indel, &tail);
+            if (kind) {
+                const uint32_t fl = A.tag_flags ? A.tag_flags[r] : 3u;
+                iq = (A.bi && (fl & 1u) && qpos >= 0) ? (int)A.bi[s0 + qpos] - 33 : 0;           /* plp.c:1023-1059 */
+                dq = (A.bd && (fl & 2u) && qpos >= 0) ? (int)A.bd[s0 + qpos] - 33 : 0;
+                rev = A.reverse[r] ? 1 : 0;
+                mq = (int16_t)A.mapq[r];
+            }
+        }
+        const bool pass = kind != 0 && !(iq < A.min_plp_idq || dq < A.min_plp_idq);              /* :1062 */
+        const bool no_ins = pass && indel <= 0, no_del = pass && indel >= 0;
+        if (!SCATTER) {
+            cnt[0] += (uint32_t)__popcll(__ballot(kind != 0));
+            cnt[1] += (uint32_t)__popcll(__ballot(kind == 1 && tail));                           /* :920-922 */
+            cnt[2] += (uint32_t)__popcll(__ballot(pass && indel == 0));
+            cnt[3] += (uint32_t)__popcll(__ballot(pass && indel > 0));
+            cnt[4] += (uint32_t)__popcll(__ballot(pass && indel < 0));
+            cnt[5] += (uint32_t)__popcll(__ballot(no_ins && !rev));
+            cnt[6] += (uint32_t)__popcll(__ballot(no_del && !rev));
+        } else {
+            const uint64_t m0 = __ballot(no_ins), m1 = __ballot(no_del), below = (1ull << lane) - 1ull;
+            if (no_ins && off0 >= 0) {
+                const int64_t slot = off0 + w0 + __popcll(m0 & below);
+                A.ne_q[0][slot] = (int16_t)iq;
+                A.ne_mq[0][slot] = mq;
+            }
+            if (no_del && off1 >= 0) {
+                const int64_t slot = off1 + w1 + __popcll(m1 & below);
+                A.ne_q[1][slot] = (int16_t)dq;
+                A.ne_mq[1][slot] = mq;
+            }
+            w0 += (uint32_t)__popcll(m0);
+            w1 += (uint32_t)__popcll(m1);
+        }
+    }
+    if (!SCATTER && lane == 0) {
+        A.cov[c] = (int32_t)cnt[0];
+        A.tails[c] = (int32_t)cnt[1];
+        A.non_indels[c] = (int32_t)cnt[2];
+        A.n_ins[c] = (int32_t)cnt[3];
+        A.n_dels[c] = (int32_t)cnt[4];
+        A.non_ins_fw[c] = (int32_t)cnt[5];
+        A.non_del_fw[c] = (int32_t)cnt[6];
+    }
+}
+
+int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *stream)
+{
+    if (a.n_reads <= 0 || a.width <= 0) {
+        return LFQ_OK;
+    }
+    const dim3 grid((unsigned)((a.width + 3) / 4)), block(256);
+    if (scatter) {
+        hipLaunchKernelGGL(lfq_plp_indel_columns_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(lfq_plp_indel_columns_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}

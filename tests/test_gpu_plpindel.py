@@ -2,6 +2,8 @@
 reference binary's own column dump (`lofreq plpsummary`), then reads -> columns -> indel calls against
 `lofreq call --call-indels --only-indels`, and the whole chain reads -> BAQ/IDAQ -> both pileups -> SNV + indel calls
 against `lofreq call --call-indels` (tests/golden/plpindel_*.json)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -39,8 +41,11 @@ def test_indel_columns_match_plpsummary(caller, path):
             S, E = cols.sides[sd], e[sn]
             assert int(S["non_fw"][c]) == E["non_fw"] and int(S["non_rv"][c]) == E["non_rv"], (ctx, sn)
             a, b = int(S["ne_off"][c]), int(S["ne_off"][c + 1])
-            got = sorted(zip(S["ne_q"][a:b].tolist(), S["ne_mq"][a:b].tolist()))
-            assert got == sorted(zip(gu.dec(E["ne_q"]).tolist(), E["ne_mq"])), (ctx, sn)
+            # position-sorted reads: the column-major kernel writes the arrays in pileup order = the reference's order
+            got, want = list(zip(S["ne_q"][a:b].tolist(), S["ne_mq"][a:b].tolist())), list(zip(gu.dec(E["ne_q"]).tolist(), E["ne_mq"]))
+            if os.environ.get("LFQ_PILEUP_ATOMIC"):
+                got, want = sorted(got), sorted(want)
+            assert got == want, (ctx, sn)
             e0, e1 = int(S["ev_off"][c]), int(S["ev_off"][c + 1])
             assert [cols.keys[sd][i] for i in range(e0, e1)] == [ev["key"] for ev in E["events"]], (ctx, sn)
             for i, ev in zip(range(e0, e1), E["events"]):
@@ -171,7 +176,10 @@ def test_indel_columns_random_reads_vs_plain_restatement(caller, min_idq, begin,
             assert [cols.keys[sd][i] for i in range(e0, e1)] == list(w["ev"][sd].keys()), (p, sd)
             a, b = int(S["ne_off"][c]), int(S["ne_off"][c + 1])
             if w["ev"][0] or w["ev"][1]:
-                assert sorted(zip(S["ne_q"][a:b].tolist(), S["ne_mq"][a:b].tolist())) == sorted(w["ne"][sd]), (p, sd)
+                got_ne, want_ne = list(zip(S["ne_q"][a:b].tolist(), S["ne_mq"][a:b].tolist())), list(w["ne"][sd])
+                if os.environ.get("LFQ_PILEUP_ATOMIC"):
+                    got_ne, want_ne = sorted(got_ne), sorted(want_ne)
+                assert got_ne == want_ne, (p, sd)
             else:
                 assert a == b
             for i, key in zip(range(e0, e1), w["ev"][sd]):
