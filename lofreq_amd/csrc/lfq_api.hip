@@ -1157,7 +1157,7 @@ struct lfq_readset {
     const char *ref;
     const uint8_t *h_bi, *h_bd, *h_ai, *h_ad, *h_flags;     /* tag bytes on the host, as given (may be null) */
     const int32_t *h_sq;
-    uint8_t *blob;
+    uint8_t *blob, *tag_blob;           /* inputs; lb / ai / ad computed by lfq_readset_baq */
     uint8_t *d_pos, *d_coff, *d_soff, *d_cig, *d_seq, *d_qual, *d_ref, *d_mapq, *d_rev, *d_bi, *d_bd, *d_lb, *d_ai,
             *d_ad, *d_fl, *d_sqb;
     bool has_lb, has_idaq, has_sqb, has_bi, has_bd;
@@ -1171,6 +1171,7 @@ void lfq_readset_destroy(lfq_readset *rs)
 {
     if (rs) {
         if (rs->blob) (void)hipFree(rs->blob);
+        if (rs->tag_blob) (void)hipFree(rs->tag_blob);
         if (rs->d_pmax) (void)hipFree(rs->d_pmax);
         delete rs;
     }
@@ -1197,6 +1198,7 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->h_flags = tg ? tg->tag_flags : nullptr;
     rs->h_sq = tg ? tg->sq : nullptr;
     rs->blob = nullptr;
+    rs->tag_blob = nullptr;
     rs->d_pmax = nullptr;
     rs->pmax_state = 0;
     rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
@@ -1214,10 +1216,12 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += al(bytes); return o; };
+    /* per-base arrays only where there is something to put: device allocations of this size are not free.  The
+     * outputs of lfq_readset_baq (lb, ai, ad) get their own allocation when that step runs. */
     const int64_t o_pos = take(n * 4), o_coff = take((n + 1) * 8), o_soff = take((n + 1) * 8), o_cig = take(rs->n_cig * 4),
-                  o_seq = take(nb + 16), o_qual = take(nb + 16), o_ref = take(rs->ref_len + 1), o_mapq = take(n), o_rev = take(n),
-                  o_bi = take(nb + 16), o_bd = take(nb + 16), o_lb = take(nb + 16), o_ai = take(nb + 16), o_ad = take(nb + 16),
-                  o_fl = take(n), o_sqb = take(n);
+                  o_seq = take(nb + 16), o_qual = take(rd->qual ? nb + 16 : 0), o_ref = take(rs->ref_len + 1), o_mapq = take(n),
+                  o_rev = take(n), o_bi = take(rs->h_bi ? nb + 16 : 0), o_bd = take(rs->h_bd ? nb + 16 : 0),
+                  o_lb = take(rd->baq ? nb + 16 : 0), o_fl = take(n), o_sqb = take(n);
     if (hipMalloc((void **)&rs->blob, (size_t)off) != hipSuccess) {
         delete rs;
         return LFQ_ERR_NOMEM;
@@ -1225,7 +1229,7 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     uint8_t *d = rs->blob;
     rs->d_pos = d + o_pos; rs->d_coff = d + o_coff; rs->d_soff = d + o_soff; rs->d_cig = d + o_cig; rs->d_seq = d + o_seq;
     rs->d_qual = d + o_qual; rs->d_ref = d + o_ref; rs->d_mapq = d + o_mapq; rs->d_rev = d + o_rev; rs->d_bi = d + o_bi;
-    rs->d_bd = d + o_bd; rs->d_lb = d + o_lb; rs->d_ai = d + o_ai; rs->d_ad = d + o_ad; rs->d_fl = d + o_fl;
+    rs->d_bd = d + o_bd; rs->d_lb = rd->baq ? d + o_lb : nullptr; rs->d_ai = nullptr; rs->d_ad = nullptr; rs->d_fl = d + o_fl;
     rs->d_sqb = d + o_sqb;
     int rc = LFQ_OK;
     auto up = [&](uint8_t *dst, const void *src, int64_t bytes) {
@@ -1442,6 +1446,15 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         }
     }
     const int64_t n_bases = rs->n_bases;
+    if (!rs->tag_blob) {                        /* lb (+ ai, ad): resident from here on */
+        const int64_t each = (n_bases + 16 + 255) / 256 * 256;
+        LFQ_TRY_HIP(hipMalloc((void **)&rs->tag_blob, (size_t)(each * (want_idaq ? 3 : 1))));
+        rs->d_lb = rs->tag_blob;
+        rs->d_ai = want_idaq ? rs->tag_blob + each : nullptr;
+        rs->d_ad = want_idaq ? rs->tag_blob + 2 * each : nullptr;
+    } else if (want_idaq && !rs->d_ai) {
+        return LFQ_ERR_INVALID;                 /* a second BAQ pass that suddenly wants ai / ad: make a new read set */
+    }
     float h_q2p[256];
     for (int i = 0; i < 256; i++) {
         h_q2p[i] = (float)pow(10, -i / 10.);                 /* kprobaln_ext.c:121-123 */
