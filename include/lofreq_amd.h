@@ -63,7 +63,14 @@ typedef enum lfq_status {
  *        NULL track = no source quality.
  * Track base pointers must be 16-byte aligned and readable up to the next multiple of 16 bytes
  * past col_off[ncols]; col_off itself may be arbitrary (columns need not be aligned).
+ *
+ * LFQ_TRACKS_NT_PACKED (flags; device-resident tracks only): the nt track holds two observations per byte.
+ * Observations are taken in groups of 8 (by their index in the track); byte k (k = 0..3) of a group's 4 bytes
+ * carries observation k in its low nibble and observation 4 + k in its high nibble -- the even / odd nibbles of a
+ * dword then line up with the group's two bq dwords.  The count kernel, the dominant one and HBM-bound, reads
+ * 1.5 instead of 2 bytes per observation.
  */
+#define LFQ_TRACKS_NT_PACKED 1
 #define LFQ_Q_MISSING 255
 
 typedef struct lfq_tracks {
@@ -78,6 +85,7 @@ typedef struct lfq_tracks {
     const int32_t *num_bases;    /* ncols, or NULL: = observation count (plp_col_t.num_bases) */
     int64_t ncols;
     int64_t max_col_obs;         /* deepest column of the batch, or 0 = unknown (costs one sync) */
+    int64_t flags;               /* LFQ_TRACKS_NT_PACKED or 0 */
 } lfq_tracks;
 
 /* the SNV-path fields of varcall_conf_t (snpcaller.h:38-63); defaults: lfq_conf_init */
@@ -431,6 +439,11 @@ int lfq_synth_fill_device(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t 
                           int64_t col_begin, int64_t ncols, uint8_t *d_nt, uint8_t *d_bq,
                           uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off, uint8_t *d_ref_base,
                           void *stream);
+/* same, with the nt track in the LFQ_TRACKS_NT_PACKED layout if nt_packed != 0 (d_nt then needs half the bytes) */
+int lfq_synth_fill_device_layout(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t plant_period,
+                                 int64_t col_begin, int64_t ncols, uint8_t *d_nt, uint8_t *d_bq,
+                                 uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off, uint8_t *d_ref_base,
+                                 int nt_packed, void *stream);
 
 /* --- device timing of the last batch (HIP events on the stream the kernels ran on) --- */
 typedef struct lfq_kernel_times {

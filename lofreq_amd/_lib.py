@@ -35,8 +35,11 @@ class Tracks(C.Structure):
         ("nt", C.c_void_p), ("bq", C.c_void_p), ("baq", C.c_void_p), ("mq", C.c_void_p),
         ("sq", C.c_void_p), ("col_off", C.c_void_p), ("ref_base", C.c_void_p),
         ("coverage_plp", C.c_void_p), ("num_bases", C.c_void_p), ("ncols", C.c_int64),
-        ("max_col_obs", C.c_int64),
+        ("max_col_obs", C.c_int64), ("flags", C.c_int64),
     ]
+
+
+LFQ_TRACKS_NT_PACKED = 1
 
 
 class BatchStats(C.Structure):
@@ -109,7 +112,7 @@ EXPORTS = [
     "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_call_snvs_submit", "lfq_call_snvs_collect", "lfq_finalize_pvals",
     "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_format_vcf", "lfq_snvqual_thresh", "lfq_sb_phred",
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
-    "lfq_synth_fill_device", "lfq_last_kernel_times",
+    "lfq_synth_fill_device", "lfq_synth_fill_device_layout", "lfq_last_kernel_times",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
@@ -172,6 +175,8 @@ def load():
     L.lfq_filter_records.argtypes = [vp, C.c_int64, C.c_int, C.c_int, vp]
     L.lfq_synth_fill_device.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64,
                                         vp, vp, vp, vp, vp, vp, vp]
+    L.lfq_synth_fill_device_layout.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64,
+                                               vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.lfq_last_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     L.lfq_indel_batch_device.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), vp, vp, C.c_int64, vp]
     L.lfq_call_indel_tests_batch.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int, vp, C.c_int64,

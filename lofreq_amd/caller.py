@@ -45,13 +45,14 @@ class PileupBatch:
     """
 
     def __init__(self, nt, bq, mq, col_off, ref_base, baq=None, sq=None, coverage_plp=None, num_bases=None,
-                 on_device=False, max_col_obs=0):
+                 on_device=False, max_col_obs=0, nt_packed=False):
         self.nt, self.bq, self.baq, self.mq, self.sq = nt, bq, baq, mq, sq
         self.col_off, self.ref_base = col_off, ref_base
         self.coverage_plp, self.num_bases = coverage_plp, num_bases
         self.on_device = on_device
         self.ncols = int(len(col_off) - 1)
         self.max_col_obs = int(max_col_obs)
+        self.nt_packed = bool(nt_packed)         # LFQ_TRACKS_NT_PACKED (device batches only)
 
     @staticmethod
     def from_columns(columns, ref_bases, coverage_plp=None, num_bases=None):
@@ -104,6 +105,7 @@ class PileupBatch:
         t.coverage_plp, t.num_bases = self._ptr(self.coverage_plp), self._ptr(self.num_bases)
         t.ncols = self.ncols
         t.max_col_obs = self.max_col_obs
+        t.flags = _lib.LFQ_TRACKS_NT_PACKED if self.nt_packed else 0
         return t
 
 
@@ -199,25 +201,28 @@ class SnvCaller:
         _lib.check(self.L.lfq_synchronize(self.h))
 
     # -- synthetic workload, generated directly in HBM -----------------------------------------
-    def synth_batch(self, seed, depth, ncols, plant_period=997, col_begin=0):
+    def synth_batch(self, seed, depth, ncols, plant_period=997, col_begin=0, nt_packed=True):
+        """the synthetic workload of include/lofreq_synth.h, generated in HBM; nt_packed: two observations per byte
+        in the nt track (LFQ_TRACKS_NT_PACKED), the layout device-resident producers should use"""
         import torch
         dev = torch.device("cuda", self.device)
         n = ncols * depth
-        pad = (n + 15) // 16 * 16 + 16
-        nt = torch.empty(pad, dtype=torch.uint8, device=dev)
+        pad = (n + 31) // 32 * 32 + 32
+        nt = torch.empty(pad // 2 if nt_packed else pad, dtype=torch.uint8, device=dev)
         bq = torch.empty(pad, dtype=torch.uint8, device=dev)
         baq = torch.empty(pad, dtype=torch.uint8, device=dev)
         mq = torch.empty(pad, dtype=torch.uint8, device=dev)
         off = torch.empty(ncols + 1, dtype=torch.int64, device=dev)
         ref = torch.empty(ncols + 16, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize(dev)
-        rc = self.L.lfq_synth_fill_device(self.h, int(seed), int(depth), int(plant_period), int(col_begin),
-                                          int(ncols), C.c_void_p(nt.data_ptr()), C.c_void_p(bq.data_ptr()),
-                                          C.c_void_p(baq.data_ptr()), C.c_void_p(mq.data_ptr()),
-                                          C.c_void_p(off.data_ptr()), C.c_void_p(ref.data_ptr()), None)
-        _lib.check(rc, "lfq_synth_fill_device")
+        rc = self.L.lfq_synth_fill_device_layout(self.h, int(seed), int(depth), int(plant_period), int(col_begin),
+                                                 int(ncols), C.c_void_p(nt.data_ptr()), C.c_void_p(bq.data_ptr()),
+                                                 C.c_void_p(baq.data_ptr()), C.c_void_p(mq.data_ptr()),
+                                                 C.c_void_p(off.data_ptr()), C.c_void_p(ref.data_ptr()),
+                                                 1 if nt_packed else 0, None)
+        _lib.check(rc, "lfq_synth_fill_device_layout")
         self.synchronize()
-        b = PileupBatch(nt, bq, mq, off, ref, baq=baq, on_device=True, max_col_obs=depth)
+        b = PileupBatch(nt, bq, mq, off, ref, baq=baq, on_device=True, max_col_obs=depth, nt_packed=nt_packed)
         b.ncols = ncols
         return b
 

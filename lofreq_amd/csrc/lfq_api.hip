@@ -484,6 +484,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
 
     LfqTracksDev T;
     T.nt = tr->nt;
+    T.nt_packed = (tr->flags & LFQ_TRACKS_NT_PACKED) ? 1 : 0;
+    T.pad_ = 0;
     T.bq = tr->bq;
     T.baq = tr->baq;
     T.mq = tr->mq;
@@ -741,6 +743,9 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
 {
     const int64_t ncols = tr->ncols;
     lfq_tracks dev = *tr;
+    if (!tracks_on_device && (tr->flags & LFQ_TRACKS_NT_PACKED)) {
+        return LFQ_ERR_INVALID;         /* the packed nt layout is for device-resident producers */
+    }
     if (!tracks_on_device) {
         /* host buffers: stage them (padded to the 16-byte contract) in one device allocation */
         const uint64_t n_obs = tr->col_off[ncols];
@@ -2368,6 +2373,14 @@ int lfq_synth_fill_device(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t pl
                           int64_t ncols, uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq,
                           uint64_t *d_col_off, uint8_t *d_ref_base, void *stream_or_null)
 {
+    return lfq_synth_fill_device_layout(c, seed, depth, plant_period, col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off,
+                                        d_ref_base, 0, stream_or_null);
+}
+
+int lfq_synth_fill_device_layout(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t plant_period, int64_t col_begin,
+                                 int64_t ncols, uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq,
+                                 uint64_t *d_col_off, uint8_t *d_ref_base, int nt_packed, void *stream_or_null)
+{
     if (!c || !d_nt || !d_bq || !d_baq || !d_mq || !d_col_off || !d_ref_base || ncols < 0 || depth == 0) {
         return LFQ_ERR_INVALID;
     }
@@ -2383,7 +2396,7 @@ int lfq_synth_fill_device(lfq_ctx *c, uint64_t seed, uint32_t depth, uint32_t pl
         s.err_thresh[q] = (t >= 18446744073709551615.0L) ? UINT64_MAX : (uint64_t)t;
     }
     hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
-    return lfq_launch_synth(&s, col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off, d_ref_base, st);
+    return lfq_launch_synth(&s, col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off, d_ref_base, nt_packed ? 1 : 0, st);
 }
 
 }  // extern "C"

@@ -19,6 +19,18 @@
 
 __device__ __forceinline__ int lfq_lane() { return (int)(threadIdx.x & 63u); }
 
+/* nt byte (code | strand << 3) of observation g.  Packed layout: groups of 8 observations in 4 bytes, byte k of a
+ * group holding observation k in its low and observation 4 + k in its high nibble -- so that the even / odd
+ * nibbles of a dword line up with the two bq dwords of the group (lfq_count_chunks). */
+__device__ __forceinline__ uint32_t lfq_nt_at(const LfqTracksDev &T, uint64_t g)
+{
+    if (!T.nt_packed) {
+        return T.nt[g];
+    }
+    const uint32_t b = T.nt[(g >> 3) * 4 + (g & 3u)];
+    return (g & 4u) ? (b >> 4) : (b & 15u);
+}
+
 /* lane i receives lane i-1's value, lane 0 receives 0 (DPP wave_shr:1, VALU, no LDS) */
 __device__ __forceinline__ int lfq_shr1_i32(int x)
 {

@@ -101,7 +101,7 @@ __device__ __forceinline__ LfqRaw lfq_load_chunk_at(uint64_t off0, int64_t n_obs
     r.sq = 255u;
     if (idx < n_obs) {
         const uint64_t g = off0 + (uint64_t)idx;
-        const uint32_t nt = T.nt[g], bq = T.bq[g], baq = T.baq ? T.baq[g] : 255u, mq = T.mq[g];
+        const uint32_t nt = lfq_nt_at(T, g), bq = T.bq[g], baq = T.baq ? T.baq[g] : 255u, mq = T.mq[g];
         r.w = nt | (bq << 8) | (baq << 16) | (mq << 24);
         r.sq = T.sq ? T.sq[g] : 255u;
     }
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
                     raw_sq = 255u;
                     if (l < n_obs) {
                         const uint64_t o = off0 + (uint64_t)l;
-                        raw_w = (uint32_t)T.nt[o] | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
+                        raw_w = lfq_nt_at(T, o) | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
                                 | ((uint32_t)T.mq[o] << 24);
                         raw_sq = T.sq ? T.sq[o] : 255u;
                     }
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
         raw_sq = 255u;
         if (active && cursor + l < n_obs) {          /* lands while the rows below run */
             const uint64_t o = off0 + (uint64_t)(cursor + l);
-            raw_w = (uint32_t)T.nt[o] | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
+            raw_w = lfq_nt_at(T, o) | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
                     | ((uint32_t)T.mq[o] << 24);
             raw_sq = T.sq ? T.sq[o] : 255u;
         }

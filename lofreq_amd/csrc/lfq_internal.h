@@ -50,6 +50,8 @@ struct LfqTracksDev {
     const uint8_t *ref_base;
     const int32_t *coverage_plp, *num_bases;
     int64_t ncols;
+    int32_t nt_packed;        /* LFQ_TRACKS_NT_PACKED: two observations per byte in the nt track (lofreq_amd.h) */
+    int32_t pad_;
 };
 
 /* one tested column, as the DP kernels consume it: everything a wavefront needs to start the column
@@ -297,6 +299,6 @@ int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_
                           lfq_col_pvals *d_pvals, int64_t pvals_capacity, int n_blocks, void *stream);
 int lfq_launch_synth(const struct lfq_synth_spec *d_spec_host, int64_t col_begin, int64_t ncols,
                      uint8_t *d_nt, uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off,
-                     uint8_t *d_ref_base, void *stream);
+                     uint8_t *d_ref_base, int nt_packed, void *stream);
 
 #endif

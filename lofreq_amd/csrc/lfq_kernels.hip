@@ -92,7 +92,7 @@ __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_
     }
 }
 
-template <bool SAME_THR>
+template <bool SAME_THR, bool PACKED>
 __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &T, uint64_t off0, uint64_t off1,
                                                  uint32_t minbq4, uint32_t minalt4, int lane = lfq_lane(),
                                                  int lanes = LFQ_WAVE)
@@ -101,6 +101,36 @@ __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &
     const uint4 *nt16 = reinterpret_cast<const uint4 *>(T.nt);
     const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq);
     const int64_t c0 = (int64_t)(off0 >> 4), c1 = (int64_t)((off1 + 15) >> 4);
+    if (PACKED) {
+        /* 16 observations per step like the byte layout, but the nt half is 8 bytes of nibbles: the even nibbles of an
+         * nt dword are the observations of the first bq dword of its group of 8, the odd nibbles those of the second
+         * (lfq_nt_at), so two mask operations turn a packed dword into the two byte-per-observation words the
+         * bit-plane counts work on -- 1.5 instead of 2 bytes of HBM traffic per observation, every load of a
+         * wavefront contiguous.  (Two steps' loads in flight per lane were measured: slower, the registers cost a
+         * wavefront of residency.) */
+        const uint2 *nt8 = reinterpret_cast<const uint2 *>(T.nt);
+        for (int64_t ch = c0 + lane; ch < c1; ch += lanes) {
+            const uint2 n2 = nt8[ch];
+            const uint4 b4 = bq16[ch];
+            const int64_t base = ch << 4;
+            const int lo = (int64_t)off0 > base ? (int)((int64_t)off0 - base) : 0;
+            const int hi = (int64_t)off1 < base + 16 ? (int)((int64_t)off1 - base) : 16;
+            const uint32_t e0 = n2.x & 0x0F0F0F0Fu, o0 = (n2.x >> 4) & 0x0F0F0F0Fu;
+            const uint32_t e1 = n2.y & 0x0F0F0F0Fu, o1 = (n2.y >> 4) & 0x0F0F0F0Fu;
+            if (lo == 0 && hi == 16) {
+                lfq_count_dword<SAME_THR>(a, e0, b4.x, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR>(a, o0, b4.y, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR>(a, e1, b4.z, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR>(a, o1, b4.w, 0x80808080u, minbq4, minalt4);
+            } else {
+                lfq_count_dword<SAME_THR>(a, e0, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
+                lfq_count_dword<SAME_THR>(a, o0, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
+                lfq_count_dword<SAME_THR>(a, e1, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
+                lfq_count_dword<SAME_THR>(a, o1, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
+            }
+        }
+        return;
+    }
     for (int64_t ch = c0 + lane; ch < c1; ch += lanes) {
         const uint4 n4 = nt16[ch];      /* (non-temporal loads were measured: no difference at 6.0 TB/s) */
         const uint4 b4 = bq16[ch];
@@ -175,6 +205,7 @@ __device__ __forceinline__ void lfq_count_emit(lfq_col_counts &r, const uint32_t
 /* Shallow columns (depth up to a few thousand): the per-column epilogue (12 reductions + the record) costs more
  * than the loads, so FOUR columns share a wavefront, 16 lanes each: 4-step reductions inside the DPP row, four
  * records built at once.  Fast path only (nt + bq tracks); everything else runs lfq_count_kernel. */
+template <bool PACKED>
 __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, LfqParams P,
                                                               lfq_col_counts *__restrict__ out,
                                                               uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
@@ -214,9 +245,9 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
         }
         if (valid && !r.gated) {
             if (same_thr) {
-                lfq_count_chunks<true>(a, T, off0, off1, minbq4, minalt4, l, 16);
+                lfq_count_chunks<true, PACKED>(a, T, off0, off1, minbq4, minalt4, l, 16);
             } else {
-                lfq_count_chunks<false>(a, T, off0, off1, minbq4, minalt4, l, 16);
+                lfq_count_chunks<false, PACKED>(a, T, off0, off1, minbq4, minalt4, l, 16);
             }
         }
         /* sums over the 16 lanes of the group (every lane of the wavefront takes part) */
@@ -254,20 +285,12 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
     }
 }
 
-/* VPAD: the highest VGPR the kernel claims (0 = what it needs, 72 -> 7 wavefronts per SIMD).  96 / 128 cap the
- * residency at 5 / 4 wavefronts per SIMD, which leaves registers for the DP kernels of the previous batch segment
- * to run beside it (LFQ_COUNT_VGPRS, with LFQ_SEGMENTS > 1). */
-template <int VPAD>
+template <bool PACKED>
 __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
                                                         const LfqLuts *__restrict__ luts,
                                                         lfq_col_counts *__restrict__ out,
                                                         uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
-    if (VPAD == 96) {
-        asm volatile("; claim v95" ::: "v95");
-    } else if (VPAD == 128) {
-        asm volatile("; claim v127" ::: "v127");
-    }
     __shared__ uint32_t s_hist[4][128];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
@@ -311,9 +334,9 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
         const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
         if (same_thr) {
-            lfq_count_chunks<true>(a, T, off0, off1, minbq4, minalt4);
+            lfq_count_chunks<true, PACKED>(a, T, off0, off1, minbq4, minalt4);
         } else {
-            lfq_count_chunks<false>(a, T, off0, off1, minbq4, minalt4);
+            lfq_count_chunks<false, PACKED>(a, T, off0, off1, minbq4, minalt4);
         }
     } else if (!r.gated) {
         /* general path: merged-quality filters and/or the median-of-reference-BQ override
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             }
             __builtin_amdgcn_wave_barrier();
             for (int64_t i = lane; i < n_obs; i += LFQ_WAVE) {
-                const uint32_t ntb = T.nt[off0 + i];
+                const uint32_t ntb = lfq_nt_at(T, off0 + (uint64_t)i);
                 if ((int)(ntb & 7u) == ref_code) {
                     atomicAdd(&s_hist[wave][T.bq[off0 + i] & 127u], 1u);
                 }
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         }
         r.median_ref_bq = median;
         for (int64_t i = lane; i < n_obs; i += LFQ_WAVE) {
-            const uint32_t ntb = T.nt[off0 + i];
+            const uint32_t ntb = lfq_nt_at(T, off0 + (uint64_t)i);
             const uint32_t code = ntb & 7u;
             if (code > 3u) {
                 continue;
@@ -638,7 +661,7 @@ __global__ __launch_bounds__(256) void lfq_synth_kernel(lfq_synth_spec S, int64_
                                                         uint8_t *__restrict__ nt, uint8_t *__restrict__ bq,
                                                         uint8_t *__restrict__ baq, uint8_t *__restrict__ mq,
                                                         uint64_t *__restrict__ col_off,
-                                                        uint8_t *__restrict__ ref_base)
+                                                        uint8_t *__restrict__ ref_base, int nt_packed)
 {
     const int64_t total = ncols * (int64_t)S.depth;
     const int64_t n16 = (total + 15) / 16;
@@ -662,7 +685,14 @@ __global__ __launch_bounds__(256) void lfq_synth_kernel(lfq_synth_spec S, int64_
             wa[b >> 2] |= (uint32_t)o.baq << (8 * (b & 3));
             wm[b >> 2] |= (uint32_t)o.mq << (8 * (b & 3));
         }
-        reinterpret_cast<uint4 *>(nt)[t] = make_uint4(wn[0], wn[1], wn[2], wn[3]);
+        if (nt_packed) {
+            /* two groups of 8 observations -> 2 x 4 bytes: byte k = observation k | observation 4 + k << 4 (lfq_nt_at) */
+            const uint32_t g0 = (wn[0] & 0x0F0F0F0Fu) | ((wn[1] & 0x0F0F0F0Fu) << 4);
+            const uint32_t g1 = (wn[2] & 0x0F0F0F0Fu) | ((wn[3] & 0x0F0F0F0Fu) << 4);
+            reinterpret_cast<uint2 *>(nt)[t] = make_uint2(g0, g1);
+        } else {
+            reinterpret_cast<uint4 *>(nt)[t] = make_uint4(wn[0], wn[1], wn[2], wn[3]);
+        }
         reinterpret_cast<uint4 *>(bq)[t] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
         reinterpret_cast<uint4 *>(baq)[t] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
         reinterpret_cast<uint4 *>(mq)[t] = make_uint4(wm[0], wm[1], wm[2], wm[3]);
@@ -728,25 +758,24 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
     }
     if (!p.general && !p.detlim_af && max_col_obs > 0 && max_col_obs < multi_below) {
         const unsigned blocks = (unsigned)((c1 - c0 + 15) / 16);
-        hipLaunchKernelGGL(lfq_count_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
-                           d_flags, c0, c1);
+        if (t.nt_packed) {
+            hipLaunchKernelGGL(lfq_count_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
+                               d_flags, c0, c1);
+        } else {
+            hipLaunchKernelGGL(lfq_count_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
+                               d_flags, c0, c1);
+        }
         LFQ_HIP_TRY(hipGetLastError());
         return LFQ_OK;
     }
     const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
-    static const int vpad = getenv("LFQ_COUNT_VGPRS") ? atoi(getenv("LFQ_COUNT_VGPRS")) : 0;
-    if (vpad == 96) {
-        hipLaunchKernelGGL(lfq_count_kernel<96>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
+    if (t.nt_packed) {
+        hipLaunchKernelGGL(lfq_count_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
                            d_counts, d_flags, c0, c1);
-        return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
-    }
-    if (vpad == 128) {
-        hipLaunchKernelGGL(lfq_count_kernel<128>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
+    } else {
+        hipLaunchKernelGGL(lfq_count_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
                            d_counts, d_flags, c0, c1);
-        return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
     }
-    hipLaunchKernelGGL(lfq_count_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                       d_counts, d_flags, c0, c1);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }
@@ -772,7 +801,7 @@ int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t
 
 int lfq_launch_synth(const lfq_synth_spec *spec, int64_t col_begin, int64_t ncols, uint8_t *d_nt,
                      uint8_t *d_bq, uint8_t *d_baq, uint8_t *d_mq, uint64_t *d_col_off, uint8_t *d_ref_base,
-                     void *stream)
+                     int nt_packed, void *stream)
 {
     if (ncols <= 0) {
         return LFQ_OK;
@@ -786,7 +815,7 @@ int lfq_launch_synth(const lfq_synth_spec *spec, int64_t col_begin, int64_t ncol
         blocks = 1;
     }
     hipLaunchKernelGGL(lfq_synth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *spec,
-                       col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off, d_ref_base);
+                       col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off, d_ref_base, nt_packed);
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }

@@ -30,7 +30,7 @@ def test_struct_layouts():
     assert C.sizeof(_lib.Conf) == 72
     assert _lib.INDEL_CALL_DTYPE.itemsize == 48 and _lib.INDEL_RECORD_DTYPE.itemsize == 80
     assert C.sizeof(_lib.IndelColumnsC) == 8 * 8 + 2 * 15 * 8 + 8
-    assert C.sizeof(_lib.Tracks) == 11 * 8
+    assert C.sizeof(_lib.Tracks) == 12 * 8
 
 
 def test_conf_defaults_match_reference():

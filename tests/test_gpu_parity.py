@@ -156,15 +156,26 @@ def test_dynamic_bonferroni_across_batches(caller, oracle):
     _compare_records(la, recs, ores, host)
 
 
-def test_synthetic_workload_matches_cpu_generator(caller, oracle):
-    """Device generator == CPU generator byte for byte; calls at depth 10000 match the oracle."""
+def _unpack_nt(packed, n):
+    """LFQ_TRACKS_NT_PACKED (include/lofreq_amd.h): byte k of a group's 4 bytes = observation k | observation 4 + k << 4"""
+    g = packed[: (n + 7) // 8 * 4].reshape(-1, 4)
+    return np.concatenate([g & 15, g >> 4], axis=1).reshape(-1)[:n]
+
+
+@pytest.mark.parametrize("nt_packed,depth", [(False, 10000), (True, 10000), (True, 9999), (True, 37), (False, 37)])
+def test_synthetic_workload_matches_cpu_generator(caller, oracle, nt_packed, depth):
+    """Device generator == CPU generator byte for byte (both nt layouts, columns that do not start on a group of 8);
+    calls match the oracle."""
     import lofreq_amd as la
-    depth, ncols = 10000, 48
-    batch = caller.synth_batch(seed=99, depth=depth, ncols=ncols, plant_period=5)
+    ncols = 48 if depth > 1000 else 700
+    batch = caller.synth_batch(seed=99, depth=depth, ncols=ncols, plant_period=5, nt_packed=nt_packed)
     host = oracle.synth_fill(99, depth, 5, 0, ncols)
     n = depth * ncols
     for k in ("nt", "bq", "baq", "mq"):
-        assert np.array_equal(getattr(batch, k).cpu().numpy()[:n], host[k]), k
+        dev = getattr(batch, k).cpu().numpy()
+        if k == "nt" and nt_packed:
+            dev = _unpack_nt(dev, n)
+        assert np.array_equal(dev[:n], host[k]), k
     assert np.array_equal(batch.ref_base.cpu().numpy()[:ncols], host["ref_base"])
     host["sq"] = None
     ores, oconf = util.run_oracle(oracle, host)
