@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--plant-period", type=int, default=997)
     ap.add_argument("--cpu-sample-cols", type=int, default=8000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nt-bytes", action="store_true",
+                    help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
     ap.add_argument("--pipeline", action="store_true",
                     help="N=1 only: two contexts, batch k+1 is submitted (lfq_call_snvs_submit) before batch k is "
                          "collected; every step still does all of its work inside the timed region")
@@ -92,7 +94,8 @@ def main():
     caller = la.SnvCaller(local_rank)
     ncols, depth = args.cols, args.depth
     col_begin = rank * ncols                      # this rank's region shard
-    batch = caller.synth_batch(SEED, depth, ncols, plant_period=args.plant_period, col_begin=col_begin)
+    batch = caller.synth_batch(SEED, depth, ncols, plant_period=args.plant_period, col_begin=col_begin,
+                               nt_packed=not args.nt_bytes)
     d_counts = torch.zeros(ncols * 64, dtype=torch.uint8, device=dev)
     pv_cap = ncols
     d_pvals = torch.zeros(pv_cap * 128, dtype=torch.uint8, device=dev)
@@ -186,7 +189,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom)
+                tj = json.load(open(pmc))
+                key = dom + ("<false>" if args.nt_bytes else "<true>") if dom == "lfq_count_kernel" else dom
+                traffic = tj.get(key)
             except Exception:
                 traffic = None
         line = {
@@ -201,6 +206,7 @@ def main():
                 "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "pipeline_depth": 2 if pipelined else 1,
+                "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
             },
             "roofline": {
@@ -213,8 +219,8 @@ def main():
                 "count_kernel": {
                     "avg_launch_ms": kt["ms_count"] / n_launch,
                     "achieved": alg_bytes / (kt["ms_count"] / n_launch * 1e-3) / 1e9 if kt["ms_count"] > 0 else 0.0,
-                    "note": "HBM-bound streaming kernel; reads only the nt+bq tracks (2 of the 4 algorithmic "
-                            "bytes per observation) in the default filter configuration"},
+                    "note": "streaming kernel; reads only the nt+bq tracks (1.5 of the 4 algorithmic bytes per "
+                            "observation with the packed nt layout, 2 with bytes) in the default filter configuration"},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

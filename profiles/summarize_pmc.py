@@ -8,6 +8,7 @@ reads are of that kind and are doubled; the other kernels' byte-granular loads a
 flagged as uncalibrated."""
 import glob
 import json
+import os
 import sqlite3
 import sys
 
@@ -29,7 +30,10 @@ def main(root, tag):
         for k, d in counters(path).items():
             allc.setdefault(k, {}).update(d)
     lines = ["# PMC summary (%s)" % tag, "",
-             "Separate `rocprofv3 --pmc` passes of `bench.py --steps 1 --warmup 0` (C3, 1 MI355X).", "",
+             "Separate `rocprofv3 --pmc <one counter> --kernel-trace` passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`",
+             "(C3, 1 MI355X).  One counter per pass: FETCH_SIZE and WRITE_SIZE together exceed what the hardware collects at once",
+             "(rocprofv3 aborts with error 38 and then sits until it is killed -- the 'hang' of the earlier attempts).",
+             "`lfq_count_kernel<true>` = packed nt layout (15 GB algorithmic: 1.5 B per observation), `<false>` = byte layout.", "",
              "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch (corrected) | SQ_INSTS_VALU | "
              "SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE |", "|---|---|---|---|---|---|---|---|"]
     traffic = {}
@@ -39,7 +43,7 @@ def main(root, tag):
         d = allc[k]
         f, n = d.get("FETCH_SIZE", (0, 1))
         w, _ = d.get("WRITE_SIZE", (0, 1))
-        wide = k in ("lfq_count_kernel", "lfq_synth_kernel")
+        wide = k.startswith("lfq_count_kernel") or k.startswith("lfq_synth_kernel")
         byt = ((2.0 if wide else 1.0) * f + w) * 1024.0 / max(n, 1)
         traffic[k] = byt
         lines.append("| %s | %d | %.0f | %.0f | %.4g %s | %.4g | %.4g | %.4g |" % (
@@ -49,11 +53,11 @@ def main(root, tag):
     text = "\n".join(lines) + "\n"
     open("profiles/%s_pmc.md" % tag, "w").write(text)
     # bench.py looks kernels up by the names it uses
-    tj = {"lfq_count_kernel": traffic.get("lfq_count_kernel"),
-          "lfq_dp_wave_kernel<1>": traffic.get("lfq_dp_wave_kernel<1>"),
-          "lfq_dp_wave_kernel<4>": traffic.get("lfq_dp_wave_kernel<4>"),
-          "lfq_dp_big_kernel": traffic.get("lfq_dp_big_kernel")}
-    json.dump(tj, open("profiles/pmc_traffic.json", "w"), indent=1)
+    tj = {}
+    if os.path.exists("profiles/pmc_traffic.json"):
+        tj = json.load(open("profiles/pmc_traffic.json"))          # keep entries of kernels this run did not launch
+    tj.update({k: v for k, v in traffic.items()})
+    json.dump(tj, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
     print(text)
 
 
