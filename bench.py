@@ -92,6 +92,7 @@ def main():
     from lofreq_amd import shard
 
     caller = la.SnvCaller(local_rank)
+    caller.set_dense_strand_counts(False)         # DP4 only for the columns that emit (what layer 2 does by itself)
     ncols, depth = args.cols, args.depth
     col_begin = rank * ncols                      # this rank's region shard
     batch = caller.synth_batch(SEED, depth, ncols, plant_period=args.plant_period, col_begin=col_begin,
@@ -125,6 +126,7 @@ def main():
     pipelined = args.pipeline and world == 1 and not args.shard_path
     if pipelined:
         callers = [caller, la.SnvCaller(local_rank)]
+        callers[1].set_dense_strand_counts(False)
 
         def submit(k):
             conf = la.VarcallConf()

@@ -146,6 +146,10 @@ class SnvCaller:
         _lib.check(rc, "lfq_call_snvs_batch")
         return rec[: n.value].copy(), counts, st
 
+    def set_dense_strand_counts(self, on):
+        """lfq_set_dense_strand_counts: off = strand counts only for the columns of the sparse output (layer 1, submit)"""
+        _lib.check(self.L.lfq_set_dense_strand_counts(self.h, 1 if on else 0), "lfq_set_dense_strand_counts")
+
     def call_snvs_submit(self, batch, conf):
         """first half of call_snvs: launch the kernels of the batch and return (one batch in flight per context)"""
         t = batch._tracks()

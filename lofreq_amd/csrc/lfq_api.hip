@@ -110,6 +110,9 @@ struct lfq_ctx {
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     LfqIndelColsOwned *plp_indel;
+    int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
+    int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
+    int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
     int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */
     const uint8_t *sub_ref_host;
     double sub_t0, sub_t1;
@@ -325,6 +328,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     }
     c->device = device_ordinal;
     c->sub_ncols = -1;
+    c->dense_strand = 1;
     hipDeviceProp_t prop;
     c->n_cu = 256;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -480,6 +484,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     LfqParams P;
     LFQ_TRY(make_params(conf, tr, &P, indel_mode));
     P.detlim_af = indel_mode ? nullptr : c->detlim_af;      /* set only inside lfq_uniq_detlim_batch */
+    P.lazy_strand = (c->lazy_now && !indel_mode && !P.general && !P.detlim_af) ? 1 : 0;
+    P.pad2_ = 0;
     LFQ_TRY(ensure_workspace(c, tr->ncols));
 
     LfqTracksDev T;
@@ -580,7 +586,11 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], dps));
         if (n_seg == 1 && !indel_mode && c->leader && !getenv("LFQ_NO_SB_PRECOMPUTE")) {
             /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start now */
-            LFQ_TRY(lfq_launch_gather_heavy(W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
+            if (P.lazy_strand) {        /* the count kernel left the strands out: count them for the heavy columns here */
+                LFQ_TRY(lfq_launch_strand_heavy(T, W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
+            } else {
+                LFQ_TRY(lfq_launch_gather_heavy(W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
+            }
             LFQ_TRY_HIP(hipEventRecord(c->ev_heavy, dps));
             lfq_sb_precompute_begin();
             {
@@ -666,6 +676,10 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     for (int i = 0; i < 3; i++) {
         LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_join[i], 0));
     }
+    if (P.lazy_strand && d_pvals && pvals_capacity > 0) {
+        /* DP4 of the columns that made it into the sparse output (lofreq_call.c:853-857) */
+        LFQ_TRY(lfq_launch_strand_pvals(T, d_pvals, gcounters + LFQ_GC_PVALS, pvals_capacity, c->n_cu, st));
+    }
     LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
     return LFQ_OK;
 }
@@ -673,7 +687,22 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
 int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
                          lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null)
 {
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    if (!c->lazy_forced) {
+        c->lazy_now = !c->dense_strand;
+    }
     return batch_device_impl(c, conf, tr, d_counts, d_pvals, pvals_capacity, stream_or_null, false);
+}
+
+int lfq_set_dense_strand_counts(lfq_ctx *c, int on)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    c->dense_strand = on ? 1 : 0;
+    return LFQ_OK;
 }
 
 int lfq_indel_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
@@ -875,7 +904,12 @@ int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tr
         return LFQ_ERR_INVALID;
     }
     *n_records = 0;
-    LFQ_TRY(lfq_call_snvs_submit(c, conf, tr, tracks_on_device));
+    /* nobody looks at the dense entries unless h_counts is asked for: strand counts only where a record comes out */
+    c->lazy_forced = 1;
+    c->lazy_now = h_counts_or_null == nullptr;
+    const int rc = lfq_call_snvs_submit(c, conf, tr, tracks_on_device);
+    c->lazy_forced = 0;
+    LFQ_TRY(rc);
     return lfq_call_snvs_collect(c, conf, records, records_capacity, n_records, h_counts_or_null, stats_out);
 }
 

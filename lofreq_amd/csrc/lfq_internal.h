@@ -42,6 +42,8 @@ struct LfqParams {
     /* `lofreq uniq --use-det-lim` (lofreq_uniq.c:274-333): per column the assumed allele frequency; the first alt
      * count becomes (int)(af * n_err_probs), the others 0, and only the 'N' reference gate applies.  null = off */
     const float *detlim_af;
+    int32_t lazy_strand;      /* 1: the count kernel skips the strand planes; lfq_strand_* fill them where a record is emitted */
+    int32_t pad2_;
 };
 
 struct LfqTracksDev {
@@ -270,6 +272,10 @@ int lfq_launch_srcq(const LfqSrcqArgs &a, const LfqLuts *d_luts, int n_blocks, v
 int lfq_launch_pileup_scatter(const LfqPileupArgs &a, void *stream);
 
 /* kernel launchers (lfq_kernels.hip); all asynchronous on `stream` */
+int lfq_launch_strand_heavy(const LfqTracksDev &t, const LfqWork &w, lfq_col_counts *d_counts, int32_t *tuples_mapped,
+                            int32_t *n_mapped, int cap_entries, int min_alt, void *stream);
+int lfq_launch_strand_pvals(const LfqTracksDev &t, lfq_col_pvals *d_pvals, const int32_t *d_n_pvals, int64_t cap, int n_blocks,
+                            void *stream);
 int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, int32_t *tuples_mapped,
                             int32_t *n_mapped, int cap_entries, int min_alt, void *stream);
 int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);

@@ -58,7 +58,7 @@ struct LfqAcc {
     uint32_t raw[4], fw[4], ge[4], ga[4];
 };
 
-template <bool SAME_THR>
+template <bool SAME_THR, bool STRAND = true>
 __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_t bqw, uint32_t vm,
                                                 uint32_t minbq4, uint32_t minalt4)
 {
@@ -73,10 +73,12 @@ __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_
     a.raw[1] += __popc(p1);
     a.raw[2] += __popc(p2);
     a.raw[3] += __popc(p3);
-    a.fw[0] += __popc(p0 & ~s3);
-    a.fw[1] += __popc(p1 & ~s3);
-    a.fw[2] += __popc(p2 & ~s3);
-    a.fw[3] += __popc(p3 & ~s3);
+    if (STRAND) {                                  /* lazy-strand mode: only the columns that emit get these (lfq_strand_*) */
+        a.fw[0] += __popc(p0 & ~s3);
+        a.fw[1] += __popc(p1 & ~s3);
+        a.fw[2] += __popc(p2 & ~s3);
+        a.fw[3] += __popc(p3 & ~s3);
+    }
     const uint32_t hi = bqw | 0x80808080u;
     const uint32_t g = hi - minbq4;                /* bit 7: bq >= min_bq (bq < 128) */
     a.ge[0] += __popc(p0 & g);
@@ -92,7 +94,7 @@ __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_
     }
 }
 
-template <bool SAME_THR, bool PACKED>
+template <bool SAME_THR, bool PACKED, bool STRAND = true>
 __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &T, uint64_t off0, uint64_t off1,
                                                  uint32_t minbq4, uint32_t minalt4, int lane = lfq_lane(),
                                                  int lanes = LFQ_WAVE)
@@ -118,15 +120,15 @@ __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &
             const uint32_t e0 = n2.x & 0x0F0F0F0Fu, o0 = (n2.x >> 4) & 0x0F0F0F0Fu;
             const uint32_t e1 = n2.y & 0x0F0F0F0Fu, o1 = (n2.y >> 4) & 0x0F0F0F0Fu;
             if (lo == 0 && hi == 16) {
-                lfq_count_dword<SAME_THR>(a, e0, b4.x, 0x80808080u, minbq4, minalt4);
-                lfq_count_dword<SAME_THR>(a, o0, b4.y, 0x80808080u, minbq4, minalt4);
-                lfq_count_dword<SAME_THR>(a, e1, b4.z, 0x80808080u, minbq4, minalt4);
-                lfq_count_dword<SAME_THR>(a, o1, b4.w, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, e0, b4.x, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, o0, b4.y, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, e1, b4.z, 0x80808080u, minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, o1, b4.w, 0x80808080u, minbq4, minalt4);
             } else {
-                lfq_count_dword<SAME_THR>(a, e0, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
-                lfq_count_dword<SAME_THR>(a, o0, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
-                lfq_count_dword<SAME_THR>(a, e1, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
-                lfq_count_dword<SAME_THR>(a, o1, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, e0, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, o0, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, e1, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
+                lfq_count_dword<SAME_THR, STRAND>(a, o1, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
             }
         }
         return;
@@ -138,15 +140,15 @@ __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &
         const int lo = (int64_t)off0 > base ? (int)((int64_t)off0 - base) : 0;
         const int hi = (int64_t)off1 < base + 16 ? (int)((int64_t)off1 - base) : 16;
         if (lo == 0 && hi == 16) {
-            lfq_count_dword<SAME_THR>(a, n4.x, b4.x, 0x80808080u, minbq4, minalt4);
-            lfq_count_dword<SAME_THR>(a, n4.y, b4.y, 0x80808080u, minbq4, minalt4);
-            lfq_count_dword<SAME_THR>(a, n4.z, b4.z, 0x80808080u, minbq4, minalt4);
-            lfq_count_dword<SAME_THR>(a, n4.w, b4.w, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.x, b4.x, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.y, b4.y, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.z, b4.z, 0x80808080u, minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.w, b4.w, 0x80808080u, minbq4, minalt4);
         } else {
-            lfq_count_dword<SAME_THR>(a, n4.x, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
-            lfq_count_dword<SAME_THR>(a, n4.y, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
-            lfq_count_dword<SAME_THR>(a, n4.z, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
-            lfq_count_dword<SAME_THR>(a, n4.w, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.x, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.y, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.z, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
+            lfq_count_dword<SAME_THR, STRAND>(a, n4.w, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
         }
     }
 }
@@ -161,7 +163,7 @@ __device__ __forceinline__ void lfq_planes_to_classes(const uint32_t n[4], uint3
 }
 
 /* counts per nucleotide -> the column record + class flag (one lane) */
-__device__ __forceinline__ void lfq_count_emit(lfq_col_counts &r, const uint32_t raw[4], const uint32_t fw[4],
+__device__ __forceinline__ void lfq_count_emit(bool strand, lfq_col_counts &r, const uint32_t raw[4], const uint32_t fw[4],
                                                const uint32_t filt[4], int ref_code,
                                                lfq_col_counts *__restrict__ out, uint8_t *__restrict__ flags,
                                                int64_t col)
@@ -175,7 +177,7 @@ __device__ __forceinline__ void lfq_count_emit(lfq_col_counts &r, const uint32_t
             const int x2 = (ref_code <= 2) ? 3 : 2;
 #define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
             r.ref_fw = (int)LFQ_PICK(fw, ref_code);
-            r.ref_rv = (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code));
+            r.ref_rv = strand ? (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code)) : 0;
             r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
             r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
             r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
@@ -205,7 +207,7 @@ __device__ __forceinline__ void lfq_count_emit(lfq_col_counts &r, const uint32_t
 /* Shallow columns (depth up to a few thousand): the per-column epilogue (12 reductions + the record) costs more
  * than the loads, so FOUR columns share a wavefront, 16 lanes each: 4-step reductions inside the DPP row, four
  * records built at once.  Fast path only (nt + bq tracks); everything else runs lfq_count_kernel. */
-template <bool PACKED>
+template <bool PACKED, bool STRAND>
 __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, LfqParams P,
                                                               lfq_col_counts *__restrict__ out,
                                                               uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
@@ -245,9 +247,9 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
         }
         if (valid && !r.gated) {
             if (same_thr) {
-                lfq_count_chunks<true, PACKED>(a, T, off0, off1, minbq4, minalt4, l, 16);
+                lfq_count_chunks<true, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4, l, 16);
             } else {
-                lfq_count_chunks<false, PACKED>(a, T, off0, off1, minbq4, minalt4, l, 16);
+                lfq_count_chunks<false, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4, l, 16);
             }
         }
         /* sums over the 16 lanes of the group (every lane of the wavefront takes part) */
@@ -280,12 +282,12 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
             filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];
         }
         if (l == 0 && valid) {
-            lfq_count_emit(r, raw, fw, filt, ref_code, out, flags, col);
+            lfq_count_emit(STRAND, r, raw, fw, filt, ref_code, out, flags, col);
         }
     }
 }
 
-template <bool PACKED>
+template <bool PACKED, bool STRAND>
 __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
                                                         const LfqLuts *__restrict__ luts,
                                                         lfq_col_counts *__restrict__ out,
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
         const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
         if (same_thr) {
-            lfq_count_chunks<true, PACKED>(a, T, off0, off1, minbq4, minalt4);
+            lfq_count_chunks<true, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4);
         } else {
-            lfq_count_chunks<false, PACKED>(a, T, off0, off1, minbq4, minalt4);
+            lfq_count_chunks<false, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4);
         }
     } else if (!r.gated) {
         /* general path: merged-quality filters and/or the median-of-reference-BQ override
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             const int x2 = (ref_code <= 2) ? 3 : 2;
 #define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
             r.ref_fw = (int)LFQ_PICK(fw, ref_code);
-            r.ref_rv = (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code));
+            r.ref_rv = STRAND ? (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code)) : 0;   /* lazy: lfq_strand_* */
             r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
             r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
             r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
@@ -758,24 +760,30 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
     }
     if (!p.general && !p.detlim_af && max_col_obs > 0 && max_col_obs < multi_below) {
         const unsigned blocks = (unsigned)((c1 - c0 + 15) / 16);
+#define LFQ_LAUNCH_MULTI(PK, ST)                                                                                     \
+        hipLaunchKernelGGL((lfq_count_multi_kernel<PK, ST>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,      \
+                           d_counts, d_flags, c0, c1)
+        const bool strand_m = !p.lazy_strand;
         if (t.nt_packed) {
-            hipLaunchKernelGGL(lfq_count_multi_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
-                               d_flags, c0, c1);
+            if (strand_m) LFQ_LAUNCH_MULTI(true, true); else LFQ_LAUNCH_MULTI(true, false);
         } else {
-            hipLaunchKernelGGL(lfq_count_multi_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_counts,
-                               d_flags, c0, c1);
+            if (strand_m) LFQ_LAUNCH_MULTI(false, true); else LFQ_LAUNCH_MULTI(false, false);
         }
+#undef LFQ_LAUNCH_MULTI
         LFQ_HIP_TRY(hipGetLastError());
         return LFQ_OK;
     }
     const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
+#define LFQ_LAUNCH_COUNT(PK, ST)                                                                                     \
+    hipLaunchKernelGGL((lfq_count_kernel<PK, ST>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,       \
+                       d_counts, d_flags, c0, c1)
+    const bool strand = !p.lazy_strand || p.general;       /* the general path evaluates every observation anyway */
     if (t.nt_packed) {
-        hipLaunchKernelGGL(lfq_count_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                           d_counts, d_flags, c0, c1);
+        if (strand) LFQ_LAUNCH_COUNT(true, true); else LFQ_LAUNCH_COUNT(true, false);
     } else {
-        hipLaunchKernelGGL(lfq_count_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,
-                           d_counts, d_flags, c0, c1);
+        if (strand) LFQ_LAUNCH_COUNT(false, true); else LFQ_LAUNCH_COUNT(false, false);
     }
+#undef LFQ_LAUNCH_COUNT
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }
@@ -822,7 +830,137 @@ int lfq_launch_synth(const lfq_synth_spec *spec, int64_t col_begin, int64_t ncol
 
 
 /* ------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------ */
+/* lazy strand counts: DP4 only where something is reported                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* The forward-strand planes are 8 of the ~30 instructions the count kernel spends per 4 observations, and the
+ * kernel is as much VALU- as HBM-bound -- but ref_fw / ref_rv / alt_fw only ever reach report_var (DP4, SB,
+ * lofreq_call.c:117-129, 853-857), i.e. the ~1e-3 of the columns that emit a record.  In lazy mode the count kernel
+ * skips them; these two kernels count them afterwards, one wavefront per column: for the heavy columns right after
+ * the scan (their DP4 tuples feed the host's strand-bias precompute while the DP runs), and for every record of the
+ * sparse output once the DP kernels are done. */
+template <bool PACKED>
+__device__ __forceinline__ void lfq_strand_of_column(const LfqTracksDev &T, int64_t col, int *ref_fw, int *ref_rv,
+                                                     int alt_fw[3], int alt_raw[3])
+{
+    const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
+    LfqAcc a;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a.raw[i] = a.fw[i] = a.ge[i] = a.ga[i] = 0;
+    }
+    lfq_count_chunks<true, PACKED, true>(a, T, off0, off1, 0x80808080u, 0x80808080u);
+    uint32_t raw[4], fw[4], rp[4], fp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        rp[i] = lfq_wave_sum_u32(a.raw[i]);
+        fp[i] = lfq_wave_sum_u32(a.fw[i]);
+    }
+    lfq_planes_to_classes(rp, raw);
+    lfq_planes_to_classes(fp, fw);
+    const uint32_t rb = T.ref_base[col];
+    const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
+    *ref_fw = *ref_rv = 0;
+    alt_fw[0] = alt_fw[1] = alt_fw[2] = 0;
+    alt_raw[0] = alt_raw[1] = alt_raw[2] = 0;
+    if (ref_code < 0) {
+        return;
+    }
+    int ai = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (x == ref_code) {
+            *ref_fw = (int)fw[x];
+            *ref_rv = (int)(raw[x] - fw[x]);
+        } else {
+            alt_fw[ai] = (int)fw[x];
+            alt_raw[ai] = (int)raw[x];
+            ai++;
+        }
+    }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void lfq_strand_heavy_kernel(LfqTracksDev T, LfqWork W, lfq_col_counts *__restrict__ counts,
+                                                               int32_t *__restrict__ tuples, int32_t *__restrict__ n_out,
+                                                               int cap_entries, int min_alt)
+{
+    const int n_light = W.counters[LFQ_CNT_LIGHT];
+    const int n_heavy = min(W.counters[LFQ_CNT_MID] + W.counters[LFQ_CNT_BIG], cap_entries);
+    const int i = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(n_out, n_heavy, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (i >= n_heavy) {
+        return;
+    }
+    const int64_t col = W.entries[n_light + i].col;
+    int ref_fw, ref_rv, alt_fw[3], alt_raw[3];
+    lfq_strand_of_column<PACKED>(T, col, &ref_fw, &ref_rv, alt_fw, alt_raw);
+    if (lfq_lane() == 0) {
+        counts[col].ref_fw = ref_fw;                 /* the DP kernels copy the dense entry into their records */
+        counts[col].ref_rv = ref_rv;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            counts[col].alt_fw[a] = alt_fw[a];
+            int4 t = make_int4(0, 0, 0, 0);
+            if (alt_raw[a] >= min_alt) {
+                t = make_int4(ref_fw, ref_rv, alt_fw[a], alt_raw[a] - alt_fw[a]);
+            }
+            reinterpret_cast<int4 *>(tuples)[3 * i + a] = t;
+        }
+    }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void lfq_strand_pvals_kernel(LfqTracksDev T, lfq_col_pvals *__restrict__ pvals,
+                                                               const int32_t *__restrict__ n_pvals_ptr, int64_t cap)
+{
+    const int64_t n = min((int64_t)*n_pvals_ptr, cap);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += n_waves) {
+        int ref_fw, ref_rv, alt_fw[3], alt_raw[3];
+        lfq_strand_of_column<PACKED>(T, pvals[i].col, &ref_fw, &ref_rv, alt_fw, alt_raw);
+        if (lfq_lane() == 0) {
+            pvals[i].counts.ref_fw = ref_fw;
+            pvals[i].counts.ref_rv = ref_rv;
+            pvals[i].counts.alt_fw[0] = alt_fw[0];
+            pvals[i].counts.alt_fw[1] = alt_fw[1];
+            pvals[i].counts.alt_fw[2] = alt_fw[2];
+        }
+    }
+}
+
+int lfq_launch_strand_heavy(const LfqTracksDev &t, const LfqWork &w, lfq_col_counts *d_counts, int32_t *tuples_mapped,
+                            int32_t *n_mapped, int cap_entries, int min_alt, void *stream)
+{
+    const unsigned blocks = (unsigned)((cap_entries + 3) / 4);
+    if (t.nt_packed) {
+        hipLaunchKernelGGL(lfq_strand_heavy_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, w, d_counts,
+                           tuples_mapped, n_mapped, cap_entries, min_alt);
+    } else {
+        hipLaunchKernelGGL(lfq_strand_heavy_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, w, d_counts,
+                           tuples_mapped, n_mapped, cap_entries, min_alt);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+int lfq_launch_strand_pvals(const LfqTracksDev &t, lfq_col_pvals *d_pvals, const int32_t *d_n_pvals, int64_t cap, int n_blocks,
+                            void *stream)
+{
+    if (t.nt_packed) {
+        hipLaunchKernelGGL(lfq_strand_pvals_kernel<true>, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, t, d_pvals,
+                           d_n_pvals, cap);
+    } else {
+        hipLaunchKernelGGL(lfq_strand_pvals_kernel<false>, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, t, d_pvals,
+                           d_n_pvals, cap);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* DP4 tuples of the columns with many alt bases -> host-mapped memory (strand-bias precompute) */
+
 /* ------------------------------------------------------------------------------------------ */
 
 __global__ __launch_bounds__(256) void lfq_gather_heavy_kernel(LfqWork W, const lfq_col_counts *__restrict__ counts,

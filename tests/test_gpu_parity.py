@@ -304,3 +304,43 @@ def test_ragged_deep_mix(caller, oracle):
     assert conf.bonf_subst == oconf.bonf_subst and conf.num_snv_tests == oconf.num_snv_tests
     _compare_records(la, recs, ores, host, tol=1e-9)
     assert len(recs) >= 8
+
+
+@pytest.mark.parametrize("depth_lo,depth_hi", [(30, 400), (3000, 9000)])
+def test_lazy_strand_counts_same_records(caller, oracle, depth_lo, depth_hi):
+    """call_snvs without the dense counts leaves the strand planes out of the count kernel and counts DP4 only for
+    the columns of the sparse output (lfq_strand_*): records byte-identical to the dense route, on host batches and
+    on both device layouts; with lfq_set_dense_strand_counts(0) layer 1 does the same"""
+    import torch
+    import lofreq_amd as la
+    rng = np.random.default_rng(17)
+    n = 400 if depth_hi < 1000 else 40
+    host = util.random_batch(rng, n, depth_lo, depth_hi, planted={3: 0.2, 11: 0.02, 20: 0.5, 33: 0.004})
+    batch = util.to_pileup_batch(la, host)
+    full, counts, _ = caller.call_snvs(batch, la.VarcallConf(), want_counts=True)
+    lazy, _, _ = caller.call_snvs(batch, la.VarcallConf())
+    assert len(full) > 0 and full.tobytes() == lazy.tobytes()
+    assert (full["alt_fw"] + full["alt_rv"] == full["alt_raw_count"]).all() and (full["ref_fw"] + full["ref_rv"] > 0).all()
+    for packed in (False, True):
+        sb = caller.synth_batch(seed=5, depth=2000, ncols=300, plant_period=7, nt_packed=packed)
+        f2, _, _ = caller.call_snvs(sb, la.VarcallConf(), want_counts=True)
+        l2, _, _ = caller.call_snvs(sb, la.VarcallConf())
+        assert len(f2) > 0 and f2.tobytes() == l2.tobytes()
+    # layer 1 with the option off: sparse records complete, dense strand fields untouched (0)
+    sb = caller.synth_batch(seed=5, depth=2000, ncols=300, plant_period=7)
+    dev = torch.device("cuda", 0)
+    d_counts = torch.zeros(300 * 64, dtype=torch.uint8, device=dev)
+    d_pvals = torch.zeros(300 * 128, dtype=torch.uint8, device=dev)
+    caller.set_dense_strand_counts(False)
+    try:
+        conf = la.VarcallConf()
+        caller.snv_batch_device(sb, conf, d_counts, d_pvals, 300)
+        st = caller.batch_finish()
+    finally:
+        caller.set_dense_strand_counts(True)
+    pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
+    recs = la.finalize_pvals(conf, pv, None)
+    assert recs.tobytes() == f2.tobytes()
+    dense = d_counts.cpu().numpy().view(la.COL_COUNTS_DTYPE)
+    quiet = np.setdiff1d(np.arange(300), pv["col"])      # (heavy columns that did not emit got their strands as well)
+    assert (dense["ref_fw"][quiet] == 0).mean() > 0.5 and (dense["alt_fw"][quiet] == 0).all(axis=1).mean() > 0.5
