@@ -192,7 +192,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 tj = json.load(open(pmc))
-                key = dom + ("<false>" if args.nt_bytes else "<true>") if dom == "lfq_count_kernel" else dom
+                # the instantiation bench.py runs: <packed nt, strand planes>; dense strand counts are switched off above
+                key = dom + ("<false, false>" if args.nt_bytes else "<true, false>") if dom == "lfq_count_kernel" else dom
                 traffic = tj.get(key)
             except Exception:
                 traffic = None

@@ -33,7 +33,8 @@ def main(root, tag):
              "Separate `rocprofv3 --pmc <one counter> --kernel-trace` passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`",
              "(C3, 1 MI355X).  One counter per pass: FETCH_SIZE and WRITE_SIZE together exceed what the hardware collects at once",
              "(rocprofv3 aborts with error 38 and then sits until it is killed -- the 'hang' of the earlier attempts).",
-             "`lfq_count_kernel<true>` = packed nt layout (15 GB algorithmic: 1.5 B per observation), `<false>` = byte layout.", "",
+             "`lfq_count_kernel<packed nt, strand planes>`: `<true, false>` is what `bench.py` runs (1.5 B per observation read,",
+             "strand counts only for the columns that emit); `<false, true>` = byte layout with dense strand counts.", "",
              "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch (corrected) | SQ_INSTS_VALU | "
              "SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE |", "|---|---|---|---|---|---|---|---|"]
     traffic = {}
