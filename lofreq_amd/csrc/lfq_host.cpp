@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -459,6 +460,9 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
     if (!conf || (!pvals && n_pvals > 0) || !n_records || n_pvals < 0) {
         return LFQ_ERR_INVALID;
     }
+    static const bool timing = getenv("LFQ_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tf[6] = {now(), 0, 0, 0, 0, 0};
     std::vector<int64_t> order((size_t)n_pvals);
     for (int64_t i = 0; i < n_pvals; i++) {
         order[(size_t)i] = i;
@@ -491,6 +495,7 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
         LfqPool::instance().run(workp, n_pvals >= 256 ? std::min(LfqPool::instance().size(), 8) : 0);
     }
 
+    tf[1] = now();
     static const char acgt[4] = {'A', 'C', 'G', 'T'};
     int64_t n_out = 0;
     for (int64_t oi = 0; oi < n_pvals; oi++) {
@@ -562,8 +567,10 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
         const int64_t n = n_out;
         std::atomic<int64_t> next(0);
         /* expensive tables were precomputed while the DP kernels ran (lfq_sb_precompute); the rest here */
+        tf[2] = now();
         LfqSbCache &cache = LfqSbCache::instance();
         cache.wait_idle();
+        tf[3] = now();
         std::vector<int64_t> miss;
         for (int64_t i = 0; i < n; i++) {
             lfq_snv_record &o = records[i];
@@ -589,6 +596,11 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
         /* waking the pool costs more than a few cheap tables */
         const int helpers = cost < 20000 ? 0 : (int)std::min<int64_t>(LfqPool::instance().size(), nm / 4);
         LfqPool::instance().run(work, helpers);
+        tf[4] = now();
+        if (timing) {
+            fprintf(stderr, "[lfq timing] finalize: p-values+QUAL %.3f  records %.3f  wait for SB precompute %.3f  SB lookups %.3f ms (%ld misses of %ld)\n",
+                    tf[1] - tf[0], tf[2] - tf[1], tf[3] - tf[2], tf[4] - tf[3], (long)nm, (long)n);
+        }
     }
     *n_records = n_out;
     return LFQ_OK;
