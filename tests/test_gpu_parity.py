@@ -344,3 +344,19 @@ def test_lazy_strand_counts_same_records(caller, oracle, depth_lo, depth_hi):
     dense = d_counts.cpu().numpy().view(la.COL_COUNTS_DTYPE)
     quiet = np.setdiff1d(np.arange(300), pv["col"])      # (heavy columns that did not emit got their strands as well)
     assert (dense["ref_fw"][quiet] == 0).mean() > 0.5 and (dense["alt_fw"][quiet] == 0).all(axis=1).mean() > 0.5
+
+
+@pytest.mark.parametrize("kw", [dict(def_alt_bq=-1), dict(min_jq=15, min_alt_jq=20), dict(min_bq=20, min_alt_bq=25),
+                                dict(flag=2), dict(bonf_dynamic=0, bonf_subst=1000, sig=0.05)])
+def test_packed_nt_layout_equals_byte_layout(caller, kw):
+    """LFQ_TRACKS_NT_PACKED against the byte layout on the same synthetic columns, through the fast count path, the
+    general (per-observation) path and every DP class: dense counts and records identical"""
+    import lofreq_amd as la
+    for depth, ncols, period in ((3001, 64, 3), (150, 900, 11)):
+        res = []
+        for packed in (False, True):
+            b = caller.synth_batch(seed=21, depth=depth, ncols=ncols, plant_period=period, nt_packed=packed)
+            recs, counts, st = caller.call_snvs(b, la.VarcallConf(**kw), want_counts=True)
+            res.append((recs.tobytes(), counts.tobytes(), st.n_tested))
+        assert res[0] == res[1], (depth, kw)
+        assert res[0][2] > 0
