@@ -110,6 +110,8 @@ struct lfq_ctx {
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     LfqIndelColsOwned *plp_indel;
+    int16_t *d_plp_ne;               /* quality arrays of the columns above, resident: [q0 | mq0 | q1 | mq1] */
+    int64_t plp_ne_total[2];
     int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
     int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
@@ -405,6 +407,7 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_plp_in) (void)hipFree(c->d_plp_in);
         if (c->d_plp_out) (void)hipFree(c->d_plp_out);
         delete c->plp_indel;
+        if (c->d_plp_ne) (void)hipFree(c->d_plp_ne);
         if (c->d_detlim) (void)hipFree(c->d_detlim);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
@@ -1071,30 +1074,104 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
     IndelPack pk;
     std::vector<lfq_indel_call> calls;
     const uint64_t flush_obs = 256u << 20;            /* pseudo-column bytes per track per device batch */
+    /* columns that came out of lfq_readset_pileup_indels on this context still have their quality arrays in HBM:
+     * the pseudo-columns are then built by lfq_indel_pack_kernel instead of on the host */
+    const bool dev_pack = c->plp_indel && b == &c->plp_indel->cols && c->d_plp_ne && !getenv("LFQ_INDEL_HOST_PACK");
+    std::vector<LfqIndelTestDesc> descs;
+    uint64_t dev_obs = 0;
+    int16_t *d_rd = nullptr;                          /* event-read arrays of both sides, uploaded once */
+    int64_t rd_n[2] = {0, 0};
+    struct RdGuard {
+        int16_t **p;
+        ~RdGuard() { if (*p) (void)hipFree(*p); }
+    } rd_guard{&d_rd};
+    if (dev_pack) {
+        LFQ_TRY_HIP(hipSetDevice(c->device));
+        for (int sd = 0; sd < 2; sd++) {
+            rd_n[sd] = b->side[sd].rd_off[b->side[sd].ev_off[b->ncols]];
+        }
+        const int64_t tot = 4 * (rd_n[0] + rd_n[1]);
+        if (tot > 0) {
+            LFQ_TRY_HIP(hipMalloc((void **)&d_rd, (size_t)tot * 2));
+            int64_t o = 0;
+            for (int sd = 0; sd < 2; sd++) {
+                const int16_t *src[4] = {b->side[sd].rd_q, b->side[sd].rd_aq, b->side[sd].rd_mq, b->side[sd].rd_sq};
+                for (int k = 0; k < 4; k++, o += rd_n[sd]) {
+                    if (rd_n[sd] > 0) {
+                        LFQ_TRY_HIP(hipMemcpyAsync(d_rd + o, src[k], (size_t)rd_n[sd] * 2, hipMemcpyHostToDevice, c->stream));
+                    }
+                }
+            }
+        }
+    }
 
     auto flush = [&]() -> int {
         if (pk.meta.empty()) {
             return LFQ_OK;
         }
-        const size_t pad = 32;
-        for (auto *v : {&pk.nt, &pk.bq, &pk.baq, &pk.mq, &pk.sq}) {
-            v->resize(v->size() + pad, 0);            /* 16-byte tail contract of the track format */
-        }
         lfq_tracks tr;
         memset(&tr, 0, sizeof(tr));
-        tr.nt = pk.nt.data();
-        tr.bq = pk.bq.data();
-        tr.baq = pk.baq.data();
-        tr.mq = pk.mq.data();
-        tr.sq = pk.sq.data();
-        tr.col_off = pk.off.data();
-        tr.ref_base = pk.ref.data();
         tr.ncols = (int64_t)pk.meta.size();
         tr.max_col_obs = pk.max_obs;
+        uint8_t *d_trk = nullptr;
+        struct TrkGuard {
+            uint8_t **p;
+            ~TrkGuard() { if (*p) (void)hipFree(*p); }
+        } trk_guard{&d_trk};
+        if (dev_pack) {
+            const int64_t nt_ = (int64_t)descs.size(), trk = (int64_t)((dev_obs + 15) / 16 * 16) + 32;
+            auto al = [](int64_t x) { return (x + 255) / 256 * 256; };
+            const int64_t o_desc = 0, o_off = o_desc + al(nt_ * (int64_t)sizeof(LfqIndelTestDesc)), o_ref = o_off + al((nt_ + 1) * 8),
+                          o_trk = o_ref + al(nt_ + 16), total = o_trk + 5 * trk;
+            LFQ_TRY_HIP(hipMalloc((void **)&d_trk, (size_t)total));
+            LFQ_TRY_HIP(hipMemcpyAsync(d_trk + o_desc, descs.data(), (size_t)nt_ * sizeof(LfqIndelTestDesc), hipMemcpyHostToDevice, c->stream));
+            LFQ_TRY_HIP(hipMemcpyAsync(d_trk + o_off, pk.off.data(), (size_t)(nt_ + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            LFQ_TRY_HIP(hipMemcpyAsync(d_trk + o_ref, pk.ref.data(), (size_t)nt_, hipMemcpyHostToDevice, c->stream));
+            LFQ_TRY_HIP(hipMemsetAsync(d_trk + o_trk, 0, (size_t)(5 * trk), c->stream));      /* the 16-byte tails are read */
+            LfqIndelPackArgs A;
+            memset(&A, 0, sizeof(A));
+            A.tests = (const LfqIndelTestDesc *)(d_trk + o_desc);
+            A.n_tests = nt_;
+            A.ne_q[0] = c->d_plp_ne;
+            A.ne_mq[0] = c->d_plp_ne + c->plp_ne_total[0];
+            A.ne_q[1] = c->d_plp_ne + 2 * c->plp_ne_total[0];
+            A.ne_mq[1] = c->d_plp_ne + 2 * c->plp_ne_total[0] + c->plp_ne_total[1];
+            int64_t o = 0;
+            for (int sd = 0; sd < 2; sd++) {
+                A.rd_q[sd] = d_rd + o; o += rd_n[sd];
+                A.rd_aq[sd] = d_rd + o; o += rd_n[sd];
+                A.rd_mq[sd] = d_rd + o; o += rd_n[sd];
+                A.rd_sq[sd] = d_rd + o; o += rd_n[sd];
+            }
+            A.use_mq = (conf->flag & LFQ_USE_MQ) ? 1 : 0;
+            A.use_sq = (conf->flag & LFQ_USE_SQ) ? 1 : 0;
+            A.use_aq = (conf->flag & LFQ_USE_IDAQ) ? 1 : 0;
+            A.nt = d_trk + o_trk;
+            A.bq = A.nt + trk;
+            A.baq = A.bq + trk;
+            A.mq = A.baq + trk;
+            A.sq = A.mq + trk;
+            LFQ_TRY(lfq_launch_indel_pack(A, c->stream));
+            tr.nt = A.nt; tr.bq = A.bq; tr.baq = A.baq; tr.mq = A.mq; tr.sq = A.sq;
+            tr.col_off = (const uint64_t *)(d_trk + o_off);
+            tr.ref_base = d_trk + o_ref;
+        } else {
+            const size_t pad = 32;
+            for (auto *v : {&pk.nt, &pk.bq, &pk.baq, &pk.mq, &pk.sq}) {
+                v->resize(v->size() + pad, 0);            /* 16-byte tail contract of the track format */
+            }
+            tr.nt = pk.nt.data();
+            tr.bq = pk.bq.data();
+            tr.baq = pk.baq.data();
+            tr.mq = pk.mq.data();
+            tr.sq = pk.sq.data();
+            tr.col_off = pk.off.data();
+            tr.ref_base = pk.ref.data();
+        }
         calls.resize(pk.meta.size());
         int64_t nc = 0;
         lfq_batch_stats st;
-        LFQ_TRY(lfq_call_indel_tests_batch(c, conf, &tr, 0, calls.data(), (int64_t)calls.size(), &nc, &st));
+        LFQ_TRY(lfq_call_indel_tests_batch(c, conf, &tr, dev_pack ? 1 : 0, calls.data(), (int64_t)calls.size(), &nc, &st));
         if (st.n_tested != (int64_t)pk.meta.size()) {
             return LFQ_ERR_INVALID;                   /* every packed event must have been a test */
         }
@@ -1124,6 +1201,8 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
             r.hrun = b->hrun ? b->hrun[m.col] : 0;
         }
         pk.clear();
+        descs.clear();
+        dev_obs = 0;
         return LFQ_OK;
     };
 
@@ -1166,8 +1245,27 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
                 if (S.key_off[e + 1] - S.key_off[e] == 1 && ign[nt4_of(key[0])]) {
                     continue;                                                /* :687-689 / :709-711 */
                 }
-                pack_indel_test(pk, b, conf, sd, col, e);
-                if (pk.nt.size() >= flush_obs) {
+                if (dev_pack) {
+                    LfqIndelTestDesc D;
+                    memset(&D, 0, sizeof(D));
+                    D.out_off = (int64_t)dev_obs;
+                    D.ne_off = S.ne_off[col];
+                    D.ne_len = (int32_t)(S.ne_off[col + 1] - S.ne_off[col]);
+                    D.rd_begin = S.rd_off[S.ev_off[col]];
+                    D.rd_len = (int32_t)(S.rd_off[S.ev_off[col + 1]] - D.rd_begin);
+                    D.me_begin = (int32_t)(S.rd_off[e] - D.rd_begin);
+                    D.me_len = (int32_t)(S.rd_off[e + 1] - S.rd_off[e]);
+                    D.side = sd;
+                    descs.push_back(D);
+                    dev_obs += (uint64_t)(D.ne_len + D.rd_len);
+                    pk.max_obs = std::max<int64_t>(pk.max_obs, D.ne_len + D.rd_len);
+                    pk.off.push_back(dev_obs);
+                    pk.ref.push_back('A');
+                    pk.meta.push_back({col, sd, (int32_t)e});
+                } else {
+                    pack_indel_test(pk, b, conf, sd, col, e);
+                }
+                if ((dev_pack ? dev_obs : (uint64_t)pk.nt.size()) >= flush_obs) {
                     LFQ_TRY(flush());
                 }
             }
@@ -1776,6 +1874,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     const lfq_readset *rd = rs;
     delete c->plp_indel;
     c->plp_indel = new LfqIndelColsOwned();
+    if (c->d_plp_ne) {
+        (void)hipFree(c->d_plp_ne);
+        c->d_plp_ne = nullptr;
+    }
+    c->plp_ne_total[0] = c->plp_ne_total[1] = 0;
     LfqIndelColsOwned &O = *c->plp_indel;
     memset(&O.cols, 0, sizeof(O.cols));
     *cols_out = &O.cols;
@@ -2027,10 +2130,14 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
         }
         (void)hipFree(d);
-        if (d_ne) (void)hipFree(d_ne);
         if (rc != LFQ_OK) {
+            if (d_ne) (void)hipFree(d_ne);
             return rc;
         }
+        /* the quality arrays stay resident: lfq_call_indels_batch builds its pseudo-columns from them on the device */
+        c->d_plp_ne = d_ne;
+        c->plp_ne_total[0] = ne_total[0];
+        c->plp_ne_total[1] = ne_total[1];
         tm[4] = lfq_now_ms();
         /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
          * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */

@@ -247,6 +247,25 @@ int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream);
 int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *stream);
 int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n, uint8_t *oa, uint8_t *ob, void *stream);
 
+/* indel pseudo-columns built on the device from the resident quality arrays of lfq_readset_pileup_indels */
+struct LfqIndelTestDesc {       /* 48 bytes: one tested event (plp_to_ins_errprobs / plp_to_del_errprobs, snpcaller.c:502-623) */
+    int64_t out_off;            /* first observation of the pseudo-column in the output tracks */
+    int64_t ne_off;             /* the column's reads without an event of this side: slice of ne_q / ne_mq */
+    int64_t rd_begin;           /* all event reads of the column (every event of this side) */
+    int32_t ne_len, rd_len;
+    int32_t me_begin, me_len;   /* the tested event's reads, relative to rd_begin */
+    int32_t side, pad_;
+};
+struct LfqIndelPackArgs {
+    const LfqIndelTestDesc *tests;
+    int64_t n_tests;
+    const int16_t *ne_q[2], *ne_mq[2];                  /* device, per side */
+    const int16_t *rd_q[2], *rd_aq[2], *rd_mq[2], *rd_sq[2];
+    int32_t use_mq, use_sq, use_aq, pad_;
+    uint8_t *nt, *bq, *baq, *mq, *sq;                   /* output tracks */
+};
+int lfq_launch_indel_pack(const LfqIndelPackArgs &a, void *stream);
+
 /* source quality (lfq_srcq.hip) */
 #define LFQ_DBL_EPSILON 2.220446049250313e-16
 #define LFQ_SRCQ_LDS_CELLS 768      /* K below this: the DP cells of a read live in LDS, else in its scratch slice */

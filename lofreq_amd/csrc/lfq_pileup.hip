@@ -532,3 +532,54 @@ int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *st
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
+
+
+/* ---- indel pseudo-columns on the device ----------------------------------------------------------------------
+ * One wavefront per tested event: the column's reads without an event of that side (indel quality, MAPQ) followed
+ * by the reads of all its events, the tested one's marked as the alt allele and carrying their alignment quality
+ * (snpcaller.c:502-623) -- what pack_indel_test does on the host, reading the quality arrays where
+ * lfq_readset_pileup_indels left them. */
+__device__ __forceinline__ uint8_t lfq_q8(int q)
+{
+    return q < 0 ? (uint8_t)255 : (uint8_t)(q > 254 ? 254 : q);
+}
+
+__global__ __launch_bounds__(256) void lfq_indel_pack_kernel(LfqIndelPackArgs A)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= A.n_tests) {
+        return;
+    }
+    const LfqIndelTestDesc D = A.tests[t];
+    const int sd = D.side;
+    const int16_t *nq = A.ne_q[sd] + D.ne_off, *nm = A.ne_mq[sd] + D.ne_off;
+    for (int i = lane; i < D.ne_len; i += 64) {
+        const int64_t o = D.out_off + i;
+        const int q = nq[i];
+        A.nt[o] = 0;
+        A.bq[o] = (uint8_t)(q < 0 ? 0 : (q > 254 ? 254 : q));
+        A.baq[o] = 255;
+        A.mq[o] = A.use_mq ? lfq_q8(nm[i]) : (uint8_t)255;
+        A.sq[o] = 255;
+    }
+    for (int i = lane; i < D.rd_len; i += 64) {
+        const int64_t o = D.out_off + D.ne_len + i, g = D.rd_begin + i;
+        const bool me = i >= D.me_begin && i < D.me_begin + D.me_len;
+        const int q = A.rd_q[sd][g];
+        A.nt[o] = me ? 1 : 0;
+        A.bq[o] = (uint8_t)(q < 0 ? 0 : (q > 254 ? 254 : q));
+        A.baq[o] = (me && A.use_aq) ? lfq_q8(A.rd_aq[sd][g]) : (uint8_t)255;
+        A.mq[o] = A.use_mq ? lfq_q8(A.rd_mq[sd][g]) : (uint8_t)255;
+        A.sq[o] = A.use_sq ? lfq_q8(A.rd_sq[sd][g]) : (uint8_t)255;
+    }
+}
+
+int lfq_launch_indel_pack(const LfqIndelPackArgs &a, void *stream)
+{
+    if (a.n_tests <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_indel_pack_kernel, dim3((unsigned)((a.n_tests + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}

@@ -117,7 +117,13 @@ def call_indels(caller, cols, conf, records_capacity=None):
     """call_indels over a batch -> (records[INDEL_RECORD_DTYPE] in reference order, number of tests).
     Mutates conf.bonf_indel / conf.num_indel_tests like the reference."""
     L = _lib.load()
-    cs = cols.c_struct()
+    # columns that came from this context's device pileup and are still current go back as the original struct: the
+    # library then builds the pseudo-columns on the device from the resident quality arrays
+    if (getattr(cols, "_c_ptr", None) is not None and cols._c_caller is caller
+            and cols._c_gen == getattr(caller, "_indel_gen", -1)):
+        cs = cols._c_ptr.contents
+    else:
+        cs = cols.c_struct()
     nev = len(cols.keys[0]) + len(cols.keys[1])
     cap = int(records_capacity if records_capacity is not None else max(nev, 16))
     rec = np.zeros(cap, dtype=_lib.INDEL_RECORD_DTYPE)

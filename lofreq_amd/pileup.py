@@ -132,11 +132,12 @@ def pileup_indel_columns(caller, reads, ref, begin, end, min_plp_idq=0):
     _lib.check(_lib.load().lfq_pileup_indel_columns(caller.h, C.byref(rd), C.byref(tags), int(begin), int(end),
                                                     int(min_plp_idq), C.byref(out), col_pos.ctypes.data),
                "lfq_pileup_indel_columns")
-    return _indel_columns_from_c(out, col_pos)
+    return _indel_columns_from_c(out, col_pos, caller)
 
 
-def _indel_columns_from_c(out, col_pos):
-    """copy a context-owned lfq_indel_columns into an IndelColumns"""
+def _indel_columns_from_c(out, col_pos, caller=None):
+    """copy a context-owned lfq_indel_columns into an IndelColumns; with `caller`, remember the original so that
+    call_indels can hand it back (its quality arrays are still resident on the device)"""
     from .indel import IndelColumns, _I32
     cs = out.contents
     ncols = int(cs.ncols)
@@ -171,6 +172,9 @@ def _indel_columns_from_c(out, col_pos):
         kc = key_chars.tobytes()
         o.keys[sd] = [kc[key_off[e]:key_off[e + 1]].decode() for e in range(nev)]
     o.cons_indel = arr(cs.cons_indel, ncols, np.uint8)
+    if caller is not None:
+        caller._indel_gen = getattr(caller, "_indel_gen", 0) + 1
+        o._c_ptr, o._c_gen, o._c_caller = out, caller._indel_gen, caller      # valid until the context's next indel pileup
     return o, col_pos[:ncols].copy()
 
 def skip_snv_columns(caller, skip):
@@ -264,4 +268,4 @@ class ReadSet:
         col_pos = np.zeros(max(end - begin, 1), np.int64)
         _lib.check(self.L.lfq_readset_pileup_indels(self.caller.h, self.h, int(begin), int(end), int(min_plp_idq),
                                                     C.byref(out), col_pos.ctypes.data), "lfq_readset_pileup_indels")
-        return _indel_columns_from_c(out, col_pos)
+        return _indel_columns_from_c(out, col_pos, self.caller)

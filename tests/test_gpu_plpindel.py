@@ -256,3 +256,22 @@ def test_resident_readset_source_quality(caller):
     dt = la.pileup_snv_tracks(caller, reads, ref, 0, len(ref), lb=None, sq=sqb)
     recs2, _, _ = caller.call_snvs(dt, la.VarcallConf(**kw))
     assert recs.tobytes() == recs2.tobytes() and len(recs) >= 3
+
+
+def test_indel_calls_device_packing_equals_host_packing(caller):
+    """columns straight from the device pileup are packed into pseudo-columns on the device (lfq_indel_pack_kernel,
+    quality arrays still resident); a copy of the same columns goes through the host packing: identical records"""
+    import lofreq_amd as la
+    fx, reads = gu.load_plpindel(gu.plpindel_fixtures()[0])
+    ref = fx["genome"].encode()
+    for flag in (la.LFQ_USE_MQ | la.LFQ_USE_IDAQ, la.LFQ_USE_MQ, 0, la.LFQ_USE_MQ | la.LFQ_USE_IDAQ | la.LFQ_USE_SQ):
+        cols, col_pos = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+        assert cols._c_ptr is not None
+        conf_d = la.VarcallConf(flag=flag, bonf_dynamic=0, bonf_indel=1, sig=1.0)       # every test is emitted
+        dev, nt_d = la.call_indels(caller, cols, conf_d)
+        cols._c_ptr = None                                                            # same data, host route
+        conf_h = la.VarcallConf(flag=flag, bonf_dynamic=0, bonf_indel=1, sig=1.0)
+        host, nt_h = la.call_indels(caller, cols, conf_h)
+        assert nt_d == nt_h > 20 and len(dev) == len(host) > 20
+        for k in dev.dtype.names:
+            assert dev[k].tobytes() == host[k].tobytes(), (flag, k)
