@@ -334,6 +334,12 @@ int lfq_pileup_snv_tracks(lfq_ctx *ctx, const lfq_pileup_reads *reads, int64_t r
  * last position of its CIGAR operation.  Entries with BI or BD below min_plp_idq are ignored (plp.c:1062).
  * *cols_out points into memory owned by the context, valid until the next lfq_pileup_indel_columns call; it goes
  * straight into lfq_call_indels_batch. */
+/* on = 0: lfq_pileup_indel_columns / lfq_readset_pileup_indels keep the ins_quals / del_quals arrays (ne_q, ne_mq: the
+ * bulk of an lfq_indel_columns) on the device only -- the pointers in the struct are NULL, ne_off stays valid -- and
+ * lfq_call_indels_batch, given that struct while it is still the context's current one, builds its pseudo-columns
+ * from the resident copy.  Saves the largest transfer of the reads -> VCF chain.  Default: on = 1. */
+int lfq_set_indel_arrays_on_host(lfq_ctx *ctx, int on);
+
 typedef struct lfq_pileup_indel_tags {
     const uint8_t *bi, *bd;    /* per base (seq_off layout): BI / BD tag bytes (quality + 33); NULL = tag absent (quality 0) */
     const uint8_t *ai, *ad;    /* per base: ai / ad tag bytes (lfq_baq_idaq_batch); NULL = absent (-1) */

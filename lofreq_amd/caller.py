@@ -150,6 +150,10 @@ class SnvCaller:
         """lfq_set_dense_strand_counts: off = strand counts only for the columns of the sparse output (layer 1, submit)"""
         _lib.check(self.L.lfq_set_dense_strand_counts(self.h, 1 if on else 0), "lfq_set_dense_strand_counts")
 
+    def set_indel_arrays_on_host(self, on):
+        """lfq_set_indel_arrays_on_host: off = the quality arrays of the indel columns stay on the device only"""
+        _lib.check(self.L.lfq_set_indel_arrays_on_host(self.h, 1 if on else 0), "lfq_set_indel_arrays_on_host")
+
     def call_snvs_submit(self, batch, conf):
         """first half of call_snvs: launch the kernels of the batch and return (one batch in flight per context)"""
         t = batch._tracks()

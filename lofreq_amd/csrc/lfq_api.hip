@@ -110,6 +110,7 @@ struct lfq_ctx {
     hipEvent_t ev_heavy;
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
     LfqIndelColsOwned *plp_indel;
+    int indel_host_arrays;           /* lfq_set_indel_arrays_on_host */
     int16_t *d_plp_ne;               /* quality arrays of the columns above, resident: [q0 | mq0 | q1 | mq1] */
     int64_t plp_ne_total[2];
     int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
@@ -331,6 +332,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     c->device = device_ordinal;
     c->sub_ncols = -1;
     c->dense_strand = 1;
+    c->indel_host_arrays = 1;
     hipDeviceProp_t prop;
     c->n_cu = 256;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -697,6 +699,15 @@ int lfq_snv_batch_device(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
         c->lazy_now = !c->dense_strand;
     }
     return batch_device_impl(c, conf, tr, d_counts, d_pvals, pvals_capacity, stream_or_null, false);
+}
+
+int lfq_set_indel_arrays_on_host(lfq_ctx *c, int on)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    c->indel_host_arrays = on ? 1 : 0;
+    return LFQ_OK;
 }
 
 int lfq_set_dense_strand_counts(lfq_ctx *c, int on)
@@ -1077,6 +1088,11 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
     /* columns that came out of lfq_readset_pileup_indels on this context still have their quality arrays in HBM:
      * the pseudo-columns are then built by lfq_indel_pack_kernel instead of on the host */
     const bool dev_pack = c->plp_indel && b == &c->plp_indel->cols && c->d_plp_ne && !getenv("LFQ_INDEL_HOST_PACK");
+    for (int sd = 0; sd < 2 && !dev_pack; sd++) {
+        if (b->ncols > 0 && b->side[sd].ne_off[b->ncols] > 0 && !b->side[sd].ne_q) {
+            return LFQ_ERR_INVALID;         /* device-only columns that are no longer the context's current ones */
+        }
+    }
     std::vector<LfqIndelTestDesc> descs;
     uint64_t dev_obs = 0;
     int16_t *d_rd = nullptr;                          /* event-read arrays of both sides, uploaded once */
@@ -1945,6 +1961,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
     tm[1] = lfq_now_ms();
     std::vector<uint8_t> g_ai, g_ad;        /* per event, when the qualities come from the device */
+    std::vector<int32_t> qsum[2];           /* per column: quality sum of the reads without an event, from the kernel */
 
     if (n == 0 || width == 0) {
         for (int sd = 0; sd < 2; sd++) {
@@ -1957,7 +1974,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         /* 2. dense counters on the device */
         LFQ_TRY_HIP(hipSetDevice(c->device));
         auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-        const int64_t o_cnt = 0, o_cur = o_cnt + 7 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
+        const int64_t o_cnt = 0, o_cur = o_cnt + 9 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
                       total = o_off + 2 * al(width * 8);
         uint8_t *d = nullptr;
         if (hipMalloc((void **)&d, (size_t)total) != hipSuccess) {
@@ -1989,16 +2006,18 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         A.begin = region_begin;
         A.width = width;
         A.min_plp_idq = min_plp_idq;
-        int32_t **cnt[7] = {&A.cov, &A.tails, &A.non_indels, &A.n_ins, &A.n_dels, &A.non_ins_fw, &A.non_del_fw};
-        for (int i = 0; i < 7; i++) {
+        int32_t **cnt[9] = {&A.cov, &A.tails, &A.non_indels, &A.n_ins, &A.n_dels, &A.non_ins_fw, &A.non_del_fw,
+                            &A.ne_qsum[0], &A.ne_qsum[1]};
+        for (int i = 0; i < 9; i++) {
             *cnt[i] = (int32_t *)(d + o_cnt + i * al(width * 4));
         }
-        std::vector<int32_t> h[7];
+        std::vector<int32_t> h[9];
         if (rc == LFQ_OK) {
             A.pmax_end = readset_pmax(c, rs);
             rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 0, c->stream) : lfq_launch_plp_indel(A, 0, c->stream);
         }
-        for (int i = 0; i < 7 && rc == LFQ_OK; i++) {
+        const bool have_qsum = A.pmax_end != nullptr;       /* the column-major kernel sums the qualities itself */
+        for (int i = 0; i < (have_qsum ? 9 : 7) && rc == LFQ_OK; i++) {
             h[i].resize((size_t)width);
             if (hipMemcpyAsync(h[i].data(), *cnt[i], (size_t)width * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
@@ -2011,6 +2030,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         /* 3. columns = covered positions; quality arrays of the reads without an event at the event positions */
         std::vector<int64_t> pos_off[2];
         int64_t ne_total[2] = {0, 0};
+        const bool host_arrays = c->indel_host_arrays || !have_qsum;   /* device-only needs the sums from the kernel */
         if (rc == LFQ_OK) {
             pos_off[0].assign((size_t)width, -1);
             pos_off[1].assign((size_t)width, -1);
@@ -2062,6 +2082,10 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                     }
                 }
                 O.hrun.push_back(hr);
+                if (have_qsum) {
+                    qsum[0].push_back(h[7][(size_t)p]);
+                    qsum[1].push_back(h[8][(size_t)p]);
+                }
                 const int32_t ne_cnt[2] = {h[2][(size_t)p] + h[4][(size_t)p], h[2][(size_t)p] + h[3][(size_t)p]};
                 const int32_t fw[2] = {h[5][(size_t)p], h[6][(size_t)p]};
                 for (int sd = 0; sd < 2; sd++) {
@@ -2091,7 +2115,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 if (rc == LFQ_OK) {
                     rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 1, c->stream) : lfq_launch_plp_indel(A, 1, c->stream);
                 }
-                for (int sd = 0; sd < 2 && rc == LFQ_OK; sd++) {
+                for (int sd = 0; sd < 2 && rc == LFQ_OK && host_arrays; sd++) {
                     O.side[sd].ne_q.resize((size_t)ne_total[sd]);
                     O.side[sd].ne_mq.resize((size_t)ne_total[sd]);
                     if (ne_total[sd] > 0
@@ -2264,8 +2288,12 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 }
                 best = std::max(best, sum);
             }
-            for (int64_t i = S.ne_off[(size_t)col]; i < S.ne_off[(size_t)col + 1]; i++) {
-                non += S.ne_q[(size_t)i];
+            if (!qsum[sd].empty()) {
+                non = qsum[sd][(size_t)col];
+            } else {
+                for (int64_t i = S.ne_off[(size_t)col]; i < S.ne_off[(size_t)col + 1]; i++) {
+                    non += S.ne_q[(size_t)i];
+                }
             }
             if (best > non) {
                 O.cons_indel[(size_t)col] = 1;
@@ -2295,8 +2323,8 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         T.non_fw = S.non_fw.data();
         T.non_rv = S.non_rv.data();
         T.ne_off = S.ne_off.data();
-        T.ne_q = S.ne_q.data();
-        T.ne_mq = S.ne_mq.data();
+        T.ne_q = S.ne_q.empty() && S.ne_off.back() > 0 ? nullptr : S.ne_q.data();       /* device-only: lfq_set_indel_arrays_on_host */
+        T.ne_mq = S.ne_mq.empty() && S.ne_off.back() > 0 ? nullptr : S.ne_mq.data();
         T.ev_off = S.ev_off.data();
         T.key_off = S.key_off.data();
         T.key_chars = S.key_chars.data();

@@ -237,6 +237,7 @@ struct LfqPlpIndelArgs {
     int32_t min_plp_idq;
     /* per reference position of the region */
     int32_t *cov, *tails, *non_indels, *n_ins, *n_dels, *non_ins_fw, *non_del_fw;
+    int32_t *ne_qsum[2];                  /* column-major kernel: sum of the indel qualities of the reads without an event (consensus, plp.c:1236) */
     /* scatter pass: positions with at least one event get the (quality, MAPQ) of their non-event reads */
     const int64_t *ne_off[2];             /* [width] start of the position's slice per side, -1 = not wanted */
     int32_t *cursor[2];                   /* [width] */

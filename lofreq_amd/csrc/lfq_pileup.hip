@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "lfq_internal.h"
+#include "lfq_device.h"
 
 __global__ __launch_bounds__(256) void lfq_pileup_count_kernel(LfqPileupArgs A)
 {
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(256) void lfq_plp_indel_columns_kernel(LfqPlpIndelA
         hi = a;
     }
     uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};      /* cov, tails, non_indels, n_ins, n_dels, non_ins_fw, non_del_fw */
+    uint32_t qs0 = 0, qs1 = 0;                    /* per lane: indel qualities of the reads without an insertion / deletion */
     uint32_t w0 = 0, w1 = 0;                      /* scatter cursors of the two sides */
     for (int64_t r0 = lo; r0 < hi; r0 += 64) {
         const int64_t r = r0 + lane;
@@ -492,6 +494,8 @@ __global__ __launch_bounds__(256) void lfq_plp_indel_columns_kernel(LfqPlpIndelA
             cnt[4] += (uint32_t)__popcll(__ballot(pass && indel < 0));
             cnt[5] += (uint32_t)__popcll(__ballot(no_ins && !rev));
             cnt[6] += (uint32_t)__popcll(__ballot(no_del && !rev));
+            qs0 += no_ins ? (uint32_t)iq : 0u;
+            qs1 += no_del ? (uint32_t)dq : 0u;
         } else {
             const uint64_t m0 = __ballot(no_ins), m1 = __ballot(no_del), below = (1ull << lane) - 1ull;
             if (no_ins && off0 >= 0) {
@@ -508,7 +512,13 @@ __global__ __launch_bounds__(256) void lfq_plp_indel_columns_kernel(LfqPlpIndelA
             w1 += (uint32_t)__popcll(m1);
         }
     }
+    if (!SCATTER) {
+        qs0 = lfq_wave_sum_u32(qs0);
+        qs1 = lfq_wave_sum_u32(qs1);
+    }
     if (!SCATTER && lane == 0) {
+        A.ne_qsum[0][c] = (int32_t)qs0;
+        A.ne_qsum[1][c] = (int32_t)qs1;
         A.cov[c] = (int32_t)cnt[0];
         A.tails[c] = (int32_t)cnt[1];
         A.non_indels[c] = (int32_t)cnt[2];

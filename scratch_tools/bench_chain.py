@@ -62,6 +62,7 @@ pr.mapq = mapq.ctypes.data; pr.reverse = rev.ctypes.data; pr.ref = rd.ref; pr.re
 tg = _lib.PileupIndelTags(); tg.bi = bi.ctypes.data; tg.bd = bd.ctypes.data; tg.ai = ai.ctypes.data; tg.ad = ad.ctypes.data
 col_pos = np.zeros(glen, np.int64)
 vp = C.c_void_p
+L.lfq_set_indel_arrays_on_host(caller.h, 0)     # the quality arrays of the indel columns stay in HBM
 for it in range(3):
     # ---- resident read set: one upload, everything else on the device copy
     T = [time.perf_counter()]
@@ -93,6 +94,7 @@ for it in range(3):
           "SNV calls %.3f s (%d tested columns, %d records) | total %.3f s = %.2f M reads/s"
           % (d[0], d[1], d[2], d[3], nt.value, d[4], d[5], st.n_tested, len(recs), sum(d), n / sum(d) / 1e6), flush=True)
 pr.baq = lb.ctypes.data
+L.lfq_set_indel_arrays_on_host(caller.h, 1)
 for it in range(2):
     T = [time.perf_counter()]
     assert L.lfq_baq_idaq_batch(caller.h, C.byref(rd), 1, lb.ctypes.data, ai.ctypes.data, ad.ctypes.data, fl.ctypes.data) == 0

@@ -275,3 +275,26 @@ def test_indel_calls_device_packing_equals_host_packing(caller):
         assert nt_d == nt_h > 20 and len(dev) == len(host) > 20
         for k in dev.dtype.names:
             assert dev[k].tobytes() == host[k].tobytes(), (flag, k)
+
+
+def test_indel_columns_device_only_arrays(caller):
+    """lfq_set_indel_arrays_on_host(0): the ins_quals / del_quals arrays never leave the device (NULL in the struct, the
+    consensus flag from the kernel's quality sums) -- same consensus flags, same indel records"""
+    import lofreq_amd as la
+    for path in gu.plpindel_fixtures():
+        fx, reads = gu.load_plpindel(path)
+        ref = fx["genome"].encode()
+        kw, _ = gu.conf_kwargs(fx["call_args"])
+        cols, col_pos = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+        want, nt_w = la.call_indels(caller, cols, la.VarcallConf(**kw))
+        caller.set_indel_arrays_on_host(False)
+        try:
+            cols2, col_pos2 = la.pileup_indel_columns(caller, reads, ref, 0, len(ref))
+            got, nt_g = la.call_indels(caller, cols2, la.VarcallConf(**kw))
+        finally:
+            caller.set_indel_arrays_on_host(True)
+        assert len(cols2.sides[0]["ne_q"]) == 0 and int(cols2.sides[0]["ne_off"][-1]) > 0
+        assert cols2.cons_indel.tolist() == cols.cons_indel.tolist() and col_pos2.tolist() == col_pos.tolist()
+        assert nt_g == nt_w and len(got) == len(want) > 0
+        for k in got.dtype.names:
+            assert got[k].tobytes() == want[k].tobytes(), k
