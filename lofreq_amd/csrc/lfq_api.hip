@@ -48,6 +48,40 @@ static inline double lfq_now_ms()
 }
 static const bool lfq_timing_on = getenv("LFQ_TIMING") != nullptr;
 
+/* per-read host loops of the read-set steps (geometry from the CIGARs, event candidates): independent reads, split
+ * over a few threads when there are enough of them.  f(begin, end, part) */
+template <typename F>
+static void lfq_for_reads(int64_t n, F f, int *parts_out = nullptr)
+{
+    int parts = 1;
+    if (n >= 200000) {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) {
+            const int lws = atoi(e);
+            if (lws > 1) {
+                hw = std::max(1u, hw / (unsigned)lws);
+            }
+        }
+        parts = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), n / 100000);
+        parts = std::max(parts, 1);
+    }
+    if (parts_out) {
+        *parts_out = parts;
+    }
+    if (parts == 1) {
+        f((int64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int p = 1; p < parts; p++) {
+        th.emplace_back([&, p] { f(n * p / parts, n * (p + 1) / parts, p); });
+    }
+    f((int64_t)0, n / parts, 0);
+    for (auto &t : th) {
+        t.join();
+    }
+}
+
 struct LfqIndelColsOwned {
     lfq_indel_columns cols;
     std::vector<uint8_t> ref_base, cons_indel;
@@ -1536,7 +1570,10 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     std::vector<LfqBaqRead> h((size_t)n);
     std::vector<int32_t> width((size_t)n, 0);
     int max_lq = 0, max_w = 0;
-    for (int64_t r = 0; r < n; r++) {
+    int part_lq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, part_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
+    int max_lq = 0, max_w = 0;                      /* of this part */
+    for (int64_t r = r_begin; r < r_end; r++) {
         LfqBaqRead &o = h[(size_t)r];
         const int l_qseq = (int)(rd->seq_off[r + 1] - rd->seq_off[r]);
         const uint32_t *cg = rd->cigar + rd->cigar_off[r];
@@ -1578,6 +1615,13 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             max_w = std::max(max_w, (b2 * 2 + 1) * 3 + 6);
             width[(size_t)r] = (b2 * 2 + 1) * 3 + 6;
         }
+    }
+    part_lq[part] = max_lq;
+    part_w[part] = max_w;
+    });
+    for (int p = 0; p < 8; p++) {
+        max_lq = std::max(max_lq, part_lq[p]);
+        max_w = std::max(max_w, part_w[p]);
     }
     /* narrow-band reads (rows of at most LFQ_BAQ_LDS_CELLS cells) first: they run in the LDS variant */
     static const bool use_lds = !(getenv("LFQ_BAQ_LDS") && atoi(getenv("LFQ_BAQ_LDS")) == 0);
@@ -1907,7 +1951,10 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     /* 1. events from the CIGARs, in read (= pileup) order */
     struct Ev { int64_t pos; int64_t read; int32_t qpos, indel; };
     std::vector<Ev> evs;
-    for (int64_t r = 0; r < n; r++) {
+    std::vector<Ev> evs_part[8];                    /* per thread, concatenated in read order below */
+    lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
+    std::vector<Ev> &evs = evs_part[part];
+    for (int64_t r = r_begin; r < r_end; r++) {
         const uint32_t *cg = rd->cigar + rd->cigar_off[r];
         const int n_cigar = (int)(rd->cigar_off[r + 1] - rd->cigar_off[r]);
         const int64_t s0 = rd->seq_off[r];
@@ -1957,6 +2004,10 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 y += l;
             }
         }
+    }
+    });
+    for (int p = 0; p < 8; p++) {
+        evs.insert(evs.end(), evs_part[p].begin(), evs_part[p].end());
     }
     std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
     tm[1] = lfq_now_ms();
