@@ -84,3 +84,31 @@ def test_pileup_then_call_device_resident(caller, oracle):
     pos0 = np.array([dt.col_pos[int(r["col"])] for r in recs], np.int64)
     text = la.format_vcf(recs, "chr1", pos0=pos0, keep=keep, filter_str="PASS")
     assert [gu.strip_hqa(l) for l in text.splitlines()] == fx["vcf"]
+
+
+def test_pileup_unsorted_reads_take_the_read_major_kernels(caller):
+    """reads that are not position-sorted cannot use the window search: the read-major (atomic) kernels run instead;
+    same columns, same observations per column as for the sorted list (any order), same calls"""
+    import lofreq_amd as la
+    fx = json.load(open(gu.pileup_fixtures()[0]))
+    reads = [{"pos0": r[0], "cigar": gu.parse_cigar(r[3]), "seq": la.encode_seq(r[4]),
+              "qual": np.array([ord(c) - 33 for c in r[5]], np.uint8), "mapq": r[2], "reverse": bool(r[1] & 16)}
+             for r in fx["reads"]]
+    lb = [np.frombuffer(r[6].encode(), np.uint8) for r in fx["reads"]]
+    ref = fx["genome"].encode()
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(len(reads))
+    res = []
+    for order in (np.arange(len(reads)), perm):
+        dt = la.pileup_snv_tracks(caller, [reads[i] for i in order], ref, 0, len(ref), lb=[lb[i] for i in order])
+        t = dt._tracks()
+        off = _fetch(t.col_off, (dt.ncols + 1) * 8).view(np.uint64)
+        n_obs = int(off[-1])
+        tr = [_fetch(p, n_obs) for p in (t.nt, t.bq, t.baq, t.mq)]
+        cols = [sorted(zip(*(x[int(off[c]):int(off[c + 1])].tolist() for x in tr))) for c in range(dt.ncols)]
+        recs, _, _ = caller.call_snvs(dt, la.VarcallConf())
+        res.append((dt.col_pos.tolist(), cols, recs.tobytes()))
+        icols, ipos = la.pileup_indel_columns(caller, [reads[i] for i in order], ref, 0, len(ref))
+        res[-1] += (ipos.tolist(), icols.num_non_indels.tolist(), icols.num_tails.tolist(), icols.coverage_plp.tolist())
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert res[0][3:] == res[1][3:]
