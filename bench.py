@@ -1,26 +1,41 @@
 #!/usr/bin/env python
 """bench.py -- pileup columns/sec of the per-column SNV calling path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C3|C2] [--mode resident|host-abi|chain]
 
-A step is one pass of the hot path (count -> running-Bonferroni scan -> Poisson-binomial DP -> host
-emit test / VCF records) over one batch of synthetic pileup columns that are ALREADY RESIDENT IN HBM
-(generated on the device by the workload spec of include/lofreq_synth.h).  Default workload =
-BASELINE.json configs[2] ("C3"): synthetic 1 Mb genome, 10000x ultra-deep, SNV-only,
---no-default-filter, dynamic Bonferroni -- the configuration the metric "pileup columns/sec at depth
-10000" is quoted on; it fits one GPU (40 GB of tracks).  With N > 1 every rank owns its own 1 Mb
-region shard (weak scaling, the reference's call-parallel model) and the only exchange is the tested
--column count all-gather + the record gather of lofreq_amd/shard.py.
+A step is one pass of the hot path (count -> running-Bonferroni scan -> Poisson-binomial DP -> host emit test /
+filter / VCF records) over one batch of synthetic pileup columns that are ALREADY RESIDENT IN HBM (generated on
+the device by the workload spec of include/lofreq_synth.h).  Default workload = BASELINE.json configs[2] ("C3"):
+synthetic 1 Mb genome, 10000x ultra-deep, SNV-only, --no-default-filter, dynamic Bonferroni -- the configuration
+the metric "pileup columns/sec at depth 10000" is quoted on; it fits one GPU (35 GB of tracks).  `--config C2` is
+configs[1] (1000x, default filter applied).  With N > 1 every rank owns its own 1 Mb region shard (weak scaling,
+the reference's call-parallel model) or, with `--scaling strong`, 1/N of one N x 1 Mb genome cut by
+lofreq_amd.shard.plan_regions; the only exchange is the tested-column count all-gather + the record gather of
+lofreq_amd/shard.py.
 
-Prints ONE JSON line on rank 0 (see the repository prompt for the contract) with two extra objects:
-`roofline` (HBM roofline of the dominant kernel from HIP-event timings taken inside the C library on
-the stream the kernels run on) and `cpu_baseline` (the oracle, single thread, on a bounded sample of
-the same workload).
+Prints ONE JSON line on rank 0 with these extra objects:
+  roofline      HBM roofline of the dominant kernel: bytes the launched instantiation moves (from the layout: the
+                library reports them per batch) / its HIP-event duration (events on the stream the kernel runs on,
+                taken inside the C library) / 8 TB/s.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes
+                that THIS run spawns on the same workload (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE
+                doubled for 16 B/lane streaming reads per MI355X_MICROARCH.md), or null when rocprofv3 is not usable.
+                `algorithmic_8d` keeps SURVEY 8(d)'s 4*depth+80 bytes per column figure (the kernel has to read only
+                1.5 of those 4 bytes, so that ratio can exceed 1 and is not called a fraction).
+  dp            secondary figure: recurrence cells processed per step (device counters), cells/s over
+                the DP span, VALU-busy of the DP kernels from an SQ_INSTS_VALU pass.
+  cpu_baseline  the oracle (CPU restatement of the reference algorithm), one pinned core, bounded sample.
+  config.secondary   (N = 1) the two paths a caller outside this benchmark takes: `host_abi` = host buffers through
+                lfq_call_snvs_batch(tracks_on_device = 0), PCIe included; `chain` = reads -> BAQ -> pileup -> calls.
 """
 import argparse
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,53 +43,321 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-SEED = 0x9E3779B97F4A7C15 ^ (3 << 32)   # SURVEY 8d seed formula, config id 3
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured for a float4 copy
+N_SIMD = 1024              # 256 CUs x 4 SIMDs
+CLK_HZ = 2.4e9
+CONFIGS = {
+    # name: (BASELINE.json index, depth, columns per GPU, default filter, CPU sample columns)
+    "C3": (2, 10000, 1000000, False, 8000),
+    "C2": (1, 1000, 1000000, True, 60000),
+}
+
+
+def seed_of(config_id):
+    return 0x9E3779B97F4A7C15 ^ (config_id << 32)      # SURVEY 8d seed formula
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--depth", type=int, default=10000)
-    ap.add_argument("--cols", type=int, default=1000000, help="columns per GPU (region shard)")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
+    ap.add_argument("--mode", choices=["resident", "host-abi", "chain"], default="resident",
+                    help="resident (default, the metric): tracks in HBM; host-abi: host buffers through the C ABI; "
+                         "chain: reads -> BAQ -> pileup -> calls on a resident read set")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--cols", type=int, default=None, help="columns per GPU (region shard)")
     ap.add_argument("--plant-period", type=int, default=997)
-    ap.add_argument("--cpu-sample-cols", type=int, default=8000)
+    ap.add_argument("--cpu-sample-cols", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the host-abi / chain measurements of config.secondary")
     ap.add_argument("--nt-bytes", action="store_true",
                     help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="N=1 only: two contexts, batch k+1 is submitted (lfq_call_snvs_submit) before batch k is "
-                         "collected; every step still does all of its work inside the timed region")
     ap.add_argument("--shard-path", action="store_true",
                     help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(depth, plant_period, sample_cols):
-    """Oracle (CPU restatement of the reference algorithm), one thread, first `sample_cols` columns of
-    the same workload.  Returns (dict for the JSON line, oracle results for the concordance check)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seed, depth, plant_period, sample_cols, default_filter):
+    """Oracle (CPU restatement of the reference algorithm), one thread pinned to one core, first `sample_cols`
+    columns of the same workload.  Returns (dict for the JSON line, oracle results for the concordance check)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as orc
     orc.build()
-    host = orc.synth_fill(SEED, depth, plant_period, 0, sample_cols)
+    host = orc.synth_fill(seed, depth, plant_period, 0, sample_cols)
     conf = orc.default_conf()
+    pinned = None
+    old_aff = None
+    try:                                            # taskset -c <first allowed core>, in-process
+        old_aff = os.sched_getaffinity(0)
+        pinned = min(old_aff)
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        pinned = None
     t0 = time.perf_counter()
     res, tm = orc.call_batch(host["nt"], host["bq"], host["baq"], host["mq"], None, host["col_off"],
                              host["ref_base"], conf, timing=True)
     dt = time.perf_counter() - t0
+    if old_aff is not None:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except OSError:
+            pass
+    # SURVEY 8d's cell count in the REFERENCE's row order (probabilities sorted ascending, its own pruning row)
+    k = np.max(res["alt_counts"], axis=1).astype(np.int64)
+    n = res["dp_rows"].astype(np.int64)
+    cells_ref = int(np.sum(np.where(n <= k, n * (n + 1) // 2, k * (k + 1) // 2 + (n - k) * k)))
     out = {
         "value": sample_cols / dt, "unit": "columns/s", "cores": 1, "kind": "port",
-        "sample": "first %d columns of the same workload (depth %d, planted SNV every %d columns), "
-                  "%.1f s wall; merge %.1f s / sort %.1f s / DP %.1f s; host cpus available: %d"
-                  % (sample_cols, depth, plant_period, dt, tm.t_merge, tm.t_sort, tm.t_dp, os.cpu_count()),
+        "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "pinned_to_core": pinned,
+        "sample": "first %d columns of the same workload (depth %d, planted SNV every %d columns), %.1f s wall on "
+                  "one pinned core; merge %.1f s / sort %.1f s / DP %.1f s"
+                  % (sample_cols, depth, plant_period, dt, tm.t_merge, tm.t_sort, tm.t_dp),
+        "dp_cells_reference_order": cells_ref,
+        "dp_cells_per_s": cells_ref / tm.t_dp if tm.t_dp > 0 else None,
     }
     return out, res
 
 
+# ---------------------------------------------------------------------------------------------------------
+# rocprofv3 counter passes, spawned by the run itself (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------------------
+
+def _short_kernel(name):
+    return name.replace("void ", "").split("(")[0]
+
+
+def pmc_pass(counter, child_args, timeout_s=240):
+    """One `rocprofv3 --pmc <counter> --kernel-trace` pass over a 2-step child run of this script.
+    -> {kernel: (sum, launches)} or None.  One counter per pass: FETCH_SIZE + WRITE_SIZE together exceed the
+    TCC slots of gfx950 (MI355X_MICROARCH.md "rocprofv3 PMC slots")."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out_dir = tempfile.mkdtemp(prefix="lfq_pmc_", dir="/tmp")
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    env["LFQ_SINGLE_STREAM"] = "1"      # counter collection serialises dispatches; cross-stream waits do not get along with it
+    cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out_dir, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+    try:
+        p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                             start_new_session=True)
+        try:
+            p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, 9)         # the exact process group started above
+            p.wait()
+            return None
+        dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+        if p.returncode != 0 or not dbs:
+            return None
+        res = {}
+        db = sqlite3.connect(dbs[0])
+        for name, cname, val, n in db.execute(
+                "select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                "group by kernel_name, counter_name"):
+            if cname == counter:
+                res[_short_kernel(name)] = (float(val), int(n))
+        db.close()
+        return res
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def live_pmc(child_args, count_kernel):
+    """HBM traffic of the count kernel and VALU instructions of the DP kernels, from three counter passes."""
+    out = {"traffic": None, "fetch_kib": None, "write_kib": None, "valu_insts_dp": None, "valu_by_kernel": None,
+           "source": "rocprofv3 --pmc passes spawned by this run (2-step child of the same command, LFQ_SINGLE_STREAM=1)"}
+    f = pmc_pass("FETCH_SIZE", child_args)
+    w = pmc_pass("WRITE_SIZE", child_args) if f is not None else None
+    v = pmc_pass("SQ_INSTS_VALU", child_args) if f is not None else None
+    if f and w and count_kernel in f and count_kernel in w:
+        fk, n = f[count_kernel]
+        wk, _ = w[count_kernel]
+        out["fetch_kib"] = fk / n
+        out["write_kib"] = wk / n
+        # FETCH_SIZE counts 64 B per 128 B request of a 16 B/lane streaming read on gfx950: doubled (guide, HBM section)
+        out["traffic"] = (2.0 * fk + wk) * 1024.0 / n
+    if v:
+        dp = {k: x for k, x in v.items() if k.startswith("lfq_dp_") or k.startswith("lfq_strand_")}
+        # per step: every DP kernel is launched once per step (the empty variants included)
+        steps = max(min(x[1] for x in dp.values()), 1) if dp else 1
+        out["valu_insts_dp"] = sum(x[0] for x in dp.values()) / steps
+        out["valu_by_kernel"] = {k: x[0] / steps for k, x in dp.items()}
+        if count_kernel in v:
+            out["valu_insts_count"] = v[count_kernel][0] / v[count_kernel][1]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# secondary paths (N = 1): host-buffer ABI, reads -> VCF chain
+# ---------------------------------------------------------------------------------------------------------
+
+def bench_host_abi(caller, la, seed, depth, ncols, plant_period, steps):
+    """Host buffers through lfq_call_snvs_batch(tracks_on_device = 0): what the plp_proc_func shim does per flush
+    (integration/lofreq_amd_shim.c).  PCIe upload included; bytes = the four byte tracks + headers."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+    orc.build()
+    host = orc.synth_fill(seed, depth, plant_period, 0, ncols)
+    batch = la.PileupBatch(host["nt"], host["bq"], host["mq"], host["col_off"], host["ref_base"], baq=host["baq"],
+                           max_col_obs=depth)
+    n_obs = int(host["col_off"][-1])
+    conf = la.VarcallConf()
+    caller.call_snvs(batch, conf, records_capacity=1 << 16)          # warm-up: staging allocation
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        conf = la.VarcallConf()
+        recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
+    dt = (time.perf_counter() - t0) / steps
+    byt = 4.0 * n_obs + ncols * 9.0
+    return {"columns_per_s": ncols / dt, "ms_per_batch": dt * 1e3, "columns_per_batch": ncols, "depth": depth,
+            "host_bytes_per_batch": byt, "effective_GBps": byt / dt / 1e9, "pcie_peak_GBps": 63.0,
+            "frac_of_pcie": byt / dt / 1e9 / 63.0, "records": int(len(recs)),
+            "note": "pageable host arrays in, VCF records out; upload + kernels + host finish per call"}
+
+
+def make_reads(n, glen, rl=150, seed=3, indel_frac=0.04):
+    """Position-sorted synthetic reads over a random genome: 0.3 % mismatches, `indel_frac` of the reads with one
+    1-3 bp insertion or deletion, BI / BD tags."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, glen).astype(np.uint8)
+    gen_ascii = np.frombuffer(b"ACGT", np.uint8)[genome].tobytes()
+    pos = np.sort(rng.integers(0, glen - rl - 20, n)).astype(np.int32)
+    has = rng.random(n) < indel_frac
+    kind = rng.random(n) < 0.5
+    ilen = rng.integers(1, 4, n)
+    cut = rng.integers(50, 100, n)
+    base = genome[(pos[:, None] + np.arange(rl + 4)[None, :])]
+    seq = np.empty((n, rl), np.uint8)
+    plain = ~has
+    seq[plain] = base[plain, :rl]
+    for i in np.nonzero(has)[0]:
+        c, k = int(cut[i]), int(ilen[i])
+        if kind[i]:
+            seq[i, :c] = base[i, :c]
+            seq[i, c:c + k] = rng.integers(0, 4, k)
+            seq[i, c + k:] = base[i, c:rl - k]
+        else:
+            seq[i, :c] = base[i, :c]
+            seq[i, c:] = base[i, c + k:rl + k]
+    cigs = np.zeros((n, 3), np.uint32)
+    ncig = np.ones(n, np.int64)
+    cigs[:, 0] = (rl << 4)
+    ii = np.nonzero(has)[0]
+    cigs[ii, 0] = (cut[ii].astype(np.uint32) << 4)
+    cigs[ii, 1] = (ilen[ii].astype(np.uint32) << 4) | np.where(kind[ii], 1, 2).astype(np.uint32)
+    cigs[ii, 2] = ((rl - cut[ii] - np.where(kind[ii], ilen[ii], 0)).astype(np.uint32) << 4)
+    ncig[ii] = 3
+    cig_off = np.zeros(n + 1, np.int64)
+    cig_off[1:] = np.cumsum(ncig)
+    cig = np.ascontiguousarray(cigs[np.arange(3)[None, :] < ncig[:, None]])
+    mism = rng.random(seq.shape) < 0.003
+    seq[mism] = (seq[mism] + 1) % 4
+    qual = np.clip(np.round(rng.normal(34, 5, seq.shape)), 2, 41).astype(np.uint8)
+    return {
+        "n": n, "rl": rl, "glen": glen, "ref": gen_ascii, "pos": pos, "cig_off": cig_off, "cig": cig,
+        "seq_off": np.arange(n + 1, dtype=np.int64) * rl, "seq": np.ascontiguousarray(seq.reshape(-1)),
+        "qual": np.ascontiguousarray(qual.reshape(-1)),
+        "bi": rng.integers(33 + 30, 33 + 50, n * rl).astype(np.uint8),
+        "bd": rng.integers(33 + 30, 33 + 50, n * rl).astype(np.uint8),
+        "mapq": np.full(n, 60, np.uint8), "rev": (rng.random(n) < 0.5).astype(np.uint8), "n_indel_reads": int(has.sum()),
+    }
+
+
+def bench_chain(caller, la, n_reads, glen, iters, call_indels=True):
+    """reads -> BAQ (+ IDAQ) -> device pileup(s) -> SNV (+ indel) calls on a resident read set: the reference's
+    `lofreq call [--call-indels]` with BAQ on (BASELINE.md end-to-end rows), everything after BAM decoding."""
+    import ctypes as C
+    from lofreq_amd import _lib
+    from lofreq_amd.pileup import DeviceTracks
+    R = make_reads(n_reads, glen)
+    L = _lib.load()
+    vp = C.c_void_p
+    pr = _lib.PileupReads()
+    pr.n_reads = R["n"]
+    pr.pos, pr.cigar_off, pr.cigar = R["pos"].ctypes.data, R["cig_off"].ctypes.data, R["cig"].ctypes.data
+    pr.seq_off, pr.seq, pr.qual = R["seq_off"].ctypes.data, R["seq"].ctypes.data, R["qual"].ctypes.data
+    pr.baq = None
+    pr.mapq, pr.reverse = R["mapq"].ctypes.data, R["rev"].ctypes.data
+    pr.ref = C.cast(C.c_char_p(R["ref"]), C.c_void_p)
+    pr.ref_len = glen
+    tg = _lib.PileupIndelTags()
+    tg.bi, tg.bd = R["bi"].ctypes.data, R["bd"].ctypes.data
+    col_pos = np.zeros(glen, np.int64)
+    L.lfq_set_indel_arrays_on_host(caller.h, 0)
+    best = None
+    for _ in range(iters + 1):                      # first iteration = warm-up (allocations)
+        T = [time.perf_counter()]
+        h = vp()
+        _lib.check(L.lfq_readset_create(caller.h, C.byref(pr), C.byref(tg), C.byref(h)), "lfq_readset_create")
+        T.append(time.perf_counter())
+        _lib.check(L.lfq_readset_baq(caller.h, h, 1, 1 if call_indels else 0), "lfq_readset_baq")
+        T.append(time.perf_counter())
+        conf = la.VarcallConf(flag=la.LFQ_USE_BAQ | la.LFQ_USE_MQ | la.LFQ_USE_IDAQ)
+        n_tests = C.c_int64(0)
+        nrec = C.c_int64(0)
+        cons = None
+        if call_indels:
+            outp = C.POINTER(_lib.IndelColumnsC)()
+            _lib.check(L.lfq_readset_pileup_indels(caller.h, h, 0, glen, 0, C.byref(outp), col_pos.ctypes.data),
+                       "lfq_readset_pileup_indels")
+            T.append(time.perf_counter())
+            cap = 1 << 20
+            rec = np.zeros(cap, dtype=_lib.INDEL_RECORD_DTYPE)
+            _lib.check(L.lfq_call_indels_batch(caller.h, C.byref(conf.c), outp, rec.ctypes.data, cap, C.byref(nrec),
+                                               C.byref(n_tests)), "lfq_call_indels_batch")
+            cons = np.frombuffer(C.string_at(outp.contents.cons_indel, outp.contents.ncols), np.uint8).copy()
+        else:
+            T.append(time.perf_counter())
+        T.append(time.perf_counter())
+        t = _lib.Tracks()
+        _lib.check(L.lfq_readset_pileup_snv(caller.h, h, 0, glen, 3, C.byref(t), col_pos.ctypes.data),
+                   "lfq_readset_pileup_snv")
+        if cons is not None:
+            _lib.check(L.lfq_pileup_skip_snv_columns(caller.h, cons.ctypes.data, len(cons)), "skip")
+        T.append(time.perf_counter())
+        recs, _, st = caller.call_snvs(DeviceTracks(t, col_pos[: t.ncols]), conf, records_capacity=1 << 18)
+        T.append(time.perf_counter())
+        L.lfq_readset_destroy(h)
+        d = [T[i + 1] - T[i] for i in range(6)]
+        tot = sum(d)
+        if best is None or tot < best["s_total"]:
+            best = {"s_total": tot, "s_upload": d[0], "s_baq": d[1], "s_indel_pileup": d[2], "s_indel_calls": d[3],
+                    "s_snv_pileup": d[4], "s_snv_calls": d[5], "columns": int(t.ncols), "indel_tests": int(n_tests.value),
+                    "snv_records": int(len(recs)), "indel_records": int(nrec.value)}
+    L.lfq_set_indel_arrays_on_host(caller.h, 1)
+    best.update({"reads": n_reads, "read_len": R["rl"], "genome_len": glen, "depth": n_reads * R["rl"] / glen,
+                 "reads_per_s": n_reads / best["s_total"], "columns_per_s": best["columns"] / best["s_total"],
+                 "call_indels": bool(call_indels),
+                 "note": "resident read set; BAM decoding (htslib, CPU) not included; reference end-to-end rows "
+                         "(BASELINE.md 2): 6736 cols/s without BAQ, 1334 cols/s with BAQ, one CPU thread"})
+    return best
+
+
 def main():
     args = parse_args()
+    cfg_idx, cfg_depth, cfg_cols, cfg_filter, cfg_sample = CONFIGS[args.config]
+    depth = args.depth or cfg_depth
+    ncols = args.cols or cfg_cols
+    seed = seed_of(3 if args.config == "C3" else 2)
     import torch
     import torch.distributed as dist
 
@@ -93,17 +376,47 @@ def main():
 
     caller = la.SnvCaller(local_rank)
     caller.set_dense_strand_counts(False)         # DP4 only for the columns that emit (what layer 2 does by itself)
-    ncols, depth = args.cols, args.depth
-    col_begin = rank * ncols                      # this rank's region shard
-    batch = caller.synth_batch(SEED, depth, ncols, plant_period=args.plant_period, col_begin=col_begin,
+
+    if args.mode == "chain":
+        res = bench_chain(caller, la, 2000000, 1000000, max(args.steps // 100, 2))
+        line = {"metric": "pileup columns/sec, reads -> VCF chain (BAQ + device pileup + SNV and indel calls)",
+                "value": res["columns_per_s"], "unit": "columns/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": res["s_total"] * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "chain: 2 M reads x 150 bp over 1 Mb (depth 300), --call-indels, BAQ on", **res}}
+        print(json.dumps(line))
+        caller.close()
+        return
+    if args.mode == "host-abi":
+        res = bench_host_abi(caller, la, seed_of(2), 1000, 200000, args.plant_period, max(args.steps // 20, 3))
+        line = {"metric": "pileup columns/sec at depth 1000, host buffers through the C ABI", "value": res["columns_per_s"],
+                "unit": "columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["ms_per_batch"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "host-abi: C2-shaped batches (200 k columns x 1000x) from host memory", **res}}
+        print(json.dumps(line))
+        caller.close()
+        return
+
+    # ---- this rank's columns ----
+    if args.scaling == "strong" and world > 1:
+        # one genome of world * ncols columns, cut into >= 2 bins per GPU (call-parallel's rule) balanced by depth
+        total = ncols * world
+        bins = shard.plan_regions([("synth", 0, total)], lambda c, b, e: float(depth) * (e - b), world)
+        mine = bins[rank]
+        col_begin, my_cols = mine[0][1], sum(e - b for _, b, e in mine)
+        assert all(mine[i][2] == mine[i + 1][1] for i in range(len(mine) - 1)), "bins of a rank are contiguous here"
+    else:
+        col_begin, my_cols = rank * ncols, ncols
+    batch = caller.synth_batch(seed, depth, my_cols, plant_period=args.plant_period, col_begin=col_begin,
                                nt_packed=not args.nt_bytes)
-    d_counts = torch.zeros(ncols * 64, dtype=torch.uint8, device=dev)
-    pv_cap = ncols
+    d_counts = torch.zeros(my_cols * 64, dtype=torch.uint8, device=dev)
+    pv_cap = my_cols
     d_pvals = torch.zeros(pv_cap * 128, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
 
     def step():
-        """One pass: kernels, sparse results to the host, exact emit test, exchange, VCF text."""
+        """One pass: kernels, sparse results to the host, exact emit test, exchange, filter, VCF text."""
         conf = la.VarcallConf()                   # default sig, dynamic Bonferroni from 1
         if world == 1 and not args.shard_path:
             # layer 2 of the C ABI (lfq_call_snvs_batch): the whole call_snvs loop over the batch in one call
@@ -117,28 +430,18 @@ def main():
                                              dist if world > 1 else None, dev)
         text = None
         if rank == 0:
-            # --no-default-filter + dynamic Bonferroni: QUAL threshold from the final factor
+            # QUAL threshold from the final dynamic Bonferroni factor (lofreq_call.c:1519-1538), then `lofreq filter`
+            # with (C2) or without (C3, --no-default-filter) its defaults
             thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
-            keep = la.filter_records(recs, thr, apply_defaults=False)
+            keep = la.filter_records(recs, thr, apply_defaults=cfg_filter)
             text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
         return conf, st, recs, text, caller.kernel_times()
 
-    pipelined = args.pipeline and world == 1 and not args.shard_path
-    if pipelined:
-        callers = [caller, la.SnvCaller(local_rank)]
-        callers[1].set_dense_strand_counts(False)
-
-        def submit(k):
-            conf = la.VarcallConf()
-            callers[k % 2].call_snvs_submit(batch, conf)
-            return conf
-
-        def collect(k, conf):
-            recs, st = callers[k % 2].call_snvs_collect(conf, records_capacity=1 << 16)
-            thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
-            keep = la.filter_records(recs, thr, apply_defaults=False)
-            text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
-            return conf, st, recs, text, callers[k % 2].kernel_times()
+    if args.pmc_child:
+        for _ in range(2):
+            step()
+        caller.close()
+        return
 
     for _ in range(args.warmup):
         step()
@@ -151,84 +454,97 @@ def main():
     kt_acc = None
     barrier()
     t0 = time.perf_counter()
-    if pipelined:
-        pending = submit(0)
-        for k in range(1, args.steps + 1):
-            nxt = submit(k) if k < args.steps else None
-            conf, st, recs, text, kt = collect(k - 1, pending)
-            kt_acc = kt if kt_acc is None else {x: kt_acc[x] + kt[x] for x in kt}
-            pending = nxt
-    else:
-        for _ in range(args.steps):
-            conf, st, recs, text, kt = step()
-            kt_acc = kt if kt_acc is None else {k: kt_acc[k] + kt[k] for k in kt}
+    for _ in range(args.steps):
+        conf, st, recs, text, kt = step()
+        kt_acc = kt if kt_acc is None else {k: kt_acc[k] + kt[k] for k in kt}
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    work = caller.dp_work()
 
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = 1e3 * elapsed / steps
-        total_cols = ncols * world
+        total_cols = my_cols * world if args.scaling == "weak" else ncols * world
         value = total_cols * steps / elapsed
         kt = {k: v / steps for k, v in kt_acc.items()}
         n_launch = max(int(round(kt["n_segments"])), 1)       # count-kernel launches per step
-        # Dominant kernel = the one with the largest summed duration per step.  (The three DP kernels run
-        # CONCURRENTLY with each other; their individual durations overlap and are not additive.)
-        # Algorithmic bytes per SURVEY 8(d): 4*depth + 80 per column; one launch covers ncols/n_launch columns.
-        alg_bytes = ncols * (4.0 * depth + 80.0) / n_launch
-        # ms_dp_light/mid/big are the spans of the three DP stream chains (quad+retry | mid+segments+fold |
-        # prep+segments+fold), which overlap; the count kernel is one launch on its own.
-        cands = {"lfq_count_kernel": kt["ms_count"] / n_launch, "dp chain: lfq_dp_quad_kernel<8>+retry": kt["ms_dp_light"] / n_launch,
-                 "dp chain: mid class": kt["ms_dp_mid"] / n_launch, "dp chain: big class": kt["ms_dp_big"] / n_launch}
-        dom = max(cands, key=cands.get)
-        dom_ms = cands[dom]
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                tj = json.load(open(pmc))
-                # the instantiation bench.py runs: <packed nt, strand planes>; dense strand counts are switched off above
-                key = dom + ("<false, false>" if args.nt_bytes else "<true, false>") if dom == "lfq_count_kernel" else dom
-                traffic = tj.get(key)
-            except Exception:
-                traffic = None
+        # Dominant kernel = the one with the largest duration per step: the count kernel (one launch, HBM-bound).
+        # The DP kernels run concurrently on three streams; their span is the `dp` block below.
+        count_name = "lfq_count_kernel<%s, false>" % ("false" if args.nt_bytes else "true")
+        if depth < 4096:
+            count_name = "lfq_count_multi_kernel<%s, false>" % ("false" if args.nt_bytes else "true")
+        dom_ms = kt["ms_count"] / n_launch
+        moved = (work["bytes_read_count"] + work["bytes_written_count"]) / n_launch     # layout bytes, this launch
+        alg_bytes = my_cols * (4.0 * depth + 80.0) / n_launch
+        achieved = moved / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        pmc = None
+        if world == 1 and not args.no_pmc:
+            child = ["--config", args.config, "--plant-period", str(args.plant_period)]
+            if args.depth:
+                child += ["--depth", str(args.depth)]
+            if args.cols:
+                child += ["--cols", str(args.cols)]
+            if args.nt_bytes:
+                child += ["--nt-bytes"]
+            pmc = live_pmc(child, count_name)
+        traffic = pmc["traffic"] if pmc else None
+        dp_ms = kt["ms_dp"]
+        valu_busy = None
+        if pmc and pmc.get("valu_insts_dp") and dp_ms > 0:
+            # wave-instructions issued by the DP kernels / what 1024 SIMDs can issue in the DP span (one VALU
+            # wave-instruction occupies its SIMD for 4 cycles)
+            valu_busy = pmc["valu_insts_dp"] / (N_SIMD * CLK_HZ / 4.0 * dp_ms * 1e-3)
         line = {
             "metric": "pileup columns/sec at depth %d" % depth,
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "C3: synthetic 1 Mb genome per GPU, uniform %dx depth, SNV-only, "
-                            "--no-default-filter, dynamic Bonferroni (BASELINE.json configs[2])" % depth,
-                "columns_per_gpu": ncols, "depth": depth, "planted_snv_period": args.plant_period,
+                "workload": "%s: synthetic %.0f Mb genome per GPU, uniform %dx depth, SNV-only, %s, dynamic Bonferroni "
+                            "(BASELINE.json configs[%d])"
+                            % (args.config, ncols / 1e6, depth,
+                               "default filter applied" if cfg_filter else "--no-default-filter", cfg_idx),
+                "columns_per_gpu": my_cols, "depth": depth, "planted_snv_period": args.plant_period,
                 "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
-                "pipeline_depth": 2 if pipelined else 1,
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
+                "host_ms_per_step": ms_per_step - kt["ms_total"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": count_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                # frac prices SURVEY 8(d)'s 4 bytes per observation; the kernel only has to READ 2 of them, so
-                # frac can exceed 1.  traffic_frac is the real HBM utilisation: measured bytes / duration / peak.
+                "bytes_per_launch": moved,
+                "bytes_note": "bytes this instantiation moves by layout: observations x (0.5 nt + 1 bq) + 9 B header in, "
+                              "64 B record + 1 B class flag out per column; reported by the library per batch",
+                "avg_launch_ms": dom_ms,
                 "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and dom_ms > 0 else None,
-                "count_kernel": {
-                    "avg_launch_ms": kt["ms_count"] / n_launch,
-                    "achieved": alg_bytes / (kt["ms_count"] / n_launch * 1e-3) / 1e9 if kt["ms_count"] > 0 else 0.0,
-                    "note": "streaming kernel; reads only the nt+bq tracks (1.5 of the 4 algorithmic bytes per "
-                            "observation with the packed nt layout, 2 with bytes) in the default filter configuration"},
+                "traffic_over_layout_bytes": (traffic / moved) if traffic and moved else None,
+                "frac_of_measured_copy_peak": achieved / 6290.0,
+                "pmc": {k: pmc[k] for k in ("fetch_kib", "write_kib", "source")} if pmc else None,
+                "algorithmic_8d": {"bytes_per_launch": alg_bytes, "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
+                                   "note": "SURVEY 8(d): 4*depth+80 B per column; the default filter configuration needs only the "
+                                           "nt and bq tracks for the counts, so this ratio to peak can exceed 1"},
+            },
+            "dp": {
+                "cells": work["cells"], "rows": work["rows"], "span_ms": dp_ms,
+                "cells_per_s": work["cells"] / (dp_ms * 1e-3) if dp_ms > 0 else None,
+                "valu_busy": valu_busy,
+                "valu_insts_per_step": pmc.get("valu_insts_dp") if pmc else None,
+                "valu_by_kernel": pmc.get("valu_by_kernel") if pmc else None,
+                "columns": {"light": work["n_light"], "mid": work["n_mid"], "big": work["n_big"],
+                            "light_finished_by_retry_kernel": work["n_light_retry"]},
+                "note": "cells = sum over tested columns of sum_{n<=N*} min(n, K), N* = this implementation's pruning row "
+                        "(track order); device counters of the last step.  span = last count kernel's end -> all DP kernels done",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = min(args.cpu_sample_cols, ncols)
-            base, ores = cpu_baseline(depth, args.plant_period, sample)
+            sample = min(args.cpu_sample_cols or cfg_sample, my_cols)
+            base, ores = cpu_baseline(seed, depth, args.plant_period, sample, cfg_filter)
             line["cpu_baseline"] = base
             # VCF concordance on the sample: same records, same QUAL, from the full GPU run
             exp = [(c, int(ores["qual"][c, a])) for c in range(sample) for a in range(3) if ores["emitted"][c, a]]
@@ -236,6 +552,17 @@ def main():
             line["config"]["vcf_concordance"] = {"sample_columns": sample, "reference_records": len(exp),
                                                  "gpu_records": len(got), "identical": exp == got}
             line["config"]["speedup_vs_cpu_1thread"] = value / base["value"]
+        if world == 1 and not args.no_secondary:
+            sec = {}
+            try:
+                sec["host_abi"] = bench_host_abi(caller, la, seed_of(2), 1000, 200000, args.plant_period, 5)
+            except Exception as e:      # secondary figures never take the headline down
+                sec["host_abi"] = {"error": repr(e)}
+            try:
+                sec["chain"] = bench_chain(caller, la, 2000000, 1000000, 2)
+            except Exception as e:
+                sec["chain"] = {"error": repr(e)}
+            line["config"]["secondary"] = sec
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -470,6 +470,22 @@ typedef struct lfq_kernel_times {
 } lfq_kernel_times;
 int lfq_last_kernel_times(lfq_ctx *ctx, lfq_kernel_times *t);
 
+/* --- DP work of the last batch (device counters; SURVEY 8d "ALGORITHMIC DP work", the secondary roofline) ---
+ * cells = sum over the tested columns of sum_{n = 1..N*} min(n, K): N* = the kept row at which this implementation's
+ * pruning test fired (track order; the reference sorts its probabilities ascending and therefore prunes LATER, so
+ * its own cell count for the same columns is larger), or the column's end.  Columns finished by the underflow
+ * shortcut count only the rows their remaining recurrence ran.  A light column that the screen kernel hands to the
+ * retry kernel is counted in both (the work was done twice). */
+typedef struct lfq_dp_work {
+    int64_t cells;             /* recurrence cells processed */
+    int64_t rows;              /* kept rows processed */
+    int64_t n_light, n_mid, n_big;   /* tested columns per scheduling class */
+    int64_t n_light_retry;     /* light columns finished by the one-column-per-wavefront kernel */
+    int64_t bytes_read_count;  /* track + header bytes the count kernel instantiation of this batch reads (layout bytes) */
+    int64_t bytes_written_count; /* dense records + class flags it writes */
+} lfq_dp_work;
+int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);
+
 #ifdef __cplusplus
 }
 #endif

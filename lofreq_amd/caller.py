@@ -69,10 +69,10 @@ class PileupBatch:
             mqs.append(np.asarray(c["mq"]).astype(np.uint8))
             if has_baq:
                 b = np.asarray(c["baq"] if c.get("baq") is not None else np.full(n, -1))
-                baqs.append(np.where(b < 0, 255, b).astype(np.uint8))
+                baqs.append(np.where(b < 0, 255, np.minimum(b, 254)).astype(np.uint8))   # clamp like the C shim
             if has_sq:
                 s = np.asarray(c["sq"] if c.get("sq") is not None else np.full(n, -1))
-                sqs.append(np.where(s < 0, 255, s).astype(np.uint8))
+                sqs.append(np.where(s < 0, 255, np.minimum(s, 254)).astype(np.uint8))
             off.append(off[-1] + n)
         cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
         rb = np.frombuffer(bytes(ref_bases), dtype=np.uint8) if isinstance(ref_bases, (bytes, bytearray, str)) \
@@ -205,6 +205,12 @@ class SnvCaller:
         _lib.check(self.L.lfq_last_kernel_times(self.h, C.byref(kt)))
         return {k: getattr(kt, k) for k, _ in kt._fields_}
 
+    def dp_work(self):
+        """lfq_last_dp_work: DP cells / rows the kernels of the last batch processed, class sizes, layout bytes"""
+        w = _lib.DpWork()
+        _lib.check(self.L.lfq_last_dp_work(self.h, C.byref(w)))
+        return {k: int(getattr(w, k)) for k, _ in w._fields_}
+
     def synchronize(self):
         _lib.check(self.L.lfq_synchronize(self.h))
 
@@ -288,11 +294,14 @@ def format_vcf(records, chrom, pos0=None, keep=None, filter_str=None):
         return ""
     p = None if pos0 is None else np.ascontiguousarray(pos0, dtype=np.int64)
     k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
-    buf = C.create_string_buffer(160 * len(r) + 64 * (len(chrom) + 1))
-    n = _lib.load().lfq_format_vcf(buf, len(buf), chrom.encode(), C.c_void_p(p.ctypes.data) if p is not None else None,
-                                   C.c_void_p(r.ctypes.data), len(r),
-                                   C.c_void_p(k.ctypes.data) if k is not None else None,
-                                   filter_str.encode() if filter_str else None)
+    args = (chrom.encode(), C.c_void_p(p.ctypes.data) if p is not None else None, C.c_void_p(r.ctypes.data), len(r),
+            C.c_void_p(k.ctypes.data) if k is not None else None, filter_str.encode() if filter_str else None)
+    L = _lib.load()
+    buf = C.create_string_buffer((len(chrom) + 128) * len(r) + 64)     # a line is about len(chrom) + 95 bytes
+    n = L.lfq_format_vcf(buf, len(buf), *args)
+    if n > len(buf):                             # the C call returns the size it needs: allocate that and repeat
+        buf = C.create_string_buffer(int(n) + 1)
+        n = L.lfq_format_vcf(buf, len(buf), *args)
     if n < 0 or n > len(buf):
         raise RuntimeError("lfq_format_vcf failed (%d)" % n)
     return buf.raw[:n].decode()

@@ -46,7 +46,7 @@ static inline double lfq_now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-static const bool lfq_timing_on = getenv("LFQ_TIMING") != nullptr;
+#define lfq_timing_on (lfq_knobs().timing != 0)
 
 /* per-read host loops of the read-set steps (geometry from the CIGARs, event candidates): independent reads, split
  * over a few threads when there are enough of them.  f(begin, end, part) */
@@ -56,12 +56,7 @@ static void lfq_for_reads(int64_t n, F f, int *parts_out = nullptr)
     int parts = 1;
     if (n >= 200000) {
         unsigned hw = std::thread::hardware_concurrency();
-        if (const char *e = getenv("LOCAL_WORLD_SIZE")) {
-            const int lws = atoi(e);
-            if (lws > 1) {
-                hw = std::max(1u, hw / (unsigned)lws);
-            }
-        }
+        hw = std::max(1u, hw / (unsigned)lfq_knobs().local_world_size);
         parts = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), n / 100000);
         parts = std::max(parts, 1);
     }
@@ -135,6 +130,10 @@ struct lfq_ctx {
     int64_t cur_ncols;
     hipEvent_t ev[4];
     lfq_kernel_times times;
+    lfq_dp_work work;
+    int64_t cur_count_read, cur_count_written;   /* layout bytes of this batch's count kernel (lfq_dp_work) */
+    const uint64_t *cur_col_off;                 /* device: CSR offsets of the batch in flight */
+    int cur_obs_bytes_x2, cur_col_bytes;
     int n_cu;
     /* strand-bias precompute (lfq_internal.h): DP4 tuples land in host-mapped memory right after the scan;
      * a leader thread waits for that and runs the Fisher tests on the host pool while the DP kernels run */
@@ -247,14 +246,8 @@ int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bool i
     P->prune_slack = 1e-6;
     P->bonf_step = 3;
     P->bonf_reset_first = 1;
-    P->phase1_chunks = LFQ_PHASE1_CHUNKS;
-    if (const char *e = getenv("LFQ_PHASE1_CHUNKS")) {
-        P->phase1_chunks = std::max(1, atoi(e));
-    }
-    P->seg_max = LFQ_SEG_MAX;
-    if (const char *e = getenv("LFQ_SEG_MAX")) {                 /* experiments: fewer, longer row segments */
-        P->seg_max = std::min(LFQ_SEG_MAX, std::max(2, atoi(e)));
-    }
+    P->phase1_chunks = lfq_knobs().phase1_chunks;
+    P->seg_max = lfq_knobs().seg_max;                            /* experiments: fewer, longer row segments */
     if (indel_mode) {
         /* call_indels: no base / merged-quality filters, every event is a test (lofreq_call.c:684-725);
          * the alignment-quality track is "used" wherever the packer filled it in */
@@ -376,8 +369,8 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
     /* counter blocks: one per segment + one batch-wide */
     ok = ok && hipMalloc((void **)&c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
-                             hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t) + 16,
+                             hipHostMallocDefault) == hipSuccess;      /* + first / last CSR offset (lfq_batch_finish) */
     for (int i = 0; ok && i < 4; i++) {
         ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     }
@@ -398,7 +391,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
             ok = hipEventCreate(&c->ev_side[i][s][0]) == hipSuccess && hipEventCreate(&c->ev_side[i][s][1]) == hipSuccess;
         }
     }
-    if (ok && !getenv("LFQ_NO_SB_PRECOMPUTE")) {
+    if (ok && !lfq_knobs().no_sb_precompute) {
         c->heavy_cap = 1 << 16;
         ok = hipHostMalloc((void **)&c->h_tuples, (size_t)c->heavy_cap * 3 * 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess
              && hipHostMalloc((void **)&c->h_nheavy, 64, hipHostMallocMapped) == hipSuccess
@@ -516,7 +509,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
     /* LFQ_SINGLE_STREAM: every kernel on the caller's stream, in dependency order (counter collection with
      * rocprofv3 --pmc serialises dispatches and does not get along with the cross-stream waits) */
-    const bool single_stream = getenv("LFQ_SINGLE_STREAM") != nullptr;
+    const LfqKnobs &kn = lfq_knobs();
+    const bool single_stream = kn.single_stream != 0;
     hipStream_t dps = single_stream ? st : c->dps;
     hipStream_t side0 = single_stream ? st : c->side[0], side1 = single_stream ? st : c->side[1];
     hipStream_t side_i[2] = {side0, side1};
@@ -547,6 +541,16 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     c->cur_pvals_cap = pvals_capacity;
     c->cur_ncols = ncols;
     c->cur_segments = 0;
+    c->cur_col_off = tr->col_off;
+    /* layout bytes per observation / per column of the count kernel instantiation this batch runs (lfq_dp_work) */
+    c->cur_obs_bytes_x2 = (T.nt_packed ? 1 : 2) + 2;                       /* nt + bq, in half bytes */
+    if (P.general) {
+        c->cur_obs_bytes_x2 += 2 * ((T.baq ? 1 : 0) + 1 + (T.sq ? 1 : 0)); /* + baq, mq, sq: full evaluation */
+        if (P.def_alt_bq == -1) {
+            c->cur_obs_bytes_x2 += (T.nt_packed ? 1 : 2) + 2;              /* median pass reads nt + bq once more */
+        }
+    }
+    c->cur_col_bytes = 8 + 1 + (T.coverage_plp ? 4 : 0) + (T.num_bases ? 4 : 0) + (P.detlim_af ? 4 : 0);
     LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
     if (ncols > 0) {
         LFQ_TRY_HIP(hipMemsetAsync(c->d_retry, 0, (size_t)ncols, st));
@@ -577,10 +581,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         /* row-split bookkeeping: 64 Ki column records, 8 Mi segment cells (128 MiB); a column that does not
          * get its cells simply runs unsplit */
         c->long_cap = 1 << 16;
-        c->pool_cells = 8 << 20;
-        if (const char *e = getenv("LFQ_SPLIT_POOL_CELLS")) {
-            c->pool_cells = std::max(0, atoi(e));               /* 0 disables row splitting */
-        }
+        c->pool_cells = kn.split_pool_cells;                    /* 0 disables row splitting */
         LFQ_TRY_HIP(hipMalloc((void **)&c->d_longs, (size_t)c->long_cap * sizeof(LfqLong)));
         LFQ_TRY_HIP(hipMalloc((void **)&c->d_pool, (size_t)std::max(c->pool_cells, 1) * sizeof(LfqSegCell)));
         LFQ_TRY_HIP(hipEventCreateWithFlags(&c->ev_segw, hipEventDisableTiming));
@@ -594,11 +595,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
      * prefix is carried from segment to segment on the device (LFQ_GC_TESTED). */
     int n_seg = 1;   /* measured on C3: with the current kernels overlapping count and DP loses (both want wave slots
                       * and VALU issue); kept switchable for experiments via LFQ_SEGMENTS */
-    if (const char *e = getenv("LFQ_SEGMENTS")) {
-        n_seg = std::min(LFQ_MAX_SEGMENTS, std::max(1, atoi(e)));
-    }
+    n_seg = kn.segments;
     c->cur_segments = n_seg;
-    const char *skip = getenv("LFQ_DEBUG_SKIP");   /* profiling aid: run the DP classes in isolation */
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], st));
     LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_join[2], 0));   /* dps starts after the memset */
 
@@ -623,7 +621,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_cnt[s][1], 0));
         LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, dps));
         LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], dps));
-        if (n_seg == 1 && !indel_mode && c->leader && !getenv("LFQ_NO_SB_PRECOMPUTE")) {
+        if (n_seg == 1 && !indel_mode && c->leader && !kn.no_sb_precompute) {
             /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start now */
             if (P.lazy_strand) {        /* the count kernel left the strands out: count them for the heavy columns here */
                 LFQ_TRY(lfq_launch_strand_heavy(T, W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
@@ -641,14 +639,11 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
          * latency-bound kernels of the long columns, or they only start when it ends */
-        int light_waves_per_cu = 10;
-        if (const char *e = getenv("LFQ_LIGHT_WAVES_PER_CU")) {
-            light_waves_per_cu = std::max(4, atoi(e));
-        }
+        const int light_waves_per_cu = kn.light_kernel == 0 ? kn.screen_waves_per_cu : kn.light_waves_per_cu;
         const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * light_waves_per_cu, std::max<int64_t>(seg_cols / 8, 4));
         const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(seg_cols, 4));
-        const bool run_big = !skip || !strstr(skip, "big"), run_mid = !skip || !strstr(skip, "mid");
-        const bool dbg_sync = getenv("LFQ_DEBUG_SYNC") != nullptr;    /* debugging aid: serialize and name the stages */
+        const bool run_big = !kn.skip_big, run_mid = !kn.skip_mid;     /* profiling aid: run the DP classes in isolation */
+        const bool dbg_sync = kn.debug_sync != 0;                      /* debugging aid: serialize and name the stages */
 #define LFQ_DBG_STAGE(name)                                                        \
     do {                                                                           \
         if (dbg_sync) {                                                            \
@@ -693,9 +688,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
             LFQ_DBG_STAGE("combine mid");
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], dps));
-        if (!skip || !strstr(skip, "light")) {
-            const char *lk = getenv("LFQ_LIGHT_KERNEL");
-            if (lk && !strcmp(lk, "wave")) {            /* A/B switch: the one-column-per-wavefront kernel */
+        if (!kn.skip_light) {
+            if (kn.light_kernel == 2) {                 /* A/B switch: the one-column-per-wavefront kernel */
                 LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, dps));
             } else {
                 LFQ_TRY(lfq_launch_dp_quad(T, P, c->d_luts, d_counts, W, c->d_retry + c0, d_pvals, pvals_capacity,
@@ -767,7 +761,16 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
     hipStream_t st = c->cur_stream ? c->cur_stream : c->stream;
     LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
                                hipMemcpyDeviceToHost, st));
+    uint64_t *h_ends = reinterpret_cast<uint64_t *>(c->h_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS);
+    h_ends[0] = h_ends[1] = 0;
+    if (c->cur_col_off && c->cur_ncols > 0) {       /* first and last CSR offset: the batch's observation count */
+        LFQ_TRY_HIP(hipMemcpyAsync(h_ends, c->cur_col_off, 8, hipMemcpyDeviceToHost, st));
+        LFQ_TRY_HIP(hipMemcpyAsync(h_ends + 1, c->cur_col_off + c->cur_ncols, 8, hipMemcpyDeviceToHost, st));
+    }
     LFQ_TRY_HIP(hipStreamSynchronize(st));
+    const int64_t batch_obs = (int64_t)(h_ends[1] - h_ends[0]);
+    c->cur_count_read = batch_obs * c->cur_obs_bytes_x2 / 2 + c->cur_ncols * c->cur_col_bytes;
+    c->cur_count_written = c->cur_ncols * (int64_t)(sizeof(lfq_col_counts) + 1);
     const int32_t *g = c->h_counters + LFQ_MAX_SEGMENTS * LFQ_NCOUNTERS;
     memset(&c->times, 0, sizeof(c->times));
     float ms = 0.f;
@@ -785,10 +788,22 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
         c->times.ms_dp = dp_end;
     }
     c->times.n_segments = c->cur_segments;
+    memset(&c->work, 0, sizeof(c->work));
+    memcpy(&c->work.cells, g + LFQ_GC_CELLS, 8);
+    memcpy(&c->work.rows, g + LFQ_GC_ROWS, 8);
+    c->work.n_light_retry = g[LFQ_GC_SCREEN_RETRY];
+    for (int s = 0; s < c->cur_segments; s++) {
+        const int32_t *sc = c->h_counters + s * LFQ_NCOUNTERS;
+        c->work.n_light += sc[LFQ_CNT_LIGHT];
+        c->work.n_mid += sc[LFQ_CNT_MID];
+        c->work.n_big += sc[LFQ_CNT_BIG];
+    }
+    c->work.bytes_read_count = c->cur_count_read;
+    c->work.bytes_written_count = c->cur_count_written;
     if (stats) {
         stats->n_tested = g[LFQ_GC_TESTED];
         stats->n_pvals = std::min<int64_t>(g[LFQ_GC_PVALS], c->cur_pvals_cap);
-        stats->n_obs = 0;
+        stats->n_obs = batch_obs;
     }
     if (g[LFQ_GC_OVERFLOW]) {
         return LFQ_ERR_CAPACITY;
@@ -803,6 +818,15 @@ int lfq_debug_counters(lfq_ctx *c, int32_t *out16)
         return LFQ_ERR_INVALID;
     }
     memcpy(out16, c->h_counters, 16 * sizeof(int32_t));   /* segment 0 */
+    return LFQ_OK;
+}
+
+int lfq_last_dp_work(lfq_ctx *c, lfq_dp_work *w)
+{
+    if (!c || !w) {
+        return LFQ_ERR_INVALID;
+    }
+    *w = c->work;
     return LFQ_OK;
 }
 
@@ -937,7 +961,6 @@ int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, i
         }
         conf->num_snv_tests += 3 * st.n_tested;
     }
-    st.n_obs = 0;
     if (stats_out) {
         *stats_out = st;
     }
@@ -1121,7 +1144,7 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
     const uint64_t flush_obs = 256u << 20;            /* pseudo-column bytes per track per device batch */
     /* columns that came out of lfq_readset_pileup_indels on this context still have their quality arrays in HBM:
      * the pseudo-columns are then built by lfq_indel_pack_kernel instead of on the host */
-    const bool dev_pack = c->plp_indel && b == &c->plp_indel->cols && c->d_plp_ne && !getenv("LFQ_INDEL_HOST_PACK");
+    const bool dev_pack = c->plp_indel && b == &c->plp_indel->cols && c->d_plp_ne && !lfq_knobs().indel_host_pack;
     for (int sd = 0; sd < 2 && !dev_pack; sd++) {
         if (b->ncols > 0 && b->side[sd].ne_off[b->ncols] > 0 && !b->side[sd].ne_q) {
             return LFQ_ERR_INVALID;         /* device-only columns that are no longer the context's current ones */
@@ -1460,7 +1483,7 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
     if (rs->pmax_state == 0) {
         rs->pmax_state = 2;
         const int64_t n = rs->n;
-        bool sorted = getenv("LFQ_PILEUP_ATOMIC") == nullptr;
+        bool sorted = !lfq_knobs().pileup_atomic;
         for (int64_t r = 1; sorted && r < n; r++) {
             sorted = rs->pos[r] >= rs->pos[r - 1];
         }
@@ -1624,7 +1647,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         max_w = std::max(max_w, part_w[p]);
     }
     /* narrow-band reads (rows of at most LFQ_BAQ_LDS_CELLS cells) first: they run in the LDS variant */
-    static const bool use_lds = !(getenv("LFQ_BAQ_LDS") && atoi(getenv("LFQ_BAQ_LDS")) == 0);
+    const bool use_lds = lfq_knobs().baq_lds != 0;
     std::vector<int32_t> order((size_t)n);
     int64_t n_narrow = 0;
     int max_lref_narrow = 0;
@@ -1702,8 +1725,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         int64_t budget_b = std::min<int64_t>((int64_t)32 << 30, (int64_t)(free_b / 2));
-        if (const char *e = getenv("LFQ_BAQ_SCRATCH_MB")) {
-            budget_b = (int64_t)atol(e) << 20;
+        if (lfq_knobs().baq_scratch_mb >= 0) {
+            budget_b = (int64_t)lfq_knobs().baq_scratch_mb << 20;
         }
         int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, budget_b / per_wave));
         auto keep = [&](auto **slot, int64_t *have, int64_t need) {

@@ -87,6 +87,21 @@ __device__ __forceinline__ LfqEntry lfq_load_entry(const LfqEntry *list, int i)
     return e;
 }
 
+/* ---- DP work accounting (SURVEY 8d secondary figure) -----------------------------------------------
+ * cells(column) = sum over the kept rows n = 1..N* of min(n, K), N* = the row this implementation stopped at.
+ * Batch-wide uint64 counters next to the sparse-output counter; read back by lfq_batch_finish. */
+__device__ __forceinline__ unsigned long long lfq_cells_of(long long n, long long K)
+{
+    return (unsigned long long)((n <= K) ? n * (n + 1) / 2 : K * (K + 1) / 2 + (n - K) * K);
+}
+
+/* one lane adds a column's work */
+__device__ __forceinline__ void lfq_account(const LfqWork &W, long long rows, long long K)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(W.gcounters + LFQ_GC_CELLS), lfq_cells_of(rows, K));
+    atomicAdd(reinterpret_cast<unsigned long long *>(W.gcounters + LFQ_GC_ROWS), (unsigned long long)rows);
+}
+
 /* the packed bytes of one observation per lane (chunk `ch` of the column); 0xffffffff = past the end */
 struct LfqRaw {
     uint32_t w;      /* nt | bq << 8 | baq << 16 | mq << 24 */
@@ -807,6 +822,9 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
 #ifdef LFQ_TRACE
     if (lane == 0) printf("col %d K %d C %d: rows done pruned=%d n_rows=%d\n", cx.col, K, C, (int)pruned, n_rows);
 #endif
+    if (lane == 0) {
+        lfq_account(W, n_rows, K);
+    }
     if (!pruned && !lfq_strip_final_prune<C>(S, lt, cx.bonf_d, cx.sig_s)) {
 #ifdef LFQ_TRACE
         if (lane == 0) printf("col %d: emitting\n", cx.col);
@@ -1169,6 +1187,191 @@ __global__ __launch_bounds__(256) void lfq_dp_retry_kernel(LfqTracksDev T, LfqPa
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* light columns, one per LANE: the screen kernel                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A light column is decided by its first few dozen rows: a handful of mismatches, and a tail probability that
+ * crosses the pruning threshold sig / bonf as soon as a couple of low-quality reads have gone by (C3: 21 rows on
+ * average, 99.9 % within 250).  That is far too little work per column for cells-across-lanes -- the lane-group
+ * kernels above spend their time waiting for one dependent byte gather per 8 rows -- so here ONE LANE owns one
+ * column: its K + 1 <= KREG cells live in registers (cell k at register KREG - 1 - K + k, i.e. the absorbing tail
+ * always in the last register and the registers below cell 0 hold zeros that stay zero, so every lane runs the
+ * same KREG - 1 FMAs whatever its K), and it reads its column 16 observations at a time with one 16-byte load per
+ * track (8 bytes of the packed nt track) from the 16-aligned window around the column start.  No neighbour
+ * exchange, no LDS rows, no renormalisation (plain doubles: a few hundred rows of factors >= 1e-10 at K <= 31 stay
+ * far inside the double range, and a cell that did underflow would only make the tail larger, which errs towards
+ * pruning LATER, never earlier... see the bound below), 64 columns per wavefront in lock step.
+ *
+ * The kernel only PRUNES (like the lane-group kernels): a lane whose tail * bonf exceeds sig * (1 + slack) drops its
+ * column -- the reference's own early exit (snpcaller.c:950), monotone in the rows, so order does not matter --
+ * and takes the next one of its wavefront's slice of the light list.  Columns that are still alive after
+ * `max_rounds` windows or at their end, and columns with K >= KREG, are flagged in `retry` for
+ * lfq_dp_retry_kernel (whole wavefront, emission).  Underflow cannot cause a false prune: cells only lose mass by
+ * rounding to zero, the tail is a sum of products of cells and probabilities, so the computed tail is never above
+ * the exact one by more than rounding (1e-16 relative per operation), which the slack of 1e-6 covers. */
+template <int KREG>
+__device__ __forceinline__ void lfq_screen_row(double (&v)[KREG], double p, double q)
+{
+    v[KREG - 1] = fma(v[KREG - 2], p, v[KREG - 1]);         /* absorbing tail: P(X >= K) */
+#pragma unroll
+    for (int j = KREG - 2; j >= 1; j--) {
+        v[j] = fma(v[j - 1], p, v[j] * q);
+    }
+    v[0] = v[0] * q;
+}
+
+#define LFQ_SCREEN_BYTE(w4, j) \
+    (((((j) >> 2) == 0 ? (w4).x : ((j) >> 2) == 1 ? (w4).y : ((j) >> 2) == 2 ? (w4).z : (w4).w) >> (8 * ((j) & 3))) & 0xffu)
+
+template <int KREG>
+__global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqParams P,
+                                                            const LfqLuts *__restrict__ g_luts, LfqWork W,
+                                                            uint8_t *__restrict__ retry, int max_rounds, int force_gl)
+{
+    constexpr int MAXK = KREG - 1;
+    __shared__ LfqLuts s_luts;
+    if (force_gl ? (force_gl != KREG) : (lfq_light_group_lanes(W) != KREG)) {
+        return;                                     /* another variant serves this batch */
+    }
+    {
+        const double *src = reinterpret_cast<const double *>(g_luts);
+        double *dst = reinterpret_cast<double *>(&s_luts);
+        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
+            dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const int lane = lfq_lane();
+    const int n_work = W.counters[LFQ_CNT_LIGHT];
+    const LfqEntry *list = W.entries;               /* the light class leads the work list */
+    const double sig_s = P.sig * (1.0 + P.prune_slack);
+    /* static slice of the light list per wavefront: no claims (one returning atomic per refill would saturate a
+     * single counter: ~88 dequeues per microsecond), consecutive entries = coalesced record loads */
+    const int n_waves = (int)gridDim.x * 4;
+    const int wv = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    int q_next = (int)((int64_t)n_work * wv / n_waves);
+    const int q_end = (int)((int64_t)n_work * (wv + 1) / n_waves);
+
+    bool active = false;
+    uint64_t off0 = 0;
+    int n_obs = 0, rel = 0, K = 0, ref_code = 0, med = 0, rounds = 0, list_idx = 0, n_kept = 0;
+    double bonf_d = 1.0;
+    double v[KREG];
+    unsigned long long acc_cells = 0, acc_rows = 0;
+    int n_retry = 0;
+
+    for (;;) {
+        /* ---- lanes without a column take the next entries of the slice ---- */
+        const uint64_t need = __ballot(!active);
+        if (need != 0ull && q_next < q_end) {
+            const int idx = q_next + __popcll(need & ((1ull << lane) - 1ull));
+            q_next += __popcll(need);
+            if (!active && idx < q_end) {
+                const uint4 *ep = reinterpret_cast<const uint4 *>(list + idx);
+                const uint4 a = ep[0], b = ep[1];
+                K = (int)b.y;
+                if (K > MAXK) {
+                    retry[idx] = 1;                 /* needs more cells than this variant keeps in registers */
+                    n_retry++;
+                } else {
+                    active = true;
+                    off0 = ((uint64_t)a.y << 32) | a.x;
+                    n_obs = (int)a.z;
+                    int64_t bonf = P.bonf_base;
+                    if (P.bonf_dynamic) {           /* lfq_col_setup */
+                        bonf = ((P.bonf_reset_first && P.bonf_base == 1) ? 0 : P.bonf_base)
+                               + (int64_t)P.bonf_step * (int)b.x;
+                    }
+                    bonf_d = (double)bonf;
+                    med = (int)(int16_t)(b.z & 0xffffu);
+                    ref_code = (int)((b.z >> 16) & 0xffu);
+                    rel = -(int)(off0 & 15u);       /* window start relative to the column start */
+                    rounds = 0;
+                    n_kept = 0;
+                    list_idx = idx;
+#pragma unroll
+                    for (int j = 0; j < KREG; j++) {
+                        v[j] = (j == MAXK - K) ? 1.0 : 0.0;
+                    }
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (q_next >= q_end) {
+                break;
+            }
+            continue;                               /* every taken entry went to retry: take more */
+        }
+
+        /* ---- this lane's window: 16 observations, one load per track ---- */
+        uint4 bqw = make_uint4(0, 0, 0, 0), baqw = make_uint4(~0u, ~0u, ~0u, ~0u), mqw = make_uint4(0, 0, 0, 0);
+        uint4 sqw = make_uint4(~0u, ~0u, ~0u, ~0u), ntw = make_uint4(0, 0, 0, 0);
+        if (active) {
+            const uint64_t wbase = (uint64_t)((int64_t)off0 + rel);        /* multiple of 16 */
+            bqw = *reinterpret_cast<const uint4 *>(T.bq + wbase);
+            mqw = *reinterpret_cast<const uint4 *>(T.mq + wbase);
+            if (T.baq) {
+                baqw = *reinterpret_cast<const uint4 *>(T.baq + wbase);
+            }
+            if (T.sq) {
+                sqw = *reinterpret_cast<const uint4 *>(T.sq + wbase);
+            }
+            if (T.nt_packed) {
+                const uint2 n2 = *reinterpret_cast<const uint2 *>(T.nt + (wbase >> 1));
+                ntw.x = n2.x;
+                ntw.y = n2.y;
+            } else {
+                ntw = *reinterpret_cast<const uint4 *>(T.nt + wbase);
+            }
+        }
+        /* ---- 16 rows ---- */
+        const bool packed = T.nt_packed != 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            /* packed layout: observation j of the window sits in dword j / 8, byte j % 4, nibble (j % 8) / 4 (lfq_nt_at) */
+            const uint32_t nib = (((j >> 3) ? ntw.y : ntw.x) >> (8 * (j & 3) + 4 * ((j & 7) >> 2))) & 15u;
+            const uint32_t ntb = packed ? nib : LFQ_SCREEN_BYTE(ntw, j);
+            const LfqObs o = lfq_eval_obs(ntb, LFQ_SCREEN_BYTE(bqw, j), LFQ_SCREEN_BYTE(baqw, j), LFQ_SCREEN_BYTE(mqw, j),
+                                          LFQ_SCREEN_BYTE(sqw, j), ref_code, med, P, &s_luts);
+            const bool keep = active && o.keep && (unsigned)(rel + j) < (unsigned)n_obs;
+            const double ps = (fabs(o.p) < LFQ_DBL_EPS) ? LFQ_DBL_EPS : o.p;                       /* lfq_eval_raw */
+            const double qf = (fabs(o.p - 1.0) < LFQ_DBL_EPS) ? 1.0 + (-o.p + LFQ_DBL_EPS) : 1.0 - o.p;
+            lfq_screen_row<KREG>(v, keep ? ps : 0.0, keep ? qf : 1.0);
+            n_kept += keep ? 1 : 0;
+        }
+        rel += 16;
+        rounds += 1;
+        if (active) {
+            const bool pruned = v[KREG - 1] * bonf_d > sig_s;
+            const bool give_up = !pruned && (rel >= n_obs || rounds >= max_rounds);
+            if (pruned || give_up) {
+                active = false;
+                acc_cells += lfq_cells_of(n_kept, K);
+                acc_rows += (unsigned long long)n_kept;
+                if (give_up) {
+                    retry[list_idx] = 1;            /* survivor: the whole-wavefront kernel finishes (and emits) it */
+                    n_retry++;
+                }
+            }
+        }
+    }
+    /* work accounting: one set of atomics per wavefront */
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        acc_cells += __shfl_xor(acc_cells, d, 64);
+        acc_rows += __shfl_xor(acc_rows, d, 64);
+        n_retry += __shfl_xor(n_retry, d, 64);
+    }
+    if (lane == 0 && acc_rows) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(W.gcounters + LFQ_GC_CELLS), acc_cells);
+        atomicAdd(reinterpret_cast<unsigned long long *>(W.gcounters + LFQ_GC_ROWS), acc_rows);
+    }
+    if (lane == 0 && n_retry) {
+        atomicAdd(&W.gcounters[LFQ_GC_SCREEN_RETRY], n_retry);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* big columns: K >= 250, one 8-wave workgroup per column                                     */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -1372,6 +1575,9 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
         }
         __threadfence_block();
         __syncthreads();
+    }
+    if (w == ((n_strips - 1) % NW) && lane == 0) {
+        lfq_account(W, rows_tail, K);
     }
     if ((!pruned || uf_mask) && w == ((n_strips - 1) % NW)) {
         /* the wave that owned the tail strip finishes the column */
@@ -1756,6 +1962,9 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
             rows_total += f & 0x3fffffff;
             pruned = pruned || (f & 0x40000000) != 0;
         }
+        if (tid == 0) {
+            lfq_account(W, rows_total, K);
+        }
         if (!pruned) {
             const LfqSegCell *seg = W.pool + R.cell0;
             for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
@@ -2080,15 +2289,19 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
     }
     const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    int force = 0;                                   /* A/B: LFQ_QUAD_LANES = 8, 16, 32 or 64 */
-    if (const char *e = getenv("LFQ_QUAD_LANES")) {
-        force = atoi(e);
-    }
-    /* one of the four serves the batch (lfq_light_group_lanes, decided on the device from the K histogram of
+    const LfqKnobs &kn = lfq_knobs();
+    const int force = kn.light_lanes;                /* A/B: LFQ_QUAD_LANES = 8, 16, 32 or 64 */
+    /* one of the variants serves the batch (lfq_light_group_lanes, decided on the device from the K histogram of
      * the scan); the others return at once */
-    hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, 64, force);
-    hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, 32, force);
-    hipLaunchKernelGGL(lfq_dp_quad_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 16, force);
+    if (kn.light_kernel == 1) {                      /* A/B: the lane-group kernels (LFQ_LIGHT_KERNEL=quad) */
+        hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, 64, force);
+        hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, 32, force);
+        hipLaunchKernelGGL(lfq_dp_quad_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 16, force);
+    } else {                                         /* one light column per lane */
+        hipLaunchKernelGGL(lfq_dp_screen_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
+        hipLaunchKernelGGL(lfq_dp_screen_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
+        hipLaunchKernelGGL(lfq_dp_screen_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 2 * kn.screen_rounds, force);
+    }
     if (force == 0 || force == 64) {
         hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
                            d_pvals, pvals_capacity, 32, force == 64 ? 0 : 1);

@@ -28,6 +28,50 @@
 #include "lofreq_amd.h"
 #include "lfq_internal.h"
 
+/* the environment knobs, parsed once (lfq_internal.h) */
+const LfqKnobs &lfq_knobs(void)
+{
+    static const LfqKnobs k = [] {
+        LfqKnobs x;
+        memset(&x, 0, sizeof(x));
+        auto geti = [](const char *name, long dflt) -> long {
+            const char *e = getenv(name);
+            return (e && *e) ? atol(e) : dflt;
+        };
+        auto has = [](const char *name) { return getenv(name) != nullptr; };
+        x.timing = has("LFQ_TIMING");
+        x.single_stream = has("LFQ_SINGLE_STREAM");
+        x.no_sb_precompute = has("LFQ_NO_SB_PRECOMPUTE");
+        x.debug_sync = has("LFQ_DEBUG_SYNC");
+        if (const char *sk = getenv("LFQ_DEBUG_SKIP")) {
+            x.skip_light = strstr(sk, "light") != nullptr;
+            x.skip_mid = strstr(sk, "mid") != nullptr;
+            x.skip_big = strstr(sk, "big") != nullptr;
+        }
+        if (const char *lk = getenv("LFQ_LIGHT_KERNEL")) {
+            x.light_kernel = !strcmp(lk, "quad") ? 1 : (!strcmp(lk, "wave") ? 2 : 0);
+        }
+        x.light_lanes = (int)geti("LFQ_QUAD_LANES", 0);
+        x.light_waves_per_cu = (int)std::max(4L, geti("LFQ_LIGHT_WAVES_PER_CU", 10));
+        x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 16));
+        x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));
+        x.phase1_chunks = (int)std::max(1L, geti("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
+        x.seg_max = (int)std::min((long)LFQ_SEG_MAX, std::max(2L, geti("LFQ_SEG_MAX", LFQ_SEG_MAX)));
+        x.segments = (int)std::min((long)LFQ_MAX_SEGMENTS, std::max(1L, geti("LFQ_SEGMENTS", 1)));
+        x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
+        x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
+        x.host_threads = (int)geti("LFQ_HOST_THREADS", -1);
+        x.local_world_size = (int)std::max(1L, geti("LOCAL_WORLD_SIZE", 1));
+        x.indel_host_pack = has("LFQ_INDEL_HOST_PACK");
+        x.pileup_atomic = has("LFQ_PILEUP_ATOMIC");
+        x.baq_lds = geti("LFQ_BAQ_LDS", 1) != 0;
+        x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
+        x.baq_kernel = (int)geti("LFQ_BAQ_KERNEL", 0);
+        return x;
+    }();
+    return k;
+}
+
 namespace {
 
 /* utils.h:42 */
@@ -152,15 +196,11 @@ private:
     LfqPool()
     {
         unsigned hw = std::thread::hardware_concurrency();
-        if (const char *e = getenv("LOCAL_WORLD_SIZE")) {       /* one process per GPU (torchrun): share the cores */
-            const int lws = atoi(e);
-            if (lws > 1) {
-                hw = std::max(1u, hw / (unsigned)lws);
-            }
-        }
+        const LfqKnobs &kn = lfq_knobs();
+        hw = std::max(1u, hw / (unsigned)kn.local_world_size);   /* one process per GPU (torchrun): share the cores */
         int n = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, 63u);
-        if (const char *e = getenv("LFQ_HOST_THREADS")) {
-            n = std::max(0, std::min(atoi(e) - 1, 255));
+        if (kn.host_threads >= 0) {
+            n = std::max(0, std::min(kn.host_threads - 1, 255));
         }
         for (int i = 0; i < n; i++) {
             threads_.emplace_back([this, i] { loop(i); });
@@ -471,7 +511,7 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
     if (!conf || (!pvals && n_pvals > 0) || !n_records || n_pvals < 0) {
         return LFQ_ERR_INVALID;
     }
-    static const bool timing = getenv("LFQ_TIMING") != nullptr;
+    const bool timing = lfq_knobs().timing != 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tf[6] = {now(), 0, 0, 0, 0, 0};
     std::vector<int64_t> order((size_t)n_pvals);

@@ -137,6 +137,9 @@ struct LfqWork {
 #define LFQ_GC_OVERFLOW 1
 #define LFQ_GC_TESTED 2        /* running total of tested columns (carry between segments) */
 #define LFQ_GC_MAXDEPTH 3
+#define LFQ_GC_CELLS 8         /* and 9: uint64, DP cells processed = sum over the kept rows n of min(n, K) (SURVEY 8d secondary) */
+#define LFQ_GC_ROWS 10         /* and 11: uint64, kept rows the DP kernels processed */
+#define LFQ_GC_SCREEN_RETRY 12 /* light columns the screen kernel handed to the one-column-per-wavefront kernel */
 #define LFQ_CNT_TESTED 0
 #define LFQ_CNT_BIG 1
 #define LFQ_CNT_MID 2
@@ -153,6 +156,35 @@ struct LfqWork {
 #define LFQ_CNT_KLE15 27            /* quad kernel for this batch (lfq_light_group_lanes) */
 #define LFQ_CNT_KLE31 28
 #define LFQ_CNT_LONG0 16       /* +class: row-split columns per cells-per-lane class (LFQ_SEG_CLASSES) */
+
+/* ---- experiment / debugging knobs ----------------------------------------------------------------
+ * Environment variables, read ONCE per process (first lfq_create / first use) into this struct; no entry point
+ * calls getenv() on its own.  All optional; DESIGN.md "Environment knobs" documents them. */
+struct LfqKnobs {
+    int timing;                /* LFQ_TIMING: host phases of the layer-2 calls to stderr */
+    int single_stream;         /* LFQ_SINGLE_STREAM: every kernel on the caller's stream (rocprofv3 --pmc passes) */
+    int no_sb_precompute;      /* LFQ_NO_SB_PRECOMPUTE */
+    int debug_sync;            /* LFQ_DEBUG_SYNC: serialise and name the stages */
+    int skip_light, skip_mid, skip_big;   /* LFQ_DEBUG_SKIP=light,mid,big: run the DP classes in isolation */
+    int light_kernel;          /* LFQ_LIGHT_KERNEL: 0 screen (default: one light column per lane), 1 quad (lane groups), 2 wave */
+    int light_lanes;           /* LFQ_QUAD_LANES: force 8 / 16 / 32 / 64 cells (lanes) per light column; 0 = per batch */
+    int light_waves_per_cu;    /* LFQ_LIGHT_WAVES_PER_CU (10): lane-group kernels */
+    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (16) */
+    int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
+    int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
+    int seg_max;               /* LFQ_SEG_MAX */
+    int segments;              /* LFQ_SEGMENTS: batch segments */
+    int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
+    long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
+    int host_threads;          /* LFQ_HOST_THREADS: -1 = from the core count */
+    int local_world_size;      /* LOCAL_WORLD_SIZE (torchrun): processes sharing this host's cores, >= 1 */
+    int indel_host_pack;       /* LFQ_INDEL_HOST_PACK */
+    int pileup_atomic;         /* LFQ_PILEUP_ATOMIC: read-major pileup kernels even for sorted reads */
+    int baq_lds;               /* LFQ_BAQ_LDS (1) */
+    long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
+    int baq_kernel;            /* LFQ_BAQ_KERNEL: A/B switch between BAQ kernel generations */
+};
+const LfqKnobs &lfq_knobs(void);
 
 /* ---- strand-bias precompute (host, lfq_host.cpp) ---------------------------------------------------
  * report_var's Fisher test (lofreq_call.c:117-129) depends only on the DP4 counts, which are final after

@@ -754,10 +754,7 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
     if (c1 <= c0) {
         return LFQ_OK;
     }
-    int64_t multi_below = 4096;                    /* deepest column of the batch below this: four columns per wavefront */
-    if (const char *e = getenv("LFQ_COUNT_MULTI_BELOW")) {
-        multi_below = atol(e);
-    }
+    const int64_t multi_below = lfq_knobs().count_multi_below;   /* deepest column of the batch below this: four columns per wavefront */
     if (!p.general && !p.detlim_af && max_col_obs > 0 && max_col_obs < multi_below) {
         const unsigned blocks = (unsigned)((c1 - c0 + 15) / 16);
 #define LFQ_LAUNCH_MULTI(PK, ST)                                                                                     \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc runs (one sqlite db per counter pass) into profiles/*.md and
-profiles/pmc_traffic.json (HBM bytes per launch of each kernel, read by bench.py for roofline.traffic).
+"""Summarise rocprofv3 --pmc runs (one sqlite db per counter pass, profiles/run_pmc.sh) into gpurun_out/<tag>_pmc.md.
+(bench.py measures roofline.traffic itself, with its own counter passes; nothing reads these files back.)
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
 gfx950 reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read: the count kernel's
@@ -26,17 +26,18 @@ def counters(db_path):
 
 def main(root, tag):
     allc = {}
-    for path in sorted(glob.glob(root + "/pmc_*/*.db")):
+    for path in sorted(glob.glob(root + "/pmc_*/**/*.db", recursive=True)):
         for k, d in counters(path).items():
             allc.setdefault(k, {}).update(d)
     lines = ["# PMC summary (%s)" % tag, "",
-             "Separate `rocprofv3 --pmc <one counter> --kernel-trace` passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`",
+             "Separate `rocprofv3 --pmc <one counter> --kernel-trace` passes of `bench.py --pmc-child` (2 steps, LFQ_SINGLE_STREAM=1)",
              "(C3, 1 MI355X).  One counter per pass: FETCH_SIZE and WRITE_SIZE together exceed what the hardware collects at once",
              "(rocprofv3 aborts with error 38 and then sits until it is killed -- the 'hang' of the earlier attempts).",
              "`lfq_count_kernel<packed nt, strand planes>`: `<true, false>` is what `bench.py` runs (1.5 B per observation read,",
              "strand counts only for the columns that emit); `<false, true>` = byte layout with dense strand counts.", "",
+             "Counter columns are sums over the launches; bytes are per launch.", "",
              "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch (corrected) | SQ_INSTS_VALU | "
-             "SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE |", "|---|---|---|---|---|---|---|---|"]
+             "SQ_WAVE_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE |", "|---|---|---|---|---|---|---|---|---|"]
     traffic = {}
     for k in sorted(allc):
         if not k.startswith("lfq_"):
@@ -47,18 +48,13 @@ def main(root, tag):
         wide = k.startswith("lfq_count_kernel") or k.startswith("lfq_synth_kernel")
         byt = ((2.0 if wide else 1.0) * f + w) * 1024.0 / max(n, 1)
         traffic[k] = byt
-        lines.append("| %s | %d | %.0f | %.0f | %.4g %s | %.4g | %.4g | %.4g |" % (
+        lines.append("| %s | %d | %.0f | %.0f | %.4g %s | %.4g | %.4g | %.4g | %.4g |" % (
             k, n, f, w, byt, "(FETCH x2: wide coalesced reads)" if wide else "(uncalibrated)",
-            d.get("SQ_INSTS_VALU", (0, 1))[0], d.get("SQ_WAVE_CYCLES", (0, 1))[0],
+            d.get("SQ_INSTS_VALU", (0, 1))[0], d.get("SQ_WAVE_CYCLES", (0, 1))[0], d.get("SQ_BUSY_CYCLES", (0, 1))[0],
             d.get("GRBM_GUI_ACTIVE", (0, 1))[0]))
     text = "\n".join(lines) + "\n"
-    open("profiles/%s_pmc.md" % tag, "w").write(text)
-    # bench.py looks kernels up by the names it uses
-    tj = {}
-    if os.path.exists("profiles/pmc_traffic.json"):
-        tj = json.load(open("profiles/pmc_traffic.json"))          # keep entries of kernels this run did not launch
-    tj.update({k: v for k, v in traffic.items()})
-    json.dump(tj, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    open("gpurun_out/%s_pmc.md" % tag, "w").write(text)
     print(text)
 
 
