@@ -127,4 +127,59 @@ __device__ __forceinline__ LfqObs lfq_eval_obs(uint32_t ntb, uint32_t bqb, uint3
     return o;
 }
 
+/* The same evaluation without control flow: every filter is a predicate, every table entry is fetched
+ * unconditionally (with a harmless index where the reference would not look), the result is selected; the
+ * wave-uniform switches of LfqParams are turned into masks once (LfqEvalMasks) so that they cost an AND / OR per
+ * observation instead of a scalar branch.  For kernels that evaluate one observation per LANE of different columns
+ * (lfq_dp_screen_kernel): there the early returns of lfq_eval_obs become EXEC-mask regions that every wavefront
+ * walks through anyway -- ~70 scalar instructions and both sides of every branch per observation.  Identical
+ * values (the same operations on the kept path). */
+struct LfqEvalMasks {
+    uint32_t own, fixed, med;       /* all-ones on exactly one: an alt base's BQ is its own / def_alt_bq / the median */
+    uint32_t fixed_q;
+    uint32_t off_baq, off_mq, off_sq;   /* 255 where the track is switched off (index 255 = "missing"), else 0 */
+    bool has_def_jp;
+};
+
+__device__ __forceinline__ LfqEvalMasks lfq_eval_masks(const LfqParams &P)
+{
+    LfqEvalMasks m;
+    m.med = (P.def_alt_bq == -1) ? ~0u : 0u;
+    m.fixed = (P.def_alt_bq > 0) ? ~0u : 0u;
+    m.own = ~(m.med | m.fixed);
+    m.fixed_q = (uint32_t)P.def_alt_bq & 255u;
+    m.off_baq = P.use_baq ? 0u : 255u;
+    m.off_mq = P.use_mq ? 0u : 255u;
+    m.off_sq = P.use_sq ? 0u : 255u;
+    m.has_def_jp = P.def_alt_jp >= 0.0;
+    return m;
+}
+
+__device__ __forceinline__ LfqObs lfq_eval_obs_flat(uint32_t ntb, uint32_t bqb, uint32_t baqb, uint32_t mqb,
+                                                    uint32_t sqb, int ref_code, int median_ref_bq,
+                                                    const LfqParams &P, const LfqEvalMasks &M, const LfqLuts *L)
+{
+    const uint32_t code = ntb & 7u;
+    const bool valid = code <= 3u;
+    const bool is_alt = valid & (code != (uint32_t)ref_code);
+    const bool bq_ok = (int)bqb >= (is_alt ? P.min_alt_bq4 : P.min_bq4);    /* min_alt_bq4 = max(min_bq, min_alt_bq) */
+    /* snpcaller.c:431-441: the quality that stands in for an alt base's own */
+    const uint32_t alt_idx = (bqb & M.own) | (M.fixed_q & M.fixed) | ((uint32_t)median_ref_bq & 255u & M.med);
+    const uint32_t bq_idx = is_alt ? alt_idx : bqb;
+    double pb = L->bq[bq_idx];
+    pb = (is_alt & (M.med != 0u) & (median_ref_bq < 0)) ? 0.0 : pb;
+    const double pa = L->baq[baqb | M.off_baq];
+    const double pm = L->mq[mqb | M.off_mq];
+    const double ps = L->sq[sqb | M.off_sq];
+    const double om = 1.0 - pm, os = 1.0 - ps, oa = 1.0 - pa;
+    double jp = pm + om * ps + om * os * pa + om * os * oa * pb;              /* snpcaller.c:334 */
+    const bool jq_bad = (jp > P.jq_reject_above) | (is_alt & (jp > P.alt_jq_reject_above));
+    jp = (is_alt & M.has_def_jp) ? P.def_alt_jp : jp;
+    LfqObs o;
+    o.keep = valid & bq_ok & !jq_bad;
+    o.is_alt = is_alt;
+    o.p = jp;
+    return o;
+}
+
 #endif

@@ -679,10 +679,12 @@ __device__ __forceinline__ int lfq_claim(int32_t *head, int n)
 /* lanes per light column for this batch: the smallest group that fits 90 % of the light columns (the rest go
  * to the retry kernel); 64 = one column per wavefront (lfq_dp_wave_kernel<1>).  Deep pileups have K ~ depth / 7000
  * per alt base from sequencing errors alone, so the best group size is a property of the batch. */
-__device__ __forceinline__ int lfq_light_group_lanes(const LfqWork &W)
+__device__ __forceinline__ int lfq_light_group_lanes(const LfqWork &W, int den)
 {
+    /* den: 1 / den of the light columns may exceed the group (they go to the retry kernel): 10 for the lane-group
+     * kernels, 2000 for the screen kernel, whose wider variants cost little and whose leftovers cost a wavefront each */
     const int64_t n = W.counters[LFQ_CNT_LIGHT];
-    const int64_t need = n - n / 10;
+    const int64_t need = n - n / den;
     if (W.counters[LFQ_CNT_KLE7] >= need) {
         return 8;
     }
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
 {
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
-    if (only_if_gl64 && lfq_light_group_lanes(W) != 64) {
+    if (only_if_gl64 && lfq_light_group_lanes(W, only_if_gl64) != 64) {   /* only_if_gl64 = the `den` of the light kernel in use */
         return;                                     /* the quad kernel serves this batch's light class */
     }
     if (MAXC > 1) {
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqPar
     constexpr int MAX_STEPS = LFQ_Q_MAX_ROWS / GL;
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
-    if (force_gl ? (force_gl != GL) : (lfq_light_group_lanes(W) != GL)) {
+    if (force_gl ? (force_gl != GL) : (lfq_light_group_lanes(W, 10) != GL)) {
         return;                                     /* another group size serves this batch */
     }
     {
@@ -1223,6 +1225,8 @@ __device__ __forceinline__ void lfq_screen_row(double (&v)[KREG], double p, doub
 #define LFQ_SCREEN_BYTE(w4, j) \
     (((((j) >> 2) == 0 ? (w4).x : ((j) >> 2) == 1 ? (w4).y : ((j) >> 2) == 2 ? (w4).z : (w4).w) >> (8 * ((j) & 3))) & 0xffu)
 
+#define LFQ_SCREEN_CLAIM 128       /* work-list entries per dequeue */
+
 template <int KREG>
 __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqParams P,
                                                             const LfqLuts *__restrict__ g_luts, LfqWork W,
@@ -1230,7 +1234,7 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
 {
     constexpr int MAXK = KREG - 1;
     __shared__ LfqLuts s_luts;
-    if (force_gl ? (force_gl != KREG) : (lfq_light_group_lanes(W) != KREG)) {
+    if (force_gl ? (force_gl != KREG) : (lfq_light_group_lanes(W, 2000) != KREG)) {
         return;                                     /* another variant serves this batch */
     }
     {
@@ -1245,27 +1249,50 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
     const int n_work = W.counters[LFQ_CNT_LIGHT];
     const LfqEntry *list = W.entries;               /* the light class leads the work list */
     const double sig_s = P.sig * (1.0 + P.prune_slack);
-    /* static slice of the light list per wavefront: no claims (one returning atomic per refill would saturate a
-     * single counter: ~88 dequeues per microsecond), consecutive entries = coalesced record loads */
-    const int n_waves = (int)gridDim.x * 4;
-    const int wv = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    int q_next = (int)((int64_t)n_work * wv / n_waves);
-    const int q_end = (int)((int64_t)n_work * (wv + 1) / n_waves);
+    const LfqEvalMasks EM = lfq_eval_masks(P);
+    /* Work distribution: the light list is cut into eight slices, one per XCD, each with its own dequeue head; a
+     * wavefront claims LFQ_SCREEN_CLAIM consecutive entries at a time from its XCD's slice (blockIdx % 8: placement is a speed
+     * matter only) and moves on to the other slices when that one is empty.  One head for everybody would
+     * saturate (~88 dequeues per microsecond on one word); a static slice per wavefront leaves most lanes idle
+     * while the last columns of each slice run out (measured: 35 % lane utilisation). */
+    const int xcd0 = (int)(blockIdx.x & 7u);
+    int xcd_try = 0;                                /* slices found empty so far */
+    int q_next = 0, q_end = 0;                      /* this wavefront's claimed, not yet assigned entries */
 
     bool active = false;
     uint64_t off0 = 0;
     int n_obs = 0, rel = 0, K = 0, ref_code = 0, med = 0, rounds = 0, list_idx = 0, n_kept = 0;
     double bonf_d = 1.0;
     double v[KREG];
+#pragma unroll
+    for (int j = 0; j < KREG; j++) {
+        v[j] = 0.0;
+    }
     unsigned long long acc_cells = 0, acc_rows = 0;
     int n_retry = 0;
 
     for (;;) {
-        /* ---- lanes without a column take the next entries of the slice ---- */
-        const uint64_t need = __ballot(!active);
-        if (need != 0ull && q_next < q_end) {
+        /* ---- lanes without a column take the next claimed entries ---- */
+        uint64_t need = __ballot(!active);
+        while (need != 0ull && (q_next < q_end || xcd_try < 8)) {
+            if (q_next >= q_end) {
+                const int x = (xcd0 + xcd_try) & 7;
+                const int lo = (int)((int64_t)n_work * x / 8), hi = (int)((int64_t)n_work * (x + 1) / 8);
+                int32_t *head = &W.counters[LFQ_CNT_XHEAD + 32 * x];
+                /* an empty slice is recognised with a plain L2 load: only claims that can succeed pay for an atomic */
+                int b = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b < hi - lo) {
+                    b = lfq_claim(head, LFQ_SCREEN_CLAIM);
+                }
+                if (b >= hi - lo) {
+                    xcd_try++;
+                    continue;
+                }
+                q_next = lo + b;
+                q_end = min(lo + b + LFQ_SCREEN_CLAIM, hi);
+            }
             const int idx = q_next + __popcll(need & ((1ull << lane) - 1ull));
-            q_next += __popcll(need);
+            q_next = min(q_next + __popcll(need), q_end);
             if (!active && idx < q_end) {
                 const uint4 *ep = reinterpret_cast<const uint4 *>(list + idx);
                 const uint4 a = ep[0], b = ep[1];
@@ -1295,12 +1322,10 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
                     }
                 }
             }
+            need = __ballot(!active);
         }
         if (__ballot(active) == 0ull) {
-            if (q_next >= q_end) {
-                break;
-            }
-            continue;                               /* every taken entry went to retry: take more */
+            break;                                  /* nothing left to claim either */
         }
 
         /* ---- this lane's window: 16 observations, one load per track ---- */
@@ -1331,11 +1356,13 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
             /* packed layout: observation j of the window sits in dword j / 8, byte j % 4, nibble (j % 8) / 4 (lfq_nt_at) */
             const uint32_t nib = (((j >> 3) ? ntw.y : ntw.x) >> (8 * (j & 3) + 4 * ((j & 7) >> 2))) & 15u;
             const uint32_t ntb = packed ? nib : LFQ_SCREEN_BYTE(ntw, j);
-            const LfqObs o = lfq_eval_obs(ntb, LFQ_SCREEN_BYTE(bqw, j), LFQ_SCREEN_BYTE(baqw, j), LFQ_SCREEN_BYTE(mqw, j),
-                                          LFQ_SCREEN_BYTE(sqw, j), ref_code, med, P, &s_luts);
-            const bool keep = active && o.keep && (unsigned)(rel + j) < (unsigned)n_obs;
-            const double ps = (fabs(o.p) < LFQ_DBL_EPS) ? LFQ_DBL_EPS : o.p;                       /* lfq_eval_raw */
-            const double qf = (fabs(o.p - 1.0) < LFQ_DBL_EPS) ? 1.0 + (-o.p + LFQ_DBL_EPS) : 1.0 - o.p;
+            const LfqObs o = lfq_eval_obs_flat(ntb, LFQ_SCREEN_BYTE(bqw, j), LFQ_SCREEN_BYTE(baqw, j), LFQ_SCREEN_BYTE(mqw, j),
+                                               LFQ_SCREEN_BYTE(sqw, j), ref_code, med, P, EM, &s_luts);
+            const bool keep = active & o.keep & ((unsigned)(rel + j) < (unsigned)n_obs);
+            /* the reference's guards against log(0) (lfq_eval_raw) as two maxima: 0 <= p <= 1 here, and within
+             * DBL_EPSILON of the ends the exact form differs by less than the pruning slack cares about */
+            const double ps = fmax(o.p, LFQ_DBL_EPS);
+            const double qf = fmax(1.0 - o.p, LFQ_DBL_EPS);
             lfq_screen_row<KREG>(v, keep ? ps : 0.0, keep ? qf : 1.0);
             n_kept += keep ? 1 : 0;
         }
@@ -2300,11 +2327,11 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
     } else {                                         /* one light column per lane */
         hipLaunchKernelGGL(lfq_dp_screen_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
         hipLaunchKernelGGL(lfq_dp_screen_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
-        hipLaunchKernelGGL(lfq_dp_screen_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 2 * kn.screen_rounds, force);
+        hipLaunchKernelGGL(lfq_dp_screen_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
     }
     if (force == 0 || force == 64) {
         hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
-                           d_pvals, pvals_capacity, 32, force == 64 ? 0 : 1);
+                           d_pvals, pvals_capacity, 32, force == 64 ? 0 : (kn.light_kernel == 1 ? 10 : 2000));
     }
     hipLaunchKernelGGL(lfq_dp_retry_kernel, grid, block, 0, st, t, p, d_luts, d_counts, w, d_retry, d_pvals,
                        pvals_capacity);

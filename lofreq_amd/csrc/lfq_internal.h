@@ -131,7 +131,7 @@ struct LfqWork {
 
 #define LFQ_MID_K 64          /* K+1 cells no longer fit one cell per lane */
 #define LFQ_BIG_K 250         /* K+1 (+alignment) cells no longer fit one 64x4 strip: strip pipeline */
-#define LFQ_NCOUNTERS 32
+#define LFQ_NCOUNTERS 320
 #define LFQ_MAX_SEGMENTS 8      /* a batch is cut into segments so that the DP of one overlaps the count of the next */
 #define LFQ_GC_PVALS 0         /* records appended to the sparse output */
 #define LFQ_GC_OVERFLOW 1
@@ -155,6 +155,8 @@ struct LfqWork {
 #define LFQ_CNT_KLE7 26             /* light columns with K <= 7 / <= 15 / <= 31: picks the lanes-per-column of the */
 #define LFQ_CNT_KLE15 27            /* quad kernel for this batch (lfq_light_group_lanes) */
 #define LFQ_CNT_KLE31 28
+#define LFQ_CNT_XHEAD 64       /* screen kernel: dequeue heads of the eight XCD slices of the light list, one per 128-byte
+                                * line (head x at counters[LFQ_CNT_XHEAD + 32 x]): atomics on one line serialise */
 #define LFQ_CNT_LONG0 16       /* +class: row-split columns per cells-per-lane class (LFQ_SEG_CLASSES) */
 
 /* ---- experiment / debugging knobs ----------------------------------------------------------------
@@ -169,8 +171,8 @@ struct LfqKnobs {
     int light_kernel;          /* LFQ_LIGHT_KERNEL: 0 screen (default: one light column per lane), 1 quad (lane groups), 2 wave */
     int light_lanes;           /* LFQ_QUAD_LANES: force 8 / 16 / 32 / 64 cells (lanes) per light column; 0 = per batch */
     int light_waves_per_cu;    /* LFQ_LIGHT_WAVES_PER_CU (10): lane-group kernels */
-    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (16) */
-    int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
+    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (8) */
+    int screen_rounds;         /* LFQ_SCREEN_ROUNDS (16): 16-row windows before a light column goes to the retry kernel */
     int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
     int seg_max;               /* LFQ_SEG_MAX */
     int segments;              /* LFQ_SEGMENTS: batch segments */
