@@ -409,6 +409,10 @@ int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
  * need confs of their own -- independent regions, as call-parallel's bins are.  Host tracks handed to submit
  * (tracks_on_device = 0) must stay valid until collect. */
 int lfq_call_snvs_submit(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *tracks, int tracks_on_device);
+/* blocks until the KERNELS of the submitted batch are done.  The pattern that keeps one GPU busy with two contexts:
+ * wait(A); submit(B, next batch); collect(A) -- the host finish of batch k runs under the kernels of batch k + 1,
+ * and the two batches' kernels never compete for the same CUs. */
+int lfq_call_snvs_wait(lfq_ctx *ctx);
 int lfq_call_snvs_collect(lfq_ctx *ctx, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
                           int64_t *n_records, lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out);
 

@@ -114,7 +114,7 @@ assert SNV_RECORD_DTYPE.itemsize == 64, SNV_RECORD_DTYPE.itemsize
 # every symbol include/lofreq_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lfq_abi_version", "lfq_strerror", "lfq_conf_init", "lfq_create", "lfq_destroy", "lfq_synchronize",
-    "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_call_snvs_submit", "lfq_call_snvs_collect", "lfq_set_dense_strand_counts", "lfq_set_indel_arrays_on_host", "lfq_finalize_pvals",
+    "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_call_snvs_submit", "lfq_call_snvs_wait", "lfq_call_snvs_collect", "lfq_set_dense_strand_counts", "lfq_set_indel_arrays_on_host", "lfq_finalize_pvals",
     "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_format_vcf", "lfq_snvqual_thresh", "lfq_sb_phred",
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_synth_fill_device_layout", "lfq_last_kernel_times", "lfq_last_dp_work",
@@ -159,6 +159,7 @@ def load():
     L.lfq_set_dense_strand_counts.argtypes = [vp, C.c_int]
     L.lfq_set_indel_arrays_on_host.argtypes = [vp, C.c_int]
     L.lfq_call_snvs_submit.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int]
+    L.lfq_call_snvs_wait.argtypes = [vp]
     L.lfq_call_snvs_collect.argtypes = [vp, C.POINTER(Conf), vp, C.c_int64, C.POINTER(C.c_int64), vp, C.POINTER(BatchStats)]
     L.lfq_call_snvs_batch.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int, vp, C.c_int64,
                                       C.POINTER(C.c_int64), vp, C.POINTER(BatchStats)]

@@ -161,6 +161,10 @@ class SnvCaller:
         _lib.check(self.L.lfq_call_snvs_submit(self.h, C.byref(conf.c), C.byref(t), 1 if batch.on_device else 0),
                    "lfq_call_snvs_submit")
 
+    def call_snvs_wait(self):
+        """block until the kernels of the submitted batch are done (lfq_call_snvs_wait)"""
+        _lib.check(self.L.lfq_call_snvs_wait(self.h), "lfq_call_snvs_wait")
+
     def call_snvs_collect(self, conf, records_capacity=1 << 16):
         """second half: wait, finish on the host -> (records, BatchStats); mutates conf like call_snvs"""
         cap = int(records_capacity)

@@ -168,6 +168,7 @@ struct lfq_ctx {
     std::mutex *lm;
     std::condition_variable *lcv;
     int leader_go, leader_stop;
+    int sb_pending;                  /* strand-bias precomputes of this context not finished yet (under lm) */
 };
 
 namespace {
@@ -297,7 +298,12 @@ void leader_main(lfq_ctx *c)
         if (hipEventSynchronize(c->ev_heavy) == hipSuccess) {
             n = std::min<int64_t>(std::max<int64_t>(*(volatile int32_t *)c->h_nheavy, 0), c->heavy_cap);
         }
-        lfq_sb_precompute(c->h_tuples, 3 * n);        /* ends the begin() bracket even when n == 0 */
+        lfq_sb_precompute(c->h_tuples, 3 * n);
+        {
+            std::lock_guard<std::mutex> lk(*c->lm);
+            c->sb_pending--;
+        }
+        c->lcv->notify_all();
     }
 }
 
@@ -629,12 +635,12 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
                 LFQ_TRY(lfq_launch_gather_heavy(W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
             }
             LFQ_TRY_HIP(hipEventRecord(c->ev_heavy, dps));
-            lfq_sb_precompute_begin();
             {
                 std::lock_guard<std::mutex> lk(*c->lm);
                 c->leader_go++;
+                c->sb_pending++;
             }
-            c->lcv->notify_one();
+            c->lcv->notify_all();
         }
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
@@ -915,6 +921,21 @@ int lfq_call_snvs_submit(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     return LFQ_OK;
 }
 
+/* blocks until the kernels of the batch submitted on this context are done (nothing else): a caller that keeps two
+ * contexts busy waits here, submits the next batch on the other context, and only then collects this one */
+int lfq_call_snvs_wait(lfq_ctx *c)
+{
+    if (!c || c->sub_ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    if (c->sub_ncols == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY_HIP(hipEventSynchronize(c->ev[3]));
+    return LFQ_OK;
+}
+
 /* layer 2, second half: wait for the batch submitted on this context, fetch the sparse records, exact emit test,
  * strand bias, records; conf's Bonferroni bookkeeping as the per-column loop does it */
 int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
@@ -946,6 +967,10 @@ int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, i
                               hipMemcpyDeviceToHost));
     }
     tp[2] = lfq_now_ms();
+    if (c->leader) {        /* this batch's strand-bias tables: usually long done (they ran under the DP kernels) */
+        std::unique_lock<std::mutex> lk(*c->lm);
+        c->lcv->wait(lk, [&] { return c->sb_pending == 0 || c->leader_stop; });
+    }
     /* the reference base of a surviving column travels in its record (lfq_col_pvals.ref_base) */
     int rc = lfq_finalize_pvals(conf, h_pv.data(), st.n_pvals, nullptr, c->sub_ref_host, records, records_capacity,
                                 n_records);

@@ -277,28 +277,18 @@ public:
         static LfqSbCache c;
         return c;
     }
-    void begin()
+    /* results of one context's precompute; entries of other batches / contexts stay (content-addressed: a key
+     * always maps to the same value) until the table gets large */
+    void publish(std::vector<std::pair<SbKey, int>> &items)
     {
         std::lock_guard<std::mutex> lk(m_);
-        inflight_++;
-    }
-    void publish_and_end(std::vector<std::pair<SbKey, int>> &items)
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            map_.clear();                       /* one batch's worth: the cache never grows without bound */
-            map_.reserve(items.size() * 2);
-            for (auto &it : items) {
-                map_.emplace(it.first, it.second);
-            }
-            inflight_--;
+        if (map_.size() + items.size() > ((size_t)1 << 18)) {
+            map_.clear();                       /* the cache never grows without bound */
         }
-        cv_.notify_all();
-    }
-    void wait_idle()
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return inflight_ == 0; });
+        map_.reserve(map_.size() + items.size());
+        for (auto &it : items) {
+            map_.emplace(it.first, it.second);
+        }
     }
     bool lookup(const SbKey &k, int *sb)
     {
@@ -324,14 +314,10 @@ public:
 
 private:
     std::mutex m_;
-    std::condition_variable cv_;
-    int inflight_ = 0;
     std::unordered_map<SbKey, int, SbKeyHash> map_;
 };
 
 }  // namespace
-
-void lfq_sb_precompute_begin(void) { LfqSbCache::instance().begin(); }
 
 void lfq_sb_precompute(const int32_t *tuples, int64_t n)
 {
@@ -360,7 +346,7 @@ void lfq_sb_precompute(const int32_t *tuples, int64_t n)
         }
     };
     LfqPool::instance().run(work, (int)std::min<int64_t>(LfqPool::instance().size(), m / 2));
-    LfqSbCache::instance().publish_and_end(items);
+    LfqSbCache::instance().publish(items);
 }
 
 extern "C" {
@@ -619,8 +605,9 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
         std::atomic<int64_t> next(0);
         /* expensive tables were precomputed while the DP kernels ran (lfq_sb_precompute); the rest here */
         tf[2] = now();
+        /* (a context waits for ITS OWN precompute before it gets here -- lfq_call_snvs_collect; other contexts'
+         * batches in flight are none of this call's business, and a miss is simply computed below) */
         LfqSbCache &cache = LfqSbCache::instance();
-        cache.wait_idle();
         tf[3] = now();
         std::vector<int64_t> miss;
         cache.with_lock([&] {

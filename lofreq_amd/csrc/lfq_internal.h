@@ -190,11 +190,11 @@ const LfqKnobs &lfq_knobs(void);
 
 /* ---- strand-bias precompute (host, lfq_host.cpp) ---------------------------------------------------
  * report_var's Fisher test (lofreq_call.c:117-129) depends only on the DP4 counts, which are final after
- * the count kernel.  While the DP kernels run, a host thread computes it for the columns with many alt
+ * the count kernel.  While the DP kernels run, a host thread of the context computes it for the columns with many alt
  * bases (the expensive ones) into a process-wide content-addressed cache that lfq_finalize_pvals consults.
- * Purely an optimisation: a miss is computed on the spot, bit-identically. */
-void lfq_sb_precompute_begin(void);
-/* tuples: n x {ref_fw, ref_rv, alt_fw, alt_rv}; all-zero tuples are skipped.  Ends the begin() bracket. */
+ * Purely an optimisation: a miss is computed on the spot, bit-identically.  Synchronisation is per context
+ * (lfq_ctx::sb_pending): a context waits for its own precompute in lfq_call_snvs_collect, never for another's. */
+/* tuples: n x {ref_fw, ref_rv, alt_fw, alt_rv}; all-zero tuples are skipped. */
 void lfq_sb_precompute(const int32_t *tuples, int64_t n);
 
 /* ---- BAQ (lfq_baq.hip) ----------------------------------------------------------------------------------- */
