@@ -9,7 +9,7 @@ the device by the workload spec of include/lofreq_synth.h).  Default workload = 
 synthetic 1 Mb genome, 10000x ultra-deep, SNV-only, --no-default-filter, dynamic Bonferroni -- the configuration
 the metric "pileup columns/sec at depth 10000" is quoted on; it fits one GPU (35 GB of tracks).  `--config C2` is
 configs[1] (1000x, default filter applied).  With N > 1 every rank owns its own 1 Mb region shard (weak scaling,
-the reference's call-parallel model) or, with `--scaling strong`, 1/N of one N x 1 Mb genome cut by
+the reference's call-parallel model) or, with `--scaling strong`, its bins of ONE 1 Mb genome cut and dealt by
 lofreq_amd.shard.plan_regions; the only exchange is the tested-column count all-gather + the record gather of
 lofreq_amd/shard.py.
 
@@ -402,26 +402,44 @@ def main():
         return
 
     # ---- this rank's columns ----
+    my_bins = None
     if args.scaling == "strong" and world > 1:
-        # one genome of world * ncols columns, cut into >= 2 bins per GPU (call-parallel's rule) balanced by depth
-        total = ncols * world
-        bins = shard.plan_regions([("synth", 0, total)], lambda c, b, e: float(depth) * (e - b), world)
-        mine = bins[rank]
-        col_begin, my_cols = mine[0][1], sum(e - b for _, b, e in mine)
-        assert all(mine[i][2] == mine[i + 1][1] for i in range(len(mine) - 1)), "bins of a rank are contiguous here"
+        # ONE genome of `--cols` columns whatever N is (a fixed 8 Mb genome would not fit one GPU at 10000x: 280 GB of
+        # tracks), cut the way call-parallel cuts it (lofreq2_call_pparallel.py:590-613): >= 2 bins per GPU, split
+        # greedily by cost (uniform depth here: by length), dealt longest first
+        total = ncols
+        bins, owner = shard.plan_regions([("synth", 0, total)], lambda c, b, e: float(depth) * (e - b), world)
+        my_bins = [(i, b, e) for i, ((_, b, e), o) in enumerate(zip(bins, owner)) if o == rank]
+        n_bins_total = len(bins)
+        my_cols = sum(e - b for _, b, e in my_bins)
+        col_begin = my_bins[0][1]
+        batches = [caller.synth_batch(seed, depth, e - b, plant_period=args.plant_period, col_begin=b,
+                                      nt_packed=not args.nt_bytes) for _, b, e in my_bins]
+        batch = batches[0]
+        cap_cols = max(e - b for _, b, e in my_bins)
     else:
         col_begin, my_cols = rank * ncols, ncols
-    batch = caller.synth_batch(seed, depth, my_cols, plant_period=args.plant_period, col_begin=col_begin,
-                               nt_packed=not args.nt_bytes)
-    d_counts = torch.zeros(my_cols * 64, dtype=torch.uint8, device=dev)
-    pv_cap = my_cols
+        batch = caller.synth_batch(seed, depth, my_cols, plant_period=args.plant_period, col_begin=col_begin,
+                                   nt_packed=not args.nt_bytes)
+        cap_cols = my_cols
+    d_counts = torch.zeros(cap_cols * 64, dtype=torch.uint8, device=dev)
+    pv_cap = cap_cols
     d_pvals = torch.zeros(pv_cap * 128, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
 
     def step():
         """One pass: kernels, sparse results to the host, exact emit test, exchange, filter, VCF text."""
         conf = la.VarcallConf()                   # default sig, dynamic Bonferroni from 1
-        if world == 1 and not args.shard_path:
+        if my_bins is not None:
+            # strong scaling: every bin of this rank is a batch of its own; one exchange for all of them
+            done = []
+            for (i, b, e), bt in zip(my_bins, batches):
+                caller.snv_batch_device(bt, conf, d_counts, d_pvals, pv_cap)
+                st = caller.batch_finish()
+                done.append((i, b, d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE).copy(),
+                             int(st.n_tested)))
+            recs, total = shard.finish_bins(conf, done, n_bins_total, dist, dev)
+        elif world == 1 and not args.shard_path:
             # layer 2 of the C ABI (lfq_call_snvs_batch): the whole call_snvs loop over the batch in one call
             recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
         else:
@@ -508,7 +526,7 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = 1e3 * elapsed / steps
-        total_cols = my_cols * world if args.scaling == "weak" else ncols * world
+        total_cols = ncols * world if my_bins is None else ncols    # weak: a shard per GPU; strong: one genome
         value = total_cols * steps / elapsed
         kt = {k: v / steps for k, v in kt_acc.items()}
         n_launch = max(int(round(kt["n_segments"])), 1)       # count-kernel launches per step
@@ -548,7 +566,7 @@ def main():
                             "(BASELINE.json configs[%d])"
                             % (args.config, ncols / 1e6, depth,
                                "default filter applied" if cfg_filter else "--no-default-filter", cfg_idx),
-                "columns_per_gpu": my_cols, "depth": depth, "planted_snv_period": args.plant_period,
+                "columns_per_gpu": my_cols, "bins_rank0": len(my_bins) if my_bins is not None else 1, "depth": depth, "planted_snv_period": args.plant_period,
                 "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",

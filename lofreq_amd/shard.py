@@ -28,6 +28,95 @@ def shard_ranges(n_items, world_size):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# region planning: call-parallel's bins (lofreq2_call_pparallel.py:590-613, 307-312), balanced by cost
+# ---------------------------------------------------------------------------------------------------------
+BIN_PER_THREAD = 2          # lofreq2_call_pparallel.py: "keep more bins than threads to make up for differences"
+MIN_BIN_LEN = 100           # :605-607 "Regions getting too small to be efficiently processed"
+
+
+def make_cost_fn(depth_profile, k_profile=None, dp_weight=2.0, bin_size=1):
+    """Cost of a range = sum of depth (the streaming count phase: bytes read) + dp_weight * sum of depth * K
+    (the recurrence: rows * cells) over its positions, from per-position (or per-`bin_size` window) profiles
+    {chrom: array}.  `k_profile` is an estimate of the largest alt count per position (0 where nothing is
+    expected); sequencing errors alone give K ~ depth / 7000, which the depth term already covers.
+    -> cost_fn(chrom, begin, end), exact on window boundaries, linear inside a window."""
+    import numpy as np
+    pref = {}
+    for chrom, d in depth_profile.items():
+        d = np.asarray(d, np.float64)
+        c = d.copy()
+        if k_profile is not None and chrom in k_profile:
+            c = c + dp_weight * d * np.asarray(k_profile[chrom], np.float64)
+        pref[chrom] = np.concatenate([[0.0], np.cumsum(c)])
+
+    def at(chrom, x):
+        p = pref[chrom]
+        w = x / float(bin_size)
+        i = min(int(w), len(p) - 2) if len(p) > 1 else 0
+        if len(p) < 2:
+            return 0.0
+        return p[i] + (p[i + 1] - p[i]) * min(w - i, 1.0) if w < len(p) - 1 else p[-1]
+
+    def cost_fn(chrom, begin, end):
+        return at(chrom, end) - at(chrom, begin)
+
+    return cost_fn
+
+
+def plan_regions(regions, cost_fn, world_size, bins_per_worker=BIN_PER_THREAD, balance=1.1, max_bins_per_worker=64):
+    """Cut `regions` [(chrom, begin, end), ...] (BED targets or whole contigs, genome order) into bins and deal them
+    to `world_size` workers.
+
+    The reference (lofreq2_call_pparallel.py:590-613) splits the LONGEST bin in half until the biggest is shorter
+    than total / (BIN_PER_THREAD * threads), then lets a process pool take bins longest first (:307-312).  Here the
+    same greedy loop runs on COST instead of length (cost_fn: sum of depth + a DP term, make_cost_fn) -- equal
+    lengths are the special case of uniform cost -- and, because one process per GPU owns its bins for the whole
+    run instead of pulling from a pool, the dealing is the pool's schedule computed up front: bins in descending
+    cost, each to the least loaded worker (LPT).  Splitting continues past the reference's 2 bins per worker until
+    the heaviest worker is within `balance` of the mean (or `max_bins_per_worker` is reached).
+
+    -> (bins, owner): bins in genome order [(chrom, begin, end)], owner[i] = worker of bin i."""
+    bins = [(c, int(b), int(e)) for c, b, e in regions if int(e) > int(b)]
+    if not bins:
+        return [], []
+    order = {}
+    for c, _, _ in bins:
+        order.setdefault(c, len(order))
+    costs = [float(cost_fn(*b)) for b in bins]
+    total = sum(costs)
+
+    def deal(costs):
+        load = [0.0] * world_size
+        owner = [0] * len(costs)
+        for i in sorted(range(len(costs)), key=lambda i: -costs[i]):
+            w = min(range(world_size), key=lambda r: load[r])
+            owner[i] = w
+            load[w] += costs[i]
+        return owner, load
+
+    target = bins_per_worker
+    while True:
+        # the reference's loop: split the most expensive bin until it is below total / (target * workers)
+        while True:
+            i = max(range(len(bins)), key=lambda i: costs[i])
+            c, b, e = bins[i]
+            if costs[i] < total / (target * world_size) or e - b < 2 * MIN_BIN_LEN:
+                break
+            mid = (b + e) // 2
+            bins[i:i + 1] = [(c, b, mid), (c, mid, e)]
+            costs[i:i + 1] = [float(cost_fn(c, b, mid)), float(cost_fn(c, mid, e))]
+        owner, load = deal(costs)
+        mean = total / world_size if total > 0 else 0.0
+        if mean <= 0 or max(load) <= balance * mean or target >= max_bins_per_worker:
+            break
+        if all(e - b < 2 * MIN_BIN_LEN for _, b, e in bins):
+            break
+        target *= 2
+    idx = sorted(range(len(bins)), key=lambda i: (order[bins[i][0]], bins[i][1]))
+    return [bins[i] for i in idx], [owner[i] for i in idx]
+
+
 def exchange_counts(local_counts, dist=None, device=None):
     """One all-gather of a small int64 vector per rank ({tested SNV columns, indel tests}).
     -> (array [world, len(local_counts)], exclusive prefix of this rank as an array)."""
@@ -123,3 +212,33 @@ def finish_indel_shard(conf, bonf_indel_start, records, n_tests_local, col_offse
         conf.c.bonf_indel = int(bonf_indel_start) + total
     conf.c.num_indel_tests += total - int(n_tests_local)
     return gather_records(rec, col_offset, dist, device), total
+
+
+def finish_bins(conf, my_bins, n_bins_total, dist=None, device=None):
+    """Sharded step over call-parallel style bins (plan_regions): this rank ran the kernels of `my_bins` =
+    [(bin_index, col_offset, sparse pvals, n_tested), ...], every bin as its own batch starting from the same
+    conf.bonf_subst.  One all-gather of the per-bin tested-column counts gives every bin its exact running
+    Bonferroni prefix (the bins before it in genome order, whoever ran them); records are finalised per bin,
+    gathered, and put into genome order on rank 0.  conf ends up as after the single-process loop."""
+    counts = np.zeros(int(n_bins_total), np.int64)
+    for b, _, _, n_tested in my_bins:
+        counts[b] = int(n_tested)
+    allc, _ = exchange_counts(counts, dist, device)
+    per_bin = allc.sum(axis=0)                       # every bin is owned by exactly one rank
+    prefix = np.concatenate([[0], np.cumsum(per_bin)[:-1]])
+    parts = []
+    for b, col_offset, pvals, _ in my_bins:
+        pv = rebase_bonferroni(pvals, int(prefix[b])) if conf.bonf_dynamic else pvals
+        r = finalize_pvals(conf, pv, None)
+        r["col"] += int(col_offset)
+        parts.append(r)
+    mine = np.concatenate(parts) if parts else np.zeros(0, _lib.SNV_RECORD_DTYPE)
+    allrecs = gather_records(mine, 0, dist, device)
+    if allrecs is not None and len(allrecs):
+        allrecs = allrecs[np.argsort(allrecs["col"], kind="stable")]
+    total = int(per_bin.sum())
+    if total > 0:
+        if conf.bonf_dynamic:
+            conf.c.bonf_subst = (0 if conf.c.bonf_subst == 1 else conf.c.bonf_subst) + 3 * total
+        conf.c.num_snv_tests += 3 * total
+    return allrecs, total

@@ -28,3 +28,16 @@ def caller():
     c = la.SnvCaller(0)
     yield c
     c.close()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """largest p-value deviation observed per regime (tests/util.py::assert_pvalue_close)"""
+    try:
+        import util
+    except ImportError:
+        return
+    rows = [(k, v) for k, v in util.PV_ERR_MAX.items() if v[1]]
+    if rows:
+        terminalreporter.write_line("p-value parity, max |dlog p| observed (tolerance 1e-10 up to |log p| = 600, 1e-9 beyond):")
+        for k, v in rows:
+            terminalreporter.write_line("    %-16s %.3g over %d records" % (k, v[0], v[1]))

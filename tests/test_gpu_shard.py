@@ -1,0 +1,86 @@
+"""-m gpu: the sharded path with REAL kernels -- two processes (gloo rendezvous on 127.0.0.1), each with its own
+context on the one GPU of the box, running the bins shard.plan_regions deals them on a synthetic genome; rank 0's
+merged records must be byte-identical to the single-process call of the whole genome (running Bonferroni factor,
+QUAL, strand bias, order).  SURVEY 8e; the reference's own check is tests/parallel.sh:40-51."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+SEED, DEPTH, NCOLS, PERIOD = 0x9E3779B97F4A7C15 ^ (5 << 32), 600, 24000, 53
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_bin(la, caller, dev, lo, hi):
+    """layer 1 on one bin's columns (generated in HBM) -> (sparse records, tested columns)"""
+    conf = la.VarcallConf()
+    n = hi - lo
+    batch = caller.synth_batch(SEED, DEPTH, n, plant_period=PERIOD, col_begin=lo)
+    d_counts = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+    d_pvals = torch.zeros(n * 128, dtype=torch.uint8, device=dev)
+    caller.snv_batch_device(batch, conf, d_counts, d_pvals, n)
+    st = caller.batch_finish()
+    pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE).copy()
+    return pv, int(st.n_tested)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    dev = torch.device("cuda", 0)
+    caller = la.SnvCaller(0)
+    # the second half of the genome counts double: bins of unequal length, interleaved owners
+    cost = lambda c, b, e: float((e - b) + max(0, e - max(b, NCOLS // 2)))
+    bins, owner = shard.plan_regions([("synth", 0, NCOLS)], cost, world)
+    mine = []
+    for i, ((_, lo, hi), o) in enumerate(zip(bins, owner)):
+        if o == rank:
+            pv, n_tested = _run_bin(la, caller, dev, lo, hi)
+            mine.append((i, lo, pv, n_tested))
+    conf = la.VarcallConf()
+    recs, total = shard.finish_bins(conf, mine, len(bins), dist, None)
+    if rank == 0:
+        np.save(out, recs.view(np.uint8))
+        np.save(out + ".meta", np.array([total, conf.bonf_subst, conf.num_snv_tests, len(bins)]))
+    caller.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import lofreq_amd as la
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out).view(la.SNV_RECORD_DTYPE)
+    total, bonf, ntests, nbins = np.load(out + ".meta.npy")
+    caller = la.SnvCaller(0)
+    conf = la.VarcallConf()
+    exp, _, st = caller.call_snvs(caller.synth_batch(SEED, DEPTH, NCOLS, plant_period=PERIOD), conf)
+    caller.close()
+    assert nbins >= 4
+    assert total == st.n_tested and bonf == conf.bonf_subst and ntests == conf.num_snv_tests
+    assert len(exp) > 100 and len(got) == len(exp)
+    for k in la.SNV_RECORD_DTYPE.names:
+        if k != "pad_":
+            assert (got[k] == exp[k]).all(), k

@@ -47,6 +47,7 @@ def _scenario(la):
     cand = np.nonzero(tested & (rng.random(ncols) < 0.03))[0]
     ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, ncols)].copy()
     pv = _fake_pvals(la, rng, cand, 3 * prefix[cand])
+    pv["ref_base"] = ref[cand]                      # device records carry their column's reference base
     return ncols, tested, prefix, ref, pv
 
 
@@ -154,3 +155,104 @@ def test_sharded_indels_equal_single_process(tmp_path, world):
     assert len(got) == len(exp)
     for k in la.INDEL_RECORD_DTYPE.names:            # field-wise: the long double carries 6 padding bytes
         assert (got[k] == exp[k]).all(), k
+
+
+# ---- call-parallel style bins (shard.plan_regions / finish_bins) --------------------------------------------
+
+def _exome_like(rng, length=3_000_000, n_targets=1200):
+    """BED-like targets with ragged depth (log-normal per target) and a few K-heavy positions"""
+    depth = np.zeros(length)
+    kest = np.zeros(length)
+    regions, pos = [], 0
+    for _ in range(n_targets):
+        pos += int(rng.integers(150, 2500))
+        ln = int(rng.integers(100, 2500))
+        if pos + ln >= length:
+            break
+        regions.append(("chr1" if pos < length // 2 else "chr2", pos, pos + ln))
+        depth[pos:pos + ln] = rng.lognormal(5.0, 1.0)
+        pos += ln
+    hot = rng.integers(0, length, 200)
+    kest[hot] = rng.integers(5, 3000, 200)
+    return regions, {"chr1": depth, "chr2": depth}, {"chr1": kest, "chr2": kest}
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_plan_regions_balances_ragged_targets(world):
+    """SURVEY 8e / lofreq2_call_pparallel.py:590-613: >= 2 bins per worker, greedy split of the biggest, dealt longest
+    first; balanced by sum of depth + a DP term to within 10 % of the mean on an exome-like BED"""
+    from lofreq_amd import shard
+    rng = np.random.default_rng(5)
+    regions, depth, kest = _exome_like(rng)
+    cost = shard.make_cost_fn(depth, kest)
+    bins, owner = shard.plan_regions(regions, cost, world)
+    # the bins tile the targets exactly, in genome order
+    assert bins == sorted(bins, key=lambda b: (b[0] != "chr1", b[1]))
+    covered = {}
+    for c, b, e in bins:
+        assert e > b
+        covered.setdefault(c, []).append((b, e))
+    want = {}
+    for c, b, e in regions:
+        want.setdefault(c, []).append((b, e))
+    for c in want:
+        merged = []
+        for b, e in sorted(covered[c]):
+            if merged and merged[-1][1] == b and not any(b == wb for wb, _ in want[c]):
+                merged[-1] = (merged[-1][0], e)
+            else:
+                merged.append((b, e))
+        assert merged == sorted(want[c]), c
+    load = np.zeros(world)
+    for b, o in zip(bins, owner):
+        load[o] += cost(*b)
+    assert load.max() <= 1.1 * load.mean(), (load.max() / load.mean())
+    assert np.bincount(owner, minlength=world).min() >= shard.BIN_PER_THREAD
+    # one uniform contig: the reference's own rule (split while the biggest is not below total / (2 * workers))
+    bins, owner = shard.plan_regions([("synth", 0, 8_000_000)], lambda c, b, e: 1e4 * (e - b), world)
+    assert len(bins) == 4 * world and sorted(np.bincount(owner)) == [4] * world
+    assert all(e - b == 8_000_000 // (4 * world) for _, b, e in bins)
+
+
+def _bins_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    ncols, tested, prefix, ref, pv = _scenario(la)
+    # ragged cost: the second half of the genome is four times as expensive
+    cost = lambda c, b, e: float((e - b) + 3 * max(0, e - max(b, ncols // 2)))
+    bins, owner = shard.plan_regions([("g", 0, ncols)], cost, world)
+    mine = []
+    for i, ((_, lo, hi), o) in enumerate(zip(bins, owner)):
+        if o != rank:
+            continue
+        p = pv[(pv["col"] >= lo) & (pv["col"] < hi)].copy()
+        p["col"] -= lo                               # every bin is its own batch: local columns, local factors
+        p["bonf"] -= 3 * int(tested[:lo].sum())
+        mine.append((i, lo, p, int(tested[lo:hi].sum())))
+    conf = la.VarcallConf()
+    recs, total = shard.finish_bins(conf, mine, len(bins), dist, None)
+    if rank == 0:
+        np.save(out, recs.view(np.uint8))
+        np.save(out + ".meta", np.array([total, conf.bonf_subst, conf.num_snv_tests, len(bins)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bins_equal_single_process(tmp_path, world):
+    """interleaved bins of several ranks: per-bin exact Bonferroni prefix + genome-order merge == one process"""
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    out = str(tmp_path / "brecs.npy")
+    mp.spawn(_bins_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out).view(la.SNV_RECORD_DTYPE)
+    total, bonf, ntests, nbins = np.load(out + ".meta.npy")
+    ncols, tested, prefix, ref, pv = _scenario(la)
+    conf = la.VarcallConf()
+    exp, total1 = shard.finish_shard(conf, pv, int(tested.sum()), ref, 0, None, None)
+    assert nbins >= 2 * world
+    assert total == total1 and bonf == conf.bonf_subst and ntests == conf.num_snv_tests
+    assert len(got) == len(exp) and got.tobytes() == exp.tobytes()

@@ -149,14 +149,34 @@ def log_of(pv):
     return float(np.log(np.longdouble(pv)))
 
 
-def assert_pvalue_close(pv_gpu, pv_ref, tol=PV_LOG_TOL, ctx=""):
-    """Sentinels must match exactly; finite values within `tol` relative."""
+# Tolerance per record (north_star: 1e-10 relative).  The reference's log-space recurrence carries its own rounding
+# noise of about ulp(|log p|) * sqrt(N) -- measured against an 80-bit exact recurrence in
+# test_oracle_kat.py::test_linear_dp_truth_and_reference_noise: 2.6e-11 at log p = -144, 2.7e-10 at log p = -3670
+# (N = 1e4) -- so beyond |log p| = 600 (p < 1e-260) no independent implementation can agree with it to 1e-10 and the
+# bar there is 1e-9; everything else, i.e. every p-value that decides a call or a QUAL below 2600, is held to 1e-10.
+PV_DEEP_LOG = 600.0
+PV_DEEP_TOL = 1e-9
+PV_ERR_MAX = {"|log p| <= 600": [0.0, 0], "|log p| > 600": [0.0, 0]}     # [max observed |dlog|, records compared]
+
+
+def pv_tol_for(pv_ref):
+    return PV_DEEP_TOL if abs(log_of(pv_ref)) > PV_DEEP_LOG else PV_LOG_TOL
+
+
+def assert_pvalue_close(pv_gpu, pv_ref, tol=None, ctx=""):
+    """Sentinels must match exactly; finite values within `tol` relative (default: per record, by |log p|)."""
     pv_gpu, pv_ref = np.longdouble(pv_gpu), np.longdouble(pv_ref)
     if pv_ref == LDBL_MAX or pv_ref == LDBL_MIN or pv_gpu == LDBL_MAX or pv_gpu == LDBL_MIN:
         assert pv_gpu == pv_ref, "sentinel mismatch %s: gpu=%r ref=%r" % (ctx, pv_gpu, pv_ref)
         return
     d = abs(log_of(pv_gpu) - log_of(pv_ref))
-    assert d <= tol, "p-value mismatch %s: gpu=%r ref=%r |dlog|=%g" % (ctx, pv_gpu, pv_ref, d)
+    deep = abs(log_of(pv_ref)) > PV_DEEP_LOG
+    if tol is None:
+        tol = PV_DEEP_TOL if deep else PV_LOG_TOL
+    st = PV_ERR_MAX["|log p| > 600" if deep else "|log p| <= 600"]
+    st[0] = max(st[0], d)
+    st[1] += 1
+    assert d <= tol, "p-value mismatch %s: gpu=%r ref=%r |dlog|=%g (tolerance %g)" % (ctx, pv_gpu, pv_ref, d, tol)
 
 
 def random_indel_columns(rng, ncols, depth_lo=20, depth_hi=400, p_event=0.5, polyat=False):
