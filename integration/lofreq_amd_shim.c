@@ -1,7 +1,10 @@
 /*
  * lofreq_amd_shim.c -- the binding a LoFreq maintainer adds to src/lofreq/ to route `lofreq call`'s SNV
  * path through liblofreq_amd.so.  Compiled inside the LoFreq tree (it needs LoFreq's own plp.h /
- * snpcaller.h / vcf.h and therefore htslib); NOT built in this repository.
+ * snpcaller.h / vcf.h and therefore htslib).  In this repository it is exercised by tests/test_shim.py (where the
+ * reference tree is mounted): compiled against the reference's own headers, driven by a mock mpileup that rebuilds
+ * plp_col_t columns from the golden fixtures with the reference's own int_varray / uthash helpers (utils.c), and
+ * checked against the packed batches tests/golden_util.py builds from the same fixtures.
  *
  *   lofreq_call.c:1474     plp_proc_func = &call_vars;     ->   plp_proc_func = &lfq_call_vars;
  *   lofreq_call.c:1477     rc = mpileup(&mplp_conf, plp_proc_func, (void*)&varcall_conf, 1, &bam);
@@ -37,7 +40,29 @@ extern long long int num_indel_tests;                     /* lofreq_call.c:85 */
 extern long int indel_calls_wo_idaq;                      /* lofreq_call.c:88 */
 
 #define LFQ_BATCH_COLS (1 << 20)        /* flush every 2^20 columns (or at the end) */
+#define LFQ_BATCH_OBS ((int64_t)1 << 30) /* ... or when a track holds 1 GiB: 100 000 columns at 10 000x (5 GiB of host
+                                          * tracks, one staging allocation of that size on the device) */
 #define LFQ_BATCH_INDEL_READS (1 << 28) /* ... or when the flattened indel columns hold this many reads */
+
+/* allocation results are checked: running out of host memory is a LOG_FATAL like everywhere else in LoFreq */
+static void *lfq_xrealloc(void *p, size_t n)
+{
+    void *q = realloc(p, n ? n : 1);
+    if (!q) {
+        LOG_FATAL("lofreq_amd: out of memory (%lu bytes)\n", (unsigned long)n);
+        exit(1);
+    }
+    return q;
+}
+static char *lfq_xstrdup(const char *s)
+{
+    char *q = strdup(s);
+    if (!q) {
+        LOG_FATAL("%s\n", "lofreq_amd: out of memory");
+        exit(1);
+    }
+    return q;
+}
 
 typedef struct {
     lfq_ctx *ctx;
@@ -65,7 +90,7 @@ static void *vpush(vec *v, int64_t k)
 {
     if (v->n + k > v->cap) {
         while (v->n + k > v->cap) v->cap = v->cap ? 2 * v->cap : 1024;
-        v->p = realloc(v->p, (size_t)v->cap * v->elt);
+        v->p = lfq_xrealloc(v->p, (size_t)v->cap * v->elt);
     }
     v->n += k;
     return (char *)v->p + (size_t)(v->n - k) * v->elt;
@@ -145,7 +170,7 @@ static void indel_add_column(const plp_col_t *p, int64_t seq)
     *(int32_t *)vpush(&I.pos, 1) = p->pos;
     *(int32_t *)vpush(&I.has_aq, 1) = p->has_indel_aqs;
     *(int64_t *)vpush(&I.seq, 1) = seq;
-    *(char **)vpush(&I.target, 1) = strdup(p->target);
+    *(char **)vpush(&I.target, 1) = lfq_xstrdup(p->target);
     *(int32_t *)vpush(&I.sd[0].non_fw, 1) = (int32_t)p->non_ins_fw_rv[0];
     *(int32_t *)vpush(&I.sd[0].non_rv, 1) = (int32_t)p->non_ins_fw_rv[1];
     *(int32_t *)vpush(&I.sd[1].non_fw, 1) = (int32_t)p->non_del_fw_rv[0];
@@ -191,7 +216,7 @@ static lfq_indel_record *indel_flush(varcall_conf_t *conf, lfq_conf *lc, int64_t
         o->rd_aq = v->rd_aq.p;  o->rd_mq = v->rd_mq.p;  o->rd_sq = v->rd_sq.p;
     }
     nev = I.sd[0].ev_fw.n + I.sd[1].ev_fw.n;
-    rec = malloc(sizeof(lfq_indel_record) * (size_t)(nev + 1));
+    rec = lfq_xrealloc(NULL, sizeof(lfq_indel_record) * (size_t)(nev + 1));
     rc = lfq_call_indels_batch(B.ctx, lc, &c, rec, nev, n_rec, &ntests);
     if (rc != LFQ_OK) {
         LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
@@ -208,7 +233,8 @@ static void indel_print(varcall_conf_t *conf, const lfq_indel_record *r)
     const int64_t *koff = v->key_off.p;
     const int64_t kl = koff[r->event + 1] - koff[r->event];
     const char rb = (char)((uint8_t *)I.ref_base.p)[r->col];
-    char *ref = malloc((size_t)kl + 2), *alt = malloc((size_t)kl + 2), *line = malloc((size_t)kl * 2 + 1024);
+    char *ref = lfq_xrealloc(NULL, (size_t)kl + 2), *alt = lfq_xrealloc(NULL, (size_t)kl + 2);
+    char *line = lfq_xrealloc(NULL, (size_t)kl * 2 + 1024);
     ref[0] = alt[0] = rb;                                    /* ins_to_str / del_to_str (lofreq_call.c:255-303) */
     memcpy((r->side == 0 ? alt : ref) + 1, (const char *)v->key_chars.p + koff[r->event], (size_t)kl);
     (r->side == 0 ? alt : ref)[kl + 1] = 0;
@@ -241,22 +267,22 @@ static void grow_obs(int64_t need)
 {
     if (need <= B.cap_obs) return;
     while (B.cap_obs < need) B.cap_obs = B.cap_obs ? 2 * B.cap_obs : (1 << 24);
-    B.nt = realloc(B.nt, B.cap_obs);  B.bq = realloc(B.bq, B.cap_obs);
-    B.baq = realloc(B.baq, B.cap_obs); B.mq = realloc(B.mq, B.cap_obs);
-    B.sq = realloc(B.sq, B.cap_obs);
+    B.nt = lfq_xrealloc(B.nt, B.cap_obs);  B.bq = lfq_xrealloc(B.bq, B.cap_obs);
+    B.baq = lfq_xrealloc(B.baq, B.cap_obs); B.mq = lfq_xrealloc(B.mq, B.cap_obs);
+    B.sq = lfq_xrealloc(B.sq, B.cap_obs);
 }
 
 static void grow_cols(int64_t need)
 {
     if (need <= B.cap_cols) return;
     while (B.cap_cols < need) B.cap_cols = B.cap_cols ? 2 * B.cap_cols : (1 << 16);
-    B.col_off = realloc(B.col_off, (B.cap_cols + 1) * sizeof(uint64_t));
-    B.ref_base = realloc(B.ref_base, B.cap_cols);
-    B.cov = realloc(B.cov, B.cap_cols * sizeof(int32_t));
-    B.nbases = realloc(B.nbases, B.cap_cols * sizeof(int32_t));
-    B.target = realloc(B.target, B.cap_cols * sizeof(char *));
-    B.pos = realloc(B.pos, B.cap_cols * sizeof(int));
-    B.seq = realloc(B.seq, B.cap_cols * sizeof(int64_t));
+    B.col_off = lfq_xrealloc(B.col_off, (B.cap_cols + 1) * sizeof(uint64_t));
+    B.ref_base = lfq_xrealloc(B.ref_base, B.cap_cols);
+    B.cov = lfq_xrealloc(B.cov, B.cap_cols * sizeof(int32_t));
+    B.nbases = lfq_xrealloc(B.nbases, B.cap_cols * sizeof(int32_t));
+    B.target = lfq_xrealloc(B.target, B.cap_cols * sizeof(char *));
+    B.pos = lfq_xrealloc(B.pos, B.cap_cols * sizeof(int));
+    B.seq = lfq_xrealloc(B.seq, B.cap_cols * sizeof(int64_t));
 }
 
 static void conf_to_lfq(const varcall_conf_t *c, lfq_conf *o)
@@ -297,7 +323,7 @@ void lfq_call_flush(varcall_conf_t *conf)
     t.coverage_plp = B.cov; t.num_bases = B.nbases;
     t.ncols = B.ncols; t.max_col_obs = B.max_depth;
 
-    rec = malloc(sizeof(lfq_snv_record) * (size_t)(3 * B.ncols));
+    rec = lfq_xrealloc(NULL, sizeof(lfq_snv_record) * (size_t)(3 * B.ncols));
     rc = lfq_call_snvs_batch(B.ctx, &lc, &t, /*tracks_on_device=*/0, rec, 3 * B.ncols, &n_rec, NULL, NULL);
     if (rc != LFQ_OK) {
         LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
@@ -349,7 +375,7 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
     B.ref_base[c] = (uint8_t)p->ref_base;
     B.cov[c] = p->coverage_plp;
     B.nbases[c] = p->num_bases;
-    B.target[c] = strdup(p->target);
+    B.target[c] = lfq_xstrdup(p->target);
     B.pos[c] = p->pos;
     B.seq[c] = g_seq;
     for (i = 0; i < NUM_NT4; i++) {            /* plp_col_t keeps one int array per nucleotide (plp.h:88-91) */
@@ -371,13 +397,30 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
     if (depth > B.max_depth) B.max_depth = depth;
     B.ncols++;
 maybe_flush:
-    if (B.ncols >= LFQ_BATCH_COLS || (I.init && I.sd[0].ne_q.n + I.sd[1].ne_q.n >= LFQ_BATCH_INDEL_READS)) {
+    if (B.ncols >= LFQ_BATCH_COLS || B.nobs >= LFQ_BATCH_OBS
+        || (I.init && I.sd[0].ne_q.n + I.sd[1].ne_q.n >= LFQ_BATCH_INDEL_READS)) {
         lfq_call_flush(conf);
     }
 }
 
 void lfq_call_shutdown(void)
 {
+    int s;
+    vec *iv[] = {&I.ref_base, &I.cov, &I.tails, &I.non_indels, &I.num_ins, &I.num_dels, &I.hrun, &I.seq, &I.pos,
+                 &I.has_aq, &I.target};
+    size_t k;
     if (B.ctx) lfq_destroy(B.ctx);
+    free(B.nt); free(B.bq); free(B.baq); free(B.mq); free(B.sq);
+    free(B.col_off); free(B.ref_base); free(B.cov); free(B.nbases); free(B.target); free(B.pos); free(B.seq);
     memset(&B, 0, sizeof(B));
+    if (I.init) {
+        for (k = 0; k < sizeof(iv) / sizeof(iv[0]); k++) free(iv[k]->p);
+        for (s = 0; s < 2; s++) {
+            side_vecs *v = &I.sd[s];
+            vec *sv[] = {&v->non_fw, &v->non_rv, &v->ne_off, &v->ne_q, &v->ne_mq, &v->ev_off, &v->key_off, &v->key_chars,
+                         &v->ev_fw, &v->ev_rv, &v->rd_off, &v->rd_q, &v->rd_aq, &v->rd_mq, &v->rd_sq};
+            for (k = 0; k < sizeof(sv) / sizeof(sv[0]); k++) free(sv[k]->p);
+        }
+        memset(&I, 0, sizeof(I));
+    }
 }

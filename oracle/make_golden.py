@@ -40,7 +40,14 @@ def write_fixture(tmp, seed, glen, nreads, planted, mapqs, min_q=3):
             if rng.random() < 10 ** (-qual[j] / 10.0):
                 seq[j] = rng.choice([c for c in "ACGT" if c != seq[j]])
             p = planted.get(pos + j)
-            if p and rng.random() < p[1]:
+            if isinstance(p, list):              # several planted alleles at one position: [(base, frac), ...]
+                u = rng.random()
+                for base, frac in p:
+                    if u < frac:
+                        seq[j] = base
+                        break
+                    u -= frac
+            elif p and rng.random() < p[1]:
                 seq[j] = p[0]
         flag = 16 if rng.random() < 0.5 else 0
         reads.append((pos, flag, int(rng.choice(mapqs)), "".join(seq), "".join(chr(33 + q) for q in qual)))
@@ -81,7 +88,9 @@ def enc(vals):
     return "".join(" " if v < 0 else chr(33 + v) for v in vals)
 
 
-def run(name, seed, glen, nreads, planted, mapqs, call_args):
+def run(name, seed, glen, nreads, planted, mapqs, call_args, keep_cols=None):
+    """keep_cols: store only these positions (and their VCF lines) -- for deep fixtures, where every column is
+    10 000 observations; needs a fixed Bonferroni factor in call_args so that columns are independent"""
     with tempfile.TemporaryDirectory() as tmp:
         genome = write_fixture(tmp, seed, glen, nreads, planted, mapqs)
         subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
@@ -98,15 +107,22 @@ def run(name, seed, glen, nreads, planted, mapqs, call_args):
                 ntests = int(line.split(":")[-1])
         vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
     cols = parse_plpsummary(plp)
+    if keep_cols is not None:
+        assert "-b" in call_args
+        cols = [c for c in cols if c["pos0"] in keep_cols]
+        vcf = [l for l in vcf if int(l.split("\t")[1]) - 1 in keep_cols]
     packed = []
     for c in cols:
         o = {}
         for nt, tr in c["obs"].items():
+            mq = tr.get("MQ", [])
             o[nt] = {"bq": enc(tr.get("BQ", [])), "baq": enc(tr["BAQ"]) if "BAQ" in tr else None,
-                     "mq": tr.get("MQ", [])}
+                     "mq": enc(mq) if keep_cols is not None and max(mq + [0]) <= 93 else mq}
         packed.append({"pos0": c["pos0"], "ref": c["ref"], "fwrv": c["fwrv"], "obs": o})
     fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
            "call_args": call_args, "genome": genome, "columns": packed, "vcf": vcf, "num_snv_tests": ntests}
+    if keep_cols is not None:
+        fix["column_subset"] = True          # num_snv_tests counts every column of the run, not only the stored ones
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".json")
     json.dump(fix, open(path, "w"), separators=(",", ":"))
@@ -647,6 +663,8 @@ def main():
         return main_plpindel()
     if "--uniq-only" in sys.argv:
         return main_uniq()
+    if "--deep10k-only" in sys.argv:
+        return main_deep10k()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
@@ -662,10 +680,21 @@ def main():
     run("snv_deep", 14, 160, 1800, planted_b, [60] * 12 + [50, 3], ["--no-default-filter", "-b", "480"])
     run("snv_minbq_sig", 15, 220, 600, planted_a, mq_mix, ["-q", "20", "-Q", "25", "-a", "0.001", "-b", "660",
                                                          "--no-default-filter"])
+    main_deep10k()
     main_indels()
     main_baq()
     main_chain()
     main_pileup()
+
+
+def main_deep10k():
+    """BASELINE.json configs[2] regime on the reference binary itself: 10 000 reads covering positions 30..99 of a
+    130 bp contig (depth 10 000 there), planted 0.5 / 1 / 5 / 50 % alleles, two columns with a second, minor allele
+    (QUAL 49314, the FE-clamp quirk that loses or keeps minor alleles).  14 of the columns stored."""
+    planted = {40: ("A", 0.005), 45: ("C", 0.01), 50: ("G", 0.05), 55: ("T", 0.5),
+               60: [("A", 0.5), ("C", 0.006)], 65: [("G", 0.05), ("T", 0.01)], 72: ("C", 0.002), 80: [("A", 0.3), ("G", 0.3)]}
+    keep = {38, 39, 40, 41, 45, 50, 55, 60, 65, 70, 72, 75, 80, 90}
+    run("snv_deep10k", 16, 130, 10000, planted, [60] * 18 + [40, 20], ["--no-default-filter", "-b", "390"], keep_cols=keep)
 
 
 if __name__ == "__main__":

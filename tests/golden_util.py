@@ -55,7 +55,7 @@ def load(path):
             strand = (np.arange(n) >= fw).astype(np.uint8)
             nts.append((np.full(n, code, np.uint8)) | (strand << 3))
             bqs.append(bq.astype(np.uint8))
-            mqs.append(np.asarray(o["mq"], np.uint8))
+            mqs.append((dec(o["mq"]) if isinstance(o["mq"], str) else np.asarray(o["mq"])).astype(np.uint8))
             if has_baq:
                 b = dec(o["baq"])
                 baqs.append(np.where(b < 0, 255, b).astype(np.uint8))

@@ -14,7 +14,8 @@ def test_oracle_reproduces_reference_binary(oracle, path):
     conf = oracle.default_conf(raw_counts_after_minbq=1, **kw)     # 2.1.4 counted raw alts after min_bq
     res, _ = oracle.call_batch(host["nt"], host["bq"], host["baq"], host["mq"], None, host["col_off"],
                                host["ref_base"], conf)
-    assert conf.num_snv_tests == fx["num_snv_tests"]
+    if not fx.get("column_subset"):      # deep fixtures store a subset of the run's columns (fixed Bonferroni factor)
+        assert conf.num_snv_tests == fx["num_snv_tests"]
     L = oracle.lib()
     recs = []
     for c in range(len(res)):

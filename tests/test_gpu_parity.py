@@ -219,7 +219,8 @@ def test_golden_reference_binary_vcf(caller, oracle):
         kw, no_default_filter = gu.conf_kwargs(fx["call_args"])
         conf = la.VarcallConf(**kw)
         recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
-        assert conf.num_snv_tests == fx["num_snv_tests"], path
+        if not fx.get("column_subset"):
+            assert conf.num_snv_tests == fx["num_snv_tests"], path
         dynamic = bool(conf.bonf_dynamic)
         if no_default_filter and not dynamic:
             keep, filt = np.ones(len(recs), bool), None
