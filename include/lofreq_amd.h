@@ -452,6 +452,21 @@ int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thr
 int lfq_uniq_detlim_batch(lfq_ctx *ctx, const lfq_tracks *tracks, int tracks_on_device, const float *af,
                           uint8_t *detectable, long double *pvalue_or_null);
 
+/* --- `lofreq uniq`, default mode (uniq_snv's binomial branch, lofreq_uniq.c:335-393, + apply_uniq_filter_mtc, :140-206).
+ * Per column (the other sample's pileup at a variant's position, uniq's own mpileup settings as above): coverage =
+ * coverage_plp (tracks->coverage_plp, or the observation count), alt_count = the bases of nucleotide alt_base[col] in
+ * the column whatever their quality (base_count, plp.c:128-132; counted on the device), pvalue =
+ * binom(coverage, alt_count, af) = P(X <= alt_count), X ~ Binomial(coverage, af) (binom.c:52-69 -> cdflib90's cdfbin),
+ * uq_out[col] = PROB_TO_PHREDQUAL_SAFE(pvalue), the value of the UQ= INFO tag; -1 where the reference adds none
+ * (coverage < 1, or cdfbin rejects its arguments).  SNVs only (indel variants take their count from the event table,
+ * which is host data: lfq_indel_columns).  lfq_uniq_mtc then decides PASS / uq_<mtc> like apply_uniq_filter_mtc:
+ * mtc_type 1 bonf, 2 holm, 3 fdr (multtest.h; `lofreq uniq` defaults: fdr, alpha 0.001, ntests 0 = the number of
+ * variants).  lfq_binom_cdf is the scalar test itself (status: cdfbin's code, 0 = ok). */
+int lfq_uniq_binom_batch(lfq_ctx *ctx, const lfq_tracks *tracks, int tracks_on_device, const float *af,
+                         const char *alt_base, int32_t *uq_out, double *pvalue_or_null);
+int lfq_uniq_mtc(const int32_t *uq, int64_t n, int mtc_type, double alpha, int64_t ntests, uint8_t *pass);
+double lfq_binom_cdf(int n, int k, double pr, int *status_or_null);
+
 /* --- synthetic workload (bench / tests): fills device tracks per include/lofreq_synth.h --- */
 int lfq_synth_fill_device(lfq_ctx *ctx, uint64_t seed, uint32_t depth, uint32_t plant_period,
                           int64_t col_begin, int64_t ncols, uint8_t *d_nt, uint8_t *d_bq,

@@ -190,6 +190,21 @@ class SnvCaller:
         _lib.check(rc, "lfq_uniq_detlim_batch")
         return det[: batch.ncols], pv[: batch.ncols]
 
+    def uniq_binom(self, batch, af, alt_bases):
+        """`lofreq uniq` default mode (uniq_snv's binomial branch, lofreq_uniq.c:335-393) over a batch of columns:
+        af[col] / alt_bases[col] = the variant's allele frequency and alt nucleotide -> (UQ phred values int32, -1 = no
+        UQ tag; p-values float64)"""
+        t = batch._tracks()
+        af = np.ascontiguousarray(af, np.float32)
+        alt = np.frombuffer(alt_bases.encode() if isinstance(alt_bases, str) else bytes(alt_bases), np.uint8).copy()
+        assert len(af) == batch.ncols == len(alt)
+        uq = np.zeros(max(batch.ncols, 1), np.int32)
+        pv = np.zeros(max(batch.ncols, 1), np.float64)
+        rc = self.L.lfq_uniq_binom_batch(self.h, C.byref(t), 1 if batch.on_device else 0, C.c_void_p(af.ctypes.data),
+                                         C.c_void_p(alt.ctypes.data), C.c_void_p(uq.ctypes.data), C.c_void_p(pv.ctypes.data))
+        _lib.check(rc, "lfq_uniq_binom_batch")
+        return uq[: batch.ncols], pv[: batch.ncols]
+
     # -- layer 1: kernels only, device-resident in and out --------------------------------------
     def snv_batch_device(self, batch, conf, d_counts, d_pvals, pvals_capacity, stream=None):
         assert batch.on_device
@@ -309,6 +324,22 @@ def format_vcf(records, chrom, pos0=None, keep=None, filter_str=None):
     if n < 0 or n > len(buf):
         raise RuntimeError("lfq_format_vcf failed (%d)" % n)
     return buf.raw[:n].decode()
+
+
+def binom_cdf(n, k, pr):
+    """lfq_binom_cdf: (P(X <= k), X ~ Binomial(n, pr); cdfbin's status code)"""
+    st = C.c_int(0)
+    p = _lib.load().lfq_binom_cdf(int(n), int(k), float(pr), C.byref(st))
+    return p, st.value
+
+
+def uniq_mtc(uq, mtc_type="fdr", alpha=0.001, ntests=0):
+    """apply_uniq_filter_mtc (lofreq_uniq.c:140-206) on UQ phred values -> boolean PASS mask"""
+    uq = np.ascontiguousarray(uq, np.int32)
+    out = np.zeros(max(len(uq), 1), np.uint8)
+    _lib.check(_lib.load().lfq_uniq_mtc(C.c_void_p(uq.ctypes.data), len(uq), {"bonf": 1, "holm": 2, "fdr": 3}[mtc_type],
+                                        float(alpha), int(ntests), C.c_void_p(out.ctypes.data)), "lfq_uniq_mtc")
+    return out[: len(uq)].astype(bool)
 
 
 def snvqual_thresh(sig, bonf_subst):

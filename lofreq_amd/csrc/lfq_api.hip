@@ -2498,6 +2498,69 @@ int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device
     return LFQ_OK;
 }
 
+/* uniq_snv's default branch for a batch of columns (lofreq_uniq.c:254-256, 335-393): the device counts the bases of
+ * every nucleotide (base_count, plp.c:128-132); coverage, the binomial test and the phred value are per-variant scalar
+ * work on the host */
+int lfq_uniq_binom_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, const float *af, const char *alt_base,
+                         int32_t *uq_out, double *pvalue_or_null)
+{
+    if (!c || !tr || !af || !alt_base || !uq_out || tr->ncols < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    const int64_t ncols = tr->ncols;
+    if (ncols == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    lfq_tracks dev;
+    LFQ_TRY(stage_tracks(c, tr, tracks_on_device, &dev));
+    LfqTracksDev T;
+    memset(&T, 0, sizeof(T));
+    T.nt = dev.nt;
+    T.bq = dev.bq;
+    T.col_off = dev.col_off;
+    T.ncols = ncols;
+    T.nt_packed = (dev.flags & LFQ_TRACKS_NT_PACKED) ? 1 : 0;
+    LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));             /* reused as int32[4] per column */
+    int32_t *d_nt = reinterpret_cast<int32_t *>(c->d_counts);
+    LFQ_TRY(lfq_launch_ntcount(T, d_nt, c->stream));
+    std::vector<int32_t> h_nt((size_t)ncols * 4);
+    std::vector<uint64_t> h_off((size_t)ncols + 1);
+    std::vector<int32_t> h_cov;
+    LFQ_TRY_HIP(hipMemcpyAsync(h_nt.data(), d_nt, (size_t)ncols * 16, hipMemcpyDeviceToHost, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(h_off.data(), dev.col_off, ((size_t)ncols + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (dev.coverage_plp) {
+        h_cov.resize((size_t)ncols);
+        LFQ_TRY_HIP(hipMemcpyAsync(h_cov.data(), dev.coverage_plp, (size_t)ncols * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < ncols; i++) {
+        uq_out[i] = -1;
+        if (pvalue_or_null) {
+            pvalue_or_null[i] = -1.0;
+        }
+        const int coverage = dev.coverage_plp ? h_cov[(size_t)i] : (int)(h_off[(size_t)i + 1] - h_off[(size_t)i]);
+        if (coverage < 1) {
+            continue;                                           /* :254-256 */
+        }
+        const char ab = alt_base[i];
+        const int code = (ab == 'A' || ab == 'a') ? 0 : (ab == 'C' || ab == 'c') ? 1 : (ab == 'G' || ab == 'g') ? 2
+                         : (ab == 'T' || ab == 't') ? 3 : 4;
+        /* bam_nt4_table sends everything else to N, whose bases are in no ACGT count; they stay uncounted here too */
+        const int alt_count = code < 4 ? h_nt[(size_t)i * 4 + code] : 0;
+        int st = 0;
+        const double pv = lfq_binom_cdf(coverage, alt_count, (double)af[i], &st);   /* :381; one-sided */
+        if (st != 0) {
+            continue;                                           /* "binom() failed": no UQ tag */
+        }
+        uq_out[i] = phred_safe(pv);                             /* :386 */
+        if (pvalue_or_null) {
+            pvalue_or_null[i] = pv;
+        }
+    }
+    return LFQ_OK;
+}
+
 int lfq_pileup_skip_snv_columns(lfq_ctx *c, const uint8_t *skip, int64_t ncols)
 {
     if (!c || !skip || ncols < 0 || !c->d_plp_out || ncols != c->plp_ncols) {

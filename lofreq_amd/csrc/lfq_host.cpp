@@ -804,6 +804,94 @@ int64_t lfq_fdr(const double *pvals, int64_t n, double alpha, int64_t num_tests,
     return nrej;
 }
 
+/* ---- `lofreq uniq`, default mode: the binomial test (binom.c:52-69 -> cdflib90's cdfbin, which = 1) ---------------
+ * P(X <= k) for X ~ Binomial(n, pr).  The reference goes through the regularised incomplete beta function (cumbin,
+ * dcdflib.c:4966-5031 -> bratio, TOMS 708); here the binomial probabilities themselves are summed in 80-bit
+ * arithmetic, from the largest term of the wanted tail outwards with the exact term ratios, until the terms no longer
+ * register: below the mode the lower tail directly, above it 1 - upper tail.  Agrees with the reference's compiled
+ * cdflib to ~1e-13 relative (tests/test_uniq.py); `status` gets cdfbin's code (0, -5 n <= 0, -4 k outside [0, n],
+ * -6 pr outside [0, 1]). */
+double lfq_binom_cdf(int n, int k, double pr, int *status_or_null)
+{
+    int st = 0;
+    double out = 0.0;
+    if (n <= 0) {
+        st = -5;
+    } else if (k < 0 || k > n) {
+        st = -4;
+    } else if (!(pr >= 0.0 && pr <= 1.0)) {
+        st = -6;
+    } else if (k >= n || pr <= 0.0) {
+        out = 1.0;                                  /* cumbin: s >= xn; cumbet: x <= 0 */
+    } else if (pr >= 1.0) {
+        out = 0.0;                                  /* all mass at n > k */
+    } else {
+        const long double N = n, P = pr, Q = 1.0L - P, odds = P / Q;
+        auto log_term = [&](int i) {
+            const long double I = i;
+            return lgammal(N + 1.0L) - lgammal(I + 1.0L) - lgammal(N - I + 1.0L) + I * logl(P) + (N - I) * log1pl(-P);
+        };
+        const int mode = (int)floorl((N + 1.0L) * P);
+        if (k < mode) {
+            /* lower tail, terms fall away from i = k downwards: t(i-1) / t(i) = i / (n - i + 1) / odds */
+            long double t = expl(log_term(k)), sum = t;
+            for (int i = k; i > 0 && t > sum * 1e-25L; i--) {
+                t *= (long double)i / (N - (long double)i + 1.0L) / odds;
+                sum += t;
+            }
+            out = (double)sum;
+        } else {
+            /* upper tail from i = k + 1 upwards: t(i+1) / t(i) = (n - i) / (i + 1) * odds */
+            long double t = expl(log_term(k + 1)), sum = t;
+            for (int i = k + 1; i < n && t > sum * 1e-25L; i++) {
+                t *= (N - (long double)i) / ((long double)i + 1.0L) * odds;
+                sum += t;
+            }
+            const long double r = 1.0L - sum;
+            out = (double)(r < 0.0L ? 0.0L : r);
+        }
+    }
+    if (status_or_null) {
+        *status_or_null = st;
+    }
+    return st ? 0.0 : out;
+}
+
+/* apply_uniq_filter_mtc (lofreq_uniq.c:140-206): PHREDQUAL_TO_PROB of the integer UQ values (no UQ tag = 0), bonf /
+ * holm / fdr over ntests (0 = the number of variants), filtered when the corrected value exceeds alpha.
+ * mtc_type as in multtest.h: 1 bonf, 2 holm, 3 fdr.  pass[i] = 1: the variant keeps PASS. */
+int lfq_uniq_mtc(const int32_t *uq, int64_t n, int mtc_type, double alpha, int64_t ntests, uint8_t *pass)
+{
+    if ((!uq || !pass) && n > 0) {
+        return LFQ_ERR_INVALID;
+    }
+    if (mtc_type < 1 || mtc_type > 3 || n < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    if (!ntests) {
+        ntests = n;
+    }
+    std::vector<double> pr((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        pr[(size_t)i] = phred_to_prob(uq[i] < 0 ? 0 : uq[i]);
+    }
+    if (mtc_type == 1) {
+        lfq_bonf_corr(pr.data(), n, ntests);
+    } else if (mtc_type == 2) {
+        lfq_holm_bonf_corr(pr.data(), n, alpha, ntests);
+    } else {
+        std::vector<int64_t> idx((size_t)std::max<int64_t>(n, 1));
+        const int64_t nrej = lfq_fdr(pr.data(), n, alpha, ntests, idx.data());
+        for (int64_t i = 0; i < nrej; i++) {
+            pr[(size_t)idx[(size_t)i]] = -1;
+        }
+    }
+    for (int64_t i = 0; i < n; i++) {
+        pass[i] = pr[(size_t)i] > alpha ? 0 : 1;
+    }
+    return LFQ_OK;
+}
+
 /* `lofreq filter` as `lofreq call` runs it on its own output (lofreq_call.c:1506-1538):
  * SNV QUAL threshold (lofreq_filter.c:313-323) and, unless --no-defaults, DP >= 10
  * (lofreq_filter.c:1095-1097, 270-305) and the strand-bias FDR filter, alpha 0.001, with the

@@ -333,6 +333,7 @@ int lfq_launch_strand_pvals(const LfqTracksDev &t, lfq_col_pvals *d_pvals, const
 int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, int32_t *tuples_mapped,
                             int32_t *n_mapped, int cap_entries, int min_alt, void *stream);
 int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);
+int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream);
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream);
 int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,

@@ -460,6 +460,50 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
     }
 }
 
+/* base_count() (plp.c:128-132) for every column: the bases of each nucleotide, whatever their quality -- what
+ * `lofreq uniq`'s binomial test counts (lofreq_uniq.c:373).  One wavefront per column over the nt track with the
+ * counting loop of lfq_count_kernel (bit planes of the raw counts); out[4 * col + x], x = A, C, G, T. */
+template <bool PACKED>
+__global__ __launch_bounds__(256) void lfq_ntcount_kernel(LfqTracksDev T, int32_t *__restrict__ out)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t col = (int64_t)blockIdx.x * 4 + wave;
+    if (col >= T.ncols) {
+        return;
+    }
+    const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
+    LfqAcc a;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        a.raw[x] = a.fw[x] = a.ge[x] = a.ga[x] = 0;
+    }
+    lfq_count_chunks<true, PACKED, false>(a, T, off0, off1, 0u, 0u);
+    uint32_t n[4], cls[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        n[x] = lfq_wave_sum_u32(a.raw[x]);
+    }
+    lfq_planes_to_classes(n, cls);
+    if (lfq_lane() < 4) {
+        const int l = lfq_lane();
+        out[4 * col + l] = (int32_t)(l == 0 ? cls[0] : l == 1 ? cls[1] : l == 2 ? cls[2] : cls[3]);
+    }
+}
+
+int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream)
+{
+    if (t.ncols <= 0) {
+        return LFQ_OK;
+    }
+    const unsigned blocks = (unsigned)((t.ncols + 3) / 4);
+    if (t.nt_packed) {
+        hipLaunchKernelGGL(lfq_ntcount_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, d_out);
+    } else {
+        hipLaunchKernelGGL(lfq_ntcount_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, d_out);
+    }
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* scan kernels: running Bonferroni prefix + work-list compaction                              */
 /* ------------------------------------------------------------------------------------------ */

@@ -1516,3 +1516,127 @@ int orc_uniq_detlim_batch(const uint8_t *nt, const uint8_t *bq, const uint8_t *b
     }
     return 0;
 }
+
+/* ---- `lofreq uniq`, default (binomial) mode ------------------------------------------------
+ *
+ * binom() (binom.c:52-69) calls cdfbin(which = 1) of cdflib90 -- THIRD-PARTY code vendored in the reference tree
+ * (src/cdflib90/dcdflib.c:1727; argument checks :1880-1935) -- which hands P(X <= s), X ~ Binomial(xn, pr), to cumbin
+ * (:4966-5031: Abramowitz & Stegun 26.5.24) = the regularised incomplete beta function I_{1-pr}(xn - s, s + 1),
+ * evaluated by bratio (TOMS 708).  This restatement evaluates the same quantity from its DEFINITION, the sum of the
+ * binomial probabilities of 0..s, in 80-bit arithmetic; it agrees with the reference's own compiled cdflib
+ * (oracle/_ref/libref_parts.so: binom.c + dcdflib.c + ipmpar.c unmodified) to better than 1e-11 relative wherever
+ * that returns a normal double (tests/test_uniq.py), and the phred value uniq_snv derives from it is an integer.
+ * Returns cdfbin's status: 0, -5 (xn <= 0), -4 (s outside [0, xn]), -6 (pr outside [0, 1]). */
+int orc_binom_cdf(double *p, int num_trials, int num_success, double prob_success)
+{
+    const long double n = (long double)num_trials, pr = (long double)prob_success;
+    long double sum = 0.0L, lq, lp, lgn;
+    int i;
+    *p = 0.0;
+    if (num_trials <= 0) {
+        return -5;
+    }
+    if (num_success < 0 || num_success > num_trials) {
+        return -4;
+    }
+    if (prob_success < 0.0 || prob_success > 1.0) {
+        return -6;
+    }
+    if (num_success >= num_trials || prob_success <= 0.0) {          /* cumbin :5021-5028; cumbet's x <= 0 exit */
+        *p = 1.0;
+        return 0;
+    }
+    if (prob_success >= 1.0) {                                       /* cumbet's y <= 0 exit: all mass at xn > s */
+        *p = 0.0;
+        return 0;
+    }
+    lp = logl(pr);
+    lq = log1pl(-pr);
+    lgn = lgammal(n + 1.0L);
+    for (i = 0; i <= num_success; i++) {
+        const long double li = (long double)i;
+        sum += expl(lgn - lgammal(li + 1.0L) - lgammal(n - li + 1.0L) + li * lp + (n - li) * lq);
+    }
+    *p = (double)(sum > 1.0L ? 1.0L : sum);
+    return 0;
+}
+
+/* uniq_snv's default branch (lofreq_uniq.c:254-256, 335-393) for a batch of columns: coverage = coverage_plp
+ * (here: the observations of the column; SNVs only), alt_count = base_count(p, alt) = every base of that
+ * nucleotide in the column whatever its quality (plp.c:128-132), pvalue = binom(coverage, alt_count, af) -- one-sided:
+ * "the other sample shows at most this many alt bases although the variant has frequency af" --
+ * UQ = PROB_TO_PHREDQUAL_SAFE(pvalue) (:386; utils.h:46).  uq[col] = -1 where the reference adds no UQ tag
+ * (coverage < 1, :254; binom() failed, :381-384). */
+int orc_uniq_binom_batch(const uint8_t *nt, const uint64_t *col_off, const int32_t *coverage_plp_or_null, int64_t ncols,
+                         const float *af, const char *alt_base, int32_t *uq, double *pvalue_or_null)
+{
+    int64_t c;
+    for (c = 0; c < ncols; c++) {
+        const uint64_t o0 = col_off[c], o1 = col_off[c + 1];
+        const int coverage = coverage_plp_or_null ? coverage_plp_or_null[c] : (int)(o1 - o0);
+        const char ab = alt_base[c];
+        const int code = (ab == 'A' || ab == 'a') ? 0 : (ab == 'C' || ab == 'c') ? 1 : (ab == 'G' || ab == 'g') ? 2
+                         : (ab == 'T' || ab == 't') ? 3 : 4;          /* bam_nt4_table */
+        int alt_count = 0;
+        uint64_t o;
+        double pv = 0.0;
+        uq[c] = -1;
+        if (pvalue_or_null) {
+            pvalue_or_null[c] = -1.0;
+        }
+        if (coverage < 1) {
+            continue;
+        }
+        for (o = o0; o < o1; o++) {
+            alt_count += ((nt[o] & 7) == code);
+        }
+        if (orc_binom_cdf(&pv, coverage, alt_count, (double)af[c]) != 0) {
+            continue;
+        }
+        uq[c] = (pv <= 0.0) ? INT_MAX : (int)(-10.0 * log10l(pv));
+        if (pvalue_or_null) {
+            pvalue_or_null[c] = pv;
+        }
+    }
+    return 0;
+}
+
+/* apply_uniq_filter_mtc (lofreq_uniq.c:140-206): uniq_probs = PHREDQUAL_TO_PROB(UQ) -- of the INTEGER phred value, 0
+ * where a variant carries no UQ tag (uniq_phred_from_var, :110-121) -- corrected by bonf / holm / fdr (multtest.c) over
+ * ntests (0 = the number of variants, :155-157); a variant is filtered when its corrected value exceeds alpha (fdr: the
+ * rejected ones are set to -1 first, :186-191).  mtc_type: 1 bonf, 2 holm, 3 fdr (multtest.h).  pass[i] = 1: not filtered. */
+int orc_uniq_mtc(const int32_t *uq, long n, int mtc_type, double alpha, long ntests, uint8_t *pass)
+{
+    double *pr = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    long i;
+    if (!pr) {
+        return -1;
+    }
+    if (!ntests) {
+        ntests = n;
+    }
+    for (i = 0; i < n; i++) {
+        const int q = uq[i] < 0 ? 0 : uq[i];
+        pr[i] = (q == INT_MAX) ? DBL_MIN : pow(10.0, -1.0 * q / 10.0);          /* utils.h:42 */
+    }
+    if (mtc_type == 1) {
+        orc_bonf_corr(pr, n, ntests);
+    } else if (mtc_type == 2) {
+        orc_holm_bonf_corr(pr, n, alpha, ntests);
+    } else if (mtc_type == 3) {
+        long *idx = (long *)malloc((size_t)(n > 0 ? n : 1) * sizeof(long));
+        const long nrej = orc_fdr(pr, n, alpha, ntests, idx);
+        for (i = 0; i < nrej; i++) {
+            pr[idx[i]] = -1;
+        }
+        free(idx);
+    } else {
+        free(pr);
+        return -1;
+    }
+    for (i = 0; i < n; i++) {
+        pass[i] = pr[i] > alpha ? 0 : 1;
+    }
+    free(pr);
+    return 0;
+}

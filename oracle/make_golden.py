@@ -634,9 +634,70 @@ def run_uniq(name, seed, glen, nreads, mapqs):
     print("%s: %d variants, %d UNIQ, %d bytes" % (name, len(out), sum(v["uniq"] for v in out), os.path.getsize(path)))
 
 
+def run_uniq_binom(name, seed, glen, nreads, mapqs):
+    """The default mode of `lofreq uniq` (uniq_snv's binomial branch, lofreq_uniq.c:335-393, + apply_uniq_filter_mtc,
+    :140-206): variants called in one sample tested against this BAM, in which some of them are present at another
+    (or the same) frequency.  Per variant the binary's UQ= value (binom() through cdflib's cdfbin) and whether it ends
+    up PASS under the default FDR correction (alpha 0.001, ntests = number of variants)."""
+    rng = np.random.default_rng(seed + 5)
+    genome_rng = np.random.default_rng(seed)
+    genome = "".join(genome_rng.choice(list("ACGT"), glen))
+    afs = [0.004, 0.01, 0.02, 0.05, 0.08, 0.15, 0.3, 0.6, 0.95]
+    present = [0.0, 0.0, 0.0, 0.003, 0.01, 0.03, 0.1, 0.3, 0.6]
+    var, planted = [], {}
+    for p0 in range(5, glen - 5, 3):
+        ref = genome[p0]
+        alt = str(rng.choice([c for c in "ACGT" if c != ref]))
+        af = float(rng.choice(afs))
+        here = float(rng.choice(present))
+        var.append((p0, ref, alt, af))
+        if here > 0:
+            planted[p0] = (alt, here)
+    with tempfile.TemporaryDirectory() as tmp:
+        g2 = write_fixture(tmp, seed, glen, nreads, planted, mapqs)
+        assert g2 == genome
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        with open(os.path.join(tmp, "t.bam"), "wb") as f:
+            subprocess.check_call([LOFREQ, "alnqual", "-b", "t.sam", "t.fa"], cwd=tmp, stdout=f)
+        subprocess.check_call([LOFREQ, "index", "t.bam"], cwd=tmp)
+        with open(os.path.join(tmp, "v.vcf"), "w") as f:
+            f.write("##fileformat=VCFv4.0\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+            for p0, ref, alt, af in var:
+                f.write("chr1\t%d\t.\t%s\t%s\t100\tPASS\tDP=100;AF=%f\n" % (p0 + 1, ref, alt, af))
+        res = subprocess.run([LOFREQ, "uniq", "--output-all", "-v", "v.vcf", "-o", "-", "t.bam"],
+                             cwd=tmp, check=True, capture_output=True, text=True).stdout
+        plp = subprocess.run([LOFREQ, "plpsummary", "-f", "t.fa", "-B", "-m", "1", "t.bam"], cwd=tmp, check=True,
+                             capture_output=True, text=True).stdout
+    got = {}
+    for line in res.splitlines():
+        if line.startswith("#"):
+            continue
+        f = line.split("\t")
+        info = dict(x.split("=") for x in f[7].split(";") if "=" in x)
+        got[int(f[1]) - 1] = (int(info["UQ"]) if "UQ" in info else None, f[6])
+    cols = {c["pos0"]: c for c in parse_plpsummary(plp)}
+    out = []
+    for p0, ref, alt, af in var:
+        c = cols.get(p0)
+        if c is None or p0 not in got:
+            continue
+        o = {nt: {"bq": enc(tr.get("BQ", [])), "mq": enc_mq(tr.get("MQ", []))} for nt, tr in c["obs"].items()}
+        out.append({"pos0": p0, "ref": ref, "alt": alt, "af": "%f" % af, "fwrv": c["fwrv"], "obs": o,
+                    "uq": got[p0][0], "filter": got[p0][1]})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "encoding": "bq: chr(33 + value); mq: 2 hex digits; af: the string written to the VCF (strtof)",
+           "mtc": "fdr", "alpha": 0.001, "variants": out}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d variants, %d PASS, UQ range %s..%s, %d bytes" % (
+        name, len(out), sum(v["filter"] == "PASS" for v in out), min(v["uq"] for v in out if v["uq"] is not None),
+        max(v["uq"] for v in out if v["uq"] is not None), os.path.getsize(path)))
+
+
 def main_uniq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     run_uniq("uniq_detlim", 81, 400, 700, mq_mix)
+    run_uniq_binom("uniq_binom", 82, 400, 1500, mq_mix)
 
 
 def main_baq():

@@ -449,3 +449,55 @@ def uniq_detlim_batch(nt, bq, baq, mq, sq, col_off, ref_base, af):
     if rc != 0:
         raise RuntimeError("orc_uniq_detlim_batch failed: %d" % rc)
     return flag[:ncols], pv[:ncols]
+
+
+def binom_cdf(n, k, pr):
+    """orc_binom_cdf -> (p, cdfbin status)"""
+    L = lib()
+    L.orc_binom_cdf.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double]
+    p = C.c_double(0.0)
+    st = L.orc_binom_cdf(C.byref(p), int(n), int(k), float(pr))
+    return p.value, st
+
+
+def ref_binom(n, k, pr):
+    """the reference's own binom() (binom.c + cdflib90 compiled unmodified into oracle/_ref) -> (p, status), or None"""
+    R = ref_parts()
+    if R is None or not hasattr(R, "binom"):
+        return None
+    R.binom.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double]
+    p = C.c_double(0.0)
+    st = R.binom(C.byref(p), None, int(n), int(k), float(pr))
+    return p.value, st
+
+
+def uniq_binom_batch(nt, col_off, af, alt_bases, coverage_plp=None):
+    """orc_uniq_binom_batch (uniq_snv's binomial branch, lofreq_uniq.c:335-393) -> (UQ int32, p-values float64)"""
+    L = lib()
+    nt = np.ascontiguousarray(nt, np.uint8)
+    col_off = np.ascontiguousarray(col_off, np.uint64)
+    af = np.ascontiguousarray(af, np.float32)
+    alt = np.frombuffer(alt_bases.encode() if isinstance(alt_bases, str) else bytes(alt_bases), np.uint8).copy()
+    n = len(col_off) - 1
+    uq = np.zeros(max(n, 1), np.int32)
+    pv = np.zeros(max(n, 1), np.float64)
+    cov = None if coverage_plp is None else np.ascontiguousarray(coverage_plp, np.int32)
+    L.orc_uniq_binom_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+    rc = L.orc_uniq_binom_batch(nt.ctypes.data, col_off.ctypes.data, cov.ctypes.data if cov is not None else None, n,
+                                af.ctypes.data, alt.ctypes.data, uq.ctypes.data, pv.ctypes.data)
+    if rc:
+        raise RuntimeError("orc_uniq_binom_batch failed: %d" % rc)
+    return uq[:n], pv[:n]
+
+
+def uniq_mtc(uq, mtc_type="fdr", alpha=0.001, ntests=0):
+    L = lib()
+    uq = np.ascontiguousarray(uq, np.int32)
+    out = np.zeros(max(len(uq), 1), np.uint8)
+    L.orc_uniq_mtc.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_long, C.c_void_p]
+    rc = L.orc_uniq_mtc(uq.ctypes.data, len(uq), {"bonf": 1, "holm": 2, "fdr": 3}[mtc_type], float(alpha), int(ntests),
+                        out.ctypes.data)
+    if rc:
+        raise RuntimeError("orc_uniq_mtc failed")
+    return out[: len(uq)].astype(bool)

@@ -200,7 +200,11 @@ def load_plpindel(path, with_alnqual_tags=True):
 
 
 def uniq_fixtures():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "uniq_*.json")))
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "uniq_detlim*.json")))
+
+
+def uniq_binom_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "uniq_binom*.json")))
 
 
 def load_uniq(path):

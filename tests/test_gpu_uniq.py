@@ -35,3 +35,32 @@ def test_uniq_detlim_random_vs_oracle(caller, oracle, seed, lo, hi, n):
             util.assert_pvalue_close(pv[c], opv[c], ctx="col %d af %g" % (c, af[c]))
             ncmp += 1
     assert ncmp > 10
+
+
+@pytest.mark.parametrize("path", gu.uniq_binom_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_uniq_binom_matches_reference_binary(caller, path):
+    """default mode of `lofreq uniq`: device base counts + host binomial test + MTC == the 2.1.4 binary's UQ= values
+    and PASS / uq_fdr decisions"""
+    import lofreq_amd as la
+    fx, host, af = gu.load_uniq(path)
+    alt = "".join(v["alt"] for v in fx["variants"])
+    uq, pv = caller.uniq_binom(util.to_pileup_batch(la, host), af, alt)
+    assert uq.tolist() == [(-1 if v["uq"] is None else v["uq"]) for v in fx["variants"]]
+    assert la.uniq_mtc(uq, fx["mtc"], fx["alpha"], 0).tolist() == [v["filter"] == "PASS" for v in fx["variants"]]
+
+
+@pytest.mark.parametrize("seed,lo,hi,n", [(1, 0, 400, 300), (2, 3000, 9000, 40)])
+def test_uniq_binom_random_vs_oracle(caller, oracle, seed, lo, hi, n):
+    import lofreq_amd as la
+    rng = np.random.default_rng(seed)
+    host = util.random_batch(rng, n, lo, hi, planted={c: float(rng.choice([0.01, 0.1, 0.4])) for c in range(0, n, 3)})
+    host["baq"] = None
+    af = rng.choice(np.array([0.0, 0.002, 0.01, 0.05, 0.1, 0.25, 0.5, 0.9, 1.0], np.float32), n)
+    alt = "".join(rng.choice(list("ACGTN"), n))
+    ouq, opv = oracle.uniq_binom_batch(host["nt"], host["col_off"], af, alt)
+    uq, pv = caller.uniq_binom(util.to_pileup_batch(la, host), af, alt)
+    assert uq.tolist() == ouq.tolist()
+    ok = ouq >= 0
+    assert np.allclose(pv[ok], opv[ok], rtol=1e-11, atol=1e-300)
+    for mtc in ("fdr", "holm"):
+        assert la.uniq_mtc(uq, mtc, 0.001, 0).tolist() == oracle.uniq_mtc(ouq, mtc, 0.001, 0).tolist()

@@ -13,3 +13,103 @@ def test_oracle_uniq_detlim_matches_reference_binary(oracle, path):
     want = [v["uniq"] for v in fx["variants"]]
     assert flag.astype(bool).tolist() == want
     assert 20 < sum(want) < len(want) - 20
+
+
+# ---- default mode: the binomial test (lofreq_uniq.c:335-393; binom.c -> cdflib90 cdfbin) and its MTC ----------------
+
+def _phred(p):
+    import numpy as np
+    return 2147483647 if p <= 0.0 else int(-10.0 * np.log10(np.longdouble(p)))
+
+
+def _binom_cases():
+    rng = np.random.default_rng(2024)
+    cases = [(1, 0, 0.5), (1, 1, 0.5), (10, 0, 0.0), (10, 3, 1.0), (10, 10, 0.3), (370, 0, 0.95), (10000, 100, 0.5),
+             (10000, 3108, 0.5), (10000, 3107, 0.5), (100000, 49000, 0.5), (100000, 50, 0.001), (5, -1, 0.5), (5, 6, 0.5),
+             (0, 0, 0.5), (-3, 0, 0.5), (7, 2, -0.1), (7, 2, 1.5)]
+    afs = [0.001, 0.004, 0.01, 0.02, 0.05, 0.08, 0.15, 0.3, 0.5, 0.6, 0.95, 0.999]
+    for _ in range(6000):
+        n = int(rng.choice([5, 30, 100, 400, 1500, 10000, 60000]) * rng.uniform(0.5, 1.5)) + 1
+        af = float(rng.choice(afs))
+        mode = rng.integers(0, 4)
+        if mode == 0:
+            k = int(rng.integers(0, n + 1))
+        elif mode == 1:
+            k = int(min(n, max(0, rng.normal(n * af, 3 * np.sqrt(n * af * (1 - af)) + 1))))
+        elif mode == 2:
+            k = int(rng.integers(0, max(1, int(n * af / 4)) + 1))
+        else:
+            k = int(min(n, n * af * rng.uniform(0.2, 1.2)))
+        cases.append((n, k, af))
+    return cases
+
+
+def test_binom_restatement_equals_reference_cdflib(oracle):
+    """orc_binom_cdf (sum of the binomial probabilities in 80-bit arithmetic) against the reference's OWN binom() --
+    binom.c + cdflib90 compiled unmodified into oracle/_ref -- on ~6000 seeded (n, k, af): same status, same UQ phred
+    integer wherever the reference's value is a normal double, p within 1e-11 relative there."""
+    if oracle.ref_binom(10, 3, 0.5) is None:
+        pytest.skip("oracle/_ref/libref_parts.so (with binom.c + cdflib90) not present")
+    worst, n_cmp = 0.0, 0
+    for n, k, af in _binom_cases():
+        rp, rs = oracle.ref_binom(n, k, af)
+        op, os_ = oracle.binom_cdf(n, k, af)
+        assert (rs == 0) == (os_ == 0), (n, k, af, rs, os_)
+        if rs != 0:
+            assert rs == os_, (n, k, af, rs, os_)
+            continue
+        if rp >= 2.3e-308:
+            assert _phred(rp) == _phred(op), (n, k, af, rp, op)
+            if rp > 0:
+                worst = max(worst, abs(op - rp) / rp)
+            n_cmp += 1
+        else:                       # denormal / underflowed result of cdflib: both say "p < 1e-307"
+            assert op < 1e-306, (n, k, af, rp, op)
+    assert n_cmp > 4000 and worst < 1e-11, (n_cmp, worst)
+
+
+def test_product_binom_equals_oracle_and_reference(oracle):
+    """lfq_binom_cdf (host code of the product: tail summation from the largest term with exact ratios) against the
+    oracle on the same cases, and against the reference's cdflib where present"""
+    import lofreq_amd as la
+    have_ref = oracle.ref_binom(10, 3, 0.5) is not None
+    worst = 0.0
+    for n, k, af in _binom_cases():
+        gp, gs = la.binom_cdf(n, k, af)
+        op, os_ = oracle.binom_cdf(n, k, af)
+        assert gs == os_, (n, k, af, gs, os_)
+        if gs != 0:
+            continue
+        if op >= 2.3e-308:
+            assert _phred(gp) == _phred(op), (n, k, af, gp, op)
+            worst = max(worst, abs(gp - op) / op)
+        else:
+            assert gp < 1e-306
+        if have_ref:
+            rp, _ = oracle.ref_binom(n, k, af)
+            if rp >= 2.3e-308:
+                assert _phred(gp) == _phred(rp), (n, k, af, gp, rp)
+    assert worst < 1e-11, worst
+
+
+@pytest.mark.parametrize("path", gu.uniq_binom_fixtures(), ids=lambda p: p.split("/")[-1])
+def test_oracle_uniq_binom_matches_reference_binary(oracle, path):
+    """UQ= values and the PASS / uq_fdr decision `lofreq uniq` (2.1.4 binary, default mode) wrote for 130 variants"""
+    fx, host, af = gu.load_uniq(path)
+    alt = "".join(v["alt"] for v in fx["variants"])
+    uq, pv = oracle.uniq_binom_batch(host["nt"], host["col_off"], af, alt)
+    want = [(-1 if v["uq"] is None else v["uq"]) for v in fx["variants"]]
+    assert uq.tolist() == want
+    keep = oracle.uniq_mtc(uq, fx["mtc"], fx["alpha"], 0)
+    assert keep.tolist() == [v["filter"] == "PASS" for v in fx["variants"]]
+    assert 20 < keep.sum() < len(keep) - 20 and 2147483647 in want
+
+
+def test_product_uniq_mtc_equals_oracle(oracle):
+    import lofreq_amd as la
+    rng = np.random.default_rng(9)
+    for mtc in ("bonf", "holm", "fdr"):
+        for alpha in (0.001, 0.05):
+            uq = rng.choice([-1, 0, 3, 17, 25, 31, 40, 55, 90, 300, 2147483647], 200).astype(np.int32)
+            for ntests in (0, 1000):
+                assert la.uniq_mtc(uq, mtc, alpha, ntests).tolist() == oracle.uniq_mtc(uq, mtc, alpha, ntests).tolist()
