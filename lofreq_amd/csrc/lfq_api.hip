@@ -2546,8 +2546,11 @@ int lfq_uniq_binom_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device,
         const char ab = alt_base[i];
         const int code = (ab == 'A' || ab == 'a') ? 0 : (ab == 'C' || ab == 'c') ? 1 : (ab == 'G' || ab == 'g') ? 2
                          : (ab == 'T' || ab == 't') ? 3 : 4;
-        /* bam_nt4_table sends everything else to N, whose bases are in no ACGT count; they stay uncounted here too */
-        const int alt_count = code < 4 ? h_nt[(size_t)i * 4 + code] : 0;
+        /* bam_nt4_table sends every other letter to N: those are the observations of the column that are in none of
+         * the four nucleotide counts */
+        const int n_col = (int)(h_off[(size_t)i + 1] - h_off[(size_t)i]);
+        const int32_t *cn = &h_nt[(size_t)i * 4];
+        const int alt_count = code < 4 ? cn[code] : n_col - cn[0] - cn[1] - cn[2] - cn[3];
         int st = 0;
         const double pv = lfq_binom_cdf(coverage, alt_count, (double)af[i], &st);   /* :381; one-sided */
         if (st != 0) {
