@@ -479,6 +479,7 @@ def main():
     pipelined = world == 1 and not args.shard_path and not args.no_pipeline
     if pipelined:
         callers = [caller, la.SnvCaller(local_rank)]
+        callers[1].set_dense_strand_counts(False)
 
         def submit(k):
             conf = la.VarcallConf()

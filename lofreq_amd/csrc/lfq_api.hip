@@ -168,10 +168,27 @@ struct lfq_ctx {
     std::mutex *lm;
     std::condition_variable *lcv;
     int leader_go, leader_stop;
+    int own_streams;                 /* holds a reference on the device's shared streams */
     int sb_pending;                  /* strand-bias precomputes of this context not finished yet (under lm) */
 };
 
 namespace {
+
+/* The four streams of a device (= the four hardware queues HIP multiplexes a process's streams onto) are shared by
+ * every context on that device.  Two contexts with four streams each would have their streams doubled up on the
+ * same queues in an order nobody chose -- measured: the light chain of one batch started only after the big chain of
+ * the same batch had finished -- while sharing them keeps the stream plan of lfq_snv_batch_device intact and simply
+ * queues a second context's batch behind the first one's, which is what a caller that pipelines batches
+ * (lfq_call_snvs_wait) wants anyway.  Completion is tracked per context with events, never by draining a stream. */
+struct LfqDeviceStreams {
+    hipStream_t stream = nullptr, dps = nullptr, side[2] = {nullptr, nullptr};
+    int refs = 0;
+};
+std::mutex g_streams_m;
+LfqDeviceStreams g_streams[64];
+
+bool acquire_streams(int device, lfq_ctx *c);
+void release_streams(int device);
 
 template <typename T>
 int grow(T **ptr, int64_t *cap, int64_t need)
@@ -264,6 +281,47 @@ int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bool i
         P->bonf_reset_first = 0;
     }
     return LFQ_OK;
+}
+
+bool acquire_streams(int device, lfq_ctx *c)
+{
+    std::lock_guard<std::mutex> lk(g_streams_m);
+    if (device < 0 || device >= 64) {
+        return false;
+    }
+    LfqDeviceStreams &d = g_streams[device];
+    if (d.refs == 0) {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        bool ok = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&d.dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
+        for (int i = 0; ok && i < 2; i++) {
+            ok = hipStreamCreateWithPriority(&d.side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
+        }
+        if (!ok) {
+            return false;
+        }
+    }
+    d.refs++;
+    c->stream = d.stream;
+    c->dps = d.dps;
+    c->side[0] = d.side[0];
+    c->side[1] = d.side[1];
+    return true;
+}
+
+void release_streams(int device)
+{
+    std::lock_guard<std::mutex> lk(g_streams_m);
+    LfqDeviceStreams &d = g_streams[device];
+    if (d.refs > 0 && --d.refs == 0) {
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.dps) (void)hipStreamDestroy(d.dps);
+        for (int i = 0; i < 2; i++) {
+            if (d.side[i]) (void)hipStreamDestroy(d.side[i]);
+        }
+        d = LfqDeviceStreams();
+    }
 }
 
 void fill_luts(LfqLuts *L)
@@ -371,7 +429,8 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
         c->n_cu = prop.multiProcessorCount;
     }
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = acquire_streams(device_ordinal, c);
+    c->own_streams = ok ? 1 : 0;
     ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
     /* counter blocks: one per segment + one batch-wide */
     ok = ok && hipMalloc((void **)&c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
@@ -379,12 +438,6 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
                              hipHostMallocDefault) == hipSuccess;      /* + first / last CSR offset (lfq_batch_finish) */
     for (int i = 0; ok && i < 4; i++) {
         ok = hipEventCreate(&c->ev[i]) == hipSuccess;
-    }
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    ok = ok && hipStreamCreateWithPriority(&c->dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
-    for (int i = 0; ok && i < 2; i++) {
-        ok = hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
     }
     for (int i = 0; ok && i < 3; i++) {
         ok = hipEventCreate(&c->ev_join[i]) == hipSuccess;
@@ -480,11 +533,9 @@ void lfq_destroy(lfq_ctx *c)
             if (e) (void)hipEventDestroy(e);
         }
     }
-    for (int i = 0; i < 2; i++) {
-        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    if (c->own_streams) {
+        release_streams(c->device);
     }
-    if (c->dps) (void)hipStreamDestroy(c->dps);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
 
@@ -764,16 +815,17 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
     if (!c) {
         return LFQ_ERR_INVALID;
     }
-    hipStream_t st = c->cur_stream ? c->cur_stream : c->stream;
-    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, st));
+    /* wait for THIS batch (its last event), not for the stream: the streams are shared with the other contexts of
+     * the device, and a batch of one of them may already be queued behind this one */
+    LFQ_TRY_HIP(hipEventSynchronize(c->ev[3]));
+    LFQ_TRY_HIP(hipMemcpy(c->h_counters, c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
+                          hipMemcpyDeviceToHost));
     uint64_t *h_ends = reinterpret_cast<uint64_t *>(c->h_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS);
     h_ends[0] = h_ends[1] = 0;
     if (c->cur_col_off && c->cur_ncols > 0) {       /* first and last CSR offset: the batch's observation count */
-        LFQ_TRY_HIP(hipMemcpyAsync(h_ends, c->cur_col_off, 8, hipMemcpyDeviceToHost, st));
-        LFQ_TRY_HIP(hipMemcpyAsync(h_ends + 1, c->cur_col_off + c->cur_ncols, 8, hipMemcpyDeviceToHost, st));
+        LFQ_TRY_HIP(hipMemcpy(h_ends, c->cur_col_off, 8, hipMemcpyDeviceToHost));
+        LFQ_TRY_HIP(hipMemcpy(h_ends + 1, c->cur_col_off + c->cur_ncols, 8, hipMemcpyDeviceToHost));
     }
-    LFQ_TRY_HIP(hipStreamSynchronize(st));
     const int64_t batch_obs = (int64_t)(h_ends[1] - h_ends[0]);
     c->cur_count_read = batch_obs * c->cur_obs_bytes_x2 / 2 + c->cur_ncols * c->cur_col_bytes;
     c->cur_count_written = c->cur_ncols * (int64_t)(sizeof(lfq_col_counts) + 1);

@@ -1930,6 +1930,11 @@ struct LfqCombShared {
     double tot_v;
     int tot_e;
     int idx, pruned;
+    /* fast fold (see lfq_comb_plan): both distributions as plain doubles under one exponential tilt */
+    double as[LFQ_COMB_CELLS];
+    double bs[LFQ_COMB_CELLS];
+    int red_lo[LFQ_COMB_THREADS / 64], red_hi[LFQ_COMB_THREADS / 64];
+    int plan_fast, plan_t, plan_sa, plan_sb;
 };
 
 __device__ __forceinline__ LfqExt lfq_ext_norm(double v, int e)
@@ -1938,6 +1943,91 @@ __device__ __forceinline__ LfqExt lfq_ext_norm(double v, int e)
     r.v = (v > 0.0) ? __builtin_amdgcn_frexp_mant(v) : 0.0;
     r.e = (v > 0.0) ? e + __builtin_amdgcn_frexp_exp(v) : LFQ_EXT_ZERO_E;
     return r;
+}
+
+/* ---- fast fold --------------------------------------------------------------------------------------------
+ * The convolution of two count distributions costs K^2 / 2 products, and with a binary exponent per cell every
+ * product drags an exponent addition, a running maximum and two ldexp behind it (~10 instructions).  But both
+ * factors are distributions of sums of independent Bernoulli trials: log-concave, their exponents fall almost
+ * linearly in the cell index (cell k ~ mu^k / k!).  Multiplying cell k by 2^(t k) with ONE integer tilt t for both
+ * factors leaves the convolution structure intact -- (a_i 2^(t i)) (b_j 2^(t j)) = a_i b_j 2^(t (i + j)) -- and, with
+ * t = minus the average slope, flattens both sequences into the range of a plain double (C3's K ~ 500 segments:
+ * ~550 binary orders after the tilt against ~2900 before).  Scaling by powers of two is exact, so the fold becomes
+ * what it looks like: one FMA per product on pre-scaled LDS arrays, and one frexp per OUTPUT cell to get back to
+ * (mantissa, exponent).  lfq_comb_plan picks t and the two shifts and checks that every non-zero cell of both
+ * factors (tail cells included) lands within 2^+-LFQ_COMB_SPAN of the centre; if not (very wide K against short
+ * segments), the fold of that pair runs the exact-exponent loops below. */
+#define LFQ_COMB_SPAN 800          /* binary orders a tilted factor may span */
+#define LFQ_COMB_TOP 380           /* largest tilted cell = 2^TOP: products <= 2^760, sums of 2048 of them < 2^1023 */
+
+/* block-wide min / max over the threads' (lo, hi); every thread gets the result */
+__device__ __forceinline__ void lfq_comb_minmax(LfqCombShared &sh, int &lo, int &hi)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+    }
+    const int w = (int)(threadIdx.x >> 6);
+    if (lfq_lane() == 0) {
+        sh.red_lo[w] = lo;
+        sh.red_hi[w] = hi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LFQ_COMB_THREADS / 64; i++) {
+        lo = min(lo, sh.red_lo[i]);
+        hi = max(hi, sh.red_hi[i]);
+    }
+    __syncthreads();
+}
+
+/* tilt + shifts for the pair (a, b) in sh.av/ae, sh.bv/be (cells 0..K, cell K = absorbing tail); true = fast fold */
+__device__ __forceinline__ bool lfq_comb_plan(LfqCombShared &sh, int K)
+{
+    const int tid = threadIdx.x;
+    /* slope of the exponents between cell 0 and the last non-zero regular cell of each factor */
+    int last_a = -1, last_b = -1;
+    for (int k = tid; k < K; k += LFQ_COMB_THREADS) {
+        if (sh.av[k] > 0.0) last_a = k;
+        if (sh.bv[k] > 0.0) last_b = k;
+    }
+    {
+        int dummy = 0;
+        lfq_comb_minmax(sh, dummy, last_a);
+        dummy = 0;
+        lfq_comb_minmax(sh, dummy, last_b);
+    }
+    if (last_a < 0 || last_b < 0 || !(sh.av[0] > 0.0) || !(sh.bv[0] > 0.0)) {
+        return false;
+    }
+    const double sl_a = last_a > 0 ? (double)(sh.ae[last_a] - sh.ae[0]) / last_a : 0.0;
+    const double sl_b = last_b > 0 ? (double)(sh.be[last_b] - sh.be[0]) / last_b : 0.0;
+    const int t = -(int)lrint(0.5 * (sl_a + sl_b));
+    int lo_a = INT_MAX, hi_a = INT_MIN, lo_b = INT_MAX, hi_b = INT_MIN;
+    for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
+        if (sh.av[k] > 0.0) {
+            const int E = sh.ae[k] + t * k;
+            lo_a = min(lo_a, E);
+            hi_a = max(hi_a, E);
+        }
+        if (sh.bv[k] > 0.0) {
+            const int E = sh.be[k] + t * k;
+            lo_b = min(lo_b, E);
+            hi_b = max(hi_b, E);
+        }
+    }
+    lfq_comb_minmax(sh, lo_a, hi_a);
+    lfq_comb_minmax(sh, lo_b, hi_b);
+    if ((long long)hi_a - lo_a > LFQ_COMB_SPAN || (long long)hi_b - lo_b > LFQ_COMB_SPAN) {
+        return false;
+    }
+    if (tid == 0) {
+        sh.plan_t = t;
+        sh.plan_sa = hi_a - LFQ_COMB_TOP;
+        sh.plan_sb = hi_b - LFQ_COMB_TOP;
+    }
+    return true;
 }
 
 template <int MODE>
@@ -2017,10 +2107,45 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                 }
                 __syncthreads();
                 LFQ_PT(0);
-                /* c_k = sum_i a_i b_(k-i), k < K: aligned to a running maximum exponent */
+                const bool fast = lfq_comb_plan(sh, K);                 /* block-uniform */
                 LfqExt out[LFQ_COMB_PER_THREAD];
+                int f_t = 0, f_sa = 0, f_sb = 0;
+                if (fast) {
+                    __syncthreads();
+                    f_t = sh.plan_t;
+                    f_sa = sh.plan_sa;
+                    f_sb = sh.plan_sb;
+                    for (int k = tid; k <= K; k += LFQ_COMB_THREADS) {
+                        sh.as[k] = (sh.av[k] > 0.0) ? ldexp(sh.av[k], sh.ae[k] + f_t * k - f_sa) : 0.0;
+                        sh.bs[k] = (sh.bv[k] > 0.0) ? ldexp(sh.bv[k], sh.be[k] + f_t * k - f_sb) : 0.0;
+                    }
+                    __syncthreads();
+                    /* c'_k = sum_i a'_i b'_(k-i): a'_i is a broadcast read, b'_(k-i) consecutive across the lanes */
+#pragma unroll
+                    for (int m = 0; m < LFQ_COMB_PER_THREAD; m++) {
+                        const int k = tid + m * LFQ_COMB_THREADS;
+                        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+                        if (k < K) {
+                            int i = 0;
+                            for (; i + 3 <= k; i += 4) {
+                                c0 = fma(sh.as[i], sh.bs[k - i], c0);
+                                c1 = fma(sh.as[i + 1], sh.bs[k - i - 1], c1);
+                                c2 = fma(sh.as[i + 2], sh.bs[k - i - 2], c2);
+                                c3 = fma(sh.as[i + 3], sh.bs[k - i - 3], c3);
+                            }
+                            for (; i <= k; i++) {
+                                c0 = fma(sh.as[i], sh.bs[k - i], c0);
+                            }
+                        }
+                        out[m] = lfq_ext_norm((c0 + c1) + (c2 + c3), f_sa + f_sb - f_t * k);
+                    }
+                }
+                /* c_k = sum_i a_i b_(k-i), k < K: aligned to a running maximum exponent */
 #pragma unroll
                 for (int m = 0; m < LFQ_COMB_PER_THREAD; m++) {
+                    if (fast) {
+                        break;
+                    }
                     const int k = tid + m * LFQ_COMB_THREADS;
                     /* four independent accumulators: the LDS reads and the ldexp/add chains of consecutive
                      * terms overlap instead of serialising */
@@ -2129,7 +2254,37 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
                 LfqExt part;
                 part.v = 0.0;
                 part.e = 0;
-                for (int i = tid; i < K; i += LFQ_COMB_THREADS) {
+                /* the same under the tilt: S'_B(j) = S_B(j) 2^(t j - s_b) >= b'_j and normally of its order (the factors
+                 * fall off beyond their mode; below it S_B ~ 1 against b_j >= b_0 = e^-mu); a'_i S'_B(K - i) carries
+                 * 2^(t K - s_a - s_b) whatever i is.  If some S'_B would leave the safe range, this pair's tail takes
+                 * the exact-exponent loop. */
+                bool fast_tail = fast;
+                if (fast) {
+                    int lo_s = INT_MAX, hi_s = INT_MIN;
+                    for (int j = tid + 1; j <= K; j += LFQ_COMB_THREADS) {
+                        if (sh.bv[j] > 0.0) {
+                            hi_s = max(hi_s, sh.be[j] + f_t * j - f_sb);
+                        }
+                    }
+                    lfq_comb_minmax(sh, lo_s, hi_s);
+                    fast_tail = hi_s <= LFQ_COMB_TOP + 200;
+                }
+                if (fast_tail) {
+                    for (int j = tid; j <= K; j += LFQ_COMB_THREADS) {
+                        sh.bs[j] = (sh.bv[j] > 0.0) ? ldexp(sh.bv[j], sh.be[j] + f_t * j - f_sb) : 0.0;
+                    }
+                    __syncthreads();
+                    double acc = 0.0;
+                    for (int i = tid; i < K; i += LFQ_COMB_THREADS) {
+                        acc = fma(sh.as[i], sh.bs[K - i], acc);
+                    }
+                    part = lfq_ext_norm(acc, f_sa + f_sb - f_t * K);
+                    if (!(acc > 0.0)) {
+                        part.v = 0.0;
+                        part.e = 0;
+                    }
+                }
+                for (int i = tid; i < K && !fast_tail; i += LFQ_COMB_THREADS) {
                     LfqExt t;
                     t.v = sh.av[i] * sh.bv[K - i];
                     t.e = sh.ae[i] + sh.be[K - i];
