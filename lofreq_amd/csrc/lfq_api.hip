@@ -169,6 +169,8 @@ struct lfq_ctx {
     std::condition_variable *lcv;
     int leader_go, leader_stop;
     int own_streams;                 /* holds a reference on the device's shared streams */
+    int kreg_hint, kreg_hint_indel;  /* screen-kernel variant for the next SNV / indel batch: from the last batch's K histogram */
+    int cur_indel_mode;
     int sb_pending;                  /* strand-bias precomputes of this context not finished yet (under lm) */
 };
 
@@ -265,6 +267,8 @@ int make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bool i
     P->bonf_step = 3;
     P->bonf_reset_first = 1;
     P->phase1_chunks = lfq_knobs().phase1_chunks;
+    P->seg_budget_mid = lfq_knobs().seg_budget_mid;
+    P->seg_budget_big = lfq_knobs().seg_budget_big;
     P->seg_max = lfq_knobs().seg_max;                            /* experiments: fewer, longer row segments */
     if (indel_mode) {
         /* call_indels: no base / merged-quality filters, every event is a test (lofreq_call.c:684-725);
@@ -599,6 +603,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     c->cur_ncols = ncols;
     c->cur_segments = 0;
     c->cur_col_off = tr->col_off;
+    c->cur_indel_mode = indel_mode ? 1 : 0;
     /* layout bytes per observation / per column of the count kernel instantiation this batch runs (lfq_dp_work) */
     c->cur_obs_bytes_x2 = (T.nt_packed ? 1 : 2) + 2;                       /* nt + bq, in half bytes */
     if (P.general) {
@@ -710,20 +715,20 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         }                                                                          \
     } while (0)
         /* Stream plan (4 streams = the 4 hardware queues; more streams would share queues and serialise):
-         *   dps     scan -> big prep -> quad (light columns) -> retry
-         *   side[0] [prep] -> row segments of the big class -> unsplit big columns -> [side[1]] -> fold + emission
-         *   side[1] [scan] -> mid kernel (first stretch of rows) -> [prep] -> row segments of the mid class
-         * The prep kernel is short but latency-bound; beside the quad kernel it starves, and everything behind
-         * it on the critical path with it, so it runs BEFORE the quad kernel. */
+         *   dps     scan -> screen (light columns) -> retry
+         *   side[0] [scan] -> big prep -> row segments of the big class -> fold tree + emission -> unsplit big columns
+         *   side[1] [scan] -> mid kernel (first stretch of rows) -> [prep] -> row segments of the mid class -> fold tree
+         * (Round 1 ran the prep kernel in front of the light kernel on dps: beside the lane-group kernel's 10 waves per
+         * CU it starved.  The screen kernel runs 8 lighter waves per CU and is no longer the longest chain.) */
         LFQ_TRY_HIP(hipStreamWaitEvent(side1, c->ev_scan[s], 0));
         LFQ_TRY_HIP(hipEventRecord(c->ev_side[1][s][0], side1));
+        LFQ_TRY_HIP(hipStreamWaitEvent(side0, c->ev_scan[s], 0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_side[0][s][0], side0));
         if (run_big) {
-            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu * 2, dps));
+            LFQ_TRY(lfq_launch_dp_big_prep(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->n_cu * 2, side0));
             LFQ_DBG_STAGE("prep");
         }
-        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, dps));
-        LFQ_TRY_HIP(hipStreamWaitEvent(side0, c->ev_prep, 0));
-        LFQ_TRY_HIP(hipEventRecord(c->ev_side[0][s][0], side0));
+        LFQ_TRY_HIP(hipEventRecord(c->ev_prep, side0));
         if (run_mid) {
             LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, side1));
             LFQ_DBG_STAGE("mid");
@@ -750,7 +755,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
                 LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, dps));
             } else {
                 LFQ_TRY(lfq_launch_dp_quad(T, P, c->d_luts, d_counts, W, c->d_retry + c0, d_pvals, pvals_capacity,
-                                           n_light_waves, dps));
+                                           n_light_waves, indel_mode ? c->kreg_hint_indel : c->kreg_hint, dps));
             }
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], dps));
@@ -856,6 +861,21 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
         c->work.n_mid += sc[LFQ_CNT_MID];
         c->work.n_big += sc[LFQ_CNT_BIG];
     }
+    {
+        /* the screen-kernel variant for this context's NEXT batch: the smallest one that leaves at most 1 in 2000 light
+         * columns of THIS batch to the retry kernel (lfq_launch_dp_quad) */
+        const int32_t *sc = c->h_counters;
+        const int64_t n_light = sc[LFQ_CNT_LIGHT];
+        int hint = 64;
+        for (int f = LFQ_NKHIST - 1; f >= 0; f--) {
+            if ((int64_t)sc[LFQ_CNT_KHIST + f] >= n_light - n_light / 2000) {
+                hint = lfq_khist_thr(f) + 1;
+            }
+        }
+        if (n_light > 0) {
+            (c->cur_indel_mode ? c->kreg_hint_indel : c->kreg_hint) = hint;
+        }
+    }
     c->work.bytes_read_count = c->cur_count_read;
     c->work.bytes_written_count = c->cur_count_written;
     if (stats) {
@@ -875,7 +895,7 @@ int lfq_debug_counters(lfq_ctx *c, int32_t *out16)
     if (!c || !out16) {
         return LFQ_ERR_INVALID;
     }
-    memcpy(out16, c->h_counters, 16 * sizeof(int32_t));   /* segment 0 */
+    memcpy(out16, c->h_counters, 64 * sizeof(int32_t));   /* segment 0; the caller's buffer holds 64 values */
     return LFQ_OK;
 }
 

@@ -152,6 +152,7 @@ struct LfqStrip {
     double v[C];
     int e, de, e_in, rows;
     bool all_zero;     /* wave-uniform: nothing has entered this strip yet */
+    double sc1, sc2;   /* lfq_strip_chunk2: 2^(e of the lane one / two to the left - e), fixed between renormalisations */
 };
 
 template <int C>
@@ -164,6 +165,7 @@ __device__ __forceinline__ void lfq_strip_init(LfqStrip<C> &S, bool first_strip,
     }
     S.e = S.de = S.e_in = S.rows = 0;
     S.all_zero = !first_strip;
+    S.sc1 = S.sc2 = 1.0;
 }
 
 /* one row of the chunk as the DP consumes it: effective p and 1-p.  Observations that do not
@@ -297,6 +299,110 @@ __device__ __forceinline__ uint64_t lfq_stage_rows(const LfqColCtx &cx, const Lf
     return km;
 }
 
+/* ---- two rows per step ------------------------------------------------------------------------------------
+ * Two consecutive rows (p1, q1), (p2, q2) applied at once:
+ *     cell[k] <- cell[k] q1 q2 + cell[k-1] (p1 q2 + q1 p2) + cell[k-2] p1 p2
+ * -- three multiply-adds per cell and TWO rows instead of four, and everything a row costs besides its cells (the
+ * neighbour exchange, the LDS read of the row, the tail cell's special case) is paid once per pair.  With the
+ * renormalisation every 16 rows instead of 8 a C = 8 segment goes from ~63 to ~30 instructions per row.  The
+ * absorbing tail cell keeps its mass (coefficient 1 instead of q1 q2) and collects the inflow of both rows:
+ *     tail <- tail + cell[K-1] (p1 + q1 p2) + cell[K-2] p1 p2,      p1 + q1 p2 = (p1 q2 + q1 p2) + p1 p2.
+ * Rows that contribute no probability are (0, 1): the pair degenerates to the other row.  Same recurrence, same
+ * products of the same probabilities; the rounding differs from row-at-a-time at the 1e-16 level. */
+struct LfqRow2 {
+    double A, B, C2, omA;       /* q1 q2, p1 q2 + q1 p2, p1 p2, 1 - q1 q2 */
+};
+
+__device__ __forceinline__ uint64_t lfq_stage_rows2(const LfqColCtx &cx, const LfqRaw &raw, const LfqParams &P,
+                                                    const LfqLuts *L, LfqRow2 *rows2)
+{
+    double ps, qf;
+    const uint64_t km = lfq_eval_raw(cx, raw, P, L, &ps, &qf);
+    const int lane = lfq_lane();
+    const bool keep = (km >> lane) & 1ull;
+    const double p = keep ? ps : 0.0, q = keep ? qf : 1.0;
+    const double p2 = __shfl_xor(p, 1, 64), q2 = __shfl_xor(q, 1, 64);       /* the other row of the pair */
+    if (!(lane & 1)) {
+        LfqRow2 r;
+        r.A = q * q2;
+        r.B = fma(p, q2, q * p2);
+        r.C2 = p * p2;
+        r.omA = 1.0 - r.A;
+        rows2[lane >> 1] = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return km;
+}
+
+/* one strip over the 64 rows of a chunk, two rows per step, renormalisation + pruning test every 16 rows; single
+ * strip (no boundary exchange with other wavefronts).  Returns true when the pruning test fires. */
+template <int C>
+__device__ __forceinline__ bool lfq_strip_chunk2(LfqStrip<C> &S, const LfqRow2 *rows2, double tflag, int lt,
+                                                 double bonf_d, double sig_s)
+{
+#pragma unroll 1
+    for (int g = 0; g < 4; g++) {
+        const double sc1 = S.sc1, sc2 = S.sc2;
+#pragma unroll
+        for (int st = 0; st < 8; st++) {
+            const LfqRow2 r = rows2[g * 8 + st];
+            const double x1 = lfq_shr1_f64(S.v[C - 1]);                              /* cell -1 */
+            double x2;                                                               /* cell -2 */
+            if constexpr (C >= 2) {
+                x2 = lfq_shr1_f64(S.v[C - 2]);
+            } else {
+                x2 = lfq_shr1_f64(x1);
+            }
+            const double A0 = fma(tflag, r.omA, r.A);           /* the tail cell keeps its mass ... */
+            const double B0 = fma(tflag, r.C2, r.B);            /* ... and takes the inflow of both rows */
+            const double Bs = B0 * sc1;
+            const double Cs = r.C2 * ((C >= 2) ? sc1 : sc2);
+#pragma unroll
+            for (int j = C - 1; j >= 2; j--) {
+                S.v[j] = fma(S.v[j - 2], r.C2, fma(S.v[j - 1], r.B, S.v[j] * r.A));
+            }
+            if constexpr (C >= 2) {
+                S.v[1] = fma(x1, r.C2 * sc1, fma(S.v[0], r.B, S.v[1] * r.A));
+            }
+            S.v[0] = fma(x2, Cs, fma(x1, Bs, S.v[0] * A0));
+        }
+        /* every 16 rows: renormalise (lane maximum to [0.5,1), exponent into e) ... */
+        double m = S.v[0];
+#pragma unroll
+        for (int j = 1; j < C; j++) {
+            m = fmax(m, S.v[j]);
+        }
+        const bool nzl = m > 0.0;
+        const uint64_t nz = __ballot(nzl);
+        const int ex = nzl ? __builtin_amdgcn_frexp_exp(m) : 0;
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            S.v[j] = ldexp(S.v[j], -ex);
+        }
+        S.e += ex;
+        /* ... empty lanes (a suffix) adopt the scale of the frontier lane ... */
+        if (nz != ~0ull && nz) {
+            const int e_front = lfq_rl_i32(S.e, 63 - __builtin_clzll(nz));
+            S.e = nzl ? S.e : e_front;
+        }
+        const int e_l1 = lfq_shr1_i32(S.e), e_l2 = lfq_shr1_i32(e_l1);
+        S.de = e_l1 - S.e;
+        /* lanes 0 (and 1) read zeros from beyond the strip: any finite scale will do */
+        S.sc1 = ldexp(1.0, max(-1000, min(1000, e_l1 - S.e)));
+        S.sc2 = ldexp(1.0, max(-1000, min(1000, e_l2 - S.e)));
+        /* ... and test the pruning condition on the tail cell */
+        const uint64_t over = __ballot(ldexp(S.v[0], S.e) * bonf_d > sig_s);
+        if ((over >> lt) & 1ull) {
+            S.rows = g * 16 + 16;
+            return true;
+        }
+    }
+    S.rows = 64;
+    return false;
+}
+
 template <int C>
 __device__ __forceinline__ bool lfq_strip_final_prune(const LfqStrip<C> &S, int lt, double bonf_d, double sig_s)
 {
@@ -365,7 +471,7 @@ __device__ __forceinline__ int lfq_seg_class(int K)
  * Called by one lane. */
 __device__ __forceinline__ LfqLong *lfq_long_reserve(const LfqWork &W, int K, int n_seg, int64_t *cell0)
 {
-    const int cells = n_seg * (K + 1);
+    const int cells = 2 * n_seg * (K + 1);          /* the segments + the intermediate results of the fold tree */
     const int c0 = atomicAdd(&W.counters[LFQ_CNT_POOL], cells);
     if (c0 + cells > W.pool_cells) {
         return nullptr;
@@ -732,7 +838,7 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
 #ifdef LFQ_PROFILE
         const long long c0 = clock64();
 #endif
-        const uint64_t km = lfq_stage_rows(cx, raw, P, L, rows);
+        const uint64_t km = lfq_stage_rows2(cx, raw, P, L, reinterpret_cast<LfqRow2 *>(rows));
 #ifdef LFQ_PROFILE
         const long long c1 = clock64();
         t_stage += c1 - c0;
@@ -755,8 +861,7 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
         const long long c2 = clock64();
         t_load += c2 - c1;
 #endif
-        const bool hit = lfq_strip_chunk<C, false>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
-                                            true, lt, cx.bonf_d, cx.sig_s);
+        const bool hit = lfq_strip_chunk2<C>(S, reinterpret_cast<const LfqRow2 *>(rows), tflag, lt, cx.bonf_d, cx.sig_s);
 #ifdef LFQ_PROFILE
         t_rows += clock64() - c2;
 #endif
@@ -770,10 +875,10 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
              * the state reached here becomes segment 0 (lfq_dp_segw_kernel, lfq_dp_combine_kernel) */
             /* fewer, longer segments when many columns are long anyway: the fold costs (segments - 1) convolutions */
             const int n_new = lfq_split_plan(K, n_chunks - (ch + 1), 1,
-                                             min(P.seg_max, max(2, 4096 / max(W.counters[LFQ_CNT_MID], 1))));
+                                             min(P.seg_max, max(2, P.seg_budget_mid / max(W.counters[LFQ_CNT_MID], 1))));
             if (n_new > 0) {
                 const int n_seg = n_new + 1;
-                const int cells = n_seg * (K + 1);
+                const int cells = 2 * n_seg * (K + 1);      /* segments + intermediates of the fold tree */
                 const int cls = lfq_seg_class(K);
                 const int per_class = W.long_cap / LFQ_SEG_CLASSES;
                 const int c0 = lfq_claim(&W.counters[LFQ_CNT_POOL], cells);
@@ -1227,16 +1332,19 @@ __device__ __forceinline__ void lfq_screen_row(double (&v)[KREG], double p, doub
 
 #define LFQ_SCREEN_CLAIM 128       /* work-list entries per dequeue */
 
-template <int KREG>
+/* LB: with the default filters (no merged-quality filter, an alt base keeps its own quality) the screen works on a
+ * LOWER BOUND of every error probability, jp >= pm + (1 - pm) pb -- the alignment- and source-quality terms of the merge
+ * (snpcaller.c:334) only ever add -- read from two of the five tracks and evaluated with one FMA.  P(X >= K) is
+ * monotone in every p, so a tail computed from lower bounds that exceeds the pruning threshold proves that the exact
+ * one does: the column is pruned a row or two later than it could be (the dropped terms are ~1 % of the error mass of
+ * a typical column), never wrongly.  Everything the screen does not prune is redone exactly by the retry kernel. */
+template <int KREG, bool LB>
 __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqParams P,
                                                             const LfqLuts *__restrict__ g_luts, LfqWork W,
-                                                            uint8_t *__restrict__ retry, int max_rounds, int force_gl)
+                                                            uint8_t *__restrict__ retry, int max_rounds)
 {
     constexpr int MAXK = KREG - 1;
     __shared__ LfqLuts s_luts;
-    if (force_gl ? (force_gl != KREG) : (lfq_light_group_lanes(W, 2000) != KREG)) {
-        return;                                     /* another variant serves this batch */
-    }
     {
         const double *src = reinterpret_cast<const double *>(g_luts);
         double *dst = reinterpret_cast<double *>(&s_luts);
@@ -1335,10 +1443,10 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
             const uint64_t wbase = (uint64_t)((int64_t)off0 + rel);        /* multiple of 16 */
             bqw = *reinterpret_cast<const uint4 *>(T.bq + wbase);
             mqw = *reinterpret_cast<const uint4 *>(T.mq + wbase);
-            if (T.baq) {
+            if (!LB && T.baq) {
                 baqw = *reinterpret_cast<const uint4 *>(T.baq + wbase);
             }
-            if (T.sq) {
+            if (!LB && T.sq) {
                 sqw = *reinterpret_cast<const uint4 *>(T.sq + wbase);
             }
             if (T.nt_packed) {
@@ -1356,6 +1464,18 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
             /* packed layout: observation j of the window sits in dword j / 8, byte j % 4, nibble (j % 8) / 4 (lfq_nt_at) */
             const uint32_t nib = (((j >> 3) ? ntw.y : ntw.x) >> (8 * (j & 3) + 4 * ((j & 7) >> 2))) & 15u;
             const uint32_t ntb = packed ? nib : LFQ_SCREEN_BYTE(ntw, j);
+            if (LB) {
+                const uint32_t code = ntb & 7u, bqb = LFQ_SCREEN_BYTE(bqw, j);
+                const bool valid = code <= 3u;
+                const bool is_alt = valid & (code != (uint32_t)ref_code);
+                const bool bq_ok = (int)bqb >= (is_alt ? P.min_alt_bq4 : P.min_bq4);
+                const double pm = s_luts.mq[LFQ_SCREEN_BYTE(mqw, j) | EM.off_mq];
+                const double pl = fma(1.0 - pm, s_luts.bq[bqb], pm);
+                const bool keep = active & valid & bq_ok & ((unsigned)(rel + j) < (unsigned)n_obs);
+                lfq_screen_row<KREG>(v, keep ? pl : 0.0, keep ? 1.0 - pl : 1.0);
+                n_kept += keep ? 1 : 0;
+                continue;
+            }
             const LfqObs o = lfq_eval_obs_flat(ntb, LFQ_SCREEN_BYTE(bqw, j), LFQ_SCREEN_BYTE(baqw, j), LFQ_SCREEN_BYTE(mqw, j),
                                                LFQ_SCREEN_BYTE(sqw, j), ref_code, med, P, EM, &s_luts);
             const bool keep = active & o.keep & ((unsigned)(rel + j) < (unsigned)n_obs);
@@ -1766,7 +1886,7 @@ __global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
             continue;
         }
         if (threadIdx.x == 0) {
-            const int n_new = lfq_split_plan(kp, n_chunks, 0, min(P.seg_max, max(2, 2048 / max(n_big, 1))));
+            const int n_new = lfq_split_plan(kp, n_chunks, 0, min(P.seg_max, max(2, P.seg_budget_big / max(n_big, 1))));
             int64_t cell0 = 0;
             LfqLong *slot = (n_new > 0) ? lfq_long_reserve(W, kp, n_new, &cell0) : nullptr;
             if (slot) {
@@ -1821,12 +1941,11 @@ __device__ __forceinline__ void lfq_wave_segment(const LfqColCtx &cx, int64_t ch
     int n_rows = 0;
     LfqRaw raw = lfq_load_chunk(cx, ch0, T);
     for (int64_t ch = ch0; ch < ch1; ch++) {
-        const uint64_t km = lfq_stage_rows(cx, raw, P, L, rows);
+        const uint64_t km = lfq_stage_rows2(cx, raw, P, L, reinterpret_cast<LfqRow2 *>(rows));
         if (ch + 1 < ch1) {
             raw = lfq_load_chunk(cx, ch + 1, T);
         }
-        const bool hit = lfq_strip_chunk<C, false>(S, rows, km, false, nullptr, nullptr, false, nullptr, nullptr, tflag,
-                                                   true, lt, cx.bonf_d, cx.sig_s);
+        const bool hit = lfq_strip_chunk2<C>(S, reinterpret_cast<const LfqRow2 *>(rows), tflag, lt, cx.bonf_d, cx.sig_s);
         n_rows += __popcll(S.rows >= 64 ? km : (km & ((1ull << S.rows) - 1ull)));
         if (hit) {
             pruned = true;
@@ -1915,6 +2034,7 @@ __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqPara
 /* ------------------------------------------------------------------------------------------ */
 
 #define LFQ_COMB_THREADS 512
+#define LFQ_FOLD_MAX_CLASS 3        /* cells-per-lane classes 0..3 (K <= 1008) are folded by lfq_dp_fold_kernel */
 #define LFQ_COMB_CELLS 2048
 #define LFQ_COMB_PER_THREAD (LFQ_COMB_CELLS / LFQ_COMB_THREADS)
 
@@ -2034,7 +2154,7 @@ template <int MODE>
 __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqParams P,
                                                                           const lfq_col_counts *__restrict__ counts,
                                                                           LfqWork W, lfq_col_pvals *__restrict__ pvals,
-                                                                          int64_t pvals_capacity)
+                                                                          int64_t pvals_capacity, int only_flagged)
 {
     __shared__ LfqCombShared sh;
     const int tid = threadIdx.x;
@@ -2066,6 +2186,9 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
         }
         const LfqLong R = W.longs[cls * per_class + h];
         const int K = R.K;
+        if (only_flagged && cls < LFQ_FOLD_MAX_CLASS + 1 && R.pad1_ == 0) {
+            continue;                               /* lfq_dp_fold_kernel finished this column */
+        }
 #ifdef LFQ_PROFILE
         const long long pw_rec = wall_clock64();
 #endif
@@ -2375,6 +2498,419 @@ __global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqPar
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* fold tree: one 4-wavefront workgroup per column, one wavefront per fold                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* lfq_dp_combine_kernel folds a column's segments one after the other with a 512-thread workgroup and ~20 block
+ * barriers per fold: ~40 us per fold whatever the arithmetic costs.  Here the folds of a column form a balanced
+ * TREE -- (0,1) (2,3) (4,5) (6,7), then (01,23) (45,67), then the root -- and every fold is done by ONE wavefront
+ * with the tilted plain-FMA arithmetic of lfq_comb_plan: the four wavefronts of the workgroup work on the four
+ * pairs of the first level at the same time, two on the second, one on the root, with one block barrier per level.
+ * The critical path of 8 segments is 3 folds instead of 7, and cheap folds are what lets the segment kernels run
+ * enough wavefronts per SIMD to leave the dependent-issue regime.
+ *
+ * The tree is also what makes the single tilt work: both factors of a fold cover about the same number of rows, so
+ * their exponents fall at about the same rate (a running total after j segments falls log2(j) bits per cell more
+ * slowly than the next segment: +-700 binary orders at K = 500, j = 7 -- no common tilt flattens both).  For equal
+ * factors the tilted span is ~0.53 K binary orders whatever the error rate: K <= 1008 always fits.
+ *
+ * Per fold: exact power-of-two scaling of both factors into LDS (zero-padded on both sides, so the product loop has
+ * no bounds), c'_k = sum_i a'_i b'_(k-i) as plain FMAs (a'_i a broadcast read, b'_(k-i) consecutive across the lanes),
+ * one frexp per output cell; the absorbing tail through S'_B(j) = b'_j + 2^-t S'_B(j + 1), a scan with a constant
+ * ratio.  Intermediate distributions live in the pool behind the column's segments (which stay untouched).  MODE 0
+ * serves cells-per-lane classes 0-1 (K <= 252), MODE 1 classes 2-3 (K <= 1008); class 4 (K <= 2016: the tilted span
+ * can exceed a double's range) and any pair that fails the span / tilt check are flagged (LfqLong::pad1_) and left to
+ * the block kernel, which runs behind this one with `only_flagged` and refolds them from the segments. */
+#define LFQ_FOLD_PAD 64
+#define LFQ_FOLD_WAVES 4
+
+template <int KMAX>
+struct LfqFoldWave {
+    double as[LFQ_FOLD_PAD + KMAX + 1 + LFQ_FOLD_PAD];
+    double bs[LFQ_FOLD_PAD + KMAX + 1 + LFQ_FOLD_PAD];
+    double xv[KMAX + 1];        /* the left factor in exact form while the tilt is planned, then the result.  (The right
+                                 * factor's exact form sits in the bs / as slots of its own cells until they are scaled.) */
+    int xe[KMAX + 1];
+};
+
+__device__ __forceinline__ int lfq_wave_min_i32(int x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        x = min(x, __shfl_xor(x, d, 64));
+    }
+    return x;
+}
+
+__device__ __forceinline__ int lfq_wave_max_i32(int x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        x = max(x, __shfl_xor(x, d, 64));
+    }
+    return x;
+}
+
+__device__ __forceinline__ void lfq_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int KMAX, int NM>
+__device__ __forceinline__ void lfq_fold_conv(LfqFoldWave<KMAX> &L, int K, int shift, int t)
+{
+    constexpr int PAD = LFQ_FOLD_PAD;
+    const int lane = lfq_lane();
+    double c[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        c[m] = 0.0;
+    }
+    const double *ap = L.as + PAD, *bp = L.bs + PAD + lane;
+#pragma unroll 2
+    for (int r = 0; r < 64; r++) {
+        double a[NM], b[NM];
+#pragma unroll
+        for (int u = 0; u < NM; u++) {
+            a[u] = ap[64 * u + r];
+            b[u] = bp[64 * u - r];
+        }
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+#pragma unroll
+            for (int u = 0; u <= m; u++) {
+                c[m] = fma(a[u], b[m - u], c[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const int k = lane + 64 * m;
+        if (k < K) {                                /* x is no longer needed: the result takes its place */
+            const LfqExt o = lfq_ext_norm(c[m], shift - t * k);
+            L.xv[k] = o.v;
+            L.xe[k] = o.e;
+        }
+    }
+}
+
+/* one fold by one wavefront: src (x) (*) seg (y) -> dst (pool) and L.xv / L.xe; false = this pair needs the exact path */
+template <int KMAX>
+__device__ __forceinline__ bool lfq_fold_pair(LfqFoldWave<KMAX> &L, const LfqSegCell *src, const LfqSegCell *seg,
+                                              LfqSegCell *dst, int K, int32_t *prof)
+{
+#ifdef LFQ_PROFILE
+    long long pt_last = wall_clock64();
+#define LFQ_FP(i) do { const long long t_ = wall_clock64(); if (lfq_lane() == 0) atomicAdd(&prof[52 + (i)], (int)(t_ - pt_last)); pt_last = t_; } while (0)
+#else
+#define LFQ_FP(i)
+#endif
+    constexpr int PAD = LFQ_FOLD_PAD;
+    const int lane = lfq_lane();
+    /* both factors into LDS in exact form (one pass each over the pool, all loads in flight together) */
+    for (int k = lane; k <= K; k += 64) {
+        const LfqSegCell a = src[k], b = seg[k];
+        L.xv[k] = a.v;
+        L.xe[k] = a.e;
+        L.bs[PAD + k] = b.v;                                        /* y: mantissa in its b' slot ... */
+        reinterpret_cast<int *>(&L.as[PAD + k])[0] = b.e;           /* ... exponent in its a' slot */
+    }
+    lfq_wave_sync();
+    LFQ_FP(0);
+#define LFQ_YV(k) (L.bs[PAD + (k)])
+#define LFQ_YE(k) (reinterpret_cast<const int *>(&L.as[PAD + (k)])[0])
+    /* tilt from the exponent slopes of both factors (regular cells 0 .. K-1) */
+    int last_a = -1, last_b = -1, ea_l = 0, eb_l = 0;
+    for (int k = lane; k < K; k += 64) {
+        if (L.xv[k] > 0.0) {
+            last_a = k;
+            ea_l = L.xe[k];
+        }
+        if (LFQ_YV(k) > 0.0) {
+            last_b = k;
+            eb_l = LFQ_YE(k);
+        }
+    }
+    last_a = lfq_wave_max_i32(last_a);
+    last_b = lfq_wave_max_i32(last_b);
+    if (last_a < 0 || last_b < 0 || !(L.xv[0] > 0.0) || !(LFQ_YV(0) > 0.0)) {
+        return false;
+    }
+    const int ea_last = lfq_rl_i32(ea_l, last_a & 63), eb_last = lfq_rl_i32(eb_l, last_b & 63);
+    const double sl_a = last_a > 0 ? (double)(ea_last - L.xe[0]) / last_a : 0.0;
+    const double sl_b = last_b > 0 ? (double)(eb_last - LFQ_YE(0)) / last_b : 0.0;
+    const int t = -(int)lrint(0.5 * (sl_a + sl_b));
+    int lo_a = INT_MAX, hi_a = INT_MIN, lo_b = INT_MAX, hi_b = INT_MIN;
+    for (int k = lane; k <= K; k += 64) {
+        if (L.xv[k] > 0.0) {
+            const int E = L.xe[k] + t * k;
+            lo_a = min(lo_a, E);
+            hi_a = max(hi_a, E);
+        }
+        if (LFQ_YV(k) > 0.0) {
+            const int E = LFQ_YE(k) + t * k;
+            lo_b = min(lo_b, E);
+            hi_b = max(hi_b, E);
+        }
+    }
+    lo_a = lfq_wave_min_i32(lo_a);
+    hi_a = lfq_wave_max_i32(hi_a);
+    lo_b = lfq_wave_min_i32(lo_b);
+    hi_b = lfq_wave_max_i32(hi_b);
+    /* (|t| bounded so that the 2^(-64 t) of the scan below stays a finite double; t < 0: cells still rising at K, e.g. the
+     * few-cell recurrences left of an underflow-shortcut column) */
+    if (t < -14 || t > 60 || (long long)hi_a - lo_a > LFQ_COMB_SPAN || (long long)hi_b - lo_b > LFQ_COMB_SPAN) {
+        return false;
+    }
+    const int sa = hi_a - LFQ_COMB_TOP, sb = hi_b - LFQ_COMB_TOP;
+    LFQ_FP(1);
+    const LfqExt tail_a = {L.xv[K], L.xe[K]};
+    const double tail_b = (LFQ_YV(K) > 0.0) ? ldexp(LFQ_YV(K), LFQ_YE(K) + t * K - sb) : 0.0;    /* inside the checked range */
+    lfq_wave_sync();                                /* (everybody has read y[K] before its slot is zeroed below) */
+    /* tilted factors, regular cells only; everything else of the arrays is zero */
+    for (int k = lane; k < KMAX + 1 + PAD; k += 64) {
+        double a_s = 0.0, b_s = 0.0;
+        if (k < K) {
+            const double yv = LFQ_YV(k);
+            const int ye = LFQ_YE(k);
+            a_s = (L.xv[k] > 0.0) ? ldexp(L.xv[k], L.xe[k] + t * k - sa) : 0.0;
+            b_s = (yv > 0.0) ? ldexp(yv, ye + t * k - sb) : 0.0;
+        }
+        L.as[PAD + k] = a_s;
+        L.bs[PAD + k] = b_s;
+    }
+#undef LFQ_YV
+#undef LFQ_YE
+    lfq_wave_sync();
+    LFQ_FP(2);
+    /* c'_k = sum_(i <= k) a'_i b'_(k-i).  Cells in chunks of 64: k = 64 m + l (l = lane), i = 64 u + r:
+     *     c'[64 m + l] = sum_r sum_(u <= m) a'[64 u + r] b'[64 (m - u) + l - r]
+     * so for one r a lane needs NM values of a' (broadcast reads) and NM values of b' (consecutive across the lanes; the
+     * zero border below b'_0 absorbs l < r) for all NM (NM + 1) / 2 products of that r: 0.44 LDS reads per multiply-add
+     * at NM = 8 instead of 2 -- a wavefront on its own gets a fraction of the LDS rate and has nothing to hide the
+     * latency behind, which made the one-product-per-two-reads loop 60 us per fold.  Cells >= K of both tilted arrays
+     * are zero, so no bounds anywhere; outputs >= K are not stored. */
+    if constexpr (KMAX <= 256) {
+        if (K <= 128) {
+            lfq_fold_conv<KMAX, 2>(L, K, sa + sb, t);
+        } else {
+            lfq_fold_conv<KMAX, 4>(L, K, sa + sb, t);
+        }
+    } else {
+        const int nm = (K + 63) / 64;               /* wave-uniform */
+        if (nm <= 6) {
+            lfq_fold_conv<KMAX, 6>(L, K, sa + sb, t);
+        } else if (nm <= 8) {
+            lfq_fold_conv<KMAX, 8>(L, K, sa + sb, t);
+        } else if (nm <= 9) {
+            lfq_fold_conv<KMAX, 9>(L, K, sa + sb, t);
+        } else if (nm <= 10) {
+            lfq_fold_conv<KMAX, 10>(L, K, sa + sb, t);
+        } else if (nm <= 12) {
+            lfq_fold_conv<KMAX, 12>(L, K, sa + sb, t);
+        } else {
+            lfq_fold_conv<KMAX, 16>(L, K, sa + sb, t);
+        }
+    }
+    lfq_wave_sync();
+    LFQ_FP(3);
+    /* S'_B(j) = sum_(m >= j) b'_m 2^(-t (m - j)), cell K = the factor's tail: chunks of 64 from the top, lane l of chunk c
+     * holds j = K - 64 c - l; y_l = x_l + rho y_(l-1), rho = 2^-t (2^(-t d) may underflow to 0 for large t d: what it
+     * would have multiplied is then below every cell of the checked span anyway) */
+    {
+        double carry = 0.0;
+        for (int c = 0; c * 64 <= K; c++) {
+            const int j = K - 64 * c - lane;
+            double y = (j == K) ? tail_b : (j >= 0 ? L.bs[PAD + j] : 0.0);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double up = __shfl_up(y, d, 64);
+                if (lane >= d) {
+                    y = fma(up, ldexp(1.0, -t * d), y);
+                }
+            }
+            y = fma(carry, ldexp(1.0, -t * (lane + 1)), y);
+            carry = lfq_rl_f64(y, 63);
+            if (j >= 0) {
+                L.bs[PAD + j] = y;
+            }
+        }
+    }
+    lfq_wave_sync();
+    LFQ_FP(4);
+    /* tail_C = tail_A + 2^(sa + sb - t K) sum_(i < K) a'_i S'_B(K - i) */
+    double acc = 0.0;
+    for (int i = lane; i < K; i += 64) {
+        acc = fma(L.as[PAD + i], L.bs[PAD + K - i], acc);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        acc += __shfl_xor(acc, d, 64);
+    }
+    if (!(acc < 1.7e308)) {                         /* S'_B left the double range: the block kernel's exact path */
+        return false;
+    }
+    LfqExt tot = tail_a;
+    if (acc > 0.0) {
+        tot = lfq_ext_add(tot, lfq_ext_norm(acc, sa + sb - t * K));
+    }
+    tot = lfq_ext_norm(tot.v, tot.e);
+    if (lane == (K & 63)) {
+        L.xv[K] = tot.v;
+        L.xe[K] = tot.e;
+    }
+    lfq_wave_sync();
+    for (int k = lane; k <= K; k += 64) {
+        LfqSegCell c;
+        c.v = L.xv[k];
+        c.e = L.xe[k];
+        c.pad_ = 0;
+        dst[k] = c;
+    }
+    LFQ_FP(5);
+    if (lfq_lane() == 0) {
+        LFQ_FP(6);
+    }
+#ifdef LFQ_PROFILE
+    if (lfq_lane() == 0) atomicAdd(&prof[60], 1);
+#endif
+    return true;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * LFQ_FOLD_WAVES) void lfq_dp_fold_kernel(LfqParams P,
+                                                                        const lfq_col_counts *__restrict__ counts,
+                                                                        LfqWork W, lfq_col_pvals *__restrict__ pvals,
+                                                                        int64_t pvals_capacity)
+{
+    constexpr int KMAX = MODE ? 1008 : 252;
+    constexpr int NW = LFQ_FOLD_WAVES;
+    __shared__ LfqFoldWave<KMAX> s_wave[NW];
+    __shared__ int s_slot[LFQ_SEG_MAX];
+    __shared__ int s_idx, s_slow;
+    const int lane = lfq_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    LfqFoldWave<KMAX> &L = s_wave[wv];
+    constexpr int C_LO = MODE ? 2 : 0, C_HI = MODE ? LFQ_FOLD_MAX_CLASS + 1 : 2;
+    const int per_class = W.long_cap / LFQ_SEG_CLASSES;
+    int n_cls[LFQ_SEG_CLASSES], n_all = 0;
+#pragma unroll
+    for (int c = 0; c < LFQ_SEG_CLASSES; c++) {
+        n_cls[c] = (c >= C_LO && c < C_HI) ? min(W.counters[LFQ_CNT_LONG0 + c], per_class) : 0;
+        n_all += n_cls[c];
+    }
+    /* the zero borders of the tilted arrays never change */
+    L.as[lane] = 0.0;
+    L.bs[lane] = 0.0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_idx = atomicAdd(&W.counters[LFQ_CNT_HEAD_FOLD + MODE], 1);
+            s_slow = 0;
+        }
+        if (threadIdx.x < LFQ_SEG_MAX) {
+            s_slot[threadIdx.x] = (int)threadIdx.x; /* where the distribution of tree node i of this level lives */
+        }
+        __syncthreads();
+        int h = s_idx;
+        if (h >= n_all) {
+            break;
+        }
+        int cls = C_HI - 1;                         /* widest class first: its folds take longest */
+        while (h >= n_cls[cls]) {
+            h -= n_cls[cls];
+            cls--;
+        }
+        LfqLong *Rp = W.longs + cls * per_class + h;
+        const LfqLong R = *Rp;
+        const int K = R.K;
+        LfqColCtx cx;
+        lfq_ctx_from_long(cx, R, P);
+        int rows_total = R.rows;
+        bool pruned = R.pruned != 0;
+        for (int sgi = R.phase1; sgi < R.n_seg; sgi++) {
+            const int f = W.pool[R.cell0 + (int64_t)sgi * (K + 1)].pad_;
+            rows_total += f & 0x3fffffff;
+            pruned = pruned || (f & 0x40000000) != 0;
+        }
+        bool slow = K > KMAX;
+        LfqSegCell *base = W.pool + R.cell0;
+        if (!pruned && !slow) {
+            int next_slot = R.n_seg;                /* intermediates go behind the segments, which stay untouched */
+            for (int stride = 1; stride < R.n_seg; stride *= 2) {
+                /* the pairs of this level, NW at a time */
+                const int n_pairs = (R.n_seg - stride + 2 * stride - 1) / (2 * stride);
+                for (int p0 = 0; p0 < n_pairs; p0 += NW) {
+                    const int pr = p0 + wv, s0 = pr * 2 * stride;
+                    if (pr < n_pairs) {
+                        const bool ok = lfq_fold_pair<KMAX>(L, base + (int64_t)s_slot[s0] * (K + 1),
+                                                            base + (int64_t)s_slot[s0 + stride] * (K + 1),
+                                                            base + (int64_t)(next_slot + pr) * (K + 1), K, W.counters);
+                        if (!ok && lane == 0) {
+                            s_slow = 1;
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    if (pr < n_pairs && lane == 0) {
+                        s_slot[s0] = next_slot + pr;
+                    }
+                    __syncthreads();
+                }
+                next_slot += n_pairs;
+                if (s_slow) {
+                    break;
+                }
+            }
+            slow = s_slow != 0;
+        }
+        if (slow) {
+            if (threadIdx.x == 0) {
+                Rp->pad1_ = 1;                      /* lfq_dp_combine_kernel(only_flagged) takes it from here */
+            }
+            continue;
+        }
+        if (wv != 0) {
+            continue;                               /* the root of the tree was folded by wavefront 0 */
+        }
+        if (!pruned) {
+            if (R.n_seg <= 1) {                     /* a single segment: nothing was folded */
+                for (int k = lane; k <= K; k += 64) {
+                    const LfqSegCell c = base[k];
+                    L.xv[k] = c.v;
+                    L.xe[k] = c.e;
+                }
+                lfq_wave_sync();
+            }
+            pruned = ldexp(L.xv[K], L.xe[K]) * cx.bonf_d > cx.sig_s;
+        }
+        if (lane == 0) {
+            lfq_account(W, rows_total, K);
+        }
+        if (!pruned) {
+            /* natural logs in poissbin()'s probvec layout, into the a' array */
+            for (int k = lane; k <= K; k += 64) {
+                const double ed = (double)L.xe[k];
+                const double v = L.xv[k];
+                L.as[k] = (v > 0.0) ? (ed * LFQ_LN2_HI + (ed * LFQ_LN2_LO + log(v))) : -INFINITY;
+            }
+            lfq_wave_sync();
+        }
+        if (!pruned || R.uf_mask) {
+            const lfq_col_counts cnt = counts[R.col];
+            lfq_emit_pvals(cx, cnt, L.as, K, !pruned, R.uf_mask, R.uf_bound, R.force_fe != 0, rows_total, W, pvals,
+                           pvals_capacity);
+        }
+        /* the probvec sat in the low border of a': zero it again */
+        lfq_wave_sync();
+        L.as[lane] = 0.0;
+        lfq_wave_sync();
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* launchers                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -2452,19 +2988,28 @@ int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_
     if (n_blocks <= 0) {
         return LFQ_OK;
     }
+    const int fold = lfq_knobs().fold_kernel;       /* LFQ_FOLD_KERNEL=0: A/B, every column through the block kernel */
     if (mode == 0) {
+        if (fold) {
+            hipLaunchKernelGGL(lfq_dp_fold_kernel<0>, dim3((unsigned)n_blocks * 4), dim3(64 * LFQ_FOLD_WAVES), 0,
+                               (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+        }
         hipLaunchKernelGGL(lfq_dp_combine_kernel<0>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
-                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, fold);
     } else {
+        if (fold) {
+            hipLaunchKernelGGL(lfq_dp_fold_kernel<1>, dim3((unsigned)n_blocks), dim3(64 * LFQ_FOLD_WAVES), 0,
+                               (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+        }
         hipLaunchKernelGGL(lfq_dp_combine_kernel<1>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
-                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, fold);
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
 
 int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                        const lfq_col_counts *d_counts, const LfqWork &w, uint8_t *d_retry, lfq_col_pvals *d_pvals,
-                       int64_t pvals_capacity, int n_waves, void *stream)
+                       int64_t pvals_capacity, int n_waves, int kreg_hint, void *stream)
 {
     if (t.ncols <= 0 || n_waves <= 0) {
         return LFQ_OK;
@@ -2472,21 +3017,48 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
     const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const LfqKnobs &kn = lfq_knobs();
-    const int force = kn.light_lanes;                /* A/B: LFQ_QUAD_LANES = 8, 16, 32 or 64 */
-    /* one of the variants serves the batch (lfq_light_group_lanes, decided on the device from the K histogram of
-     * the scan); the others return at once */
+    int force = kn.light_lanes;                      /* A/B: LFQ_QUAD_LANES = cells (lanes) per light column, or 64 */
     if (kn.light_kernel == 1) {                      /* A/B: the lane-group kernels (LFQ_LIGHT_KERNEL=quad) */
+        /* one of the variants serves the batch (lfq_light_group_lanes, decided on the device from the K histogram
+         * of the scan); the others return at once */
         hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, 64, force);
         hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, 32, force);
         hipLaunchKernelGGL(lfq_dp_quad_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 16, force);
-    } else {                                         /* one light column per lane */
-        hipLaunchKernelGGL(lfq_dp_screen_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
-        hipLaunchKernelGGL(lfq_dp_screen_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
-        hipLaunchKernelGGL(lfq_dp_screen_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, kn.screen_rounds, force);
-    }
-    if (force == 0 || force == 64) {
-        hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
-                           d_pvals, pvals_capacity, 32, force == 64 ? 0 : (kn.light_kernel == 1 ? 10 : 2000));
+        if (force == 0 || force == 64) {
+            hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
+                               d_pvals, pvals_capacity, 32, force == 64 ? 0 : 10);
+        }
+    } else {
+        /* one light column per lane: ONE variant is launched, chosen on the host from the K histogram the scan of this
+         * context's previous batch left behind (a batch cannot wait for its own scan without stalling the host).  Any
+         * choice is correct: a column with more alt bases than the variant has cells goes to the retry kernel. */
+        if (!force) {
+            force = kreg_hint > 0 ? kreg_hint : 8;
+        }
+        /* lower-bound evaluation where the filters allow it (see the kernel) */
+        const bool lb = !p.general && p.def_alt_bq == 0 && p.def_alt_jp < 0.0 && !kn.screen_exact;
+#define LFQ_LAUNCH_SCREEN(KR)                                                                                        \
+    do {                                                                                                             \
+        if (lb) {                                                                                                    \
+            hipLaunchKernelGGL((lfq_dp_screen_kernel<KR, true>), grid, block, 0, st, t, p, d_luts, w, d_retry,       \
+                               kn.screen_rounds);                                                                    \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL((lfq_dp_screen_kernel<KR, false>), grid, block, 0, st, t, p, d_luts, w, d_retry,      \
+                               kn.screen_rounds);                                                                    \
+        }                                                                                                            \
+    } while (0)
+        if (force <= 6) LFQ_LAUNCH_SCREEN(6);
+        else if (force <= 8) LFQ_LAUNCH_SCREEN(8);
+        else if (force <= 10) LFQ_LAUNCH_SCREEN(10);
+        else if (force <= 12) LFQ_LAUNCH_SCREEN(12);
+        else if (force <= 16) LFQ_LAUNCH_SCREEN(16);
+        else if (force <= 24) LFQ_LAUNCH_SCREEN(24);
+        else if (force <= 32) LFQ_LAUNCH_SCREEN(32);
+        else {
+            hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
+                               d_pvals, pvals_capacity, 32, 0);
+        }
+#undef LFQ_LAUNCH_SCREEN
     }
     hipLaunchKernelGGL(lfq_dp_retry_kernel, grid, block, 0, st, t, p, d_luts, d_counts, w, d_retry, d_pvals,
                        pvals_capacity);

@@ -54,9 +54,13 @@ const LfqKnobs &lfq_knobs(void)
         x.light_lanes = (int)geti("LFQ_QUAD_LANES", 0);
         x.light_waves_per_cu = (int)std::max(4L, geti("LFQ_LIGHT_WAVES_PER_CU", 10));
         x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 8));
-        x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 16));
+        x.screen_exact = has("LFQ_SCREEN_EXACT");
+        x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));
         x.phase1_chunks = (int)std::max(1L, geti("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
         x.seg_max = (int)std::min((long)LFQ_SEG_MAX, std::max(2L, geti("LFQ_SEG_MAX", LFQ_SEG_MAX)));
+        x.fold_kernel = geti("LFQ_FOLD_KERNEL", 1) != 0;
+        x.seg_budget_mid = (int)std::max(1L, geti("LFQ_SEG_BUDGET_MID", 4096));
+        x.seg_budget_big = (int)std::max(1L, geti("LFQ_SEG_BUDGET_BIG", 4096));
         x.segments = (int)std::min((long)LFQ_MAX_SEGMENTS, std::max(1L, geti("LFQ_SEGMENTS", 1)));
         x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);

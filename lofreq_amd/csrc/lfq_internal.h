@@ -38,6 +38,8 @@ struct LfqParams {
     double sig;               /* (double)(float)conf->sig */
     double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
     int32_t seg_max;          /* row segments per split column, 2..LFQ_SEG_MAX */
+    int32_t seg_budget_mid, seg_budget_big;   /* segments per column = min(seg_max, budget / columns of the class): a few
+                                               * thousand wavefronts of row segments fill the chip, more only cost folds */
     int32_t phase1_chunks;    /* mid class: 64-row chunks run unsplit before a surviving column is cut up */
     /* `lofreq uniq --use-det-lim` (lofreq_uniq.c:274-333): per column the assumed allele frequency; the first alt
      * count becomes (int)(af * n_err_probs), the others 0, and only the 'N' reference gate applies.  null = off */
@@ -115,6 +117,15 @@ struct LfqLong {              /* 128 bytes */
 #define LFQ_SPLIT_MAX_K 2016      /* 63 * 32: one wavefront at 32 cells per lane; the combine kernel keeps two
                                    * (K+1)-cell distributions in LDS */
 
+/* largest K a screen-kernel variant with lfq_khist_thr(f) + 1 cells per lane serves (lfq_dp_screen_kernel<KREG>) */
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline int lfq_khist_thr(int f)
+{
+    return f == 0 ? 5 : f == 1 ? 7 : f == 2 ? 9 : f == 3 ? 11 : f == 4 ? 15 : f == 5 ? 23 : 31;
+}
+
 /* work lists and counters produced by the scan kernels, consumed by the DP kernel */
 struct LfqWork {
     int32_t *tested_prefix;   /* [ncols] inclusive count of tested columns up to and incl. c */
@@ -152,11 +163,14 @@ struct LfqWork {
 #define LFQ_CNT_HEAD_PREP 6
 #define LFQ_CNT_POOL 7         /* cells handed out from LfqWork::pool */
 #define LFQ_CNT_HEAD_COMB 24        /* and 25: one head per fold kernel mode */
+#define LFQ_CNT_HEAD_FOLD 48        /* and 49: the wavefront-per-column fold kernel's heads */
 #define LFQ_CNT_KLE7 26             /* light columns with K <= 7 / <= 15 / <= 31: picks the lanes-per-column of the */
 #define LFQ_CNT_KLE15 27            /* quad kernel for this batch (lfq_light_group_lanes) */
 #define LFQ_CNT_KLE31 28
 #define LFQ_CNT_XHEAD 64       /* screen kernel: dequeue heads of the eight XCD slices of the light list, one per 128-byte
                                 * line (head x at counters[LFQ_CNT_XHEAD + 32 x]): atomics on one line serialise */
+#define LFQ_CNT_KHIST 40            /* .. 46: light columns with K <= lfq_khist_thr(f): the screen kernel's register variants */
+#define LFQ_NKHIST 7
 #define LFQ_CNT_LONG0 16       /* +class: row-split columns per cells-per-lane class (LFQ_SEG_CLASSES) */
 
 /* ---- experiment / debugging knobs ----------------------------------------------------------------
@@ -172,9 +186,12 @@ struct LfqKnobs {
     int light_lanes;           /* LFQ_QUAD_LANES: force 8 / 16 / 32 / 64 cells (lanes) per light column; 0 = per batch */
     int light_waves_per_cu;    /* LFQ_LIGHT_WAVES_PER_CU (10): lane-group kernels */
     int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (8) */
-    int screen_rounds;         /* LFQ_SCREEN_ROUNDS (16): 16-row windows before a light column goes to the retry kernel */
+    int screen_exact;          /* LFQ_SCREEN_EXACT: the screen kernel evaluates the full quality merge instead of its lower bound */
+    int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
     int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
+    int fold_kernel;           /* LFQ_FOLD_KERNEL (1): segments folded by one wavefront per column (0: block kernel only) */
     int seg_max;               /* LFQ_SEG_MAX */
+    int seg_budget_mid, seg_budget_big;   /* LFQ_SEG_BUDGET_MID (4096), LFQ_SEG_BUDGET_BIG (4096) */
     int segments;              /* LFQ_SEGMENTS: batch segments */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
@@ -341,9 +358,12 @@ int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t
 int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                         const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                         int64_t pvals_capacity, int n_waves, void *stream);
+/* kreg_hint: cells per lane of the screen kernel variant to launch (from the K histogram of the context's previous
+ * batch; any value is correct, a poor one only sends more columns to the retry kernel); 64 = the light class needs
+ * whole wavefronts */
 int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                        const lfq_col_counts *d_counts, const LfqWork &w, uint8_t *d_retry, lfq_col_pvals *d_pvals,
-                       int64_t pvals_capacity, int n_waves, void *stream);
+                       int64_t pvals_capacity, int n_waves, int kreg_hint, void *stream);
 int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                       const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                       int64_t pvals_capacity, int n_waves, void *stream);

@@ -645,6 +645,7 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
     const uint32_t base_big = base_mid + (uint32_t)W.counters[LFQ_CNT_MID];
     const uint32_t carry_in = (uint32_t)W.counters[LFQ_CNT_CARRY_IN];
     uint32_t kle7 = 0, kle15 = 0, kle31 = 0;       /* K histogram of the light class (lfq_light_group_lanes) */
+    unsigned long long khist = 0;
     for (int i = 0; i < LFQ_SCAN_ITEMS; i++) {
         const int64_t c = base + i;
         if (c >= ncols) {
@@ -662,6 +663,11 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
                 kle7 += cn->kmax <= 7;
                 kle15 += cn->kmax <= 15;
                 kle31 += cn->kmax <= 31;
+                /* finer histogram for the screen kernel's register variants: 9-bit fields, <= 4 per thread */
+#pragma unroll
+                for (int f = 0; f < LFQ_NKHIST; f++) {
+                    khist += (unsigned long long)(cn->kmax <= lfq_khist_thr(f)) << (9 * f);
+                }
             }
             ex.t++;
             const uint32_t rb = T.ref_base[c];
@@ -680,22 +686,33 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
         W.tested_prefix[c] = (int32_t)(carry_in + ex.t);   /* inclusive, batch-wide */
     }
     /* one set of global atomics per workgroup (per wavefront they contend: +0.1 ms on a 1 M column batch) */
-    __shared__ uint32_t s_k[3];
-    if (threadIdx.x < 3) {
+    __shared__ uint32_t s_k[3 + LFQ_NKHIST];
+    if (threadIdx.x < 3 + LFQ_NKHIST) {
         s_k[threadIdx.x] = 0;
     }
     __syncthreads();
     kle7 = lfq_wave_sum_u32(kle7);
     kle15 = lfq_wave_sum_u32(kle15);
     kle31 = lfq_wave_sum_u32(kle31);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        khist += __shfl_xor(khist, d, 64);          /* 64 lanes x <= 4: every field stays below 2^9 */
+    }
     if (lfq_lane() == 0 && kle31) {
         atomicAdd(&s_k[0], kle7);
         atomicAdd(&s_k[1], kle15);
         atomicAdd(&s_k[2], kle31);
+#pragma unroll
+        for (int f = 0; f < LFQ_NKHIST; f++) {
+            atomicAdd(&s_k[3 + f], (uint32_t)((khist >> (9 * f)) & 511ull));
+        }
     }
     __syncthreads();
     if (threadIdx.x < 3 && s_k[2]) {
         atomicAdd(&W.counters[LFQ_CNT_KLE7 + (int)threadIdx.x], (int)s_k[threadIdx.x]);
+    }
+    if (threadIdx.x >= 3 && threadIdx.x < 3 + LFQ_NKHIST && s_k[2]) {
+        atomicAdd(&W.counters[LFQ_CNT_KHIST + (int)threadIdx.x - 3], (int)s_k[threadIdx.x]);
     }
 }
 
