@@ -200,8 +200,9 @@ def live_pmc(child_args, count_kernel):
         out["traffic"] = (2.0 * fk + wk) * 1024.0 / n
     if v:
         dp = {k: x for k, x in v.items() if k.startswith("lfq_dp_") or k.startswith("lfq_strand_")}
-        # per step: every DP kernel is launched once per step (the empty variants included)
-        steps = max(min(x[1] for x in dp.values()), 1) if dp else 1
+        # per step: the pass ran as many steps as it launched count kernels (the screen kernel's variant may differ
+        # between the first step of a context and the later ones, so no single DP kernel counts the steps)
+        steps = max(v[count_kernel][1], 1) if count_kernel in v else 2
         out["valu_insts_dp"] = sum(x[0] for x in dp.values()) / steps
         out["valu_by_kernel"] = {k: x[0] / steps for k, x in dp.items()}
         if count_kernel in v:
