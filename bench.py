@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- pileup columns/sec of the per-column SNV calling path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config C3|C2] [--mode resident|host-abi|chain]
+    python bench.py --gpus N --steps K --warmup W [--config C3|C2] [--mode resident|host-abi|chain|baq]
 
 A step is one pass of the hot path (count -> running-Bonferroni scan -> Poisson-binomial DP -> host emit test /
 filter / VCF records) over one batch of synthetic pileup columns that are ALREADY RESIDENT IN HBM (generated on
@@ -63,7 +63,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
-    ap.add_argument("--mode", choices=["resident", "host-abi", "chain"], default="resident",
+    ap.add_argument("--idaq", action="store_true", help="--mode baq: also the indel alignment qualities (ai / ad)")
+    ap.add_argument("--mode", choices=["resident", "host-abi", "chain", "baq"], default="resident",
                     help="resident (default, the metric): tracks in HBM; host-abi: host buffers through the C ABI; "
                          "chain: reads -> BAQ -> pileup -> calls on a resident read set")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -286,6 +287,40 @@ def make_reads(n, glen, rl=150, seed=3, indel_frac=0.04):
     }
 
 
+def bench_baq(caller, la, n_reads, glen, iters, want_idaq=False):
+    """the BAQ (kpa_ext_glocal, bam_md_ext.c:260-491) step alone on a resident read set: `lofreq alnqual` / the
+    on-the-fly BAQ of `lofreq call`, per 400 K x 150 bp reads (the unit VERDICT r01 item 4 is quoted on)"""
+    import ctypes as C
+    from lofreq_amd import _lib
+    R = make_reads(n_reads, glen, indel_frac=0.04 if want_idaq else 0.0)
+    L = _lib.load()
+    pr = _lib.PileupReads()
+    pr.n_reads = R["n"]
+    pr.pos, pr.cigar_off, pr.cigar = R["pos"].ctypes.data, R["cig_off"].ctypes.data, R["cig"].ctypes.data
+    pr.seq_off, pr.seq, pr.qual = R["seq_off"].ctypes.data, R["seq"].ctypes.data, R["qual"].ctypes.data
+    pr.baq = None
+    pr.mapq, pr.reverse = R["mapq"].ctypes.data, R["rev"].ctypes.data
+    pr.ref = C.cast(C.c_char_p(R["ref"]), C.c_void_p)
+    pr.ref_len = glen
+    tg = _lib.PileupIndelTags()
+    tg.bi, tg.bd = R["bi"].ctypes.data, R["bd"].ctypes.data
+    h = C.c_void_p()
+    _lib.check(L.lfq_readset_create(caller.h, C.byref(pr), C.byref(tg), C.byref(h)), "lfq_readset_create")
+    best = None
+    for _ in range(iters + 1):
+        t0 = time.perf_counter()
+        _lib.check(L.lfq_readset_baq(caller.h, h, 1, 1 if want_idaq else 0), "lfq_readset_baq")
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    L.lfq_readset_destroy(h)
+    n_bases = int(R["seq_off"][-1])
+    return {"reads": R["n"], "read_len": 150, "idaq": bool(want_idaq), "s_call": best, "reads_per_s": R["n"] / best,
+            # seq + qual + one reference window in, lb out (DESIGN 6b)
+            "algorithmic_bytes": 3 * n_bases + R["n"] * (150 + 14),
+            "note": "wall time of lfq_readset_baq (host geometry of the CIGARs + kernel + sync) on a resident read "
+                    "set; kernel time alone: profiles/r02_baq_stats.md"}
+
+
 def bench_chain(caller, la, n_reads, glen, iters, call_indels=True):
     """reads -> BAQ (+ IDAQ) -> device pileup(s) -> SNV (+ indel) calls on a resident read set: the reference's
     `lofreq call [--call-indels]` with BAQ on (BASELINE.md end-to-end rows), everything after BAM decoding."""
@@ -388,6 +423,15 @@ def main():
                 "warmup": args.warmup, "ms_per_step": res["s_total"] * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "chain: 2 M reads x 150 bp over 1 Mb (depth 300), --call-indels, BAQ on", **res}}
+        print(json.dumps(line))
+        caller.close()
+        return
+    if args.mode == "baq":
+        res = bench_baq(caller, la, 400000, 2000000, max(args.steps // 20, 3), want_idaq=bool(args.idaq))
+        line = {"metric": "reads/sec through BAQ (kpa_ext_glocal per read), resident read set", "value": res["reads_per_s"],
+                "unit": "reads/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["s_call"] * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "baq: 400 K reads x 150 bp over 2 Mb", **res}}
         print(json.dumps(line))
         caller.close()
         return

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblofreq_amd.so")
+LIB_PATH = os.environ.get("LFQ_AMD_LIB") or os.path.join(_HERE, "liblofreq_amd.so")   # LFQ_AMD_LIB: another build of the same library (A/B runs)
 
 LFQ_OK = 0
 LFQ_ERR_CAPACITY = -4

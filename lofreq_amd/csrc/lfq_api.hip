@@ -1747,13 +1747,14 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     const bool use_lds = lfq_knobs().baq_lds != 0;
     std::vector<int32_t> order((size_t)n);
     int64_t n_narrow = 0;
-    int max_lref_narrow = 0;
+    int max_lref_narrow = 0, max_lq_narrow = 0;
     {
         int64_t wi = n;
         for (int64_t r = 0; r < n; r++) {
             if (use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
                 order[(size_t)n_narrow++] = (int32_t)r;
                 max_lref_narrow = std::max(max_lref_narrow, h[(size_t)r].l_ref);
+                max_lq_narrow = std::max(max_lq_narrow, h[(size_t)r].l_qseq);
             }
         }
         for (int64_t r = n - 1; r >= 0; r--) {
@@ -1825,7 +1826,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         if (lfq_knobs().baq_scratch_mb >= 0) {
             budget_b = (int64_t)lfq_knobs().baq_scratch_mb << 20;
         }
-        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64, budget_b / per_wave));
+        /* + 1: the narrow and the wide reads round up to whole wavefronts separately */
+        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64 + 1, budget_b / per_wave));
         auto keep = [&](auto **slot, int64_t *have, int64_t need) {
             if (need > *have) {
                 if (*slot) (void)hipFree(*slot);
@@ -1858,13 +1860,50 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         A.tmp8 = d_tmp8;
         A.order = (const int32_t *)(d_blob + o_ord);
         A.max_lref = max_lref_narrow;
-        for (int64_t first = 0; rc == LFQ_OK && first < n_narrow; first += waves * 64) {
-            A.first_read = (int32_t)first;
-            rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n_narrow - first), 1, c->stream);
-        }
-        for (int64_t first = n_narrow; rc == LFQ_OK && first < n; first += waves * 64) {
-            A.first_read = (int32_t)first;
-            rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
+        A.lds_rows = max_lq_narrow + 1;
+        /* the few reads with a wider band (indels longer than the default band) are a handful of latency-bound
+         * wavefronts: they run beside the narrow-band kernel on a side stream when everything fits one launch each
+         * (disjoint reads, disjoint scratch: wavefront w of a launch owns slot w, the wide launch starts behind the
+         * narrow one's slots) */
+        const int64_t waves_narrow = (n_narrow + 63) / 64, waves_wide = (n - n_narrow + 63) / 64;
+        const bool beside = n_narrow > 0 && n > n_narrow && waves_narrow + waves_wide <= waves && c->side[0] != nullptr
+                            && !lfq_knobs().single_stream;
+        if (beside) {
+            LfqBaqArgs Aw = A;
+            Aw.scratch = A.scratch + (size_t)waves_narrow * (size_t)(per_wave / 8);
+            Aw.expect = A.expect + (size_t)waves_narrow * A.rows * 64;
+            Aw.tmp8 = A.tmp8 + (size_t)waves_narrow * 2 * A.rows * 64;
+            if (want_idaq) {
+                Aw.itab = A.itab + (size_t)waves_narrow * LFQ_BAQ_MAX_INDELS * 4 * 64;
+                Aw.terms = A.terms + (size_t)waves_narrow * LFQ_BAQ_MAX_TERMS * 64;
+            }
+            Aw.first_read = (int32_t)n_narrow;
+            /* the side stream starts after the uploads / memsets queued on c->stream, c->stream ends after it */
+            if (hipEventRecord(c->ev_join[0], c->stream) != hipSuccess || hipStreamWaitEvent(c->side[0], c->ev_join[0], 0) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (rc == LFQ_OK) {
+                rc = lfq_launch_baq(Aw, n - n_narrow, 0, c->side[0]);
+            }
+            if (rc == LFQ_OK && (hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess)) {
+                rc = LFQ_ERR_HIP;
+            }
+            A.first_read = 0;
+            if (rc == LFQ_OK) {
+                rc = lfq_launch_baq(A, n_narrow, 1, c->stream);
+            }
+            if (rc == LFQ_OK && hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        } else {
+            for (int64_t first = 0; rc == LFQ_OK && first < n_narrow; first += waves * 64) {
+                A.first_read = (int32_t)first;
+                rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n_narrow - first), 1, c->stream);
+            }
+            for (int64_t first = n_narrow; rc == LFQ_OK && first < n; first += waves * 64) {
+                A.first_read = (int32_t)first;
+                rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
+            }
         }
     }
     std::vector<uint8_t> dfl;

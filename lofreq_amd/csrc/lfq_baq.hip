@@ -574,6 +574,689 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
 #undef RC
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Narrow-band reads, rows in REGISTERS (lfq_baq_reg_kernel).
+ *
+ * With the default band of 7 a row of the HMM is 15 cells x 3 states.  In the band-relative layout -- slot j of row i
+ * holds reference position k = i - bw + j -- every dependency of the recurrences has a STATIC slot distance:
+ *     forward   (i, k) <- (i-1, k-1) = slot j of the old row (match / all three states), (i-1, k) = slot j + 1
+ *               (insertion), (i, k-1) = slot j - 1 of the new row (deletion);
+ *     backward  (i, k) <- (i+1, k+1) = slot j, (i+1, k) = slot j - 1 of the old row, (i, k+1) = slot j + 1 of the new row.
+ * So the row lives in 45 doubles of registers, updated in place (ascending j forward, descending j backward) by a
+ * fully unrolled loop over the 15 slots: no LDS round trip inside the dependent chain, two wavefronts per SIMD.
+ * Cells outside [max(1, i - bw), min(l_ref, i + bw)] are kept at exactly 0, which is what the reference reads from
+ * its calloc'ed matrices there.  Same operations in the same order on the same doubles as kpa_ext_glocal
+ * (kprobaln_ext.c:134-268; -ffp-contract=off): bit-identical state / quality per base.
+ *
+ * Schedule.  The row index i is the same for all 64 reads of a wavefront (a read shorter than the longest one idles
+ * at the ends), and the rows are cut into three ranges: the interior rows, where every read of the wavefront has all
+ * 15 cells (8 <= i, i + 7 <= l_ref, i <= l_query), run a branch-free body without the per-cell bounds; the few rows
+ * before and after run the general body.  Separate loops, so that the masks of the general body cost the interior
+ * loop no registers: it fits 2 wavefronts per SIMD without spilling.
+ *
+ * Inside the row loops only the forward matrix moves through HBM (write-once in the forward pass, read-once by the
+ * MAP step: (match, insertion) of a slot as one 16-byte pair, 1 KiB contiguous per wavefront and slot):
+ *   - base code and quality of every row: LDS ((code | quality << 8) per row and read, staged once), the quality's
+ *     probability one row ahead from the 1 KiB table (cache resident);
+ *   - the reference bases of the band: a 64-bit window of sixteen 4-bit codes that shifts by one base per row; the
+ *     codes that enter it come 16 rows at a time, four 4-byte loads requested 16 rows before they are needed;
+ *   - 1 / s[i] and expect[i-1] of the backward pass: four rows per batch, requested four to eight rows ahead;
+ *   - the BAQ byte of a row goes into the LDS slot of a row that is done, the extended-BAQ passes run there and
+ *     the read's bytes leave in one burst.
+ * The LDS-row kernel above (LFQ_BAQ_KERNEL=1) is the previous implementation, kept for A/B runs. */
+#define LFQ_BAQ_NB 15
+struct alignas(16) LfqBaqPair {
+    double m, i;
+};
+/* One wavefront per SIMD: the interior row needs ~330 registers (45 + 30 doubles of rows, the transition matrix,
+ * the prefetch batches), which the unified 512-entry file of gfx950 holds (256 VGPRs + AGPRs as the overflow).  At two
+ * wavefronts per SIMD (256 in all) the row loops spill into scratch, whose reloads queue behind the forward matrix's
+ * stores: measured 12.8 ms against 7.0 ms per 400 K reads. */
+#define LFQ_BAQ_WAVES 1
+
+/* sixteen 4-bit base codes out of four ASCII dwords (byte t of dword d = code 4 d + t) */
+__device__ __forceinline__ unsigned long long lfq_baq_pack16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3)
+{
+    const uint32_t d[4] = {d0, d1, d2, d3};
+    unsigned long long w = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        w |= (unsigned long long)lfq_baq_code((int)((d[t >> 2] >> (8 * (t & 3))) & 0xffu)) << (4 * t);
+    }
+    return w;
+}
+
+/* the ASCII bytes of reference positions p .. p + 3 of a read's window (1-based; 'N' outside 1 .. l_ref) */
+__device__ __forceinline__ uint32_t lfq_baq_ref4(const uint8_t *refw, int p, int l_ref)
+{
+    if (p >= 1 && p + 3 <= l_ref) {
+        uint32_t v;
+        __builtin_memcpy(&v, refw + p, 4);           /* unaligned dword */
+        return v;
+    }
+    uint32_t v = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int k = p + t;
+        v |= (uint32_t)((k >= 1 && k <= l_ref) ? refw[k] : (uint8_t)'N') << (8 * t);
+    }
+    return v;
+}
+
+/* one interior row of the forward pass (all 15 cells exist for every read of the wavefront); HASN: some read has an
+ * N in its window or as its base */
+template <bool HASN, bool IDAQ>
+__device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[LFQ_BAQ_NB + 1], double (&O1)[LFQ_BAQ_NB + 1],
+                                                double (&O2)[LFQ_BAQ_NB + 1], unsigned long long win, int qyi, double e_eq,
+                                                double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp, double *f2p,
+                                                bool keep_f2, double &sum_out)
+{
+    constexpr int NB = LFQ_BAQ_NB;
+    const unsigned long long xq = win ^ (0x1111111111111111ull * (unsigned long long)(qyi & 3));
+    double sum = 0., m_prev = 0., d_prev = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        double e = ((xq >> (4 * j)) & 15ull) == 0 ? e_eq : e_ne;
+        if (HASN) {
+            e = (((win >> (4 * j)) & 4ull) != 0 || qyi > 3) ? 1. : e;
+        }
+        const double a0 = O0[j] * rs, a1 = O1[j] * rs, a2 = O2[j] * rs;
+        const double c0 = O0[j + 1] * rs, c1 = O1[j + 1] * rs;
+        const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
+        const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
+        const double f2 = m[2] * m_prev + m[8] * d_prev;
+        fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
+        if (IDAQ && keep_f2) {
+            f2p[(size_t)j * 64] = f2;
+        }
+        m_prev = f0;
+        d_prev = f2;
+        sum += f0 + f1 + f2;
+        O0[j] = f0;
+        O1[j] = f1;
+        O2[j] = f2;
+    }
+    sum_out = sum;
+}
+
+/* one interior row of the backward pass: O <- row i from row i + 1 (both scaled), all 15 cells */
+template <bool HASN, bool IDAQ>
+__device__ __forceinline__ void lfq_baq_bwd_row(double (&O0)[LFQ_BAQ_NB + 1], double (&O1)[LFQ_BAQ_NB + 1],
+                                                double (&O2)[LFQ_BAQ_NB + 1], unsigned long long win, int qy1, double e_eq,
+                                                double e_ne, double ys, const double (&m)[9])
+{
+    constexpr int NB = LFQ_BAQ_NB;
+    const unsigned long long xq = win ^ (0x1111111111111111ull * (unsigned long long)(qy1 & 3));
+    double d01 = 0.;
+#pragma unroll
+    for (int j = NB - 1; j >= 0; --j) {
+        double em = ((xq >> (4 * j)) & 15ull) == 0 ? e_eq : e_ne;
+        if (HASN) {
+            em = (((win >> (4 * j)) & 4ull) != 0 || qy1 > 3) ? 1. : em;
+        }
+        const double o101 = j > 0 ? O1[j > 0 ? j - 1 : 0] : 0.;
+        const double e = em * O0[j];
+        const double b0 = e * m[0] + LFQ_BAQ_EI * m[1] * o101 + m[2] * d01;
+        const double b1 = e * m[3] + LFQ_BAQ_EI * m[4] * o101;
+        const double b2 = e * m[6] + m[8] * d01;                          /* times y = 1. (i > 1) */
+        O0[j] = b0 * ys;
+        O1[j] = b1 * ys;
+        if (IDAQ) {
+            O2[j] = b2 * ys;
+        }
+        d01 = b2;
+    }
+}
+
+/* IDAQ = false: lb only -- no indel table, no deletion row in the backward pass (it exists there only as the running
+ * d01 of the recurrence) */
+/* s[l_query + 1] (kprobaln_ext.c:184-189): the cells of the last row within the band limits, k ascending */
+__device__ __forceinline__ double lfq_baq_sfin(const double (&O0)[LFQ_BAQ_NB + 1], const double (&O1)[LFQ_BAQ_NB + 1], double rs,
+                                               double sM, double sI, int l_query, int l_ref, int bw)
+{
+    double sum = 0.;
+    const int xl = l_query - bw > 0 ? l_query - bw : 0;
+#pragma unroll
+    for (int j = 0; j < LFQ_BAQ_NB; j++) {
+        const int k = l_query - bw + j;
+        if (j < 2 * bw + 1 && k >= 1 && k <= l_ref && k >= xl && k <= xl + 2 * bw) {
+            sum += (O0[j] * rs) * sM + (O1[j] * rs) * sI;
+        }
+    }
+    return sum;
+}
+
+template <bool IDAQ>
+__global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqArgs A, int64_t n_launch)
+{
+    extern __shared__ uint16_t s_rowq[];         /* [lds_rows + 2][64]: base code | quality << 8 of row i; later the BAQ bytes */
+    constexpr int NB = LFQ_BAQ_NB;
+    const int lane = (int)threadIdx.x;
+    const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = ridx < n_launch;
+    const int64_t rid = A.order ? (int64_t)A.order[A.first_read + (live ? ridx : 0)] : A.first_read + (live ? ridx : 0);
+    const LfqBaqRead R = A.reads[rid];
+    const int W = A.W, rows = A.rows;
+    double *F = A.scratch + (size_t)blockIdx.x * ((size_t)rows * W + 2 * (size_t)W + 2 * ((size_t)rows + 2)) * 64;
+    double *S = F + (size_t)rows * W * 64 + 2 * (size_t)W * 64;
+    int32_t *expect = A.expect + (size_t)blockIdx.x * rows * 64;
+    /* forward row i in the scratch: (match, insertion) of slot j as one 16-byte pair at pair index j and the deletion
+     * cells (idaq only) behind the pairs */
+#define FP(i_) ((LfqBaqPair *)(F + (size_t)(i_) * W * 64) + lane)
+#define FQ2(i_, j_) F[((size_t)(i_) * W + 2 * LFQ_BAQ_NB + (j_)) * 64 + lane]
+#define SQ(i_) S[(size_t)(i_) * 64 + lane]
+#define RQ(i_) S[(size_t)(rows + 2 + (i_)) * 64 + lane]
+#define ROWQ(i_) ((int)s_rowq[(size_t)(i_) * 64 + lane])
+    /* a lane without a read runs along on zeros (its scratch column is its own) and writes no result */
+    const bool act = live && R.l_qseq > 0 && R.l_ref > 0;
+    const int l_query = act ? R.l_qseq : 0, l_ref = act ? R.l_ref : 1;
+    const int64_t s0 = A.seq_off[rid];
+    const uint8_t *query = A.seq + s0 - 1, *iqual = A.qual + s0 - 1;     /* 1-based like the reference */
+    const uint8_t *refw = A.ref + R.xb - 1;
+    uint8_t *out = A.lb_out + s0;
+    int Lmax = l_query;                              /* rows of the longest read of the wavefront */
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(Lmax, off);
+        Lmax = o > Lmax ? o : Lmax;
+    }
+    for (int i = 0; i <= Lmax + 1; i++) {
+        s_rowq[(size_t)i * 64 + lane] = (i >= 1 && i <= l_query) ? (uint16_t)(query[i] | (iqual[i] << 8)) : (uint16_t)4;
+    }
+    int bw = l_ref > l_query ? l_ref : l_query;                          /* kprobaln_ext.c:99-101 */
+    if (bw > R.bw) bw = R.bw;
+    if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);            /* <= 7: the host sends only such reads here */
+    if (!act) bw = 7;
+    const int bw2 = bw * 2 + 1;
+    const float par_d = 0.00001f, par_e = 0.4f;                          /* kpa_ext_par_lofreq_illumina */
+    double m[9];
+    const double sM = 1. / (2 * l_query + 2), sI = sM;                   /* :127-132 */
+    m[0] = (1 - par_d - par_d) * (1 - sM); m[1] = m[2] = par_d * (1 - sM);
+    m[3] = (1 - par_e) * (1 - sI); m[4] = par_e * (1 - sI); m[5] = 0.;
+    m[6] = 1 - par_e; m[7] = 0.; m[8] = par_e;
+    const double bM = (1 - par_d) / l_ref, bI = par_d / l_ref;
+    bool keep_f2 = false;                            /* deletion cells of the forward matrix: only for idaq terms */
+    if (IDAQ && act) {
+        const uint32_t *cg0 = A.cigar + R.cigar_off;
+        for (int k = 0; k < R.n_cigar; ++k) {
+            keep_f2 = keep_f2 || ((cg0[k] & 0xf) == 2);
+        }
+        keep_f2 = keep_f2 && A.itab != nullptr;
+    }
+    /* interior rows: [8, f_hi] forward, [8, b_hi] backward -- every read of the wavefront has all 15 cells there (and,
+     * backward, is neither at its last row nor at the last reference position) */
+    int f_hi = 0, b_hi = 0;
+    {
+        int fh = act ? (bw == 7 ? (l_query < l_ref - 7 ? l_query : l_ref - 7) : 0) : 1 << 30;
+        int bh = act ? (bw == 7 ? (l_query - 1 < l_ref - 8 ? l_query - 1 : l_ref - 8) : 0) : 1 << 30;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o1 = __shfl_xor(fh, off), o2 = __shfl_xor(bh, off);
+            fh = o1 < fh ? o1 : fh;
+            bh = o2 < bh ? o2 : bh;
+        }
+        f_hi = fh < 8 ? 0 : fh;                      /* no interior range: the masked body takes every row */
+        b_hi = bh < 8 ? 0 : bh;
+    }
+
+    /* the row: slot j = k - i + bw; O[NB] is the always-zero slot beyond the band */
+    double O0[NB + 1], O1[NB + 1], O2[NB + 1];
+#pragma unroll
+    for (int j = 0; j <= NB; j++) {
+        O0[j] = O1[j] = O2[j] = 0.;
+    }
+    /* ---- forward (:134-190): rows >= 2 stay unscaled in the registers and in HBM, 1 / s[i] is applied by the reader ---- */
+    RQ(0) = 1.;
+    RQ(1) = 1.;
+    double s_row1 = 1., s_last = 1., s_fin = 0.;     /* s[1], s[l_query], s[l_query + 1] */
+    {
+        /* row 1 (:141-157): k = 1 .. min(l_ref, bw + 1) -> slots bw .. 2 bw */
+        double sum = 0.;
+        const int end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const double ql = A.qual2prob[ROWQ(1) >> 8];
+        const int qy1 = ROWQ(1) & 0xff;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int k = 1 - bw + j;
+            if (j < bw2 && k >= 1 && k <= end) {
+                const double e = lfq_baq_emit(lfq_baq_code(refw[k]), qy1, ql);
+                const double f0 = e * bM, f1 = LFQ_BAQ_EI * bI;
+                O0[j] = f0;
+                O1[j] = f1;
+                sum += f0 + f1;
+            }
+        }
+        s_row1 = sum;
+        s_last = sum;
+        if (IDAQ) {
+            SQ(1) = sum;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int k = 1 - bw + j;
+            if (j < bw2 && k >= 1 && k <= end) {
+                O0[j] = O0[j] / sum;
+                O1[j] = O1[j] / sum;
+                FP(1)[(size_t)j * 64] = LfqBaqPair{O0[j], O1[j]};
+                if (keep_f2) {
+                    FQ2(1, j) = 0. / sum;
+                }
+            }
+        }
+    }
+    /* codes of reference positions i - bw .. i - bw + 15 of the row about to be computed, 4 bits each; the code that
+     * enters after row i (position i - bw + 16) is nibble i & 15 of `nxt`, the codes of the 16 rows after that are on
+     * their way in `pd` */
+    unsigned long long win, nxt;
+    uint32_t pd0, pd1, pd2, pd3;
+    win = lfq_baq_pack16(lfq_baq_ref4(refw, 2 - bw, l_ref), lfq_baq_ref4(refw, 6 - bw, l_ref), lfq_baq_ref4(refw, 10 - bw, l_ref),
+                         lfq_baq_ref4(refw, 14 - bw, l_ref));
+    nxt = lfq_baq_pack16(lfq_baq_ref4(refw, 16 - bw, l_ref), lfq_baq_ref4(refw, 20 - bw, l_ref), lfq_baq_ref4(refw, 24 - bw, l_ref),
+                         lfq_baq_ref4(refw, 28 - bw, l_ref));
+    pd0 = lfq_baq_ref4(refw, 32 - bw, l_ref); pd1 = lfq_baq_ref4(refw, 36 - bw, l_ref);
+    pd2 = lfq_baq_ref4(refw, 40 - bw, l_ref); pd3 = lfq_baq_ref4(refw, 44 - bw, l_ref);
+    double rs_next = 1.;                             /* RQ(1) */
+    /* base code and quality of a row come out of LDS one row ahead */
+    int rq_next = ROWQ(2);
+    double ql_next = A.qual2prob[rq_next >> 8];
+    if (l_query == 1) {
+        s_fin = lfq_baq_sfin(O0, O1, 1., sM, sI, l_query, l_ref, bw);
+    }
+    for (int i = 2; i <= Lmax; ++i) {
+        double sum = 0.;
+        const double qli = ql_next;
+        const double rs = rs_next;                   /* pending scale of row i-1 */
+        const int qyi = rq_next & 0xff;
+        rq_next = ROWQ(i + 1);
+        ql_next = A.qual2prob[rq_next >> 8];
+        const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);      /* enters the window for row i + 1 */
+        const double e_eq = 1. - qli, e_ne = qli * LFQ_BAQ_EM;           /* lfq_baq_emit's two non-trivial values */
+        LfqBaqPair *fp = FP(i);
+        if (i >= 8 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
+            const bool has_n = qyi > 3 || (win & 0x0444444444444444ull) != 0;
+            if (__any(has_n)) {
+                lfq_baq_fwd_row<true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, &FQ2(i, 0), keep_f2, sum);
+            } else {
+                lfq_baq_fwd_row<false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, &FQ2(i, 0), keep_f2, sum);
+            }
+        } else {
+            /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
+             * (k < 1) need no mask: what they read of row i - 1 is 0, so they come out as exactly 0, like the
+             * reference's untouched cells.  A read past its last row (i > l_query) has no valid cell. */
+            const int jmax = i <= l_query ? (l_ref - i + bw < 2 * bw ? l_ref - i + bw : 2 * bw) : -1;
+            double m_prev = 0., d_prev = 0.;         /* cell k-1 of this row (unscaled, like the reference at that point) */
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const bool valid = j <= jmax;
+                const int r = (int)((win >> (4 * j)) & 15ull);
+                const double e = (r > 3 || qyi > 3) ? 1. : (r == qyi ? e_eq : e_ne);
+                const double a0 = O0[j] * rs, a1 = O1[j] * rs, a2 = O2[j] * rs;
+                const double c0 = O0[j + 1] * rs, c1 = O1[j + 1] * rs;
+                const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
+                const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
+                const double f2 = m[2] * m_prev + m[8] * d_prev;
+                if (valid) {
+                    fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
+                    if (keep_f2) {
+                        FQ2(i, j) = f2;
+                    }
+                }
+                m_prev = f0;
+                d_prev = f2;
+                sum += valid ? f0 + f1 + f2 : 0.;    /* + 0. leaves the sum as it is */
+                O0[j] = valid ? f0 : 0.;
+                O1[j] = valid ? f1 : 0.;
+                O2[j] = valid ? f2 : 0.;
+            }
+        }
+        win = (win >> 4) | ((unsigned long long)code_in << 60);
+        if ((i & 15) == 15) {                        /* the next 16 codes have had 16 rows to arrive; request the ones after */
+            nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
+            const int p = i + 33 - bw;               /* row i + 17's code: position (i + 17) - bw + 16 */
+            pd0 = lfq_baq_ref4(refw, p, l_ref); pd1 = lfq_baq_ref4(refw, p + 4, l_ref);
+            pd2 = lfq_baq_ref4(refw, p + 8, l_ref); pd3 = lfq_baq_ref4(refw, p + 12, l_ref);
+        }
+        if (i <= l_query) {
+            if (IDAQ) {
+                SQ(i) = sum;
+            }
+            s_last = sum;
+            rs_next = 1. / sum;
+            RQ(i) = rs_next;
+        }
+        if (__any(i == l_query)) {                   /* some read's last row: its s[l_query + 1] while the row is there */
+            const double v = lfq_baq_sfin(O0, O1, rs_next, sM, sI, l_query, l_ref, bw);
+            s_fin = i == l_query ? v : s_fin;
+        }
+    }
+
+    /* ---- expected reference offset of every matched query base (bam_md_ext.c:409-447) ---- */
+    for (int i = 0; i < l_query; i++) {
+        expect[(size_t)i * 64 + lane] = INT32_MIN;       /* not in a match block (the offset itself can be negative) */
+    }
+    if (act) {
+        const uint32_t *cg = A.cigar + R.cigar_off;
+        int x = R.pos, y = 0;
+        for (int k = 0; k < R.n_cigar; ++k) {
+            const int op = cg[k] & 0xf, l = cg[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                for (int i = y; i < y + l; ++i) {
+                    expect[(size_t)i * 64 + lane] = x - R.xb + (i - y);
+                }
+                x += l; y += l;
+            } else if (op == 4 || op == 1) {
+                y += l;
+            } else if (op == 2) {
+                x += l;
+            }
+        }
+    }
+
+    /* ---- indel table for idaq (bam_md_ext.c:95-234): which posterior cells each indel needs ---- */
+    int n_tab = 0, n_ins = 0, n_del = 0;
+    int32_t *itab = IDAQ && A.itab ? A.itab + (size_t)blockIdx.x * LFQ_BAQ_MAX_INDELS * 4 * 64 : nullptr;
+    double *terms = A.terms ? A.terms + (size_t)blockIdx.x * LFQ_BAQ_MAX_TERMS * 64 : nullptr;
+#define IT(e_, f_) itab[((size_t)(e_) * 4 + (f_)) * 64 + lane]
+#define TM(t_) terms[(size_t)(t_) * 64 + lane]
+    uint8_t *ai = A.ai_out ? A.ai_out + s0 : nullptr, *ad = A.ad_out ? A.ad_out + s0 : nullptr;
+    if (IDAQ && act && itab) {
+        const uint32_t *cg = A.cigar + R.cigar_off;
+        const int xe = R.xb + l_ref;
+        int x = R.pos, y = 0, n_terms = 0;
+        for (int i = 0; i < l_query; i++) {
+            ai[i] = '~';
+            ad[i] = '~';
+        }
+        for (int k = 0; k < R.n_cigar; ++k) {
+            const int op = cg[k] & 0xf, oplen = cg[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                x += oplen; y += oplen;
+            } else if (op == 2) {                   /* deletion; the reference's skips do not advance x (:112-114) */
+                const int rpos = x, qpos = y;
+                if (qpos == 0) continue;
+                if (oplen > 16) continue;
+                n_del += 1;
+                x += oplen;
+                int ref_i = x, rep = 0, rep_i = 0;
+                while (ref_i < xe) {
+                    if (A.ref[ref_i] != A.ref[rpos + rep_i]) break;
+                    rep += 1; ref_i += 1; rep_i += 1;
+                    if (rep_i >= oplen) rep_i = 0;
+                }
+                int nt = rep + 1;
+                if (qpos + nt - 1 > l_query) nt = l_query - qpos + 1;          /* `if (qpos+j > l_qseq) break` */
+                if (n_tab < LFQ_BAQ_MAX_INDELS && n_terms + nt <= LFQ_BAQ_MAX_TERMS) {
+                    IT(n_tab, 0) = (qpos << 1) | 1;                            /* bit 0: deletion */
+                    IT(n_tab, 1) = rpos - R.xb + 1;
+                    IT(n_tab, 2) = nt;
+                    IT(n_tab, 3) = n_terms;
+                    for (int j = 0; j < nt; j++) {
+                        TM(n_terms + j) = -1.;                                 /* "not added" */
+                    }
+                    n_terms += nt;
+                    n_tab += 1;
+                }
+            } else if (op == 1) {                   /* insertion; the skips do not advance y (:181-183) */
+                const int rpos = x, qpos = y;
+                if (oplen > 16) continue;
+                n_ins += 1;
+                if (qpos == 0) continue;
+                y += oplen;
+                int ref_i = x, rep = 0, rep_i = 0;
+                while (ref_i < xe) {
+                    const int b = query[1 + qpos + rep_i];                     /* 0..4 -> seq_nt16_str letter */
+                    if (A.ref[ref_i] != (uint8_t)"ACGTN"[b > 4 ? 4 : b]) break;
+                    rep += 1; ref_i += 1; rep_i += 1;
+                    if (rep_i >= oplen) rep_i = 0;
+                }
+                int nt = rep + 1;
+                if (qpos + nt > l_query) nt = l_query - qpos;                  /* `if (qpos+j+1 > l_qseq) break` */
+                if (nt < 0) nt = 0;
+                if (n_tab < LFQ_BAQ_MAX_INDELS && n_terms + nt <= LFQ_BAQ_MAX_TERMS) {
+                    IT(n_tab, 0) = qpos << 1;
+                    IT(n_tab, 1) = rpos - R.xb;
+                    IT(n_tab, 2) = nt;
+                    IT(n_tab, 3) = n_terms;
+                    for (int j = 0; j < nt; j++) {
+                        TM(n_terms + j) = -1.;
+                    }
+                    n_terms += nt;
+                    n_tab += 1;
+                }
+            } else if (op == 4) {
+                y += oplen;
+            }
+        }
+        A.tag_flags[rid] = (uint8_t)((n_ins ? 1 : 0) | (n_del ? 2 : 0));
+    }
+
+
+    /* ---- backward (:206-238), with the MAP step of a row (:254-281) as soon as the row exists ---- */
+    const double b_init0 = sM / s_last / s_fin, b_init1 = sI / s_last / s_fin;
+    /* codes of positions i - bw + 1 .. i - bw + 16 for the row about to be computed (the emission of cell k looks at
+     * k + 1); after row i the code of position i - bw enters: nibble i & 15 of `nxt` */
+    win = lfq_baq_pack16(lfq_baq_ref4(refw, Lmax - bw + 1, l_ref), lfq_baq_ref4(refw, Lmax - bw + 5, l_ref),
+                         lfq_baq_ref4(refw, Lmax - bw + 9, l_ref), lfq_baq_ref4(refw, Lmax - bw + 13, l_ref));
+    {
+        const int p = ((Lmax >> 4) << 4) - bw;
+        nxt = lfq_baq_pack16(lfq_baq_ref4(refw, p, l_ref), lfq_baq_ref4(refw, p + 4, l_ref), lfq_baq_ref4(refw, p + 8, l_ref),
+                             lfq_baq_ref4(refw, p + 12, l_ref));
+        pd0 = lfq_baq_ref4(refw, p - 16, l_ref); pd1 = lfq_baq_ref4(refw, p - 12, l_ref);
+        pd2 = lfq_baq_ref4(refw, p - 8, l_ref); pd3 = lfq_baq_ref4(refw, p - 4, l_ref);
+    }
+    /* 1 / s[i] and expect[i-1] in batches of four rows (rows 4 q .. 4 q + 3), the batch after the current one requested
+     * four to eight rows before its first use */
+    double rA0, rA1, rA2, rA3, rB0, rB1, rB2, rB3;
+    int eA0, eA1, eA2, eA3, eB0, eB1, eB2, eB3;
+#define LFQ_BAQ_CLAMP(x_) ((x_) > l_query ? (l_query < 1 ? 1 : l_query) : ((x_) < 1 ? 1 : (x_)))
+#define LFQ_BAQ_BATCH(q_, r0, r1, r2, r3, e0, e1, e2, e3) \
+    do { \
+        const int b_ = 4 * (q_); \
+        const int i0_ = LFQ_BAQ_CLAMP(b_), i1_ = LFQ_BAQ_CLAMP(b_ + 1), i2_ = LFQ_BAQ_CLAMP(b_ + 2), i3_ = LFQ_BAQ_CLAMP(b_ + 3); \
+        r0 = RQ(i0_); r1 = RQ(i1_); r2 = RQ(i2_); r3 = RQ(i3_); \
+        e0 = expect[(size_t)(i0_ - 1) * 64 + lane]; e1 = expect[(size_t)(i1_ - 1) * 64 + lane]; \
+        e2 = expect[(size_t)(i2_ - 1) * 64 + lane]; e3 = expect[(size_t)(i3_ - 1) * 64 + lane]; \
+    } while (0)
+    LFQ_BAQ_BATCH(Lmax >> 2, rA0, rA1, rA2, rA3, eA0, eA1, eA2, eA3);
+    LFQ_BAQ_BATCH((Lmax >> 2) - 1, rB0, rB1, rB2, rB3, eB0, eB1, eB2, eB3);
+    for (int i = Lmax; i >= 1; --i) {
+        const int t4 = i & 3;
+        const double c_r = t4 == 0 ? rA0 : (t4 == 1 ? rA1 : (t4 == 2 ? rA2 : rA3));           /* 1 / s[i] */
+        const int c_ex = t4 == 0 ? eA0 : (t4 == 1 ? eA1 : (t4 == 2 ? eA2 : eA3));
+        if (t4 == 0) {                               /* row i - 1 opens the next batch */
+            rA0 = rB0; rA1 = rB1; rA2 = rB2; rA3 = rB3;
+            eA0 = eB0; eA1 = eB1; eA2 = eB2; eA3 = eB3;
+            LFQ_BAQ_BATCH((i >> 2) - 2, rB0, rB1, rB2, rB3, eB0, eB1, eB2, eB3);
+        }
+        const int rq_up = ROWQ(i + 1), c_iq = ROWQ(i) >> 8;
+        const int c_qy = rq_up & 0xff;               /* query[i + 1] */
+        const double c_ql = A.qual2prob[rq_up >> 8];
+        const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);
+        const bool on = i <= l_query;
+        const LfqBaqPair *fp = FP(i);
+        const double e_eq = 1. - c_ql, e_ne = c_ql * LFQ_BAQ_EM;
+        /* the forward cells the MAP step of this row needs are requested now and land while the backward row is computed */
+        double fz0[NB], fz1[NB];
+        double sum = 0., max = 0.;
+        int max_u = -1;                              /* 4 j + state of the maximum */
+        const double rsi = c_r;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {               /* every slot: a lane's row is its own and zero-filled where it has no cell */
+            const LfqBaqPair v = fp[(size_t)j * 64];
+            fz0[j] = v.m;
+            fz1[j] = v.i;
+        }
+        if (i >= 8 && i <= b_hi) {                   /* interior row */
+            const bool has_n = c_qy > 3 || (win & 0x0444444444444444ull) != 0;
+            /* ys = 1 / s[i]: the same division as the forward pass's 1 / sum (i >= 8) */
+            if (__any(has_n)) {
+                lfq_baq_bwd_row<true, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
+            } else {
+                lfq_baq_bwd_row<false, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
+            }
+            /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const double z0 = (fz0[j] * rsi) * O0[j];
+                max_u = z0 > max ? 4 * j : max_u;
+                max = z0 > max ? z0 : max;
+                sum += z0;
+                const double z1 = (fz1[j] * rsi) * O1[j];
+                max_u = z1 > max ? 4 * j + 1 : max_u;
+                max = z1 > max ? z1 : max;
+                sum += z1;
+            }
+        } else {
+            /* the same arithmetic, cells outside [max(1, i - bw), min(l_ref, i + bw)] masked to 0: slots jmin .. jmax;
+             * a read that is not at this row yet (i > l_query) has none, one at its last row takes the start values */
+            const int jmin = bw - i + 1 > 0 ? bw - i + 1 : 0;
+            const int jmax = on ? (l_ref - i + bw < 2 * bw ? l_ref - i + bw : 2 * bw) : -1;
+            const int jz = l_ref - i + bw;           /* k >= l_ref: no emission beyond the last reference base (:226) */
+            const bool last = i == l_query;
+            const double y = (i > 1);
+            const double ys = i == 1 ? 1. / s_row1 : c_r;                /* 1. / s[i]; RQ(1) is row 1's pending scale, 1. */
+            const int xl = l_query - bw > 0 ? l_query - bw : 0;
+            double d01 = 0.;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                const bool valid = j >= jmin && j <= jmax;
+                const int r = (int)((win >> (4 * j)) & 15ull);
+                const double em = (r > 3 || c_qy > 3) ? 1. : (r == c_qy ? e_eq : e_ne);
+                const double o101 = j > 0 ? O1[j > 0 ? j - 1 : 0] : 0.;
+                const double e = (j >= jz ? 0 : em) * O0[j];
+                const double b0 = e * m[0] + LFQ_BAQ_EI * m[1] * o101 + m[2] * d01;
+                const double b1 = e * m[3] + LFQ_BAQ_EI * m[4] * o101;
+                const double b2 = (e * m[6] + m[8] * d01) * y;
+                /* the last row of a read: the start values (:206-214) on the cells within the band limits */
+                const int k = i - bw + j;
+                const bool in = valid && k >= xl && k <= xl + 2 * bw;
+                d01 = valid ? b2 : 0.;
+                O0[j] = last ? (in ? b_init0 : 0.) : (valid ? b0 * ys : 0.);
+                O1[j] = last ? (in ? b_init1 : 0.) : (valid ? b1 * ys : 0.);
+                O2[j] = last ? 0. : (valid ? b2 * ys : 0.);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const bool valid = j >= jmin && j <= jmax;
+                const double z0 = valid ? (fz0[j] * rsi) * O0[j] : -1.;  /* -1.: never the maximum, adds 0. */
+                max_u = z0 > max ? 4 * j : max_u;
+                max = z0 > max ? z0 : max;
+                sum += valid ? z0 : 0.;
+                const double z1 = valid ? (fz1[j] * rsi) * O1[j] : -1.;
+                max_u = z1 > max ? 4 * j + 1 : max_u;
+                max = z1 > max ? z1 : max;
+                sum += valid ? z1 : 0.;
+            }
+        }
+        win = (win << 4) | (unsigned long long)code_in;
+        if ((i & 15) == 0) {
+            nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
+            const int p = i - 32 - bw;               /* rows i - 32 .. i - 17 */
+            pd0 = lfq_baq_ref4(refw, p, l_ref); pd1 = lfq_baq_ref4(refw, p + 4, l_ref);
+            pd2 = lfq_baq_ref4(refw, p + 8, l_ref); pd3 = lfq_baq_ref4(refw, p + 12, l_ref);
+        }
+        if (on) {
+            const int max_k = max_u < 0 ? -1 : ((i - bw - 1) << 2) + max_u;
+            if (IDAQ) {
+                int beg = 1, end = l_ref, x;
+                x = i - bw; beg = beg > x ? beg : x;
+                x = i + bw; end = end < x ? end : x;
+                for (int e = 0; e < n_tab; e++) {   /* pd cells of this row that an indel needs (:147-163, :207-224) */
+                    const int t0 = IT(e, 0), is_del = t0 & 1, qpos = t0 >> 1;
+                    const int jj = is_del ? i - qpos : i - qpos - 1;
+                    if (jj < 0 || jj >= IT(e, 2)) continue;
+                    const int kk = IT(e, 1) + jj;
+                    const int xx = i - bw > 0 ? i - bw : 0;
+                    const int u = (kk - xx + 1) * 3;
+                    if (u < 3 || u >= bw2 * 3 + 3) continue;                  /* u_within_limits */
+                    const int st = is_del ? 2 : 1;
+                    double term = 0.;            /* outside the band of row i the reference's matrices hold 0 (calloc) */
+                    if (kk >= beg && kk <= end) {
+                        const int js = kk - (i - bw);
+                        double bcell = 0.;
+#pragma unroll
+                        for (int j = 0; j < NB; j++) {   /* the row is in registers: pick the slot without indexing them */
+                            bcell = (j == js) ? (st == 2 ? O2[j] : O1[j]) : bcell;
+                        }
+                        const double fcell = st == 2 ? FQ2(i, js) : FP(i)[(size_t)js * 64].i;
+                        term = (fcell * rsi) * bcell * SQ(i);
+                    }
+                    TM(IT(e, 3) + jj) = term;
+                }
+            }
+            max /= sum;
+            int qk = (int)(-4.343 * log(1. - max) + .499);
+            qk = qk > 100 ? 99 : qk;
+            int bq = c_iq;
+            if (c_ex != INT32_MIN) {
+                const bool off = (max_k & 3) != 0 || (max_k >> 2) != c_ex;
+                bq = A.baq_extended ? (off ? 0 : qk) : qk;
+            }
+            s_rowq[(size_t)(i + 1) * 64 + lane] = (uint16_t)bq;      /* out[i - 1]: the slot of row i + 1 is free now */
+        }
+    }
+#define OUTE(i0_) s_rowq[(size_t)((i0_) + 2) * 64 + lane]
+
+    /* ---- extended BAQ: min of the running maxima from both ends of each match block (:437-446), in the LDS slots:
+     * the low byte keeps out[i], the high byte takes the maximum from the left ---- */
+    if (act && A.baq_extended) {
+        const uint32_t *cg = A.cigar + R.cigar_off;
+        int y = 0;
+        for (int k = 0; k < R.n_cigar; ++k) {
+            const int op = cg[k] & 0xf, l = cg[k] >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                if (l > 0) {
+                    int run = OUTE(y) & 0xff;
+                    OUTE(y) = (uint16_t)(run | (run << 8));
+                    for (int i = y + 1; i < y + l; ++i) {
+                        const int o = OUTE(i) & 0xff;
+                        run = o > run ? o : run;
+                        OUTE(i) = (uint16_t)(o | (run << 8));
+                    }
+                    run = 0;
+                    for (int i = y + l - 1; i >= y; --i) {
+                        const int v = OUTE(i), o = v & 0xff, lf = v >> 8;
+                        run = o > run ? o : run;
+                        OUTE(i) = (uint16_t)(lf < run ? lf : run);
+                    }
+                }
+                y += l;
+            } else if (op == 4 || op == 1) {
+                y += l;
+            }
+        }
+    }
+    for (int i = 0; i < l_query; ++i) {                                  /* :456-462 */
+        const int o = OUTE(i) & 0xff;
+        out[i] = (uint8_t)((o > 93 ? 93 : o) + 33);
+    }
+    /* ---- idaq: sum each indel's terms in the reference's order (j ascending), 1 - sum -> phred char ---- */
+    for (int e = 0; IDAQ && e < n_tab; e++) {
+        const int t0 = IT(e, 0), is_del = t0 & 1, qpos = t0 >> 1, nt = IT(e, 2), off = IT(e, 3);
+        double ap = 0;
+        for (int j = 0; j < nt; j++) {
+            const double t = TM(off + j);
+            if (t >= 0.) {
+                ap += t;
+            }
+        }
+        ap = 1 - ap;
+        const int qv = (ap < 0.0 + 2.220446049250313e-16) ? 126 + 1 : ((int)(-10 * log10(ap)) + 33);   /* :55-56 */
+        const uint8_t ch = (uint8_t)(qv < 33 ? '!' : (qv > 126 ? '~' : qv));
+        (is_del ? ad : ai)[qpos - 1] = ch;
+    }
+#undef IT
+#undef TM
+#undef SQ
+#undef RQ
+#undef FP
+#undef FQ2
+#undef ROWQ
+#undef OUTE
+#undef LFQ_BAQ_BATCH
+#undef LFQ_BAQ_CLAMP
+}
+
 int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
 {
     if (n_launch <= 0) {
@@ -582,6 +1265,16 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
     const unsigned blocks = (unsigned)((n_launch + 63) / 64);
     if (lds) {
         const size_t ref_bytes = ((size_t)a.max_lref / 2 + 2) * 64;
+        if (lfq_knobs().baq_kernel == 0) {           /* default: rows in registers; LFQ_BAQ_KERNEL=1: the LDS-row kernel (A/B) */
+            /* (base | quality) of every row, later the BAQ bytes (see the kernel) */
+            const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2;
+            if (a.itab) {
+                hipLaunchKernelGGL(lfq_baq_reg_kernel<true>, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, a, n_launch);
+            } else {
+                hipLaunchKernelGGL(lfq_baq_reg_kernel<false>, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, a, n_launch);
+            }
+            return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+        }
         hipLaunchKernelGGL(lfq_baq_kernel<true>, dim3(blocks), dim3(64), ref_bytes, (hipStream_t)stream, a, n_launch);
     } else {
         hipLaunchKernelGGL(lfq_baq_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, a, n_launch);

@@ -241,6 +241,7 @@ struct LfqBaqArgs {
     int32_t first_read;        /* reads [first_read, first_read + n_launch) of the arrays (of `order`, if given) */
     const int32_t *order;      /* read indices, narrow-band reads first; null = identity */
     int32_t max_lref;          /* longest reference window among the narrow-band reads (LDS sizing) */
+    int32_t lds_rows;          /* longest narrow-band read + 1: rows of the per-row scalars the register kernel keeps in LDS */
     /* indel alignment qualities (idaq, bam_md_ext.c:73-248); all null / 0 = not requested */
     uint8_t *ai_out, *ad_out;  /* [seq_off[n]] bytes of the ai / ad tags ('~' = nothing) */
     uint8_t *tag_flags;        /* [n] bit 0: the read gets an ai tag, bit 1: an ad tag */
@@ -251,7 +252,8 @@ struct LfqBaqArgs {
 #define LFQ_BAQ_MAX_TERMS 1024
 #define LFQ_BAQ_LDS_CELLS 51    /* row width (cells) up to which a read runs in the LDS variant of the kernel */
 #define LFQ_BAQ_LDS_BAND 15      /* cells (reference positions) per row of such a read: 2 * 7 + 1 */
-#define LFQ_BAQ_LDS_MAX_LREF 500 /* ... and whose reference window (one code byte per base and lane in LDS) is this short */
+#define LFQ_BAQ_LDS_MAX_LREF 300 /* ... and whose reference window is this short: codes (32 B per base pair and wavefront) + row
+                                  * scalars (128 B per query base) + 1 KiB stay below 64 KiB of LDS per wavefront */
 int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream);
 
 /* ---- device-side pileup (lfq_pileup.hip) ------------------------------------------------------------------ */
