@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the host-abi / chain measurements of config.secondary")
     ap.add_argument("--nt-bytes", action="store_true",
                     help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="N = 1, pipelined loop: batches whose kernels may be on the GPU at the same time (2: the count "
+                         "kernel of batch k + 1 beside the DP kernels of batch k; 1: one batch's kernels at a time)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: one context, every step waits for its own host finish before the next batch is launched "
                          "(default: two contexts; the host finish of step k runs under the kernels of step k + 1)")
@@ -541,6 +544,20 @@ def main():
         def run_steps(n):
             acc = None
             out = None
+            if args.in_flight >= 2:
+                # two batches in flight: batch k + 1 is launched BEFORE batch k is waited for, so its count kernel
+                # (HBM-bound, on the main stream) runs beside the DP kernels of batch k (issue-bound, high-priority
+                # streams); n submits and n finishes, every batch complete inside the timed region
+                confs = {0: submit(0)}
+                if n > 1:
+                    confs[1] = submit(1)
+                for k in range(n):
+                    callers[k % 2].call_snvs_wait()
+                    out = finish(k, confs.pop(k))
+                    if k + 2 < n:
+                        confs[k + 2] = submit(k + 2)
+                    acc = out[4] if acc is None else {x: acc[x] + out[4][x] for x in acc}
+                return out, acc
             pending = submit(0)
             for k in range(n):
                 callers[k % 2].call_snvs_wait()

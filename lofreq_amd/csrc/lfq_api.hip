@@ -763,19 +763,24 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
             LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][1], side_i[i]));
         }
     }
-    /* join everything back into the caller's stream */
+    /* Join.  A caller that passed its own stream gets everything joined back into it.  On the library's own streams
+     * (layer 2) the batch ends on the dps stream instead and `st` carries nothing but the memsets and count kernels:
+     * the count kernel of the NEXT batch (another context on the same device streams) then starts as soon as this
+     * batch's count kernel is done and streams through HBM while this batch's DP kernels -- latency / issue-bound,
+     * < 1 GB of traffic, on the high-priority streams -- run beside it. */
+    hipStream_t jn = (st != c->stream || single_stream) ? st : dps;
     LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));                     /* all count kernels done */
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[0], side0));
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[1], side1));
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], dps));
     for (int i = 0; i < 3; i++) {
-        LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_join[i], 0));
+        LFQ_TRY_HIP(hipStreamWaitEvent(jn, c->ev_join[i], 0));
     }
     if (P.lazy_strand && d_pvals && pvals_capacity > 0) {
         /* DP4 of the columns that made it into the sparse output (lofreq_call.c:853-857) */
-        LFQ_TRY(lfq_launch_strand_pvals(T, d_pvals, gcounters + LFQ_GC_PVALS, pvals_capacity, c->n_cu, st));
+        LFQ_TRY(lfq_launch_strand_pvals(T, d_pvals, gcounters + LFQ_GC_PVALS, pvals_capacity, c->n_cu, jn));
     }
-    LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
+    LFQ_TRY_HIP(hipEventRecord(c->ev[3], jn));
     return LFQ_OK;
 }
 

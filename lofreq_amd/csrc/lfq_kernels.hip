@@ -94,6 +94,47 @@ __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_
     }
 }
 
+/* The same counts for the packed nt layout, EIGHT observations per operation: a packed nt dword holds the codes of the
+ * observations of two bq dwords (even nibbles <-> bytes of `bqa`, odd nibbles <-> bytes of `bqb`, lfq_nt_at), so the
+ * planes are formed in the nibble domain (everything lives in bit 3 of each nibble, `vm` = 0x8 per observation in
+ * range) and only the quality gates come from the byte domain: bit 7 of a byte of `bqb`'s gate IS bit 3 of its odd
+ * nibble, `bqa`'s gate moves down by 4.  26 instead of 46 instructions per 8 observations. */
+template <bool SAME_THR, bool STRAND = true>
+__device__ __forceinline__ void lfq_count_nib8(LfqAcc &a, uint32_t ntw, uint32_t bqa, uint32_t bqb, uint32_t vm,
+                                               uint32_t minbq4, uint32_t minalt4)
+{
+    const uint32_t s0 = ntw << 3, s1 = ntw << 2, s2 = ntw << 1;
+    const uint32_t p0 = vm & ~s2;                  /* valid: in range and not N */
+    const uint32_t p1 = p0 & s0;
+    const uint32_t p2 = p0 & s1;
+    const uint32_t p3 = p1 & s1;
+    a.raw[0] += __popc(p0);
+    a.raw[1] += __popc(p1);
+    a.raw[2] += __popc(p2);
+    a.raw[3] += __popc(p3);
+    if (STRAND) {                                  /* the strand flag is bit 3 of the nibble itself */
+        a.fw[0] += __popc(p0 & ~ntw);
+        a.fw[1] += __popc(p1 & ~ntw);
+        a.fw[2] += __popc(p2 & ~ntw);
+        a.fw[3] += __popc(p3 & ~ntw);
+    }
+    const uint32_t ha = bqa | 0x80808080u, hb = bqb | 0x80808080u;
+    const uint32_t ga = ha - minbq4, gb = hb - minbq4;             /* bit 7 of a byte: bq >= min_bq (bq < 128) */
+    const uint32_t g = ((ga >> 4) & 0x08080808u) | (gb & 0x80808080u);
+    a.ge[0] += __popc(p0 & g);
+    a.ge[1] += __popc(p1 & g);
+    a.ge[2] += __popc(p2 & g);
+    a.ge[3] += __popc(p3 & g);
+    if (!SAME_THR) {
+        const uint32_t ga2 = ha - minalt4, gb2 = hb - minalt4;
+        const uint32_t g2 = (((ga2 >> 4) & 0x08080808u) | (gb2 & 0x80808080u)) & g;       /* ... and >= min_alt_bq */
+        a.ga[0] += __popc(p0 & g2);
+        a.ga[1] += __popc(p1 & g2);
+        a.ga[2] += __popc(p2 & g2);
+        a.ga[3] += __popc(p3 & g2);
+    }
+}
+
 template <bool SAME_THR, bool PACKED, bool STRAND = true>
 __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &T, uint64_t off0, uint64_t off1,
                                                  uint32_t minbq4, uint32_t minalt4, int lane = lfq_lane(),
@@ -106,8 +147,8 @@ __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &
     if (PACKED) {
         /* 16 observations per step like the byte layout, but the nt half is 8 bytes of nibbles: the even nibbles of an
          * nt dword are the observations of the first bq dword of its group of 8, the odd nibbles those of the second
-         * (lfq_nt_at), so two mask operations turn a packed dword into the two byte-per-observation words the
-         * bit-plane counts work on -- 1.5 instead of 2 bytes of HBM traffic per observation, every load of a
+         * (lfq_nt_at), so the bit-plane counts run on the packed dword itself, eight observations at a time
+         * (lfq_count_nib8) -- 1.5 instead of 2 bytes of HBM traffic per observation, every load of a
          * wavefront contiguous.  (Two steps' loads in flight per lane were measured: slower, the registers cost a
          * wavefront of residency.) */
         const uint2 *nt8 = reinterpret_cast<const uint2 *>(T.nt);
@@ -117,18 +158,14 @@ __device__ __forceinline__ void lfq_count_chunks(LfqAcc &a, const LfqTracksDev &
             const int64_t base = ch << 4;
             const int lo = (int64_t)off0 > base ? (int)((int64_t)off0 - base) : 0;
             const int hi = (int64_t)off1 < base + 16 ? (int)((int64_t)off1 - base) : 16;
-            const uint32_t e0 = n2.x & 0x0F0F0F0Fu, o0 = (n2.x >> 4) & 0x0F0F0F0Fu;
-            const uint32_t e1 = n2.y & 0x0F0F0F0Fu, o1 = (n2.y >> 4) & 0x0F0F0F0Fu;
             if (lo == 0 && hi == 16) {
-                lfq_count_dword<SAME_THR, STRAND>(a, e0, b4.x, 0x80808080u, minbq4, minalt4);
-                lfq_count_dword<SAME_THR, STRAND>(a, o0, b4.y, 0x80808080u, minbq4, minalt4);
-                lfq_count_dword<SAME_THR, STRAND>(a, e1, b4.z, 0x80808080u, minbq4, minalt4);
-                lfq_count_dword<SAME_THR, STRAND>(a, o1, b4.w, 0x80808080u, minbq4, minalt4);
+                lfq_count_nib8<SAME_THR, STRAND>(a, n2.x, b4.x, b4.y, 0x88888888u, minbq4, minalt4);
+                lfq_count_nib8<SAME_THR, STRAND>(a, n2.y, b4.z, b4.w, 0x88888888u, minbq4, minalt4);
             } else {
-                lfq_count_dword<SAME_THR, STRAND>(a, e0, b4.x, lfq_bytes_mask(lo, hi, 0), minbq4, minalt4);
-                lfq_count_dword<SAME_THR, STRAND>(a, o0, b4.y, lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
-                lfq_count_dword<SAME_THR, STRAND>(a, e1, b4.z, lfq_bytes_mask(lo, hi, 2), minbq4, minalt4);
-                lfq_count_dword<SAME_THR, STRAND>(a, o1, b4.w, lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
+                lfq_count_nib8<SAME_THR, STRAND>(a, n2.x, b4.x, b4.y,
+                                                 (lfq_bytes_mask(lo, hi, 0) >> 4) | lfq_bytes_mask(lo, hi, 1), minbq4, minalt4);
+                lfq_count_nib8<SAME_THR, STRAND>(a, n2.y, b4.z, b4.w,
+                                                 (lfq_bytes_mask(lo, hi, 2) >> 4) | lfq_bytes_mask(lo, hi, 3), minbq4, minalt4);
             }
         }
         return;
