@@ -141,7 +141,12 @@ struct lfq_ctx {
     int32_t *h_nheavy, *d_nheavy_mapped;
     int heavy_cap;
     hipEvent_t ev_heavy;
-    uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out */
+    uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out (grow-only:
+                                      * hipMalloc / hipFree of gigabytes per region cost milliseconds each) */
+    int64_t plp_in_bytes, plp_out_bytes;
+    uint8_t *d_tmp[3];               /* grow-only temporaries of the read-set steps: BAQ geometry, indel counters, gathers */
+    int64_t tmp_bytes[3];
+    int64_t plp_ne_cap;              /* capacity of d_plp_ne in int16 elements */
     LfqIndelColsOwned *plp_indel;
     int indel_host_arrays;           /* lfq_set_indel_arrays_on_host */
     int16_t *d_plp_ne;               /* quality arrays of the columns above, resident: [q0 | mq0 | q1 | mq1] */
@@ -500,6 +505,9 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_plp_out) (void)hipFree(c->d_plp_out);
         delete c->plp_indel;
         if (c->d_plp_ne) (void)hipFree(c->d_plp_ne);
+        for (int i = 0; i < 3; i++) {
+            if (c->d_tmp[i]) (void)hipFree(c->d_tmp[i]);
+        }
         if (c->d_detlim) (void)hipFree(c->d_detlim);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
@@ -1691,6 +1699,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    double tmb[5] = {lfq_now_ms(), 0, 0, 0, 0};
     /* geometry of every read: alignment window and band width (bam_md_ext.c:312-380, :396-399) */
     std::vector<LfqBaqRead> h((size_t)n);
     std::vector<int32_t> width((size_t)n, 0);
@@ -1748,6 +1757,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         max_lq = std::max(max_lq, part_lq[p]);
         max_w = std::max(max_w, part_w[p]);
     }
+    tmb[1] = lfq_now_ms();
     /* narrow-band reads (rows of at most LFQ_BAQ_LDS_CELLS cells) first: they run in the LDS variant */
     const bool use_lds = lfq_knobs().baq_lds != 0;
     std::vector<int32_t> order((size_t)n);
@@ -1787,7 +1797,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
     const int64_t o_reads = 0, o_q2p = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_ord = o_q2p + al(1024),
                   total = o_ord + al(n * 4);
-    LFQ_TRY_HIP(hipMalloc((void **)&d_blob, (size_t)total));
+    LFQ_TRY(grow(&c->d_tmp[0], &c->tmp_bytes[0], total));
+    d_blob = c->d_tmp[0];
     int rc = LFQ_OK;
     auto up = [&](int64_t off, const void *src, int64_t bytes) {
         if (rc == LFQ_OK && bytes > 0 && hipMemcpyAsync(d_blob + off, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
@@ -1803,6 +1814,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                                            || hipMemsetAsync(rs->d_fl, 0, (size_t)n, c->stream) != hipSuccess)))) {
         rc = LFQ_ERR_HIP;
     }
+    tmb[2] = lfq_now_ms();
     double *d_scr = nullptr;
     int32_t *d_expect = nullptr;
     uint8_t *d_tmp8 = nullptr;
@@ -1866,21 +1878,26 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         A.order = (const int32_t *)(d_blob + o_ord);
         A.max_lref = max_lref_narrow;
         A.lds_rows = max_lq_narrow + 1;
-        /* the few reads with a wider band (indels longer than the default band) are a handful of latency-bound
-         * wavefronts: they run beside the narrow-band kernel on a side stream when everything fits one launch each
-         * (disjoint reads, disjoint scratch: wavefront w of a launch owns slot w, the wide launch starts behind the
-         * narrow one's slots) */
-        const int64_t waves_narrow = (n_narrow + 63) / 64, waves_wide = (n - n_narrow + 63) / 64;
-        const bool beside = n_narrow > 0 && n > n_narrow && waves_narrow + waves_wide <= waves && c->side[0] != nullptr
+        /* The few reads with a wider band (indels longer than the default band) are a handful of latency-bound
+         * wavefronts: they run beside the narrow-band launches on a side stream, in scratch slots of their own behind the
+         * narrow ones' (wavefront w of a launch owns slot w).  The narrow-band kernel runs one wavefront per SIMD, so a
+         * launch is cut to a whole number of rounds over the SIMDs: a launch of 7.3 rounds takes as long as one of 8. */
+        const int64_t waves_wide = (n - n_narrow + 63) / 64;
+        const bool beside = n_narrow > 0 && n > n_narrow && waves_wide < waves / 4 && c->side[0] != nullptr
                             && !lfq_knobs().single_stream;
+        int64_t waves_n = beside ? waves - waves_wide : waves;          /* slots of a narrow launch */
+        const int64_t round = (int64_t)c->n_cu * 4;
+        if ((n_narrow + 63) / 64 > waves_n && waves_n > round) {       /* more than one launch: whole rounds each */
+            waves_n = waves_n / round * round;
+        }
         if (beside) {
             LfqBaqArgs Aw = A;
-            Aw.scratch = A.scratch + (size_t)waves_narrow * (size_t)(per_wave / 8);
-            Aw.expect = A.expect + (size_t)waves_narrow * A.rows * 64;
-            Aw.tmp8 = A.tmp8 + (size_t)waves_narrow * 2 * A.rows * 64;
+            Aw.scratch = A.scratch + (size_t)waves_n * (size_t)(per_wave / 8);
+            Aw.expect = A.expect + (size_t)waves_n * A.rows * 64;
+            Aw.tmp8 = A.tmp8 + (size_t)waves_n * 2 * A.rows * 64;
             if (want_idaq) {
-                Aw.itab = A.itab + (size_t)waves_narrow * LFQ_BAQ_MAX_INDELS * 4 * 64;
-                Aw.terms = A.terms + (size_t)waves_narrow * LFQ_BAQ_MAX_TERMS * 64;
+                Aw.itab = A.itab + (size_t)waves_n * LFQ_BAQ_MAX_INDELS * 4 * 64;
+                Aw.terms = A.terms + (size_t)waves_n * LFQ_BAQ_MAX_TERMS * 64;
             }
             Aw.first_read = (int32_t)n_narrow;
             /* the side stream starts after the uploads / memsets queued on c->stream, c->stream ends after it */
@@ -1893,24 +1910,23 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             if (rc == LFQ_OK && (hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess)) {
                 rc = LFQ_ERR_HIP;
             }
-            A.first_read = 0;
-            if (rc == LFQ_OK) {
-                rc = lfq_launch_baq(A, n_narrow, 1, c->stream);
-            }
+        }
+        for (int64_t first = 0; rc == LFQ_OK && first < n_narrow; first += waves_n * 64) {
+            A.first_read = (int32_t)first;
+            rc = lfq_launch_baq(A, std::min<int64_t>(waves_n * 64, n_narrow - first), 1, c->stream);
+        }
+        if (beside) {
             if (rc == LFQ_OK && hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
         } else {
-            for (int64_t first = 0; rc == LFQ_OK && first < n_narrow; first += waves * 64) {
-                A.first_read = (int32_t)first;
-                rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n_narrow - first), 1, c->stream);
-            }
             for (int64_t first = n_narrow; rc == LFQ_OK && first < n; first += waves * 64) {
                 A.first_read = (int32_t)first;
                 rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
             }
         }
     }
+    tmb[3] = lfq_now_ms();
     std::vector<uint8_t> dfl;
     if (rc == LFQ_OK && want_idaq) {            /* which reads got an ai / ad tag (bam_md_ext.c:238-243): bits 2, 3 */
         dfl.resize((size_t)n);
@@ -1921,7 +1937,11 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
         rc = LFQ_ERR_HIP;
     }
-    (void)hipFree(d_blob);
+    tmb[4] = lfq_now_ms();
+    if (lfq_timing_on) {
+        fprintf(stderr, "[lfq timing] baq: geometry %.1f  order + allocations + uploads %.1f  scratch + launches %.1f  kernels (sync) %.1f ms\n",
+                tmb[1] - tmb[0], tmb[2] - tmb[1], tmb[3] - tmb[2], tmb[4] - tmb[3]);
+    }
     if (rc == LFQ_OK) {
         rs->has_lb = true;
         if (want_idaq) {
@@ -1972,9 +1992,7 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     /* per-position counters (kept until the next call) */
     const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
                   total = o_cidx + al(width * 4);
-    if (c->d_plp_in) (void)hipFree(c->d_plp_in);
-    c->d_plp_in = nullptr;
-    LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_in, (size_t)total));
+    LFQ_TRY(grow(&c->d_plp_in, &c->plp_in_bytes, total));
     uint8_t *d = c->d_plp_in;
     LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), c->stream));
     LfqPileupArgs A;
@@ -2005,37 +2023,62 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
     LFQ_TRY_HIP(hipMemcpyAsync(nb.data(), A.nb, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
-    std::vector<uint64_t> off(1, 0);
-    std::vector<int32_t> h_cov, h_nb;
-    std::vector<uint8_t> h_ref;
+    /* two passes over the positions, both split over a few threads: covered positions and bases per part, then every
+     * part fills its slice */
+    int64_t part_cols[9] = {0}, part_obs[9] = {0}, part_max[8] = {0};
+    int parts = 1;
+    lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
+        int64_t nc = 0, no = 0, mx = 0;
+        for (int64_t p = p0; p < p1; p++) {
+            if (cov[(size_t)p] > 0) {
+                nc++;
+                no += nb[(size_t)p];
+                mx = std::max<int64_t>(mx, nb[(size_t)p]);
+            }
+        }
+        part_cols[part + 1] = nc;
+        part_obs[part + 1] = no;
+        part_max[part] = mx;
+    }, &parts);
     int64_t max_obs = 0;
-    for (int64_t p = 0; p < width; p++) {
-        if (cov[(size_t)p] <= 0) {
-            continue;
-        }
-        cidx[(size_t)p] = (int32_t)h_cov.size();
-        if (col_pos_out) {
-            col_pos_out[h_cov.size()] = region_begin + p;
-        }
-        h_cov.push_back(cov[(size_t)p]);
-        h_nb.push_back(nb[(size_t)p]);
-        const int64_t gp = region_begin + p;
-        char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';           /* plp.c:818-823 */
-        if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
-            rb = 'N';
-        }
-        h_ref.push_back((uint8_t)rb);
-        off.push_back(off.back() + (uint64_t)nb[(size_t)p]);
-        max_obs = std::max<int64_t>(max_obs, nb[(size_t)p]);
+    for (int q = 0; q < parts; q++) {
+        part_cols[q + 1] += part_cols[q];
+        part_obs[q + 1] += part_obs[q];
+        max_obs = std::max(max_obs, part_max[q]);
     }
+    std::vector<uint64_t> off((size_t)part_cols[parts] + 1, 0);
+    std::vector<int32_t> h_cov((size_t)part_cols[parts]), h_nb((size_t)part_cols[parts]);
+    std::vector<uint8_t> h_ref((size_t)part_cols[parts]);
+    lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
+        size_t ci = (size_t)part_cols[part];
+        uint64_t run = (uint64_t)part_obs[part];
+        for (int64_t p = p0; p < p1; p++) {
+            if (cov[(size_t)p] <= 0) {
+                continue;
+            }
+            cidx[(size_t)p] = (int32_t)ci;
+            if (col_pos_out) {
+                col_pos_out[ci] = region_begin + p;
+            }
+            h_cov[ci] = cov[(size_t)p];
+            h_nb[ci] = nb[(size_t)p];
+            const int64_t gp = region_begin + p;
+            char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';           /* plp.c:818-823 */
+            if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
+                rb = 'N';
+            }
+            h_ref[ci] = (uint8_t)rb;
+            run += (uint64_t)nb[(size_t)p];
+            off[ci + 1] = run;
+            ci++;
+        }
+    });
     const int64_t ncols = (int64_t)h_cov.size();
     const int64_t n_obs = (int64_t)off.back(), trk = al(n_obs + 32);
     const int64_t t_off = 0, t_ref = t_off + al((ncols + 1) * 8), t_cov = t_ref + al(ncols + 16), t_nb = t_cov + al(ncols * 4 + 16),
                   t_nt = t_nb + al(ncols * 4 + 16), t_bq = t_nt + trk, t_baq = t_bq + trk, t_mq = t_baq + trk,
                   t_sq = t_mq + trk, t_total = t_sq + (rs->has_sqb ? trk : 0);
-    if (c->d_plp_out) (void)hipFree(c->d_plp_out);
-    c->d_plp_out = nullptr;
-    LFQ_TRY_HIP(hipMalloc((void **)&c->d_plp_out, (size_t)t_total));
+    LFQ_TRY(grow(&c->d_plp_out, &c->plp_out_bytes, t_total));
     uint8_t *t = c->d_plp_out;
     LFQ_TRY_HIP(hipMemsetAsync(t + t_nt, 0, (size_t)(t_total - t_nt), c->stream));     /* the 16-byte tails are read */
     LFQ_TRY_HIP(hipMemcpyAsync(t + t_off, off.data(), (size_t)(ncols + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -2098,10 +2141,6 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     const lfq_readset *rd = rs;
     delete c->plp_indel;
     c->plp_indel = new LfqIndelColsOwned();
-    if (c->d_plp_ne) {
-        (void)hipFree(c->d_plp_ne);
-        c->d_plp_ne = nullptr;
-    }
     c->plp_ne_total[0] = c->plp_ne_total[1] = 0;
     LfqIndelColsOwned &O = *c->plp_indel;
     memset(&O.cols, 0, sizeof(O.cols));
@@ -2191,10 +2230,8 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
         const int64_t o_cnt = 0, o_cur = o_cnt + 9 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
                       total = o_off + 2 * al(width * 8);
-        uint8_t *d = nullptr;
-        if (hipMalloc((void **)&d, (size_t)total) != hipSuccess) {
-            return LFQ_ERR_NOMEM;
-        }
+        LFQ_TRY(grow(&c->d_tmp[1], &c->tmp_bytes[1], total));
+        uint8_t *d = c->d_tmp[1];
         int16_t *d_ne = nullptr;
         int rc = LFQ_OK;
         auto up = [&](int64_t off, const void *src, int64_t bytes) {
@@ -2244,79 +2281,116 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         tm[2] = lfq_now_ms();
         /* 3. columns = covered positions; quality arrays of the reads without an event at the event positions */
         std::vector<int64_t> pos_off[2];
+        std::vector<int32_t> col_of;                /* column index of an event position */
         int64_t ne_total[2] = {0, 0};
         const bool host_arrays = c->indel_host_arrays || !have_qsum;   /* device-only needs the sums from the kernel */
         if (rc == LFQ_OK) {
             pos_off[0].assign((size_t)width, -1);
             pos_off[1].assign((size_t)width, -1);
+            col_of.assign((size_t)width, -1);
             std::vector<uint8_t> has_ev((size_t)width, 0);
             for (const Ev &e : evs) {
                 has_ev[(size_t)(e.pos - region_begin)] = 1;
             }
-            size_t n_cov = 0;
-            for (int64_t p = 0; p < width; p++) {
-                n_cov += h[0][(size_t)p] > 0;
-            }
-            for (auto *v : {&O.cov, &O.tails, &O.non_indels, &O.n_ins, &O.n_dels, &O.hrun}) {
-                v->reserve(n_cov);
-            }
-            O.ref_base.reserve(n_cov);
-            for (int sd = 0; sd < 2; sd++) {
-                O.side[sd].non_fw.reserve(n_cov);
-                O.side[sd].non_rv.reserve(n_cov);
-                O.side[sd].ne_off.reserve(n_cov + 1);
-                O.side[sd].ev_off.reserve(n_cov + 1);
-                O.side[sd].ne_off.push_back(0);
-            }
-            for (int64_t p = 0; p < width; p++) {
-                if (h[0][(size_t)p] <= 0) {
-                    continue;
-                }
-                const int64_t gp = region_begin + p;
-                if (col_pos_out) {
-                    col_pos_out[O.cov.size()] = gp;
-                }
-                char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';       /* plp.c:818-823 */
-                if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
-                    rb = 'N';
-                }
-                O.ref_base.push_back((uint8_t)rb);
-                O.cov.push_back(h[0][(size_t)p]);
-                O.tails.push_back(h[1][(size_t)p]);
-                O.non_indels.push_back(h[2][(size_t)p]);
-                O.n_ins.push_back(h[3][(size_t)p]);
-                O.n_dels.push_back(h[4][(size_t)p]);
-                int hr = 1;                                             /* get_hrun, plp.c:744-787 */
-                if (gp + 1 < rd->ref_len) {
-                    const int ch = toupper((unsigned char)rd->ref[gp + 1]);
-                    for (int64_t i = gp + 2; i < rd->ref_len && toupper((unsigned char)rd->ref[i]) == ch; i++) {
-                        hr++;
+            /* two passes over the positions, both split over a few threads: count the covered positions and the
+             * non-event reads at event positions per part, then every part fills its slice of the column arrays */
+            int64_t part_cov[9] = {0}, part_ne[2][9] = {{0}, {0}};
+            int parts = 1;
+            lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
+                int64_t nc = 0, ne0 = 0, ne1 = 0;
+                for (int64_t p = p0; p < p1; p++) {
+                    if (h[0][(size_t)p] <= 0) {
+                        continue;
                     }
-                    for (int64_t i = gp; i >= 0 && toupper((unsigned char)rd->ref[i]) == ch; i--) {
-                        hr++;
-                    }
-                }
-                O.hrun.push_back(hr);
-                if (have_qsum) {
-                    qsum[0].push_back(h[7][(size_t)p]);
-                    qsum[1].push_back(h[8][(size_t)p]);
-                }
-                const int32_t ne_cnt[2] = {h[2][(size_t)p] + h[4][(size_t)p], h[2][(size_t)p] + h[3][(size_t)p]};
-                const int32_t fw[2] = {h[5][(size_t)p], h[6][(size_t)p]};
-                for (int sd = 0; sd < 2; sd++) {
-                    O.side[sd].non_fw.push_back(fw[sd]);
-                    O.side[sd].non_rv.push_back(ne_cnt[sd] - fw[sd]);
+                    nc++;
                     if (has_ev[(size_t)p]) {
-                        pos_off[sd][(size_t)p] = ne_total[sd];
-                        ne_total[sd] += ne_cnt[sd];
+                        ne0 += h[2][(size_t)p] + h[4][(size_t)p];
+                        ne1 += h[2][(size_t)p] + h[3][(size_t)p];
                     }
-                    O.side[sd].ne_off.push_back(ne_total[sd]);
                 }
+                part_cov[part + 1] = nc;
+                part_ne[0][part + 1] = ne0;
+                part_ne[1][part + 1] = ne1;
+            }, &parts);
+            for (int q = 0; q < parts; q++) {
+                part_cov[q + 1] += part_cov[q];
+                part_ne[0][q + 1] += part_ne[0][q];
+                part_ne[1][q + 1] += part_ne[1][q];
             }
+            const size_t n_cov = (size_t)part_cov[parts];
+            ne_total[0] = part_ne[0][parts];
+            ne_total[1] = part_ne[1][parts];
+            for (auto *v : {&O.cov, &O.tails, &O.non_indels, &O.n_ins, &O.n_dels, &O.hrun}) {
+                v->resize(n_cov);
+            }
+            O.ref_base.resize(n_cov);
+            if (have_qsum) {
+                qsum[0].resize(n_cov);
+                qsum[1].resize(n_cov);
+            }
+            for (int sd = 0; sd < 2; sd++) {
+                O.side[sd].non_fw.resize(n_cov);
+                O.side[sd].non_rv.resize(n_cov);
+                O.side[sd].ne_off.resize(n_cov + 1);
+                O.side[sd].ev_off.reserve(n_cov + 1);
+                O.side[sd].ne_off[0] = 0;
+            }
+            lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
+                size_t ci = (size_t)part_cov[part];
+                int64_t run[2] = {part_ne[0][part], part_ne[1][part]};
+                for (int64_t p = p0; p < p1; p++) {
+                    if (h[0][(size_t)p] <= 0) {
+                        continue;
+                    }
+                    const int64_t gp = region_begin + p;
+                    if (col_pos_out) {
+                        col_pos_out[ci] = gp;
+                    }
+                    char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';       /* plp.c:818-823 */
+                    if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
+                        rb = 'N';
+                    }
+                    O.ref_base[ci] = (uint8_t)rb;
+                    O.cov[ci] = h[0][(size_t)p];
+                    O.tails[ci] = h[1][(size_t)p];
+                    O.non_indels[ci] = h[2][(size_t)p];
+                    O.n_ins[ci] = h[3][(size_t)p];
+                    O.n_dels[ci] = h[4][(size_t)p];
+                    int hr = 1;                                             /* get_hrun, plp.c:744-787 */
+                    if (gp + 1 < rd->ref_len) {
+                        const int ch = toupper((unsigned char)rd->ref[gp + 1]);
+                        for (int64_t i = gp + 2; i < rd->ref_len && toupper((unsigned char)rd->ref[i]) == ch; i++) {
+                            hr++;
+                        }
+                        for (int64_t i = gp; i >= 0 && toupper((unsigned char)rd->ref[i]) == ch; i--) {
+                            hr++;
+                        }
+                    }
+                    O.hrun[ci] = hr;
+                    if (have_qsum) {
+                        qsum[0][ci] = h[7][(size_t)p];
+                        qsum[1][ci] = h[8][(size_t)p];
+                    }
+                    const int32_t ne_cnt[2] = {h[2][(size_t)p] + h[4][(size_t)p], h[2][(size_t)p] + h[3][(size_t)p]};
+                    const int32_t fw[2] = {h[5][(size_t)p], h[6][(size_t)p]};
+                    for (int sd = 0; sd < 2; sd++) {
+                        O.side[sd].non_fw[ci] = fw[sd];
+                        O.side[sd].non_rv[ci] = ne_cnt[sd] - fw[sd];
+                        if (has_ev[(size_t)p]) {
+                            pos_off[sd][(size_t)p] = run[sd];
+                            run[sd] += ne_cnt[sd];
+                            col_of[(size_t)p] = (int32_t)ci;
+                        }
+                        O.side[sd].ne_off[ci + 1] = run[sd];
+                    }
+                    ci++;
+                }
+            });
             const int64_t ne_all = ne_total[0] + ne_total[1];
-            if (ne_all > 0 && hipMalloc((void **)&d_ne, (size_t)ne_all * 4) != hipSuccess) {
+            if (ne_all > 0 && grow(&c->d_plp_ne, &c->plp_ne_cap, ne_all * 2) != LFQ_OK) {
                 rc = LFQ_ERR_NOMEM;
             }
+            d_ne = c->d_plp_ne;
             if (rc == LFQ_OK && ne_all > 0) {
                 for (int sd = 0; sd < 2; sd++) {
                     up(o_off + sd * al(width * 8), pos_off[sd].data(), width * 8);
@@ -2351,11 +2425,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             for (size_t i = 0; i < evs.size(); i++) {
                 idx[i] = rd->seq_off[evs[i].read] + evs[i].qpos;
             }
-            uint8_t *dg = nullptr;
             const int64_t ne = (int64_t)evs.size();
-            if (hipMalloc((void **)&dg, (size_t)(ne * 10)) != hipSuccess) {
+            if (grow(&c->d_tmp[2], &c->tmp_bytes[2], ne * 10) != LFQ_OK) {
                 rc = LFQ_ERR_NOMEM;
             } else {
+                uint8_t *dg = c->d_tmp[2];
                 g_ai.resize(evs.size());
                 g_ad.resize(evs.size());
                 if (hipMemcpyAsync(dg, idx.data(), (size_t)ne * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess
@@ -2365,30 +2439,18 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                     || hipStreamSynchronize(c->stream) != hipSuccess) {
                     rc = LFQ_ERR_HIP;
                 }
-                (void)hipFree(dg);
             }
         }
-        (void)hipFree(d);
         if (rc != LFQ_OK) {
-            if (d_ne) (void)hipFree(d_ne);
             return rc;
         }
-        /* the quality arrays stay resident: lfq_call_indels_batch builds its pseudo-columns from them on the device */
-        c->d_plp_ne = d_ne;
+        /* the quality arrays stay resident (c->d_plp_ne): lfq_call_indels_batch builds its pseudo-columns from them on the device */
         c->plp_ne_total[0] = ne_total[0];
         c->plp_ne_total[1] = ne_total[1];
         tm[4] = lfq_now_ms();
         /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
          * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */
-        std::vector<int64_t> col_of((size_t)width, -1);
-        {
-            int64_t ci = 0;
-            for (int64_t p = 0; p < width; p++) {
-                if (h[0][(size_t)p] > 0) {
-                    col_of[(size_t)p] = ci++;
-                }
-            }
-        }
+        /* columns with events are few: the ev_off entries of the columns in between are filled as ranges */
         for (int sd = 0; sd < 2; sd++) {
             LfqIndelColsOwned::Side &S = O.side[sd];
             S.ev_off.push_back(0);
@@ -2400,16 +2462,22 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         std::vector<std::vector<size_t>> members;
         std::string key;
         size_t ei = 0;
-        for (int64_t col = 0; col < ncols; col++) {
+        int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
+        while (ei < evs.size()) {
+            const int64_t ppos = evs[ei].pos - region_begin;
             size_t e1 = ei;
-            while (e1 < evs.size() && col_of[(size_t)(evs[e1].pos - region_begin)] == col) {
+            while (e1 < evs.size() && evs[e1].pos - region_begin == ppos) {
                 e1++;
             }
-            if (e1 == ei) {                             /* the common case: a column without events */
-                O.side[0].ev_off.push_back((int64_t)O.side[0].ev_fw.size());
-                O.side[1].ev_off.push_back((int64_t)O.side[1].ev_fw.size());
+            if (h[0][(size_t)ppos] <= 0) {          /* (cannot happen: a read with an event covers its position) */
+                ei = e1;
                 continue;
             }
+            const int64_t col = col_of[(size_t)ppos];
+            for (int sd = 0; sd < 2; sd++) {        /* the event-less columns before this one */
+                O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(col - col_done), (int64_t)O.side[sd].ev_fw.size());
+            }
+            col_done = col + 1;
             for (int sd = 0; sd < 2; sd++) {
                 LfqIndelColsOwned::Side &S = O.side[sd];
                 keys.clear();                           /* (reused across columns: no allocation in the common case) */
@@ -2483,6 +2551,9 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 S.ev_off.push_back((int64_t)S.ev_fw.size());
             }
             ei = e1;
+        }
+        for (int sd = 0; sd < 2; sd++) {            /* the event-less columns behind the last event */
+            O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(ncols - col_done), (int64_t)O.side[sd].ev_fw.size());
         }
     }
     tm[5] = lfq_now_ms();
