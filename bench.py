@@ -408,10 +408,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # LFQ_BENCH_ONE_GPU=1 (debugging the N > 1 loop on a one-GPU box): every rank on cuda:0, exchange over gloo
+    one_gpu = os.environ.get("LFQ_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = "cpu" if one_gpu else dev              # where the exchanged tensors live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import lofreq_amd as la
     from lofreq_amd import shard
@@ -486,7 +494,7 @@ def main():
                 st = caller.batch_finish()
                 done.append((i, b, d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE).copy(),
                              int(st.n_tested)))
-            recs, total = shard.finish_bins(conf, done, n_bins_total, dist, dev)
+            recs, total = shard.finish_bins(conf, done, n_bins_total, dist, xdev)
         elif world == 1 and not args.shard_path:
             # layer 2 of the C ABI (lfq_call_snvs_batch): the whole call_snvs loop over the batch in one call
             recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
@@ -496,7 +504,7 @@ def main():
             st = caller.batch_finish()
             pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
             recs, total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin,      # records carry their ref base
-                                             dist if world > 1 else None, dev)
+                                             dist if world > 1 else None, xdev)
         text = None
         if rank == 0:
             # QUAL threshold from the final dynamic Bonferroni factor (lofreq_call.c:1519-1538), then `lofreq filter`
@@ -524,22 +532,43 @@ def main():
     # kernels of step k are done, step k + 1 is launched on the other context and only then step k is finished on
     # the host (sparse D2H, exact emit test, strand bias, filter, VCF text).  Every step still does all of its work
     # inside the timed region; the two steps' kernels never run at the same time.
-    pipelined = world == 1 and not args.shard_path and not args.no_pipeline
+    pipelined = my_bins is None and not args.no_pipeline
+    layer2 = world == 1 and not args.shard_path
     if pipelined:
         callers = [caller, la.SnvCaller(local_rank)]
         callers[1].set_dense_strand_counts(False)
+        # the sharded step (layer 1 + exchange) pipelines the same way: every context has its own device-side outputs
+        out_bufs = [(d_counts, d_pvals), (torch.zeros_like(d_counts), torch.zeros_like(d_pvals))]
 
         def submit(k):
             conf = la.VarcallConf()
-            callers[k % 2].call_snvs_submit(batch, conf)
+            if layer2:
+                callers[k % 2].call_snvs_submit(batch, conf)
+            else:
+                dc, dp = out_bufs[k % 2]
+                callers[k % 2].snv_batch_device(batch, conf, dc, dp, pv_cap)
             return conf
 
         def finish(k, conf):
-            recs, st = callers[k % 2].call_snvs_collect(conf, records_capacity=1 << 16)
-            thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
-            keep = la.filter_records(recs, thr, apply_defaults=cfg_filter)
-            text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
+            if layer2:
+                recs, st = callers[k % 2].call_snvs_collect(conf, records_capacity=1 << 16)
+            else:
+                # host + exchange half of the sharded step, under the kernels of the next one: the running Bonferroni
+                # factor needs every rank's tested-column count, rank 0 gets everybody's records
+                st = callers[k % 2].batch_finish()
+                pv = out_bufs[k % 2][1][: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
+                recs, _total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin, dist if world > 1 else None, xdev)
+            text = None
+            if rank == 0:
+                thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
+                keep = la.filter_records(recs, thr, apply_defaults=cfg_filter)
+                text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
             return conf, st, recs, text, callers[k % 2].kernel_times()
+
+        def wait(k):
+            if layer2:
+                callers[k % 2].call_snvs_wait()
+            # (layer 1: lfq_batch_finish waits for the batch's event itself)
 
         def run_steps(n):
             acc = None
@@ -552,7 +581,7 @@ def main():
                 if n > 1:
                     confs[1] = submit(1)
                 for k in range(n):
-                    callers[k % 2].call_snvs_wait()
+                    wait(k)
                     out = finish(k, confs.pop(k))
                     if k + 2 < n:
                         confs[k + 2] = submit(k + 2)
@@ -560,7 +589,9 @@ def main():
                 return out, acc
             pending = submit(0)
             for k in range(n):
-                callers[k % 2].call_snvs_wait()
+                wait(k)
+                if not layer2:
+                    callers[k % 2].synchronize()      # layer 1 has no separate wait: the kernels of step k are done here
                 nxt = submit(k + 1) if k + 1 < n else None
                 out = finish(k, pending)
                 acc = out[4] if acc is None else {x: acc[x] + out[4][x] for x in acc}
@@ -581,7 +612,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     work = (callers[(args.steps - 1) % 2] if pipelined else caller).dp_work()

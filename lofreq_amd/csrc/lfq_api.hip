@@ -557,6 +557,7 @@ int lfq_synchronize(lfq_ctx *c)
         return LFQ_ERR_INVALID;
     }
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    LFQ_TRY_HIP(hipEventSynchronize(c->ev[3]));    /* a batch ends on the dps stream (batch_device_impl), not on c->stream */
     return LFQ_OK;
 }
 
