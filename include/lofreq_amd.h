@@ -505,6 +505,27 @@ typedef struct lfq_dp_work {
 } lfq_dp_work;
 int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);
 
+/* --- N processes, one per GPU: the exchange of a sharded run, from C ---
+ * The reference's `call-parallel` wrapper runs one `lofreq call -r <bin>` per worker and merges afterwards: it sums the
+ * per-worker test counts it parses from the logs and concatenates the VCFs (lofreq2_call_pparallel.py:131-185, 685-707).
+ * Here every process calls its shard with the SAME starting conf (layer 1 or 2), then:
+ *     lfq_shard_exchange_counts   one all-gather of a few int64 per rank (tested columns, indel tests) -> every rank's
+ *                                 counts and this rank's exclusive prefix
+ *     lfq_shard_rebase_bonferroni the shard-local running Bonferroni factors of the sparse p-value records become the
+ *                                 single-process ones (3 tests per tested column of the earlier shards,
+ *                                 lofreq_call.c:794-801); lfq_finalize_pvals then applies the exact emit test
+ *     lfq_shard_gather_records    every rank's reported variants, in shard order, `col` made global by col_offset
+ *     lfq_shard_advance_conf      conf->bonf_subst / num_snv_tests as after the single-process loop over all shards
+ * `comm` is an ncclComm_t of RCCL (one rank per process, created by the caller: ncclCommInitRank) or NULL when
+ * world == 1.  RCCL is looked up at run time (dlopen of librccl): the library has no link-time dependency on it.
+ * lofreq_amd/shard.py is the same exchange on torch.distributed; tests/test_shard_c.py holds the two against each other. */
+int lfq_shard_exchange_counts(lfq_ctx *ctx, void *comm, int world, int rank, const int64_t *local, int n,
+                              int64_t *all_out /* [world][n] */, int64_t *prefix_out /* [n] */);
+int lfq_shard_rebase_bonferroni(lfq_col_pvals *pvals, int64_t n, int64_t prefix_tested);
+int lfq_shard_gather_records(lfq_ctx *ctx, void *comm, int world, int rank, const lfq_snv_record *recs, int64_t n,
+                             int64_t col_offset, lfq_snv_record *out, int64_t capacity, int64_t *n_out);
+int lfq_shard_advance_conf(lfq_conf *conf, int64_t total_tested);
+
 #ifdef __cplusplus
 }
 #endif

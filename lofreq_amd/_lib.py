@@ -122,6 +122,7 @@ EXPORTS = [
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
     "lfq_uniq_detlim_batch", "lfq_uniq_binom_batch", "lfq_uniq_mtc", "lfq_binom_cdf",
+    "lfq_shard_exchange_counts", "lfq_shard_rebase_bonferroni", "lfq_shard_gather_records", "lfq_shard_advance_conf",
     "lfq_readset_create", "lfq_readset_destroy", "lfq_readset_baq", "lfq_readset_source_qual",
     "lfq_readset_pileup_snv", "lfq_readset_pileup_indels", "lfq_readset_fetch_tags",
 ]
@@ -202,6 +203,11 @@ def load():
     L.lfq_uniq_detlim_batch.argtypes = [vp, C.POINTER(Tracks), C.c_int, vp, vp, vp]
     L.lfq_uniq_binom_batch.argtypes = [vp, C.POINTER(Tracks), C.c_int, vp, vp, vp, vp]
     L.lfq_uniq_mtc.argtypes = [vp, C.c_int64, C.c_int, C.c_double, C.c_int64, vp]
+    L.lfq_shard_exchange_counts.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+    L.lfq_shard_rebase_bonferroni.argtypes = [vp, C.c_int64, C.c_int64]
+    L.lfq_shard_gather_records.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int64, vp, C.c_int64,
+                                           C.POINTER(C.c_int64)]
+    L.lfq_shard_advance_conf.argtypes = [C.POINTER(Conf), C.c_int64]
     L.lfq_binom_cdf.restype = C.c_double
     L.lfq_binom_cdf.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
     L.lfq_readset_create.argtypes = [vp, C.POINTER(PileupReads), C.POINTER(PileupIndelTags), C.POINTER(vp)]

@@ -2922,3 +2922,144 @@ int lfq_synth_fill_device_layout(lfq_ctx *c, uint64_t seed, uint32_t depth, uint
 }
 
 }  // extern "C"
+
+/* ---- the exchange of a sharded run from C (include/lofreq_amd.h, "N processes") ------------------------------------ */
+#include <dlfcn.h>
+namespace {
+typedef int (*lfq_nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+lfq_nccl_allgather_fn lfq_rccl_allgather()
+{
+    static lfq_nccl_allgather_fn fn = [] {
+        /* the copy the process already has (PyTorch brings its own) before the system one */
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2; pass++) {
+            for (const char *nm : names) {
+                void *h = dlopen(nm, RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (h) {
+                    void *f = dlsym(h, "ncclAllGather");
+                    if (f) {
+                        return (lfq_nccl_allgather_fn)f;
+                    }
+                }
+            }
+        }
+        return (lfq_nccl_allgather_fn) nullptr;
+    }();
+    return fn;
+}
+
+/* all-gather of `bytes` bytes per rank through device staging buffers of the context */
+int shard_allgather_bytes(lfq_ctx *c, void *comm, int world, int rank, const void *mine, size_t bytes, void *all)
+{
+    if (world == 1 || !comm) {
+        if (world != 1) {
+            return LFQ_ERR_INVALID;
+        }
+        memcpy(all, mine, bytes);
+        return LFQ_OK;
+    }
+    lfq_nccl_allgather_fn ag = lfq_rccl_allgather();
+    if (!ag || !c) {
+        return LFQ_ERR_UNSUPPORTED;
+    }
+    (void)rank;
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    const int64_t padded = (int64_t)((bytes + 255) / 256 * 256);
+    LFQ_TRY(grow(&c->d_tmp[2], &c->tmp_bytes[2], padded * (world + 1)));
+    uint8_t *d_send = c->d_tmp[2], *d_recv = c->d_tmp[2] + padded;
+    LFQ_TRY_HIP(hipMemcpyAsync(d_send, mine, bytes, hipMemcpyHostToDevice, c->stream));
+    if (ag(d_send, d_recv, (size_t)padded, /* ncclUint8 */ 1, comm, c->stream) != 0) {
+        return LFQ_ERR_HIP;
+    }
+    std::vector<uint8_t> h((size_t)padded * world);
+    LFQ_TRY_HIP(hipMemcpyAsync(h.data(), d_recv, (size_t)padded * world, hipMemcpyDeviceToHost, c->stream));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < world; r++) {
+        memcpy((uint8_t *)all + (size_t)r * bytes, h.data() + (size_t)r * padded, bytes);
+    }
+    return LFQ_OK;
+}
+}  // namespace
+
+int lfq_shard_exchange_counts(lfq_ctx *c, void *comm, int world, int rank, const int64_t *local, int n, int64_t *all_out,
+                              int64_t *prefix_out)
+{
+    if (world < 1 || rank < 0 || rank >= world || n < 0 || (n > 0 && (!local || !all_out))) {
+        return LFQ_ERR_INVALID;
+    }
+    if (n == 0) {
+        return LFQ_OK;
+    }
+    LFQ_TRY(shard_allgather_bytes(c, comm, world, rank, local, (size_t)n * 8, all_out));
+    if (prefix_out) {
+        for (int i = 0; i < n; i++) {
+            int64_t p = 0;
+            for (int r = 0; r < rank; r++) {
+                p += all_out[(size_t)r * n + i];
+            }
+            prefix_out[i] = p;
+        }
+    }
+    return LFQ_OK;
+}
+
+int lfq_shard_rebase_bonferroni(lfq_col_pvals *pvals, int64_t n, int64_t prefix_tested)
+{
+    if (n < 0 || (n > 0 && !pvals) || prefix_tested < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        pvals[i].bonf += 3 * prefix_tested;         /* every tested column of an earlier shard: 3 tests (lofreq_call.c:794-801) */
+    }
+    return LFQ_OK;
+}
+
+int lfq_shard_advance_conf(lfq_conf *conf, int64_t total_tested)
+{
+    if (!conf || total_tested < 0) {
+        return LFQ_ERR_INVALID;
+    }
+    if (total_tested > 0) {
+        if (conf->bonf_dynamic) {
+            conf->bonf_subst = (conf->bonf_subst == 1 ? 0 : conf->bonf_subst) + 3 * total_tested;
+        }
+        conf->num_snv_tests += 3 * total_tested;
+    }
+    return LFQ_OK;
+}
+
+int lfq_shard_gather_records(lfq_ctx *c, void *comm, int world, int rank, const lfq_snv_record *recs, int64_t n,
+                             int64_t col_offset, lfq_snv_record *out, int64_t capacity, int64_t *n_out)
+{
+    if (world < 1 || rank < 0 || rank >= world || n < 0 || (n > 0 && !recs) || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        return LFQ_ERR_INVALID;
+    }
+    std::vector<int64_t> counts((size_t)world);
+    LFQ_TRY(shard_allgather_bytes(c, comm, world, rank, &n, 8, counts.data()));
+    int64_t total = 0, most = 0;
+    for (int r = 0; r < world; r++) {
+        total += counts[(size_t)r];
+        most = std::max(most, counts[(size_t)r]);
+    }
+    *n_out = total;
+    if (total > capacity) {
+        return LFQ_ERR_CAPACITY;
+    }
+    if (most == 0) {
+        return LFQ_OK;
+    }
+    std::vector<lfq_snv_record> mine((size_t)most), all((size_t)most * world);
+    memset((void *)mine.data(), 0, (size_t)most * sizeof(lfq_snv_record));
+    for (int64_t i = 0; i < n; i++) {
+        mine[(size_t)i] = recs[i];
+        mine[(size_t)i].col += col_offset;
+    }
+    LFQ_TRY(shard_allgather_bytes(c, comm, world, rank, mine.data(), (size_t)most * sizeof(lfq_snv_record), all.data()));
+    int64_t o = 0;
+    for (int r = 0; r < world; r++) {
+        for (int64_t i = 0; i < counts[(size_t)r]; i++) {
+            out[o++] = all[(size_t)r * most + (size_t)i];
+        }
+    }
+    return LFQ_OK;
+}
