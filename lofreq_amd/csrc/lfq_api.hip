@@ -145,6 +145,8 @@ struct lfq_ctx {
                                       * hipMalloc / hipFree of gigabytes per region cost milliseconds each) */
     int64_t plp_in_bytes, plp_out_bytes;
     uint8_t *d_tmp[3];               /* grow-only temporaries of the read-set steps: BAQ geometry, indel counters, gathers */
+    uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
+    int64_t pin_bytes;
     int64_t tmp_bytes[3];
     int64_t plp_ne_cap;              /* capacity of d_plp_ne in int16 elements */
     LfqIndelColsOwned *plp_indel;
@@ -508,6 +510,7 @@ void lfq_destroy(lfq_ctx *c)
         for (int i = 0; i < 3; i++) {
             if (c->d_tmp[i]) (void)hipFree(c->d_tmp[i]);
         }
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
         if (c->d_detlim) (void)hipFree(c->d_detlim);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
@@ -1702,12 +1705,28 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     LFQ_TRY_HIP(hipSetDevice(c->device));
     double tmb[5] = {lfq_now_ms(), 0, 0, 0, 0};
     /* geometry of every read: alignment window and band width (bam_md_ext.c:312-380, :396-399) */
-    std::vector<LfqBaqRead> h((size_t)n);
-    std::vector<int32_t> width((size_t)n, 0);
+    /* (pinned, grow-only host buffers: 28 bytes per read are written once by the threads below and go out by DMA; a
+     * std::vector would zero 56 MB for 2 M reads first and be copied through a staging buffer afterwards) */
+    const int64_t h_bytes = (n * (int64_t)sizeof(LfqBaqRead) + 255) / 256 * 256, ord_bytes = (n * 4 + 255) / 256 * 256;
+    if (h_bytes + ord_bytes > c->pin_bytes) {
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->h_pin = nullptr;
+        c->pin_bytes = 0;
+        LFQ_TRY_HIP(hipHostMalloc((void **)&c->h_pin, (size_t)(h_bytes + ord_bytes), hipHostMallocDefault));
+        c->pin_bytes = h_bytes + ord_bytes;
+    }
+    LfqBaqRead *h = (LfqBaqRead *)c->h_pin;
+    int32_t *order = (int32_t *)(c->h_pin + h_bytes);
+    std::unique_ptr<int32_t[]> width(new int32_t[(size_t)n]);
+    const bool use_lds = lfq_knobs().baq_lds != 0;
     int max_lq = 0, max_w = 0;
     int part_lq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, part_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t part_narrow[9] = {0};
+    int part_lrn[8] = {0}, part_lqn[8] = {0};
+    int parts = 1;
     lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
-    int max_lq = 0, max_w = 0;                      /* of this part */
+    int max_lq = 0, max_w = 0, lrn = 0, lqn = 0;    /* of this part */
+    int64_t n_nar = 0;
     for (int64_t r = r_begin; r < r_end; r++) {
         LfqBaqRead &o = h[(size_t)r];
         const int l_qseq = (int)(rd->seq_off[r + 1] - rd->seq_off[r]);
@@ -1742,43 +1761,51 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         o.bw = bw;
         o.n_cigar = n_cigar;
         o.cigar_off = rd->cigar_off[r];
+        int wr = 0;
         if (l_qseq > 0 && o.l_ref > 0) {
             int b2 = std::max(o.l_ref, l_qseq);
             if (b2 > bw) b2 = bw;
             if (b2 < abs(o.l_ref - l_qseq)) b2 = abs(o.l_ref - l_qseq);
             max_lq = std::max(max_lq, l_qseq);
             max_w = std::max(max_w, (b2 * 2 + 1) * 3 + 6);
-            width[(size_t)r] = (b2 * 2 + 1) * 3 + 6;
+            wr = (b2 * 2 + 1) * 3 + 6;
+        }
+        width[(size_t)r] = wr;
+        /* narrow-band reads (rows of at most LFQ_BAQ_LDS_CELLS cells, a short reference window) run in the register kernel */
+        if (use_lds && wr <= LFQ_BAQ_LDS_CELLS && o.l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
+            n_nar++;
+            lrn = std::max(lrn, o.l_ref);
+            lqn = std::max(lqn, l_qseq);
         }
     }
     part_lq[part] = max_lq;
     part_w[part] = max_w;
-    });
-    for (int p = 0; p < 8; p++) {
+    part_narrow[part + 1] = n_nar;
+    part_lrn[part] = lrn;
+    part_lqn[part] = lqn;
+    }, &parts);
+    int max_lref_narrow = 0, max_lq_narrow = 0;
+    for (int p = 0; p < parts; p++) {
         max_lq = std::max(max_lq, part_lq[p]);
         max_w = std::max(max_w, part_w[p]);
+        max_lref_narrow = std::max(max_lref_narrow, part_lrn[p]);
+        max_lq_narrow = std::max(max_lq_narrow, part_lqn[p]);
+        part_narrow[p + 1] += part_narrow[p];
     }
     tmb[1] = lfq_now_ms();
-    /* narrow-band reads (rows of at most LFQ_BAQ_LDS_CELLS cells) first: they run in the LDS variant */
-    const bool use_lds = lfq_knobs().baq_lds != 0;
-    std::vector<int32_t> order((size_t)n);
-    int64_t n_narrow = 0;
-    int max_lref_narrow = 0, max_lq_narrow = 0;
-    {
-        int64_t wi = n;
-        for (int64_t r = 0; r < n; r++) {
+    /* launch order: the narrow-band reads first, in input order (neighbouring reads share their reference window in the
+     * caches); the others behind them.  Every part of the read range knows where its reads go. */
+    const int64_t n_narrow = part_narrow[parts];
+    lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
+        int64_t ni = part_narrow[part], wi = n - 1 - (r_begin - part_narrow[part]);   /* wide reads before this part: r_begin - narrow before */
+        for (int64_t r = r_begin; r < r_end; r++) {
             if (use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
-                order[(size_t)n_narrow++] = (int32_t)r;
-                max_lref_narrow = std::max(max_lref_narrow, h[(size_t)r].l_ref);
-                max_lq_narrow = std::max(max_lq_narrow, h[(size_t)r].l_qseq);
+                order[(size_t)ni++] = (int32_t)r;
+            } else {
+                order[(size_t)wi--] = (int32_t)r;
             }
         }
-        for (int64_t r = n - 1; r >= 0; r--) {
-            if (!(use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF)) {
-                order[(size_t)--wi] = (int32_t)r;
-            }
-        }
-    }
+    });
     const int64_t n_bases = rs->n_bases;
     if (!rs->tag_blob) {                        /* lb (+ ai, ad): resident from here on */
         const int64_t each = (n_bases + 16 + 255) / 256 * 256;
@@ -1806,9 +1833,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             rc = LFQ_ERR_HIP;
         }
     };
-    up(o_reads, h.data(), n * (int64_t)sizeof(LfqBaqRead));
+    up(o_reads, h, n * (int64_t)sizeof(LfqBaqRead));
     up(o_q2p, h_q2p, 1024);
-    up(o_ord, order.data(), n * 4);
+    up(o_ord, order, n * 4);
     if (rc == LFQ_OK && (hipMemsetAsync(rs->d_lb, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
                          || (want_idaq && (hipMemsetAsync(rs->d_ai, '~', (size_t)n_bases, c->stream) != hipSuccess
                                            || hipMemsetAsync(rs->d_ad, '~', (size_t)n_bases, c->stream) != hipSuccess
@@ -2451,7 +2478,9 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         tm[4] = lfq_now_ms();
         /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
          * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */
-        /* columns with events are few: the ev_off entries of the columns in between are filled as ranges */
+        /* Columns with events are few and independent of one another: the event list is cut at position boundaries into a
+         * few parts, every part builds the tables of its columns on its own thread, and the parts are appended in order
+         * (offsets shifted by what came before; the ev_off entries of the event-less columns in between are range fills). */
         for (int sd = 0; sd < 2; sd++) {
             LfqIndelColsOwned::Side &S = O.side[sd];
             S.ev_off.push_back(0);
@@ -2459,102 +2488,162 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             S.rd_off.push_back(0);
         }
         const int64_t ncols = (int64_t)O.cov.size();
-        std::vector<std::string> keys;
-        std::vector<std::vector<size_t>> members;
-        std::string key;
-        size_t ei = 0;
-        int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
-        while (ei < evs.size()) {
-            const int64_t ppos = evs[ei].pos - region_begin;
-            size_t e1 = ei;
-            while (e1 < evs.size() && evs[e1].pos - region_begin == ppos) {
-                e1++;
+        struct PartTables {
+            LfqIndelColsOwned::Side side[2];        /* key_off / rd_off: local running totals, no leading 0 */
+            std::vector<int64_t> cols;              /* columns with events, ascending */
+            std::vector<int64_t> ev_after[2];       /* local event count of each side after each of them */
+        };
+        const int n_parts = (int)std::max<size_t>(1, std::min<size_t>(8, evs.size() / 4096));
+        std::vector<PartTables> pt((size_t)n_parts);
+        std::vector<size_t> cut((size_t)n_parts + 1, evs.size());
+        cut[0] = 0;
+        for (int t = 1; t < n_parts; t++) {
+            size_t k = evs.size() * (size_t)t / (size_t)n_parts;
+            while (k < evs.size() && k > 0 && evs[k].pos == evs[k - 1].pos) {
+                k++;
             }
-            if (h[0][(size_t)ppos] <= 0) {          /* (cannot happen: a read with an event covers its position) */
+            cut[(size_t)t] = std::max(k, cut[(size_t)t - 1]);
+        }
+        auto build = [&](int t) {
+            PartTables &P = pt[(size_t)t];
+            std::vector<std::string> keys;
+            std::vector<std::vector<size_t>> members;
+            std::string key;
+            size_t ei = cut[(size_t)t];
+            const size_t e_end = cut[(size_t)t + 1];
+            while (ei < e_end) {
+                const int64_t ppos = evs[ei].pos - region_begin;
+                size_t e1 = ei;
+                while (e1 < e_end && evs[e1].pos - region_begin == ppos) {
+                    e1++;
+                }
+                if (h[0][(size_t)ppos] <= 0) {      /* (cannot happen: a read with an event covers its position) */
+                    ei = e1;
+                    continue;
+                }
+                P.cols.push_back(col_of[(size_t)ppos]);
+                for (int sd = 0; sd < 2; sd++) {
+                    LfqIndelColsOwned::Side &S = P.side[sd];
+                    keys.clear();                       /* (reused across columns: no allocation in the common case) */
+                    for (auto &m : members) {
+                        m.clear();
+                    }
+                    size_t n_keys = 0;
+                    for (size_t i = ei; i < e1; i++) {
+                        const Ev &e = evs[i];
+                        if ((e.indel > 0) != (sd == 0)) {
+                            continue;
+                        }
+                        key.clear();
+                        if (sd == 0) {                                  /* inserted bases, plp.c:1082-1086 */
+                            const int64_t s0 = rd->seq_off[e.read], lq = rd->seq_off[e.read + 1] - s0;
+                            for (int j = 1; j <= e.indel; j++) {
+                                const int64_t q = e.qpos + j;
+                                const uint8_t code = q < lq ? rd->seq[s0 + q] : 4;
+                                key.push_back("ACGTN"[code > 4 ? 4 : code]);
+                            }
+                        } else {                                        /* deleted reference bases, :1127-1131 */
+                            for (int j = 1; j <= -e.indel; j++) {
+                                const int64_t g = e.pos + j;
+                                key.push_back(g < rd->ref_len ? (char)toupper((unsigned char)rd->ref[g]) : 'N');
+                            }
+                        }
+                        size_t ki = 0;
+                        while (ki < n_keys && keys[ki] != key) {
+                            ki++;
+                        }
+                        if (ki == n_keys) {
+                            keys.push_back(key);
+                            if (members.size() <= n_keys) {
+                                members.emplace_back();
+                            }
+                            n_keys++;
+                        }
+                        members[ki].push_back(i);
+                    }
+                    for (size_t ki = 0; ki < n_keys; ki++) {
+                        int fw = 0, rv = 0;
+                        for (size_t i : members[ki]) {
+                            const Ev &e = evs[i];
+                            const int64_t s0 = rd->seq_off[e.read];
+                            const uint32_t fl = t_fl[e.read];
+                            const uint8_t *qa = sd == 0 ? t_bi : t_bd, *aa = sd == 0 ? t_ai : t_ad;
+                            const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u)), tagged = (fl & (sd == 0 ? 4u : 8u)) != 0;
+                            S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
+                            int aq = -1;                                                 /* :1069-1073, 1113-1117 */
+                            if (tagged && !g_ai.empty()) {
+                                aq = (int)(sd == 0 ? g_ai[i] : g_ad[i]) - 33;
+                            } else if (tagged && aa) {
+                                aq = (int)aa[s0 + e.qpos] - 33;
+                            }
+                            S.rd_aq.push_back((int16_t)aq);
+                            S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
+                            const int32_t sq = t_sq ? t_sq[e.read] : -1;
+                            S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
+                            if (rd->reverse[e.read]) {
+                                rv++;
+                            } else {
+                                fw++;
+                            }
+                        }
+                        S.ev_fw.push_back(fw);
+                        S.ev_rv.push_back(rv);
+                        S.key_chars.insert(S.key_chars.end(), keys[ki].begin(), keys[ki].end());
+                        S.key_off.push_back((int64_t)S.key_chars.size());
+                        S.rd_off.push_back((int64_t)S.rd_q.size());
+                    }
+                    P.ev_after[sd].push_back((int64_t)S.ev_fw.size());
+                }
                 ei = e1;
-                continue;
             }
-            const int64_t col = col_of[(size_t)ppos];
-            for (int sd = 0; sd < 2; sd++) {        /* the event-less columns before this one */
-                O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(col - col_done), (int64_t)O.side[sd].ev_fw.size());
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < n_parts; t++) {
+                th.emplace_back(build, t);
             }
-            col_done = col + 1;
+            build(0);
+            for (auto &x : th) {
+                x.join();
+            }
+        }
+        int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
+        for (int t = 0; t < n_parts; t++) {
+            PartTables &P = pt[(size_t)t];
+            int64_t ev_base[2], rd_base[2], key_base[2];
             for (int sd = 0; sd < 2; sd++) {
                 LfqIndelColsOwned::Side &S = O.side[sd];
-                keys.clear();                           /* (reused across columns: no allocation in the common case) */
-                for (auto &m : members) {
-                    m.clear();
+                const LfqIndelColsOwned::Side &L = P.side[sd];
+                ev_base[sd] = (int64_t)S.ev_fw.size();
+                rd_base[sd] = (int64_t)S.rd_q.size();
+                key_base[sd] = (int64_t)S.key_chars.size();
+                S.ev_fw.insert(S.ev_fw.end(), L.ev_fw.begin(), L.ev_fw.end());
+                S.ev_rv.insert(S.ev_rv.end(), L.ev_rv.begin(), L.ev_rv.end());
+                S.key_chars.insert(S.key_chars.end(), L.key_chars.begin(), L.key_chars.end());
+                S.rd_q.insert(S.rd_q.end(), L.rd_q.begin(), L.rd_q.end());
+                S.rd_aq.insert(S.rd_aq.end(), L.rd_aq.begin(), L.rd_aq.end());
+                S.rd_mq.insert(S.rd_mq.end(), L.rd_mq.begin(), L.rd_mq.end());
+                S.rd_sq.insert(S.rd_sq.end(), L.rd_sq.begin(), L.rd_sq.end());
+                for (int64_t v : L.key_off) {
+                    S.key_off.push_back(v + key_base[sd]);
                 }
-                size_t n_keys = 0;
-                for (size_t i = ei; i < e1; i++) {
-                    const Ev &e = evs[i];
-                    if ((e.indel > 0) != (sd == 0)) {
-                        continue;
-                    }
-                    key.clear();
-                    if (sd == 0) {                                      /* inserted bases, plp.c:1082-1086 */
-                        const int64_t s0 = rd->seq_off[e.read], lq = rd->seq_off[e.read + 1] - s0;
-                        for (int j = 1; j <= e.indel; j++) {
-                            const int64_t q = e.qpos + j;
-                            const uint8_t code = q < lq ? rd->seq[s0 + q] : 4;
-                            key.push_back("ACGTN"[code > 4 ? 4 : code]);
-                        }
-                    } else {                                            /* deleted reference bases, :1127-1131 */
-                        for (int j = 1; j <= -e.indel; j++) {
-                            const int64_t g = e.pos + j;
-                            key.push_back(g < rd->ref_len ? (char)toupper((unsigned char)rd->ref[g]) : 'N');
-                        }
-                    }
-                    size_t ki = 0;
-                    while (ki < n_keys && keys[ki] != key) {
-                        ki++;
-                    }
-                    if (ki == n_keys) {
-                        keys.push_back(key);
-                        if (members.size() <= n_keys) {
-                            members.emplace_back();
-                        }
-                        n_keys++;
-                    }
-                    members[ki].push_back(i);
+                for (int64_t v : L.rd_off) {
+                    S.rd_off.push_back(v + rd_base[sd]);
                 }
-                for (size_t ki = 0; ki < n_keys; ki++) {
-                    int fw = 0, rv = 0;
-                    for (size_t i : members[ki]) {
-                        const Ev &e = evs[i];
-                        const int64_t s0 = rd->seq_off[e.read];
-                        const uint32_t fl = t_fl[e.read];
-                        const uint8_t *qa = sd == 0 ? t_bi : t_bd, *aa = sd == 0 ? t_ai : t_ad;
-                        const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u)), tagged = (fl & (sd == 0 ? 4u : 8u)) != 0;
-                        S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
-                        int aq = -1;                                                     /* :1069-1073, 1113-1117 */
-                        if (tagged && !g_ai.empty()) {
-                            aq = (int)(sd == 0 ? g_ai[i] : g_ad[i]) - 33;
-                        } else if (tagged && aa) {
-                            aq = (int)aa[s0 + e.qpos] - 33;
-                        }
-                        S.rd_aq.push_back((int16_t)aq);
-                        S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
-                        const int32_t sq = t_sq ? t_sq[e.read] : -1;
-                        S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
-                        if (rd->reverse[e.read]) {
-                            rv++;
-                        } else {
-                            fw++;
-                        }
-                    }
-                    S.ev_fw.push_back(fw);
-                    S.ev_rv.push_back(rv);
-                    S.key_chars.insert(S.key_chars.end(), keys[ki].begin(), keys[ki].end());
-                    S.key_off.push_back((int64_t)S.key_chars.size());
-                    S.rd_off.push_back((int64_t)S.rd_q.size());
-                }
-                S.ev_off.push_back((int64_t)S.ev_fw.size());
             }
-            ei = e1;
+            for (size_t i = 0; i < P.cols.size(); i++) {
+                const int64_t col = P.cols[i];
+                for (int sd = 0; sd < 2; sd++) {
+                    LfqIndelColsOwned::Side &S = O.side[sd];
+                    /* the event-less columns before this one repeat the running event count */
+                    S.ev_off.insert(S.ev_off.end(), (size_t)(col - col_done), S.ev_off.back());
+                    S.ev_off.push_back(ev_base[sd] + P.ev_after[sd][i]);
+                }
+                col_done = col + 1;
+            }
         }
         for (int sd = 0; sd < 2; sd++) {            /* the event-less columns behind the last event */
-            O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(ncols - col_done), (int64_t)O.side[sd].ev_fw.size());
+            O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(ncols - col_done), O.side[sd].ev_off.back());
         }
     }
     tm[5] = lfq_now_ms();
