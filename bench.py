@@ -77,7 +77,7 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the host-abi / chain measurements of config.secondary")
     ap.add_argument("--nt-bytes", action="store_true",
                     help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
                     help="N = 1, pipelined loop: batches whose kernels may be on the GPU at the same time (2: the count "
                          "kernel of batch k + 1 beside the DP kernels of batch k; 1: one batch's kernels at a time)")
     ap.add_argument("--no-pipeline", action="store_true",
