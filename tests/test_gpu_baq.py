@@ -73,6 +73,34 @@ def test_baq_random_reads_vs_oracle(caller, oracle, extended):
     assert nb > 20000
 
 
+@pytest.mark.parametrize("rl,n", [(150, 320), (250, 192), (320, 70)])
+def test_baq_uniform_length_wavefronts(caller, oracle, rl, n):
+    """What the register kernel's interior path sees: whole wavefronts of plain reads of one length (every row between
+    the ends takes the branch-free body), with N bases in some reads and a stretch of N in the reference (the body
+    variant with the N case, chosen per row for the whole wavefront), mismatches, and -- at 320 bp -- reference windows
+    beyond the register kernel's limit, which the host sends to the all-HBM kernel."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(100 + rl)
+    g = rng.choice(list("ACGT"), 4000)
+    g[1200:1260] = "N"
+    genome = "".join(g)
+    reads = []
+    for i in range(n):
+        pos = int(rng.integers(0, len(genome) - rl - 1))
+        seq = list(genome[pos:pos + rl])
+        for j in np.nonzero(rng.random(rl) < 0.01)[0]:
+            seq[j] = str(rng.choice(list("ACGT")))
+        if i % 7 == 0:
+            seq[int(rng.integers(0, rl))] = "N"
+        reads.append({"pos0": pos, "cigar": [("M", rl)], "seq": la.encode_seq("".join(seq)),
+                      "qual": np.clip(np.round(rng.normal(33, 6, rl)), 2, 41).astype(np.uint8)})
+    for extended in (True, False):
+        out = la.baq_batch(caller, reads, genome.encode(), extended=extended)
+        for r, o in zip(reads, out):
+            exp = oracle.baq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), extended=extended)
+            assert o.tobytes() == exp.tobytes(), (rl, r["pos0"], extended)
+
+
 def test_baq_empty(caller):
     import lofreq_amd as la
     assert la.baq_batch(caller, [], b"ACGT") == []
