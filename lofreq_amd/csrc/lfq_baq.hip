@@ -954,6 +954,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 
     /* ---- indel table for idaq (bam_md_ext.c:95-234): which posterior cells each indel needs ---- */
     int n_tab = 0, n_ins = 0, n_del = 0;
+    int it_lo = 1 << 30, it_hi = -1;               /* rows at which some kept indel of this read needs a posterior cell */
     int32_t *itab = IDAQ && A.itab ? A.itab + (size_t)blockIdx.x * LFQ_BAQ_MAX_INDELS * 4 * 64 : nullptr;
     double *terms = A.terms ? A.terms + (size_t)blockIdx.x * LFQ_BAQ_MAX_TERMS * 64 : nullptr;
 #define IT(e_, f_) itab[((size_t)(e_) * 4 + (f_)) * 64 + lane]
@@ -986,6 +987,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 int nt = rep + 1;
                 if (qpos + nt - 1 > l_query) nt = l_query - qpos + 1;          /* `if (qpos+j > l_qseq) break` */
                 if (n_tab < LFQ_BAQ_MAX_INDELS && n_terms + nt <= LFQ_BAQ_MAX_TERMS) {
+                    it_lo = min(it_lo, qpos);
+                    it_hi = max(it_hi, qpos + nt - 1);
                     IT(n_tab, 0) = (qpos << 1) | 1;                            /* bit 0: deletion */
                     IT(n_tab, 1) = rpos - R.xb + 1;
                     IT(n_tab, 2) = nt;
@@ -1013,6 +1016,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 if (qpos + nt > l_query) nt = l_query - qpos;                  /* `if (qpos+j+1 > l_qseq) break` */
                 if (nt < 0) nt = 0;
                 if (n_tab < LFQ_BAQ_MAX_INDELS && n_terms + nt <= LFQ_BAQ_MAX_TERMS) {
+                    it_lo = min(it_lo, qpos + 1);
+                    it_hi = max(it_hi, qpos + nt);
                     IT(n_tab, 0) = qpos << 1;
                     IT(n_tab, 1) = rpos - R.xb;
                     IT(n_tab, 2) = nt;
@@ -1157,7 +1162,9 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         }
         if (on) {
             const int max_k = max_u < 0 ? -1 : ((i - bw - 1) << 2) + max_u;
-            if (IDAQ) {
+            /* (the table sits in the scratch: the loop over it runs only at the few rows where this read has a term due,
+             * not as a chain of dependent loads in every row) */
+            if (IDAQ && i >= it_lo && i <= it_hi) {
                 int beg = 1, end = l_ref, x;
                 x = i - bw; beg = beg > x ? beg : x;
                 x = i + bw; end = end < x ? end : x;
