@@ -648,8 +648,8 @@ __device__ __forceinline__ uint32_t lfq_baq_ref4(const uint8_t *refw, int p, int
 template <bool HASN, bool IDAQ>
 __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[LFQ_BAQ_NB + 1], double (&O1)[LFQ_BAQ_NB + 1],
                                                 double (&O2)[LFQ_BAQ_NB + 1], unsigned long long win, int qyi, double e_eq,
-                                                double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp, double *f2p,
-                                                bool keep_f2, double &sum_out)
+                                                double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp,
+                                                double &sum_out)
 {
     constexpr int NB = LFQ_BAQ_NB;
     const unsigned long long xq = win ^ (0x1111111111111111ull * (unsigned long long)(qyi & 3));
@@ -666,9 +666,6 @@ __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[LFQ_BAQ_NB + 1], do
         const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
         const double f2 = m[2] * m_prev + m[8] * d_prev;
         fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
-        if (IDAQ && keep_f2) {
-            f2p[(size_t)j * 64] = f2;
-        }
         m_prev = f0;
         d_prev = f2;
         sum += f0 + f1 + f2;
@@ -741,9 +738,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     double *S = F + (size_t)rows * W * 64 + 2 * (size_t)W * 64;
     int32_t *expect = A.expect + (size_t)blockIdx.x * rows * 64;
     /* forward row i in the scratch: (match, insertion) of slot j as one 16-byte pair at pair index j and the deletion
-     * cells (idaq only) behind the pairs */
+     * cells are not stored: the few an indel's quality needs are recomputed from the row's match cells */
 #define FP(i_) ((LfqBaqPair *)(F + (size_t)(i_) * W * 64) + lane)
-#define FQ2(i_, j_) F[((size_t)(i_) * W + 2 * LFQ_BAQ_NB + (j_)) * 64 + lane]
 #define SQ(i_) S[(size_t)(i_) * 64 + lane]
 #define RQ(i_) S[(size_t)(rows + 2 + (i_)) * 64 + lane]
 #define ROWQ(i_) ((int)s_rowq[(size_t)(i_) * 64 + lane])
@@ -775,14 +771,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     m[3] = (1 - par_e) * (1 - sI); m[4] = par_e * (1 - sI); m[5] = 0.;
     m[6] = 1 - par_e; m[7] = 0.; m[8] = par_e;
     const double bM = (1 - par_d) / l_ref, bI = par_d / l_ref;
-    bool keep_f2 = false;                            /* deletion cells of the forward matrix: only for idaq terms */
-    if (IDAQ && act) {
-        const uint32_t *cg0 = A.cigar + R.cigar_off;
-        for (int k = 0; k < R.n_cigar; ++k) {
-            keep_f2 = keep_f2 || ((cg0[k] & 0xf) == 2);
-        }
-        keep_f2 = keep_f2 && A.itab != nullptr;
-    }
     /* interior rows: [8, f_hi] forward, [8, b_hi] backward -- every read of the wavefront has all 15 cells there (and,
      * backward, is neither at its last row nor at the last reference position) */
     int f_hi = 0, b_hi = 0;
@@ -838,9 +826,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 O0[j] = O0[j] / sum;
                 O1[j] = O1[j] / sum;
                 FP(1)[(size_t)j * 64] = LfqBaqPair{O0[j], O1[j]};
-                if (keep_f2) {
-                    FQ2(1, j) = 0. / sum;
-                }
             }
         }
     }
@@ -875,9 +860,9 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         if (i >= 8 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
             const bool has_n = qyi > 3 || (win & 0x0444444444444444ull) != 0;
             if (__any(has_n)) {
-                lfq_baq_fwd_row<true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, &FQ2(i, 0), keep_f2, sum);
+                lfq_baq_fwd_row<true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             } else {
-                lfq_baq_fwd_row<false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, &FQ2(i, 0), keep_f2, sum);
+                lfq_baq_fwd_row<false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             }
         } else {
             /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
@@ -897,9 +882,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 const double f2 = m[2] * m_prev + m[8] * d_prev;
                 if (valid) {
                     fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
-                    if (keep_f2) {
-                        FQ2(i, j) = f2;
-                    }
                 }
                 m_prev = f0;
                 d_prev = f2;
@@ -1185,7 +1167,18 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                         for (int j = 0; j < NB; j++) {   /* the row is in registers: pick the slot without indexing them */
                             bcell = (j == js) ? (st == 2 ? O2[j] : O1[j]) : bcell;
                         }
-                        const double fcell = st == 2 ? FQ2(i, js) : FP(i)[(size_t)js * 64].i;
+                        /* the forward cell: the insertion cell is among the row's cells loaded for the MAP step; a
+                         * deletion cell is recomputed from the row's match cells, f2(k) = m2 f0(k-1) + m8 f2(k-1) from
+                         * 0 at the left end of the band -- the operations of the forward pass on the values it stored
+                         * (row 1 has no deletion cells: kprobaln_ext.c:141-157 leaves them 0) */
+                        double fcell = 0., mp_ = 0., dp_ = 0.;
+#pragma unroll
+                        for (int j = 0; j < NB; j++) {
+                            const double f2j = m[2] * mp_ + m[8] * dp_;
+                            fcell = (j == js) ? (st == 2 ? (i > 1 ? f2j : 0.) : fz1[j]) : fcell;
+                            mp_ = fz0[j];
+                            dp_ = f2j;
+                        }
                         term = (fcell * rsi) * bcell * SQ(i);
                     }
                     TM(IT(e, 3) + jj) = term;
@@ -1257,7 +1250,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #undef SQ
 #undef RQ
 #undef FP
-#undef FQ2
 #undef ROWQ
 #undef OUTE
 #undef LFQ_BAQ_BATCH
