@@ -1721,12 +1721,13 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     const bool use_lds = lfq_knobs().baq_lds != 0;
     int max_lq = 0, max_w = 0;
     int part_lq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, part_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t part_narrow[9] = {0};
+    int64_t part_narrow[9] = {0}, part_band8[9] = {0};
+    const bool reg_kernel = lfq_knobs().baq_kernel == 0;    /* the register kernel also has a band-8 instantiation */
     int part_lrn[8] = {0}, part_lqn[8] = {0};
     int parts = 1;
     lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
     int max_lq = 0, max_w = 0, lrn = 0, lqn = 0;    /* of this part */
-    int64_t n_nar = 0;
+    int64_t n_nar = 0, n_b8 = 0;
     for (int64_t r = r_begin; r < r_end; r++) {
         LfqBaqRead &o = h[(size_t)r];
         const int l_qseq = (int)(rd->seq_off[r + 1] - rd->seq_off[r]);
@@ -1776,11 +1777,15 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             n_nar++;
             lrn = std::max(lrn, o.l_ref);
             lqn = std::max(lqn, l_qseq);
+        } else if (use_lds && reg_kernel && wr == LFQ_BAQ_BAND8_CELLS && o.l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
+            n_b8++;                                     /* band 8: a deletion of odd length (bam_md_ext.c:353-356) */
+            lqn = std::max(lqn, l_qseq);
         }
     }
     part_lq[part] = max_lq;
     part_w[part] = max_w;
     part_narrow[part + 1] = n_nar;
+    part_band8[part + 1] = n_b8;
     part_lrn[part] = lrn;
     part_lqn[part] = lqn;
     }, &parts);
@@ -1791,16 +1796,21 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         max_lref_narrow = std::max(max_lref_narrow, part_lrn[p]);
         max_lq_narrow = std::max(max_lq_narrow, part_lqn[p]);
         part_narrow[p + 1] += part_narrow[p];
+        part_band8[p + 1] += part_band8[p];
     }
     tmb[1] = lfq_now_ms();
     /* launch order: the narrow-band reads first, in input order (neighbouring reads share their reference window in the
-     * caches); the others behind them.  Every part of the read range knows where its reads go. */
-    const int64_t n_narrow = part_narrow[parts];
+     * caches), then the band-8 reads, the others behind them.  Every part of the read range knows where its reads go. */
+    const int64_t n_narrow = part_narrow[parts], n_band8 = part_band8[parts];
     lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
-        int64_t ni = part_narrow[part], wi = n - 1 - (r_begin - part_narrow[part]);   /* wide reads before this part: r_begin - narrow before */
+        int64_t ni = part_narrow[part], bi = n_narrow + part_band8[part];
+        int64_t wi = n - 1 - (r_begin - part_narrow[part] - part_band8[part]);    /* wide reads before this part */
         for (int64_t r = r_begin; r < r_end; r++) {
-            if (use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
+            const bool short_ref = h[(size_t)r].l_ref <= LFQ_BAQ_LDS_MAX_LREF;
+            if (use_lds && width[(size_t)r] <= LFQ_BAQ_LDS_CELLS && short_ref) {
                 order[(size_t)ni++] = (int32_t)r;
+            } else if (use_lds && reg_kernel && width[(size_t)r] == LFQ_BAQ_BAND8_CELLS && short_ref) {
+                order[(size_t)bi++] = (int32_t)r;
             } else {
                 order[(size_t)wi--] = (int32_t)r;
             }
@@ -1871,8 +1881,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         if (lfq_knobs().baq_scratch_mb >= 0) {
             budget_b = (int64_t)lfq_knobs().baq_scratch_mb << 20;
         }
-        /* + 1: the narrow and the wide reads round up to whole wavefronts separately */
-        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64 + 1, budget_b / per_wave));
+        /* + 2: the three classes of reads round up to whole wavefronts separately */
+        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64 + 2, budget_b / per_wave));
         auto keep = [&](auto **slot, int64_t *have, int64_t need) {
             if (need > *have) {
                 if (*slot) (void)hipFree(*slot);
@@ -1906,36 +1916,58 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         A.order = (const int32_t *)(d_blob + o_ord);
         A.max_lref = max_lref_narrow;
         A.lds_rows = max_lq_narrow + 1;
-        /* The few reads with a wider band (indels longer than the default band) are a handful of latency-bound
-         * wavefronts: they run beside the narrow-band launches on a side stream, in scratch slots of their own behind the
-         * narrow ones' (wavefront w of a launch owns slot w).  The narrow-band kernel runs one wavefront per SIMD, so a
-         * launch is cut to a whole number of rounds over the SIMDs: a launch of 7.3 rounds takes as long as one of 8. */
-        const int64_t waves_wide = (n - n_narrow + 63) / 64;
-        const bool beside = n_narrow > 0 && n > n_narrow && waves_wide < waves / 4 && c->side[0] != nullptr
-                            && !lfq_knobs().single_stream;
-        int64_t waves_n = beside ? waves - waves_wide : waves;          /* slots of a narrow launch */
+        /* The reads with a wider band are few: band 8 (a deletion of odd length; the register kernel's second
+         * instantiation) and everything beyond (the all-HBM kernel, a handful of latency-bound wavefronts).  They run
+         * beside the narrow-band launches on the side streams, in scratch slots of their own behind the narrow ones'
+         * (wavefront w of a launch owns slot w).  The narrow-band kernel runs one wavefront per SIMD, so a launch is cut
+         * to a whole number of rounds over the SIMDs: a launch of 7.3 rounds takes as long as one of 8. */
+        const int64_t n_wide = n - n_narrow - n_band8;
+        const int64_t waves_wide = (n_wide + 63) / 64, waves_b8 = (n_band8 + 63) / 64;
+        const bool beside = n_narrow > 0 && waves_wide + waves_b8 > 0 && waves_wide + waves_b8 < waves / 4
+                            && c->side[0] != nullptr && c->side[1] != nullptr && !lfq_knobs().single_stream;
+        int64_t waves_n = beside ? waves - waves_wide - waves_b8 : waves;      /* slots of a narrow launch */
         const int64_t round = (int64_t)c->n_cu * 4;
         if ((n_narrow + 63) / 64 > waves_n && waves_n > round) {       /* more than one launch: whole rounds each */
             waves_n = waves_n / round * round;
         }
-        if (beside) {
-            LfqBaqArgs Aw = A;
-            Aw.scratch = A.scratch + (size_t)waves_n * (size_t)(per_wave / 8);
-            Aw.expect = A.expect + (size_t)waves_n * A.rows * 64;
-            Aw.tmp8 = A.tmp8 + (size_t)waves_n * 2 * A.rows * 64;
+        auto at_slot = [&](int64_t slot) {          /* the arguments with the scratch of wavefront slot `slot` first */
+            LfqBaqArgs X = A;
+            X.scratch = A.scratch + (size_t)slot * (size_t)(per_wave / 8);
+            X.expect = A.expect + (size_t)slot * A.rows * 64;
+            X.tmp8 = A.tmp8 + (size_t)slot * 2 * A.rows * 64;
             if (want_idaq) {
-                Aw.itab = A.itab + (size_t)waves_n * LFQ_BAQ_MAX_INDELS * 4 * 64;
-                Aw.terms = A.terms + (size_t)waves_n * LFQ_BAQ_MAX_TERMS * 64;
+                X.itab = A.itab + (size_t)slot * LFQ_BAQ_MAX_INDELS * 4 * 64;
+                X.terms = A.terms + (size_t)slot * LFQ_BAQ_MAX_TERMS * 64;
             }
-            Aw.first_read = (int32_t)n_narrow;
-            /* the side stream starts after the uploads / memsets queued on c->stream, c->stream ends after it */
-            if (hipEventRecord(c->ev_join[0], c->stream) != hipSuccess || hipStreamWaitEvent(c->side[0], c->ev_join[0], 0) != hipSuccess) {
+            return X;
+        };
+        if (beside) {
+            /* the side streams start after the uploads / memsets queued on c->stream, c->stream ends after them */
+            if (hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
-            if (rc == LFQ_OK) {
-                rc = lfq_launch_baq(Aw, n - n_narrow, 0, c->side[0]);
+            if (rc == LFQ_OK && n_wide > 0) {
+                LfqBaqArgs Aw = at_slot(waves_n + waves_b8);
+                Aw.first_read = (int32_t)(n_narrow + n_band8);
+                if (hipStreamWaitEvent(c->side[0], c->ev_join[0], 0) != hipSuccess) {
+                    rc = LFQ_ERR_HIP;
+                }
+                if (rc == LFQ_OK) {
+                    rc = lfq_launch_baq(Aw, n_wide, 0, c->side[0]);
+                }
             }
-            if (rc == LFQ_OK && (hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess)) {
+            if (rc == LFQ_OK && n_band8 > 0) {
+                LfqBaqArgs Ab = at_slot(waves_n);
+                Ab.first_read = (int32_t)n_narrow;
+                if (hipStreamWaitEvent(c->side[1], c->ev_join[0], 0) != hipSuccess) {
+                    rc = LFQ_ERR_HIP;
+                }
+                if (rc == LFQ_OK) {
+                    rc = lfq_launch_baq(Ab, n_band8, 2, c->side[1]);
+                }
+            }
+            if (rc == LFQ_OK && (hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess
+                                 || hipEventRecord(c->ev_join[2], c->side[1]) != hipSuccess)) {
                 rc = LFQ_ERR_HIP;
             }
         }
@@ -1944,11 +1976,16 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             rc = lfq_launch_baq(A, std::min<int64_t>(waves_n * 64, n_narrow - first), 1, c->stream);
         }
         if (beside) {
-            if (rc == LFQ_OK && hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess) {
+            if (rc == LFQ_OK && (hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess
+                                 || hipStreamWaitEvent(c->stream, c->ev_join[2], 0) != hipSuccess)) {
                 rc = LFQ_ERR_HIP;
             }
         } else {
-            for (int64_t first = n_narrow; rc == LFQ_OK && first < n; first += waves * 64) {
+            for (int64_t first = n_narrow; rc == LFQ_OK && first < n_narrow + n_band8; first += waves * 64) {
+                A.first_read = (int32_t)first;
+                rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n_narrow + n_band8 - first), 2, c->stream);
+            }
+            for (int64_t first = n_narrow + n_band8; rc == LFQ_OK && first < n; first += waves * 64) {
                 A.first_read = (int32_t)first;
                 rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
             }

@@ -604,7 +604,23 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
  *   - the BAQ byte of a row goes into the LDS slot of a row that is done, the extended-BAQ passes run there and
  *     the read's bytes leave in one burst.
  * The LDS-row kernel above (LFQ_BAQ_KERNEL=1) is the previous implementation, kept for A/B runs. */
-#define LFQ_BAQ_NB 15
+#define LFQ_BAQ_NB 15              /* slots of the default band: 2 * 7 + 1 */
+#define LFQ_BAQ_NB_WIDE 17         /* band 8: what a read with a deletion of odd length gets (bam_md_ext.c:353-356) */
+
+/* the reference codes of a row's slots as 4-bit fields: 64 bits hold the 15 slots of band 7 and the code that enters
+ * next; band 8 takes a 128-bit word */
+template <int NB> struct LfqBaqWinT { typedef unsigned long long type; };
+template <> struct LfqBaqWinT<LFQ_BAQ_NB_WIDE> { typedef unsigned __int128 type; };
+template <int NB, typename W>
+__device__ __forceinline__ W lfq_baq_nibbles(unsigned v)        /* v in each of the NB lowest nibbles */
+{
+    W w = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        w |= (W)v << (4 * j);
+    }
+    return w;
+}
 struct alignas(16) LfqBaqPair {
     double m, i;
 };
@@ -645,20 +661,20 @@ __device__ __forceinline__ uint32_t lfq_baq_ref4(const uint8_t *refw, int p, int
 
 /* one interior row of the forward pass (all 15 cells exist for every read of the wavefront); HASN: some read has an
  * N in its window or as its base */
-template <bool HASN, bool IDAQ>
-__device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[LFQ_BAQ_NB + 1], double (&O1)[LFQ_BAQ_NB + 1],
-                                                double (&O2)[LFQ_BAQ_NB + 1], unsigned long long win, int qyi, double e_eq,
+template <int NB, bool HASN, bool IDAQ>
+__device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O1)[NB + 1], double (&O2)[NB + 1],
+                                                typename LfqBaqWinT<NB>::type win, int qyi, double e_eq,
                                                 double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp,
                                                 double &sum_out)
 {
-    constexpr int NB = LFQ_BAQ_NB;
-    const unsigned long long xq = win ^ (0x1111111111111111ull * (unsigned long long)(qyi & 3));
+    typedef typename LfqBaqWinT<NB>::type WinT;
+    const WinT xq = win ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(qyi & 3));
     double sum = 0., m_prev = 0., d_prev = 0.;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-        double e = ((xq >> (4 * j)) & 15ull) == 0 ? e_eq : e_ne;
+        double e = ((unsigned)(xq >> (4 * j)) & 15u) == 0 ? e_eq : e_ne;
         if (HASN) {
-            e = (((win >> (4 * j)) & 4ull) != 0 || qyi > 3) ? 1. : e;
+            e = (((unsigned)(win >> (4 * j)) & 4u) != 0 || qyi > 3) ? 1. : e;
         }
         const double a0 = O0[j] * rs, a1 = O1[j] * rs, a2 = O2[j] * rs;
         const double c0 = O0[j + 1] * rs, c1 = O1[j + 1] * rs;
@@ -677,19 +693,19 @@ __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[LFQ_BAQ_NB + 1], do
 }
 
 /* one interior row of the backward pass: O <- row i from row i + 1 (both scaled), all 15 cells */
-template <bool HASN, bool IDAQ>
-__device__ __forceinline__ void lfq_baq_bwd_row(double (&O0)[LFQ_BAQ_NB + 1], double (&O1)[LFQ_BAQ_NB + 1],
-                                                double (&O2)[LFQ_BAQ_NB + 1], unsigned long long win, int qy1, double e_eq,
+template <int NB, bool HASN, bool IDAQ>
+__device__ __forceinline__ void lfq_baq_bwd_row(double (&O0)[NB + 1], double (&O1)[NB + 1], double (&O2)[NB + 1],
+                                                typename LfqBaqWinT<NB>::type win, int qy1, double e_eq,
                                                 double e_ne, double ys, const double (&m)[9])
 {
-    constexpr int NB = LFQ_BAQ_NB;
-    const unsigned long long xq = win ^ (0x1111111111111111ull * (unsigned long long)(qy1 & 3));
+    typedef typename LfqBaqWinT<NB>::type WinT;
+    const WinT xq = win ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(qy1 & 3));
     double d01 = 0.;
 #pragma unroll
     for (int j = NB - 1; j >= 0; --j) {
-        double em = ((xq >> (4 * j)) & 15ull) == 0 ? e_eq : e_ne;
+        double em = ((unsigned)(xq >> (4 * j)) & 15u) == 0 ? e_eq : e_ne;
         if (HASN) {
-            em = (((win >> (4 * j)) & 4ull) != 0 || qy1 > 3) ? 1. : em;
+            em = (((unsigned)(win >> (4 * j)) & 4u) != 0 || qy1 > 3) ? 1. : em;
         }
         const double o101 = j > 0 ? O1[j > 0 ? j - 1 : 0] : 0.;
         const double e = em * O0[j];
@@ -708,13 +724,14 @@ __device__ __forceinline__ void lfq_baq_bwd_row(double (&O0)[LFQ_BAQ_NB + 1], do
 /* IDAQ = false: lb only -- no indel table, no deletion row in the backward pass (it exists there only as the running
  * d01 of the recurrence) */
 /* s[l_query + 1] (kprobaln_ext.c:184-189): the cells of the last row within the band limits, k ascending */
-__device__ __forceinline__ double lfq_baq_sfin(const double (&O0)[LFQ_BAQ_NB + 1], const double (&O1)[LFQ_BAQ_NB + 1], double rs,
+template <int NB>
+__device__ __forceinline__ double lfq_baq_sfin(const double (&O0)[NB + 1], const double (&O1)[NB + 1], double rs,
                                                double sM, double sI, int l_query, int l_ref, int bw)
 {
     double sum = 0.;
     const int xl = l_query - bw > 0 ? l_query - bw : 0;
 #pragma unroll
-    for (int j = 0; j < LFQ_BAQ_NB; j++) {
+    for (int j = 0; j < NB; j++) {
         const int k = l_query - bw + j;
         if (j < 2 * bw + 1 && k >= 1 && k <= l_ref && k >= xl && k <= xl + 2 * bw) {
             sum += (O0[j] * rs) * sM + (O1[j] * rs) * sI;
@@ -723,11 +740,12 @@ __device__ __forceinline__ double lfq_baq_sfin(const double (&O0)[LFQ_BAQ_NB + 1
     return sum;
 }
 
-template <bool IDAQ>
+template <int NB, bool IDAQ>
 __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqArgs A, int64_t n_launch)
 {
+    typedef typename LfqBaqWinT<NB>::type WinT;
+    constexpr int BWF = (NB - 1) / 2;               /* the band this instantiation holds in full */
     extern __shared__ uint16_t s_rowq[];         /* [lds_rows + 2][64]: base code | quality << 8 of row i; later the BAQ bytes */
-    constexpr int NB = LFQ_BAQ_NB;
     const int lane = (int)threadIdx.x;
     const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
     const bool live = ridx < n_launch;
@@ -762,7 +780,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     int bw = l_ref > l_query ? l_ref : l_query;                          /* kprobaln_ext.c:99-101 */
     if (bw > R.bw) bw = R.bw;
     if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);            /* <= 7: the host sends only such reads here */
-    if (!act) bw = 7;
+    if (!act) bw = BWF;
     const int bw2 = bw * 2 + 1;
     const float par_d = 0.00001f, par_e = 0.4f;                          /* kpa_ext_par_lofreq_illumina */
     double m[9];
@@ -775,16 +793,16 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
      * backward, is neither at its last row nor at the last reference position) */
     int f_hi = 0, b_hi = 0;
     {
-        int fh = act ? (bw == 7 ? (l_query < l_ref - 7 ? l_query : l_ref - 7) : 0) : 1 << 30;
-        int bh = act ? (bw == 7 ? (l_query - 1 < l_ref - 8 ? l_query - 1 : l_ref - 8) : 0) : 1 << 30;
+        int fh = act ? (bw == BWF ? (l_query < l_ref - BWF ? l_query : l_ref - BWF) : 0) : 1 << 30;
+        int bh = act ? (bw == BWF ? (l_query - 1 < l_ref - BWF - 1 ? l_query - 1 : l_ref - BWF - 1) : 0) : 1 << 30;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const int o1 = __shfl_xor(fh, off), o2 = __shfl_xor(bh, off);
             fh = o1 < fh ? o1 : fh;
             bh = o2 < bh ? o2 : bh;
         }
-        f_hi = fh < 8 ? 0 : fh;                      /* no interior range: the masked body takes every row */
-        b_hi = bh < 8 ? 0 : bh;
+        f_hi = fh < BWF + 1 ? 0 : fh;                /* no interior range: the masked body takes every row */
+        b_hi = bh < BWF + 1 ? 0 : bh;
     }
 
     /* the row: slot j = k - i + bw; O[NB] is the always-zero slot beyond the band */
@@ -829,23 +847,35 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             }
         }
     }
-    /* codes of reference positions i - bw .. i - bw + 15 of the row about to be computed, 4 bits each; the code that
-     * enters after row i (position i - bw + 16) is nibble i & 15 of `nxt`, the codes of the 16 rows after that are on
-     * their way in `pd` */
-    unsigned long long win, nxt;
+    /* codes of reference positions i - bw .. i - bw + NB of the row about to be computed, 4 bits each (slot j = nibble j,
+     * nibble NB = the code that becomes slot NB - 1 of the next row); the code that enters after row i (position
+     * i - bw + NB + 1) is nibble i & 15 of `nxt`, the codes of the 16 rows after that are on their way in `pd` */
+    WinT win = 0;
+    unsigned long long nxt;
     uint32_t pd0, pd1, pd2, pd3;
-    win = lfq_baq_pack16(lfq_baq_ref4(refw, 2 - bw, l_ref), lfq_baq_ref4(refw, 6 - bw, l_ref), lfq_baq_ref4(refw, 10 - bw, l_ref),
-                         lfq_baq_ref4(refw, 14 - bw, l_ref));
-    nxt = lfq_baq_pack16(lfq_baq_ref4(refw, 16 - bw, l_ref), lfq_baq_ref4(refw, 20 - bw, l_ref), lfq_baq_ref4(refw, 24 - bw, l_ref),
-                         lfq_baq_ref4(refw, 28 - bw, l_ref));
-    pd0 = lfq_baq_ref4(refw, 32 - bw, l_ref); pd1 = lfq_baq_ref4(refw, 36 - bw, l_ref);
-    pd2 = lfq_baq_ref4(refw, 40 - bw, l_ref); pd3 = lfq_baq_ref4(refw, 44 - bw, l_ref);
+#pragma unroll
+    for (int q = 0; q < (NB + 1 + 3) / 4; q++) {     /* positions 2 - bw .. 2 - bw + NB: the slots of row 2 and the lookahead */
+        const uint32_t d = lfq_baq_ref4(refw, 2 - bw + 4 * q, l_ref);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (4 * q + t <= NB) {
+                win |= (WinT)(unsigned)lfq_baq_code((int)((d >> (8 * t)) & 0xffu)) << (4 * (4 * q + t));
+            }
+        }
+    }
+    {
+        const int p = NB + 1 - bw;                   /* the code entering after row i: position i - bw + NB + 1 */
+        nxt = lfq_baq_pack16(lfq_baq_ref4(refw, p, l_ref), lfq_baq_ref4(refw, p + 4, l_ref), lfq_baq_ref4(refw, p + 8, l_ref),
+                             lfq_baq_ref4(refw, p + 12, l_ref));
+        pd0 = lfq_baq_ref4(refw, p + 16, l_ref); pd1 = lfq_baq_ref4(refw, p + 20, l_ref);
+        pd2 = lfq_baq_ref4(refw, p + 24, l_ref); pd3 = lfq_baq_ref4(refw, p + 28, l_ref);
+    }
     double rs_next = 1.;                             /* RQ(1) */
     /* base code and quality of a row come out of LDS one row ahead */
     int rq_next = ROWQ(2);
     double ql_next = A.qual2prob[rq_next >> 8];
     if (l_query == 1) {
-        s_fin = lfq_baq_sfin(O0, O1, 1., sM, sI, l_query, l_ref, bw);
+        s_fin = lfq_baq_sfin<NB>(O0, O1, 1., sM, sI, l_query, l_ref, bw);
     }
     for (int i = 2; i <= Lmax; ++i) {
         double sum = 0.;
@@ -857,12 +887,12 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);      /* enters the window for row i + 1 */
         const double e_eq = 1. - qli, e_ne = qli * LFQ_BAQ_EM;           /* lfq_baq_emit's two non-trivial values */
         LfqBaqPair *fp = FP(i);
-        if (i >= 8 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
-            const bool has_n = qyi > 3 || (win & 0x0444444444444444ull) != 0;
+        if (i >= BWF + 1 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
+            const bool has_n = qyi > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             if (__any(has_n)) {
-                lfq_baq_fwd_row<true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+                lfq_baq_fwd_row<NB, true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             } else {
-                lfq_baq_fwd_row<false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+                lfq_baq_fwd_row<NB, false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             }
         } else {
             /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
@@ -873,7 +903,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #pragma unroll
             for (int j = 0; j < NB; j++) {
                 const bool valid = j <= jmax;
-                const int r = (int)((win >> (4 * j)) & 15ull);
+                const int r = (int)((unsigned)(win >> (4 * j)) & 15u);
                 const double e = (r > 3 || qyi > 3) ? 1. : (r == qyi ? e_eq : e_ne);
                 const double a0 = O0[j] * rs, a1 = O1[j] * rs, a2 = O2[j] * rs;
                 const double c0 = O0[j + 1] * rs, c1 = O1[j + 1] * rs;
@@ -891,10 +921,10 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 O2[j] = valid ? f2 : 0.;
             }
         }
-        win = (win >> 4) | ((unsigned long long)code_in << 60);
+        win = (win >> 4) | ((WinT)(unsigned)code_in << (4 * NB));
         if ((i & 15) == 15) {                        /* the next 16 codes have had 16 rows to arrive; request the ones after */
             nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
-            const int p = i + 33 - bw;               /* row i + 17's code: position (i + 17) - bw + 16 */
+            const int p = i + 18 + NB - bw;          /* row i + 17's code: position (i + 17) - bw + NB + 1 */
             pd0 = lfq_baq_ref4(refw, p, l_ref); pd1 = lfq_baq_ref4(refw, p + 4, l_ref);
             pd2 = lfq_baq_ref4(refw, p + 8, l_ref); pd3 = lfq_baq_ref4(refw, p + 12, l_ref);
         }
@@ -907,7 +937,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             RQ(i) = rs_next;
         }
         if (__any(i == l_query)) {                   /* some read's last row: its s[l_query + 1] while the row is there */
-            const double v = lfq_baq_sfin(O0, O1, rs_next, sM, sI, l_query, l_ref, bw);
+            const double v = lfq_baq_sfin<NB>(O0, O1, rs_next, sM, sI, l_query, l_ref, bw);
             s_fin = i == l_query ? v : s_fin;
         }
     }
@@ -1020,10 +1050,19 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 
     /* ---- backward (:206-238), with the MAP step of a row (:254-281) as soon as the row exists ---- */
     const double b_init0 = sM / s_last / s_fin, b_init1 = sI / s_last / s_fin;
-    /* codes of positions i - bw + 1 .. i - bw + 16 for the row about to be computed (the emission of cell k looks at
+    /* codes of positions i - bw + 1 .. i - bw + NB for the row about to be computed (the emission of cell k looks at
      * k + 1); after row i the code of position i - bw enters: nibble i & 15 of `nxt` */
-    win = lfq_baq_pack16(lfq_baq_ref4(refw, Lmax - bw + 1, l_ref), lfq_baq_ref4(refw, Lmax - bw + 5, l_ref),
-                         lfq_baq_ref4(refw, Lmax - bw + 9, l_ref), lfq_baq_ref4(refw, Lmax - bw + 13, l_ref));
+    win = 0;
+#pragma unroll
+    for (int q = 0; q < (NB + 3) / 4; q++) {
+        const uint32_t d = lfq_baq_ref4(refw, Lmax - bw + 1 + 4 * q, l_ref);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (4 * q + t < NB) {
+                win |= (WinT)(unsigned)lfq_baq_code((int)((d >> (8 * t)) & 0xffu)) << (4 * (4 * q + t));
+            }
+        }
+    }
     {
         const int p = ((Lmax >> 4) << 4) - bw;
         nxt = lfq_baq_pack16(lfq_baq_ref4(refw, p, l_ref), lfq_baq_ref4(refw, p + 4, l_ref), lfq_baq_ref4(refw, p + 8, l_ref),
@@ -1073,13 +1112,13 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             fz0[j] = v.m;
             fz1[j] = v.i;
         }
-        if (i >= 8 && i <= b_hi) {                   /* interior row */
-            const bool has_n = c_qy > 3 || (win & 0x0444444444444444ull) != 0;
+        if (i >= BWF + 1 && i <= b_hi) {                   /* interior row */
+            const bool has_n = c_qy > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             /* ys = 1 / s[i]: the same division as the forward pass's 1 / sum (i >= 8) */
             if (__any(has_n)) {
-                lfq_baq_bwd_row<true, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
+                lfq_baq_bwd_row<NB, true, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
             } else {
-                lfq_baq_bwd_row<false, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
+                lfq_baq_bwd_row<NB, false, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
             }
             /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
 #pragma unroll
@@ -1107,7 +1146,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #pragma unroll
             for (int j = NB - 1; j >= 0; --j) {
                 const bool valid = j >= jmin && j <= jmax;
-                const int r = (int)((win >> (4 * j)) & 15ull);
+                const int r = (int)((unsigned)(win >> (4 * j)) & 15u);
                 const double em = (r > 3 || c_qy > 3) ? 1. : (r == c_qy ? e_eq : e_ne);
                 const double o101 = j > 0 ? O1[j > 0 ? j - 1 : 0] : 0.;
                 const double e = (j >= jz ? 0 : em) * O0[j];
@@ -1135,7 +1174,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 sum += valid ? z1 : 0.;
             }
         }
-        win = (win << 4) | (unsigned long long)code_in;
+        win = (win << 4) | (WinT)(unsigned)code_in;
         if ((i & 15) == 0) {
             nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
             const int p = i - 32 - bw;               /* rows i - 32 .. i - 17 */
@@ -1256,6 +1295,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #undef LFQ_BAQ_CLAMP
 }
 
+/* lds: 0 = the all-HBM kernel (any band), 1 = band <= 7 (rows in registers / LDS), 2 = band 8 (rows in registers) */
 int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
 {
     if (n_launch <= 0) {
@@ -1267,12 +1307,20 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
         if (lfq_knobs().baq_kernel == 0) {           /* default: rows in registers; LFQ_BAQ_KERNEL=1: the LDS-row kernel (A/B) */
             /* (base | quality) of every row, later the BAQ bytes (see the kernel) */
             const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2;
-            if (a.itab) {
-                hipLaunchKernelGGL(lfq_baq_reg_kernel<true>, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, a, n_launch);
+            const hipStream_t st = (hipStream_t)stream;
+            if (lds == 2 && a.itab) {
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+            } else if (lds == 2) {
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+            } else if (a.itab) {
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             } else {
-                hipLaunchKernelGGL(lfq_baq_reg_kernel<false>, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, a, n_launch);
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             }
             return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+        }
+        if (lds == 2) {
+            return LFQ_ERR_INVALID;                  /* the LDS-row kernel holds band 7 only: the host sends it nothing else */
         }
         hipLaunchKernelGGL(lfq_baq_kernel<true>, dim3(blocks), dim3(64), ref_bytes, (hipStream_t)stream, a, n_launch);
     } else {

@@ -251,6 +251,7 @@ struct LfqBaqArgs {
 #define LFQ_BAQ_MAX_INDELS 64
 #define LFQ_BAQ_MAX_TERMS 1024
 #define LFQ_BAQ_LDS_CELLS 51    /* row width (cells) up to which a read runs in the LDS variant of the kernel */
+#define LFQ_BAQ_BAND8_CELLS 57  /* row width (cells) of band 8: (2 * 8 + 1) * 3 + 6 */
 #define LFQ_BAQ_LDS_BAND 15      /* cells (reference positions) per row of such a read: 2 * 7 + 1 */
 #define LFQ_BAQ_LDS_MAX_LREF 300 /* ... and whose reference window is this short: codes (32 B per base pair and wavefront) + row
                                   * scalars (128 B per query base) + 1 KiB stay below 64 KiB of LDS per wavefront */

@@ -101,6 +101,36 @@ def test_baq_uniform_length_wavefronts(caller, oracle, rl, n):
             assert o.tobytes() == exp.tobytes(), (rl, r["pos0"], extended)
 
 
+@pytest.mark.parametrize("dlen", [1, 2, 3, 9])
+def test_baq_deletion_bands(caller, oracle, dlen):
+    """Whole wavefronts of reads with one deletion of `dlen` bases: odd lengths widen the band to 8 (the register kernel's
+    second instantiation: its interior path needs every read of a wavefront at band 8), 2 keeps band 7, 9 goes to the
+    all-HBM kernel.  lb, ai and ad against the oracle."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(300 + dlen)
+    genome = "".join(rng.choice(list("ACGT"), 3000))
+    reads = []
+    for _ in range(200):
+        rl = 150
+        pos = int(rng.integers(10, len(genome) - rl - dlen - 10))
+        cut = int(rng.integers(40, 110))
+        seq = list(genome[pos:pos + cut] + genome[pos + cut + dlen:pos + dlen + rl])
+        for j in np.nonzero(rng.random(rl) < 0.01)[0]:
+            seq[j] = str(rng.choice(list("ACGT")))
+        reads.append({"pos0": pos, "cigar": [("M", cut), ("D", dlen), ("M", rl - cut)], "seq": la.encode_seq("".join(seq)),
+                      "qual": np.clip(np.round(rng.normal(33, 6, rl)), 2, 41).astype(np.uint8)})
+    out = la.baq_batch(caller, reads, genome.encode(), extended=True, idaq=True)
+    n_ad = 0
+    for r, (lb, ai, ad) in zip(reads, out):
+        elb, eai, ead = oracle.baq_idaq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), True)
+        assert lb.tobytes() == elb.tobytes(), (dlen, r["pos0"])
+        assert (ai is None) == (eai is None) and (ad is None) == (ead is None), (dlen, r["pos0"])
+        if ad is not None:
+            assert ad.tobytes() == ead.tobytes(), (dlen, r["pos0"])
+            n_ad += 1
+    assert n_ad > 100
+
+
 def test_baq_empty(caller):
     import lofreq_amd as la
     assert la.baq_batch(caller, [], b"ACGT") == []
