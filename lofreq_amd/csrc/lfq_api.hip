@@ -147,6 +147,8 @@ struct lfq_ctx {
     uint8_t *d_tmp[3];               /* grow-only temporaries of the read-set steps: BAQ geometry, indel counters, gathers */
     uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
     int64_t pin_bytes;
+    uint8_t *h_pin2;                 /* pinned landing area of the indel pileup's per-position counters (grow-only) */
+    int64_t pin2_bytes;
     int64_t tmp_bytes[3];
     int64_t plp_ne_cap;              /* capacity of d_plp_ne in int16 elements */
     LfqIndelColsOwned *plp_indel;
@@ -511,6 +513,7 @@ void lfq_destroy(lfq_ctx *c)
             if (c->d_tmp[i]) (void)hipFree(c->d_tmp[i]);
         }
         if (c->h_pin) (void)hipHostFree(c->h_pin);
+        if (c->h_pin2) (void)hipHostFree(c->h_pin2);
         if (c->d_detlim) (void)hipFree(c->d_detlim);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
@@ -2328,15 +2331,30 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         for (int i = 0; i < 9; i++) {
             *cnt[i] = (int32_t *)(d + o_cnt + i * al(width * 4));
         }
-        std::vector<int32_t> h[9];
+        /* the nine per-position counters come back into pinned memory (grow-only): DMA instead of a staged copy */
+        int32_t *h[9] = {nullptr};
+        {
+            const int64_t need = 9 * al(width * 4);
+            if (need > c->pin2_bytes) {
+                if (c->h_pin2) (void)hipHostFree(c->h_pin2);
+                c->h_pin2 = nullptr;
+                c->pin2_bytes = 0;
+                if (hipHostMalloc((void **)&c->h_pin2, (size_t)need, hipHostMallocDefault) != hipSuccess) {
+                    return LFQ_ERR_NOMEM;
+                }
+                c->pin2_bytes = need;
+            }
+            for (int i = 0; i < 9; i++) {
+                h[i] = (int32_t *)(c->h_pin2 + i * al(width * 4));
+            }
+        }
         if (rc == LFQ_OK) {
             A.pmax_end = readset_pmax(c, rs);
             rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 0, c->stream) : lfq_launch_plp_indel(A, 0, c->stream);
         }
         const bool have_qsum = A.pmax_end != nullptr;       /* the column-major kernel sums the qualities itself */
         for (int i = 0; i < (have_qsum ? 9 : 7) && rc == LFQ_OK; i++) {
-            h[i].resize((size_t)width);
-            if (hipMemcpyAsync(h[i].data(), *cnt[i], (size_t)width * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+            if (hipMemcpyAsync(h[i], *cnt[i], (size_t)width * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
         }
