@@ -228,7 +228,7 @@ __device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *ro
                 const int eb = in_e[r0 + r];
                 S.e_in = eb;
                 x = in_sel ? xb : x;
-                dei = in_sel ? (eb - S.e) : dei;
+                dei = in_sel ? min(eb - S.e, 1000) : dei;
                 out_v[out_slot0 + (r0 + r) * out_stride] = S.v[C - 1];
                 out_e[out_slot0 + (r0 + r) * out_stride] = S.e;
             }
@@ -268,7 +268,10 @@ __device__ __forceinline__ bool lfq_strip_chunk(LfqStrip<C> &S, const LfqRow *ro
                 S.e = S.e_in;
             }
         }
-        S.de = lfq_shr1_i32(S.e) - S.e;
+        /* lane 0 has no left neighbour (the shift brings in value 0 and exponent 0): once its own exponent is below -1024 --
+         * P(X < C) of a column with more than ~700 expected errors, or after twenty observations of error probability 1 --
+         * 2^(0 - e) is no longer a double and 0 * inf would poison the strip.  Any finite scale does for a zero. */
+        S.de = min(lfq_shr1_i32(S.e) - S.e, 1000);
         /* ... and test the pruning condition on the tail cell */
         if (owns_tail) {
             const uint64_t over = __ballot(ldexp(S.v[0], S.e) * bonf_d > sig_s);
@@ -388,7 +391,7 @@ __device__ __forceinline__ bool lfq_strip_chunk2(LfqStrip<C> &S, const LfqRow2 *
             S.e = nzl ? S.e : e_front;
         }
         const int e_l1 = lfq_shr1_i32(S.e), e_l2 = lfq_shr1_i32(e_l1);
-        S.de = e_l1 - S.e;
+        S.de = min(e_l1 - S.e, 1000);                 /* (lane 0: see lfq_strip_chunk) */
         /* lanes 0 (and 1) read zeros from beyond the strip: any finite scale will do */
         S.sc1 = ldexp(1.0, max(-1000, min(1000, e_l1 - S.e)));
         S.sc2 = ldexp(1.0, max(-1000, min(1000, e_l2 - S.e)));

@@ -1,0 +1,68 @@
+"""Not a pytest module: a longer randomised parity run for the GPU box (`python tests/stress_gpu.py [n_seeds]`).
+Same comparisons as tests/test_gpu_parity.py::test_default_conf_random and tests/test_gpu_baq.py, over many more seeds
+and shapes; prints what it covered and exits non-zero on the first difference."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+
+import util                                   # noqa: E402
+import test_gpu_parity as tp                  # noqa: E402
+import test_gpu_baq as tb                     # noqa: E402
+
+
+def main(n_seeds):
+    import lofreq_amd as la
+    import pyoracle as oracle
+    oracle.build()
+    caller = la.SnvCaller(0)
+    n_rec = n_cols = 0
+    shapes = [(0, 300, 300), (900, 1100, 150), (1, 70, 300), (2000, 6000, 40), (9000, 11000, 12), (100, 4000, 80)]
+    for seed in range(100, 100 + n_seeds):
+        rng = np.random.default_rng(seed)
+        lo, hi, ncols = shapes[seed % len(shapes)]
+        afs = rng.choice([0.003, 0.01, 0.02, 0.05, 0.1, 0.3, 0.5, 0.9, 1.0], 8)
+        planted = {c: float(af) for c, af in zip(range(int(rng.integers(0, 9)), ncols, int(rng.integers(11, 41))), afs)}
+        host = util.random_batch(rng, ncols, lo, hi, planted=planted, ref_n_frac=0.02)
+        kw = {}
+        if seed % 5 == 0:
+            kw = dict(min_bq=int(rng.integers(0, 20)), min_alt_bq=int(rng.integers(0, 25)))
+        ores, oconf = util.run_oracle(oracle, host, **kw)
+        conf = la.VarcallConf(**kw)
+        recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
+        util.assert_counts_equal(counts, ores, host)
+        assert conf.bonf_subst == oconf.bonf_subst and conf.num_snv_tests == oconf.num_snv_tests, seed
+        try:
+            tp._compare_records(la, recs, ores, host)
+        except AssertionError:
+            print("FAILED at seed", seed, "shape", (lo, hi, ncols), "planted", planted, "conf", kw)
+            raise
+        n_rec += len(recs)
+        n_cols += ncols
+    print("snv: %d seeds, %d columns, %d records identical" % (n_seeds, n_cols, n_rec))
+    n_reads = 0
+    for seed in range(200, 200 + max(n_seeds // 4, 2)):
+        rng = np.random.default_rng(seed)
+        genome = "".join(rng.choice(list("ACGT"), 4000))
+        reads = tb._random_reads(rng, genome, 500, 20, int(rng.choice([100, 160, 260])))
+        for extended in (True, False):
+            out = la.baq_batch(caller, reads, genome.encode(), extended=extended, idaq=True)
+            for r, (lb, ai, ad) in zip(reads, out):
+                elb, eai, ead = oracle.baq_idaq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), extended)
+                assert lb.tobytes() == elb.tobytes(), (seed, r["pos0"], r["cigar"])
+                assert (ai is None) == (eai is None) and (ad is None) == (ead is None)
+                assert ai is None or ai.tobytes() == eai.tobytes()
+                assert ad is None or ad.tobytes() == ead.tobytes()
+        n_reads += len(reads)
+    print("baq: %d reads x 2 modes identical (lb, ai, ad)" % n_reads)
+    print("p-value deviations:", dict(util.PV_ERR_MAX) if hasattr(util, "PV_ERR_MAX") else "")
+    caller.close()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 60)

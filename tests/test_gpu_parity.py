@@ -308,6 +308,38 @@ def test_ragged_deep_mix(caller, oracle):
     assert len(recs) >= 8
 
 
+@pytest.mark.parametrize("kind", ["certain_errors", "noisy"])
+@pytest.mark.parametrize("af", [0.004, 0.1, 0.23, 0.7])
+def test_cells_below_double_range_at_the_left_end(caller, oracle, kind, af):
+    """Columns whose LOW counts are impossible: P(X < 4) drops below 2^-1024 -- after twenty-odd observations with error
+    probability 1 (BAQ 0: the base is certainly misaligned) or with more than ~700 expected errors (10 000 reads at Q8).
+    Lane 0 of a strip has no left neighbour; its exponent difference to "nothing" once overflowed to inf and 0 * inf
+    poisoned the column (log p = -inf, a call with QUAL INT_MIN).  All K classes: light / mid (wave kernels), row split,
+    and the unsplit multi-pass kernel (K > 2016)."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(int(af * 1000) + (7 if kind == "noisy" else 0))
+    host = util.random_batch(rng, 6, 9500, 10500, planted={1: af, 4: af}, low_bq_frac=0.0)
+    if kind == "certain_errors":
+        for c in (1, 4):
+            a, b = int(host["col_off"][c]), int(host["col_off"][c + 1])
+            idx = rng.choice(np.arange(a, b), 40, replace=False)
+            host["baq"][idx] = 0
+    else:
+        host["bq"][:] = np.clip(np.round(rng.normal(8, 2, len(host["bq"]))), 2, 14).astype(np.uint8)
+    ores, oconf = util.run_oracle(oracle, host)
+    conf = la.VarcallConf()
+    recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
+    util.assert_counts_equal(counts, ores, host)
+    assert conf.bonf_subst == oconf.bonf_subst and conf.num_snv_tests == oconf.num_snv_tests
+    _compare_records(la, recs, ores, host)
+    # every p-value the device produced is a number
+    counts2, pvals, st2 = util.run_layer1(la, caller, host, la.VarcallConf())
+    for p in pvals:
+        for a in range(3):
+            if p["status"][a] == 1:
+                assert np.isfinite(p["logp"][a]), (int(p["col"]), a, p["logp"])
+
+
 @pytest.mark.parametrize("depth_lo,depth_hi", [(30, 400), (3000, 9000)])
 def test_lazy_strand_counts_same_records(caller, oracle, depth_lo, depth_hi):
     """call_snvs without the dense counts leaves the strand planes out of the count kernel and counts DP4 only for
