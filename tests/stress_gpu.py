@@ -22,16 +22,23 @@ def main(n_seeds):
     oracle.build()
     caller = la.SnvCaller(0)
     n_rec = n_cols = 0
-    shapes = [(0, 300, 300), (900, 1100, 150), (1, 70, 300), (2000, 6000, 40), (9000, 11000, 12), (100, 4000, 80)]
+    shapes = [(0, 300, 300), (900, 1100, 150), (1, 70, 300), (2000, 6000, 40), (9000, 11000, 12), (100, 4000, 80),
+              (30000, 60000, 3), (90000, 110000, 2), (9000, 11000, 6)]
+    confs = [dict(), dict(), dict(), dict(min_jq=15), dict(min_alt_jq=20), dict(def_alt_bq=-1), dict(def_alt_bq=20),
+             dict(def_alt_jq=25), dict(flag=2), dict(flag=1), dict(flag=0), dict(flag=7), dict(min_cov=40),
+             dict(bonf_dynamic=0, bonf_subst=3000), dict(sig=0.05), dict(sig=1e-6)]
     for seed in range(100, 100 + n_seeds):
         rng = np.random.default_rng(seed)
         lo, hi, ncols = shapes[seed % len(shapes)]
         afs = rng.choice([0.003, 0.01, 0.02, 0.05, 0.1, 0.3, 0.5, 0.9, 1.0], 8)
-        planted = {c: float(af) for c, af in zip(range(int(rng.integers(0, 9)), ncols, int(rng.integers(11, 41))), afs)}
-        host = util.random_batch(rng, ncols, lo, hi, planted=planted, ref_n_frac=0.02)
-        kw = {}
+        planted = {c: float(af) for c, af in zip(range(int(rng.integers(0, 9)), ncols, int(rng.integers(1, 41))), afs)}
+        host = util.random_batch(rng, ncols, lo, hi, planted=planted, ref_n_frac=0.02, with_sq=bool(seed % 3 == 0),
+                                 with_baq=bool(seed % 7 != 0), low_bq_frac=float(rng.choice([0.0, 0.02, 0.3])))
+        if seed % 11 == 0:                      # a noisy run: qualities around Q10
+            host["bq"][:] = np.clip(np.round(rng.normal(10, 4, len(host["bq"]))), 0, 41).astype(np.uint8)
+        kw = dict(confs[(seed // 3) % len(confs)])
         if seed % 5 == 0:
-            kw = dict(min_bq=int(rng.integers(0, 20)), min_alt_bq=int(rng.integers(0, 25)))
+            kw.update(min_bq=int(rng.integers(0, 20)), min_alt_bq=int(rng.integers(0, 25)))
         ores, oconf = util.run_oracle(oracle, host, **kw)
         conf = la.VarcallConf(**kw)
         recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)

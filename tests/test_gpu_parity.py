@@ -21,7 +21,8 @@ def _compare_records(la, recs, ores, host, tol=None):      # None: per record, 1
         assert int(r["qual"]) == int(ores["qual"][c, a]), (c, a, r["qual"], ores["qual"][c, a])
         assert int(r["alt_raw_count"]) == int(ores["alt_raw_counts"][c, a])
         assert int(r["hqa"]) == int(ores["alt_counts"][c, a])
-        util.assert_pvalue_close(r["pvalue"], ores["pvalue"][c, a], tol, ctx="col %d allele %d" % (c, a))
+        util.assert_pvalue_close(r["pvalue"], ores["pvalue"][c, a], tol, ctx="col %d allele %d" % (c, a),
+                                 n_obs=int(host["col_off"][c + 1] - host["col_off"][c]))
 
 
 @pytest.mark.parametrize("seed,depth_lo,depth_hi,ncols", [(1, 0, 300, 400), (2, 900, 1100, 200), (3, 1, 70, 300)])

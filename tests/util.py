@@ -163,8 +163,11 @@ def pv_tol_for(pv_ref):
     return PV_DEEP_TOL if abs(log_of(pv_ref)) > PV_DEEP_LOG else PV_LOG_TOL
 
 
-def assert_pvalue_close(pv_gpu, pv_ref, tol=None, ctx=""):
-    """Sentinels must match exactly; finite values within `tol` relative (default: per record, by |log p|)."""
+def assert_pvalue_close(pv_gpu, pv_ref, tol=None, ctx="", n_obs=None):
+    """Sentinels must match exactly; finite values within `tol` relative (default: per record, by |log p|).
+    n_obs: the column's depth when it is beyond the 1e4 the bars above were measured at -- the reference's noise grows
+    like sqrt(N) (measured: 4.7e-10 against the 80-bit recurrence at N = 45 000, K = 13 500, log p = -8096), and so does
+    the deep-tail bar; only tests/stress_gpu.py has such columns."""
     pv_gpu, pv_ref = np.longdouble(pv_gpu), np.longdouble(pv_ref)
     if pv_ref == LDBL_MAX or pv_ref == LDBL_MIN or pv_gpu == LDBL_MAX or pv_gpu == LDBL_MIN:
         assert pv_gpu == pv_ref, "sentinel mismatch %s: gpu=%r ref=%r" % (ctx, pv_gpu, pv_ref)
@@ -173,6 +176,8 @@ def assert_pvalue_close(pv_gpu, pv_ref, tol=None, ctx=""):
     deep = abs(log_of(pv_ref)) > PV_DEEP_LOG
     if tol is None:
         tol = PV_DEEP_TOL if deep else PV_LOG_TOL
+        if deep and n_obs is not None and n_obs > 1e4:
+            tol = tol * (n_obs / 1e4) ** 0.5
     st = PV_ERR_MAX["|log p| > 600" if deep else "|log p| <= 600"]
     st[0] = max(st[0], d)
     st[1] += 1
