@@ -67,6 +67,24 @@ def main(n_seeds):
                 assert ad is None or ad.tobytes() == ead.tobytes()
         n_reads += len(reads)
     print("baq: %d reads x 2 modes identical (lb, ai, ad)" % n_reads)
+    # the seed-parameterised bodies of the other GPU parity tests, over more seeds and shapes
+    import test_gpu_indel as ti
+    import test_gpu_uniq as tu
+    n_other = 0
+    for seed in range(300, 300 + max(n_seeds // 6, 3)):
+        rng = np.random.default_rng(seed)
+        lo = int(rng.choice([1, 20, 300, 1500, 6000]))
+        hi = lo + int(rng.integers(10, 3000))
+        n = int(max(40, 40000 // hi))
+        for name, fn in (("indel", ti.test_indel_default_conf_random), ("uniq detlim", tu.test_uniq_detlim_random_vs_oracle),
+                         ("uniq binom", tu.test_uniq_binom_random_vs_oracle)):
+            try:
+                fn(caller, oracle, seed, lo, hi, n)
+            except AssertionError:
+                print("FAILED", name, "seed", seed, "depth", (lo, hi), "n", n)
+                raise
+            n_other += 1
+    print("indel / uniq: %d seeded runs identical to the oracle" % n_other)
     print("p-value deviations:", dict(util.PV_ERR_MAX) if hasattr(util, "PV_ERR_MAX") else "")
     caller.close()
 
