@@ -53,7 +53,7 @@ const LfqKnobs &lfq_knobs(void)
         }
         x.light_lanes = (int)geti("LFQ_QUAD_LANES", 0);
         x.light_waves_per_cu = (int)std::max(4L, geti("LFQ_LIGHT_WAVES_PER_CU", 10));
-        x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 8));
+        x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 4));
         x.screen_exact = has("LFQ_SCREEN_EXACT");
         x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));
         x.phase1_chunks = (int)std::max(1L, geti("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));

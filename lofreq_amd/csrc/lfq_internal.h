@@ -185,7 +185,7 @@ struct LfqKnobs {
     int light_kernel;          /* LFQ_LIGHT_KERNEL: 0 screen (default: one light column per lane), 1 quad (lane groups), 2 wave */
     int light_lanes;           /* LFQ_QUAD_LANES: force 8 / 16 / 32 / 64 cells (lanes) per light column; 0 = per batch */
     int light_waves_per_cu;    /* LFQ_LIGHT_WAVES_PER_CU (10): lane-group kernels */
-    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (8) */
+    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (4): the screen is latency-bound per column, more wavefronts only crowd the two critical chains */
     int screen_exact;          /* LFQ_SCREEN_EXACT: the screen kernel evaluates the full quality merge instead of its lower bound */
     int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
     int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
