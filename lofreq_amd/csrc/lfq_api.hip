@@ -54,10 +54,11 @@ template <typename F>
 static void lfq_for_reads(int64_t n, F f, int *parts_out = nullptr)
 {
     int parts = 1;
-    if (n >= 200000) {
+    const int64_t par_min = lfq_knobs().host_par_min;        /* LFQ_HOST_PAR_MIN (200000): below it one thread does it */
+    if (n >= par_min) {
         unsigned hw = std::thread::hardware_concurrency();
         hw = std::max(1u, hw / (unsigned)lfq_knobs().local_world_size);
-        parts = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), n / 100000);
+        parts = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), n / std::max<int64_t>(par_min / 2, 1));
         parts = std::max(parts, 1);
     }
     if (parts_out) {
@@ -2548,7 +2549,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             std::vector<int64_t> cols;              /* columns with events, ascending */
             std::vector<int64_t> ev_after[2];       /* local event count of each side after each of them */
         };
-        const int n_parts = (int)std::max<size_t>(1, std::min<size_t>(8, evs.size() / 4096));
+        const int n_parts = (int)std::max<size_t>(1, std::min<size_t>(8, evs.size() / (size_t)std::max<int64_t>(lfq_knobs().host_par_min / 48, 1)));
         std::vector<PartTables> pt((size_t)n_parts);
         std::vector<size_t> cut((size_t)n_parts + 1, evs.size());
         cut[0] = 0;

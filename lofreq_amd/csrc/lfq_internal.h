@@ -196,6 +196,7 @@ struct LfqKnobs {
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
     int host_threads;          /* LFQ_HOST_THREADS: -1 = from the core count */
+    long host_par_min;         /* LFQ_HOST_PAR_MIN (200000): reads / positions from which the host loops of the read-set steps split over threads */
     int local_world_size;      /* LOCAL_WORLD_SIZE (torchrun): processes sharing this host's cores, >= 1 */
     int indel_host_pack;       /* LFQ_INDEL_HOST_PACK */
     int pileup_atomic;         /* LFQ_PILEUP_ATOMIC: read-major pileup kernels even for sorted reads */

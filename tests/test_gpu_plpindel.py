@@ -300,3 +300,58 @@ def test_indel_columns_device_only_arrays(caller):
         assert nt_g == nt_w and len(got) == len(want) > 0
         for k in got.dtype.names:
             assert got[k].tobytes() == want[k].tobytes(), k
+
+
+def _chain_digest_script():
+    return r'''
+import sys, hashlib, json
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+import lofreq_amd as la
+import test_gpu_plpindel as T
+rng = np.random.default_rng(77)
+glen = 12000
+genome = rng.integers(0, 4, glen).astype(np.uint8)
+ref = "".join("ACGT"[c] for c in genome).encode()
+reads = T._random_indel_reads(rng, 6000, glen, genome)
+for r in reads:
+    r["ai"] = r["ad"] = None
+caller = la.SnvCaller(0)
+h = hashlib.sha256()
+rs = la.ReadSet(caller, reads, ref)
+rs.baq(extended=True, idaq=True)
+lb, ai, ad, fl = rs.fetch_tags(idaq=True)
+for a in (lb, ai, ad, fl):
+    h.update(np.ascontiguousarray(a).tobytes())
+cols, col_pos = rs.pileup_indels(0, glen)
+h.update(col_pos.tobytes())
+for k in ("coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun", "ref_base", "cons_indel"):
+    h.update(np.ascontiguousarray(getattr(cols, k)).tobytes())
+for sd in range(2):
+    S = cols.sides[sd]
+    for k in ("non_fw", "non_rv", "ne_off", "ne_q", "ne_mq", "ev_off", "ev_fw", "ev_rv", "rd_off", "rd_q", "rd_aq", "rd_mq", "rd_sq"):
+        h.update(np.ascontiguousarray(S[k]).tobytes())
+    h.update("|".join(cols.keys[sd]).encode())
+dt = rs.pileup_snv(0, glen)
+recs, _, st = caller.call_snvs(dt, la.VarcallConf())
+h.update(recs.tobytes()); h.update(dt.col_pos.tobytes())
+print(json.dumps({"digest": h.hexdigest(), "ncols": int(cols.ncols), "events": [len(cols.keys[0]), len(cols.keys[1])], "recs": len(recs)}))
+'''
+
+
+def test_host_loops_parallel_equals_serial(tmp_path):
+    """the host-side loops of the read-set steps (BAQ geometry + launch order, events from the CIGARs, column assembly,
+    event tables, SNV column prefix) split over threads from LFQ_HOST_PAR_MIN reads / positions on (200 000 by default:
+    no other test is that large).  The same 6 000-read chain with the threshold at 500 and at 'never': identical tags,
+    columns, event tables and calls."""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for par_min in ("500", "1000000000"):
+        env = dict(os.environ, LFQ_HOST_PAR_MIN=par_min)
+        r = subprocess.run([sys.executable, "-c", _chain_digest_script()], cwd=root, env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1], outs
+    assert outs[0]["ncols"] > 5000 and sum(outs[0]["events"]) > 1000
