@@ -90,6 +90,8 @@ struct LfqIndelColsOwned {
     } side[2];
 };
 
+#define LFQ_PIN_SLOTS 40
+
 struct lfq_ctx {
     int device;
     hipStream_t stream;
@@ -145,12 +147,13 @@ struct lfq_ctx {
     uint8_t *d_plp_in, *d_plp_out;   /* device-side pileup: inputs + counters, and the tracks handed out (grow-only:
                                       * hipMalloc / hipFree of gigabytes per region cost milliseconds each) */
     int64_t plp_in_bytes, plp_out_bytes;
-    uint8_t *d_tmp[3];               /* grow-only temporaries of the read-set steps: BAQ geometry, indel counters, gathers */
+    uint8_t *d_tmp[5];               /* grow-only temporaries: BAQ geometry, indel counters, gathers, and the event-read
+                                      * arrays + pseudo-column tracks of lfq_call_indels_batch */
     uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
     int64_t pin_bytes;
     uint8_t *h_pin2;                 /* pinned landing area of the indel pileup's per-position counters (grow-only) */
     int64_t pin2_bytes;
-    int64_t tmp_bytes[3];
+    int64_t tmp_bytes[5];
     int64_t plp_ne_cap;              /* capacity of d_plp_ne in int16 elements */
     LfqIndelColsOwned *plp_indel;
     int indel_host_arrays;           /* lfq_set_indel_arrays_on_host */
@@ -182,6 +185,7 @@ struct lfq_ctx {
     int kreg_hint, kreg_hint_indel;  /* screen-kernel variant for the next SNV / indel batch: from the last batch's K histogram */
     int cur_indel_mode;
     int sb_pending;                  /* strand-bias precomputes of this context not finished yet (under lm) */
+    struct { void *p; size_t cap; int used; } pin_pool[LFQ_PIN_SLOTS];   /* LfqPin: pinned host temporaries */
 };
 
 namespace {
@@ -220,6 +224,90 @@ int grow(T **ptr, int64_t *cap, int64_t need)
     *cap = n;
     return LFQ_OK;
 }
+
+/* Host temporaries a DMA reads or writes come from a grow-only pool of pinned blocks owned by the context, never from
+ * a std::vector.  Functionally pageable memory would do -- but the runtime registers a pageable range with the driver
+ * for the copy, and when a multi-megabyte vector later goes back to the OS (free -> munmap) the driver's MMU notifier
+ * evicts the process's hardware queues: the device sat idle for 20-30 ms before the next launch (measured on the
+ * read-set chain: the SNV call after lfq_readset_pileup_snv, 3 processes in 4 -- whenever glibc served the vectors
+ * from mmap; never with MALLOC_MMAP_THRESHOLD_ raised).  Blocks are handed back on scope exit and reused. */
+void *pin_acquire(lfq_ctx *c, size_t bytes, int *slot)
+{
+    int best = -1, empty = -1, smallest = -1;
+    for (int i = 0; i < LFQ_PIN_SLOTS; i++) {
+        auto &b = c->pin_pool[i];
+        if (b.used) {
+            continue;
+        }
+        if (!b.p) {
+            empty = (empty < 0) ? i : empty;
+        } else if (b.cap >= bytes) {
+            best = (best < 0 || b.cap < c->pin_pool[best].cap) ? i : best;
+        } else {
+            smallest = (smallest < 0 || b.cap < c->pin_pool[smallest].cap) ? i : smallest;
+        }
+    }
+    if (best < 0) {
+        best = (empty >= 0) ? empty : smallest;     /* no free block fits: a new one, in place of the smallest if full */
+        if (best < 0) {
+            return nullptr;
+        }
+        auto &b = c->pin_pool[best];
+        if (b.p) {
+            (void)hipHostFree(b.p);
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 16);
+        if (hipHostMalloc(&b.p, cap, hipHostMallocDefault) != hipSuccess) {
+            b.p = nullptr;
+            return nullptr;
+        }
+        b.cap = cap;
+    }
+    c->pin_pool[best].used = 1;
+    *slot = best;
+    return c->pin_pool[best].p;
+}
+
+template <typename T>
+struct LfqPin {
+    lfq_ctx *c;
+    T *p = nullptr;
+    size_t n = 0;
+    int slot = -1;
+    LfqPin(lfq_ctx *ctx, size_t count) : c(ctx), n(count)
+    {
+        p = (T *)pin_acquire(c, std::max<size_t>(count, 1) * sizeof(T), &slot);
+    }
+    LfqPin(lfq_ctx *ctx, size_t count, T v) : LfqPin(ctx, count)
+    {
+        if (p) {
+            std::fill(p, p + n, v);
+        }
+    }
+    LfqPin(const LfqPin &) = delete;
+    LfqPin &operator=(const LfqPin &) = delete;
+    ~LfqPin()
+    {
+        if (slot >= 0) {
+            c->pin_pool[slot].used = 0;
+        }
+    }
+    bool ok() const { return p != nullptr; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T &back() { return p[n - 1]; }
+};
+#define LFQ_PIN_OK(v)                                                                                                  \
+    do {                                                                                                               \
+        if (!(v).ok()) {                                                                                               \
+            return LFQ_ERR_NOMEM;                                                                                      \
+        }                                                                                                              \
+    } while (0)
 
 /* PROB_TO_PHREDQUAL_SAFE (utils.h:46) */
 int phred_safe(double p) { return (p <= 0.0) ? INT32_MAX : (int)(-10.0 * log10l(p)); }
@@ -510,10 +598,13 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_plp_out) (void)hipFree(c->d_plp_out);
         delete c->plp_indel;
         if (c->d_plp_ne) (void)hipFree(c->d_plp_ne);
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 5; i++) {
             if (c->d_tmp[i]) (void)hipFree(c->d_tmp[i]);
         }
         if (c->h_pin) (void)hipHostFree(c->h_pin);
+        for (int i = 0; i < LFQ_PIN_SLOTS; i++) {
+            if (c->pin_pool[i].p) (void)hipHostFree(c->pin_pool[i].p);
+        }
         if (c->h_pin2) (void)hipHostFree(c->h_pin2);
         if (c->d_detlim) (void)hipFree(c->d_detlim);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
@@ -635,6 +726,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     }
     LFQ_TRY_HIP(hipEventRecord(c->ev[0], st));
     if (ncols == 0) {
+        LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters,
+                                   (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
         return LFQ_OK;
     }
@@ -796,6 +889,18 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         /* DP4 of the columns that made it into the sparse output (lofreq_call.c:853-857) */
         LFQ_TRY(lfq_launch_strand_pvals(T, d_pvals, gcounters + LFQ_GC_PVALS, pvals_capacity, c->n_cu, jn));
     }
+    /* the batch's counters and the two ends of its CSR offsets travel to pinned memory as part of the batch:
+     * lfq_batch_finish then only waits for ev[3] (a synchronous hipMemcpy there takes the null stream, and the null
+     * stream's turn can sit behind unrelated work queued on the device) */
+    LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, jn));
+    {
+        uint64_t *h_ends = reinterpret_cast<uint64_t *>(c->h_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS);
+        if (c->cur_col_off) {
+            LFQ_TRY_HIP(hipMemcpyAsync(h_ends, c->cur_col_off, 8, hipMemcpyDeviceToHost, jn));
+            LFQ_TRY_HIP(hipMemcpyAsync(h_ends + 1, c->cur_col_off + c->cur_ncols, 8, hipMemcpyDeviceToHost, jn));
+        }
+    }
     LFQ_TRY_HIP(hipEventRecord(c->ev[3], jn));
     return LFQ_OK;
 }
@@ -844,15 +949,9 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
     /* wait for THIS batch (its last event), not for the stream: the streams are shared with the other contexts of
      * the device, and a batch of one of them may already be queued behind this one */
     LFQ_TRY_HIP(hipEventSynchronize(c->ev[3]));
-    LFQ_TRY_HIP(hipMemcpy(c->h_counters, c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t),
-                          hipMemcpyDeviceToHost));
-    uint64_t *h_ends = reinterpret_cast<uint64_t *>(c->h_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS);
-    h_ends[0] = h_ends[1] = 0;
-    if (c->cur_col_off && c->cur_ncols > 0) {       /* first and last CSR offset: the batch's observation count */
-        LFQ_TRY_HIP(hipMemcpy(h_ends, c->cur_col_off, 8, hipMemcpyDeviceToHost));
-        LFQ_TRY_HIP(hipMemcpy(h_ends + 1, c->cur_col_off + c->cur_ncols, 8, hipMemcpyDeviceToHost));
-    }
-    const int64_t batch_obs = (int64_t)(h_ends[1] - h_ends[0]);
+    /* counters + first and last CSR offset (the batch's observation count) were copied by the batch itself */
+    const uint64_t *h_ends = reinterpret_cast<const uint64_t *>(c->h_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS);
+    const int64_t batch_obs = (c->cur_col_off && c->cur_ncols > 0) ? (int64_t)(h_ends[1] - h_ends[0]) : 0;
     c->cur_count_read = batch_obs * c->cur_obs_bytes_x2 / 2 + c->cur_ncols * c->cur_col_bytes;
     c->cur_count_written = c->cur_ncols * (int64_t)(sizeof(lfq_col_counts) + 1);
     const int32_t *g = c->h_counters + LFQ_MAX_SEGMENTS * LFQ_NCOUNTERS;
@@ -1050,7 +1149,8 @@ int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, i
     lfq_batch_stats st;
     LFQ_TRY(lfq_batch_finish(c, &st));
     tp[1] = lfq_now_ms();
-    std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
+    LfqPin<lfq_col_pvals> h_pv(c, (size_t)st.n_pvals);
+    LFQ_PIN_OK(h_pv);
     if (st.n_pvals > 0) {
         LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals),
                               hipMemcpyDeviceToHost));
@@ -1123,15 +1223,17 @@ int lfq_call_indel_tests_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr,
     LFQ_TRY(lfq_indel_batch_device(c, conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream));
     lfq_batch_stats st;
     LFQ_TRY(lfq_batch_finish(c, &st));
-    std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
+    LfqPin<lfq_col_pvals> h_pv(c, (size_t)st.n_pvals);
+    LFQ_PIN_OK(h_pv);
     if (st.n_pvals > 0) {
         LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals),
                               hipMemcpyDeviceToHost));
     }
-    std::sort(h_pv.begin(), h_pv.end(), [](const lfq_col_pvals &a, const lfq_col_pvals &b) { return a.col < b.col; });
+    std::sort(h_pv.data(), h_pv.data() + h_pv.size(), [](const lfq_col_pvals &a, const lfq_col_pvals &b) { return a.col < b.col; });
     int64_t n_out = 0;
     int rc = LFQ_OK;
-    for (const lfq_col_pvals &r : h_pv) {
+    for (size_t pi = 0; pi < h_pv.size(); pi++) {
+        const lfq_col_pvals &r = h_pv[pi];
         const long double pv = lfq_pvalue_from_log(r.logp[0], r.status[0]);
         if (pv * (long long)r.bonf < conf->sig) {                 /* lofreq_call.c:326 / :384 */
             if (n_out >= calls_capacity) {
@@ -1272,10 +1374,6 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
     uint64_t dev_obs = 0;
     int16_t *d_rd = nullptr;                          /* event-read arrays of both sides, uploaded once */
     int64_t rd_n[2] = {0, 0};
-    struct RdGuard {
-        int16_t **p;
-        ~RdGuard() { if (*p) (void)hipFree(*p); }
-    } rd_guard{&d_rd};
     if (dev_pack) {
         LFQ_TRY_HIP(hipSetDevice(c->device));
         for (int sd = 0; sd < 2; sd++) {
@@ -1283,7 +1381,8 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
         }
         const int64_t tot = 4 * (rd_n[0] + rd_n[1]);
         if (tot > 0) {
-            LFQ_TRY_HIP(hipMalloc((void **)&d_rd, (size_t)tot * 2));
+            LFQ_TRY(grow(&c->d_tmp[3], &c->tmp_bytes[3], tot * 2));
+            d_rd = (int16_t *)c->d_tmp[3];
             int64_t o = 0;
             for (int sd = 0; sd < 2; sd++) {
                 const int16_t *src[4] = {b->side[sd].rd_q, b->side[sd].rd_aq, b->side[sd].rd_mq, b->side[sd].rd_sq};
@@ -1305,19 +1404,22 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
         tr.ncols = (int64_t)pk.meta.size();
         tr.max_col_obs = pk.max_obs;
         uint8_t *d_trk = nullptr;
-        struct TrkGuard {
-            uint8_t **p;
-            ~TrkGuard() { if (*p) (void)hipFree(*p); }
-        } trk_guard{&d_trk};
         if (dev_pack) {
             const int64_t nt_ = (int64_t)descs.size(), trk = (int64_t)((dev_obs + 15) / 16 * 16) + 32;
             auto al = [](int64_t x) { return (x + 255) / 256 * 256; };
             const int64_t o_desc = 0, o_off = o_desc + al(nt_ * (int64_t)sizeof(LfqIndelTestDesc)), o_ref = o_off + al((nt_ + 1) * 8),
                           o_trk = o_ref + al(nt_ + 16), total = o_trk + 5 * trk;
-            LFQ_TRY_HIP(hipMalloc((void **)&d_trk, (size_t)total));
-            LFQ_TRY_HIP(hipMemcpyAsync(d_trk + o_desc, descs.data(), (size_t)nt_ * sizeof(LfqIndelTestDesc), hipMemcpyHostToDevice, c->stream));
-            LFQ_TRY_HIP(hipMemcpyAsync(d_trk + o_off, pk.off.data(), (size_t)(nt_ + 1) * 8, hipMemcpyHostToDevice, c->stream));
-            LFQ_TRY_HIP(hipMemcpyAsync(d_trk + o_ref, pk.ref.data(), (size_t)nt_, hipMemcpyHostToDevice, c->stream));
+            LFQ_TRY(grow(&c->d_tmp[4], &c->tmp_bytes[4], total));
+            d_trk = c->d_tmp[4];
+            /* descriptors, offsets and reference bytes in one pinned block (laid out as on the device), one copy */
+            LfqPin<uint8_t> hp(c, (size_t)o_trk);
+            LFQ_PIN_OK(hp);
+            memcpy(hp.data() + o_desc, descs.data(), (size_t)nt_ * sizeof(LfqIndelTestDesc));
+            memcpy(hp.data() + o_off, pk.off.data(), (size_t)(nt_ + 1) * 8);
+            memcpy(hp.data() + o_ref, pk.ref.data(), (size_t)nt_);
+            LFQ_TRY_HIP(hipMemcpyAsync(d_trk, hp.data(), (size_t)o_trk, hipMemcpyHostToDevice, c->stream));
+            /* the pinned block goes back to the pool at the end of this scope: the copy must have read it by then */
+            LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
             LFQ_TRY_HIP(hipMemsetAsync(d_trk + o_trk, 0, (size_t)(5 * trk), c->stream));      /* the 16-byte tails are read */
             LfqIndelPackArgs A;
             memset(&A, 0, sizeof(A));
@@ -1491,13 +1593,38 @@ struct lfq_readset {
     bool has_lb, has_idaq, has_sqb, has_bi, has_bd;
     std::vector<uint8_t> fl;            /* per read: bit 0..3 = has BI / BD / ai / ad (host flags or from the device BAQ) */
     std::vector<int32_t> sq32;          /* source quality per read once computed */
+    /* lfq_readset_baq returns when its kernels are queued: what follows on the device is ordered by the stream, what the
+     * host needs (which reads got an ai / ad tag) arrives in pinned memory and is picked up by readset_baq_wait */
+    uint8_t *d_tagfl, *h_fl_pin;        /* [n] bit 0: ai, bit 1: ad written by the kernels; [n] merged flags on their way back */
+    hipEvent_t ev_baq;
+    bool baq_pending, baq_idaq;
     int32_t *d_pmax;                    /* position-sorted reads: running maximum of the end coordinates (lazily) */
     int pmax_state;                     /* 0 unknown, 1 sorted (d_pmax valid), 2 unsorted */
 };
 
+/* the host side of an lfq_readset_baq that is still running: merged tag flags (bit 0 BI, 1 BD, 2 ai, 3 ad) into rs->fl */
+static int readset_baq_wait(lfq_readset *rs)
+{
+    if (!rs || !rs->baq_pending) {
+        return LFQ_OK;
+    }
+    rs->baq_pending = false;
+    if (hipEventSynchronize(rs->ev_baq) != hipSuccess) {
+        return LFQ_ERR_HIP;
+    }
+    if (rs->baq_idaq && rs->h_fl_pin) {
+        memcpy(rs->fl.data(), rs->h_fl_pin, (size_t)rs->n);
+    }
+    return LFQ_OK;
+}
+
 void lfq_readset_destroy(lfq_readset *rs)
 {
     if (rs) {
+        (void)readset_baq_wait(rs);
+        if (rs->ev_baq) (void)hipEventDestroy(rs->ev_baq);
+        if (rs->h_fl_pin) (void)hipHostFree(rs->h_fl_pin);
+        if (rs->d_tagfl) (void)hipFree(rs->d_tagfl);
         if (rs->blob) (void)hipFree(rs->blob);
         if (rs->tag_blob) (void)hipFree(rs->tag_blob);
         if (rs->d_pmax) (void)hipFree(rs->d_pmax);
@@ -1606,9 +1733,9 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
             sorted = rs->pos[r] >= rs->pos[r - 1];
         }
         if (sorted && n > 0) {
-            std::vector<int32_t> pmax((size_t)n);
+            LfqPin<int32_t> pmax(c, (size_t)n);
             int32_t run = INT32_MIN;
-            for (int64_t r = 0; r < n; r++) {
+            for (int64_t r = 0; pmax.ok() && r < n; r++) {
                 const uint32_t *cg = rs->cigar + rs->cigar_off[r];
                 const int nc = (int)(rs->cigar_off[r + 1] - rs->cigar_off[r]);
                 int64_t e = rs->pos[r];
@@ -1621,7 +1748,7 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
                 run = std::max<int32_t>(run, (int32_t)std::min<int64_t>(e, INT32_MAX));
                 pmax[(size_t)r] = run;
             }
-            if (hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
+            if (pmax.ok() && hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
                 && hipMemcpy(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) {
                 rs->pmax_state = 1;
             } else if (rs->d_pmax) {
@@ -1645,6 +1772,7 @@ int lfq_readset_fetch_tags(lfq_ctx *c, lfq_readset *rs, uint8_t *lb_out, uint8_t
         return LFQ_ERR_INVALID;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY(readset_baq_wait(rs));
     if (lb_out) LFQ_TRY_HIP(hipMemcpyAsync(lb_out, rs->d_lb, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
     if (ai_out) LFQ_TRY_HIP(hipMemcpyAsync(ai_out, rs->d_ai, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
     if (ad_out) LFQ_TRY_HIP(hipMemcpyAsync(ad_out, rs->d_ad, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
@@ -1707,6 +1835,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY(readset_baq_wait(rs));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));   /* the pinned geometry / order buffers below may still be on their way out */
     double tmb[5] = {lfq_now_ms(), 0, 0, 0, 0};
     /* geometry of every read: alignment window and band width (bam_md_ext.c:312-380, :396-399) */
     /* (pinned, grow-only host buffers: 28 bytes per read are written once by the threads below and go out by DMA; a
@@ -1827,6 +1957,11 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         rs->d_lb = rs->tag_blob;
         rs->d_ai = want_idaq ? rs->tag_blob + each : nullptr;
         rs->d_ad = want_idaq ? rs->tag_blob + 2 * each : nullptr;
+        LFQ_TRY_HIP(hipEventCreateWithFlags(&rs->ev_baq, hipEventDisableTiming));
+        if (want_idaq) {
+            LFQ_TRY_HIP(hipMalloc((void **)&rs->d_tagfl, (size_t)n));
+            LFQ_TRY_HIP(hipHostMalloc((void **)&rs->h_fl_pin, (size_t)n, hipHostMallocDefault));
+        }
     } else if (want_idaq && !rs->d_ai) {
         return LFQ_ERR_INVALID;                 /* a second BAQ pass that suddenly wants ai / ad: make a new read set */
     }
@@ -1853,7 +1988,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     if (rc == LFQ_OK && (hipMemsetAsync(rs->d_lb, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
                          || (want_idaq && (hipMemsetAsync(rs->d_ai, '~', (size_t)n_bases, c->stream) != hipSuccess
                                            || hipMemsetAsync(rs->d_ad, '~', (size_t)n_bases, c->stream) != hipSuccess
-                                           || hipMemsetAsync(rs->d_fl, 0, (size_t)n, c->stream) != hipSuccess)))) {
+                                           || hipMemsetAsync(rs->d_tagfl, 0, (size_t)n, c->stream) != hipSuccess)))) {
         rc = LFQ_ERR_HIP;
     }
     tmb[2] = lfq_now_ms();
@@ -1909,7 +2044,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             A.terms = c->d_baq_terms;
             A.ai_out = rs->d_ai;
             A.ad_out = rs->d_ad;
-            A.tag_flags = rs->d_fl;
+            A.tag_flags = rs->d_tagfl;
         }
         d_scr = c->d_baq_scr;
         d_expect = c->d_baq_expect;
@@ -1996,34 +2131,33 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         }
     }
     tmb[3] = lfq_now_ms();
-    std::vector<uint8_t> dfl;
-    if (rc == LFQ_OK && want_idaq) {            /* which reads got an ai / ad tag (bam_md_ext.c:238-243): bits 2, 3 */
-        dfl.resize((size_t)n);
-        if (hipMemcpyAsync(dfl.data(), rs->d_fl, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+    /* which reads got an ai / ad tag (bam_md_ext.c:238-243) joins the resident flags as bits 2, 3 on the device; the
+     * merged byte travels to pinned memory for the host's event tables.  Nothing here waits for the kernels. */
+    if (rc == LFQ_OK && want_idaq) {
+        rc = lfq_launch_flag_merge(rs->d_fl, rs->d_tagfl, n, c->stream);
+        if (rc == LFQ_OK && hipMemcpyAsync(rs->h_fl_pin, rs->d_fl, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             rc = LFQ_ERR_HIP;
         }
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
+    if (rc == LFQ_OK && hipEventRecord(rs->ev_baq, c->stream) != hipSuccess) {
         rc = LFQ_ERR_HIP;
     }
+    if (rc != LFQ_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    rs->baq_pending = true;
+    rs->baq_idaq = want_idaq;
     tmb[4] = lfq_now_ms();
     if (lfq_timing_on) {
-        fprintf(stderr, "[lfq timing] baq: geometry %.1f  order + allocations + uploads %.1f  scratch + launches %.1f  kernels (sync) %.1f ms\n",
-                tmb[1] - tmb[0], tmb[2] - tmb[1], tmb[3] - tmb[2], tmb[4] - tmb[3]);
+        (void)hipStreamSynchronize(c->stream);
+        fprintf(stderr, "[lfq timing] baq: geometry %.1f  order + allocations + uploads %.1f  scratch + launches %.1f  kernels (sync, timing only) %.1f ms\n",
+                tmb[1] - tmb[0], tmb[2] - tmb[1], tmb[3] - tmb[2], lfq_now_ms() - tmb[3]);
     }
-    if (rc == LFQ_OK) {
-        rs->has_lb = true;
-        if (want_idaq) {
-            rs->has_idaq = true;
-            rs->h_ai = rs->h_ad = nullptr;      /* superseded by the device result */
-            for (int64_t r = 0; r < n; r++) {
-                rs->fl[(size_t)r] = (uint8_t)((rs->fl[(size_t)r] & 3u) | ((dfl[(size_t)r] & 3u) << 2));
-            }
-            /* the resident flags follow the host layout (bit 0 BI, 1 BD, 2 ai, 3 ad) again */
-            if (hipMemcpy(rs->d_fl, rs->fl.data(), (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
-                rc = LFQ_ERR_HIP;
-            }
-        }
+    rs->has_lb = true;
+    if (want_idaq) {
+        rs->has_idaq = true;
+        rs->h_ai = rs->h_ad = nullptr;          /* superseded by the device result */
     }
     return rc;
 }
@@ -2088,7 +2222,10 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     const bool sorted = A.pmax_end != nullptr;
     LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, c->stream) : lfq_launch_pileup_count(A, c->stream));
     /* prefix sums on the host: 8 bytes per reference position of the region, once per region */
-    std::vector<int32_t> cov((size_t)width), nb((size_t)width), cidx((size_t)width, -1);
+    LfqPin<int32_t> cov(c, (size_t)width), nb(c, (size_t)width), cidx(c, (size_t)width, -1);
+    LFQ_PIN_OK(cov);
+    LFQ_PIN_OK(nb);
+    LFQ_PIN_OK(cidx);
     LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
     LFQ_TRY_HIP(hipMemcpyAsync(nb.data(), A.nb, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
@@ -2115,9 +2252,14 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
         part_obs[q + 1] += part_obs[q];
         max_obs = std::max(max_obs, part_max[q]);
     }
-    std::vector<uint64_t> off((size_t)part_cols[parts] + 1, 0);
-    std::vector<int32_t> h_cov((size_t)part_cols[parts]), h_nb((size_t)part_cols[parts]);
-    std::vector<uint8_t> h_ref((size_t)part_cols[parts]);
+    LfqPin<uint64_t> off(c, (size_t)part_cols[parts] + 1);
+    LfqPin<int32_t> h_cov(c, (size_t)part_cols[parts]), h_nb(c, (size_t)part_cols[parts]);
+    LfqPin<uint8_t> h_ref(c, (size_t)part_cols[parts]);
+    LFQ_PIN_OK(off);
+    LFQ_PIN_OK(h_cov);
+    LFQ_PIN_OK(h_nb);
+    LFQ_PIN_OK(h_ref);
+    off[0] = 0;
     lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
         size_t ci = (size_t)part_cols[part];
         uint64_t run = (uint64_t)part_obs[part];
@@ -2364,13 +2506,17 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         }
         tm[2] = lfq_now_ms();
         /* 3. columns = covered positions; quality arrays of the reads without an event at the event positions */
-        std::vector<int64_t> pos_off[2];
+        LfqPin<int64_t> pos_off_ins(c, (size_t)width), pos_off_del(c, (size_t)width);      /* DMA sources: pinned */
+        if (!pos_off_ins.ok() || !pos_off_del.ok()) {
+            rc = LFQ_ERR_NOMEM;
+        }
+        int64_t *const pos_off[2] = {pos_off_ins.data(), pos_off_del.data()};
         std::vector<int32_t> col_of;                /* column index of an event position */
         int64_t ne_total[2] = {0, 0};
         const bool host_arrays = c->indel_host_arrays || !have_qsum;   /* device-only needs the sums from the kernel */
         if (rc == LFQ_OK) {
-            pos_off[0].assign((size_t)width, -1);
-            pos_off[1].assign((size_t)width, -1);
+            std::fill(pos_off[0], pos_off[0] + width, (int64_t)-1);
+            std::fill(pos_off[1], pos_off[1] + width, (int64_t)-1);
             col_of.assign((size_t)width, -1);
             std::vector<uint8_t> has_ev((size_t)width, 0);
             for (const Ev &e : evs) {
@@ -2477,7 +2623,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             d_ne = c->d_plp_ne;
             if (rc == LFQ_OK && ne_all > 0) {
                 for (int sd = 0; sd < 2; sd++) {
-                    up(o_off + sd * al(width * 8), pos_off[sd].data(), width * 8);
+                    up(o_off + sd * al(width * 8), pos_off[sd], width * 8);
                     A.ne_off[sd] = (const int64_t *)(d + o_off + sd * al(width * 8));
                     A.cursor[sd] = (int32_t *)(d + o_cur + sd * al(width * 4));
                 }
@@ -2505,7 +2651,8 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         tm[3] = lfq_now_ms();
         /* ai / ad of the event reads when lfq_readset_baq left them on the device */
         if (rc == LFQ_OK && rs->has_idaq && !evs.empty()) {
-            std::vector<int64_t> idx(evs.size());
+            LfqPin<int64_t> idx(c, evs.size());
+            LFQ_PIN_OK(idx);
             for (size_t i = 0; i < evs.size(); i++) {
                 idx[i] = rd->seq_off[evs[i].read] + evs[i].qpos;
             }
@@ -2532,6 +2679,9 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         c->plp_ne_total[0] = ne_total[0];
         c->plp_ne_total[1] = ne_total[1];
         tm[4] = lfq_now_ms();
+        if (readset_baq_wait(rs) != LFQ_OK) {       /* the ai / ad bits of rs->fl (t_fl) are read from here on */
+            return LFQ_ERR_HIP;
+        }
         /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
          * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */
         /* Columns with events are few and independent of one another: the event list is cut at position boundaries into a
@@ -2806,7 +2956,8 @@ int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device
     LFQ_TRY(rc);
     lfq_batch_stats st;
     LFQ_TRY(lfq_batch_finish(c, &st));
-    std::vector<lfq_col_pvals> h_pv((size_t)st.n_pvals);
+    LfqPin<lfq_col_pvals> h_pv(c, (size_t)st.n_pvals);
+    LFQ_PIN_OK(h_pv);
     if (st.n_pvals > 0) {
         LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals), hipMemcpyDeviceToHost));
     }
@@ -2818,7 +2969,8 @@ int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device
     }
     const int bonf = 1;
     const float alpha = 0.01f;
-    for (const lfq_col_pvals &p : h_pv) {
+    for (size_t pi = 0; pi < h_pv.size(); pi++) {
+        const lfq_col_pvals &p = h_pv[pi];
         if (p.col < 0 || p.col >= ncols || p.status[0] == LFQ_PV_NONE) {
             continue;
         }
@@ -2857,13 +3009,14 @@ int lfq_uniq_binom_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device,
     LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));             /* reused as int32[4] per column */
     int32_t *d_nt = reinterpret_cast<int32_t *>(c->d_counts);
     LFQ_TRY(lfq_launch_ntcount(T, d_nt, c->stream));
-    std::vector<int32_t> h_nt((size_t)ncols * 4);
-    std::vector<uint64_t> h_off((size_t)ncols + 1);
-    std::vector<int32_t> h_cov;
+    LfqPin<int32_t> h_nt(c, (size_t)ncols * 4), h_cov(c, dev.coverage_plp ? (size_t)ncols : 0);
+    LfqPin<uint64_t> h_off(c, (size_t)ncols + 1);
+    LFQ_PIN_OK(h_nt);
+    LFQ_PIN_OK(h_cov);
+    LFQ_PIN_OK(h_off);
     LFQ_TRY_HIP(hipMemcpyAsync(h_nt.data(), d_nt, (size_t)ncols * 16, hipMemcpyDeviceToHost, c->stream));
     LFQ_TRY_HIP(hipMemcpyAsync(h_off.data(), dev.col_off, ((size_t)ncols + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     if (dev.coverage_plp) {
-        h_cov.resize((size_t)ncols);
         LFQ_TRY_HIP(hipMemcpyAsync(h_cov.data(), dev.coverage_plp, (size_t)ncols * 4, hipMemcpyDeviceToHost, c->stream));
     }
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
@@ -2906,18 +3059,14 @@ int lfq_pileup_skip_snv_columns(lfq_ctx *c, const uint8_t *skip, int64_t ncols)
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
-    std::vector<int32_t> nb((size_t)ncols);
-    LFQ_TRY_HIP(hipMemcpy(nb.data(), c->d_plp_nb, (size_t)ncols * 4, hipMemcpyDeviceToHost));
-    bool any = false;
-    for (int64_t i = 0; i < ncols; i++) {
-        if (skip[i]) {
-            nb[(size_t)i] = 0;
-            any = true;
-        }
-    }
-    if (any) {
-        LFQ_TRY_HIP(hipMemcpy(c->d_plp_nb, nb.data(), (size_t)ncols * 4, hipMemcpyHostToDevice));
-    }
+    /* the skip bytes go through a pinned block and are applied on the device, in stream order before the batch */
+    LfqPin<uint8_t> h(c, (size_t)ncols);
+    LFQ_PIN_OK(h);
+    memcpy(h.data(), skip, (size_t)ncols);
+    LFQ_TRY(grow(&c->d_tmp[2], &c->tmp_bytes[2], ncols));
+    LFQ_TRY_HIP(hipMemcpyAsync(c->d_tmp[2], h.data(), (size_t)ncols, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY(lfq_launch_skip_columns(c->d_plp_nb, c->d_tmp[2], ncols, c->stream));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
     return LFQ_OK;
 }
 
@@ -2971,8 +3120,11 @@ int lfq_readset_source_qual(lfq_ctx *c, lfq_readset *rs, int def_nm_q, int min_b
         return LFQ_ERR_NOMEM;
     }
     int rc = LFQ_OK;
-    std::vector<double> prob((size_t)n);
-    std::vector<uint8_t> st((size_t)n);
+    LfqPin<double> prob(c, (size_t)n);
+    LfqPin<uint8_t> st(c, (size_t)n);
+    if (!prob.ok() || !st.ok()) {
+        rc = LFQ_ERR_NOMEM;
+    }
     if (ign && hipMemcpyAsync(d + o_ign, ign, (size_t)rd->ref_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
         rc = LFQ_ERR_HIP;
     }
@@ -3011,7 +3163,8 @@ int lfq_readset_source_qual(lfq_ctx *c, lfq_readset *rs, int def_nm_q, int min_b
     }
     const int perfect = (int)(-10.0L * log10l(LDBL_MIN));       /* PROB_TO_PHREDQUAL(LDBL_MIN) = 49314, plp.c:521 */
     rs->sq32.resize((size_t)n);
-    std::vector<uint8_t> sqb((size_t)n);
+    LfqPin<uint8_t> sqb(c, (size_t)n);
+    LFQ_PIN_OK(sqb);
     for (int64_t r = 0; r < n; r++) {
         int q;
         if (st[(size_t)r] == LFQ_SRCQ_NA) {
@@ -3116,7 +3269,8 @@ int shard_allgather_bytes(lfq_ctx *c, void *comm, int world, int rank, const voi
     if (ag(d_send, d_recv, (size_t)padded, /* ncclUint8 */ 1, comm, c->stream) != 0) {
         return LFQ_ERR_HIP;
     }
-    std::vector<uint8_t> h((size_t)padded * world);
+    LfqPin<uint8_t> h(c, (size_t)padded * world);
+    LFQ_PIN_OK(h);
     LFQ_TRY_HIP(hipMemcpyAsync(h.data(), d_recv, (size_t)padded * world, hipMemcpyDeviceToHost, c->stream));
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
     for (int r = 0; r < world; r++) {

@@ -593,3 +593,40 @@ int lfq_launch_indel_pack(const LfqIndelPackArgs &a, void *stream)
     hipLaunchKernelGGL(lfq_indel_pack_kernel, dim3((unsigned)((a.n_tests + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
+
+/* per read: the resident tag flags (bit 0 BI, 1 BD) take the ai / ad bits the BAQ kernels left in `tag` (bit 0 ai, 1 ad) */
+__global__ __launch_bounds__(256) void lfq_flag_merge_kernel(uint8_t *fl, const uint8_t *tag, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        fl[i] = (uint8_t)((fl[i] & 3u) | ((tag[i] & 3u) << 2));
+    }
+}
+
+int lfq_launch_flag_merge(uint8_t *fl, const uint8_t *tag, int64_t n, void *stream)
+{
+    if (n <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_flag_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fl, tag, n);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+/* columns the caller takes out of the SNV pass (lofreq_call.c:1049-1053: a column whose consensus is an indel is
+ * not tested for substitutions): their base count goes to 0, which is what the count kernel's depth test reads */
+__global__ __launch_bounds__(256) void lfq_skip_columns_kernel(int32_t *nb, const uint8_t *skip, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && skip[i]) {
+        nb[i] = 0;
+    }
+}
+
+int lfq_launch_skip_columns(int32_t *nb, const uint8_t *skip, int64_t n, void *stream)
+{
+    if (n <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_skip_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nb, skip, n);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
