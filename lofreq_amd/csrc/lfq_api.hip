@@ -88,6 +88,18 @@ struct LfqIndelColsOwned {
         std::vector<int16_t> ne_q, ne_mq, rd_q, rd_aq, rd_mq, rd_sq;
         std::vector<char> key_chars;
     } side[2];
+    void reset()
+    {
+        memset(&cols, 0, sizeof(cols));
+        ref_base.clear(); cons_indel.clear();
+        cov.clear(); tails.clear(); non_indels.clear(); n_ins.clear(); n_dels.clear(); hrun.clear();
+        for (Side &s : side) {
+            s.non_fw.clear(); s.non_rv.clear(); s.ev_fw.clear(); s.ev_rv.clear();
+            s.ne_off.clear(); s.ev_off.clear(); s.key_off.clear(); s.rd_off.clear();
+            s.ne_q.clear(); s.ne_mq.clear(); s.rd_q.clear(); s.rd_aq.clear(); s.rd_mq.clear(); s.rd_sq.clear();
+            s.key_chars.clear();
+        }
+    }
 };
 
 #define LFQ_PIN_SLOTS 40
@@ -149,6 +161,7 @@ struct lfq_ctx {
     int64_t plp_in_bytes, plp_out_bytes;
     uint8_t *d_tmp[5];               /* grow-only temporaries: BAQ geometry, indel counters, gathers, and the event-read
                                       * arrays + pseudo-column tracks of lfq_call_indels_batch */
+    hipStream_t up_stream;           /* lfq_readset_create's uploads (created on first use) */
     uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
     int64_t pin_bytes;
     uint8_t *h_pin2;                 /* pinned landing area of the indel pileup's per-position counters (grow-only) */
@@ -601,6 +614,7 @@ void lfq_destroy(lfq_ctx *c)
         for (int i = 0; i < 5; i++) {
             if (c->d_tmp[i]) (void)hipFree(c->d_tmp[i]);
         }
+        if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         for (int i = 0; i < LFQ_PIN_SLOTS; i++) {
             if (c->pin_pool[i].p) (void)hipHostFree(c->pin_pool[i].p);
@@ -1600,7 +1614,27 @@ struct lfq_readset {
     bool baq_pending, baq_idaq;
     int32_t *d_pmax;                    /* position-sorted reads: running maximum of the end coordinates (lazily) */
     int pmax_state;                     /* 0 unknown, 1 sorted (d_pmax valid), 2 unsorted */
+    /* lfq_readset_create returns while the reads are still crossing PCIe (a helper thread feeds the copies of the caller's
+     * pageable arrays to the upload stream): host-only work of the next step -- the BAQ geometry -- runs meanwhile, and
+     * every step calls readset_upload_wait before its first device operation on the read set */
+    std::thread *up_thread;
+    int up_rc;
+    LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
 };
+
+static int readset_upload_wait(lfq_readset *rs)
+{
+    if (rs && rs->up_thread) {
+        rs->up_thread->join();
+        delete rs->up_thread;
+        rs->up_thread = nullptr;
+    }
+    if (rs && rs->up_fl) {
+        delete rs->up_fl;
+        rs->up_fl = nullptr;
+    }
+    return rs ? rs->up_rc : LFQ_OK;
+}
 
 /* the host side of an lfq_readset_baq that is still running: merged tag flags (bit 0 BI, 1 BD, 2 ai, 3 ad) into rs->fl */
 static int readset_baq_wait(lfq_readset *rs)
@@ -1621,6 +1655,7 @@ static int readset_baq_wait(lfq_readset *rs)
 void lfq_readset_destroy(lfq_readset *rs)
 {
     if (rs) {
+        (void)readset_upload_wait(rs);
         (void)readset_baq_wait(rs);
         if (rs->ev_baq) (void)hipEventDestroy(rs->ev_baq);
         if (rs->h_fl_pin) (void)hipHostFree(rs->h_fl_pin);
@@ -1656,6 +1691,9 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->tag_blob = nullptr;
     rs->d_pmax = nullptr;
     rs->pmax_state = 0;
+    rs->up_thread = nullptr;
+    rs->up_rc = LFQ_OK;
+    rs->up_fl = nullptr;
     rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
     const int64_t n = rs->n, nb = rs->n_bases;
     rs->fl.assign((size_t)std::max<int64_t>(n, 1), 0);
@@ -1686,36 +1724,58 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->d_qual = d + o_qual; rs->d_ref = d + o_ref; rs->d_mapq = d + o_mapq; rs->d_rev = d + o_rev; rs->d_bi = d + o_bi;
     rs->d_bd = d + o_bd; rs->d_lb = rd->baq ? d + o_lb : nullptr; rs->d_ai = nullptr; rs->d_ad = nullptr; rs->d_fl = d + o_fl;
     rs->d_sqb = d + o_sqb;
-    int rc = LFQ_OK;
-    auto up = [&](uint8_t *dst, const void *src, int64_t bytes) {
-        if (rc == LFQ_OK && src && bytes > 0 && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-            rc = LFQ_ERR_HIP;
+    if (!c->up_stream && hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) {
+        c->up_stream = nullptr;
+        lfq_readset_destroy(rs);
+        return LFQ_ERR_HIP;
+    }
+    rs->up_fl = new LfqPin<uint8_t>(c, (size_t)n);       /* not from rs->fl: see LfqPin */
+    if (!rs->up_fl->ok()) {
+        lfq_readset_destroy(rs);
+        return LFQ_ERR_NOMEM;
+    }
+    memcpy(rs->up_fl->data(), rs->fl.data(), (size_t)n);
+    struct Copy { uint8_t *dst; const void *src; int64_t bytes; };
+    const Copy copies[] = {{rs->d_pos, rd->pos, n * 4}, {rs->d_coff, rd->cigar_off, (n + 1) * 8}, {rs->d_soff, rd->seq_off, (n + 1) * 8},
+                           {rs->d_cig, rd->cigar, rs->n_cig * 4}, {rs->d_seq, rd->seq, nb}, {rs->d_qual, rd->qual, nb},
+                           {rs->d_ref, rd->ref, rs->ref_len}, {rs->d_mapq, rd->mapq, n}, {rs->d_rev, rd->reverse, n},
+                           {rs->d_bi, rs->h_bi, nb}, {rs->d_bd, rs->h_bd, nb}, {rs->d_lb, rd->baq, nb}, {rs->d_sqb, rd->sq, n},
+                           {rs->d_fl, rs->up_fl->data(), n}};
+    std::vector<Copy> todo;
+    int64_t up_bytes = 0;
+    for (const Copy &x : copies) {
+        if (x.src && x.bytes > 0) {
+            todo.push_back(x);
+            up_bytes += x.bytes;
         }
-    };
-    up(rs->d_pos, rd->pos, n * 4);
-    up(rs->d_coff, rd->cigar_off, (n + 1) * 8);
-    up(rs->d_soff, rd->seq_off, (n + 1) * 8);
-    up(rs->d_cig, rd->cigar, rs->n_cig * 4);
-    up(rs->d_seq, rd->seq, nb);
-    up(rs->d_qual, rd->qual, nb);
-    up(rs->d_ref, rd->ref, rs->ref_len);
-    up(rs->d_mapq, rd->mapq, n);
-    up(rs->d_rev, rd->reverse, n);
-    up(rs->d_bi, rs->h_bi, nb);
-    up(rs->d_bd, rs->h_bd, nb);
-    up(rs->d_lb, rd->baq, nb);
-    up(rs->d_sqb, rd->sq, n);
-    up(rs->d_fl, rs->fl.data(), n);
+    }
     rs->has_bi = rs->h_bi != nullptr;
     rs->has_bd = rs->h_bd != nullptr;
     rs->has_lb = rd->baq != nullptr;
     rs->has_sqb = rd->sq != nullptr;
-    if (rc == LFQ_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
-        rc = LFQ_ERR_HIP;
-    }
-    if (rc != LFQ_OK) {
-        lfq_readset_destroy(rs);
-        return rc;
+    const int device = c->device;
+    hipStream_t ups = c->up_stream;
+    auto run = [rs, todo, device, ups]() {
+        int rc = hipSetDevice(device) == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+        for (const Copy &x : todo) {
+            if (rc == LFQ_OK && hipMemcpyAsync(x.dst, x.src, (size_t)x.bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        }
+        if (hipStreamSynchronize(ups) != hipSuccess && rc == LFQ_OK) {
+            rc = LFQ_ERR_HIP;
+        }
+        rs->up_rc = rc;
+    };
+    if (up_bytes >= ((int64_t)8 << 20) && !lfq_knobs().sync_upload) {
+        rs->up_thread = new std::thread(run);           /* readset_upload_wait joins it */
+    } else {
+        run();
+        const int rc = readset_upload_wait(rs);
+        if (rc != LFQ_OK) {
+            lfq_readset_destroy(rs);
+            return rc;
+        }
     }
     *out = rs;
     return LFQ_OK;
@@ -1728,32 +1788,59 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
     if (rs->pmax_state == 0) {
         rs->pmax_state = 2;
         const int64_t n = rs->n;
-        bool sorted = !lfq_knobs().pileup_atomic;
-        for (int64_t r = 1; sorted && r < n; r++) {
-            sorted = rs->pos[r] >= rs->pos[r - 1];
-        }
-        if (sorted && n > 0) {
-            LfqPin<int32_t> pmax(c, (size_t)n);
-            int32_t run = INT32_MIN;
-            for (int64_t r = 0; pmax.ok() && r < n; r++) {
-                const uint32_t *cg = rs->cigar + rs->cigar_off[r];
-                const int nc = (int)(rs->cigar_off[r + 1] - rs->cigar_off[r]);
-                int64_t e = rs->pos[r];
-                for (int k = 0; k < nc; k++) {
-                    const int op = cg[k] & 0xf;
-                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) {
-                        e += cg[k] >> 4;
+        LfqPin<int32_t> pmax(c, (size_t)std::max<int64_t>(n, 1));
+        if (!lfq_knobs().pileup_atomic && n > 0 && pmax.ok()) {
+            /* two passes split over a few threads: end coordinate and running maximum inside a part (and whether the
+             * part is sorted), then the maximum of the parts before it */
+            int32_t part_max[8];
+            bool part_sorted[8];
+            int parts = 1;
+            lfq_for_reads(n, [&](int64_t r0, int64_t r1, int part) {
+                int32_t run = INT32_MIN;
+                bool sorted = true;
+                for (int64_t r = r0; r < r1; r++) {
+                    const uint32_t *cg = rs->cigar + rs->cigar_off[r];
+                    const int nc = (int)(rs->cigar_off[r + 1] - rs->cigar_off[r]);
+                    int64_t e = rs->pos[r];
+                    for (int k = 0; k < nc; k++) {
+                        const int op = cg[k] & 0xf;
+                        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) {
+                            e += cg[k] >> 4;
+                        }
                     }
+                    run = std::max<int32_t>(run, (int32_t)std::min<int64_t>(e, INT32_MAX));
+                    pmax[(size_t)r] = run;
+                    sorted = sorted && (r == 0 || rs->pos[r] >= rs->pos[r - 1]);     /* r0 - 1 belongs to the part before */
                 }
-                run = std::max<int32_t>(run, (int32_t)std::min<int64_t>(e, INT32_MAX));
-                pmax[(size_t)r] = run;
+                part_max[part] = run;
+                part_sorted[part] = sorted;
+            }, &parts);
+            bool sorted = true;
+            for (int q = 0; q < parts; q++) {
+                sorted = sorted && part_sorted[q];
             }
-            if (pmax.ok() && hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
-                && hipMemcpy(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) {
-                rs->pmax_state = 1;
-            } else if (rs->d_pmax) {
-                (void)hipFree(rs->d_pmax);
-                rs->d_pmax = nullptr;
+            if (sorted && parts > 1) {
+                int32_t before[8];
+                before[0] = INT32_MIN;
+                for (int q = 1; q < parts; q++) {
+                    before[q] = std::max(before[q - 1], part_max[q - 1]);
+                }
+                lfq_for_reads(n, [&](int64_t r0, int64_t r1, int part) {
+                    const int32_t m = before[part];
+                    for (int64_t r = r0; r < r1 && pmax[(size_t)r] < m; r++) {     /* the running maximum only grows */
+                        pmax[(size_t)r] = m;
+                    }
+                });
+            }
+            if (sorted) {
+                if (hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
+                    && hipMemcpyAsync(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                    && hipStreamSynchronize(c->stream) == hipSuccess) {
+                    rs->pmax_state = 1;
+                } else if (rs->d_pmax) {
+                    (void)hipFree(rs->d_pmax);
+                    rs->d_pmax = nullptr;
+                }
             }
         }
     }
@@ -1772,6 +1859,7 @@ int lfq_readset_fetch_tags(lfq_ctx *c, lfq_readset *rs, uint8_t *lb_out, uint8_t
         return LFQ_ERR_INVALID;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY(readset_upload_wait(rs));
     LFQ_TRY(readset_baq_wait(rs));
     if (lb_out) LFQ_TRY_HIP(hipMemcpyAsync(lb_out, rs->d_lb, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
     if (ai_out) LFQ_TRY_HIP(hipMemcpyAsync(ai_out, rs->d_ai, (size_t)rs->n_bases, hipMemcpyDeviceToHost, c->stream));
@@ -1950,6 +2038,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             }
         }
     });
+    LFQ_TRY(readset_upload_wait(rs));           /* the geometry above ran while the reads were still on their way */
     const int64_t n_bases = rs->n_bases;
     if (!rs->tag_blob) {                        /* lb (+ ai, ad): resident from here on */
         const int64_t each = (n_bases + 16 + 255) / 256 * 256;
@@ -2191,6 +2280,7 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY(readset_upload_wait(rs));
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
     /* per-position counters (kept until the next call) */
     const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
@@ -2350,8 +2440,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         return LFQ_ERR_INVALID;
     }
     const lfq_readset *rd = rs;
-    delete c->plp_indel;
-    c->plp_indel = new LfqIndelColsOwned();
+    if (c->plp_indel) {
+        c->plp_indel->reset();              /* keeps the capacity: see LfqPin for what freeing a DMA target costs */
+    } else {
+        c->plp_indel = new LfqIndelColsOwned();
+    }
     c->plp_ne_total[0] = c->plp_ne_total[1] = 0;
     LfqIndelColsOwned &O = *c->plp_indel;
     memset(&O.cols, 0, sizeof(O.cols));
@@ -2438,6 +2531,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     } else {
         /* 2. dense counters on the device */
         LFQ_TRY_HIP(hipSetDevice(c->device));
+        LFQ_TRY(readset_upload_wait(rs));
         auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
         const int64_t o_cnt = 0, o_cur = o_cnt + 9 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
                       total = o_off + 2 * al(width * 8);
@@ -3106,6 +3200,7 @@ int lfq_readset_source_qual(lfq_ctx *c, lfq_readset *rs, int def_nm_q, int min_b
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY(readset_upload_wait(rs));
     int64_t max_ops = 0;                                /* bound of K: one operation per base or CIGAR element */
     for (int64_t r = 0; r < n; r++) {
         max_ops = std::max<int64_t>(max_ops, (rd->seq_off[r + 1] - rd->seq_off[r]) + (rd->cigar_off[r + 1] - rd->cigar_off[r]));
