@@ -1783,7 +1783,7 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
 
 /* position-sorted reads (what mpileup requires) take the column-major pileup kernels, which find the reads that can
  * overlap a position by binary search: they need the running maximum of the end coordinates.  -> device array or null */
-static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
+static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs, hipStream_t st)
 {
     if (rs->pmax_state == 0) {
         rs->pmax_state = 2;
@@ -1834,8 +1834,8 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs)
             }
             if (sorted) {
                 if (hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
-                    && hipMemcpyAsync(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess
-                    && hipStreamSynchronize(c->stream) == hipSuccess) {
+                    && hipMemcpyAsync(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) == hipSuccess
+                    && hipStreamSynchronize(st) == hipSuccess) {
                     rs->pmax_state = 1;
                 } else if (rs->d_pmax) {
                     (void)hipFree(rs->d_pmax);
@@ -2308,7 +2308,7 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.nb = (int32_t *)(d + o_nb);
     A.cursor = (int32_t *)(d + o_cur);
     /* position-sorted reads (the normal case): the column-major kernels; otherwise one thread per read + atomics */
-    A.pmax_end = readset_pmax(c, rs);
+    A.pmax_end = readset_pmax(c, rs, c->stream);
     const bool sorted = A.pmax_end != nullptr;
     LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, c->stream) : lfq_launch_pileup_count(A, c->stream));
     /* prefix sums on the host: 8 bytes per reference position of the region, once per region */
@@ -2532,6 +2532,10 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         /* 2. dense counters on the device */
         LFQ_TRY_HIP(hipSetDevice(c->device));
         LFQ_TRY(readset_upload_wait(rs));
+        /* Steps 2 and 3 read nothing lfq_readset_baq writes (of the flag bytes only the BI / BD bits, which its merge
+         * kernel leaves as they are): while its kernels are still running they go to another stream and run beside them --
+         * the BAQ kernels hold one wavefront per SIMD and 416 of its 512 registers, these kernels need 40. */
+        hipStream_t ps = (rs->baq_pending && c->dps && !lfq_knobs().single_stream) ? c->dps : c->stream;
         auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
         const int64_t o_cnt = 0, o_cur = o_cnt + 9 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
                       total = o_off + 2 * al(width * 8);
@@ -2541,11 +2545,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         int rc = LFQ_OK;
         auto up = [&](int64_t off, const void *src, int64_t bytes) {
             if (rc == LFQ_OK && src && bytes > 0
-                && hipMemcpyAsync(d + off, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                && hipMemcpyAsync(d + off, src, (size_t)bytes, hipMemcpyHostToDevice, ps) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
         };
-        if (rc == LFQ_OK && hipMemsetAsync(d + o_cnt, 0, (size_t)(o_off - o_cnt), c->stream) != hipSuccess) {
+        if (rc == LFQ_OK && hipMemsetAsync(d + o_cnt, 0, (size_t)(o_off - o_cnt), ps) != hipSuccess) {
             rc = LFQ_ERR_HIP;
         }
         LfqPlpIndelArgs A;
@@ -2586,16 +2590,16 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
         }
         if (rc == LFQ_OK) {
-            A.pmax_end = readset_pmax(c, rs);
-            rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 0, c->stream) : lfq_launch_plp_indel(A, 0, c->stream);
+            A.pmax_end = readset_pmax(c, rs, ps);
+            rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 0, ps) : lfq_launch_plp_indel(A, 0, ps);
         }
         const bool have_qsum = A.pmax_end != nullptr;       /* the column-major kernel sums the qualities itself */
         for (int i = 0; i < (have_qsum ? 9 : 7) && rc == LFQ_OK; i++) {
-            if (hipMemcpyAsync(h[i], *cnt[i], (size_t)width * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+            if (hipMemcpyAsync(h[i], *cnt[i], (size_t)width * 4, hipMemcpyDeviceToHost, ps) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
         }
-        if (rc == LFQ_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+        if (rc == LFQ_OK && hipStreamSynchronize(ps) != hipSuccess) {
             rc = LFQ_ERR_HIP;
         }
         tm[2] = lfq_now_ms();
@@ -2726,18 +2730,18 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 A.ne_q[1] = d_ne + 2 * ne_total[0];
                 A.ne_mq[1] = d_ne + 2 * ne_total[0] + ne_total[1];
                 if (rc == LFQ_OK) {
-                    rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 1, c->stream) : lfq_launch_plp_indel(A, 1, c->stream);
+                    rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 1, ps) : lfq_launch_plp_indel(A, 1, ps);
                 }
                 for (int sd = 0; sd < 2 && rc == LFQ_OK && host_arrays; sd++) {
                     O.side[sd].ne_q.resize((size_t)ne_total[sd]);
                     O.side[sd].ne_mq.resize((size_t)ne_total[sd]);
                     if (ne_total[sd] > 0
-                        && (hipMemcpyAsync(O.side[sd].ne_q.data(), A.ne_q[sd], (size_t)ne_total[sd] * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess
-                            || hipMemcpyAsync(O.side[sd].ne_mq.data(), A.ne_mq[sd], (size_t)ne_total[sd] * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess)) {
+                        && (hipMemcpyAsync(O.side[sd].ne_q.data(), A.ne_q[sd], (size_t)ne_total[sd] * 2, hipMemcpyDeviceToHost, ps) != hipSuccess
+                            || hipMemcpyAsync(O.side[sd].ne_mq.data(), A.ne_mq[sd], (size_t)ne_total[sd] * 2, hipMemcpyDeviceToHost, ps) != hipSuccess)) {
                         rc = LFQ_ERR_HIP;
                     }
                 }
-                if (hipStreamSynchronize(c->stream) != hipSuccess && rc == LFQ_OK) {
+                if (hipStreamSynchronize(ps) != hipSuccess && rc == LFQ_OK) {
                     rc = LFQ_ERR_HIP;
                 }
             }
