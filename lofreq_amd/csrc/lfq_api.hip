@@ -1767,7 +1767,8 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
         }
         rs->up_rc = rc;
     };
-    if (up_bytes >= ((int64_t)8 << 20) && !lfq_knobs().sync_upload) {
+    const int up_mode = lfq_knobs().sync_upload;        /* 0: helper thread from 8 MB on, 1: never, 2: always */
+    if (up_mode == 2 || (up_bytes >= ((int64_t)8 << 20) && up_mode == 0)) {
         rs->up_thread = new std::thread(run);           /* readset_upload_wait joins it */
     } else {
         run();

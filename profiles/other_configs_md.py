@@ -1,0 +1,31 @@
+"""r0N_other_configs.jsonl (profiles/r02_collect.sh) -> the markdown table of profiles/r0N_other_configs.md.
+    python profiles/other_configs_md.py gpurun_out/r02_other_configs.jsonl > profiles/r02_other_configs.md"""
+import json
+import sys
+
+NAMES = ["C2 (10^6 columns x 1000)", "C5 shard (3.75 x 10^6 columns x 200)", "C4, SNV part (4.6 x 10^6 columns x 500)",
+         "--mode host-abi (200 k columns x 1000 from host memory)",
+         "--mode chain (2 M reads x 150 bp -> VCF, --call-indels, BAQ on)", "--mode baq (400 K reads x 150 bp)"]
+lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
+print("# bench.py on the other configurations (1 MI355X; round 2).  C2 / depth 200 / depth 500: --steps 60 --warmup 5 --no-cpu-baseline --no-pmc")
+print("# --no-secondary, pipelined two-context loop; host-abi, chain, baq: the --mode runs.  The headline configuration (C3) is in r02_bench_line.json.")
+print()
+print("| run | ms/step | value | count ms | scan ms | DP ms (light / mid / big chains) |")
+print("|---|---|---|---|---|---|")
+for name, l in zip(NAMES, lines):
+    d = json.loads(l)
+    k = d.get("config", {}).get("kernel_ms") or {}
+    def g(key):
+        v = k.get(key)
+        return "" if v is None else ("%.3f" % v if v < 0.2 else "%.2f" % v)
+    dp = ""
+    if k:
+        dp = "%s (%s / %s / %s)" % (g("ms_dp"), g("ms_dp_light"), g("ms_dp_mid"), g("ms_dp_big"))
+    print("| %s | %.2f | %.3g %s | %s | %s | %s |" % (name, d["ms_per_step"], d["value"], d["unit"], g("ms_count"), g("ms_scan"), dp))
+print()
+print("Raw JSON lines:")
+print()
+print("```")
+for l in lines:
+    print(l.rstrip())
+print("```")

@@ -335,6 +335,16 @@ for sd in range(2):
 dt = rs.pileup_snv(0, glen)
 recs, _, st = caller.call_snvs(dt, la.VarcallConf())
 h.update(recs.tobytes()); h.update(dt.col_pos.tobytes())
+# the same columns when the indel pileup is called while the BAQ kernels are still running (nothing fetched in
+# between): its counter and scatter kernels then run beside them on another stream
+snap = {(sd, k): np.array(cols.sides[sd][k]) for sd in range(2) for k in ("ne_off", "ne_q", "ne_mq", "ev_off", "rd_off", "rd_q", "rd_aq")}
+cov = np.array(cols.coverage_plp)
+rs2 = la.ReadSet(caller, reads, ref)
+rs2.baq(extended=True, idaq=True)
+cols2, col_pos2 = rs2.pileup_indels(0, glen)
+assert np.array_equal(col_pos2, col_pos) and np.array_equal(cols2.coverage_plp, cov)
+for (sd, k), v in snap.items():
+    assert np.array_equal(cols2.sides[sd][k], v), (sd, k)
 print(json.dumps({"digest": h.hexdigest(), "ncols": int(cols.ncols), "events": [len(cols.keys[0]), len(cols.keys[1])], "recs": len(recs)}))
 '''
 
@@ -355,3 +365,11 @@ def test_host_loops_parallel_equals_serial(tmp_path):
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1], outs
     assert outs[0]["ncols"] > 5000 and sum(outs[0]["events"]) > 1000
+    # lfq_readset_create hands uploads of 8 MB and more to a helper thread and returns (the BAQ geometry runs under
+    # them); LFQ_SYNC_UPLOAD=2 does that for this small set too, =1 never: same results
+    for mode in ("2", "1"):
+        env = dict(os.environ, LFQ_SYNC_UPLOAD=mode)
+        r = subprocess.run([sys.executable, "-c", _chain_digest_script()], cwd=root, env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert json.loads(r.stdout.strip().splitlines()[-1]) == outs[0], mode
