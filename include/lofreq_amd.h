@@ -362,7 +362,11 @@ int lfq_pileup_skip_snv_columns(lfq_ctx *ctx, const uint8_t *skip, int64_t ncols
  * comes back.  The host arrays handed to lfq_readset_create must outlive the read set (the sparse host-side
  * steps -- geometry from the CIGARs, the indel event tables -- read them in place).  The host-buffer entry points
  * above (lfq_baq_idaq_batch, lfq_source_qual_batch, lfq_pileup_snv_tracks, lfq_pileup_indel_columns) are these
- * functions around a temporary read set. */
+ * functions around a temporary read set.
+ * Completion: lfq_readset_create may return while its copies are still in flight (a helper thread feeds them to an
+ * upload stream) and lfq_readset_baq returns when its kernels are queued; every later call on the read set waits for
+ * what it needs, lfq_readset_destroy for everything.  The caller sees no difference as long as the host arrays stay
+ * as they are until the read set is destroyed (they must outlive it anyway). */
 typedef struct lfq_readset lfq_readset;
 int lfq_readset_create(lfq_ctx *ctx, const lfq_pileup_reads *reads, const lfq_pileup_indel_tags *tags_or_null,
                        lfq_readset **out);
