@@ -5,7 +5,9 @@ import sys
 
 NAMES = ["C2 (10^6 columns x 1000)", "C5 shard (3.75 x 10^6 columns x 200)", "C4, SNV part (4.6 x 10^6 columns x 500)",
          "--mode host-abi (200 k columns x 1000 from host memory)",
-         "--mode chain (2 M reads x 150 bp -> VCF, --call-indels, BAQ on)", "--mode baq (400 K reads x 150 bp)"]
+         "--mode chain (regions of 2 M reads x 150 bp -> VCF, --call-indels, BAQ on; 1 step = 1 region)",
+         "--mode chain --workers 2 (two region workers = processes on the one GPU)",
+         "--mode chain --workers 3", "--mode baq (400 K reads x 150 bp)"]
 lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
 print("# bench.py on the other configurations (1 MI355X; round 2).  C2 / depth 200 / depth 500: --steps 60 --warmup 5 --no-cpu-baseline --no-pmc")
 print("# --no-secondary, pipelined two-context loop; host-abi, chain, baq: the --mode runs.  The headline configuration (C3) is in r02_bench_line.json.")

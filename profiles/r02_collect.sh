@@ -1,4 +1,5 @@
 set -u
+rm -f gpurun_out/r02_other_configs.jsonl
 R=$GRAFT_REPO_ROOT
 cd $R
 bash profiles/profile.sh r02 > /dev/null 2>&1
@@ -10,5 +11,7 @@ for cfg in "--config C2" "--cols 3750000 --depth 200" "--cols 4600000 --depth 50
 done
 python bench.py --mode host-abi --steps 100 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl
 python bench.py --mode chain --steps 300 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl
+python bench.py --mode chain --steps 600 --workers 2 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl
+python bench.py --mode chain --steps 600 --workers 3 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl
 python bench.py --mode baq --steps 100 2>/dev/null | tail -1 >> gpurun_out/r02_other_configs.jsonl
 ls gpurun_out | head -40
