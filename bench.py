@@ -353,7 +353,7 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
     for it in range(iters + 1):                     # first iteration = warm-up (allocations)
         if it == 1:
             if start_barrier is not None:
-                start_barrier.wait()                # region workers: every process starts its timed regions together
+                start_barrier.wait(timeout=300)     # region workers: every process starts its timed regions together
             wall[0] = time.time()
         T = [time.perf_counter()]
         h = vp()
@@ -436,12 +436,29 @@ def chain_workers(n_workers, iters):
     procs = [ctx.Process(target=_chain_worker, args=(i, iters, barrier, queue)) for i in range(n_workers)]
     for p in procs:
         p.start()
-    results = [queue.get(timeout=900) for _ in procs]
+    import queue as pyqueue
+    results = []
+    deadline = time.time() + 420
+    while len(results) < n_workers and time.time() < deadline:
+        try:
+            results.append(queue.get(timeout=1.0))
+        except pyqueue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):      # a worker died without reporting
+                break
+    if len(results) < n_workers or any("error" in r for _, r in results):
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=30)
+        bad = [r["error"] for _, r in results if "error" in r]
+        raise RuntimeError("chain worker failed: %s" % (bad[0] if bad else "no result (exit codes %s)" % [p.exitcode for p in procs]))
     for p in procs:
         p.join(timeout=60)
-    bad = [r for _, r in results if "error" in r]
-    if bad:
-        raise SystemExit("chain worker failed: %s" % bad[0]["error"])
     res = [r for _, r in sorted(results, key=lambda x: x[0])]
     span = max(r["wall_end"] for r in res) - min(r["wall_begin"] for r in res)
     regions = sum(r["iterations"] for r in res)
