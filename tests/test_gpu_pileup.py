@@ -112,3 +112,34 @@ def test_pileup_unsorted_reads_take_the_read_major_kernels(caller):
         res[-1] += (ipos.tolist(), icols.num_non_indels.tolist(), icols.num_tails.tolist(), icols.coverage_plp.tolist())
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
     assert res[0][3:] == res[1][3:]
+
+
+@pytest.mark.parametrize("n_reads", [1, 2, 63, 64, 65, 66, 129, 130, 4224, 4225, 4226, 4300])
+def test_window_search_at_its_round_boundaries(caller, n_reads):
+    """the column-major kernels find a position's window of reads with 64 probes per round (lfq_wave_first_above): read
+    counts at the edges of one, two and three rounds (64, 65, 65 * 65 = 4225), windows at both ends of the read list.
+    Same columns and the same observations per column as the read-major kernels (which do not search) on the shuffled list."""
+    import lofreq_amd as la
+    import test_gpu_plpindel as T
+    rng = np.random.default_rng(1000 + n_reads)
+    glen = 900
+    genome = rng.integers(0, 4, glen).astype(np.uint8)
+    ref = "".join("ACGT"[c] for c in genome).encode()
+    reads = T._random_indel_reads(rng, n_reads, glen, genome)
+    perm = rng.permutation(n_reads)
+    if n_reads > 1 and all(reads[perm[i]]["pos0"] <= reads[perm[i + 1]]["pos0"] for i in range(n_reads - 1)):
+        perm = perm[::-1].copy()                            # (two reads: make sure the second list is not sorted)
+    res = []
+    for order in (np.arange(n_reads), perm):
+        rd = [reads[i] for i in order]
+        dt = la.pileup_snv_tracks(caller, rd, ref, 0, glen)
+        t = dt._tracks()
+        off = _fetch(t.col_off, (dt.ncols + 1) * 8).view(np.uint64)
+        n_obs = int(off[-1])
+        tr = [_fetch(p, max(n_obs, 1))[:n_obs] for p in (t.nt, t.bq, t.mq)]
+        cols = [sorted(zip(*(x[int(off[c]):int(off[c + 1])].tolist() for x in tr))) for c in range(dt.ncols)]
+        icols, ipos = la.pileup_indel_columns(caller, rd, ref, 0, glen)
+        res.append((dt.col_pos.tolist(), cols, ipos.tolist(), icols.coverage_plp.tolist(), icols.num_non_indels.tolist(),
+                    icols.num_tails.tolist(), icols.num_ins.tolist(), icols.num_dels.tolist()))
+    assert res[0] == res[1]
+    assert len(res[0][0]) > 0
