@@ -1409,10 +1409,13 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
         }
     }
 
+    double t_flush = 0.0, t_tests = 0.0;
+    const double t_begin = lfq_now_ms();
     auto flush = [&]() -> int {
         if (pk.meta.empty()) {
             return LFQ_OK;
         }
+        const double tf0 = lfq_now_ms();
         lfq_tracks tr;
         memset(&tr, 0, sizeof(tr));
         tr.ncols = (int64_t)pk.meta.size();
@@ -1478,7 +1481,10 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
         calls.resize(pk.meta.size());
         int64_t nc = 0;
         lfq_batch_stats st;
+        const double tf1 = lfq_now_ms();
         LFQ_TRY(lfq_call_indel_tests_batch(c, conf, &tr, dev_pack ? 1 : 0, calls.data(), (int64_t)calls.size(), &nc, &st));
+        t_tests += lfq_now_ms() - tf1;
+        t_flush += tf1 - tf0;
         if (st.n_tested != (int64_t)pk.meta.size()) {
             return LFQ_ERR_INVALID;                   /* every packed event must have been a test */
         }
@@ -1513,7 +1519,9 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
         return LFQ_OK;
     };
 
-    for (int64_t col = 0; col < b->ncols; col++) {
+    /* the gates of call_vars' indel part over the columns [c0, c1): emit(col, side, event) for every event that is tested */
+    auto scan = [&](int64_t c0, int64_t c1, auto &&emit) -> int {
+    for (int64_t col = c0; col < c1; col++) {
         if (b->ref_base[col] == 'N') {
             continue;                                                        /* lofreq_call.c:892 */
         }
@@ -1552,33 +1560,94 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
                 if (S.key_off[e + 1] - S.key_off[e] == 1 && ign[nt4_of(key[0])]) {
                     continue;                                                /* :687-689 / :709-711 */
                 }
-                if (dev_pack) {
-                    LfqIndelTestDesc D;
-                    memset(&D, 0, sizeof(D));
-                    D.out_off = (int64_t)dev_obs;
-                    D.ne_off = S.ne_off[col];
-                    D.ne_len = (int32_t)(S.ne_off[col + 1] - S.ne_off[col]);
-                    D.rd_begin = S.rd_off[S.ev_off[col]];
-                    D.rd_len = (int32_t)(S.rd_off[S.ev_off[col + 1]] - D.rd_begin);
-                    D.me_begin = (int32_t)(S.rd_off[e] - D.rd_begin);
-                    D.me_len = (int32_t)(S.rd_off[e + 1] - S.rd_off[e]);
-                    D.side = sd;
-                    descs.push_back(D);
-                    dev_obs += (uint64_t)(D.ne_len + D.rd_len);
-                    pk.max_obs = std::max<int64_t>(pk.max_obs, D.ne_len + D.rd_len);
-                    pk.off.push_back(dev_obs);
-                    pk.ref.push_back('A');
-                    pk.meta.push_back({col, sd, (int32_t)e});
-                } else {
-                    pack_indel_test(pk, b, conf, sd, col, e);
-                }
-                if ((dev_pack ? dev_obs : (uint64_t)pk.nt.size()) >= flush_obs) {
-                    LFQ_TRY(flush());
-                }
+                LFQ_TRY(emit(col, sd, e));
             }
         }
     }
+    return LFQ_OK;
+    };
+    /* one tested event of the device-packed path: where its pseudo-column comes from and goes to */
+    auto describe = [&](int64_t col, int sd, int64_t e, uint64_t out_off) {
+        const lfq_indel_side &S = b->side[sd];
+        LfqIndelTestDesc D;
+        memset(&D, 0, sizeof(D));
+        D.out_off = (int64_t)out_off;
+        D.ne_off = S.ne_off[col];
+        D.ne_len = (int32_t)(S.ne_off[col + 1] - S.ne_off[col]);
+        D.rd_begin = S.rd_off[S.ev_off[col]];
+        D.rd_len = (int32_t)(S.rd_off[S.ev_off[col + 1]] - D.rd_begin);
+        D.me_begin = (int32_t)(S.rd_off[e] - D.rd_begin);
+        D.me_len = (int32_t)(S.rd_off[e + 1] - S.rd_off[e]);
+        D.side = sd;
+        return D;
+    };
+    auto append = [&](const LfqIndelTestDesc &D, int64_t col, int64_t e) {
+        descs.push_back(D);
+        dev_obs = (uint64_t)D.out_off + (uint64_t)(D.ne_len + D.rd_len);
+        pk.max_obs = std::max<int64_t>(pk.max_obs, D.ne_len + D.rd_len);
+        pk.off.push_back(dev_obs);
+        pk.ref.push_back('A');
+        pk.meta.push_back({col, D.side, (int32_t)e});
+    };
+    struct PartTests {
+        std::vector<LfqIndelTestDesc> descs;        /* out_off relative to the part's first observation */
+        std::vector<IndelPack::Meta> meta;
+        uint64_t obs = 0;
+    };
+    PartTests part_tests[8];
+    int scan_parts = 1;
+    bool scanned = false;
+    if (dev_pack) {
+        /* the scan over the columns (1 M of them for 1 Mb, nearly all without an event) split over a few threads; the
+         * tests of the parts are appended in column order afterwards, so descriptors, offsets and flushes are those of
+         * the one-thread loop unless a part alone exceeds a device batch (then that loop runs) */
+        lfq_for_reads(b->ncols, [&](int64_t c0, int64_t c1, int part) {
+            PartTests &P = part_tests[part];
+            (void)scan(c0, c1, [&](int64_t col, int sd, int64_t e) -> int {
+                const LfqIndelTestDesc D = describe(col, sd, e, P.obs);
+                P.descs.push_back(D);
+                P.meta.push_back({col, sd, (int32_t)e});
+                P.obs += (uint64_t)(D.ne_len + D.rd_len);
+                return LFQ_OK;
+            });
+        }, &scan_parts);
+        scanned = true;
+        for (int q = 0; q < scan_parts; q++) {
+            scanned = scanned && part_tests[q].obs < flush_obs;
+        }
+    }
+    if (scanned) {
+        for (int q = 0; q < scan_parts; q++) {
+            const PartTests &P = part_tests[q];
+            if (dev_obs + P.obs >= flush_obs) {
+                LFQ_TRY(flush());
+            }
+            const uint64_t first = dev_obs;
+            for (size_t i = 0; i < P.descs.size(); i++) {
+                LfqIndelTestDesc D = P.descs[i];
+                D.out_off += (int64_t)first;
+                append(D, P.meta[i].col, P.meta[i].event);
+            }
+        }
+    } else {
+        LFQ_TRY(scan(0, b->ncols, [&](int64_t col, int sd, int64_t e) -> int {
+            if (dev_pack) {
+                append(describe(col, sd, e, dev_obs), col, e);
+            } else {
+                pack_indel_test(pk, b, conf, sd, col, e);
+            }
+            if ((dev_pack ? dev_obs : (uint64_t)pk.nt.size()) >= flush_obs) {
+                return flush();
+            }
+            return LFQ_OK;
+        }));
+    }
     LFQ_TRY(flush());
+    if (lfq_timing_on) {
+        const double all = lfq_now_ms() - t_begin;
+        fprintf(stderr, "[lfq timing] indel calls: test descriptors %.1f  upload + pack %.1f  tests batch %.1f ms (%ld tests, %ld records)\n",
+                all - t_flush - t_tests, t_flush, t_tests, (long)n_tests, (long)n_out);
+    }
     *n_records = n_out;
     if (n_tests_out) {
         *n_tests_out = n_tests;

@@ -332,6 +332,11 @@ for sd in range(2):
     for k in ("non_fw", "non_rv", "ne_off", "ne_q", "ne_mq", "ev_off", "ev_fw", "ev_rv", "rd_off", "rd_q", "rd_aq", "rd_mq", "rd_sq"):
         h.update(np.ascontiguousarray(S[k]).tobytes())
     h.update("|".join(cols.keys[sd]).encode())
+# indel tests on the columns while they are this context's current ones (pseudo-columns packed on the device; the scan
+# of the gates over the columns is one of the threaded host loops)
+irecs, n_itests = la.call_indels(caller, cols, la.VarcallConf(flag=la.LFQ_USE_MQ | la.LFQ_USE_IDAQ, bonf_dynamic=0, bonf_indel=1, sig=1.0))
+assert n_itests > 500 and len(irecs) > 100
+h.update(irecs.tobytes()); h.update(str(n_itests).encode())
 dt = rs.pileup_snv(0, glen)
 recs, _, st = caller.call_snvs(dt, la.VarcallConf())
 h.update(recs.tobytes()); h.update(dt.col_pos.tobytes())
