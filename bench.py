@@ -397,7 +397,8 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
                     "s_snv_pileup": d[4], "s_snv_calls": d[5], "columns": int(t.ncols), "indel_tests": int(n_tests.value),
                     "snv_records": int(len(recs)), "indel_records": int(nrec.value)}
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
-    best.update({"s_mean": sum(totals) / max(len(totals), 1), "iterations": len(totals), "wall_begin": wall[0], "wall_end": wall[1]})
+    best.update({"s_mean": sum(totals) / max(len(totals), 1), "iterations": len(totals), "s_each": [round(t, 5) for t in totals[:16]],
+                 "wall_begin": wall[0], "wall_end": wall[1]})
     best.update({"reads": n_reads, "read_len": R["rl"], "genome_len": glen, "depth": n_reads * R["rl"] / glen,
                  "reads_per_s": n_reads / best["s_total"], "columns_per_s": best["columns"] / best["s_total"],
                  "call_indels": bool(call_indels),

@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -1687,9 +1688,23 @@ struct lfq_readset {
      * pageable arrays to the upload stream): host-only work of the next step -- the BAQ geometry -- runs meanwhile, and
      * every step calls readset_upload_wait before its first device operation on the read set */
     std::thread *up_thread;
+    std::atomic<int> up_stage;          /* 1: everything but BI / BD has landed (what lfq_readset_baq reads), 2: all of it */
     int up_rc;
     LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
 };
+
+/* the reads, qualities, CIGARs and the contig are on the device (BI / BD may still be on their way: the BAQ kernels do
+ * not read them, and 600 of the 1300 MB of a 2 M-read region then cross PCIe under those kernels) */
+static int readset_upload_wait_inputs(lfq_readset *rs)
+{
+    if (rs && rs->up_thread) {
+        while (rs->up_stage.load(std::memory_order_acquire) < 1) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        return rs->up_rc;
+    }
+    return rs ? rs->up_rc : LFQ_OK;
+}
 
 static int readset_upload_wait(lfq_readset *rs)
 {
@@ -1761,6 +1776,7 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->d_pmax = nullptr;
     rs->pmax_state = 0;
     rs->up_thread = nullptr;
+    rs->up_stage.store(0);
     rs->up_rc = LFQ_OK;
     rs->up_fl = nullptr;
     rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
@@ -1805,17 +1821,22 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     }
     memcpy(rs->up_fl->data(), rs->fl.data(), (size_t)n);
     struct Copy { uint8_t *dst; const void *src; int64_t bytes; };
+    /* BI / BD last: lfq_readset_baq, usually the first step, does not read them */
     const Copy copies[] = {{rs->d_pos, rd->pos, n * 4}, {rs->d_coff, rd->cigar_off, (n + 1) * 8}, {rs->d_soff, rd->seq_off, (n + 1) * 8},
                            {rs->d_cig, rd->cigar, rs->n_cig * 4}, {rs->d_seq, rd->seq, nb}, {rs->d_qual, rd->qual, nb},
                            {rs->d_ref, rd->ref, rs->ref_len}, {rs->d_mapq, rd->mapq, n}, {rs->d_rev, rd->reverse, n},
-                           {rs->d_bi, rs->h_bi, nb}, {rs->d_bd, rs->h_bd, nb}, {rs->d_lb, rd->baq, nb}, {rs->d_sqb, rd->sq, n},
-                           {rs->d_fl, rs->up_fl->data(), n}};
+                           {rs->d_lb, rd->baq, nb}, {rs->d_sqb, rd->sq, n}, {rs->d_fl, rs->up_fl->data(), n},
+                           {rs->d_bi, rs->h_bi, nb}, {rs->d_bd, rs->h_bd, nb}};
     std::vector<Copy> todo;
     int64_t up_bytes = 0;
+    size_t n_first = 0;                                 /* copies before BI / BD */
     for (const Copy &x : copies) {
         if (x.src && x.bytes > 0) {
             todo.push_back(x);
             up_bytes += x.bytes;
+            if (x.dst != rs->d_bi && x.dst != rs->d_bd) {
+                n_first = todo.size();
+            }
         }
     }
     rs->has_bi = rs->h_bi != nullptr;
@@ -1824,17 +1845,21 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->has_sqb = rd->sq != nullptr;
     const int device = c->device;
     hipStream_t ups = c->up_stream;
-    auto run = [rs, todo, device, ups]() {
+    auto run = [rs, todo, n_first, device, ups]() {
         int rc = hipSetDevice(device) == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
-        for (const Copy &x : todo) {
-            if (rc == LFQ_OK && hipMemcpyAsync(x.dst, x.src, (size_t)x.bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
+        for (size_t i = 0; i <= todo.size(); i++) {
+            if (i == n_first || i == todo.size()) {     /* a stage is complete when its copies have landed */
+                if (hipStreamSynchronize(ups) != hipSuccess && rc == LFQ_OK) {
+                    rc = LFQ_ERR_HIP;
+                }
+                rs->up_rc = rc;
+                rs->up_stage.store(i == todo.size() ? 2 : 1, std::memory_order_release);
+            }
+            if (i < todo.size() && rc == LFQ_OK
+                && hipMemcpyAsync(todo[i].dst, todo[i].src, (size_t)todo[i].bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
         }
-        if (hipStreamSynchronize(ups) != hipSuccess && rc == LFQ_OK) {
-            rc = LFQ_ERR_HIP;
-        }
-        rs->up_rc = rc;
     };
     const int up_mode = lfq_knobs().sync_upload;        /* 0: helper thread from 8 MB on, 1: never, 2: always */
     if (up_mode == 2 || (up_bytes >= ((int64_t)8 << 20) && up_mode == 0)) {
@@ -2108,7 +2133,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             }
         }
     });
-    LFQ_TRY(readset_upload_wait(rs));           /* the geometry above ran while the reads were still on their way */
+    LFQ_TRY(readset_upload_wait_inputs(rs));    /* the geometry above ran while the reads were still on their way */
     const int64_t n_bases = rs->n_bases;
     if (!rs->tag_blob) {                        /* lb (+ ai, ad): resident from here on */
         const int64_t each = (n_bases + 16 + 255) / 256 * 256;
