@@ -1618,17 +1618,33 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
         }
     }
     if (scanned) {
+        size_t total_tests = 0;
+        for (int q = 0; q < scan_parts; q++) {
+            total_tests += part_tests[q].descs.size();
+        }
+        descs.reserve(total_tests);
+        pk.off.reserve(total_tests + 1);
+        pk.meta.reserve(total_tests);
         for (int q = 0; q < scan_parts; q++) {
             const PartTests &P = part_tests[q];
             if (dev_obs + P.obs >= flush_obs) {
                 LFQ_TRY(flush());
             }
             const uint64_t first = dev_obs;
-            for (size_t i = 0; i < P.descs.size(); i++) {
-                LfqIndelTestDesc D = P.descs[i];
+            const size_t at = descs.size(), m = P.descs.size();
+            descs.insert(descs.end(), P.descs.begin(), P.descs.end());
+            pk.meta.insert(pk.meta.end(), P.meta.begin(), P.meta.end());
+            pk.ref.insert(pk.ref.end(), m, (uint8_t)'A');
+            pk.off.resize(pk.off.size() + m);
+            uint64_t *off_out = pk.off.data() + pk.off.size() - m;
+            for (size_t i = 0; i < m; i++) {
+                LfqIndelTestDesc &D = descs[at + i];
                 D.out_off += (int64_t)first;
-                append(D, P.meta[i].col, P.meta[i].event);
+                const int64_t len = (int64_t)D.ne_len + D.rd_len;
+                pk.max_obs = std::max(pk.max_obs, len);
+                off_out[i] = (uint64_t)(D.out_off + len);
             }
+            dev_obs = first + P.obs;
         }
     } else {
         LFQ_TRY(scan(0, b->ncols, [&](int64_t col, int sd, int64_t e) -> int {
