@@ -1705,7 +1705,7 @@ struct lfq_readset {
      * every step calls readset_upload_wait before its first device operation on the read set */
     std::thread *up_thread;
     std::atomic<int> up_stage;          /* 1: everything but BI / BD has landed (what lfq_readset_baq reads), 2: all of it */
-    int up_rc;
+    std::atomic<int> up_rc;        /* written by the helper thread at the end of each stage */
     LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
 };
 
