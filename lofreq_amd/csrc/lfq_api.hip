@@ -1719,7 +1719,7 @@ static int readset_upload_wait_inputs(lfq_readset *rs)
         }
         return rs->up_rc;
     }
-    return rs ? rs->up_rc : LFQ_OK;
+    return rs ? rs->up_rc.load() : (int)LFQ_OK;
 }
 
 static int readset_upload_wait(lfq_readset *rs)
@@ -1733,7 +1733,7 @@ static int readset_upload_wait(lfq_readset *rs)
         delete rs->up_fl;
         rs->up_fl = nullptr;
     }
-    return rs ? rs->up_rc : LFQ_OK;
+    return rs ? rs->up_rc.load() : (int)LFQ_OK;
 }
 
 /* the host side of an lfq_readset_baq that is still running: merged tag flags (bit 0 BI, 1 BD, 2 ai, 3 ad) into rs->fl */
