@@ -162,6 +162,10 @@ struct lfq_ctx {
     int64_t plp_in_bytes, plp_out_bytes;
     uint8_t *d_tmp[5];               /* grow-only temporaries: BAQ geometry, indel counters, gathers, and the event-read
                                       * arrays + pseudo-column tracks of lfq_call_indels_batch */
+    /* the allocations of the read set destroyed last (reads, tags, read ends, tag flags, pinned flags): the next
+     * lfq_readset_create / _baq takes them over when they are large enough -- a worker goes from region to region, and
+     * hipMalloc + hipFree of 2 GB per region are milliseconds and a device synchronisation each */
+    struct { void *p; size_t cap; } rs_cache[5];
     hipStream_t up_stream;           /* lfq_readset_create's uploads (created on first use) */
     uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
     int64_t pin_bytes;
@@ -614,6 +618,9 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_plp_ne) (void)hipFree(c->d_plp_ne);
         for (int i = 0; i < 5; i++) {
             if (c->d_tmp[i]) (void)hipFree(c->d_tmp[i]);
+        }
+        for (int k = 0; k < 5; k++) {                   /* 4 = LFQ_RSC_PINFL: pinned host memory */
+            if (c->rs_cache[k].p) (void)(k == 4 ? hipHostFree(c->rs_cache[k].p) : hipFree(c->rs_cache[k].p));
         }
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1677,8 +1684,57 @@ int lfq_call_indels_batch(lfq_ctx *c, lfq_conf *conf, const lfq_indel_columns *b
  * copy and leave their per-base results (lb, ai, ad, sq) there for the next stage.  The host arrays handed to
  * lfq_readset_create stay the caller's and must outlive the read set: the sparse host-side steps (geometry from the
  * CIGARs, the indel event tables) read them in place. */
+enum { LFQ_RSC_BLOB = 0, LFQ_RSC_TAGS = 1, LFQ_RSC_PMAX = 2, LFQ_RSC_TAGFL = 3, LFQ_RSC_PINFL = 4 };
+
+static void rs_cache_free(int kind, void *p)
+{
+    if (p) {
+        (void)(kind == LFQ_RSC_PINFL ? hipHostFree(p) : hipFree(p));
+    }
+}
+
+/* `bytes` of device memory (pinned host memory for LFQ_RSC_PINFL): the cached block of this kind if it is large enough */
+static void *rs_cache_take(lfq_ctx *c, int kind, size_t bytes, size_t *cap_out)
+{
+    auto &e = c->rs_cache[kind];
+    if (e.p && e.cap >= bytes) {
+        void *p = e.p;
+        *cap_out = e.cap;
+        e.p = nullptr;
+        e.cap = 0;
+        return p;
+    }
+    rs_cache_free(kind, e.p);
+    e.p = nullptr;
+    e.cap = 0;
+    void *p = nullptr;
+    const size_t want = std::max<size_t>(bytes, 256);
+    const hipError_t rc = (kind == LFQ_RSC_PINFL) ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    if (rc != hipSuccess) {
+        return nullptr;
+    }
+    *cap_out = want;
+    return p;
+}
+
+static void rs_cache_give(lfq_ctx *c, int kind, void *p, size_t cap)
+{
+    if (!p) {
+        return;
+    }
+    auto &e = c->rs_cache[kind];
+    if (!e.p || cap > e.cap) {
+        rs_cache_free(kind, e.p);
+        e.p = p;
+        e.cap = cap;
+    } else {
+        rs_cache_free(kind, p);
+    }
+}
+
 struct lfq_readset {
     lfq_ctx *c;
+    size_t cap[5];                      /* capacities of blob, tag_blob, d_pmax, d_tagfl, h_fl_pin (rs_cache_*) */
     int64_t n, n_bases, n_cig, ref_len;
     const int32_t *pos;
     const int64_t *cigar_off, *seq_off;
@@ -1758,11 +1814,12 @@ void lfq_readset_destroy(lfq_readset *rs)
         (void)readset_upload_wait(rs);
         (void)readset_baq_wait(rs);
         if (rs->ev_baq) (void)hipEventDestroy(rs->ev_baq);
-        if (rs->h_fl_pin) (void)hipHostFree(rs->h_fl_pin);
-        if (rs->d_tagfl) (void)hipFree(rs->d_tagfl);
-        if (rs->blob) (void)hipFree(rs->blob);
-        if (rs->tag_blob) (void)hipFree(rs->tag_blob);
-        if (rs->d_pmax) (void)hipFree(rs->d_pmax);
+        (void)hipStreamSynchronize(rs->c->stream);      /* nothing queued may still use what goes back to the cache */
+        rs_cache_give(rs->c, LFQ_RSC_PINFL, rs->h_fl_pin, rs->cap[LFQ_RSC_PINFL]);
+        rs_cache_give(rs->c, LFQ_RSC_TAGFL, rs->d_tagfl, rs->cap[LFQ_RSC_TAGFL]);
+        rs_cache_give(rs->c, LFQ_RSC_BLOB, rs->blob, rs->cap[LFQ_RSC_BLOB]);
+        rs_cache_give(rs->c, LFQ_RSC_TAGS, rs->tag_blob, rs->cap[LFQ_RSC_TAGS]);
+        rs_cache_give(rs->c, LFQ_RSC_PMAX, rs->d_pmax, rs->cap[LFQ_RSC_PMAX]);
         delete rs;
     }
 }
@@ -1790,6 +1847,9 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->blob = nullptr;
     rs->tag_blob = nullptr;
     rs->d_pmax = nullptr;
+    rs->d_tagfl = nullptr;
+    rs->h_fl_pin = nullptr;
+    memset(rs->cap, 0, sizeof(rs->cap));
     rs->pmax_state = 0;
     rs->up_thread = nullptr;
     rs->up_stage.store(0);
@@ -1797,11 +1857,12 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->up_fl = nullptr;
     rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
     const int64_t n = rs->n, nb = rs->n_bases;
-    rs->fl.assign((size_t)std::max<int64_t>(n, 1), 0);
-    for (int64_t r = 0; r < n; r++) {
-        const uint32_t f = rs->h_flags ? rs->h_flags[r] : 15u;
-        rs->fl[(size_t)r] = (uint8_t)((rs->h_bi && (f & 1u) ? 1 : 0) | (rs->h_bd && (f & 2u) ? 2 : 0)
-                                      | (rs->h_ai && (f & 4u) ? 4 : 0) | (rs->h_ad && (f & 8u) ? 8 : 0));
+    {
+        const uint32_t have = (rs->h_bi ? 1u : 0u) | (rs->h_bd ? 2u : 0u) | (rs->h_ai ? 4u : 0u) | (rs->h_ad ? 8u : 0u);
+        rs->fl.assign((size_t)std::max<int64_t>(n, 1), (uint8_t)have);      /* no per-read flags: every read has every tag given */
+        for (int64_t r = 0; rs->h_flags && r < n; r++) {
+            rs->fl[(size_t)r] = (uint8_t)(rs->h_flags[r] & have);
+        }
     }
     if (n == 0) {
         *out = rs;
@@ -1816,7 +1877,8 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
                   o_seq = take(nb + 16), o_qual = take(rd->qual ? nb + 16 : 0), o_ref = take(rs->ref_len + 1), o_mapq = take(n),
                   o_rev = take(n), o_bi = take(rs->h_bi ? nb + 16 : 0), o_bd = take(rs->h_bd ? nb + 16 : 0),
                   o_lb = take(rd->baq ? nb + 16 : 0), o_fl = take(n), o_sqb = take(n);
-    if (hipMalloc((void **)&rs->blob, (size_t)off) != hipSuccess) {
+    rs->blob = (uint8_t *)rs_cache_take(c, LFQ_RSC_BLOB, (size_t)off, &rs->cap[LFQ_RSC_BLOB]);
+    if (!rs->blob) {
         delete rs;
         return LFQ_ERR_NOMEM;
     }
@@ -1944,12 +2006,13 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs, hipStream_t st)
                 });
             }
             if (sorted) {
-                if (hipMalloc((void **)&rs->d_pmax, (size_t)n * 4) == hipSuccess
+                rs->d_pmax = (int32_t *)rs_cache_take(c, LFQ_RSC_PMAX, (size_t)n * 4, &rs->cap[LFQ_RSC_PMAX]);
+                if (rs->d_pmax
                     && hipMemcpyAsync(rs->d_pmax, pmax.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) == hipSuccess
                     && hipStreamSynchronize(st) == hipSuccess) {
                     rs->pmax_state = 1;
                 } else if (rs->d_pmax) {
-                    (void)hipFree(rs->d_pmax);
+                    rs_cache_give(c, LFQ_RSC_PMAX, rs->d_pmax, rs->cap[LFQ_RSC_PMAX]);
                     rs->d_pmax = nullptr;
                 }
             }
@@ -2166,14 +2229,20 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     const int64_t n_bases = rs->n_bases;
     if (!rs->tag_blob) {                        /* lb (+ ai, ad): resident from here on */
         const int64_t each = (n_bases + 16 + 255) / 256 * 256;
-        LFQ_TRY_HIP(hipMalloc((void **)&rs->tag_blob, (size_t)(each * (want_idaq ? 3 : 1))));
+        rs->tag_blob = (uint8_t *)rs_cache_take(c, LFQ_RSC_TAGS, (size_t)(each * (want_idaq ? 3 : 1)), &rs->cap[LFQ_RSC_TAGS]);
+        if (!rs->tag_blob) {
+            return LFQ_ERR_NOMEM;
+        }
         rs->d_lb = rs->tag_blob;
         rs->d_ai = want_idaq ? rs->tag_blob + each : nullptr;
         rs->d_ad = want_idaq ? rs->tag_blob + 2 * each : nullptr;
         LFQ_TRY_HIP(hipEventCreateWithFlags(&rs->ev_baq, hipEventDisableTiming));
         if (want_idaq) {
-            LFQ_TRY_HIP(hipMalloc((void **)&rs->d_tagfl, (size_t)n));
-            LFQ_TRY_HIP(hipHostMalloc((void **)&rs->h_fl_pin, (size_t)n, hipHostMallocDefault));
+            rs->d_tagfl = (uint8_t *)rs_cache_take(c, LFQ_RSC_TAGFL, (size_t)n, &rs->cap[LFQ_RSC_TAGFL]);
+            rs->h_fl_pin = (uint8_t *)rs_cache_take(c, LFQ_RSC_PINFL, (size_t)n, &rs->cap[LFQ_RSC_PINFL]);
+            if (!rs->d_tagfl || !rs->h_fl_pin) {
+                return LFQ_ERR_NOMEM;
+            }
         }
     } else if (want_idaq && !rs->d_ai) {
         return LFQ_ERR_INVALID;                 /* a second BAQ pass that suddenly wants ai / ad: make a new read set */
