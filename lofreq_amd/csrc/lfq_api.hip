@@ -1761,6 +1761,8 @@ struct lfq_readset {
      * every step calls readset_upload_wait before its first device operation on the read set */
     std::thread *up_thread;
     std::atomic<int> up_stage;          /* 1: everything but BI / BD has landed (what lfq_readset_baq reads), 2: all of it */
+    std::atomic<int> up_chunks;         /* bases + qualities of the reads [0, n * up_chunks / up_nchunks) have landed */
+    int up_nchunks;
     std::atomic<int> up_rc;        /* written by the helper thread at the end of each stage */
     LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
 };
@@ -1774,6 +1776,22 @@ static int readset_upload_wait_inputs(lfq_readset *rs)
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
         return rs->up_rc;
+    }
+    return rs ? rs->up_rc.load() : (int)LFQ_OK;
+}
+
+/* ... and for a launch over the reads up to (and including) r_last: the small arrays and the chunks of bases and
+ * qualities that hold them */
+static int readset_upload_wait_reads(lfq_readset *rs, int64_t r_last)
+{
+    if (rs && rs->up_thread) {
+        int need = 1;
+        while (need < rs->up_nchunks && rs->n * need / rs->up_nchunks <= r_last) {
+            need++;
+        }
+        while (rs->up_chunks.load(std::memory_order_acquire) < need) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
     }
     return rs ? rs->up_rc.load() : (int)LFQ_OK;
 }
@@ -1853,6 +1871,8 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->pmax_state = 0;
     rs->up_thread = nullptr;
     rs->up_stage.store(0);
+    rs->up_chunks.store(0);
+    rs->up_nchunks = 1;
     rs->up_rc = LFQ_OK;
     rs->up_fl = nullptr;
     rs->has_lb = rs->has_idaq = rs->has_sqb = rs->has_bi = rs->has_bd = false;
@@ -1898,24 +1918,45 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
         return LFQ_ERR_NOMEM;
     }
     memcpy(rs->up_fl->data(), rs->fl.data(), (size_t)n);
-    struct Copy { uint8_t *dst; const void *src; int64_t bytes; };
-    /* BI / BD last: lfq_readset_baq, usually the first step, does not read them */
-    const Copy copies[] = {{rs->d_pos, rd->pos, n * 4}, {rs->d_coff, rd->cigar_off, (n + 1) * 8}, {rs->d_soff, rd->seq_off, (n + 1) * 8},
-                           {rs->d_cig, rd->cigar, rs->n_cig * 4}, {rs->d_seq, rd->seq, nb}, {rs->d_qual, rd->qual, nb},
-                           {rs->d_ref, rd->ref, rs->ref_len}, {rs->d_mapq, rd->mapq, n}, {rs->d_rev, rd->reverse, n},
-                           {rs->d_lb, rd->baq, nb}, {rs->d_sqb, rd->sq, n}, {rs->d_fl, rs->up_fl->data(), n},
-                           {rs->d_bi, rs->h_bi, nb}, {rs->d_bd, rs->h_bd, nb}};
+    /* The order of the copies follows what lfq_readset_baq, usually the first step, needs: the small per-read arrays, then
+     * bases and qualities in chunks of reads -- its launch over reads [a, b) starts when the chunks up to read b have
+     * landed (readset_upload_wait_reads) --, BI / BD, which it does not read, last. */
+    struct Copy { uint8_t *dst; const void *src; int64_t bytes; int chunks_after, stage_after; };
     std::vector<Copy> todo;
     int64_t up_bytes = 0;
-    size_t n_first = 0;                                 /* copies before BI / BD */
-    for (const Copy &x : copies) {
-        if (x.src && x.bytes > 0) {
-            todo.push_back(x);
-            up_bytes += x.bytes;
-            if (x.dst != rs->d_bi && x.dst != rs->d_bd) {
-                n_first = todo.size();
-            }
+    auto add = [&](uint8_t *dst, const void *src, int64_t bytes) {
+        if (src && bytes > 0) {
+            todo.push_back({dst, src, bytes, 0, 0});
+            up_bytes += bytes;
         }
+    };
+    add(rs->d_pos, rd->pos, n * 4);
+    add(rs->d_coff, rd->cigar_off, (n + 1) * 8);
+    add(rs->d_soff, rd->seq_off, (n + 1) * 8);
+    add(rs->d_cig, rd->cigar, rs->n_cig * 4);
+    add(rs->d_ref, rd->ref, rs->ref_len);
+    add(rs->d_mapq, rd->mapq, n);
+    add(rs->d_rev, rd->reverse, n);
+    add(rs->d_lb, rd->baq, nb);
+    add(rs->d_sqb, rd->sq, n);
+    add(rs->d_fl, rs->up_fl->data(), n);
+    const int n_chunks = nb >= ((int64_t)64 << 20) ? 4 : 1;
+    rs->up_nchunks = n_chunks;
+    for (int j = 0; j < n_chunks; j++) {
+        const int64_t b0 = rd->seq_off[n * j / n_chunks], b1 = rd->seq_off[n * (j + 1) / n_chunks];
+        add(rs->d_seq + b0, rd->seq + b0, b1 - b0);
+        add(rs->d_qual + b0, rd->qual ? rd->qual + b0 : nullptr, b1 - b0);
+        if (!todo.empty()) {
+            todo.back().chunks_after = j + 1;
+        }
+    }
+    if (!todo.empty()) {
+        todo.back().stage_after = 1;
+    }
+    add(rs->d_bi, rs->h_bi, nb);
+    add(rs->d_bd, rs->h_bd, nb);
+    if (!todo.empty()) {
+        todo.back().stage_after = 2;
     }
     rs->has_bi = rs->h_bi != nullptr;
     rs->has_bd = rs->h_bd != nullptr;
@@ -1923,21 +1964,28 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     rs->has_sqb = rd->sq != nullptr;
     const int device = c->device;
     hipStream_t ups = c->up_stream;
-    auto run = [rs, todo, n_first, device, ups]() {
+    auto run = [rs, todo, n_chunks, device, ups]() {
         int rc = hipSetDevice(device) == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
-        for (size_t i = 0; i <= todo.size(); i++) {
-            if (i == n_first || i == todo.size()) {     /* a stage is complete when its copies have landed */
+        for (const Copy &x : todo) {
+            if (rc == LFQ_OK && hipMemcpyAsync(x.dst, x.src, (size_t)x.bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (x.chunks_after || x.stage_after) {      /* progress is published when the copies have landed */
                 if (hipStreamSynchronize(ups) != hipSuccess && rc == LFQ_OK) {
                     rc = LFQ_ERR_HIP;
                 }
                 rs->up_rc = rc;
-                rs->up_stage.store(i == todo.size() ? 2 : 1, std::memory_order_release);
-            }
-            if (i < todo.size() && rc == LFQ_OK
-                && hipMemcpyAsync(todo[i].dst, todo[i].src, (size_t)todo[i].bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
-                rc = LFQ_ERR_HIP;
+                if (x.chunks_after) {
+                    rs->up_chunks.store(x.chunks_after, std::memory_order_release);
+                }
+                if (x.stage_after) {
+                    rs->up_stage.store(x.stage_after, std::memory_order_release);
+                }
             }
         }
+        rs->up_rc = rc;
+        rs->up_chunks.store(n_chunks, std::memory_order_release);
+        rs->up_stage.store(2, std::memory_order_release);
     };
     const int up_mode = lfq_knobs().sync_upload;        /* 0: helper thread from 8 MB on, 1: never, 2: always */
     if (up_mode == 2 || (up_bytes >= ((int64_t)8 << 20) && up_mode == 0)) {
@@ -2225,7 +2273,6 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             }
         }
     });
-    LFQ_TRY(readset_upload_wait_inputs(rs));    /* the geometry above ran while the reads were still on their way */
     const int64_t n_bases = rs->n_bases;
     if (!rs->tag_blob) {                        /* lb (+ ai, ad): resident from here on */
         const int64_t each = (n_bases + 16 + 255) / 256 * 256;
@@ -2362,11 +2409,32 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             }
             return X;
         };
-        if (beside) {
-            /* the side streams start after the uploads / memsets queued on c->stream, c->stream ends after them */
-            if (hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
-                rc = LFQ_ERR_HIP;
+        /* The reads may still be crossing PCIe (lfq_readset_create): a launch waits for the chunks of bases and qualities
+         * that hold its reads -- the plain narrow-band launches walk the reads in input order, so the first one starts
+         * after a quarter of them --, everything else for all of them. */
+        if (beside && hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;       /* the side streams start after the uploads / memsets queued on c->stream so far */
+        }
+        {
+            LfqBaqArgs Ap = A;                      /* the plain instantiation: no indel table */
+            Ap.itab = nullptr;
+            Ap.terms = nullptr;
+            Ap.ai_out = Ap.ad_out = nullptr;
+            Ap.tag_flags = nullptr;
+            for (int64_t first = 0; rc == LFQ_OK && first < n_plain; first += waves_n * 64) {
+                const int64_t cnt = std::min<int64_t>(waves_n * 64, n_plain - first);
+                rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)]);
+                Ap.first_read = (int32_t)first;
+                if (rc == LFQ_OK) {
+                    rc = lfq_launch_baq(Ap, cnt, 1, c->stream);
+                }
             }
+        }
+        if (rc == LFQ_OK) {
+            rc = readset_upload_wait_inputs(rs);
+        }
+        if (beside) {
+            /* wide-band and band-8 reads on the side streams, beside the narrow-band launches; c->stream ends after them */
             if (rc == LFQ_OK && n_wide > 0) {
                 LfqBaqArgs Aw = at_slot(waves_n + waves_b8);
                 Aw.first_read = (int32_t)(n_narrow + n_band8);
@@ -2390,17 +2458,6 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             if (rc == LFQ_OK && (hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess
                                  || hipEventRecord(c->ev_join[2], c->side[1]) != hipSuccess)) {
                 rc = LFQ_ERR_HIP;
-            }
-        }
-        {
-            LfqBaqArgs Ap = A;                      /* the plain instantiation: no indel table */
-            Ap.itab = nullptr;
-            Ap.terms = nullptr;
-            Ap.ai_out = Ap.ad_out = nullptr;
-            Ap.tag_flags = nullptr;
-            for (int64_t first = 0; rc == LFQ_OK && first < n_plain; first += waves_n * 64) {
-                Ap.first_read = (int32_t)first;
-                rc = lfq_launch_baq(Ap, std::min<int64_t>(waves_n * 64, n_plain - first), 1, c->stream);
             }
         }
         for (int64_t first = n_plain; rc == LFQ_OK && first < n_narrow; first += waves_n * 64) {
