@@ -20,6 +20,8 @@
 #include <mutex>
 #include <string>
 #include <atomic>
+#include <functional>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -49,6 +51,100 @@ static inline double lfq_now_ms()
 }
 #define lfq_timing_on (lfq_knobs().timing != 0)
 
+/* The helper threads of the host loops below.  A region's steps run a dozen such loops milliseconds apart; threads
+ * created (or woken from a condition variable) per loop start on idle cores and the same loop took anything between
+ * 0.7 and 4.5 ms (BAQ geometry of 400 K reads, 4 threads; one thread: 2.4 ms).  These seven stay: after a loop they spin
+ * for LFQ_HOST_SPIN_US (2000) microseconds waiting for the next one before they go to sleep.  One loop at a time
+ * (try_run fails when another thread is using the pool, and in a forked child: the caller then creates threads). */
+class LfqLoopPool {
+public:
+    static LfqLoopPool &instance()
+    {
+        static LfqLoopPool p;
+        return p;
+    }
+    bool try_run(int parts, const std::function<void(int)> &task)       /* task(1 .. parts - 1) here, part 0 by the caller */
+    {
+        if (parts - 1 > (int)th_.size() || getpid() != pid_ || !call_m_.try_lock()) {
+            return false;
+        }
+        /* every helper acknowledges every generation (those beyond `parts` without running anything): none of them can
+         * still be looking at this generation's task when the next one is written */
+        job_ = &task;
+        want_ = parts - 1;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            { std::lock_guard<std::mutex> lk(m_); }
+            cv_.notify_all();
+        }
+        return true;
+    }
+    void finish()                                                        /* after the caller's own part */
+    {
+        while (pending_.load(std::memory_order_acquire) > 0) {
+            __builtin_ia32_pause();
+        }
+        job_ = nullptr;
+        call_m_.unlock();
+    }
+
+private:
+    LfqLoopPool() : pid_(getpid())
+    {
+        spin_us_ = lfq_knobs().host_spin_us;
+        const int n = spin_us_ < 0 ? 0 : 7;
+        for (int i = 0; i < n; i++) {
+            th_.emplace_back([this, i] { loop(i); });
+        }
+    }
+    ~LfqLoopPool()
+    {
+        stop_.store(true);
+        gen_.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(m_); }
+        cv_.notify_all();
+        for (auto &t : th_) {
+            t.join();
+        }
+    }
+    void loop(int idx)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const double t0 = lfq_now_ms();
+            int polls = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                __builtin_ia32_pause();
+                if ((++polls & 255) == 0 && (lfq_now_ms() - t0) * 1e3 > (double)spin_us_) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    sleepers_.fetch_add(1, std::memory_order_release);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                    sleepers_.fetch_sub(1, std::memory_order_release);
+                }
+            }
+            if (stop_.load()) {
+                return;
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            if (idx < want_ && job_) {
+                (*job_)(idx + 1);
+            }
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex call_m_, m_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
+    const std::function<void(int)> *job_ = nullptr;
+    int want_ = 0;
+    long spin_us_ = 2000;
+    pid_t pid_;
+};
+
 /* per-read host loops of the read-set steps (geometry from the CIGARs, event candidates): independent reads, split
  * over a few threads when there are enough of them.  f(begin, end, part) */
 template <typename F>
@@ -67,6 +163,13 @@ static void lfq_for_reads(int64_t n, F f, int *parts_out = nullptr)
     }
     if (parts == 1) {
         f((int64_t)0, n, 0);
+        return;
+    }
+    const std::function<void(int)> task = [&](int p) { f(n * p / parts, n * (p + 1) / parts, p); };
+    LfqLoopPool &pool = LfqLoopPool::instance();
+    if (pool.try_run(parts, task)) {
+        f((int64_t)0, n / parts, 0);
+        pool.finish();
         return;
     }
     std::vector<std::thread> th;

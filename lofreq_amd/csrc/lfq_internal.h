@@ -195,6 +195,7 @@ struct LfqKnobs {
     int segments;              /* LFQ_SEGMENTS: batch segments */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
+    long host_spin_us;         /* LFQ_HOST_SPIN_US (2000): how long the helper threads of the host loops spin for the next loop; -1 = no pool */
     int sync_upload;           /* LFQ_SYNC_UPLOAD: 1 = lfq_readset_create waits for its copies itself (no helper thread), 2 = helper thread whatever the size */
     int host_threads;          /* LFQ_HOST_THREADS: -1 = from the core count */
     long host_par_min;         /* LFQ_HOST_PAR_MIN (200000): reads / positions from which the host loops of the read-set steps split over threads */
