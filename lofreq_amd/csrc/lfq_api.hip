@@ -100,6 +100,12 @@ private:
     }
     ~LfqLoopPool()
     {
+        if (getpid() != pid_) {                 /* a forked child: the threads stayed with the parent */
+            for (auto &t : th_) {
+                t.detach();
+            }
+            return;
+        }
         stop_.store(true);
         gen_.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> lk(m_); }
