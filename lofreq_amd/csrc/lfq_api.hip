@@ -2270,12 +2270,16 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     }
     LfqBaqRead *h = (LfqBaqRead *)c->h_pin;
     int32_t *order = (int32_t *)(c->h_pin + h_bytes);
-    std::unique_ptr<int32_t[]> width(new int32_t[(size_t)n]);
+    /* (from the context's pinned pool: fresh memory would be page-faulted in by the threads below while the upload
+     * thread is pinning the caller's arrays -- the two fight over the address-space lock) */
+    LfqPin<int32_t> width(c, (size_t)n);
+    LFQ_PIN_OK(width);
     const bool use_lds = lfq_knobs().baq_lds != 0;
     int max_lq = 0, max_w = 0;
     int part_lq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, part_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t part_narrow[9] = {0}, part_band8[9] = {0}, part_plain[9] = {0};
-    std::unique_ptr<uint8_t[]> has_id(new uint8_t[(size_t)n]);      /* the read has an I or D operation (what idaq looks at) */
+    LfqPin<uint8_t> has_id(c, (size_t)n);                            /* the read has an I or D operation (what idaq looks at) */
+    LFQ_PIN_OK(has_id);
     const bool reg_kernel = lfq_knobs().baq_kernel == 0;    /* the register kernel also has a band-8 instantiation */
     int part_lrn[8] = {0}, part_lqn[8] = {0};
     int parts = 1;
