@@ -3276,13 +3276,20 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
         };
         {
-            std::vector<std::thread> th;
-            for (int t = 1; t < n_parts; t++) {
-                th.emplace_back(build, t);
-            }
-            build(0);
-            for (auto &x : th) {
-                x.join();
+            const std::function<void(int)> task = [&](int t) { build(t); };
+            LfqLoopPool &pool = LfqLoopPool::instance();
+            if (n_parts > 1 && pool.try_run(n_parts, task)) {
+                build(0);
+                pool.finish();
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < n_parts; t++) {
+                    th.emplace_back(build, t);
+                }
+                build(0);
+                for (auto &x : th) {
+                    x.join();
+                }
             }
         }
         int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
