@@ -366,7 +366,9 @@ int lfq_pileup_skip_snv_columns(lfq_ctx *ctx, const uint8_t *skip, int64_t ncols
  * Completion: lfq_readset_create may return while its copies are still in flight (a helper thread feeds them to an
  * upload stream) and lfq_readset_baq returns when its kernels are queued; every later call on the read set waits for
  * what it needs, lfq_readset_destroy for everything.  The caller sees no difference as long as the host arrays stay
- * as they are until the read set is destroyed (they must outlive it anyway). */
+ * as they are until the read set is destroyed (they must outlive it anyway).
+ * A read set belongs to its context: destroy it before lfq_destroy(ctx) (its device allocations go back to the context,
+ * which hands them to the next read set -- keep one context per worker from region to region). */
 typedef struct lfq_readset lfq_readset;
 int lfq_readset_create(lfq_ctx *ctx, const lfq_pileup_reads *reads, const lfq_pileup_indel_tags *tags_or_null,
                        lfq_readset **out);
