@@ -121,6 +121,8 @@ class SnvCaller:
 
     def close(self):
         if getattr(self, "h", None):
+            for rs in list(getattr(self, "_readsets", ())):     # a read set is destroyed before its context
+                rs.close()
             self.L.lfq_destroy(self.h)
             self.h = None
 

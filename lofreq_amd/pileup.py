@@ -222,6 +222,10 @@ class ReadSet:
         h = C.c_void_p()
         _lib.check(self.L.lfq_readset_create(caller.h, C.byref(rd), C.byref(tags), C.byref(h)), "lfq_readset_create")
         self.h = h
+        if not hasattr(caller, "_readsets"):
+            import weakref
+            caller._readsets = weakref.WeakSet()
+        caller._readsets.add(self)                  # SnvCaller.close() closes its read sets first
 
     def close(self):
         if getattr(self, "h", None):

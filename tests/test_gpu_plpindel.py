@@ -378,3 +378,29 @@ def test_host_loops_parallel_equals_serial(tmp_path):
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert json.loads(r.stdout.strip().splitlines()[-1]) == outs[0], mode
+
+
+def test_context_closed_before_its_read_set():
+    """a read set hands its device allocations back to its context on destruction: SnvCaller.close() therefore closes
+    the context's read sets first, and closing them again afterwards is a no-op"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(5)
+    glen = 2000
+    genome = rng.integers(0, 4, glen).astype(np.uint8)
+    ref = "".join("ACGT"[c] for c in genome).encode()
+    reads = _random_indel_reads(rng, 200, glen, genome)
+    own = la.SnvCaller(0)
+    rs = la.ReadSet(own, reads, ref)
+    rs.baq(extended=True, idaq=True)
+    rs2 = la.ReadSet(own, reads, ref)               # takes over nothing yet: rs is still alive
+    rs2.close()
+    rs3 = la.ReadSet(own, reads, ref)               # ... and this one the allocations rs2 gave back
+    rs3.baq(extended=True, idaq=True)
+    a = rs.fetch_tags(idaq=True)
+    b = rs3.fetch_tags(idaq=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    own.close()
+    assert rs.h is None and rs3.h is None
+    rs.close()
+    rs3.close()
