@@ -87,6 +87,12 @@ def parse_args():
                     help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
     ap.add_argument("--workers", type=int, default=1,
                     help="--mode chain: region workers (processes) sharing the GPU, as call-parallel runs one per bin")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed blocks of --steps steps: the first one is the reported value, all of them go into `repeats`")
+    ap.add_argument("--no-full-check", action="store_true",
+                    help="N = 1: skip the whole-batch oracle run on all host cores (config.vcf_concordance then covers the "
+                         "cpu_baseline sample only)")
+    ap.add_argument("--full-check-procs", type=int, default=None, help="oracle processes of the whole-batch check")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -223,10 +229,14 @@ def live_pmc(child_args, count_kernel):
 def bench_host_abi(caller, la, seed, depth, ncols, plant_period, steps):
     """Host buffers through lfq_call_snvs_batch(tracks_on_device = 0): what the plp_proc_func shim does per flush
     (integration/lofreq_amd_shim.c).  PCIe upload included; bytes = the four byte tracks + headers."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import pyoracle as orc
-    orc.build()
-    host = orc.synth_fill(seed, depth, plant_period, 0, ncols)
+    # the workload of include/lofreq_synth.h, generated on the device in the byte layout and copied to (pageable) host
+    # arrays: what a caller outside this benchmark holds
+    dev_b = caller.synth_batch(seed, depth, ncols, plant_period=plant_period, nt_packed=False)
+    n = ncols * depth
+    host = {"nt": dev_b.nt[:n].cpu().numpy().copy(), "bq": dev_b.bq[:n].cpu().numpy().copy(),
+            "baq": dev_b.baq[:n].cpu().numpy().copy(), "mq": dev_b.mq[:n].cpu().numpy().copy(),
+            "col_off": dev_b.col_off.cpu().numpy().astype(np.uint64), "ref_base": dev_b.ref_base[:ncols].cpu().numpy().copy()}
+    del dev_b
     batch = la.PileupBatch(host["nt"], host["bq"], host["mq"], host["col_off"], host["ref_base"], baq=host["baq"],
                            max_col_obs=depth)
     n_obs = int(host["col_off"][-1])
@@ -471,18 +481,67 @@ def chain_workers(n_workers, iters):
                     "aggregate over the span from the first timed start to the last end"}
 
 
+def full_check(args, caller, la, batch, d_counts, d_pvals, pv_cap, seed, depth, ncols, default_filter, recs, text):
+    """The batch of the timed steps, whole, against the oracle on all host cores (oracle/full_check.py): the dense
+    integer outputs of the SAME count-kernel instantiation the timed steps ran (layer 1 on the resident batch), the
+    records and the VCF text of the last timed step.  On a host too small to finish in about a minute: every planted
+    column plus a stride."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import full_check as fc
+    import pyoracle as orc
+    orc.build()
+    conf = la.VarcallConf()
+    caller.snv_batch_device(batch, conf, d_counts, d_pvals, pv_cap)
+    st = caller.batch_finish()
+    counts = d_counts[: ncols * 64].cpu().numpy().view(la.COL_COUNTS_DTYPE).copy()
+    procs = args.full_check_procs or fc.default_procs()
+    est_s = ncols * depth * 1.7e-7 / procs              # ~1.6 ms per 10 000x column on one core of the bench hosts
+    columns = None
+    if est_s > 75.0:
+        stride = int(est_s / 45.0) + 1
+        planted = np.arange(0, ncols, max(args.plant_period, 1))
+        columns = np.union1d(planted, np.arange(0, ncols, stride))
+    out = fc.check_batch(orc, seed, depth, args.plant_period, ncols, counts, recs, gpu_vcf_text=text,
+                         default_filter=default_filter, procs=procs, columns=columns)
+    out["scope"] = "every column of the timed batch" if columns is None else \
+        "planted columns + every %d-th column (host too small for all of them)" % stride
+    out["tested_columns"] = int(st.n_tested)
+    return out
+
+
+def spawn_ranks(n):
+    """re-exec this command under torch.distributed.run with n ranks on this node; -> exit code"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs across processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     cfg_idx, cfg_depth, cfg_cols, cfg_filter, cfg_sample = CONFIGS[args.config]
     depth = args.depth or cfg_depth
     ncols = args.cols or cfg_cols
     seed = seed_of(3 if args.config == "C3" else 2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: launch the N ranks (one process per GPU) the way the driver does --
+        # the reference's parallel wrapper forks its own workers too (lofreq2_call_pparallel.py:590-667)
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # LFQ_BENCH_ONE_GPU=1 (debugging the N > 1 loop on a one-GPU box): every rank on cuda:0, exchange over gloo
@@ -492,11 +551,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     xdev = "cpu" if one_gpu else dev              # where the exchanged tensors live
+    comm_ranks = 1
     if world > 1:
+        if not one_gpu and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: %d ranks but %d visible GPUs (LFQ_BENCH_ONE_GPU=1 puts every rank on cuda:0 "
+                             "with the exchange over gloo)" % (world, torch.cuda.device_count()))
         if one_gpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+        # the communicator's own idea of the job: a sum of ones over its ranks (RCCL all-reduce over xGMI on GPUs)
+        ones = torch.ones(1, dtype=torch.int64, device=xdev)
+        dist.all_reduce(ones)
+        comm_ranks = int(ones.item())
+        if comm_ranks != world:
+            raise SystemExit("bench.py: communicator spans %d ranks, expected %d" % (comm_ranks, world))
 
     import lofreq_amd as la
     from lofreq_amd import shard
@@ -688,21 +757,30 @@ def main():
 
         run_steps(max(args.warmup, 2))              # both contexts warm (workspace allocations)
 
-    kt_acc = None
-    barrier()
-    t0 = time.perf_counter()
-    if pipelined:
-        (conf, st, recs, text, kt), kt_acc = run_steps(args.steps)
-    else:
-        for _ in range(args.steps):
-            conf, st, recs, text, kt = step()
-            kt_acc = kt if kt_acc is None else {k: kt_acc[k] + kt[k] for k in kt}
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_block():
+        """EXACTLY --steps steps between two barrier + synchronize pairs -> (seconds: max over ranks, last step, kernel times)"""
+        acc = None
+        barrier()
+        t0 = time.perf_counter()
+        if pipelined:
+            out, acc = run_steps(args.steps)
+        else:
+            for _ in range(args.steps):
+                out = step()
+                acc = out[4] if acc is None else {k: acc[k] + out[4][k] for k in acc}
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=xdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out, acc
+
+    # the reported value is the FIRST block after the warm-up; the further blocks only show the run's own spread
+    elapsed, (conf, st, recs, text, kt), kt_acc = timed_block()
+    block_s = [elapsed]
+    for _ in range(max(args.repeats, 1) - 1):
+        block_s.append(timed_block()[0])
     work = (callers[(args.steps - 1) % 2] if pipelined else caller).dp_work()
 
     if rank == 0:
@@ -743,6 +821,13 @@ def main():
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "repeats": {"blocks": len(block_s), "steps_per_block": args.steps,
+                        "ms_per_step_first": 1e3 * block_s[0] / steps,
+                        "ms_per_step_min": 1e3 * min(block_s) / steps,
+                        "ms_per_step_median": 1e3 * float(np.median(block_s)) / steps,
+                        "ms_per_step_max": 1e3 * max(block_s) / steps,
+                        "note": "`value` / `ms_per_step` are the first block (the contract's K steps after W warm-up steps); "
+                                "the other blocks are the same K steps timed again"},
             "config": {
                 "workload": "%s: synthetic %.0f Mb genome per GPU, uniform %dx depth, SNV-only, %s, dynamic Bonferroni "
                             "(BASELINE.json configs[%d])"
@@ -750,6 +835,7 @@ def main():
                                "default filter applied" if cfg_filter else "--no-default-filter", cfg_idx),
                 "columns_per_gpu": my_cols, "bins_rank0": len(my_bins) if my_bins is not None else 1, "depth": depth, "planted_snv_period": args.plant_period,
                 "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
+                "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
@@ -793,6 +879,15 @@ def main():
             line["config"]["vcf_concordance"] = {"sample_columns": sample, "reference_records": len(exp),
                                                  "gpu_records": len(got), "identical": exp == got}
             line["config"]["speedup_vs_cpu_1thread"] = value / base["value"]
+        if world == 1 and not args.no_full_check and my_bins is None:
+            # the whole timed batch against the oracle: every column's integer outputs, every record, the VCF text
+            # (the reference's own full-size check compares whole VCFs, tests/parallel.sh:40-51)
+            try:
+                line["config"]["vcf_concordance_sample"] = line["config"].get("vcf_concordance")
+                line["config"]["vcf_concordance"] = full_check(args, caller, la, batch, d_counts, d_pvals, pv_cap, seed,
+                                                                depth, my_cols, cfg_filter, recs, text)
+            except Exception as e:
+                line["config"]["vcf_concordance"] = {"error": repr(e), "identical": False}
         if world == 1 and not args.no_secondary:
             sec = {}
             try:

@@ -177,7 +177,11 @@ int lfq_synchronize(lfq_ctx *ctx);
 /* All pointers in `tracks` and the outputs are DEVICE pointers.  `d_counts` holds ncols entries;
  * `d_pvals` holds pvals_capacity entries.  `bonf_base` is conf->bonf_subst before this batch.
  * `stream` is a hipStream_t (NULL = the context's own stream).  Asynchronous; `stats` is filled
- * by lfq_batch_finish(), which waits for the batch. */
+ * by lfq_batch_finish(), which waits for the batch.
+ * ONE batch in flight per context: a batch ends on an internal stream (its DP kernels), and what the library itself
+ * queues for the context afterwards (the next batch, a pileup or generator call that rewrites context-owned tracks) is
+ * ordered behind the batch's last event -- but the caller's own writes to d_counts / d_pvals / the tracks are not:
+ * call lfq_batch_finish() (or pass your stream, into which the batch is then joined) before touching them. */
 int lfq_snv_batch_device(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *tracks,
                          lfq_col_counts *d_counts, lfq_col_pvals *d_pvals, int64_t pvals_capacity,
                          void *stream);
@@ -413,7 +417,8 @@ int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
  * the host.  While batch k is collected, the kernels of batch k+1 (submitted on another context) run.  conf's
  * running Bonferroni factor is read at submit and advanced at collect, so batches in flight at the same time
  * need confs of their own -- independent regions, as call-parallel's bins are.  Host tracks handed to submit
- * (tracks_on_device = 0) must stay valid until collect. */
+ * (tracks_on_device = 0) must stay valid until collect.  A second submit on a context whose batch has not been
+ * collected returns LFQ_ERR_INVALID. */
 int lfq_call_snvs_submit(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *tracks, int tracks_on_device);
 /* blocks until the KERNELS of the submitted batch are done.  The pattern that keeps one GPU busy with two contexts:
  * wait(A); submit(B, next batch); collect(A) -- the host finish of batch k runs under the kernels of batch k + 1,
@@ -454,7 +459,9 @@ int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thr
  * replaced by (int)(af * n_err_probs) (float product, truncated), snpcaller(bonf 1, alpha 0.01f);
  * detectable[col] = pvalue * 1 < 0.01f, the condition under which uniq_snv adds the UNIQ flag.  Only the 'N'
  * reference gate applies (uniq_snv does not go through call_snvs).  pvalue_or_null[col] gets snpcaller's value for
- * the columns that were emitted (LDBL_MAX elsewhere: K = 0, or pruned as not significant). */
+ * the columns that were emitted (LDBL_MAX elsewhere: K = 0, or pruned as not significant).
+ * An AF outside [0, 1] is reset like the reference does (af < 0 -> 0.01, af > 1 -> 1.0, lofreq_uniq.c:262-268), here
+ * and in lfq_uniq_binom_batch; a NaN is LFQ_ERR_INVALID. */
 int lfq_uniq_detlim_batch(lfq_ctx *ctx, const lfq_tracks *tracks, int tracks_on_device, const float *af,
                           uint8_t *detectable, long double *pvalue_or_null);
 
@@ -520,7 +527,9 @@ int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);
  *     lfq_shard_rebase_bonferroni the shard-local running Bonferroni factors of the sparse p-value records become the
  *                                 single-process ones (3 tests per tested column of the earlier shards,
  *                                 lofreq_call.c:794-801); lfq_finalize_pvals then applies the exact emit test
- *     lfq_shard_gather_records    every rank's reported variants, in shard order, `col` made global by col_offset
+ *     lfq_shard_gather_records    every rank's reported variants, in shard order, `col` made global by col_offset;
+ *                                 every rank takes part whatever its `capacity` (0 on the ranks that do not want the
+ *                                 records): too little room returns LFQ_ERR_CAPACITY with *n_out = the total
  *     lfq_shard_advance_conf      conf->bonf_subst / num_snv_tests as after the single-process loop over all shards
  * `comm` is an ncclComm_t of RCCL (one rank per process, created by the caller: ncclCommInitRank) or NULL when
  * world == 1.  RCCL is looked up at run time (dlopen of librccl): the library has no link-time dependency on it.

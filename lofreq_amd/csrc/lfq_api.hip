@@ -56,6 +56,14 @@ static inline double lfq_now_ms()
  * 0.7 and 4.5 ms (BAQ geometry of 400 K reads, 4 threads; one thread: 2.4 ms).  These seven stay: after a loop they spin
  * for LFQ_HOST_SPIN_US (2000) microseconds waiting for the next one before they go to sleep.  One loop at a time
  * (try_run fails when another thread is using the pool, and in a forked child: the caller then creates threads). */
+#if defined(__x86_64__) || defined(__i386__)
+#define LFQ_CPU_PAUSE() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define LFQ_CPU_PAUSE() __asm__ __volatile__("yield")
+#else
+#define LFQ_CPU_PAUSE() std::this_thread::yield()
+#endif
+
 class LfqLoopPool {
 public:
     static LfqLoopPool &instance()
@@ -73,8 +81,10 @@ public:
         job_ = &task;
         want_ = parts - 1;
         pending_.store((int)th_.size(), std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_release);
-        if (sleepers_.load(std::memory_order_acquire) > 0) {
+        /* W gen_ then R sleepers_ here, W sleepers_ then R gen_ in the helper: sequentially consistent on both sides,
+         * so that at least one of them sees the other's write and no wake-up is lost on a weaker memory model */
+        gen_.fetch_add(1, std::memory_order_seq_cst);
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) {
             { std::lock_guard<std::mutex> lk(m_); }
             cv_.notify_all();
         }
@@ -83,7 +93,7 @@ public:
     void finish()                                                        /* after the caller's own part */
     {
         while (pending_.load(std::memory_order_acquire) > 0) {
-            __builtin_ia32_pause();
+            LFQ_CPU_PAUSE();
         }
         job_ = nullptr;
         call_m_.unlock();
@@ -93,7 +103,9 @@ private:
     LfqLoopPool() : pid_(getpid())
     {
         spin_us_ = lfq_knobs().host_spin_us;
-        const int n = spin_us_ < 0 ? 0 : 7;
+        /* the helpers spin between loops: a node's ranks share its cores (LOCAL_WORLD_SIZE processes) */
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency() / (unsigned)std::max(lfq_knobs().local_world_size, 1));
+        const int n = spin_us_ < 0 ? 0 : (int)std::min(7u, hw - 1u);
         for (int i = 0; i < n; i++) {
             th_.emplace_back([this, i] { loop(i); });
         }
@@ -107,7 +119,7 @@ private:
             return;
         }
         stop_.store(true);
-        gen_.fetch_add(1, std::memory_order_release);
+        gen_.fetch_add(1, std::memory_order_seq_cst);
         { std::lock_guard<std::mutex> lk(m_); }
         cv_.notify_all();
         for (auto &t : th_) {
@@ -121,12 +133,12 @@ private:
             const double t0 = lfq_now_ms();
             int polls = 0;
             while (gen_.load(std::memory_order_acquire) == seen) {
-                __builtin_ia32_pause();
+                LFQ_CPU_PAUSE();
                 if ((++polls & 255) == 0 && (lfq_now_ms() - t0) * 1e3 > (double)spin_us_) {
                     std::unique_lock<std::mutex> lk(m_);
-                    sleepers_.fetch_add(1, std::memory_order_release);
-                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-                    sleepers_.fetch_sub(1, std::memory_order_release);
+                    sleepers_.fetch_add(1, std::memory_order_seq_cst);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_seq_cst) != seen; });
+                    sleepers_.fetch_sub(1, std::memory_order_seq_cst);
                 }
             }
             if (stop_.load()) {
@@ -290,6 +302,7 @@ struct lfq_ctx {
     int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
     int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */
+    int batch_recorded;              /* ev[3] has been recorded: a batch of this context may still be running */
     const uint8_t *sub_ref_host;
     double sub_t0, sub_t1;
     const float *detlim_af;          /* device: per-column allele frequency while lfq_uniq_detlim_batch runs, else null */
@@ -790,6 +803,18 @@ int lfq_synchronize(lfq_ctx *c)
     return LFQ_OK;
 }
 
+/* A batch ends on the dps stream (the join in batch_device_impl), not on the stream it was launched on.  Everything
+ * the library itself queues afterwards that rewrites what the batch's DP kernels still read or write -- the next
+ * batch's counter / retry memsets, the staging copies of host tracks, the pileup's output tracks and num_bases, a
+ * generator fill -- waits for the batch's last event first.  One batch in flight per context (layer 1 too). */
+static int order_after_batch(lfq_ctx *c, hipStream_t st)
+{
+    if (c->batch_recorded) {
+        LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev[3], 0));
+    }
+    return LFQ_OK;
+}
+
 static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr, lfq_col_counts *d_counts,
                              lfq_col_pvals *d_pvals, int64_t pvals_capacity, void *stream_or_null,
                              bool indel_mode)
@@ -851,6 +876,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         }
     }
     c->cur_col_bytes = 8 + 1 + (T.coverage_plp ? 4 : 0) + (T.num_bases ? 4 : 0) + (P.detlim_af ? 4 : 0);
+    LFQ_TRY(order_after_batch(c, st));
     LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
     if (ncols > 0) {
         LFQ_TRY_HIP(hipMemsetAsync(c->d_retry, 0, (size_t)ncols, st));
@@ -860,6 +886,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         LFQ_TRY_HIP(hipMemcpyAsync(c->h_counters, c->d_counters,
                                    (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         LFQ_TRY_HIP(hipEventRecord(c->ev[3], st));
+        c->batch_recorded = 1;
         return LFQ_OK;
     }
 
@@ -1033,6 +1060,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         }
     }
     LFQ_TRY_HIP(hipEventRecord(c->ev[3], jn));
+    c->batch_recorded = 1;
     return LFQ_OK;
 }
 
@@ -1181,6 +1209,7 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
         const uint64_t n_obs = tr->col_off[ncols];
         const int64_t trk = (int64_t)((n_obs + 15) / 16 * 16) + 16;
         int64_t need = 5 * trk + (ncols + 1) * 8 + (ncols + 16) + 2 * (ncols * 4 + 16) + 64;
+        LFQ_TRY(order_after_batch(c, c->stream));      /* the previous batch may still read the staging area */
         LFQ_TRY(grow(&c->d_stage, &c->stage_bytes, need));
         uint8_t *p = c->d_stage;
         auto put = [&](const void *src, int64_t bytes, int64_t reserve) -> uint8_t * {
@@ -1225,7 +1254,9 @@ int lfq_call_snvs_submit(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr,
     if (!c || !conf || !tr || tr->ncols < 0) {
         return LFQ_ERR_INVALID;
     }
-    c->sub_ncols = -1;
+    if (c->sub_ncols >= 0) {
+        return LFQ_ERR_INVALID;         /* a submitted batch has not been collected: one batch in flight per context */
+    }
     c->sub_t0 = lfq_now_ms();
     if (tr->ncols == 0) {
         c->sub_ncols = 0;
@@ -2407,10 +2438,14 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     } else if (want_idaq && !rs->d_ai) {
         return LFQ_ERR_INVALID;                 /* a second BAQ pass that suddenly wants ai / ad: make a new read set */
     }
-    float h_q2p[256];
-    for (int i = 0; i < 256; i++) {
-        h_q2p[i] = (float)pow(10, -i / 10.);                 /* kprobaln_ext.c:121-123 */
-    }
+    /* the quality table outlives the call: the copy below is asynchronous and this function returns when it is queued */
+    static const float *const h_q2p = [] {
+        static float t[256];
+        for (int i = 0; i < 256; i++) {
+            t[i] = (float)pow(10, -i / 10.);                 /* kprobaln_ext.c:121-123 */
+        }
+        return (const float *)t;
+    }();
     /* per-call device data: geometry, launch order, the quality table (the reads themselves are resident) */
     uint8_t *d_blob = nullptr;
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
@@ -2659,6 +2694,7 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     /* per-position counters (kept until the next call) */
     const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
                   total = o_cidx + al(width * 4);
+    LFQ_TRY(order_after_batch(c, c->stream));          /* the tracks of the previous call may still be a running batch's input */
     LFQ_TRY(grow(&c->d_plp_in, &c->plp_in_bytes, total));
     uint8_t *d = c->d_plp_in;
     LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), c->stream));
@@ -3400,6 +3436,15 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     return LFQ_OK;
 }
 
+/* lofreq_uniq.c:262-268: an AF parsed from the VCF that is out of bounds is reset, not rejected */
+static inline float lfq_uniq_reset_af(float af)
+{
+    if (af < 0.0 || af > 1.0) {
+        return af < 0.0 ? 0.01f : 1.0f;
+    }
+    return af;
+}
+
 /* uniq_snv with --use-det-lim (lofreq_uniq.c:274-333) for a batch of columns: the default varcall_conf
  * (init_varcall_conf), alt_counts = {(int)(af * n_err_probs), 0, 0}, snpcaller(bonf 1, alpha 0.01f) */
 int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, const float *af,
@@ -3412,12 +3457,18 @@ int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device
     if (ncols == 0) {
         return LFQ_OK;
     }
-    for (int64_t i = 0; i < ncols; i++) {
-        if (!(af[i] >= 0.0f && af[i] <= 1.0f)) {
-            return LFQ_ERR_INVALID;                     /* the reference rejects such an AF too (:262-268) */
-        }
-    }
+    /* an AF outside [0, 1] is logged and RESET by the reference (af < 0 -> 0.01, af > 1 -> 1.0, lofreq_uniq.c:262-268:
+     * LOG_FATAL there does not exit) and the variant is processed with the new value; a NaN passes both comparisons
+     * there and is refused here */
     LFQ_TRY_HIP(hipSetDevice(c->device));
+    LfqPin<float> h_af(c, (size_t)ncols);
+    LFQ_PIN_OK(h_af);
+    for (int64_t i = 0; i < ncols; i++) {
+        if (af[i] != af[i]) {
+            return LFQ_ERR_INVALID;
+        }
+        h_af[(size_t)i] = lfq_uniq_reset_af(af[i]);
+    }
     lfq_conf conf;
     lfq_conf_init(&conf);
     conf.bonf_dynamic = 0;
@@ -3428,7 +3479,7 @@ int lfq_uniq_detlim_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device
     LFQ_TRY(grow(&c->d_counts, &c->counts_cap, ncols));
     LFQ_TRY(grow(&c->d_pvals, &c->pvals_cap, ncols));
     LFQ_TRY(grow(&c->d_detlim, &c->detlim_cap, ncols));
-    LFQ_TRY_HIP(hipMemcpyAsync(c->d_detlim, af, (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(c->d_detlim, h_af.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
     c->detlim_af = c->d_detlim;
     int rc = lfq_snv_batch_device(c, &conf, &dev, c->d_counts, c->d_pvals, c->pvals_cap, c->stream);
     c->detlim_af = nullptr;
@@ -3517,7 +3568,7 @@ int lfq_uniq_binom_batch(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device,
         const int32_t *cn = &h_nt[(size_t)i * 4];
         const int alt_count = code < 4 ? cn[code] : n_col - cn[0] - cn[1] - cn[2] - cn[3];
         int st = 0;
-        const double pv = lfq_binom_cdf(coverage, alt_count, (double)af[i], &st);   /* :381; one-sided */
+        const double pv = lfq_binom_cdf(coverage, alt_count, (double)lfq_uniq_reset_af(af[i]), &st);   /* :262-268, :381; one-sided */
         if (st != 0) {
             continue;                                           /* "binom() failed": no UQ tag */
         }
@@ -3542,6 +3593,7 @@ int lfq_pileup_skip_snv_columns(lfq_ctx *c, const uint8_t *skip, int64_t ncols)
     LfqPin<uint8_t> h(c, (size_t)ncols);
     LFQ_PIN_OK(h);
     memcpy(h.data(), skip, (size_t)ncols);
+    LFQ_TRY(order_after_batch(c, c->stream));
     LFQ_TRY(grow(&c->d_tmp[2], &c->tmp_bytes[2], ncols));
     LFQ_TRY_HIP(hipMemcpyAsync(c->d_tmp[2], h.data(), (size_t)ncols, hipMemcpyHostToDevice, c->stream));
     LFQ_TRY(lfq_launch_skip_columns(c->d_plp_nb, c->d_tmp[2], ncols, c->stream));
@@ -3696,6 +3748,7 @@ int lfq_synth_fill_device_layout(lfq_ctx *c, uint64_t seed, uint32_t depth, uint
         s.err_thresh[q] = (t >= 18446744073709551615.0L) ? UINT64_MAX : (uint64_t)t;
     }
     hipStream_t st = stream_or_null ? (hipStream_t)stream_or_null : c->stream;
+    LFQ_TRY(order_after_batch(c, st));                 /* the target may be the tracks of a batch that is still running */
     return lfq_launch_synth(&s, col_begin, ncols, d_nt, d_bq, d_baq, d_mq, d_col_off, d_ref_base, nt_packed ? 1 : 0, st);
 }
 
@@ -3821,12 +3874,11 @@ int lfq_shard_gather_records(lfq_ctx *c, void *comm, int world, int rank, const 
         most = std::max(most, counts[(size_t)r]);
     }
     *n_out = total;
-    if (total > capacity) {
-        return LFQ_ERR_CAPACITY;
-    }
-    if (most == 0) {
+    if (most == 0) {                /* the same on every rank: nobody enters the second collective */
         return LFQ_OK;
     }
+    /* `capacity` is a local value (a caller may want the records on rank 0 only): the decision to enter the second
+     * all-gather must not depend on it, or the ranks with enough room wait for ever for the ones without */
     std::vector<lfq_snv_record> mine((size_t)most), all((size_t)most * world);
     memset((void *)mine.data(), 0, (size_t)most * sizeof(lfq_snv_record));
     for (int64_t i = 0; i < n; i++) {
@@ -3836,9 +3888,9 @@ int lfq_shard_gather_records(lfq_ctx *c, void *comm, int world, int rank, const 
     LFQ_TRY(shard_allgather_bytes(c, comm, world, rank, mine.data(), (size_t)most * sizeof(lfq_snv_record), all.data()));
     int64_t o = 0;
     for (int r = 0; r < world; r++) {
-        for (int64_t i = 0; i < counts[(size_t)r]; i++) {
+        for (int64_t i = 0; i < counts[(size_t)r] && o < capacity; i++) {
             out[o++] = all[(size_t)r * most + (size_t)i];
         }
     }
-    return LFQ_OK;
+    return total > capacity ? LFQ_ERR_CAPACITY : LFQ_OK;      /* *n_out says how many there are */
 }

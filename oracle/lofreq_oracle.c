@@ -308,6 +308,81 @@ int orc_snpcaller(long double pv_out[3], double logp_out[3], const double *ep, i
     return 0;
 }
 
+/* ---- ground truth for the tolerance story (NOT a restatement of reference code) --------------------
+ * The tail probabilities P(X >= counts[i]) of the Poisson-binomial distribution the reference's
+ * pruned_calc_prob_dist (snpcaller.c:831-972) iterates in log space, here as the plain linear-space
+ * recurrence  v[k] <- v[k]*(1-p) + v[k-1]*p  with the absorbing tail at K = max(counts)
+ * in x87 80-bit long double: 64-bit mantissa, one rounding of 2^-64 per operation, range down to 1e-4932.
+ * No pruning, no Bonferroni factor, any row order (the distribution does not depend on it).  Used by the
+ * tests to show how far the reference's own log-space chain (and the device's scaled-double recurrence)
+ * are from the exact value.  Returns 0, or -1 when out of memory / K == 0.  tails_log[i] = logl(tail), NAN
+ * where counts[i] == 0; a tail below LDBL_MIN (denormal / zero) is reported as -INFINITY. */
+int orc_tail_truth(long double tails[3], double tails_log[3], const double *ep, int n_ep, const int counts[3])
+{
+    long double *v;
+    int i, k, n, kmax = 0;
+
+    for (i = 0; i < 3; i++) {
+        tails[i] = 0.0L;
+        tails_log[i] = NAN;
+        if (counts[i] > kmax) {
+            kmax = counts[i];
+        }
+    }
+    if (kmax == 0) {
+        return -1;
+    }
+    v = calloc((size_t)kmax + 1, sizeof(long double));
+    if (!v) {
+        return -1;
+    }
+    v[0] = 1.0L;
+    for (n = 0; n < n_ep; n++) {
+        long double p = (long double)ep[n], q = 1.0L - p;
+        int top = n + 1 < kmax ? n + 1 : kmax;           /* cells above the row index are still 0 */
+        if (top == kmax) {
+            v[kmax] += v[kmax - 1] * p;                  /* absorbing tail: P(X >= K) */
+            top = kmax - 1;
+        }
+        for (k = top; k >= 1; k--) {
+            v[k] = v[k] * q + v[k - 1] * p;
+        }
+        v[0] *= q;
+    }
+    for (i = 0; i < 3; i++) {
+        long double t = 0.0L;
+        if (counts[i] == 0) {
+            continue;
+        }
+        for (k = kmax; k >= counts[i]; k--) {            /* smallest terms first */
+            t += v[k];
+        }
+        tails[i] = t;
+        tails_log[i] = (t >= LDBL_MIN) ? (double)logl(t) : -INFINITY;
+    }
+    free(v);
+    return 0;
+}
+
+/* orc_tail_truth for one packed column: the error probabilities come from orc_col_errprobs (the pinned
+ * restatement of plp_to_errprobs), everything after it is the 80-bit recurrence above. */
+int orc_col_tail_truth(long double tails[3], double tails_log[3], int counts_out[3],
+                       const uint8_t *nt, const uint8_t *bq, const uint8_t *baq, const uint8_t *mq,
+                       const uint8_t *sq, int64_t n_obs, char ref_base, const orc_conf *conf)
+{
+    double *ep = malloc(sizeof(double) * (size_t)(n_obs > 0 ? n_obs : 1));
+    int n_ep = 0, alt_base[3], alt_raw[3], rc;
+    if (!ep) {
+        return -1;
+    }
+    rc = orc_col_errprobs(ep, &n_ep, alt_base, counts_out, alt_raw, nt, bq, baq, mq, sq, n_obs, ref_base, conf);
+    if (rc == 0) {
+        rc = orc_tail_truth(tails, tails_log, ep, n_ep, counts_out);
+    }
+    free(ep);
+    return rc;
+}
+
 static int orc_unpack_q(uint8_t v)
 {
     return (v == ORC_Q_MISSING) ? -1 : (int)v;

@@ -208,6 +208,49 @@ def snpcaller(err_probs, counts, bonf, sig):
     return pv, [lp[i] for i in range(3)], rows.value
 
 
+def tail_truth(err_probs, counts):
+    """orc_tail_truth: the tail probabilities P(X >= counts[i]) by the 80-bit linear-space recurrence (ground
+    truth of the tolerance story, not reference code) -> (tails np.longdouble[3], natural logs float[3])"""
+    ep = np.ascontiguousarray(err_probs, dtype=np.float64)
+    tails = np.zeros(3, np.longdouble)
+    logs = (C.c_double * 3)()
+    cnt = (C.c_int * 3)(*[int(x) for x in counts])
+    L = lib()
+    L.orc_tail_truth.restype = C.c_int
+    L.orc_tail_truth.argtypes = [_ldp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+    rc = L.orc_tail_truth(tails.ctypes.data_as(_ldp), logs, ep.ctypes.data_as(C.POINTER(C.c_double)), len(ep), cnt)
+    if rc:
+        raise RuntimeError("orc_tail_truth failed (all counts zero?)")
+    return tails, [logs[i] for i in range(3)]
+
+
+def col_tail_truth(host, col, conf):
+    """orc_col_tail_truth on column `col` of packed host tracks (dict as tests/util.py builds them)
+    -> (tails np.longdouble[3], natural logs float[3], filtered alt counts[3])"""
+    a, b = int(host["col_off"][col]), int(host["col_off"][col + 1])
+    keep, ptrs = [], []
+    for k in ("nt", "bq", "baq", "mq", "sq"):
+        v = host.get(k)
+        if v is None:
+            ptrs.append(None)
+        else:
+            arr = np.ascontiguousarray(v[a:b], np.uint8)
+            keep.append(arr)
+            ptrs.append(arr.ctypes.data)
+    tails = np.zeros(3, np.longdouble)
+    logs = (C.c_double * 3)()
+    cnt = (C.c_int * 3)()
+    L = lib()
+    L.orc_col_tail_truth.restype = C.c_int
+    L.orc_col_tail_truth.argtypes = [_ldp, C.POINTER(C.c_double), C.POINTER(C.c_int)] + [C.c_void_p] * 5 + \
+        [C.c_int64, C.c_char, C.POINTER(Conf)]
+    rc = L.orc_col_tail_truth(tails.ctypes.data_as(_ldp), logs, cnt, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                              b - a, bytes([int(host["ref_base"][col])]), C.byref(conf))
+    if rc:
+        raise RuntimeError("orc_col_tail_truth failed")
+    return tails, [logs[i] for i in range(3)], [cnt[i] for i in range(3)]
+
+
 def prob_to_phred(p):
     """PROB_TO_PHREDQUAL on an np.longdouble without losing the 80-bit range."""
     a = np.array([p], np.longdouble)

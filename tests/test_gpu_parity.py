@@ -434,3 +434,92 @@ def test_config_c2_depth1000_default_filter(caller, oracle):
     text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
     lines = text.strip().split("\n")
     assert len(lines) == int(keep.sum()) and all(ln.split("\t")[6] == "PASS" for ln in lines)
+
+
+@pytest.mark.timeout(900)
+def test_config_c3_full_batch(caller, oracle):
+    """BASELINE.json configs[2] (C3) at FULL size: the resident 10^6-column x 10 000x batch the benchmark times -- the
+    work distribution that only exists there (eight per-XCD queues over 997 k light columns, the screen kernel's KREG
+    instantiation chosen from the previous batch's histogram: <8> on a context's first step, <10> afterwards, the
+    4096-segment pool budgets).  Step 1 and step 2 of the same context must return the same records; the batch is
+    compared with the oracle run on all host cores (oracle/full_check.py): every column's integer outputs, every record,
+    the VCF text -- or, on a host with few cores, every planted column plus a stride of 20 000 columns."""
+    import os
+    import full_check as fc
+    import lofreq_amd as la
+    import torch
+    seed, depth, ncols, period = 0x9E3779B97F4A7C15 ^ (3 << 32), 10000, 1000000, 997
+    own = la.SnvCaller(0)                               # a fresh context: its first step is really a first step
+    own.set_dense_strand_counts(False)
+    try:
+        batch = own.synth_batch(seed, depth, ncols, plant_period=period)
+        steps = []
+        for _ in range(2):
+            conf = la.VarcallConf()
+            recs, _, st = own.call_snvs(batch, conf, records_capacity=1 << 16)
+            steps.append((recs, int(st.n_tested), int(conf.bonf_subst), own.dp_work()))
+        assert steps[0][0].tobytes() == steps[1][0].tobytes() and steps[0][1:3] == steps[1][1:3]
+        recs, n_tested, bonf = steps[1][:3]
+        assert len(recs) >= 700 and bonf == 3 * n_tested
+        thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
+        text = la.format_vcf(recs, "synth", keep=la.filter_records(recs, thr, apply_defaults=False), filter_str="PASS")
+        # dense integer outputs of the same (lazy strand count) instantiation: layer 1 on the resident batch
+        dev = torch.device("cuda", 0)
+        d_counts = torch.zeros(ncols * 64, dtype=torch.uint8, device=dev)
+        d_pvals = torch.zeros(ncols * 128, dtype=torch.uint8, device=dev)
+        own.snv_batch_device(batch, la.VarcallConf(), d_counts, d_pvals, ncols)
+        st = own.batch_finish()
+        assert int(st.n_tested) == n_tested
+        counts = d_counts.cpu().numpy().view(la.COL_COUNTS_DTYPE).copy()
+        del d_counts, d_pvals
+    finally:
+        del batch
+        own.close()
+        torch.cuda.empty_cache()
+    procs = fc.default_procs()
+    cols = None
+    if procs < 48 or os.environ.get("LFQ_C3_SAMPLE") == "1":
+        cols = np.union1d(np.arange(0, ncols, period), np.arange(0, ncols, 50))
+    out = fc.check_batch(oracle, seed, depth, period, ncols, counts, recs, gpu_vcf_text=text, columns=cols, procs=procs)
+    print("C3 full batch: %s" % {k: v for k, v in out.items() if k != "mismatches"})
+    assert out["identical"], out["mismatches"]
+    assert out["records_compared"] == (len(recs) if cols is None else int(np.isin(recs["col"], cols).sum()))
+    assert out["columns_compared"] == (ncols if cols is None else len(cols))
+    if cols is None:
+        assert out["vcf_text_identical"] and out["vcf_lines"] > 0
+
+
+def test_deep_tail_against_80bit_truth(caller, oracle):
+    """The tolerance story of DESIGN 5, on the DEVICE's values: every p-value beyond |log p| = 600 of deep columns
+    (K from ~100 to ~2500 at 10 000x: light, mid, row-split and unsplit routes) against the 80-bit linear-space
+    recurrence (orc_tail_truth) -- bar 2e-11 -- next to the reference's own log-space chain (the oracle), whose distance
+    from the same truth is what the oracle-relative bar of 1e-9 pays for."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(2024)
+    afs = [0.015, 0.02, 0.03, 0.05, 0.08, 0.12, 0.16, 0.2, 0.24, 0.04, 0.1, 0.0]
+    planted = {c: af for c, af in enumerate(afs * 3) if af > 0}
+    host = util.random_batch(rng, len(afs) * 3, 9000, 10000, planted=planted)
+    kw = dict(bonf_dynamic=0, bonf_subst=1, sig=1.0)           # nothing pruned: every allele has a value
+    ores, oconf = util.run_oracle(oracle, host, **kw)
+    counts, pvals, st = util.run_layer1(la, caller, host, la.VarcallConf(**kw))
+    util.assert_counts_equal(counts, ores, host)
+    worst_dev, worst_ref, n = 0.0, 0.0, 0
+    for p in pvals:
+        c = int(p["col"])
+        tails, tlog, cnt = oracle.col_tail_truth(host, c, oconf)
+        assert cnt == [int(x) for x in ores["alt_counts"][c]]
+        for a in range(3):
+            if cnt[a] == 0 or int(p["status"][a]) != la.LFQ_PV_LOG:
+                continue
+            if not np.isfinite(tlog[a]) or abs(tlog[a]) <= util.PV_DEEP_LOG or tlog[a] < -11300.0:
+                continue
+            d_dev = abs(float(p["logp"][a]) - tlog[a])
+            d_ref = abs(float(ores["logp"][c, a]) - tlog[a])
+            worst_dev, worst_ref, n = max(worst_dev, d_dev), max(worst_ref, d_ref), n + 1
+            assert d_dev <= 2e-11, (c, a, float(p["logp"][a]), tlog[a], d_dev)
+            # and the p-value the host hands out (expl of that log) against expl of the truth
+            gpv = la.pvalue_from_log(p["logp"][a], int(p["status"][a]))
+            assert abs(util.log_of(gpv) - tlog[a]) <= 2e-11
+    print("deep tail vs 80-bit truth over %d p-values: device %.3g, reference log-space chain %.3g" % (n, worst_dev, worst_ref))
+    assert n >= 20, n
+    assert worst_ref <= 1e-9

@@ -84,3 +84,38 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     for k in la.SNV_RECORD_DTYPE.names:
         if k != "pad_":
             assert (got[k] == exp[k]).all(), k
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (torch.distributed.run, one process per
+    rank) and prints ONE line with n_gpus = 2; on this one-GPU box both ranks share cuda:0 and exchange over gloo
+    (LFQ_BENCH_ONE_GPU=1).  A world size that contradicts --gpus is refused."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LFQ_BENCH_ONE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--cols", "40000", "--repeats", "2"], env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["columns_per_gpu"] == 40000 and d["value"] > 0 and d["repeats"]["blocks"] == 2
+    # the same shard alone: twice the columns per step with two ranks
+    p1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                         "--cols", "40000", "--no-pmc", "--no-cpu-baseline", "--no-secondary", "--no-full-check"],
+                        env=env, capture_output=True, text=True, timeout=500)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    d1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["config"]["records_per_step"] > 0
+    # --gpus 2 under a launcher that started one rank: refused
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29513")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        env=env2, capture_output=True, text=True, timeout=200)
+    assert p2.returncode != 0 and "WORLD_SIZE" in (p2.stderr + p2.stdout)
