@@ -27,6 +27,7 @@
 #ifndef LOFREQ_AMD_H
 #define LOFREQ_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -170,6 +171,15 @@ int lfq_abi_version(void);
 const char *lfq_strerror(int status);
 void lfq_conf_init(lfq_conf *conf);                 /* init_varcall_conf, snpcaller.c:627-651 */
 int lfq_create(lfq_ctx **ctx, int device_ordinal);  /* one context per GPU / stream */
+/* Which GPU a worker PROCESS takes.  The reference's parallel wrapper forks one `lofreq call -r <bin>` per worker
+ * (lofreq2_call_pparallel.py:640-667); with this every such process lands on a GPU of its own without the wrapper
+ * knowing about GPUs:  LFQ_DEVICE (an ordinal, taken literally)  >  LOCAL_RANK (torchrun-style launchers, modulo the
+ * device count)  >  the first free worker slot k of the node (a lock file <LFQ_SLOT_DIR or /tmp>/lofreq_amd.<uid>.slot<k>
+ * held for the life of the process: device k mod n, so W concurrent workers spread over the n GPUs and a slot is
+ * reused when its worker exits)  >  getpid() mod n.  n_devices <= 0: ask the HIP runtime.  Returns the ordinal
+ * (>= 0) for lfq_create, or a negative lfq_status; *slot_out_or_null gets the slot (or -1). */
+int lfq_device_count(void);
+int lfq_pick_device(int n_devices, int *slot_out_or_null);
 void lfq_destroy(lfq_ctx *ctx);
 int lfq_synchronize(lfq_ctx *ctx);
 
@@ -427,6 +437,13 @@ int lfq_call_snvs_wait(lfq_ctx *ctx);
 int lfq_call_snvs_collect(lfq_ctx *ctx, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
                           int64_t *n_records, lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out);
 
+/* second half for a SHARDED run (N processes, below): the batch's sparse records as the device wrote them -- shard-local
+ * running Bonferroni factors, no emit test yet.  The caller exchanges its test counts (lfq_shard_exchange_counts),
+ * rebases the factors (lfq_shard_rebase_bonferroni) and then runs lfq_finalize_pvals.  conf is not advanced
+ * (lfq_shard_advance_conf does that with the batch's stats->n_tested).  LFQ_ERR_CAPACITY: *n_pvals says how many. */
+int lfq_call_snvs_collect_pvals(lfq_ctx *ctx, lfq_col_pvals *pvals, int64_t pvals_capacity, int64_t *n_pvals,
+                                lfq_batch_stats *stats_out);
+
 /* host finishing step of layer 2, exposed for tests: sparse device records -> reported SNVs */
 int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t n_pvals,
                        const int32_t *coverage_plp_or_null, const uint8_t *ref_base,
@@ -534,6 +551,13 @@ int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);
  * `comm` is an ncclComm_t of RCCL (one rank per process, created by the caller: ncclCommInitRank) or NULL when
  * world == 1.  RCCL is looked up at run time (dlopen of librccl): the library has no link-time dependency on it.
  * lofreq_amd/shard.py is the same exchange on torch.distributed; tests/test_shard_c.py holds the two against each other. */
+/* A launcher that has no RCCL communicator (MPI, a shared directory, a test double) supplies the one collective the
+ * exchange needs: all-gather of `bytes` bytes per rank, host buffers, recv = world * bytes in rank order; 0 = ok.
+ * While set (process-wide; NULL restores RCCL) `comm` is ignored by the lfq_shard_* calls. */
+typedef int (*lfq_host_allgather_fn)(void *user, int world, int rank, const void *send, void *recv, size_t bytes);
+int lfq_shard_set_host_allgather(lfq_host_allgather_fn fn, void *user);
+/* the collective itself: `bytes` bytes of every rank, in rank order (all = world * bytes) */
+int lfq_shard_allgather(lfq_ctx *ctx, void *comm, int world, int rank, const void *mine, int64_t bytes, void *all);
 int lfq_shard_exchange_counts(lfq_ctx *ctx, void *comm, int world, int rank, const int64_t *local, int n,
                               int64_t *all_out /* [world][n] */, int64_t *prefix_out /* [n] */);
 int lfq_shard_rebase_bonferroni(lfq_col_pvals *pvals, int64_t n, int64_t prefix_tested);

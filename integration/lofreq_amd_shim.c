@@ -307,9 +307,14 @@ void lfq_call_flush(varcall_conf_t *conf)
     int rc;
 
     if (B.ncols == 0 && (!I.init || I.ncols == 0)) return;
-    if (!B.ctx && lfq_create(&B.ctx, 0) != LFQ_OK) {
-        LOG_FATAL("%s\n", "lofreq_amd: no usable MI355X / HIP device");
-        exit(1);
+    if (!B.ctx) {
+        /* one `lofreq call -r <bin>` per worker of the parallel wrapper (lofreq2_call_pparallel.py:640-667): each
+         * process takes a GPU of its own -- LFQ_DEVICE, LOCAL_RANK, or the first free worker slot of the node */
+        const int dev = lfq_pick_device(0, NULL);
+        if (dev < 0 || lfq_create(&B.ctx, dev) != LFQ_OK) {
+            LOG_FATAL("%s\n", "lofreq_amd: no usable MI355X / HIP device");
+            exit(1);
+        }
     }
     conf_to_lfq(conf, &lc);
     irec = indel_flush(conf, &lc, &n_irec);

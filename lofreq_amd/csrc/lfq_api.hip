@@ -22,6 +22,8 @@
 #include <atomic>
 #include <functional>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/file.h>
 #include <thread>
 #include <vector>
 
@@ -644,6 +646,78 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
 }  // namespace
 
 extern "C" {
+
+int lfq_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 0) {
+        return 0;
+    }
+    return ndev;
+}
+
+/* Which GPU a worker process takes (include/lofreq_amd.h).  The slot files are held (flock) for the life of the process:
+ * the descriptor is deliberately never closed. */
+int lfq_pick_device(int n_devices, int *slot_out)
+{
+    if (slot_out) {
+        *slot_out = -1;
+    }
+    if (n_devices <= 0) {
+        n_devices = lfq_device_count();
+    }
+    if (n_devices <= 0) {
+        return LFQ_ERR_NO_DEVICE;
+    }
+    auto env_int = [](const char *name, long *v) {
+        const char *e = getenv(name);
+        if (!e || !*e) {
+            return false;
+        }
+        char *end = nullptr;
+        const long x = strtol(e, &end, 10);
+        if (end == e || *end != 0 || x < 0) {
+            return false;
+        }
+        *v = x;
+        return true;
+    };
+    long v = 0;
+    if (env_int("LFQ_DEVICE", &v)) {
+        return v < n_devices ? (int)v : LFQ_ERR_INVALID;        /* an explicit ordinal is taken literally */
+    }
+    if (env_int("LOCAL_RANK", &v)) {
+        return (int)(v % n_devices);                            /* torchrun / mpirun style launchers */
+    }
+    static int held_slot = -1;                                  /* this process already holds a slot */
+    if (held_slot >= 0) {
+        if (slot_out) {
+            *slot_out = held_slot;
+        }
+        return held_slot % n_devices;
+    }
+    const char *dir = getenv("LFQ_SLOT_DIR");
+    if (!dir || !*dir) {
+        dir = "/tmp";
+    }
+    for (int k = 0; k < 64 * n_devices; k++) {
+        char path[512];
+        snprintf(path, sizeof(path), "%s/lofreq_amd.%ld.slot%d", dir, (long)getuid(), k);
+        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (fd < 0) {
+            break;                                              /* no usable directory: fall through to the pid rule */
+        }
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
+            held_slot = k;
+            if (slot_out) {
+                *slot_out = k;
+            }
+            return k % n_devices;
+        }
+        close(fd);
+    }
+    return (int)((long)getpid() % n_devices);
+}
 
 int lfq_create(lfq_ctx **out, int device_ordinal)
 {
@@ -1345,6 +1419,45 @@ int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, i
         *stats_out = st;
     }
     return rc;
+}
+
+/* second half for a sharded run: the sparse device records as they are (shard-local running Bonferroni factors, no
+ * emit test yet) -- the caller exchanges its test counts, rebases the factors (lfq_shard_rebase_bonferroni) and only
+ * then runs lfq_finalize_pvals.  conf is not touched. */
+int lfq_call_snvs_collect_pvals(lfq_ctx *c, lfq_col_pvals *pvals, int64_t pvals_capacity, int64_t *n_pvals,
+                                lfq_batch_stats *stats_out)
+{
+    if (!c || !n_pvals || c->sub_ncols < 0 || pvals_capacity < 0 || (pvals_capacity > 0 && !pvals)) {
+        return LFQ_ERR_INVALID;
+    }
+    *n_pvals = 0;
+    const int64_t ncols = c->sub_ncols;
+    c->sub_ncols = -1;
+    if (ncols == 0) {
+        if (stats_out) memset(stats_out, 0, sizeof(*stats_out));
+        return LFQ_OK;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    lfq_batch_stats st;
+    LFQ_TRY(lfq_batch_finish(c, &st));
+    if (c->leader) {        /* the strand-bias precompute of this batch is finished before its context is reused */
+        std::unique_lock<std::mutex> lk(*c->lm);
+        c->lcv->wait(lk, [&] { return c->sb_pending == 0 || c->leader_stop; });
+    }
+    if (stats_out) {
+        *stats_out = st;
+    }
+    *n_pvals = st.n_pvals;
+    if (st.n_pvals > pvals_capacity) {
+        return LFQ_ERR_CAPACITY;
+    }
+    if (st.n_pvals > 0) {
+        LfqPin<lfq_col_pvals> h_pv(c, (size_t)st.n_pvals);
+        LFQ_PIN_OK(h_pv);
+        LFQ_TRY_HIP(hipMemcpy(h_pv.data(), c->d_pvals, (size_t)st.n_pvals * sizeof(lfq_col_pvals), hipMemcpyDeviceToHost));
+        memcpy(pvals, h_pv.data(), (size_t)st.n_pvals * sizeof(lfq_col_pvals));
+    }
+    return LFQ_OK;
 }
 
 int lfq_call_snvs_batch(lfq_ctx *c, lfq_conf *conf, const lfq_tracks *tr, int tracks_on_device,
@@ -3779,9 +3892,16 @@ lfq_nccl_allgather_fn lfq_rccl_allgather()
     return fn;
 }
 
+lfq_host_allgather_fn g_host_allgather = nullptr;
+void *g_host_allgather_user = nullptr;
+
 /* all-gather of `bytes` bytes per rank through device staging buffers of the context */
 int shard_allgather_bytes(lfq_ctx *c, void *comm, int world, int rank, const void *mine, size_t bytes, void *all)
 {
+    if (world > 1 && g_host_allgather) {
+        /* a launcher-supplied host transport (MPI, files, a test double) instead of RCCL */
+        return g_host_allgather(g_host_allgather_user, world, rank, mine, all, bytes) == 0 ? LFQ_OK : LFQ_ERR_HIP;
+    }
     if (world == 1 || !comm) {
         if (world != 1) {
             return LFQ_ERR_INVALID;
@@ -3812,6 +3932,24 @@ int shard_allgather_bytes(lfq_ctx *c, void *comm, int world, int rank, const voi
     return LFQ_OK;
 }
 }  // namespace
+
+int lfq_shard_allgather(lfq_ctx *c, void *comm, int world, int rank, const void *mine, int64_t bytes, void *all)
+{
+    if (world < 1 || rank < 0 || rank >= world || bytes < 0 || (bytes > 0 && (!mine || !all))) {
+        return LFQ_ERR_INVALID;
+    }
+    if (bytes == 0) {
+        return LFQ_OK;
+    }
+    return shard_allgather_bytes(c, comm, world, rank, mine, (size_t)bytes, all);
+}
+
+int lfq_shard_set_host_allgather(lfq_host_allgather_fn fn, void *user)
+{
+    g_host_allgather = fn;
+    g_host_allgather_user = user;
+    return LFQ_OK;
+}
 
 int lfq_shard_exchange_counts(lfq_ctx *c, void *comm, int world, int rank, const int64_t *local, int n, int64_t *all_out,
                               int64_t *prefix_out)

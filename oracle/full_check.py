@@ -48,11 +48,32 @@ def _run_chunk(args):
     return out
 
 
-def default_procs():
+def cpu_budget():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a
+    container that shows 256 CPUs may be allowed the time of a dozen)"""
     try:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def default_procs():
+    n = cpu_budget()
     return max(1, n - 2 if n > 8 else n)
 
 

@@ -443,7 +443,7 @@ def test_config_c3_full_batch(caller, oracle):
     instantiation chosen from the previous batch's histogram: <8> on a context's first step, <10> afterwards, the
     4096-segment pool budgets).  Step 1 and step 2 of the same context must return the same records; the batch is
     compared with the oracle run on all host cores (oracle/full_check.py): every column's integer outputs, every record,
-    the VCF text -- or, on a host with few cores, every planted column plus a stride of 20 000 columns."""
+    the VCF text -- or, on a host with few cores, every planted column plus every 10th (50th) column."""
     import os
     import full_check as fc
     import lofreq_amd as la
@@ -479,7 +479,9 @@ def test_config_c3_full_batch(caller, oracle):
     procs = fc.default_procs()
     cols = None
     if procs < 48 or os.environ.get("LFQ_C3_SAMPLE") == "1":
-        cols = np.union1d(np.arange(0, ncols, period), np.arange(0, ncols, 50))
+        # ~1.6 ms of oracle per column and core: all 10^6 columns need ~27 core-minutes (the bench hosts grant 16 cores)
+        stride = 10 if procs >= 12 else 50
+        cols = np.union1d(np.arange(0, ncols, period), np.arange(0, ncols, stride))
     out = fc.check_batch(oracle, seed, depth, period, ncols, counts, recs, gpu_vcf_text=text, columns=cols, procs=procs)
     print("C3 full batch: %s" % {k: v for k, v in out.items() if k != "mismatches"})
     assert out["identical"], out["mismatches"]
@@ -491,12 +493,12 @@ def test_config_c3_full_batch(caller, oracle):
 
 def test_deep_tail_against_80bit_truth(caller, oracle):
     """The tolerance story of DESIGN 5, on the DEVICE's values: every p-value beyond |log p| = 600 of deep columns
-    (K from ~100 to ~2500 at 10 000x: light, mid, row-split and unsplit routes) against the 80-bit linear-space
+    (K from ~300 to ~1800 per allele at 10 000x: the mid and big classes, row-split and unsplit routes) against the 80-bit linear-space
     recurrence (orc_tail_truth) -- bar 2e-11 -- next to the reference's own log-space chain (the oracle), whose distance
     from the same truth is what the oracle-relative bar of 1e-9 pays for."""
     import lofreq_amd as la
     rng = np.random.default_rng(2024)
-    afs = [0.015, 0.02, 0.03, 0.05, 0.08, 0.12, 0.16, 0.2, 0.24, 0.04, 0.1, 0.0]
+    afs = [0.1, 0.15, 0.2, 0.25, 0.3, 0.35, 0.4, 0.45, 0.5, 0.55, 0.0]      # random_batch spreads a planted rate over the three alt bases
     planted = {c: af for c, af in enumerate(afs * 3) if af > 0}
     host = util.random_batch(rng, len(afs) * 3, 9000, 10000, planted=planted)
     kw = dict(bonf_dynamic=0, bonf_subst=1, sig=1.0)           # nothing pruned: every allele has a value
@@ -521,5 +523,5 @@ def test_deep_tail_against_80bit_truth(caller, oracle):
             gpv = la.pvalue_from_log(p["logp"][a], int(p["status"][a]))
             assert abs(util.log_of(gpv) - tlog[a]) <= 2e-11
     print("deep tail vs 80-bit truth over %d p-values: device %.3g, reference log-space chain %.3g" % (n, worst_dev, worst_ref))
-    assert n >= 20, n
+    assert n >= 50, n
     assert worst_ref <= 1e-9

@@ -119,3 +119,92 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                         env=env2, capture_output=True, text=True, timeout=200)
     assert p2.returncode != 0 and "WORLD_SIZE" in (p2.stderr + p2.stdout)
+
+
+_PAR_WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+root, libpar, out = sys.argv[1:4]
+sys.path.insert(0, root)
+import lofreq_amd as la
+from lofreq_amd import _lib
+SEED, DEPTH, NCOLS, PERIOD = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+L = _lib.load()
+P = C.CDLL(libpar)
+par = C.c_void_p()
+assert P.lfq_par_init(C.byref(par), 1) == 0 and par.value
+P.lfq_par_world.argtypes = P.lfq_par_rank.argtypes = [C.c_void_p]
+P.lfq_par_ctx.argtypes = [C.c_void_p]; P.lfq_par_ctx.restype = C.c_void_p
+world, rank = P.lfq_par_world(par), P.lfq_par_rank(par)
+ctx = C.c_void_p(P.lfq_par_ctx(par))                     # the worker's context, created by lfq_par_init on its GPU
+caller = la.SnvCaller.__new__(la.SnvCaller)
+caller.L, caller.h, caller.device = L, ctx, 0
+lo, hi = NCOLS * rank // world, NCOLS * (rank + 1) // world
+# two flushes per worker, like a shim that fills two batches: the local running factor carries over
+conf = la.VarcallConf()
+pvs, tested = [], 0
+mid = (lo + hi) // 2
+for b, e in ((lo, mid), (mid, hi)):
+    batch = caller.synth_batch(SEED, DEPTH, e - b, plant_period=PERIOD, col_begin=b)
+    caller.call_snvs_submit(batch, conf)
+    pv = np.zeros(e - b, _lib.COL_PVALS_DTYPE)
+    n = C.c_int64(0); st = _lib.BatchStats()
+    assert L.lfq_call_snvs_collect_pvals(caller.h, C.c_void_p(pv.ctypes.data), len(pv), C.byref(n), C.byref(st)) == 0
+    pv = pv[: n.value].copy()
+    pv["col"] += b                                       # the key: the global column
+    pvs.append(pv)
+    assert L.lfq_shard_advance_conf(C.byref(conf.c), st.n_tested) == 0      # this worker's own running factor
+    tested += st.n_tested
+pv = np.concatenate(pvs)
+start = la.VarcallConf()                                 # what every worker started from
+rec_p = C.c_void_p(); n_rec = C.c_int64(0)
+P.lfq_par_merge_snvs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+rc = P.lfq_par_merge_snvs(par, C.byref(start.c), C.c_void_p(pv.ctypes.data), len(pv), tested, 0, C.byref(rec_p), C.byref(n_rec))
+assert rc == 0, rc
+if rank == 0:
+    recs = np.frombuffer(C.string_at(rec_p.value, 64 * n_rec.value), la.SNV_RECORD_DTYPE).copy()
+    np.save(out, recs.view(np.uint8))
+    np.save(out + ".meta", np.array([start.bonf_subst, start.num_snv_tests]))
+else:
+    assert not rec_p.value
+P.lfq_par_destroy.argtypes = [C.c_void_p]
+P.lfq_par_destroy(par)                                   # destroys the context too
+'''
+
+
+@pytest.mark.timeout(600)
+def test_c_workers_real_kernels_files_transport(tmp_path):
+    """integration/lofreq_amd_parallel.c with REAL kernels: two worker processes (both on cuda:0 -- RCCL refuses two
+    ranks on one GPU, so the all-gathers go through the files transport), each calling its half of a synthetic genome
+    in two flushes through lfq_call_snvs_submit / lfq_call_snvs_collect_pvals, then lfq_par_merge_snvs: rank 0's merged
+    records and the final conf equal the single-process call of the whole genome."""
+    import subprocess
+    import lofreq_amd as la
+    libpar = str(tmp_path / "liblofreq_amd_parallel.so")
+    subprocess.run(["gcc", "-std=gnu99", "-O1", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "integration", "lofreq_amd_parallel.c"), "-L" + os.path.join(ROOT, "lofreq_amd"),
+                    "-llofreq_amd", "-Wl,-rpath," + os.path.join(ROOT, "lofreq_amd"), "-ldl", "-o", libpar],
+                   check=True, capture_output=True, text=True)
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(_PAR_WORKER)
+    out = str(tmp_path / "recs.npy")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, LFQ_PAR_WORLD="2", LFQ_PAR_RANK=str(r), LFQ_PAR_RENDEZVOUS=str(tmp_path / "rdv"),
+                   LFQ_PAR_TRANSPORT="files", LFQ_PAR_TIMEOUT_S="240", LFQ_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, script, ROOT, libpar, out, str(SEED), str(DEPTH), str(NCOLS), str(PERIOD)],
+                                      env=env, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _, err = p.communicate(timeout=500)
+        assert p.returncode == 0, err[-3000:]
+    got = np.load(out).view(la.SNV_RECORD_DTYPE)
+    bonf, ntests = np.load(out + ".meta.npy")
+    caller = la.SnvCaller(0)
+    conf = la.VarcallConf()
+    exp, _, st = caller.call_snvs(caller.synth_batch(SEED, DEPTH, NCOLS, plant_period=PERIOD), conf)
+    caller.close()
+    assert bonf == conf.bonf_subst and ntests == conf.num_snv_tests
+    assert len(exp) > 100 and len(got) == len(exp)
+    for k in la.SNV_RECORD_DTYPE.names:
+        if k != "pad_":
+            assert (got[k] == exp[k]).all(), k
