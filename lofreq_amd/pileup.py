@@ -227,6 +227,48 @@ class ReadSet:
             caller._readsets = weakref.WeakSet()
         caller._readsets.add(self)                  # SnvCaller.close() closes its read sets first
 
+    @classmethod
+    def from_arrays(cls, caller, R):
+        """the same from flat arrays (no per-read Python objects): R = dict with n, pos (int32), cig_off / seq_off (int64),
+        cig (uint32, BAM encoding), seq (codes 0..4), qual, mapq, rev (uint8 per read), ref (bytes), and optionally
+        bi / bd (tag bytes per base), lb (tag bytes per base), flags (uint8 per read, bits 0 / 1 = has BI / BD)"""
+        self = cls.__new__(cls)
+        self.caller = caller
+        self.L = _lib.load()
+        self.n = int(R["n"])
+        keep = {k: np.ascontiguousarray(R[k], dt) for k, dt in (("pos", np.int32), ("cig_off", np.int64), ("cig", np.uint32),
+                                                                ("seq_off", np.int64), ("seq", np.uint8), ("qual", np.uint8),
+                                                                ("mapq", np.uint8), ("rev", np.uint8))}
+        keep["ref"] = bytes(R["ref"])
+        rd = _lib.PileupReads()
+        rd.n_reads = self.n
+        rd.pos, rd.cigar_off, rd.cigar = keep["pos"].ctypes.data, keep["cig_off"].ctypes.data, keep["cig"].ctypes.data
+        rd.seq_off, rd.seq, rd.qual = keep["seq_off"].ctypes.data, keep["seq"].ctypes.data, keep["qual"].ctypes.data
+        rd.mapq, rd.reverse = keep["mapq"].ctypes.data, keep["rev"].ctypes.data
+        rd.ref = C.cast(C.c_char_p(keep["ref"]), C.c_void_p)
+        rd.ref_len = len(keep["ref"])
+        if R.get("lb") is not None:
+            keep["lb"] = np.ascontiguousarray(R["lb"], np.uint8)
+            rd.baq = keep["lb"].ctypes.data
+        tags = _lib.PileupIndelTags()
+        for name in ("bi", "bd"):
+            if R.get(name) is not None:
+                keep[name] = np.ascontiguousarray(R[name], np.uint8)
+                setattr(tags, name, keep[name].ctypes.data)
+        if R.get("flags") is not None:
+            keep["flags"] = np.ascontiguousarray(R["flags"], np.uint8)
+            tags.tag_flags = keep["flags"].ctypes.data
+        self._keep = keep
+        self.seq_off = keep["seq_off"]
+        h = C.c_void_p()
+        _lib.check(self.L.lfq_readset_create(caller.h, C.byref(rd), C.byref(tags), C.byref(h)), "lfq_readset_create")
+        self.h = h
+        if not hasattr(caller, "_readsets"):
+            import weakref
+            caller._readsets = weakref.WeakSet()
+        caller._readsets.add(self)
+        return self
+
     def close(self):
         if getattr(self, "h", None):
             self.L.lfq_readset_destroy(self.h)

@@ -1715,3 +1715,32 @@ int orc_uniq_mtc(const int32_t *uq, long n, int mtc_type, double alpha, long nte
     free(pr);
     return 0;
 }
+
+/* orc_baq_idaq_read over reads [r0, r1) of packed read arrays (the layout of orc_reads): lb / ai / ad bytes per base
+ * ('~' = 126 where a read gets no ai / ad, like the tags the reference leaves out), flags[r] bit 0 / 1 = read has an
+ * ai / ad tag.  What mplp_func does per read before the pileup (plp.c:667-683). */
+int orc_baq_idaq_reads(const orc_reads *rd, int64_t r0, int64_t r1, int baq_extended, int want_idaq,
+                       uint8_t *lb, uint8_t *ai, uint8_t *ad, uint8_t *flags)
+{
+    int64_t r;
+    for (r = r0; r < r1; r++) {
+        const int64_t so = rd->seq_off[r], l = rd->seq_off[r + 1] - so;
+        const int64_t c0 = rd->cigar_off[r];
+        const int nc = (int)(rd->cigar_off[r + 1] - c0);
+        int rc;
+        if (want_idaq) {
+            memset(ai + so, 126, (size_t)l);
+            memset(ad + so, 126, (size_t)l);
+        }
+        rc = orc_baq_idaq_read(rd->pos[r], rd->cigar + c0, nc, rd->seq + so, rd->qual + so, (int)l, rd->ref, rd->ref_len,
+                               baq_extended, lb + so, want_idaq ? ai + so : NULL, want_idaq ? ad + so : NULL);
+        if (!(rc & 1)) {
+            memset(lb + so, 33, (size_t)l);         /* (zero-length reads aside, the tag is always written) */
+        }
+        if (flags) {
+            flags[r] = (uint8_t)((rc >> 1) & 3);
+        }
+    }
+    return 0;
+}
+

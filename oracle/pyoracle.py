@@ -17,7 +17,7 @@ def build(force=False):
     """Compile the C restatement (and, where the reference tree is mounted, oracle/_ref)."""
     src_newer = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("lofreq_oracle.c", "lofreq_oracle.h", "synth_ref.c")
+        for f in ("lofreq_oracle.c", "lofreq_oracle.h", "synth_ref.c", "orc_pileup.c")
     )
     if force or src_newer:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -544,3 +544,186 @@ def uniq_mtc(uq, mtc_type="fdr", alpha=0.001, ntests=0):
     if rc:
         raise RuntimeError("orc_uniq_mtc failed")
     return out[: len(uq)].astype(bool)
+
+
+# ---- the column builder (oracle/orc_pileup.c: compile_plp_col over htslib's pileup entries) -------------------------
+
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("pos", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq", C.c_void_p), ("qual", C.c_void_p), ("lb", C.c_void_p),
+                ("mapq", C.c_void_p), ("reverse", C.c_void_p), ("bi", C.c_void_p), ("bd", C.c_void_p),
+                ("ai", C.c_void_p), ("ad", C.c_void_p), ("tag_flags", C.c_void_p), ("sq", C.c_void_p),
+                ("ref", C.c_char_p), ("ref_len", C.c_int64)]
+
+
+class PlpOut(C.Structure):
+    _fields_ = [("ncols", C.c_int64), ("col_pos", C.c_void_p), ("nt", C.c_void_p), ("bq", C.c_void_p),
+                ("baq", C.c_void_p), ("mq", C.c_void_p), ("sq", C.c_void_p), ("col_off", C.c_void_p),
+                ("coverage_plp", C.c_void_p), ("num_bases", C.c_void_p), ("cons_indel", C.c_void_p),
+                ("indel", IndelBatch)]
+
+
+def pack_reads(reads, ref):
+    """reads: dicts {pos0, cigar [(op, len)], seq (codes 0..4), qual, mapq, reverse[, lb, bi, bd, ai, ad (tag bytes),
+    sq]} sorted by pos0 -> the flat arrays orc_pileup_region takes (same layout as the product's lfq_pileup_reads)"""
+    ops = "MIDNSHP=X"
+    n = len(reads)
+    P = {"n": n, "ref": bytes(ref)}
+    P["pos"] = np.asarray([r["pos0"] for r in reads] or [0], np.int32)
+    cig_off = np.zeros(n + 1, np.int64)
+    seq_off = np.zeros(n + 1, np.int64)
+    cig = []
+    for i, r in enumerate(reads):
+        cig.extend((l << 4) | ops.index(o) for o, l in r["cigar"])
+        cig_off[i + 1] = len(cig)
+        seq_off[i + 1] = seq_off[i] + len(r["seq"])
+    P["cig_off"], P["seq_off"] = cig_off, seq_off
+    P["cig"] = np.asarray(cig or [0], np.uint32)
+    cat = lambda k: np.concatenate([np.asarray(r[k], np.uint8) for r in reads]) if n else np.zeros(1, np.uint8)
+    P["seq"], P["qual"] = cat("seq"), cat("qual")
+    P["mapq"] = np.asarray([r["mapq"] for r in reads] or [0], np.uint8)
+    P["rev"] = np.asarray([1 if r["reverse"] else 0 for r in reads] or [0], np.uint8)
+    nb = int(seq_off[-1])
+    flags = np.zeros(max(n, 1), np.uint8)
+    for bit, name in enumerate(("bi", "bd", "ai", "ad")):
+        P[name] = None
+        if any(r.get(name) is not None for r in reads):
+            arr = np.full(max(nb, 1), 33, np.uint8)
+            for i, r in enumerate(reads):
+                if r.get(name) is not None:
+                    arr[seq_off[i]:seq_off[i + 1]] = np.asarray(r[name], np.uint8)
+                    flags[i] |= 1 << bit
+            P[name] = arr
+    P["flags"] = flags
+    P["lb"] = cat("lb") if n and all(r.get("lb") is not None for r in reads) else None
+    P["sq"] = np.asarray([(-1 if r.get("sq") is None else r["sq"]) for r in reads], np.int32) \
+        if any(r.get("sq") is not None for r in reads) else None
+    return P
+
+
+def _reads_struct(P):
+    R = Reads()
+    keep = []
+
+    def ptr(a, dt):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    R.n_reads = P["n"]
+    R.pos, R.cigar_off, R.cigar = ptr(P["pos"], np.int32), ptr(P["cig_off"], np.int64), ptr(P["cig"], np.uint32)
+    R.seq_off, R.seq, R.qual = ptr(P["seq_off"], np.int64), ptr(P["seq"], np.uint8), ptr(P["qual"], np.uint8)
+    R.lb = ptr(P.get("lb"), np.uint8)
+    R.mapq, R.reverse = ptr(P["mapq"], np.uint8), ptr(P["rev"], np.uint8)
+    for k in ("bi", "bd", "ai", "ad"):
+        setattr(R, k, ptr(P.get(k), np.uint8))
+    R.tag_flags = ptr(P.get("flags"), np.uint8)
+    R.sq = ptr(P.get("sq"), np.int32)
+    R.ref, R.ref_len = P["ref"], len(P["ref"])
+    keep.append(P["ref"])
+    return R, keep
+
+
+def _baq_range(args):
+    P, r0, r1, extended, idaq = args
+    L = lib()
+    L.orc_baq_idaq_reads.restype = C.c_int
+    L.orc_baq_idaq_reads.argtypes = [C.POINTER(Reads), C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4
+    R, keep = _reads_struct(P)
+    nb = int(P["seq_off"][-1])
+    lb = np.zeros(max(nb, 1), np.uint8)
+    ai = np.zeros(max(nb, 1), np.uint8) if idaq else None
+    ad = np.zeros(max(nb, 1), np.uint8) if idaq else None
+    fl = np.zeros(max(P["n"], 1), np.uint8)
+    rc = L.orc_baq_idaq_reads(C.byref(R), int(r0), int(r1), 1 if extended else 0, 1 if idaq else 0, lb.ctypes.data,
+                              ai.ctypes.data if idaq else None, ad.ctypes.data if idaq else None, fl.ctypes.data)
+    assert rc == 0
+    a, b = int(P["seq_off"][r0]), int(P["seq_off"][r1])
+    return lb[a:b], (ai[a:b] if idaq else None), (ad[a:b] if idaq else None), fl[r0:r1]
+
+
+def baq_idaq_reads(P, extended=True, idaq=True, procs=1):
+    """the lb (and ai / ad) tags of every read of packed reads P by orc_baq_idaq_read -- what mplp_func computes on the
+    fly (plp.c:667-683) -- in `procs` processes.  Sets P["lb"], P["ai"], P["ad"] and bits 2 / 3 of P["flags"]."""
+    n = P["n"]
+    if procs > 1 and n >= 4096:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        cuts = [n * i // procs for i in range(procs + 1)]
+        with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
+            parts = list(ex.map(_baq_range, [(P, cuts[i], cuts[i + 1], extended, idaq) for i in range(procs)]))
+    else:
+        parts = [_baq_range((P, 0, n, extended, idaq))]
+    P["lb"] = np.concatenate([p[0] for p in parts])
+    fl = np.concatenate([p[3] for p in parts])
+    flags = np.asarray(P.get("flags") if P.get("flags") is not None else np.zeros(max(n, 1), np.uint8)).copy()
+    flags[:n] &= 3
+    if idaq:
+        P["ai"] = np.concatenate([p[1] for p in parts])
+        P["ad"] = np.concatenate([p[2] for p in parts])
+        flags[:n] |= (fl & 1) << 2 | (fl & 2) << 2
+    P["flags"] = flags
+    return P
+
+
+def pileup_region(P, begin, end, min_plp_bq=3, min_plp_idq=0, use_baq=True, use_sq=False):
+    """orc_pileup_region on packed reads (pack_reads, or arrays in the same layout) ->
+    dict(col_pos, host = packed SNV tracks for call_batch (incl. coverage_plp / num_bases), cons_indel,
+         flat = the indel fields for call_indels_batch)"""
+    L = lib()
+    L.orc_pileup_region.restype = C.c_void_p
+    L.orc_pileup_region.argtypes = [C.POINTER(Reads), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_plp_region_out.restype = C.POINTER(PlpOut)
+    L.orc_plp_region_out.argtypes = [C.c_void_p]
+    L.orc_plp_region_free.argtypes = [C.c_void_p]
+    R, keep = _reads_struct(P)
+    h = L.orc_pileup_region(C.byref(R), int(begin), int(end), int(min_plp_bq), int(min_plp_idq), 1 if use_baq else 0,
+                            1 if use_sq else 0)
+    if not h:
+        raise MemoryError("orc_pileup_region")
+    try:
+        o = L.orc_plp_region_out(h).contents
+        nc = int(o.ncols)
+
+        def arr(p, count, dt):
+            if not p or count == 0:
+                return np.zeros(0, dt)
+            return np.frombuffer(C.string_at(p, count * np.dtype(dt).itemsize), dt).copy()
+
+        col_off = arr(o.col_off, nc + 1, np.uint64)
+        nobs = int(col_off[-1]) if nc else 0
+        pad = nobs + 32
+        ib = o.indel
+        host = dict(nt=arr(o.nt, pad, np.uint8), bq=arr(o.bq, pad, np.uint8),
+                    baq=arr(o.baq, pad, np.uint8) if o.baq else None, mq=arr(o.mq, pad, np.uint8),
+                    sq=arr(o.sq, pad, np.uint8) if o.sq else None, col_off=col_off,
+                    ref_base=np.frombuffer(C.string_at(ib.ref_base, nc), np.uint8).copy() if nc else np.zeros(0, np.uint8),
+                    coverage_plp=arr(o.coverage_plp, nc, np.int32), num_bases=arr(o.num_bases, nc, np.int32))
+        flat = {"ncols": nc, "ref_base": host["ref_base"]}
+        for k in ("coverage_plp", "num_tails", "num_non_indels", "num_ins", "num_dels", "hrun"):
+            flat[k] = np.frombuffer(C.string_at(getattr(ib, k), nc * 4), np.int32).copy() if nc else np.zeros(0, np.int32)
+        for k in ("non_fw", "non_rv", "ne_off", "ne_q", "ne_mq", "ev_off", "key_off", "key_chars", "ev_fw", "ev_rv", "rd_off",
+                  "rd_q", "rd_aq", "rd_mq", "rd_sq"):
+            flat[k] = [None, None]
+        for s in (0, 1):
+            i64 = lambda p, n: np.frombuffer(C.string_at(C.cast(p, C.c_void_p), n * 8), np.int64).copy()
+            i32 = lambda p, n: np.frombuffer(C.string_at(C.cast(p, C.c_void_p), n * 4), np.int32).copy() if n else np.zeros(0, np.int32)
+            i16 = lambda p, n: np.frombuffer(C.string_at(C.cast(p, C.c_void_p), n * 2), np.int16).copy() if n else np.zeros(0, np.int16)
+            flat["non_fw"][s], flat["non_rv"][s] = i32(ib.non_fw[s], nc), i32(ib.non_rv[s], nc)
+            flat["ne_off"][s] = i64(ib.ne_off[s], nc + 1)
+            nne = int(flat["ne_off"][s][-1])
+            flat["ne_q"][s], flat["ne_mq"][s] = i16(ib.ne_q[s], nne), i16(ib.ne_mq[s], nne)
+            flat["ev_off"][s] = i64(ib.ev_off[s], nc + 1)
+            nev = int(flat["ev_off"][s][-1])
+            flat["key_off"][s] = i64(ib.key_off[s], nev + 1)
+            flat["key_chars"][s] = C.string_at(ib.key_chars[s], int(flat["key_off"][s][-1]))
+            flat["ev_fw"][s], flat["ev_rv"][s] = i32(ib.ev_fw[s], nev), i32(ib.ev_rv[s], nev)
+            flat["rd_off"][s] = i64(ib.rd_off[s], nev + 1)
+            nrd = int(flat["rd_off"][s][-1])
+            for k in ("rd_q", "rd_aq", "rd_mq", "rd_sq"):
+                flat[k][s] = i16(getattr(ib, k)[s], nrd)
+        return dict(col_pos=arr(o.col_pos, nc, np.int64), host=host, cons_indel=arr(o.cons_indel, nc, np.uint8), flat=flat)
+    finally:
+        L.orc_plp_region_free(h)

@@ -229,3 +229,85 @@ def random_indel_columns(rng, ncols, depth_lo=20, depth_hi=400, p_event=0.5, pol
         col["num_non_indels"] = max(depth - tot_ev[0] - tot_ev[1], 0)
         cols.append(col)
     return cols
+
+
+def make_region_reads(seed, glen, depth, rl=150, snv_every=400, indel_every=1500, err=0.003, lo=0, hi=None):
+    """Position-sorted synthetic reads over [lo, hi) of a random genome of length glen, with PLANTED variants so that the
+    callers have something to report: an SNV site every `snv_every` bases (allele frequency cycling 1 %, 3 %, 10 %, 50 %) and
+    an insertion / deletion site (1-3 bases, alternating) every `indel_every` bases (AF cycling 3 %, 10 %, 30 %) carried by
+    the reads that cover it with at least 12 bases on both sides; sequencing errors at rate `err`, qualities ~N(34, 5)
+    clipped to 2..41, BI / BD 30..49, mapping quality 60 (8 %: 20..59), random strands.  The genome depends on the seed
+    only, so regions of one genome can be generated separately.
+    -> dict of flat arrays in the layout of lfq_pileup_reads / orc_reads (keys as oracle/pyoracle.py::pack_reads)."""
+    hi = glen if hi is None else hi
+    genome = np.random.default_rng(seed).integers(0, 4, glen).astype(np.uint8)
+    rng = np.random.default_rng([seed, lo, hi])
+    n = int(depth * (hi - lo) / rl)
+    pos = np.sort(rng.integers(max(lo - rl + 1, 0), max(min(hi, glen - rl - 8), 1), n)).astype(np.int64)
+    snv_sites = np.arange(snv_every // 2, glen, snv_every)
+    snv_af = np.array([0.01, 0.03, 0.1, 0.5])[np.arange(len(snv_sites)) % 4]
+    snv_alt = (genome[snv_sites] + 1 + (np.arange(len(snv_sites)) % 3)) % 4
+    ind_sites = np.arange(indel_every // 3, glen - rl, indel_every)
+    ind_af = np.array([0.03, 0.1, 0.3])[np.arange(len(ind_sites)) % 3]
+    ind_len = 1 + (np.arange(len(ind_sites)) % 3)
+    ind_ins = (np.arange(len(ind_sites)) % 2) == 0
+    ins_seq = np.random.default_rng(seed + 1).integers(0, 4, (len(ind_sites), 3)).astype(np.uint8)
+    # which reads carry which planted indel (at most one per read)
+    carry = np.full(n, -1, np.int64)
+    si = np.searchsorted(ind_sites, pos + 12)
+    for k in range(2):                                          # a read spans at most a couple of sites
+        j = si + k
+        ok = (j < len(ind_sites))
+        jj = np.where(ok, j, 0)
+        inside = ok & (ind_sites[jj] >= pos + 12) & (ind_sites[jj] <= pos + rl - 16) & (carry < 0)
+        take = inside & (rng.random(n) < ind_af[jj])
+        carry[take] = jj[take]
+    seqs = np.empty((n, rl), np.uint8)
+    ref_idx = pos[:, None] + np.arange(rl)[None, :]
+    plain = carry < 0
+    seqs[plain] = genome[ref_idx[plain]]
+    cig = np.zeros((n, 3), np.uint32)
+    ncig = np.ones(n, np.int64)
+    cig[:, 0] = rl << 4
+    # reference coordinate of every base (for the planted SNVs), -1 for inserted bases
+    rpos = ref_idx.copy()
+    for i in np.nonzero(~plain)[0]:
+        s = int(carry[i])
+        c = int(ind_sites[s] - pos[i]) + 1                      # bases before the event (the event follows base c - 1)
+        L = int(ind_len[s])
+        if ind_ins[s]:
+            seqs[i, :c] = genome[pos[i]:pos[i] + c]
+            seqs[i, c:c + L] = ins_seq[s, :L]
+            seqs[i, c + L:] = genome[pos[i] + c:pos[i] + rl - L]
+            rpos[i, c:c + L] = -1
+            rpos[i, c + L:] = np.arange(pos[i] + c, pos[i] + rl - L)
+            cig[i] = [(c << 4), (L << 4) | 1, ((rl - c - L) << 4)]
+        else:
+            seqs[i, :c] = genome[pos[i]:pos[i] + c]
+            seqs[i, c:] = genome[pos[i] + c + L:pos[i] + rl + L]
+            rpos[i, c:] = np.arange(pos[i] + c + L, pos[i] + rl + L)
+            cig[i] = [(c << 4), (L << 4) | 2, ((rl - c) << 4)]
+        ncig[i] = 3
+    # planted SNVs: a read base on a site becomes the alt allele with the site's frequency
+    on = np.isin(rpos, snv_sites)
+    if on.any():
+        ri, ci = np.nonzero(on)
+        sidx = np.searchsorted(snv_sites, rpos[ri, ci])
+        flip = rng.random(len(ri)) < snv_af[sidx]
+        seqs[ri[flip], ci[flip]] = snv_alt[sidx[flip]]
+    mism = rng.random(seqs.shape) < err
+    seqs[mism] = (seqs[mism] + 1 + rng.integers(0, 3, int(mism.sum()))) % 4
+    qual = np.clip(np.round(rng.normal(34, 5, seqs.shape)), 2, 41).astype(np.uint8)
+    cig_off = np.zeros(n + 1, np.int64)
+    cig_off[1:] = np.cumsum(ncig)
+    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(20, 60, n)).astype(np.uint8)
+    return {
+        "n": n, "rl": rl, "glen": glen, "ref": np.frombuffer(b"ACGT", np.uint8)[genome].tobytes(),
+        "pos": pos.astype(np.int32), "cig_off": cig_off, "cig": np.ascontiguousarray(cig[np.arange(3)[None, :] < ncig[:, None]]),
+        "seq_off": np.arange(n + 1, dtype=np.int64) * rl, "seq": np.ascontiguousarray(seqs.reshape(-1)),
+        "qual": np.ascontiguousarray(qual.reshape(-1)),
+        "bi": rng.integers(33 + 30, 33 + 50, n * rl).astype(np.uint8), "bd": rng.integers(33 + 30, 33 + 50, n * rl).astype(np.uint8),
+        "ai": None, "ad": None, "lb": None, "sq": None, "flags": np.full(max(n, 1), 3, np.uint8),
+        "mapq": mapq, "rev": (rng.random(n) < 0.5).astype(np.uint8),
+        "n_indel_reads": int((~plain).sum()), "snv_sites": snv_sites, "indel_sites": ind_sites,
+    }
