@@ -1275,6 +1275,9 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
 {
     const int64_t ncols = tr->ncols;
     lfq_tracks dev = *tr;
+    if (ncols > 0 && (!tr->nt || !tr->bq || !tr->mq || !tr->col_off || !tr->ref_base)) {
+        return LFQ_ERR_INVALID;         /* (baq and sq may be NULL: track off) */
+    }
     if (!tracks_on_device && (tr->flags & LFQ_TRACKS_NT_PACKED)) {
         return LFQ_ERR_INVALID;         /* the packed nt layout is for device-resident producers */
     }

@@ -665,7 +665,7 @@ template <int NB, bool HASN, bool IDAQ>
 __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O1)[NB + 1], double (&O2)[NB + 1],
                                                 typename LfqBaqWinT<NB>::type win, int qyi, double e_eq,
                                                 double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp,
-                                                double &sum_out)
+                                                bool store, double &sum_out)
 {
     typedef typename LfqBaqWinT<NB>::type WinT;
     const WinT xq = win ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(qyi & 3));
@@ -681,7 +681,9 @@ __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O
         const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
         const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
         const double f2 = m[2] * m_prev + m[8] * d_prev;
-        fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
+        if (store) {                                 /* wave-uniform: only the even rows go to HBM */
+            fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
+        }
         m_prev = f0;
         d_prev = f2;
         sum += f0 + f1 + f2;
@@ -690,6 +692,82 @@ __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O
         O2[j] = f2;
     }
     sum_out = sum;
+}
+
+/* The forward cells (match, insertion) of an ODD row i >= 3 from the stored cells of row i - 1, inside the backward sweep:
+ * the forward pass keeps only the even rows (and row 1) in HBM -- half the bytes of the kernel's dominant stream -- and
+ * this redoes the forward step of the row in between with the operations of lfq_baq_fwd_row / the masked forward body
+ * in the same order on the same values: the deletion cells of row i - 1 first (f2(k) = m2 f0(k-1) + m8 f2(k-1), what
+ * the forward pass had in O2), then f0 / f1 of row i.  Bit-identical by construction (-ffp-contract=off, no
+ * reassociation).  Cells a row does not have (beyond the end of the reference) come out as don't-care values: every
+ * reader masks them, and they only ever feed cells that do not exist either. */
+template <int NB, bool HASN>
+__device__ __forceinline__ void lfq_baq_refwd_row(const double (&A0)[NB], const double (&A1)[NB],
+                                                  typename LfqBaqWinT<NB>::type win, int qyi, double e_eq, double e_ne,
+                                                  double rs, const double (&m)[9], double (&F0)[NB], double (&F1)[NB])
+{
+    typedef typename LfqBaqWinT<NB>::type WinT;
+    const WinT xq = win ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(qyi & 3));
+    double mp = 0., dp = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        double e = ((unsigned)(xq >> (4 * j)) & 15u) == 0 ? e_eq : e_ne;
+        if (HASN) {
+            e = (((unsigned)(win >> (4 * j)) & 4u) != 0 || qyi > 3) ? 1. : e;
+        }
+        const double a2u = m[2] * mp + m[8] * dp;   /* deletion cell j of row i - 1 (row i - 1 >= 2: it has them) */
+        mp = A0[j];
+        dp = a2u;
+        const double a0 = A0[j] * rs, a1 = A1[j] * rs, a2 = a2u * rs;
+        const double c0 = (j + 1 < NB ? A0[j + 1 < NB ? j + 1 : j] : 0.) * rs, c1 = (j + 1 < NB ? A1[j + 1 < NB ? j + 1 : j] : 0.) * rs;
+        F0[j] = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
+        F1[j] = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
+    }
+}
+
+/* MAP step of row i (kprobaln_ext.c:254-281): z = f b over the cells in ascending k, match before insertion, the first
+ * maximum wins (z > max).  ODD: the forward cells of the row are not in HBM -- each is recomputed right here from the
+ * stored row below (G = row i - 1) exactly as lfq_baq_refwd_row does, and consumed at once, so that no second row of
+ * forward cells occupies registers.  MASKED: the edge rows, cells outside jmin .. jmax count as absent. */
+template <int NB, bool ODD, bool HASN, bool MASKED>
+__device__ __forceinline__ void lfq_baq_map_row(const double (&O0)[NB + 1], const double (&O1)[NB + 1], const double (&G0)[NB],
+                                                const double (&G1)[NB], typename LfqBaqWinT<NB>::type fwin, int f_qy,
+                                                double f_eq, double f_ne, double f_rs, const double (&m)[9], double rsi,
+                                                int jmin, int jmax, double &sum, double &max, int &max_u)
+{
+    typedef typename LfqBaqWinT<NB>::type WinT;
+    const WinT xq = fwin ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(f_qy & 3));
+    double mp = 0., dp = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        double f0, f1;
+        if (ODD) {
+            double e = ((unsigned)(xq >> (4 * j)) & 15u) == 0 ? f_eq : f_ne;
+            if (HASN) {
+                e = (((unsigned)(fwin >> (4 * j)) & 4u) != 0 || f_qy > 3) ? 1. : e;
+            }
+            const double a2u = m[2] * mp + m[8] * dp;
+            mp = G0[j];
+            dp = a2u;
+            const double a0 = G0[j] * f_rs, a1 = G1[j] * f_rs, a2 = a2u * f_rs;
+            const double c0 = (j + 1 < NB ? G0[j + 1 < NB ? j + 1 : j] : 0.) * f_rs;
+            const double c1 = (j + 1 < NB ? G1[j + 1 < NB ? j + 1 : j] : 0.) * f_rs;
+            f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
+            f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
+        } else {
+            f0 = G0[j];
+            f1 = G1[j];
+        }
+        const bool valid = !MASKED || (j >= jmin && j <= jmax);
+        const double z0 = valid ? (f0 * rsi) * O0[j] : -1.;              /* -1.: never the maximum, adds 0. */
+        max_u = z0 > max ? 4 * j : max_u;
+        max = z0 > max ? z0 : max;
+        sum += valid ? z0 : 0.;
+        const double z1 = valid ? (f1 * rsi) * O1[j] : -1.;
+        max_u = z1 > max ? 4 * j + 1 : max_u;
+        max = z1 > max ? z1 : max;
+        sum += valid ? z1 : 0.;
+    }
 }
 
 /* one interior row of the backward pass: O <- row i from row i + 1 (both scaled), all 15 cells */
@@ -777,6 +855,16 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     for (int i = 0; i <= Lmax + 1; i++) {
         s_rowq[(size_t)i * 64 + lane] = (i >= 1 && i <= l_query) ? (uint16_t)(query[i] | (iqual[i] << 8)) : (uint16_t)4;
     }
+    /* the quality table in LDS: a row's lookup then waits on lgkmcnt only.  As a global load it counted in vmcnt, which
+     * retires in order on this ISA -- every row waited for its table entry behind the forward matrix's stores (forward
+     * pass) or behind the next stored row's loads (backward sweep), i.e. the full HBM latency the prefetching was there
+     * to hide, once per row. */
+    __shared__ double s_q2p[256];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        s_q2p[t * 64 + lane] = (double)A.qual2prob[t * 64 + lane];
+    }
+    __syncthreads();
     int bw = l_ref > l_query ? l_ref : l_query;                          /* kprobaln_ext.c:99-101 */
     if (bw > R.bw) bw = R.bw;
     if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);            /* <= 7: the host sends only such reads here */
@@ -819,7 +907,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         /* row 1 (:141-157): k = 1 .. min(l_ref, bw + 1) -> slots bw .. 2 bw */
         double sum = 0.;
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
-        const double ql = A.qual2prob[ROWQ(1) >> 8];
+        const double ql = s_q2p[ROWQ(1) >> 8];
         const int qy1 = ROWQ(1) & 0xff;
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -873,7 +961,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     double rs_next = 1.;                             /* RQ(1) */
     /* base code and quality of a row come out of LDS one row ahead */
     int rq_next = ROWQ(2);
-    double ql_next = A.qual2prob[rq_next >> 8];
+    double ql_next = s_q2p[rq_next >> 8];
     if (l_query == 1) {
         s_fin = lfq_baq_sfin<NB>(O0, O1, 1., sM, sI, l_query, l_ref, bw);
     }
@@ -883,16 +971,17 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         const double rs = rs_next;                   /* pending scale of row i-1 */
         const int qyi = rq_next & 0xff;
         rq_next = ROWQ(i + 1);
-        ql_next = A.qual2prob[rq_next >> 8];
+        ql_next = s_q2p[rq_next >> 8];
         const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);      /* enters the window for row i + 1 */
         const double e_eq = 1. - qli, e_ne = qli * LFQ_BAQ_EM;           /* lfq_baq_emit's two non-trivial values */
         LfqBaqPair *fp = FP(i);
+        const bool store = (i & 1) == 0;             /* odd rows >= 3 are recomputed by the backward sweep (lfq_baq_refwd_row) */
         if (i >= BWF + 1 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
             const bool has_n = qyi > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             if (__any(has_n)) {
-                lfq_baq_fwd_row<NB, true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+                lfq_baq_fwd_row<NB, true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, store, sum);
             } else {
-                lfq_baq_fwd_row<NB, false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+                lfq_baq_fwd_row<NB, false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, store, sum);
             }
         } else {
             /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
@@ -910,7 +999,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
                 const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
                 const double f2 = m[2] * m_prev + m[8] * d_prev;
-                if (valid) {
+                if (valid && store) {
                     fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
                 }
                 m_prev = f0;
@@ -1085,6 +1174,20 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     } while (0)
     LFQ_BAQ_BATCH(Lmax >> 2, rA0, rA1, rA2, rA3, eA0, eA1, eA2, eA3);
     LFQ_BAQ_BATCH((Lmax >> 2) - 1, rB0, rB1, rB2, rB3, eB0, eB1, eB2, eB3);
+    /* G: the forward cells of the stored row (even, or row 1) the sweep meets next -- row i itself at a stored row, row
+     * i - 1 at an odd row, whose own cells are recomputed from it.  Requested one stored row ahead: the load issued at a
+     * stored row lands during that row's and (usually) the following odd row's arithmetic. */
+    double G0[NB], G1[NB];
+    {
+        const int g_row = ((Lmax & 1) == 0 || Lmax == 1) ? Lmax : Lmax - 1;
+        const LfqBaqPair *gp = FP(g_row);
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const LfqBaqPair v = gp[(size_t)j * 64];
+            G0[j] = v.m;
+            G1[j] = v.i;
+        }
+    }
     for (int i = Lmax; i >= 1; --i) {
         const int t4 = i & 3;
         const double c_r = t4 == 0 ? rA0 : (t4 == 1 ? rA1 : (t4 == 2 ? rA2 : rA3));           /* 1 / s[i] */
@@ -1096,22 +1199,26 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         }
         const int rq_up = ROWQ(i + 1), c_iq = ROWQ(i) >> 8;
         const int c_qy = rq_up & 0xff;               /* query[i + 1] */
-        const double c_ql = A.qual2prob[rq_up >> 8];
+        const double c_ql = s_q2p[rq_up >> 8];
         const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);
         const bool on = i <= l_query;
-        const LfqBaqPair *fp = FP(i);
         const double e_eq = 1. - c_ql, e_ne = c_ql * LFQ_BAQ_EM;
-        /* the forward cells the MAP step of this row needs are requested now and land while the backward row is computed */
-        double fz0[NB], fz1[NB];
         double sum = 0., max = 0.;
         int max_u = -1;                              /* 4 j + state of the maximum */
         const double rsi = c_r;
-#pragma unroll
-        for (int j = 0; j < NB; j++) {               /* every slot: a lane's row is its own and zero-filled where it has no cell */
-            const LfqBaqPair v = fp[(size_t)j * 64];
-            fz0[j] = v.m;
-            fz1[j] = v.i;
-        }
+        /* The forward cells the MAP step needs.  A stored row (even, or row 1): G is this row.  An odd row >= 3: its cells
+         * are recomputed slot by slot inside the MAP loop from the stored row below (G = row i - 1) with the forward
+         * pass's own operations (lfq_baq_map_row<ODD>).  The forward window of row i (positions i - bw ..) is the backward
+         * window one base further down; the pending scale of row i - 1 is 1 / s[i - 1], which sits in the same batch of
+         * four (i odd: i & 3 is 1 or 3). */
+        const bool odd = (i & 1) != 0 && i >= 3;
+        const WinT fwin = (win << 4) | (WinT)(unsigned)code_in;
+        const int rq_i = ROWQ(i);
+        const int f_qy = rq_i & 0xff;
+        const double f_ql = s_q2p[rq_i >> 8];
+        const double f_eq = 1. - f_ql, f_ne = f_ql * LFQ_BAQ_EM;
+        const double f_rs = (i & 3) == 1 ? rA0 : rA2;
+        const bool f_has_n = __any(f_qy > 3 || (fwin & lfq_baq_nibbles<NB, WinT>(4u)) != 0) != 0;
         if (i >= BWF + 1 && i <= b_hi) {                   /* interior row */
             const bool has_n = c_qy > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             /* ys = 1 / s[i]: the same division as the forward pass's 1 / sum (i >= 8) */
@@ -1121,16 +1228,12 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 lfq_baq_bwd_row<NB, false, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
             }
             /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const double z0 = (fz0[j] * rsi) * O0[j];
-                max_u = z0 > max ? 4 * j : max_u;
-                max = z0 > max ? z0 : max;
-                sum += z0;
-                const double z1 = (fz1[j] * rsi) * O1[j];
-                max_u = z1 > max ? 4 * j + 1 : max_u;
-                max = z1 > max ? z1 : max;
-                sum += z1;
+            if (!odd) {
+                lfq_baq_map_row<NB, false, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
+            } else if (f_has_n) {
+                lfq_baq_map_row<NB, true, true, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
+            } else {
+                lfq_baq_map_row<NB, true, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
             }
         } else {
             /* the same arithmetic, cells outside [max(1, i - bw), min(l_ref, i + bw)] masked to 0: slots jmin .. jmax;
@@ -1161,17 +1264,10 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 O1[j] = last ? (in ? b_init1 : 0.) : (valid ? b1 * ys : 0.);
                 O2[j] = last ? 0. : (valid ? b2 * ys : 0.);
             }
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const bool valid = j >= jmin && j <= jmax;
-                const double z0 = valid ? (fz0[j] * rsi) * O0[j] : -1.;  /* -1.: never the maximum, adds 0. */
-                max_u = z0 > max ? 4 * j : max_u;
-                max = z0 > max ? z0 : max;
-                sum += valid ? z0 : 0.;
-                const double z1 = valid ? (fz1[j] * rsi) * O1[j] : -1.;
-                max_u = z1 > max ? 4 * j + 1 : max_u;
-                max = z1 > max ? z1 : max;
-                sum += valid ? z1 : 0.;
+            if (!odd) {
+                lfq_baq_map_row<NB, false, false, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
+            } else {
+                lfq_baq_map_row<NB, true, true, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
             }
         }
         win = (win << 4) | (WinT)(unsigned)code_in;
@@ -1186,6 +1282,17 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             /* (the table sits in the scratch: the loop over it runs only at the few rows where this read has a term due,
              * not as a chain of dependent loads in every row) */
             if (IDAQ && i >= it_lo && i <= it_hi) {
+                /* the row's forward cells once more, as arrays (only at the few rows where an indel of this read has a term due) */
+                double fz0[NB], fz1[NB];
+                if (odd) {
+                    lfq_baq_refwd_row<NB, true>(G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, fz0, fz1);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        fz0[j] = G0[j];
+                        fz1[j] = G1[j];
+                    }
+                }
                 int beg = 1, end = l_ref, x;
                 x = i - bw; beg = beg > x ? beg : x;
                 x = i + bw; end = end < x ? end : x;
@@ -1232,6 +1339,17 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 bq = A.baq_extended ? (off ? 0 : qk) : qk;
             }
             s_rowq[(size_t)(i + 1) * 64 + lane] = (uint16_t)bq;      /* out[i - 1]: the slot of row i + 1 is free now */
+        }
+        if (!odd && i >= 2) {
+            /* this stored row is done with: the next one (row i - 2, or row 1 below row 2) is requested now and lands while
+             * the odd row in between computes its backward cells */
+            const LfqBaqPair *gp = FP(i == 2 ? 1 : i - 2);
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const LfqBaqPair v = gp[(size_t)j * 64];
+                G0[j] = v.m;
+                G1[j] = v.i;
+            }
         }
     }
 #define OUTE(i0_) s_rowq[(size_t)((i0_) + 2) * 64 + lane]

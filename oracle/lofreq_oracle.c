@@ -1546,6 +1546,18 @@ done:
     return src_qual;
 }
 
+
+/* lofreq_uniq.c:262-268: an AF parsed from the VCF that is out of bounds is logged ("LOG_FATAL", which does not exit)
+ * and RESET -- af < 0 -> 0.01, af > 1 -> 1.0 -- and the variant is processed with the new value */
+static float orc_uniq_af(float af)
+{
+    if (af < 0.0 || af > 1.0) {
+        float new_af = af < 0.0 ? 0.01 : 1.0;
+        af = new_af;
+    }
+    return af;
+}
+
 /* ---- `lofreq uniq --use-det-lim`: uniq_snv, lofreq_uniq.c:222-333 ------------------------
  * per column: default varcall_conf, plp_to_errprobs, alt_counts = {af * num_err_probs (float product, truncated),
  * 0, 0}, snpcaller(bonf 1, alpha (double)0.01f, -1); flag[col] = pvalues[0] * (float)bonf < alpha (:314), the
@@ -1580,7 +1592,7 @@ int orc_uniq_detlim_batch(const uint8_t *nt, const uint8_t *bq, const uint8_t *b
             return -1;
         }
         /* NB no qsort here: uniq_snv hands the probabilities to snpcaller in plp_to_errprobs order (:293-305) */
-        alt_counts[0] = af[c] * n_ep;                               /* :300 */
+        alt_counts[0] = orc_uniq_af(af[c]) * n_ep;                  /* :262-268, :300 */
         alt_counts[1] = alt_counts[2] = 0;
         orc_snpcaller(pv, NULL, ep, n_ep, alt_counts, bonf, alpha, NULL);       /* :303 */
         if (pvalue) {
@@ -1665,7 +1677,7 @@ int orc_uniq_binom_batch(const uint8_t *nt, const uint64_t *col_off, const int32
         for (o = o0; o < o1; o++) {
             alt_count += ((nt[o] & 7) == code);
         }
-        if (orc_binom_cdf(&pv, coverage, alt_count, (double)af[c]) != 0) {
+        if (orc_binom_cdf(&pv, coverage, alt_count, (double)orc_uniq_af(af[c])) != 0) {       /* :262-268, :381 */
             continue;
         }
         uq[c] = (pv <= 0.0) ? INT_MAX : (int)(-10.0 * log10l(pv));

@@ -99,14 +99,14 @@ def test_config_c4_shape_reads_to_vcf_with_indels(caller, oracle):
 
 # ---- C5 shape: BED targets over two ranks -------------------------------------------------------------------------------
 
-GLEN5, DEPTH5, SEED5 = 150000, 200, 505
+GLEN5, DEPTH5, SEED5 = 200000, 200, 505
 
 
 def _targets():
-    """ragged exome-like targets: 45 intervals of 150 .. 3500 bases with gaps, about 50 000 target positions"""
+    """ragged exome-like targets: 60 intervals of 150 .. 3500 bases with gaps, about 58 000 target positions"""
     rng = np.random.default_rng(55)
     t, x = [], 500
-    while len(t) < 45 and x < GLEN5 - 5000:
+    while len(t) < 60 and x < GLEN5 - 5000:
         l = int(rng.choice([150, 300, 600, 1200, 2000, 3500], p=[0.2, 0.25, 0.2, 0.15, 0.12, 0.08]))
         t.append(("chr1", x, x + l))
         x += l + int(rng.integers(200, 3500))
@@ -175,7 +175,7 @@ def test_config_c5_shape_bed_targets_two_ranks(tmp_path, oracle):
     oracle.baq_idaq_reads(P, extended=True, idaq=False, procs=_procs())
     kw = dict(flag=la.LFQ_USE_BAQ | la.LFQ_USE_MQ | la.LFQ_USE_IDAQ)
     ref = oc.call_targets(oracle, P, R["ref"], _targets(), kw)
-    assert ref["n_columns"] >= 45000
+    assert ref["n_columns"] >= 50000
     assert total * 3 == ref["n_snv_tests"] == ntests and bonf == ref["conf"].bonf_subst
     conf = la.VarcallConf()
     conf.c.bonf_subst, conf.c.num_snv_tests = int(bonf), int(ntests)

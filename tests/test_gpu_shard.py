@@ -167,8 +167,9 @@ if rank == 0:
     np.save(out + ".meta", np.array([start.bonf_subst, start.num_snv_tests]))
 else:
     assert not rec_p.value
+caller.h = None                                          # the context belongs to the lfq_par handle ...
 P.lfq_par_destroy.argtypes = [C.c_void_p]
-P.lfq_par_destroy(par)                                   # destroys the context too
+P.lfq_par_destroy(par)                                   # ... which destroys it
 '''
 
 

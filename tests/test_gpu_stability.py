@@ -61,8 +61,14 @@ def test_invalid_arguments_are_error_codes(caller):
     assert L.lfq_pileup_indel_columns(caller.h, C.byref(rd), None, 10, 0, 0, C.byref(out), None) < 0   # end < begin
     t = _lib.Tracks()
     t.ncols = 3
-    af = np.array([0.1, 2.0, 0.1], np.float32)                  # AF out of range (lofreq_uniq.c:262-268)
+    af = np.array([0.1, 0.2, 0.1], np.float32)
     det = np.zeros(3, np.uint8)
+    assert L.lfq_uniq_detlim_batch(caller.h, C.byref(t), 0, vp(af.ctypes.data), vp(det.ctypes.data), None) < 0   # no tracks
+    one = np.zeros(32, np.uint8)
+    off = np.array([0, 4, 8, 12], np.uint64)
+    t.nt = t.bq = t.mq = vp(one.ctypes.data)
+    t.col_off, t.ref_base = vp(off.ctypes.data), vp(np.frombuffer(b"ACG" + bytes(13), np.uint8).copy().ctypes.data)
+    af[1] = np.nan                                              # a NaN AF is refused (an AF out of [0, 1] is RESET: test_gpu_uniq)
     assert L.lfq_uniq_detlim_batch(caller.h, C.byref(t), 0, vp(af.ctypes.data), vp(det.ctypes.data), None) < 0
 
 

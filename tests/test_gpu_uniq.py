@@ -23,7 +23,8 @@ def test_uniq_detlim_random_vs_oracle(caller, oracle, seed, lo, hi, n):
     rng = np.random.default_rng(seed)
     host = util.random_batch(rng, n, lo, hi)
     host["baq"] = None                          # uniq's mpileup carries no BAQ (lofreq_uniq.c:465)
-    af = rng.choice(np.array([0.0, 0.0005, 0.002, 0.005, 0.01, 0.02, 0.05, 0.1, 0.25, 0.5, 0.9, 1.0], np.float32), n)
+    # incl. AFs out of bounds: the reference logs them and RESETS them (af < 0 -> 0.01, af > 1 -> 1.0, lofreq_uniq.c:262-268)
+    af = rng.choice(np.array([0.0, 0.0005, 0.002, 0.005, 0.01, 0.02, 0.05, 0.1, 0.25, 0.5, 0.9, 1.0, -0.3, 1.7], np.float32), n)
     flag, opv = oracle.uniq_detlim_batch(host["nt"], host["bq"], None, host["mq"], None, host["col_off"],
                                          host["ref_base"], af)
     det, pv = caller.uniq_detlim(util.to_pileup_batch(la, host), af)
@@ -55,11 +56,13 @@ def test_uniq_binom_random_vs_oracle(caller, oracle, seed, lo, hi, n):
     rng = np.random.default_rng(seed)
     host = util.random_batch(rng, n, lo, hi, planted={c: float(rng.choice([0.01, 0.1, 0.4])) for c in range(0, n, 3)})
     host["baq"] = None
-    af = rng.choice(np.array([0.0, 0.002, 0.01, 0.05, 0.1, 0.25, 0.5, 0.9, 1.0], np.float32), n)
+    af = rng.choice(np.array([0.0, 0.002, 0.01, 0.05, 0.1, 0.25, 0.5, 0.9, 1.0, -2.0, 1.25], np.float32), n)
     alt = "".join(rng.choice(list("ACGTN"), n))
     ouq, opv = oracle.uniq_binom_batch(host["nt"], host["col_off"], af, alt)
     uq, pv = caller.uniq_binom(util.to_pileup_batch(la, host), af, alt)
     assert uq.tolist() == ouq.tolist()
+    oob = (af < 0) | (af > 1)
+    assert oob.sum() > 5 and (ouq[oob & (np.diff(host["col_off"]).astype(np.int64) > 0)] >= 0).all()      # reset, not dropped
     ok = ouq >= 0
     assert np.allclose(pv[ok], opv[ok], rtol=1e-11, atol=1e-300)
     for mtc in ("fdr", "holm"):
