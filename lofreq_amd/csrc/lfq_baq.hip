@@ -661,11 +661,11 @@ __device__ __forceinline__ uint32_t lfq_baq_ref4(const uint8_t *refw, int p, int
 
 /* one interior row of the forward pass (all 15 cells exist for every read of the wavefront); HASN: some read has an
  * N in its window or as its base */
-template <int NB, bool HASN, bool IDAQ>
+template <int NB, bool HASN, bool IDAQ, bool STORE>
 __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O1)[NB + 1], double (&O2)[NB + 1],
                                                 typename LfqBaqWinT<NB>::type win, int qyi, double e_eq,
                                                 double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp,
-                                                bool store, double &sum_out)
+                                                double &sum_out)
 {
     typedef typename LfqBaqWinT<NB>::type WinT;
     const WinT xq = win ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(qyi & 3));
@@ -681,7 +681,8 @@ __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O
         const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
         const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
         const double f2 = m[2] * m_prev + m[8] * d_prev;
-        if (store) {                                 /* wave-uniform: only the even rows go to HBM */
+        if (STORE) {                                 /* only the even rows go to HBM (a template parameter: a run-time
+                                                      * flag, although wave-uniform, cut the row into 15 basic blocks) */
             fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
         }
         m_prev = f0;
@@ -761,11 +762,11 @@ __device__ __forceinline__ void lfq_baq_map_row(const double (&O0)[NB + 1], cons
         const bool valid = !MASKED || (j >= jmin && j <= jmax);
         const double z0 = valid ? (f0 * rsi) * O0[j] : -1.;              /* -1.: never the maximum, adds 0. */
         max_u = z0 > max ? 4 * j : max_u;
-        max = z0 > max ? z0 : max;
+        max = __builtin_fmax(z0, max);               /* = z0 > max ? z0 : max (no NaNs here), one instruction */
         sum += valid ? z0 : 0.;
         const double z1 = valid ? (f1 * rsi) * O1[j] : -1.;
         max_u = z1 > max ? 4 * j + 1 : max_u;
-        max = z1 > max ? z1 : max;
+        max = __builtin_fmax(z1, max);
         sum += valid ? z1 : 0.;
     }
 }
@@ -823,7 +824,12 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 {
     typedef typename LfqBaqWinT<NB>::type WinT;
     constexpr int BWF = (NB - 1) / 2;               /* the band this instantiation holds in full */
-    extern __shared__ uint16_t s_rowq[];         /* [lds_rows + 2][64]: base code | quality << 8 of row i; later the BAQ bytes */
+    /* dynamic LDS: [NB][64] (match, insertion) pairs = the stored forward row the backward sweep needs next, brought in by
+     * global_load_lds (HBM -> LDS without passing through registers); then [lds_rows + 2][64] base code | quality << 8 of
+     * row i, later the BAQ bytes */
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    LfqBaqPair *const s_g = reinterpret_cast<LfqBaqPair *>(s_dyn);
+    uint16_t *const s_rowq = reinterpret_cast<uint16_t *>(s_dyn + (size_t)NB * 64 * sizeof(LfqBaqPair));
     const int lane = (int)threadIdx.x;
     const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
     const bool live = ridx < n_launch;
@@ -852,8 +858,32 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         const int o = __shfl_xor(Lmax, off);
         Lmax = o > Lmax ? o : Lmax;
     }
-    for (int i = 0; i <= Lmax + 1; i++) {
-        s_rowq[(size_t)i * 64 + lane] = (i >= 1 && i <= l_query) ? (uint16_t)(query[i] | (iqual[i] << 8)) : (uint16_t)4;
+    /* (base code | quality << 8) of every row into LDS: 64 bases per step as eight unaligned 16-byte loads of the read's own
+     * bytes, all in flight before the first LDS write (one byte pair per iteration waited out a full memory round trip
+     * 150 times per wavefront: a quarter of the forward pass) */
+    s_rowq[lane] = (uint16_t)4;                      /* row 0 */
+    for (int i0 = 1; i0 <= Lmax + 1; i0 += 64) {
+        uint4 qv[4], bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            qv[c] = bv[c] = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 + 16 * c <= l_query) {            /* the arrays carry 16 bytes of padding behind the last read */
+                __builtin_memcpy(&qv[c], query + i0 + 16 * c, 16);
+                __builtin_memcpy(&bv[c], iqual + i0 + 16 * c, 16);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t qw[4] = {qv[c].x, qv[c].y, qv[c].z, qv[c].w}, bw_[4] = {bv[c].x, bv[c].y, bv[c].z, bv[c].w};
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int i = i0 + 16 * c + t;
+                if (i <= Lmax + 1) {
+                    const uint32_t qb = (qw[t >> 2] >> (8 * (t & 3))) & 0xffu, bb = (bw_[t >> 2] >> (8 * (t & 3))) & 0xffu;
+                    s_rowq[(size_t)i * 64 + lane] = i <= l_query ? (uint16_t)(qb | (bb << 8)) : (uint16_t)4;
+                }
+            }
+        }
     }
     /* the quality table in LDS: a row's lookup then waits on lgkmcnt only.  As a global load it counted in vmcnt, which
      * retires in order on this ISA -- every row waited for its table entry behind the forward matrix's stores (forward
@@ -975,13 +1005,23 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);      /* enters the window for row i + 1 */
         const double e_eq = 1. - qli, e_ne = qli * LFQ_BAQ_EM;           /* lfq_baq_emit's two non-trivial values */
         LfqBaqPair *fp = FP(i);
+#ifdef LFQ_BAQ_NO_STORE                             /* timing experiment: what the forward matrix's stores cost */
+        const bool store = false;
+#else
         const bool store = (i & 1) == 0;             /* odd rows >= 3 are recomputed by the backward sweep (lfq_baq_refwd_row) */
+#endif
         if (i >= BWF + 1 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
             const bool has_n = qyi > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             if (__any(has_n)) {
-                lfq_baq_fwd_row<NB, true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, store, sum);
+                if (store) {
+                    lfq_baq_fwd_row<NB, true, IDAQ, true>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+                } else {
+                    lfq_baq_fwd_row<NB, true, IDAQ, false>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+                }
+            } else if (store) {
+                lfq_baq_fwd_row<NB, false, IDAQ, true>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             } else {
-                lfq_baq_fwd_row<NB, false, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, store, sum);
+                lfq_baq_fwd_row<NB, false, IDAQ, false>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             }
         } else {
             /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
@@ -1031,6 +1071,12 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         }
     }
 
+#ifdef LFQ_BAQ_FWD_ONLY                             /* timing experiment (profiles/ab_baq.sh): the forward pass alone */
+    if (A.rows >= 0) {
+        if (act) out[0] = (uint8_t)(s_last + s_fin);
+        return;
+    }
+#endif
     /* ---- expected reference offset of every matched query base (bam_md_ext.c:409-447) ---- */
     for (int i = 0; i < l_query; i++) {
         expect[(size_t)i * 64 + lane] = INT32_MIN;       /* not in a match block (the offset itself can be negative) */
@@ -1174,20 +1220,39 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     } while (0)
     LFQ_BAQ_BATCH(Lmax >> 2, rA0, rA1, rA2, rA3, eA0, eA1, eA2, eA3);
     LFQ_BAQ_BATCH((Lmax >> 2) - 1, rB0, rB1, rB2, rB3, eB0, eB1, eB2, eB3);
-    /* G: the forward cells of the stored row (even, or row 1) the sweep meets next -- row i itself at a stored row, row
-     * i - 1 at an odd row, whose own cells are recomputed from it.  Requested one stored row ahead: the load issued at a
-     * stored row lands during that row's and (usually) the following odd row's arithmetic. */
+    /* G: the forward cells of the stored row (even, or row 1) the sweep is at -- row i itself at a stored row, row i - 1 at
+     * an odd row, whose own cells are recomputed from it.  A stored row travels HBM -> LDS by global_load_lds (no
+     * registers on the way, so it can be requested two rows of arithmetic before it is needed: the registers of the row
+     * in use stay untouched) and LDS -> G when the sweep reaches the odd row above it; at that moment the LDS buffer is
+     * free again and the stored row after it is requested. */
     double G0[NB], G1[NB];
-    {
-        const int g_row = ((Lmax & 1) == 0 || Lmax == 1) ? Lmax : Lmax - 1;
-        const LfqBaqPair *gp = FP(g_row);
+    int g_have = -1;
+    auto dma_row = [&](int row) {
+        const LfqBaqPair *gp = FP(row);
 #pragma unroll
         for (int j = 0; j < NB; j++) {
-            const LfqBaqPair v = gp[(size_t)j * 64];
-            G0[j] = v.m;
-            G1[j] = v.i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)j * 64),
+                                             (__attribute__((address_space(3))) void *)(s_g + j * 64), 16, 0, 0);
         }
-    }
+    };
+    auto ensure_g = [&](int need) {                  /* need: wave-uniform */
+        if (need != g_have) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(0): the row has landed in LDS */
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const LfqBaqPair v = s_g[j * 64 + lane];
+                G0[j] = v.m;
+                G1[j] = v.i;
+            }
+            g_have = need;
+            const int next = need == 2 ? 1 : need - 2;
+            if (next >= 1) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): the reads above are done with the buffer */
+                dma_row(next);
+            }
+        }
+    };
+    dma_row(((Lmax & 1) == 0 || Lmax == 1) ? Lmax : Lmax - 1);
     for (int i = Lmax; i >= 1; --i) {
         const int t4 = i & 3;
         const double c_r = t4 == 0 ? rA0 : (t4 == 1 ? rA1 : (t4 == 2 ? rA2 : rA3));           /* 1 / s[i] */
@@ -1228,6 +1293,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 lfq_baq_bwd_row<NB, false, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
             }
             /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
+            ensure_g(odd ? i - 1 : i);
             if (!odd) {
                 lfq_baq_map_row<NB, false, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
             } else if (f_has_n) {
@@ -1264,6 +1330,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 O1[j] = last ? (in ? b_init1 : 0.) : (valid ? b1 * ys : 0.);
                 O2[j] = last ? 0. : (valid ? b2 * ys : 0.);
             }
+            ensure_g(odd ? i - 1 : i);
             if (!odd) {
                 lfq_baq_map_row<NB, false, false, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
             } else {
@@ -1340,17 +1407,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             }
             s_rowq[(size_t)(i + 1) * 64 + lane] = (uint16_t)bq;      /* out[i - 1]: the slot of row i + 1 is free now */
         }
-        if (!odd && i >= 2) {
-            /* this stored row is done with: the next one (row i - 2, or row 1 below row 2) is requested now and lands while
-             * the odd row in between computes its backward cells */
-            const LfqBaqPair *gp = FP(i == 2 ? 1 : i - 2);
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const LfqBaqPair v = gp[(size_t)j * 64];
-                G0[j] = v.m;
-                G1[j] = v.i;
-            }
-        }
     }
 #define OUTE(i0_) s_rowq[(size_t)((i0_) + 2) * 64 + lane]
 
@@ -1383,7 +1439,16 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             }
         }
     }
-    for (int i = 0; i < l_query; ++i) {                                  /* :456-462 */
+    for (int i = 0; i + 4 <= l_query; i += 4) {                          /* :456-462, four bytes per (unaligned) store */
+        uint32_t w = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int o = OUTE(i + t) & 0xff;
+            w |= (uint32_t)((o > 93 ? 93 : o) + 33) << (8 * t);
+        }
+        __builtin_memcpy(out + i, &w, 4);
+    }
+    for (int i = l_query & ~3; i < l_query; ++i) {
         const int o = OUTE(i) & 0xff;
         out[i] = (uint8_t)((o > 93 ? 93 : o) + 33);
     }
@@ -1424,7 +1489,7 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
         const size_t ref_bytes = ((size_t)a.max_lref / 2 + 2) * 64;
         if (lfq_knobs().baq_kernel == 0) {           /* default: rows in registers; LFQ_BAQ_KERNEL=1: the LDS-row kernel (A/B) */
             /* (base | quality) of every row, later the BAQ bytes (see the kernel) */
-            const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2;
+            const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2 + (size_t)(lds == 2 ? LFQ_BAQ_NB_WIDE : LFQ_BAQ_NB) * 64 * 16;
             const hipStream_t st = (hipStream_t)stream;
             if (lds == 2 && a.itab) {
                 hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
