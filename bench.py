@@ -237,8 +237,10 @@ def bench_host_abi(caller, la, seed, depth, ncols, plant_period, steps):
             "baq": dev_b.baq[:n].cpu().numpy().copy(), "mq": dev_b.mq[:n].cpu().numpy().copy(),
             "col_off": dev_b.col_off.cpu().numpy().astype(np.uint64), "ref_base": dev_b.ref_base[:ncols].cpu().numpy().copy()}
     del dev_b
+    # the nt track nibble-packed on the host, as the plp_proc_func shim builds it while the columns arrive
+    # (integration/lofreq_amd_shim.c): 3.5 instead of 4 bytes per observation over PCIe
     batch = la.PileupBatch(host["nt"], host["bq"], host["mq"], host["col_off"], host["ref_base"], baq=host["baq"],
-                           max_col_obs=depth)
+                           max_col_obs=depth).packed()
     n_obs = int(host["col_off"][-1])
     conf = la.VarcallConf()
     caller.call_snvs(batch, conf, records_capacity=1 << 16)          # warm-up: staging allocation
@@ -247,10 +249,10 @@ def bench_host_abi(caller, la, seed, depth, ncols, plant_period, steps):
         conf = la.VarcallConf()
         recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
     dt = (time.perf_counter() - t0) / steps
-    byt = 4.0 * n_obs + ncols * 9.0
+    byt = 3.5 * n_obs + ncols * 9.0
     return {"columns_per_s": ncols / dt, "ms_per_batch": dt * 1e3, "columns_per_batch": ncols, "depth": depth,
             "host_bytes_per_batch": byt, "effective_GBps": byt / dt / 1e9, "pcie_peak_GBps": 63.0,
-            "frac_of_pcie": byt / dt / 1e9 / 63.0, "records": int(len(recs)),
+            "frac_of_pcie": byt / dt / 1e9 / 63.0, "records": int(len(recs)), "nt_layout": "packed nibbles (host-packed)",
             "note": "pageable host arrays in, VCF records out; upload + kernels + host finish per call"}
 
 
@@ -409,7 +411,8 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
     best.update({"s_mean": sum(totals) / max(len(totals), 1), "iterations": len(totals), "s_each": [round(t, 5) for t in totals[:16]],
                  "wall_begin": wall[0], "wall_end": wall[1]})
-    best.update({"reads": n_reads, "read_len": R["rl"], "genome_len": glen, "depth": n_reads * R["rl"] / glen,
+    best.update({"nt_layout": "packed nibbles (written by the device pileup)" if (t.flags & 1) else "bytes",
+                 "reads": n_reads, "read_len": R["rl"], "genome_len": glen, "depth": n_reads * R["rl"] / glen,
                  "reads_per_s": n_reads / best["s_total"], "columns_per_s": best["columns"] / best["s_total"],
                  "call_indels": bool(call_indels),
                  "note": "resident read set; BAM decoding (htslib, CPU) not included; reference end-to-end rows "

@@ -65,7 +65,9 @@ typedef enum lfq_status {
  * Track base pointers must be 16-byte aligned and readable up to the next multiple of 16 bytes
  * past col_off[ncols]; col_off itself may be arbitrary (columns need not be aligned).
  *
- * LFQ_TRACKS_NT_PACKED (flags; device-resident tracks only): the nt track holds two observations per byte.
+ * LFQ_TRACKS_NT_PACKED (flags): the nt track holds two observations per byte ((n_obs + 7) / 8 * 4 bytes).  What the device
+ * pileup (lfq_pileup_snv_tracks / lfq_readset_pileup_snv) hands out by default, what the plp_proc_func shim
+ * (integration/lofreq_amd_shim.c) builds as the columns arrive, and what lfq_pack_nt_track makes of a byte track.
  * Observations are taken in groups of 8 (by their index in the track); byte k (k = 0..3) of a group's 4 bytes
  * carries observation k in its low nibble and observation 4 + k in its high nibble -- the even / odd nibbles of a
  * dword then line up with the group's two bq dwords.  The count kernel, the dominant one and HBM-bound, reads
@@ -421,6 +423,11 @@ int lfq_source_qual_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int def_nm_q
  * the records).  Default: on = 1.  lfq_call_snvs_batch decides by itself: dense strand counts exactly when
  * h_counts_or_null is given. */
 int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
+
+/* nt layout of the tracks the device pileup returns: on = 1 (default) LFQ_TRACKS_NT_PACKED, on = 0 one byte per
+ * observation.  lfq_pack_nt_track: the same packing for a host byte track (packed_out: (n_obs + 7) / 8 * 4 bytes). */
+int lfq_set_pileup_nt_packed(lfq_ctx *ctx, int on);
+int lfq_pack_nt_track(const uint8_t *nt_bytes, int64_t n_obs, uint8_t *packed_out);
 
 /* lfq_call_snvs_batch in two halves, for callers that keep more than one batch in flight (one context per batch in
  * flight): submit launches the kernels and returns; collect waits, fetches the sparse records and finishes them on

@@ -327,6 +327,7 @@ void lfq_call_flush(varcall_conf_t *conf)
     t.col_off = B.col_off; t.ref_base = B.ref_base;
     t.coverage_plp = B.cov; t.num_bases = B.nbases;
     t.ncols = B.ncols; t.max_col_obs = B.max_depth;
+    t.flags = LFQ_TRACKS_NT_PACKED;          /* half the nt bytes over PCIe, the 1.5-bytes-per-observation count kernel */
 
     rec = lfq_xrealloc(NULL, sizeof(lfq_snv_record) * (size_t)(3 * B.ncols));
     rc = lfq_call_snvs_batch(B.ctx, &lc, &t, /*tracks_on_device=*/0, rec, 3 * B.ncols, &n_rec, NULL, NULL);
@@ -388,7 +389,12 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
         for (j = 0; j < p->base_quals[i].n; j++) {
             const int64_t o = B.nobs++;
             int q;
-            B.nt[o] = (uint8_t)(i | (((long)j >= fw) ? 8 : 0));
+            /* LFQ_TRACKS_NT_PACKED: observation o sits in byte (o >> 3) * 4 + (o & 3), low nibble for o & 7 < 4 */
+            {
+                uint8_t *b = &B.nt[((o >> 3) << 2) + (o & 3)];
+                const uint8_t v = (uint8_t)(i | (((long)j >= fw) ? 8 : 0));
+                *b = (o & 4) ? (uint8_t)((*b & 0x0F) | (v << 4)) : v;
+            }
             B.bq[o] = (uint8_t)p->base_quals[i].data[j];
             q = p->baq_quals[i].n ? p->baq_quals[i].data[j] : -1;
             B.baq[o] = (uint8_t)(q < 0 ? LFQ_Q_MISSING : q);

@@ -305,6 +305,7 @@ struct lfq_ctx {
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
     int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */
     int batch_recorded;              /* ev[3] has been recorded: a batch of this context may still be running */
+    int plp_nt_bytes;                /* lfq_set_pileup_nt_packed(ctx, 0): the device pileup hands out one nt byte per observation */
     const uint8_t *sub_ref_host;
     double sub_t0, sub_t1;
     const float *detlim_af;          /* device: per-column allele frequency while lfq_uniq_detlim_batch runs, else null */
@@ -1159,6 +1160,36 @@ int lfq_set_indel_arrays_on_host(lfq_ctx *c, int on)
     return LFQ_OK;
 }
 
+int lfq_set_pileup_nt_packed(lfq_ctx *c, int on)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    c->plp_nt_bytes = on ? 0 : 1;
+    return LFQ_OK;
+}
+
+int lfq_pack_nt_track(const uint8_t *nt_bytes, int64_t n_obs, uint8_t *packed_out)
+{
+    if (n_obs < 0 || (n_obs > 0 && (!nt_bytes || !packed_out))) {
+        return LFQ_ERR_INVALID;
+    }
+    const int64_t full = n_obs / 8;
+    for (int64_t g = 0; g < full; g++) {
+        for (int k = 0; k < 4; k++) {
+            packed_out[4 * g + k] = (uint8_t)((nt_bytes[8 * g + k] & 15) | ((nt_bytes[8 * g + 4 + k] & 15) << 4));
+        }
+    }
+    if (n_obs & 7) {
+        uint8_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        memcpy(last, nt_bytes + 8 * full, (size_t)(n_obs & 7));
+        for (int k = 0; k < 4; k++) {
+            packed_out[4 * full + k] = (uint8_t)((last[k] & 15) | ((last[4 + k] & 15) << 4));
+        }
+    }
+    return LFQ_OK;
+}
+
 int lfq_set_dense_strand_counts(lfq_ctx *c, int on)
 {
     if (!c) {
@@ -1278,9 +1309,6 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
     if (ncols > 0 && (!tr->nt || !tr->bq || !tr->mq || !tr->col_off || !tr->ref_base)) {
         return LFQ_ERR_INVALID;         /* (baq and sq may be NULL: track off) */
     }
-    if (!tracks_on_device && (tr->flags & LFQ_TRACKS_NT_PACKED)) {
-        return LFQ_ERR_INVALID;         /* the packed nt layout is for device-resident producers */
-    }
     if (!tracks_on_device) {
         /* host buffers: stage them (padded to the 16-byte contract) in one device allocation */
         const uint64_t n_obs = tr->col_off[ncols];
@@ -1300,7 +1328,9 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
             }
             return dst;
         };
-        dev.nt = put(tr->nt, (int64_t)n_obs, trk);
+        /* a host producer that packs its nt track (lfq_pack_nt_track, or nibble by nibble as the columns arrive) sends
+         * half the bytes of that track over PCIe and gets the 1.5-bytes-per-observation count kernel */
+        dev.nt = put(tr->nt, (tr->flags & LFQ_TRACKS_NT_PACKED) ? (int64_t)((n_obs + 7) / 8 * 4) : (int64_t)n_obs, trk);
         dev.bq = put(tr->bq, (int64_t)n_obs, trk);
         dev.baq = put(tr->baq, (int64_t)n_obs, trk);
         dev.mq = put(tr->mq, (int64_t)n_obs, trk);
@@ -2902,9 +2932,10 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     });
     const int64_t ncols = (int64_t)h_cov.size();
     const int64_t n_obs = (int64_t)off.back(), trk = al(n_obs + 32);
+    const bool nt_packed = !c->plp_nt_bytes;
     const int64_t t_off = 0, t_ref = t_off + al((ncols + 1) * 8), t_cov = t_ref + al(ncols + 16), t_nb = t_cov + al(ncols * 4 + 16),
                   t_nt = t_nb + al(ncols * 4 + 16), t_bq = t_nt + trk, t_baq = t_bq + trk, t_mq = t_baq + trk,
-                  t_sq = t_mq + trk, t_total = t_sq + (rs->has_sqb ? trk : 0);
+                  t_sq = t_mq + trk, t_ntp = t_sq + (rs->has_sqb ? trk : 0), t_total = t_ntp + (nt_packed ? al(trk / 2 + 16) : 0);
     LFQ_TRY(grow(&c->d_plp_out, &c->plp_out_bytes, t_total));
     uint8_t *t = c->d_plp_out;
     LFQ_TRY_HIP(hipMemsetAsync(t + t_nt, 0, (size_t)(t_total - t_nt), c->stream));     /* the 16-byte tails are read */
@@ -2923,8 +2954,14 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.t_mq = t + t_mq;
     A.t_sq = rs->has_sqb ? t + t_sq : nullptr;
     LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 1, c->stream) : lfq_launch_pileup_scatter(A, c->stream));
+    if (nt_packed) {
+        /* the layout the count kernel reads 1.5 instead of 2 bytes per observation of (LFQ_TRACKS_NT_PACKED): the scatter
+         * pass writes bytes (two lanes, often of two wavefronts, would share a byte), one streaming pass packs them */
+        LFQ_TRY(lfq_launch_pack_nt(t + t_nt, t + t_ntp, n_obs, c->stream));
+    }
     LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
-    out->nt = t + t_nt;
+    out->nt = nt_packed ? t + t_ntp : t + t_nt;
+    out->flags = nt_packed ? LFQ_TRACKS_NT_PACKED : 0;
     out->bq = t + t_bq;
     out->baq = t + t_baq;
     out->mq = t + t_mq;

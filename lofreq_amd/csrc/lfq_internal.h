@@ -305,6 +305,7 @@ int lfq_launch_plp_indel(const LfqPlpIndelArgs &a, int scatter, void *stream);
 int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *stream);
 int lfq_launch_flag_merge(uint8_t *fl, const uint8_t *tag, int64_t n, void *stream);
 int lfq_launch_skip_columns(int32_t *nb, const uint8_t *skip, int64_t n, void *stream);
+int lfq_launch_pack_nt(const uint8_t *nt_bytes, uint8_t *nt_packed, int64_t n_obs, void *stream);
 int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n, uint8_t *oa, uint8_t *ob, void *stream);
 
 /* indel pseudo-columns built on the device from the resident quality arrays of lfq_readset_pileup_indels */

@@ -620,6 +620,29 @@ __global__ __launch_bounds__(256) void lfq_skip_columns_kernel(int32_t *nb, cons
     }
 }
 
+/* byte-per-observation nt track -> LFQ_TRACKS_NT_PACKED (include/lofreq_amd.h): observations in groups of 8 by their index in
+ * the track, byte k of a group's four bytes = observation k (low nibble) | observation 4 + k (high nibble).  One thread
+ * per group: 8 bytes in, 4 bytes out; the track is zero-padded past its last observation. */
+__global__ void lfq_pack_nt_kernel(const uint2 *__restrict__ nt, uint32_t *__restrict__ out, int64_t n_groups)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_groups) {
+        const uint2 v = nt[g];
+        out[g] = (v.x & 0x0F0F0F0Fu) | ((v.y & 0x0F0F0F0Fu) << 4);
+    }
+}
+
+int lfq_launch_pack_nt(const uint8_t *nt_bytes, uint8_t *nt_packed, int64_t n_obs, void *stream)
+{
+    const int64_t n_groups = (n_obs + 7) / 8;
+    if (n_groups <= 0) {
+        return LFQ_OK;
+    }
+    hipLaunchKernelGGL(lfq_pack_nt_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint2 *)nt_bytes, (uint32_t *)nt_packed, n_groups);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
 int lfq_launch_skip_columns(int32_t *nb, const uint8_t *skip, int64_t n, void *stream)
 {
     if (n <= 0) {

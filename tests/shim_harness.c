@@ -100,7 +100,8 @@ int lfq_call_snvs_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_tracks *t, int t
     put(t->ref_base, (size_t)t->ncols);
     put(t->coverage_plp, (size_t)t->ncols * 4);
     put(t->num_bases, (size_t)t->ncols * 4);
-    put(t->nt, (size_t)n_obs);
+    put_i64(t->flags);
+    put(t->nt, (t->flags & LFQ_TRACKS_NT_PACKED) ? (size_t)((n_obs + 7) / 8 * 4) : (size_t)n_obs);
     put(t->bq, (size_t)n_obs);
     put(t->mq, (size_t)n_obs);
     if (t->baq) put(t->baq, (size_t)n_obs);

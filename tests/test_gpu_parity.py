@@ -397,6 +397,29 @@ def test_packed_nt_layout_equals_byte_layout(caller, kw):
         assert res[0][2] > 0
 
 
+@pytest.mark.parametrize("seed,lo,hi,n,with_sq", [(5, 0, 300, 400, False), (6, 2000, 9000, 30, True), (7, 1, 17, 500, False)])
+def test_host_tracks_packed_nt_equal_byte_tracks(caller, oracle, seed, lo, hi, n, with_sq):
+    """a HOST producer that nibble-packs its nt track (what the plp_proc_func shim does as the columns arrive;
+    lfq_pack_nt_track): lfq_call_snvs_batch(tracks_on_device = 0, LFQ_TRACKS_NT_PACKED) returns the records and dense
+    counts of the byte tracks -- and both equal the oracle.  Ragged columns, empty ones, observation counts that are not
+    multiples of 8."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(seed)
+    host = util.random_batch(rng, n, lo, hi, with_sq=with_sq, planted={c: 0.2 for c in range(3, n, 29)}, ref_n_frac=0.02)
+    kw = dict(flag=7) if with_sq else {}
+    ores, oconf = util.run_oracle(oracle, host, **kw)
+    b = util.to_pileup_batch(la, host)
+    res = []
+    for batch in (b, b.packed()):
+        conf = la.VarcallConf(**kw)
+        recs, counts, st = caller.call_snvs(batch, conf, want_counts=True)
+        res.append((recs.tobytes(), counts.tobytes(), int(st.n_tested), int(conf.bonf_subst)))
+        util.assert_counts_equal(counts, ores, host)
+        _compare_records(la, recs, ores, host)
+    assert res[0] == res[1] and res[0][3] == oconf.bonf_subst
+    assert b.packed().nt.nbytes < b.nt.nbytes // 2 + 32
+
+
 def test_config_c2_depth1000_default_filter(caller, oracle):
     """BASELINE.json configs[1] (C2) at test size: the synthetic generator at depth 1000, dynamic Bonferroni, QUAL
     threshold from the final factor and the DEFAULT filter (DP >= 10, strand-bias FDR) -- device tracks through layer 2,

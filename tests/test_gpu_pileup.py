@@ -21,8 +21,28 @@ def _fetch(ptr, nbytes):
     return out
 
 
+def _fetch_nt(t, n_obs):
+    """the nt track of device tracks, one code per observation whatever the layout (LFQ_TRACKS_NT_PACKED: observation o
+    sits in byte (o >> 3) * 4 + (o & 3), nibble (o & 7) >> 2)"""
+    if not (t.flags & 1):
+        return _fetch(t.nt, max(n_obs, 1))[:n_obs]
+    raw = _fetch(t.nt, (n_obs + 7) // 8 * 4 + 4)
+    o = np.arange(n_obs)
+    return ((raw[(o >> 3) * 4 + (o & 3)] >> (4 * ((o & 7) >> 2))) & 15).astype(np.uint8)
+
+
+@pytest.mark.parametrize("packed", [True, False], ids=["nt_packed", "nt_bytes"])
 @pytest.mark.parametrize("path", gu.pileup_fixtures(), ids=lambda p: p.split("/")[-1])
-def test_pileup_matches_plpsummary(caller, path):
+def test_pileup_matches_plpsummary(caller, path, packed):
+    import lofreq_amd as la
+    caller.set_pileup_nt_packed(packed)
+    try:
+        _pileup_matches_plpsummary(caller, path, packed)
+    finally:
+        caller.set_pileup_nt_packed(True)
+
+
+def _pileup_matches_plpsummary(caller, path, packed):
     import lofreq_amd as la
     fx = json.load(open(path))
     reads = [{"pos0": r[0], "cigar": gu.parse_cigar(r[3]), "seq": la.encode_seq(r[4]),
@@ -35,7 +55,9 @@ def test_pileup_matches_plpsummary(caller, path):
     ncols = dt.ncols
     off = _fetch(t.col_off, (ncols + 1) * 8).view(np.uint64)
     n_obs = int(off[-1])
-    nt, bq, baq, mq = (_fetch(p, n_obs) for p in (t.nt, t.bq, t.baq, t.mq))
+    assert bool(t.flags & 1) == packed           # the layout the context was asked for (default: packed)
+    nt = _fetch_nt(t, n_obs)
+    bq, baq, mq = (_fetch(p, n_obs) for p in (t.bq, t.baq, t.mq))
     ref = _fetch(t.ref_base, ncols)
     exp = {c["pos0"]: c for c in fx["columns"]}
     assert ncols >= len(exp)
@@ -104,7 +126,7 @@ def test_pileup_unsorted_reads_take_the_read_major_kernels(caller):
         t = dt._tracks()
         off = _fetch(t.col_off, (dt.ncols + 1) * 8).view(np.uint64)
         n_obs = int(off[-1])
-        tr = [_fetch(p, n_obs) for p in (t.nt, t.bq, t.baq, t.mq)]
+        tr = [_fetch_nt(t, n_obs)] + [_fetch(p, n_obs) for p in (t.bq, t.baq, t.mq)]
         cols = [sorted(zip(*(x[int(off[c]):int(off[c + 1])].tolist() for x in tr))) for c in range(dt.ncols)]
         recs, _, _ = caller.call_snvs(dt, la.VarcallConf())
         res.append((dt.col_pos.tolist(), cols, recs.tobytes()))
@@ -136,7 +158,7 @@ def test_window_search_at_its_round_boundaries(caller, n_reads):
         t = dt._tracks()
         off = _fetch(t.col_off, (dt.ncols + 1) * 8).view(np.uint64)
         n_obs = int(off[-1])
-        tr = [_fetch(p, max(n_obs, 1))[:n_obs] for p in (t.nt, t.bq, t.mq)]
+        tr = [_fetch_nt(t, n_obs)] + [_fetch(p, max(n_obs, 1))[:n_obs] for p in (t.bq, t.mq)]
         cols = [sorted(zip(*(x[int(off[c]):int(off[c + 1])].tolist() for x in tr))) for c in range(dt.ncols)]
         icols, ipos = la.pileup_indel_columns(caller, rd, ref, 0, glen)
         res.append((dt.col_pos.tolist(), cols, ipos.tolist(), icols.coverage_plp.tolist(), icols.num_non_indels.tolist(),

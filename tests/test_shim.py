@@ -123,7 +123,13 @@ def test_shim_packs_snv_columns_like_golden_util(harness, tmp_path, path):
     ref = out.arr("u1", nc)
     cov = out.arr("<i4", nc)
     nb = out.arr("<i4", nc)
-    tracks = {k: out.arr("u1", n_obs) for k in (["nt", "bq", "mq"] + (["baq"] if has_baq else []))}
+    # the shim hands over the nt track nibble-packed (LFQ_TRACKS_NT_PACKED): observation o in byte (o >> 3) * 4 + (o & 3),
+    # nibble (o & 7) >> 2
+    assert out.i64() == 1
+    raw = out.arr("u1", (n_obs + 7) // 8 * 4)
+    o = np.arange(n_obs)
+    tracks = {"nt": ((raw[(o >> 3) * 4 + (o & 3)] >> (4 * ((o & 7) >> 2))) & 15).astype(np.uint8)}
+    tracks.update({k: out.arr("u1", n_obs) for k in (["bq", "mq"] + (["baq"] if has_baq else []))})
     depth = np.diff(host["col_off"].astype(np.int64))
     assert np.array_equal(np.diff(col_off.astype(np.int64)), depth[keep])
     assert np.array_equal(ref, host["ref_base"][keep])
