@@ -1043,7 +1043,7 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
          * latency-bound kernels of the long columns, or they only start when it ends */
-        const int light_waves_per_cu = kn.light_kernel == 0 ? kn.screen_waves_per_cu : kn.light_waves_per_cu;
+        const int light_waves_per_cu = kn.light_kernel == 0 ? kn.screen_waves_per_cu : 10;
         const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * light_waves_per_cu, std::max<int64_t>(seg_cols / 8, 4));
         const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(seg_cols, 4));
         const bool run_big = !kn.skip_big, run_mid = !kn.skip_mid;     /* profiling aid: run the DP classes in isolation */

@@ -785,27 +785,6 @@ __device__ __forceinline__ int lfq_claim(int32_t *head, int n)
     return __builtin_amdgcn_readfirstlane(old);
 }
 
-/* lanes per light column for this batch: the smallest group that fits 90 % of the light columns (the rest go
- * to the retry kernel); 64 = one column per wavefront (lfq_dp_wave_kernel<1>).  Deep pileups have K ~ depth / 7000
- * per alt base from sequencing errors alone, so the best group size is a property of the batch. */
-__device__ __forceinline__ int lfq_light_group_lanes(const LfqWork &W, int den)
-{
-    /* den: 1 / den of the light columns may exceed the group (they go to the retry kernel): 10 for the lane-group
-     * kernels, 2000 for the screen kernel, whose wider variants cost little and whose leftovers cost a wavefront each */
-    const int64_t n = W.counters[LFQ_CNT_LIGHT];
-    const int64_t need = n - n / den;
-    if (W.counters[LFQ_CNT_KLE7] >= need) {
-        return 8;
-    }
-    if (W.counters[LFQ_CNT_KLE15] >= need) {
-        return 16;
-    }
-    if (W.counters[LFQ_CNT_KLE31] >= need) {
-        return 32;
-    }
-    return 64;
-}
-
 /* what the column pipeline wants loaded while this column computes */
 struct LfqPrefetch {
     bool want_raw, want_entry;
@@ -955,9 +934,7 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
 {
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
-    if (only_if_gl64 && lfq_light_group_lanes(W, only_if_gl64) != 64) {   /* only_if_gl64 = the `den` of the light kernel in use */
-        return;                                     /* the quad kernel serves this batch's light class */
-    }
+    (void)only_if_gl64;
     if (MAXC > 1) {
         /* few, long, latency-bound columns sharing SIMDs with the throughput-bound light kernel:
          * win the issue arbitration (MI355X_MICROARCH "two waves per SIMD", item 2) */
@@ -1034,222 +1011,8 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
 /* light columns, four at a time                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Almost every column of a deep pileup is "light": a handful of mismatches (K <= 15) whose tail
- * probability crosses the pruning threshold within a few dozen rows.  One column per wavefront leaves
- * 60 of 64 lanes idle in the recurrence, so this kernel runs FOUR columns per wavefront, one per 16-lane
- * DPP row: cell k of a column on lane k of its row (row_shr:1 brings the left neighbour, bound_ctrl feeds
- * 0 into cell 0), GL observations of each column evaluated per step (one per lane), GL rows of the
- * recurrence per step, pruning test every 8 rows.  A lane group whose column is pruned takes the next
- * column from the wavefront's claimed batch.  The kernel only PRUNES: a column that reaches its end
- * unpruned, or has K >= GL, is flagged in `retry` and done from scratch by
- * lfq_dp_retry_kernel (one wavefront per column, emission included) -- under 1 % of the columns. */
-#define LFQ_Q_MAX_ROWS (1 << 20)     /* effectively none: a deep column may need thousands of rows before its tail crosses
-                                      * the threshold, and running it twice costs more than keeping its lane group */
 
-__device__ __forceinline__ int lfq_rowshr1_i32(int x)
-{
-    return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    /* row_shr:1, 0 into lane 0 of each row */
-}
-
-__device__ __forceinline__ double lfq_rowshr1_f64(double x)
-{
-    const int lo = lfq_rowshr1_i32(__double2loint(x));
-    const int hi = lfq_rowshr1_i32(__double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-
-/* left neighbour within a GL-lane group: row_shr:1 inside a 16-lane DPP row, wave_shr:1 for 32-lane groups;
- * what is dragged in at the first lane of a group is multiplied by 2^-4000 = 0 by the caller */
-template <int GL>
-__device__ __forceinline__ int lfq_grpshr1_i32(int x)
-{
-    return GL <= 16 ? lfq_rowshr1_i32(x) : lfq_shr1_i32(x);
-}
-
-template <int GL>
-__device__ __forceinline__ double lfq_grpshr1_f64(double x)
-{
-    return GL <= 16 ? lfq_rowshr1_f64(x) : lfq_shr1_f64(x);
-}
-
-/* GL = lanes per column: 8 (eight columns per wavefront, K <= 7), 16 (four, K <= 15) or 32 (two, K <= 31). */
-template <int GL>
-__global__ __launch_bounds__(256) void lfq_dp_quad_kernel(LfqTracksDev T, LfqParams P,
-                                                          const LfqLuts *__restrict__ g_luts, LfqWork W,
-                                                          uint8_t *__restrict__ retry, int batch, int force_gl)
-{
-    constexpr int NG = 64 / GL;                     /* columns in flight per wavefront */
-    constexpr int MAXK = GL - 1;
-    constexpr int MAX_STEPS = LFQ_Q_MAX_ROWS / GL;
-    __shared__ LfqLuts s_luts;
-    __shared__ LfqRow s_rows[4][64];
-    if (force_gl ? (force_gl != GL) : (lfq_light_group_lanes(W, 10) != GL)) {
-        return;                                     /* another group size serves this batch */
-    }
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
-    __syncthreads();
-    const int lane = lfq_lane();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g = lane / GL, l = lane % GL;
-    const int n_work = W.counters[LFQ_CNT_LIGHT];
-    const LfqEntry *list = W.entries;               /* the light class leads the work list */
-    LfqRow *rows = s_rows[wave];
-    const double sig_s = P.sig * (1.0 + P.prune_slack);
-
-    int q_next = 0, q_end = 0;                      /* this wavefront's claimed batch (wave-uniform) */
-    bool exhausted = false;
-    /* state of the lane group's column, replicated on its GL lanes */
-    bool active = false;
-    uint64_t off0 = 0;
-    int n_obs = 0, cursor = 0, K = 0, ref_code = 0, med = 0, steps = 0, list_idx = 0;
-    double bonf_d = 1.0, tflag = 0.0;
-    double v = 0.0;
-    int e = 0, de = 0;
-    uint32_t raw_w = 4u, raw_sq = 255u;             /* the observation this lane evaluates in the next step */
-
-    for (;;) {
-        /* ---- hand new columns to the lane groups that have none ---- */
-        uint64_t need = __ballot(!active);
-        while (need != 0ull && !exhausted) {
-            if (q_next >= q_end) {
-                const int b0 = lfq_claim(&W.counters[LFQ_CNT_HEAD_LIGHT], batch);
-                if (b0 >= n_work) {
-                    exhausted = true;
-                    break;
-                }
-                q_next = b0;
-                q_end = min(b0 + batch, n_work);
-            }
-            unsigned gm = 0;
-#pragma unroll
-            for (int gi = 0; gi < NG; gi++) {
-                gm |= (unsigned)((need >> (gi * GL)) & 1ull) << gi;
-            }
-            const int take = min(__popc(gm), q_end - q_next);
-            const int rank = __popc(gm & ((1u << g) - 1u));
-            const bool mine = !active && rank < take;
-            const int idx = q_next + rank;
-            q_next += take;
-            if (mine) {
-                const uint4 *ep = reinterpret_cast<const uint4 *>(list + idx);
-                const uint4 a = ep[0], b = ep[1];
-                K = (int)b.y;
-                if (K > MAXK) {
-                    if (l == 0) {
-                        retry[idx] = 1;             /* needs more lanes: one-column-per-wave kernel */
-                    }
-                } else {
-                    active = true;
-                    off0 = ((uint64_t)a.y << 32) | a.x;
-                    n_obs = (int)a.z;
-                    int64_t bonf = P.bonf_base;
-                    if (P.bonf_dynamic) {           /* lfq_col_setup */
-                        bonf = ((P.bonf_reset_first && P.bonf_base == 1) ? 0 : P.bonf_base)
-                               + (int64_t)P.bonf_step * (int)b.x;
-                    }
-                    bonf_d = (double)bonf;
-                    med = (int)(int16_t)(b.z & 0xffffu);
-                    ref_code = (int)((b.z >> 16) & 0xffu);
-                    cursor = 0;
-                    steps = 0;
-                    list_idx = idx;
-                    v = (l == 0) ? 1.0 : 0.0;
-                    e = 0;
-                    de = (l == 0) ? -4000 : 0;
-                    tflag = (l == K) ? 1.0 : 0.0;
-                    raw_w = 4u;
-                    raw_sq = 255u;
-                    if (l < n_obs) {
-                        const uint64_t o = off0 + (uint64_t)l;
-                        raw_w = lfq_nt_at(T, o) | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
-                                | ((uint32_t)T.mq[o] << 24);
-                        raw_sq = T.sq ? T.sq[o] : 255u;
-                    }
-                }
-            }
-            need = __ballot(!active);
-        }
-        if (__ballot(active) == 0ull) {
-            break;
-        }
-
-        /* ---- GL observations per column: (p, 1-p) rows into LDS ---- */
-        {
-            const LfqObs o = lfq_eval_obs(raw_w & 0xffu, (raw_w >> 8) & 0xffu, (raw_w >> 16) & 0xffu, raw_w >> 24, raw_sq,
-                                          ref_code, med, P, &s_luts);
-            const bool keep = active && o.keep;
-            const double ps = (fabs(o.p) < LFQ_DBL_EPS) ? LFQ_DBL_EPS : o.p;                       /* lfq_eval_raw */
-            const double qf = (fabs(o.p - 1.0) < LFQ_DBL_EPS) ? 1.0 + (-o.p + LFQ_DBL_EPS) : 1.0 - o.p;
-            LfqRow r;
-            r.p = keep ? ps : 0.0;
-            r.q = keep ? qf : 1.0;
-            rows[lane] = r;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        cursor += GL;
-        raw_w = 4u;                                  /* an N base: ignored */
-        raw_sq = 255u;
-        if (active && cursor + l < n_obs) {          /* lands while the rows below run */
-            const uint64_t o = off0 + (uint64_t)(cursor + l);
-            raw_w = lfq_nt_at(T, o) | ((uint32_t)T.bq[o] << 8) | ((T.baq ? (uint32_t)T.baq[o] : 255u) << 16)
-                    | ((uint32_t)T.mq[o] << 24);
-            raw_sq = T.sq ? T.sq[o] : 255u;
-        }
-
-        /* ---- GL rows, renormalisation + pruning test after each 8 ---- */
-        bool pruned = false;
-        const LfqRow *grow = rows + g * GL;
-#pragma unroll
-        for (int part = 0; part < GL / 8; part++) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const LfqRow pq = grow[part * 8 + r];
-                const double x = lfq_grpshr1_f64<GL>(v);
-                const double pe = ldexp(pq.p, de);
-                const double q0 = fma(tflag, pq.p, pq.q);
-                v = fma(x, pe, v * q0);
-            }
-            const bool nzl = v > 0.0;
-            const uint64_t nz = __ballot(nzl);
-            const int ex = nzl ? __builtin_amdgcn_frexp_exp(v) : 0;
-            v = ldexp(v, -ex);
-            e += ex;
-            /* empty cells (a suffix of the lane group) adopt the scale of the frontier cell */
-            const unsigned field = (unsigned)(nz >> (g * GL)) & (unsigned)((1ull << GL) - 1ull);
-            const int front = g * GL + (field ? 31 - __clz((int)field) : l);
-            const int e_front = __shfl(e, nzl ? lane : front, 64);
-            e = nzl ? e : e_front;
-            const int e_left = lfq_grpshr1_i32<GL>(e);           /* all lanes: a DPP read of a masked-off lane is 0 */
-            de = (l == 0) ? -4000 : e_left - e;                  /* nothing enters cell 0 */
-            const uint64_t over = __ballot(ldexp(v, e) * bonf_d > sig_s);
-            pruned = pruned || ((over >> (g * GL + K)) & 1ull) != 0ull;
-        }
-        steps += 1;
-        if (active) {
-            if (pruned) {
-#ifdef LFQ_TRACE
-                if (l == K) printf("quad prune: lane %d g %d K %d v %g e %d tail %g bonf %g sig %g steps %d idx %d\n", lane, g, K, v, e, ldexp(v, e), bonf_d, sig_s, steps, list_idx);
-#endif
-                active = false;                     /* p * bonf > sig for good: nothing to report */
-            } else if (cursor >= n_obs || steps >= MAX_STEPS) {
-                if (l == 0) {
-                    retry[list_idx] = 1;            /* survivor (or a long one): finish it on a whole wavefront */
-                }
-                active = false;
-            }
-        }
-    }
-}
-
-/* the columns the quad kernel flagged: static partition of the light list over the wavefronts */
+/* the columns the screen kernel flagged: static partition of the light list over the wavefronts */
 __global__ __launch_bounds__(256) void lfq_dp_retry_kernel(LfqTracksDev T, LfqParams P,
                                                            const LfqLuts *__restrict__ g_luts,
                                                            const lfq_col_counts *__restrict__ counts, LfqWork W,
@@ -3020,18 +2783,8 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
     const dim3 grid((unsigned)((n_waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const LfqKnobs &kn = lfq_knobs();
-    int force = kn.light_lanes;                      /* A/B: LFQ_QUAD_LANES = cells (lanes) per light column, or 64 */
-    if (kn.light_kernel == 1) {                      /* A/B: the lane-group kernels (LFQ_LIGHT_KERNEL=quad) */
-        /* one of the variants serves the batch (lfq_light_group_lanes, decided on the device from the K histogram
-         * of the scan); the others return at once */
-        hipLaunchKernelGGL(lfq_dp_quad_kernel<8>, grid, block, 0, st, t, p, d_luts, w, d_retry, 64, force);
-        hipLaunchKernelGGL(lfq_dp_quad_kernel<16>, grid, block, 0, st, t, p, d_luts, w, d_retry, 32, force);
-        hipLaunchKernelGGL(lfq_dp_quad_kernel<32>, grid, block, 0, st, t, p, d_luts, w, d_retry, 16, force);
-        if (force == 0 || force == 64) {
-            hipLaunchKernelGGL(lfq_dp_wave_kernel<1>, grid, block, 0, st, t, p, d_luts, d_counts, w, -1, LFQ_CNT_LIGHT,
-                               d_pvals, pvals_capacity, 32, force == 64 ? 0 : 10);
-        }
-    } else {
+    int force = 0;
+    {
         /* one light column per lane: ONE variant is launched, chosen on the host from the K histogram the scan of this
          * context's previous batch left behind (a batch cannot wait for its own scan without stalling the host).  Any
          * choice is correct: a column with more alt bases than the variant has cells goes to the retry kernel. */

@@ -49,10 +49,8 @@ const LfqKnobs &lfq_knobs(void)
             x.skip_big = strstr(sk, "big") != nullptr;
         }
         if (const char *lk = getenv("LFQ_LIGHT_KERNEL")) {
-            x.light_kernel = !strcmp(lk, "quad") ? 1 : (!strcmp(lk, "wave") ? 2 : 0);
+            x.light_kernel = !strcmp(lk, "wave") ? 2 : 0;
         }
-        x.light_lanes = (int)geti("LFQ_QUAD_LANES", 0);
-        x.light_waves_per_cu = (int)std::max(4L, geti("LFQ_LIGHT_WAVES_PER_CU", 10));
         x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 4));
         x.screen_exact = has("LFQ_SCREEN_EXACT");
         x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));

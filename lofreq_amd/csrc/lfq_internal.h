@@ -164,8 +164,8 @@ struct LfqWork {
 #define LFQ_CNT_POOL 7         /* cells handed out from LfqWork::pool */
 #define LFQ_CNT_HEAD_COMB 24        /* and 25: one head per fold kernel mode */
 #define LFQ_CNT_HEAD_FOLD 48        /* and 49: the wavefront-per-column fold kernel's heads */
-#define LFQ_CNT_KLE7 26             /* light columns with K <= 7 / <= 15 / <= 31: picks the lanes-per-column of the */
-#define LFQ_CNT_KLE15 27            /* quad kernel for this batch (lfq_light_group_lanes) */
+#define LFQ_CNT_KLE7 26             /* light columns with K <= 7 / <= 15 / <= 31 (coarse histogram of the scan) */
+#define LFQ_CNT_KLE15 27
 #define LFQ_CNT_KLE31 28
 #define LFQ_CNT_XHEAD 64       /* screen kernel: dequeue heads of the eight XCD slices of the light list, one per 128-byte
                                 * line (head x at counters[LFQ_CNT_XHEAD + 32 x]): atomics on one line serialise */
@@ -182,9 +182,8 @@ struct LfqKnobs {
     int no_sb_precompute;      /* LFQ_NO_SB_PRECOMPUTE */
     int debug_sync;            /* LFQ_DEBUG_SYNC: serialise and name the stages */
     int skip_light, skip_mid, skip_big;   /* LFQ_DEBUG_SKIP=light,mid,big: run the DP classes in isolation */
-    int light_kernel;          /* LFQ_LIGHT_KERNEL: 0 screen (default: one light column per lane), 1 quad (lane groups), 2 wave */
-    int light_lanes;           /* LFQ_QUAD_LANES: force 8 / 16 / 32 / 64 cells (lanes) per light column; 0 = per batch */
-    int light_waves_per_cu;    /* LFQ_LIGHT_WAVES_PER_CU (10): lane-group kernels */
+    int light_kernel;          /* LFQ_LIGHT_KERNEL=wave: 2 = one light column per wavefront instead of the screen kernel (the
+                                * kernel that serves K >= 32 anyway); 0 = screen (one light column per lane) */
     int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (4): the screen is latency-bound per column, more wavefronts only crowd the two critical chains */
     int screen_exact;          /* LFQ_SCREEN_EXACT: the screen kernel evaluates the full quality merge instead of its lower bound */
     int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */

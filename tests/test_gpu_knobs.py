@@ -1,0 +1,48 @@
+"""-m gpu: the code paths that only run under an environment knob (fallbacks for inputs the default route cannot take,
+and A/B switches that are still in the tree) get the parity tests of their area, each in a process of its own with the
+knob set -- so that nothing that can be selected at run time is untested.  The knobs are read once per process
+(lfq_knobs(), lfq_internal.h); DESIGN.md lists them."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+DP = ["tests/test_gpu_parity.py", "-k", "default_conf_random or row_split or ragged_deep or underflow or fe_clamp or cells_below or "
+      "golden_reference or dynamic_bonferroni or edge_cases"]
+BAQ = ["tests/test_gpu_baq.py"]
+PLP = ["tests/test_gpu_pileup.py", "tests/test_gpu_plpindel.py", "-k", "not host_loops and not window_search"]
+CHAIN = ["tests/test_gpu_plpindel.py", "-k", "chain or device_only or device_packing", "tests/test_gpu_indel.py"]
+
+CASES = [
+    ("LFQ_SPLIT_POOL_CELLS=0", DP),          # no row split: every long column on the unsplit kernels
+    ("LFQ_SPLIT_POOL_CELLS=60000", DP),      # a pool that runs out: split and unsplit columns in one batch
+    ("LFQ_FOLD_KERNEL=0", DP),               # segments combined by the block kernel only
+    ("LFQ_LIGHT_KERNEL=wave", DP),           # one light column per wavefront (what K >= 32 gets anyway)
+    ("LFQ_SCREEN_EXACT=1", DP),              # the screen kernel with the full quality merge instead of its lower bound
+    ("LFQ_SCREEN_ROUNDS=2", DP),             # nearly every light column through the retry kernel
+    ("LFQ_SEGMENTS=3", DP),                  # batch segments: running Bonferroni prefix carried on the device
+    ("LFQ_SINGLE_STREAM=1", DP),             # every kernel on one stream (what the counter passes run)
+    ("LFQ_NO_SB_PRECOMPUTE=1", DP),          # strand bias computed at collect time only
+    ("LFQ_COUNT_MULTI_BELOW=0", DP),         # shallow batches on the one-column-per-wavefront count kernel
+    ("LFQ_BAQ_KERNEL=1", BAQ),               # the LDS-row BAQ kernel
+    ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
+    ("LFQ_PILEUP_ATOMIC=1", PLP),            # read-major pileup kernels (what unsorted reads get)
+    ("LFQ_INDEL_HOST_PACK=1", CHAIN),        # indel pseudo-columns packed on the host
+    ("LFQ_SYNC_UPLOAD=1", CHAIN),            # lfq_readset_create waits for its copies itself
+    ("LFQ_HOST_SPIN_US=-1", CHAIN),          # host loops on threads created per loop
+]
+
+
+@pytest.mark.parametrize("knob,sel", CASES, ids=[c[0] for c in CASES])
+def test_knob_selected_paths(knob, sel):
+    k, v = knob.split("=")
+    env = dict(os.environ, **{k: v})
+    p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=800)
+    tail = (p.stdout + p.stderr)[-1500:]
+    assert p.returncode == 0, tail
+    assert " passed" in p.stdout and "failed" not in p.stdout.splitlines()[-1], tail
