@@ -538,10 +538,35 @@ bool acquire_streams(int device, lfq_ctx *c)
     if (d.refs == 0) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        bool ok = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&d.dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
-        for (int i = 0; ok && i < 2; i++) {
-            ok = hipStreamCreateWithPriority(&d.side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
+        bool ok = true;
+        const int split = lfq_knobs().cu_split;
+        hipDeviceProp_t prop;
+        int n_cu = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            n_cu = prop.multiProcessorCount;
+        }
+        if (split > 0 && split < n_cu) {
+            /* Spatial partition (LFQ_CU_SPLIT): the three DP streams own `split` CUs, the main stream the rest, so that
+             * with two batches in flight the HBM-bound count kernel of batch k + 1 and the latency / issue-bound DP
+             * chains of batch k do not take wave slots and issue cycles from each other.  Bit i of a queue's CU mask is
+             * CU i / n_xcc of XCC i mod n_xcc on this part (the mask is dealt round-robin over the XCDs), so a prefix of
+             * the mask is the same number of CUs on every XCD. */
+            const int words = (n_cu + 31) / 32;
+            std::vector<uint32_t> m_dp((size_t)words, 0u), m_main((size_t)words, 0u);
+            for (int i = 0; i < n_cu; i++) {
+                (i < split ? m_dp : m_main)[(size_t)(i >> 5)] |= 1u << (i & 31);
+            }
+            ok = hipExtStreamCreateWithCUMask(&d.stream, (uint32_t)words, m_main.data()) == hipSuccess;
+            ok = ok && hipExtStreamCreateWithCUMask(&d.dps, (uint32_t)words, m_dp.data()) == hipSuccess;
+            for (int i = 0; ok && i < 2; i++) {
+                ok = hipExtStreamCreateWithCUMask(&d.side[i], (uint32_t)words, m_dp.data()) == hipSuccess;
+            }
+        } else {
+            ok = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipStreamCreateWithPriority(&d.dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
+            for (int i = 0; ok && i < 2; i++) {
+                ok = hipStreamCreateWithPriority(&d.side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
+            }
         }
         if (!ok) {
             return false;

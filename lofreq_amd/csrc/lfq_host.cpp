@@ -62,6 +62,7 @@ const LfqKnobs &lfq_knobs(void)
         x.segments = (int)std::min((long)LFQ_MAX_SEGMENTS, std::max(1L, geti("LFQ_SEGMENTS", 1)));
         x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
+        x.cu_split = (int)std::max(0L, geti("LFQ_CU_SPLIT", 0));
         x.sync_upload = (int)geti("LFQ_SYNC_UPLOAD", 0);
         x.host_spin_us = geti("LFQ_HOST_SPIN_US", 2000);
         x.host_threads = (int)geti("LFQ_HOST_THREADS", -1);

@@ -204,6 +204,8 @@ struct LfqKnobs {
     int baq_lds;               /* LFQ_BAQ_LDS (1) */
     long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
     int baq_kernel;            /* LFQ_BAQ_KERNEL: A/B switch between BAQ kernel generations */
+    int cu_split;              /* LFQ_CU_SPLIT=n: the DP streams of a device are created with a CU mask of n CUs, the main
+                                * stream (count kernels, pileup, BAQ) with the other CUs: spatial partition for two batches in flight */
 };
 const LfqKnobs &lfq_knobs(void);
 

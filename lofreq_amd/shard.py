@@ -117,11 +117,15 @@ def plan_regions(regions, cost_fn, world_size, bins_per_worker=BIN_PER_THREAD, b
     return [bins[i] for i in idx], [owner[i] for i in idx]
 
 
+# tests: run the collectives even in a world of one rank (the RCCL calls of the N > 1 path on a one-GPU box)
+_FORCE_COLLECTIVES = __import__("os").environ.get("LFQ_SHARD_FORCE_COLLECTIVES") == "1"
+
+
 def exchange_counts(local_counts, dist=None, device=None):
     """One all-gather of a small int64 vector per rank ({tested SNV columns, indel tests}).
     -> (array [world, len(local_counts)], exclusive prefix of this rank as an array)."""
     v = np.asarray(local_counts, np.int64).reshape(-1)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES):
         return v.reshape(1, -1), np.zeros_like(v)
     import torch
     ws, rank = dist.get_world_size(), dist.get_rank()
@@ -152,11 +156,12 @@ def gather_records(records, col_offset, dist=None, device=None):
     rec = records.copy()
     rdtype = rec.dtype
     rec["col"] += int(col_offset)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES):
         return rec
     import torch
     ws, rank = dist.get_world_size(), dist.get_rank()
     dev = device or "cpu"
+    # the record counts (every rank needs the largest one: a gather moves equal-sized pieces) ...
     n_mine = torch.tensor([len(rec)], dtype=torch.int64, device=dev)
     n_all = torch.zeros(ws, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(n_all, n_mine)
@@ -166,13 +171,12 @@ def gather_records(records, col_offset, dist=None, device=None):
     buf = np.zeros(cap * width, np.uint8)
     buf[: len(rec) * width] = rec.view(np.uint8).reshape(-1)
     mine = torch.from_numpy(buf).to(dev)
-    out = torch.zeros(ws * cap * width, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out, mine)
+    # ... then ONE gather of the fixed-size records to rank 0 (north_star: "a single RCCL gather for the final VCF merge")
+    pieces = [torch.zeros(cap * width, dtype=torch.uint8, device=dev) for _ in range(ws)] if rank == 0 else None
+    dist.gather(mine, pieces, dst=0)
     if rank != 0:
         return None
-    out = out.cpu().numpy()
-    parts = [out[r * cap * width: r * cap * width + n_all[r] * width].view(rdtype)
-             for r in range(ws)]
+    parts = [pieces[r].cpu().numpy()[: n_all[r] * width].view(rdtype) for r in range(ws)]
     return np.concatenate(parts) if parts else rec[:0]
 
 

@@ -209,3 +209,59 @@ def test_c_workers_real_kernels_files_transport(tmp_path):
     for k in la.SNV_RECORD_DTYPE.names:
         if k != "pad_":
             assert (got[k] == exp[k]).all(), k
+
+
+_NCCL_WORKER = r'''
+import os, sys
+import numpy as np
+root, out = sys.argv[1:3]
+sys.path.insert(0, root)
+os.environ["LFQ_SHARD_FORCE_COLLECTIVES"] = "1"          # the collectives run although the world has one rank
+import torch
+import torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+import lofreq_amd as la
+from lofreq_amd import shard
+assert shard._FORCE_COLLECTIVES
+caller = la.SnvCaller(0)
+SEED, DEPTH, NCOLS, PERIOD = (int(x) for x in sys.argv[3:7])
+batch = caller.synth_batch(SEED, DEPTH, NCOLS, plant_period=PERIOD)
+conf = la.VarcallConf()
+d_counts = torch.zeros(NCOLS * 64, dtype=torch.uint8, device=dev)
+d_pvals = torch.zeros(NCOLS * 128, dtype=torch.uint8, device=dev)
+caller.snv_batch_device(batch, conf, d_counts, d_pvals, NCOLS)
+st = caller.batch_finish()
+pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
+recs, total = shard.finish_shard(conf, pv, st.n_tested, None, 0, dist, dev)       # all-gather + gather on cuda tensors: RCCL
+ones = torch.ones(1, dtype=torch.int64, device=dev); dist.all_reduce(ones)
+np.save(out, recs.view(np.uint8))
+np.save(out + ".meta", np.array([total, conf.bonf_subst, conf.num_snv_tests, int(ones.item()), dist.get_backend() == "nccl"]))
+caller.close()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_exchange_through_rccl_one_rank(tmp_path):
+    """the collectives of the N > 1 benchmark path (all_gather_into_tensor of int64 counts, gather of the uint8 record
+    buffers, on CUDA tensors) through the real RCCL backend -- a process group of one rank, the collectives forced on
+    (LFQ_SHARD_FORCE_COLLECTIVES): what an 8-GPU node runs per step, minus the peers"""
+    import subprocess
+    import lofreq_amd as la
+    script = str(tmp_path / "w.py")
+    open(script, "w").write(_NCCL_WORKER)
+    out = str(tmp_path / "recs.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, script, ROOT, out, str(SEED), str(DEPTH), str(NCOLS), str(PERIOD)], env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    got = np.load(out).view(la.SNV_RECORD_DTYPE)
+    total, bonf, ntests, ranks, is_nccl = np.load(out + ".meta.npy")
+    assert is_nccl == 1 and ranks == 1
+    caller = la.SnvCaller(0)
+    conf = la.VarcallConf()
+    exp, _, st = caller.call_snvs(caller.synth_batch(SEED, DEPTH, NCOLS, plant_period=PERIOD), conf)
+    caller.close()
+    assert total == st.n_tested and bonf == conf.bonf_subst and ntests == conf.num_snv_tests
+    assert len(exp) > 100 and got.tobytes() == exp.tobytes()
