@@ -227,33 +227,61 @@ def live_pmc(child_args, count_kernel):
 # ---------------------------------------------------------------------------------------------------------
 
 def bench_host_abi(caller, la, seed, depth, ncols, plant_period, steps):
-    """Host buffers through lfq_call_snvs_batch(tracks_on_device = 0): what the plp_proc_func shim does per flush
-    (integration/lofreq_amd_shim.c).  PCIe upload included; bytes = the four byte tracks + headers."""
-    # the workload of include/lofreq_synth.h, generated on the device in the byte layout and copied to (pageable) host
-    # arrays: what a caller outside this benchmark holds
+    """Host buffers through the C ABI, the way the plp_proc_func shim hands them over (integration/lofreq_amd_shim.c): the
+    tracks in PINNED host memory (lfq_host_alloc), nt nibble-packed, two batches in flight -- lfq_call_snvs_submit of
+    batch k + 1 (its DMA uploads) before lfq_call_snvs_collect of batch k, on two contexts, every batch an independent
+    region with a conf of its own.  PCIe upload included; bytes = the tracks as sent + headers."""
+    import torch
+    # the workload of include/lofreq_synth.h, generated on the device in the byte layout and copied to host arrays
     dev_b = caller.synth_batch(seed, depth, ncols, plant_period=plant_period, nt_packed=False)
     n = ncols * depth
-    host = {"nt": dev_b.nt[:n].cpu().numpy().copy(), "bq": dev_b.bq[:n].cpu().numpy().copy(),
-            "baq": dev_b.baq[:n].cpu().numpy().copy(), "mq": dev_b.mq[:n].cpu().numpy().copy(),
-            "col_off": dev_b.col_off.cpu().numpy().astype(np.uint64), "ref_base": dev_b.ref_base[:ncols].cpu().numpy().copy()}
+
+    def pinned(t):
+        h = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
+        h.copy_(t.cpu())
+        return h
+
+    col_off = dev_b.col_off.cpu().numpy().astype(np.uint64)
+    ref = dev_b.ref_base[:ncols].cpu().numpy().copy()
+    sets = []
+    for _ in range(2):
+        plain = la.PileupBatch(dev_b.nt[:n].cpu().numpy(), dev_b.bq[:n].cpu().numpy(), dev_b.mq[:n].cpu().numpy(), col_off, ref,
+                               baq=dev_b.baq[:n].cpu().numpy(), max_col_obs=depth).packed()
+        keep = {k: pinned(torch.from_numpy(np.ascontiguousarray(getattr(plain, k)))) for k in ("nt", "bq", "mq", "baq")}
+        b = la.PileupBatch(keep["nt"].numpy(), keep["bq"].numpy(), keep["mq"].numpy(), col_off, ref, baq=keep["baq"].numpy(),
+                           max_col_obs=depth, nt_packed=True)
+        b._pinned = keep
+        sets.append(b)
     del dev_b
-    # the nt track nibble-packed on the host, as the plp_proc_func shim builds it while the columns arrive
-    # (integration/lofreq_amd_shim.c): 3.5 instead of 4 bytes per observation over PCIe
-    batch = la.PileupBatch(host["nt"], host["bq"], host["mq"], host["col_off"], host["ref_base"], baq=host["baq"],
-                           max_col_obs=depth).packed()
-    n_obs = int(host["col_off"][-1])
-    conf = la.VarcallConf()
-    caller.call_snvs(batch, conf, records_capacity=1 << 16)          # warm-up: staging allocation
+    n_obs = int(col_off[-1])
+    callers = [caller, la.SnvCaller(caller.device)]
+    confs = [None, None]
+
+    def submit(k):
+        confs[k % 2] = la.VarcallConf()
+        callers[k % 2].call_snvs_submit(sets[k % 2], confs[k % 2])
+
+    def collect(k):
+        return callers[k % 2].call_snvs_collect(confs[k % 2], records_capacity=1 << 16)
+
+    submit(0)
+    collect(0)                                       # warm-up: staging allocations of both contexts
+    submit(1)
+    collect(1)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        conf = la.VarcallConf()
-        recs, _, st = caller.call_snvs(batch, conf, records_capacity=1 << 16)
+    submit(0)
+    for k in range(steps):
+        if k + 1 < steps:
+            submit(k + 1)
+        recs, st = collect(k)
     dt = (time.perf_counter() - t0) / steps
+    callers[1].close()
     byt = 3.5 * n_obs + ncols * 9.0
     return {"columns_per_s": ncols / dt, "ms_per_batch": dt * 1e3, "columns_per_batch": ncols, "depth": depth,
             "host_bytes_per_batch": byt, "effective_GBps": byt / dt / 1e9, "pcie_peak_GBps": 63.0,
             "frac_of_pcie": byt / dt / 1e9 / 63.0, "records": int(len(recs)), "nt_layout": "packed nibbles (host-packed)",
-            "note": "pageable host arrays in, VCF records out; upload + kernels + host finish per call"}
+            "note": "pinned host arrays in (lfq_host_alloc: what the shim's buffers are), VCF records out; two batches in "
+                    "flight: the upload of batch k + 1 under the kernels of batch k; upload + kernels + host finish per batch"}
 
 
 def make_reads(n, glen, rl=150, seed=3, indel_frac=0.04):

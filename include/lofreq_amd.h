@@ -181,6 +181,11 @@ int lfq_create(lfq_ctx **ctx, int device_ordinal);  /* one context per GPU / str
  * reused when its worker exits)  >  getpid() mod n.  n_devices <= 0: ask the HIP runtime.  Returns the ordinal
  * (>= 0) for lfq_create, or a negative lfq_status; *slot_out_or_null gets the slot (or -1). */
 int lfq_device_count(void);
+/* Pinned host memory for a producer's track buffers (hipHostMalloc): with it the uploads of lfq_call_snvs_submit(...,
+ * tracks_on_device = 0) are DMA transfers at the link's rate that return at once -- pageable memory is staged.  NULL when
+ * there is no device / no memory. */
+void *lfq_host_alloc(size_t bytes);
+void lfq_host_free(void *p);
 int lfq_pick_device(int n_devices, int *slot_out_or_null);
 void lfq_destroy(lfq_ctx *ctx);
 int lfq_synchronize(lfq_ctx *ctx);

@@ -40,8 +40,8 @@ extern long long int num_indel_tests;                     /* lofreq_call.c:85 */
 extern long int indel_calls_wo_idaq;                      /* lofreq_call.c:88 */
 
 #define LFQ_BATCH_COLS (1 << 20)        /* flush every 2^20 columns (or at the end) */
-#define LFQ_BATCH_OBS ((int64_t)1 << 30) /* ... or when a track holds 1 GiB: 100 000 columns at 10 000x (5 GiB of host
-                                          * tracks, one staging allocation of that size on the device) */
+#define LFQ_BATCH_OBS ((int64_t)1 << 28) /* ... or when a track holds 256 Mi observations: 26 000 columns at 10 000x (1.1 GiB of
+                                          * pinned host tracks per batch, two batches, one staging allocation on the device) */
 #define LFQ_BATCH_INDEL_READS (1 << 28) /* ... or when the flattened indel columns hold this many reads */
 
 /* allocation results are checked: running out of host memory is a LOG_FATAL like everywhere else in LoFreq */
@@ -65,8 +65,7 @@ static char *lfq_xstrdup(const char *s)
 }
 
 typedef struct {
-    lfq_ctx *ctx;
-    /* packed tracks (host), grown on demand */
+    /* packed tracks (host, pinned: lfq_host_alloc), grown on demand */
     uint8_t *nt, *bq, *baq, *mq, *sq;
     uint64_t *col_off;
     uint8_t *ref_base;
@@ -80,8 +79,22 @@ typedef struct {
     int64_t *seq;                       /* arrival number of the column (merge key with the indel batch) */
 } lfq_batch;
 
-static lfq_batch B;
+/* Two batches: while the kernels of one run (lfq_call_snvs_submit returns when its copies and kernels are queued) mpileup's
+ * thread -- the only thread of `lofreq call` -- goes on filling the other.  A batch is collected, and its records are
+ * printed, when the next one is full or at the final flush: output order = column order. */
+static lfq_batch BB[2];
+static int g_cur;
+#define B BB[g_cur]
+static lfq_ctx *g_ctx;
 static int64_t g_seq;
+static struct {
+    int active;                         /* a submitted batch waits for its collect */
+    int which;                          /* its buffer set */
+    lfq_conf lc;                        /* the conf it was submitted with */
+    char **iline;                       /* formatted indel records of the same columns, with their arrival numbers */
+    int64_t *iseq;
+    int64_t n_iline;
+} P;
 
 /* ---- indel fields of the columns that carry indel events (lfq_indel_columns, flattened) ------------- */
 typedef struct { void *p; int64_t n, cap; size_t elt; } vec;
@@ -217,7 +230,7 @@ static lfq_indel_record *indel_flush(varcall_conf_t *conf, lfq_conf *lc, int64_t
     }
     nev = I.sd[0].ev_fw.n + I.sd[1].ev_fw.n;
     rec = lfq_xrealloc(NULL, sizeof(lfq_indel_record) * (size_t)(nev + 1));
-    rc = lfq_call_indels_batch(B.ctx, lc, &c, rec, nev, n_rec, &ntests);
+    rc = lfq_call_indels_batch(g_ctx, lc, &c, rec, nev, n_rec, &ntests);
     if (rc != LFQ_OK) {
         LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
         exit(1);
@@ -227,7 +240,7 @@ static lfq_indel_record *indel_flush(varcall_conf_t *conf, lfq_conf *lc, int64_t
     return rec;
 }
 
-static void indel_print(varcall_conf_t *conf, const lfq_indel_record *r)
+static char *indel_line(const lfq_indel_record *r)
 {
     const side_vecs *v = &I.sd[r->side];
     const int64_t *koff = v->key_off.p;
@@ -242,9 +255,9 @@ static void indel_print(varcall_conf_t *conf, const lfq_indel_record *r)
     lfq_format_indel_record(line, (int)(kl * 2 + 1024), ((char **)I.target.p)[r->col], ((int32_t *)I.pos.p)[r->col],
                             ref, alt, r->qual, r->dp, r->af, r->sb, r->ref_fw, r->ref_rv, r->alt_fw, r->alt_rv,
                             r->hrun, NULL);
-    vcf_printf(&conf->vcf_out, "%s", line);
     if (!((int32_t *)I.has_aq.p)[r->col]) indel_calls_wo_idaq += 1;   /* report_var, lofreq_call.c:109-111 */
-    free(ref); free(alt); free(line);
+    free(ref); free(alt);
+    return line;
 }
 
 static void indel_reset(void)
@@ -263,13 +276,27 @@ static void indel_reset(void)
     I.ncols = 0;
 }
 
+/* the five observation tracks live in pinned memory: their upload is then a DMA that lfq_call_snvs_submit only queues */
+static uint8_t *pinned_grow(uint8_t *p, int64_t used, int64_t cap)
+{
+    uint8_t *q = (uint8_t *)lfq_host_alloc((size_t)cap);
+    if (!q) {
+        LOG_FATAL("lofreq_amd: no pinned host memory (%lu bytes): is there a HIP device?\n", (unsigned long)cap);
+        exit(1);
+    }
+    if (p && used > 0) memcpy(q, p, (size_t)used);
+    lfq_host_free(p);
+    return q;
+}
+
 static void grow_obs(int64_t need)
 {
+    const int64_t used = B.nobs;
     if (need <= B.cap_obs) return;
     while (B.cap_obs < need) B.cap_obs = B.cap_obs ? 2 * B.cap_obs : (1 << 24);
-    B.nt = lfq_xrealloc(B.nt, B.cap_obs);  B.bq = lfq_xrealloc(B.bq, B.cap_obs);
-    B.baq = lfq_xrealloc(B.baq, B.cap_obs); B.mq = lfq_xrealloc(B.mq, B.cap_obs);
-    B.sq = lfq_xrealloc(B.sq, B.cap_obs);
+    B.nt = pinned_grow(B.nt, (used + 1) / 2 + 4, B.cap_obs);  B.bq = pinned_grow(B.bq, used, B.cap_obs);
+    B.baq = pinned_grow(B.baq, used, B.cap_obs); B.mq = pinned_grow(B.mq, used, B.cap_obs);
+    B.sq = pinned_grow(B.sq, used, B.cap_obs);
 }
 
 static void grow_cols(int64_t need)
@@ -296,66 +323,122 @@ static void conf_to_lfq(const varcall_conf_t *c, lfq_conf *o)
     o->bonf_indel = c->bonf_indel;      o->num_indel_tests = num_indel_tests;
 }
 
-/* call after mpileup() returns, and whenever the batch is full */
-void lfq_call_flush(varcall_conf_t *conf)
+static void ensure_ctx(void)
 {
-    lfq_conf lc;
-    lfq_tracks t;
-    lfq_snv_record *rec = NULL;
-    lfq_indel_record *irec;
-    int64_t n_rec = 0, n_irec = 0, i, k;
-    int rc;
-
-    if (B.ncols == 0 && (!I.init || I.ncols == 0)) return;
-    if (!B.ctx) {
+    if (!g_ctx) {
         /* one `lofreq call -r <bin>` per worker of the parallel wrapper (lofreq2_call_pparallel.py:640-667): each
          * process takes a GPU of its own -- LFQ_DEVICE, LOCAL_RANK, or the first free worker slot of the node */
         const int dev = lfq_pick_device(0, NULL);
-        if (dev < 0 || lfq_create(&B.ctx, dev) != LFQ_OK) {
+        if (dev < 0 || lfq_create(&g_ctx, dev) != LFQ_OK) {
             LOG_FATAL("%s\n", "lofreq_amd: no usable MI355X / HIP device");
             exit(1);
         }
     }
-    conf_to_lfq(conf, &lc);
-    irec = indel_flush(conf, &lc, &n_irec);
-    if (B.ncols == 0) goto print;
-    B.col_off[B.ncols] = (uint64_t)B.nobs;
-    memset(&t, 0, sizeof(t));
-    t.nt = B.nt; t.bq = B.bq; t.mq = B.mq;
-    t.baq = B.use_baq ? B.baq : NULL;
-    t.sq = B.use_sq ? B.sq : NULL;
-    t.col_off = B.col_off; t.ref_base = B.ref_base;
-    t.coverage_plp = B.cov; t.num_bases = B.nbases;
-    t.ncols = B.ncols; t.max_col_obs = B.max_depth;
-    t.flags = LFQ_TRACKS_NT_PACKED;          /* half the nt bytes over PCIe, the 1.5-bytes-per-observation count kernel */
+}
 
-    rec = lfq_xrealloc(NULL, sizeof(lfq_snv_record) * (size_t)(3 * B.ncols));
-    rc = lfq_call_snvs_batch(B.ctx, &lc, &t, /*tracks_on_device=*/0, rec, 3 * B.ncols, &n_rec, NULL, NULL);
+/* wait for the batch submitted at the previous flush, finish it on the host, print its columns' records */
+static void collect_pending(varcall_conf_t *conf)
+{
+    lfq_batch *b = &BB[P.which];
+    lfq_snv_record *rec;
+    int64_t n_rec = 0, i, k;
+    int rc;
+    if (!P.active) return;
+    rec = lfq_xrealloc(NULL, sizeof(lfq_snv_record) * (size_t)(3 * b->ncols + 1));
+    rc = b->ncols ? lfq_call_snvs_collect(g_ctx, &P.lc, rec, 3 * b->ncols, &n_rec, NULL, NULL) : LFQ_OK;
     if (rc != LFQ_OK) {
         LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
         exit(1);
     }
-    conf->bonf_subst = lc.bonf_subst;        /* lofreq_call.c:794-800 */
-    num_snv_tests = lc.num_snv_tests;        /* lofreq_call.c:801 */
-print:
+    if (b->ncols) {
+        conf->bonf_subst = P.lc.bonf_subst;      /* lofreq_call.c:794-800 */
+        num_snv_tests = P.lc.num_snv_tests;      /* lofreq_call.c:801 */
+    }
     /* merge by arrival number; a column's indel records precede its SNV records (call_vars :896 / :928) */
-    for (i = 0, k = 0; i < n_rec || k < n_irec;) {
-        const int64_t s_snv = i < n_rec ? B.seq[rec[i].col] : INT64_MAX;
-        const int64_t s_ind = k < n_irec ? ((int64_t *)I.seq.p)[irec[k].col] : INT64_MAX;
+    for (i = 0, k = 0; i < n_rec || k < P.n_iline;) {
+        const int64_t s_snv = i < n_rec ? b->seq[rec[i].col] : INT64_MAX;
+        const int64_t s_ind = k < P.n_iline ? P.iseq[k] : INT64_MAX;
         if (s_ind <= s_snv) {
-            indel_print(conf, &irec[k++]);
+            vcf_printf(&conf->vcf_out, "%s", P.iline[k]);
+            free(P.iline[k++]);
         } else {                            /* vcf_write_var (vcf.c:469-497), FILTER '.' like report_var */
             char line[512];
-            lfq_format_snv_record(line, sizeof(line), B.target[rec[i].col], B.pos[rec[i].col], &rec[i], NULL);
+            lfq_format_snv_record(line, sizeof(line), b->target[rec[i].col], b->pos[rec[i].col], &rec[i], NULL);
             vcf_printf(&conf->vcf_out, "%s", line);
             i++;
         }
     }
     free(rec);
+    free(P.iline); free(P.iseq);
+    P.iline = NULL; P.iseq = NULL; P.n_iline = 0;
+    for (i = 0; i < b->ncols; i++) free(b->target[i]);
+    b->ncols = 0; b->nobs = 0; b->max_depth = 0;
+    P.active = 0;
+}
+
+/* the batch is full: finish the previous one (its kernels ran while this one was filled), queue this one, go on */
+static void flush_async(varcall_conf_t *conf)
+{
+    lfq_conf lc;
+    lfq_tracks t;
+    lfq_indel_record *irec;
+    int64_t n_irec = 0, k;
+    int rc;
+
+    if (B.ncols == 0 && (!I.init || I.ncols == 0)) return;
+    ensure_ctx();
+    collect_pending(conf);                   /* conf now carries the running factors up to this batch's first column */
+    conf_to_lfq(conf, &lc);
+    irec = indel_flush(conf, &lc, &n_irec);  /* call_indels of this batch's columns: synchronous, few tests */
+    P.iline = lfq_xrealloc(NULL, sizeof(char *) * (size_t)(n_irec + 1));
+    P.iseq = lfq_xrealloc(NULL, sizeof(int64_t) * (size_t)(n_irec + 1));
+    for (k = 0; k < n_irec; k++) {
+        P.iline[k] = indel_line(&irec[k]);
+        P.iseq[k] = ((int64_t *)I.seq.p)[irec[k].col];
+    }
+    P.n_iline = n_irec;
     free(irec);
     if (I.init) indel_reset();
-    for (i = 0; i < B.ncols; i++) free(B.target[i]);
-    B.ncols = 0; B.nobs = 0; B.max_depth = 0;
+    P.which = g_cur;
+    P.active = 1;
+    if (B.ncols > 0) {
+        B.col_off[B.ncols] = (uint64_t)B.nobs;
+        memset(&t, 0, sizeof(t));
+        t.nt = B.nt; t.bq = B.bq; t.mq = B.mq;
+        t.baq = B.use_baq ? B.baq : NULL;
+        t.sq = B.use_sq ? B.sq : NULL;
+        t.col_off = B.col_off; t.ref_base = B.ref_base;
+        t.coverage_plp = B.cov; t.num_bases = B.nbases;
+        t.ncols = B.ncols; t.max_col_obs = B.max_depth;
+        t.flags = LFQ_TRACKS_NT_PACKED;      /* half the nt bytes over PCIe, the 1.5-bytes-per-observation count kernel */
+        P.lc = lc;
+        rc = lfq_call_snvs_submit(g_ctx, &P.lc, &t, /*tracks_on_device=*/0);    /* copies + kernels queued; returns */
+        if (rc != LFQ_OK) {
+            LOG_FATAL("lofreq_amd: %s\n", lfq_strerror(rc));
+            exit(1);
+        }
+    }
+    g_cur ^= 1;                              /* the other buffer set was collected above: it is empty */
+}
+
+/* call after mpileup() returns: queues what is left and finishes everything */
+void lfq_call_flush(varcall_conf_t *conf)
+{
+    flush_async(conf);
+    if (P.active) {
+        ensure_ctx();
+        collect_pending(conf);
+    }
+}
+
+static int64_t batch_cols(void)         /* LFQ_BATCH_COLS, or LFQ_SHIM_BATCH_COLS from the environment (tuning, tests) */
+{
+    static int64_t n;
+    if (!n) {
+        const char *e = getenv("LFQ_SHIM_BATCH_COLS");
+        n = (e && atoll(e) > 0) ? atoll(e) : LFQ_BATCH_COLS;
+    }
+    return n;
 }
 
 /* the drop-in plp_proc_func (plp.h:159-163) */
@@ -408,9 +491,9 @@ void lfq_call_vars(const plp_col_t *p, void *confp)
     if (depth > B.max_depth) B.max_depth = depth;
     B.ncols++;
 maybe_flush:
-    if (B.ncols >= LFQ_BATCH_COLS || B.nobs >= LFQ_BATCH_OBS
+    if (B.ncols >= batch_cols() || B.nobs >= LFQ_BATCH_OBS
         || (I.init && I.sd[0].ne_q.n + I.sd[1].ne_q.n >= LFQ_BATCH_INDEL_READS)) {
-        lfq_call_flush(conf);
+        flush_async(conf);
     }
 }
 
@@ -420,10 +503,15 @@ void lfq_call_shutdown(void)
     vec *iv[] = {&I.ref_base, &I.cov, &I.tails, &I.non_indels, &I.num_ins, &I.num_dels, &I.hrun, &I.seq, &I.pos,
                  &I.has_aq, &I.target};
     size_t k;
-    if (B.ctx) lfq_destroy(B.ctx);
-    free(B.nt); free(B.bq); free(B.baq); free(B.mq); free(B.sq);
-    free(B.col_off); free(B.ref_base); free(B.cov); free(B.nbases); free(B.target); free(B.pos); free(B.seq);
-    memset(&B, 0, sizeof(B));
+    for (g_cur = 0; g_cur < 2; g_cur++) {
+        lfq_host_free(B.nt); lfq_host_free(B.bq); lfq_host_free(B.baq); lfq_host_free(B.mq); lfq_host_free(B.sq);
+        free(B.col_off); free(B.ref_base); free(B.cov); free(B.nbases); free(B.target); free(B.pos); free(B.seq);
+        memset(&B, 0, sizeof(B));
+    }
+    g_cur = 0;
+    if (g_ctx) lfq_destroy(g_ctx);
+    g_ctx = NULL;
+    memset(&P, 0, sizeof(P));
     if (I.init) {
         for (k = 0; k < sizeof(iv) / sizeof(iv[0]); k++) free(iv[k]->p);
         for (s = 0; s < 2; s++) {

@@ -673,6 +673,25 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
 
 extern "C" {
 
+/* pinned host memory for a producer's track buffers: the copies of lfq_call_snvs_submit(tracks_on_device = 0) are then
+ * DMA transfers that return at once and run at the link's rate (pageable memory is staged by the runtime) */
+void *lfq_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void lfq_host_free(void *p)
+{
+    if (p) {
+        (void)hipHostFree(p);
+    }
+}
+
 int lfq_device_count(void)
 {
     int ndev = 0;

@@ -82,6 +82,30 @@ int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t po
 static void put(const void *p, size_t n) { fwrite(p, 1, n, g_out); }
 static void put_i64(int64_t v) { put(&v, 8); }
 
+void *lfq_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void lfq_host_free(void *p) { free(p); }
+
+/* the shim submits a batch when it is full and collects it at the next flush: the mock dumps at submit (the tracks must
+ * be complete by then) and hands back no records at collect */
+static int64_t g_sub_ncols = -1;
+int lfq_call_snvs_submit(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *t, int tracks_on_device)
+{
+    int64_t n = 0;
+    if (g_sub_ncols >= 0) return LFQ_ERR_INVALID;         /* one batch in flight per context */
+    g_sub_ncols = t->ncols;
+    return lfq_call_snvs_batch(ctx, (lfq_conf *)conf, t, tracks_on_device, NULL, 0, &n, NULL, NULL) == LFQ_OK ? LFQ_OK : LFQ_ERR_INVALID;
+}
+int lfq_call_snvs_collect(lfq_ctx *ctx, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
+                          int64_t *n_records, lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out)
+{
+    (void)ctx; (void)records; (void)records_capacity; (void)h_counts_or_null; (void)stats_out;
+    if (g_sub_ncols < 0) return LFQ_ERR_INVALID;
+    *n_records = 0;
+    conf->num_snv_tests += 3 * g_sub_ncols;     /* so that the shim's write-back of the counters can be seen */
+    g_sub_ncols = -1;
+    return LFQ_OK;
+}
+
 int lfq_call_snvs_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_tracks *t, int tracks_on_device,
                         lfq_snv_record *records, int64_t records_capacity, int64_t *n_records,
                         lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats)
@@ -107,7 +131,6 @@ int lfq_call_snvs_batch(lfq_ctx *ctx, lfq_conf *conf, const lfq_tracks *t, int t
     if (t->baq) put(t->baq, (size_t)n_obs);
     if (t->sq) put(t->sq, (size_t)n_obs);
     *n_records = 0;
-    conf->num_snv_tests += 3 * t->ncols;        /* so that the shim's write-back of the counters can be seen */
     return LFQ_OK;
 }
 

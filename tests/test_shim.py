@@ -79,11 +79,11 @@ def _snv_columns_blob(fx, cons_indel_cols=()):
     return b"".join(out)
 
 
-def _run(harness, tmp_path, header, blob, ncols):
+def _run(harness, tmp_path, header, blob, ncols, env=None):
     inp, outp = str(tmp_path / "cols.bin"), str(tmp_path / "out.bin")
     with open(inp, "wb") as f:
         f.write(_i32(*header) + _i32(ncols) + blob)
-    r = subprocess.run([harness, inp, outp], capture_output=True, text=True)
+    r = subprocess.run([harness, inp, outp], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
     return open(outp, "rb").read()
 
@@ -142,6 +142,43 @@ def test_shim_packs_snv_columns_like_golden_util(harness, tmp_path, path):
         assert np.array_equal(a, host[k][sel]), k
     assert out.tag() == b"DONE"
     assert out.i64() == 1 and out.i64() == 3 * nc      # bonf_subst / num_snv_tests written back from the library's conf
+
+
+def test_shim_batches_in_flight(harness, tmp_path):
+    """small batches (LFQ_SHIM_BATCH_COLS): a full batch is submitted and mpileup's thread goes on filling the other
+    buffer set; every batch is complete when it is handed over, the batches cover the columns in order, the counters
+    written back at the end are those of all of them"""
+    path = gu.fixtures()[0]
+    fx, host = gu.load(path)
+    ncols = len(fx["columns"])
+    out = _Reader(_run(harness, tmp_path, (1, 1, 1, 0, 3), _snv_columns_blob(fx), ncols, env={"LFQ_SHIM_BATCH_COLS": "7"}))
+    keep = np.array([c["ref"] != "N" for c in fx["columns"]])
+    depth = np.diff(host["col_off"].astype(np.int64))[keep]
+    sel = np.concatenate([np.arange(int(host["col_off"][c]), int(host["col_off"][c + 1])) for c in np.nonzero(keep)[0]])
+    got = {"nt": [], "bq": [], "mq": []}
+    seen, n_batches = 0, 0
+    while True:
+        tag = out.tag()
+        if tag != b"SNVB":
+            break
+        nc, n_obs, on_dev, has_baq, has_sq, max_obs, bonf = [out.i64() for _ in range(7)]
+        assert nc <= 7 and bonf == 1 + 0 * n_batches            # (the mock advances no Bonferroni factor)
+        col_off = out.arr("<u8", nc + 1)
+        assert np.array_equal(np.diff(col_off.astype(np.int64)), depth[seen:seen + nc])
+        out.arr("u1", nc); out.arr("<i4", nc); out.arr("<i4", nc)
+        assert out.i64() == 1
+        raw = out.arr("u1", (n_obs + 7) // 8 * 4)
+        o = np.arange(n_obs)
+        got["nt"].append(((raw[(o >> 3) * 4 + (o & 3)] >> (4 * ((o & 7) >> 2))) & 15).astype(np.uint8))
+        got["bq"].append(out.arr("u1", n_obs)); got["mq"].append(out.arr("u1", n_obs))
+        if has_baq:
+            out.arr("u1", n_obs)
+        seen += nc
+        n_batches += 1
+    assert tag == b"DONE" and n_batches == -(-int(keep.sum()) // 7) and seen == int(keep.sum())
+    for k in got:
+        assert np.array_equal(np.concatenate(got[k]), host[k][sel]), k
+    assert out.i64() == 1 and out.i64() == 3 * seen
 
 
 def test_shim_skips_snvs_at_consensus_indel_columns(harness, tmp_path):
