@@ -276,10 +276,22 @@ def bench_host_abi(caller, la, seed, depth, ncols, plant_period, steps):
         recs, st = collect(k)
     dt = (time.perf_counter() - t0) / steps
     callers[1].close()
+    # the link's own rate for comparison: a plain pinned host -> device copy of 256 MiB
+    hp = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()
+    dd = torch.empty(1 << 28, dtype=torch.uint8, device=torch.device("cuda", caller.device))
+    dd.copy_(hp, non_blocking=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(4):
+        dd.copy_(hp, non_blocking=True)
+    torch.cuda.synchronize()
+    link = 4 * (1 << 28) / (time.perf_counter() - t1) / 1e9
+    del hp, dd
     byt = 3.5 * n_obs + ncols * 9.0
     return {"columns_per_s": ncols / dt, "ms_per_batch": dt * 1e3, "columns_per_batch": ncols, "depth": depth,
             "host_bytes_per_batch": byt, "effective_GBps": byt / dt / 1e9, "pcie_peak_GBps": 63.0,
-            "frac_of_pcie": byt / dt / 1e9 / 63.0, "records": int(len(recs)), "nt_layout": "packed nibbles (host-packed)",
+            "frac_of_pcie": byt / dt / 1e9 / 63.0, "pcie_measured_copy_GBps": link, "frac_of_measured_copy": byt / dt / 1e9 / link,
+            "records": int(len(recs)), "nt_layout": "packed nibbles (host-packed)",
             "note": "pinned host arrays in (lfq_host_alloc: what the shim's buffers are), VCF records out; two batches in "
                     "flight: the upload of batch k + 1 under the kernels of batch k; upload + kernels + host finish per batch"}
 

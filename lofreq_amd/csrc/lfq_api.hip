@@ -289,7 +289,8 @@ struct lfq_ctx {
      * lfq_readset_create / _baq takes them over when they are large enough -- a worker goes from region to region, and
      * hipMalloc + hipFree of 2 GB per region are milliseconds and a device synchronisation each */
     struct { void *p; size_t cap; } rs_cache[5];
-    hipStream_t up_stream;           /* lfq_readset_create's uploads (created on first use) */
+    hipStream_t up_stream;           /* lfq_readset_create's uploads and the staging copies of host tracks (created on first use) */
+    hipEvent_t ev_up;                /* end of the staging copies of a batch of host tracks */
     uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
     int64_t pin_bytes;
     uint8_t *h_pin2;                 /* pinned landing area of the indel pileup's per-position counters (grow-only) */
@@ -864,6 +865,7 @@ void lfq_destroy(lfq_ctx *c)
             if (c->rs_cache[k].p) (void)(k == 4 ? hipHostFree(c->rs_cache[k].p) : hipFree(c->rs_cache[k].p));
         }
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+        if (c->ev_up) (void)hipEventDestroy(c->ev_up);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         for (int i = 0; i < LFQ_PIN_SLOTS; i++) {
             if (c->pin_pool[i].p) (void)hipHostFree(c->pin_pool[i].p);
@@ -1358,7 +1360,18 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
         const uint64_t n_obs = tr->col_off[ncols];
         const int64_t trk = (int64_t)((n_obs + 15) / 16 * 16) + 16;
         int64_t need = 5 * trk + (ncols + 1) * 8 + (ncols + 16) + 2 * (ncols * 4 + 16) + 64;
-        LFQ_TRY(order_after_batch(c, c->stream));      /* the previous batch may still read the staging area */
+        /* the copies go to the context's own upload stream: the device's main stream is shared by its contexts, and a
+         * second context's upload queued there would wait behind this one's count kernel instead of running beside it.
+         * The batch's first kernel waits for the copies (event), the copies for the previous batch of this context. */
+        if (!c->up_stream && hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) {
+            c->up_stream = nullptr;
+            return LFQ_ERR_HIP;
+        }
+        if (!c->ev_up && hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming) != hipSuccess) {
+            return LFQ_ERR_HIP;
+        }
+        hipStream_t ups = c->up_stream;
+        LFQ_TRY(order_after_batch(c, ups));            /* the previous batch may still read the staging area */
         LFQ_TRY(grow(&c->d_stage, &c->stage_bytes, need));
         uint8_t *p = c->d_stage;
         auto put = [&](const void *src, int64_t bytes, int64_t reserve) -> uint8_t * {
@@ -1367,7 +1380,7 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
             if (!src) {
                 return nullptr;
             }
-            if (bytes > 0 && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            if (bytes > 0 && hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
                 return nullptr;
             }
             return dst;
@@ -1393,6 +1406,8 @@ static int stage_tracks(lfq_ctx *c, const lfq_tracks *tr, int tracks_on_device, 
             }
             dev.max_col_obs = (int64_t)md;
         }
+        LFQ_TRY_HIP(hipEventRecord(c->ev_up, ups));
+        LFQ_TRY_HIP(hipStreamWaitEvent(c->stream, c->ev_up, 0));
     }
 
     *dev_out = dev;
