@@ -399,6 +399,10 @@ int lfq_readset_baq(lfq_ctx *ctx, lfq_readset *rs, int baq_extended, int want_id
 /* source quality; the per-read byte for the sq track stays on the device, sq_out_or_null gets source_qual()'s value */
 int lfq_readset_source_qual(lfq_ctx *ctx, lfq_readset *rs, int def_nm_q, int min_bq, const uint8_t *ign_or_null,
                             int32_t *sq_out_or_null);
+/* Returns when the scatter pass is QUEUED: ncols, col_pos_out and max_col_obs are final, the tracks themselves are
+ * complete in stream order -- lfq_call_snvs_batch(..., tracks_on_device = 1), lfq_pileup_skip_snv_columns and the uniq
+ * calls are queued behind them; call lfq_synchronize(ctx) before reading the device memory yourself.  A region worker
+ * calls it between the indel pileup and the indel tests: the scatter pass then runs under the host part of the tests. */
 int lfq_readset_pileup_snv(lfq_ctx *ctx, lfq_readset *rs, int64_t region_begin, int64_t region_end, int min_plp_bq,
                            lfq_tracks *tracks_out, int64_t *col_pos_out);
 int lfq_readset_pileup_indels(lfq_ctx *ctx, lfq_readset *rs, int64_t region_begin, int64_t region_end, int min_plp_idq,

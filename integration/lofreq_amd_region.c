@@ -38,6 +38,11 @@ typedef struct {
     int64_t ref_len, beg, end;
     lfq_readset *rs;
     int started;
+    /* the SNV tracks of the region: their first pass runs beside the BAQ kernels, the scatter pass is queued behind them
+     * (lfq_readset_pileup_snv returns at once) */
+    lfq_tracks t;
+    int have_tracks;
+    int64_t *col_pos_s, pos_cap;
 } reg_buf;
 
 struct lfq_region {
@@ -51,7 +56,7 @@ struct lfq_region {
     int open;                       /* lfq_region_begin called, lfq_region_end not yet */
     int64_t wo_idaq;
     /* outputs, grown on demand */
-    int64_t *col_pos_s, *col_pos_i, pos_cap;
+    int64_t *col_pos_i, pos_cap;
     lfq_snv_record *srec;
     int64_t srec_cap;
     lfq_indel_record *irec;
@@ -86,6 +91,7 @@ static void buf_free(reg_buf *b)
         free(all[i]->p);
     }
     free(b->target);
+    free(b->col_pos_s);
 }
 
 int lfq_region_open(lfq_region **out, lfq_ctx *ctx, lfq_conf *conf, const lfq_region_opts *opts,
@@ -249,20 +255,33 @@ static int region_start(lfq_region *r, reg_buf *b)
             return rc;
         }
     }
+    b->have_tracks = 0;
     b->started = 1;
     return LFQ_OK;
+}
+
+/* the SNV tracks of the region; returns when the scatter pass is queued */
+static int region_snv_tracks(lfq_region *r, reg_buf *b)
+{
+    const int64_t width = b->end - b->beg + 1;
+    int rc;
+    if (width > b->pos_cap) {
+        int64_t *a = (int64_t *)realloc(b->col_pos_s, sizeof(int64_t) * (size_t)width);
+        if (!a) {
+            return LFQ_ERR_NOMEM;
+        }
+        b->col_pos_s = a;
+        b->pos_cap = width;
+    }
+    rc = lfq_readset_pileup_snv(r->ctx, b->rs, b->beg, b->end, r->o.min_plp_bq, &b->t, b->col_pos_s);
+    b->have_tracks = rc == LFQ_OK;
+    return rc;
 }
 
 static int grow_out(lfq_region *r, int64_t width)
 {
     if (width > r->pos_cap) {
-        int64_t *a = (int64_t *)realloc(r->col_pos_s, sizeof(int64_t) * (size_t)width);
-        int64_t *c;
-        if (!a) {
-            return LFQ_ERR_NOMEM;
-        }
-        r->col_pos_s = a;
-        c = (int64_t *)realloc(r->col_pos_i, sizeof(int64_t) * (size_t)width);
+        int64_t *c = (int64_t *)realloc(r->col_pos_i, sizeof(int64_t) * (size_t)width);
         if (!c) {
             return LFQ_ERR_NOMEM;
         }
@@ -294,6 +313,9 @@ static int region_finish(lfq_region *r, reg_buf *b)
      * without BI / BD no event can win the consensus (its quality sum is 0, plp.c:1236-1270) */
     if (rc == LFQ_OK && (r->o.call_indels || b->any_bi || b->any_bd)) {
         rc = lfq_readset_pileup_indels(r->ctx, b->rs, b->beg, b->end, r->o.min_plp_idq, &cols, r->col_pos_i);
+        if (rc == LFQ_OK && !r->o.only_indels) {
+            rc = region_snv_tracks(r, b);       /* its scatter pass runs under the host part of the indel tests below */
+        }
         if (rc == LFQ_OK && r->o.call_indels && cols && cols->ncols > 0) {
             const int64_t nev = cols->side[0].ev_off[cols->ncols] + cols->side[1].ev_off[cols->ncols];
             if (nev + 16 > r->irec_cap) {
@@ -310,9 +332,12 @@ static int region_finish(lfq_region *r, reg_buf *b)
             }
         }
     }
-    if (rc == LFQ_OK && !r->o.only_indels) {
-        rc = lfq_readset_pileup_snv(r->ctx, b->rs, b->beg, b->end, r->o.min_plp_bq, &t, r->col_pos_s);
-        if (rc == LFQ_OK && cols && cols->cons_indel && cols->ncols == t.ncols && t.ncols > 0) {
+    if (rc == LFQ_OK && !r->o.only_indels && !b->have_tracks) {
+        rc = region_snv_tracks(r, b);           /* (no indel pileup ran) */
+    }
+    if (rc == LFQ_OK && b->have_tracks) {
+        t = b->t;
+        if (cols && cols->cons_indel && cols->ncols == t.ncols && t.ncols > 0) {
             rc = lfq_pileup_skip_snv_columns(r->ctx, cols->cons_indel, cols->ncols);
         }
         if (rc == LFQ_OK && t.ncols > 0) {
@@ -331,7 +356,7 @@ static int region_finish(lfq_region *r, reg_buf *b)
         }
     }
     while (rc == LFQ_OK && (i < n_srec || k < n_irec)) {
-        const int64_t p_snv = i < n_srec ? r->col_pos_s[r->srec[i].col] : INT64_MAX;
+        const int64_t p_snv = i < n_srec ? b->col_pos_s[r->srec[i].col] : INT64_MAX;
         const int64_t p_ind = k < n_irec ? r->col_pos_i[r->irec[k].col] : INT64_MAX;
         if (p_ind <= p_snv) {
             /* ins_to_str / del_to_str (lofreq_call.c:255-303): REF / ALT of an indel event */
@@ -420,7 +445,6 @@ int lfq_region_close(lfq_region *r, int64_t *wo_idaq)
     lfq_set_indel_arrays_on_host(r->ctx, 1);
     buf_free(&r->buf[0]);
     buf_free(&r->buf[1]);
-    free(r->col_pos_s);
     free(r->col_pos_i);
     free(r->srec);
     free(r->irec);

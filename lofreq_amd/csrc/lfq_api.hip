@@ -2876,7 +2876,7 @@ int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region
     lfq_readset *rs = nullptr;
     LFQ_TRY(lfq_readset_create(c, rd, nullptr, &rs));
     const int rc = lfq_readset_pileup_snv(c, rs, region_begin, region_end, min_plp_bq, out, col_pos_out);
-    lfq_readset_destroy(rs);            /* the tracks live in the context, not in the read set */
+    lfq_readset_destroy(rs);            /* the tracks live in the context, not in the read set; waits for the scatter pass */
     return rc;
 }
 
@@ -2899,10 +2899,15 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     /* per-position counters (kept until the next call) */
     const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
                   total = o_cidx + al(width * 4);
+    /* Everything goes to the main stream, behind the BAQ kernels if they are still running (the scatter pass reads their
+     * lb bytes; pass 0 beside them was measured: 2 ms alone, 14 ms squeezed between wavefronts that hold 416 of a SIMD's
+     * 512 registers, with the host waiting for its result).  Nothing waits for the scatter pass: the tracks are complete
+     * in stream order (see the header) -- the host goes on with the indel tests while it runs. */
+    hipStream_t ps = c->stream;
     LFQ_TRY(order_after_batch(c, c->stream));          /* the tracks of the previous call may still be a running batch's input */
     LFQ_TRY(grow(&c->d_plp_in, &c->plp_in_bytes, total));
     uint8_t *d = c->d_plp_in;
-    LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), c->stream));
+    LFQ_TRY_HIP(hipMemsetAsync(d + o_cov, 0, (size_t)(o_cidx - o_cov), ps));
     LfqPileupArgs A;
     memset(&A, 0, sizeof(A));
     A.n_reads = n;
@@ -2923,17 +2928,17 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.nb = (int32_t *)(d + o_nb);
     A.cursor = (int32_t *)(d + o_cur);
     /* position-sorted reads (the normal case): the column-major kernels; otherwise one thread per read + atomics */
-    A.pmax_end = readset_pmax(c, rs, c->stream);
+    A.pmax_end = readset_pmax(c, rs, ps);
     const bool sorted = A.pmax_end != nullptr;
-    LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, c->stream) : lfq_launch_pileup_count(A, c->stream));
+    LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, ps) : lfq_launch_pileup_count(A, ps));
     /* prefix sums on the host: 8 bytes per reference position of the region, once per region */
     LfqPin<int32_t> cov(c, (size_t)width), nb(c, (size_t)width), cidx(c, (size_t)width, -1);
     LFQ_PIN_OK(cov);
     LFQ_PIN_OK(nb);
     LFQ_PIN_OK(cidx);
-    LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
-    LFQ_TRY_HIP(hipMemcpyAsync(nb.data(), A.nb, (size_t)width * 4, hipMemcpyDeviceToHost, c->stream));
-    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, ps));
+    LFQ_TRY_HIP(hipMemcpyAsync(nb.data(), A.nb, (size_t)width * 4, hipMemcpyDeviceToHost, ps));
+    LFQ_TRY_HIP(hipStreamSynchronize(ps));
     /* two passes over the positions, both split over a few threads: covered positions and bases per part, then every
      * part fills its slice */
     int64_t part_cols[9] = {0}, part_obs[9] = {0}, part_max[8] = {0};
@@ -2997,14 +3002,17 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
                   t_sq = t_mq + trk, t_ntp = t_sq + (rs->has_sqb ? trk : 0), t_total = t_ntp + (nt_packed ? al(trk / 2 + 16) : 0);
     LFQ_TRY(grow(&c->d_plp_out, &c->plp_out_bytes, t_total));
     uint8_t *t = c->d_plp_out;
-    LFQ_TRY_HIP(hipMemsetAsync(t + t_nt, 0, (size_t)(t_total - t_nt), c->stream));     /* the 16-byte tails are read */
-    LFQ_TRY_HIP(hipMemcpyAsync(t + t_off, off.data(), (size_t)(ncols + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemsetAsync(t + t_nt, 0, (size_t)(t_total - t_nt), ps));            /* the 16-byte tails are read */
+    LFQ_TRY_HIP(hipMemcpyAsync(t + t_off, off.data(), (size_t)(ncols + 1) * 8, hipMemcpyHostToDevice, ps));
     if (ncols > 0) {
-        LFQ_TRY_HIP(hipMemcpyAsync(t + t_ref, h_ref.data(), (size_t)ncols, hipMemcpyHostToDevice, c->stream));
-        LFQ_TRY_HIP(hipMemcpyAsync(t + t_cov, h_cov.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
-        LFQ_TRY_HIP(hipMemcpyAsync(t + t_nb, h_nb.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, c->stream));
+        LFQ_TRY_HIP(hipMemcpyAsync(t + t_ref, h_ref.data(), (size_t)ncols, hipMemcpyHostToDevice, ps));
+        LFQ_TRY_HIP(hipMemcpyAsync(t + t_cov, h_cov.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, ps));
+        LFQ_TRY_HIP(hipMemcpyAsync(t + t_nb, h_nb.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, ps));
     }
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_cidx, cidx.data(), (size_t)width * 4, hipMemcpyHostToDevice, c->stream));
+    LFQ_TRY_HIP(hipMemcpyAsync(d + o_cidx, cidx.data(), (size_t)width * 4, hipMemcpyHostToDevice, ps));
+    /* the pinned blocks these copies read go back to the pool when this function returns: they are waited for here (a
+     * few megabytes on a stream that carries nothing else); the scatter pass below touches no host memory */
+    LFQ_TRY_HIP(hipStreamSynchronize(ps));
     A.col_index = (const int32_t *)(d + o_cidx);
     A.col_off = (const uint64_t *)(t + t_off);
     A.t_nt = t + t_nt;
@@ -3018,7 +3026,8 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
          * pass writes bytes (two lanes, often of two wavefronts, would share a byte), one streaming pass packs them */
         LFQ_TRY(lfq_launch_pack_nt(t + t_nt, t + t_ntp, n_obs, c->stream));
     }
-    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    /* (no wait: what consumes the tracks -- lfq_call_snvs_batch, lfq_pileup_skip_snv_columns, the uniq calls -- is
+     * queued on the same stream; lfq_readset_destroy and lfq_synchronize wait for it) */
     out->nt = nt_packed ? t + t_ntp : t + t_nt;
     out->flags = nt_packed ? LFQ_TRACKS_NT_PACKED : 0;
     out->bq = t + t_bq;

@@ -302,11 +302,15 @@ class ReadSet:
         _lib.check(self.L.lfq_readset_fetch_tags(self.caller.h, self.h, p(lb), p(ai), p(ad), p(fl)), "lfq_readset_fetch_tags")
         return lb, ai, ad, fl
 
-    def pileup_snv(self, begin, end, min_plp_bq=3):
+    def pileup_snv(self, begin, end, min_plp_bq=3, sync=False):
+        """lfq_readset_pileup_snv returns when the scatter pass is queued: the tracks are complete in stream order (the calls
+        that take them are queued behind); sync=True waits, for code that reads the device memory itself"""
         t = _lib.Tracks()
         col_pos = np.zeros(max(end - begin, 1), np.int64)
         _lib.check(self.L.lfq_readset_pileup_snv(self.caller.h, self.h, int(begin), int(end), int(min_plp_bq), C.byref(t),
                                                  col_pos.ctypes.data), "lfq_readset_pileup_snv")
+        if sync:
+            self.caller.synchronize()
         return DeviceTracks(t, col_pos[: int(t.ncols)].copy())
 
     def pileup_indels(self, begin, end, min_plp_idq=0):
