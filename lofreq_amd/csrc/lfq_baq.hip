@@ -627,7 +627,8 @@ struct alignas(16) LfqBaqPair {
 /* One wavefront per SIMD: the interior row needs ~330 registers (45 + 30 doubles of rows, the transition matrix,
  * the prefetch batches), which the unified 512-entry file of gfx950 holds (256 VGPRs + AGPRs as the overflow).  At two
  * wavefronts per SIMD (256 in all) the row loops spill into scratch, whose reloads queue behind the forward matrix's
- * stores: measured 12.8 ms against 7.0 ms per 400 K reads. */
+ * stores: measured 12.8 ms against 7.0 ms per 400 K reads.  (Round 3, after the row bodies shrank to 310 registers:
+ * still 203 spilled at 256, 364 B of scratch per lane -- not taken.) */
 #define LFQ_BAQ_WAVES 1
 
 /* sixteen 4-bit base codes out of four ASCII dwords (byte t of dword d = code 4 d + t) */
@@ -661,11 +662,10 @@ __device__ __forceinline__ uint32_t lfq_baq_ref4(const uint8_t *refw, int p, int
 
 /* one interior row of the forward pass (all 15 cells exist for every read of the wavefront); HASN: some read has an
  * N in its window or as its base */
-template <int NB, bool HASN, bool IDAQ, bool STORE>
+template <int NB, bool HASN, bool IDAQ>
 __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O1)[NB + 1], double (&O2)[NB + 1],
                                                 typename LfqBaqWinT<NB>::type win, int qyi, double e_eq,
-                                                double e_ne, double rs, const double (&m)[9], LfqBaqPair *fp,
-                                                double &sum_out)
+                                                double e_ne, double rs, const double (&m)[9], double &sum_out)
 {
     typedef typename LfqBaqWinT<NB>::type WinT;
     const WinT xq = win ^ (lfq_baq_nibbles<NB, WinT>(1u) * (WinT)(unsigned)(qyi & 3));
@@ -681,10 +681,6 @@ __device__ __forceinline__ void lfq_baq_fwd_row(double (&O0)[NB + 1], double (&O
         const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
         const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
         const double f2 = m[2] * m_prev + m[8] * d_prev;
-        if (STORE) {                                 /* only the even rows go to HBM (a template parameter: a run-time
-                                                      * flag, although wave-uniform, cut the row into 15 basic blocks) */
-            fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
-        }
         m_prev = f0;
         d_prev = f2;
         sum += f0 + f1 + f2;
@@ -1012,16 +1008,16 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #endif
         if (i >= BWF + 1 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
             const bool has_n = qyi > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
-            if (__any(has_n)) {
-                if (store) {
-                    lfq_baq_fwd_row<NB, true, IDAQ, true>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
-                } else {
-                    lfq_baq_fwd_row<NB, true, IDAQ, false>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
+            /* ONE instantiation of the row (the N case always handled: a handful of instructions per slot): with two or
+             * four variants of the body the compiler kept the row in different registers in each and paid ~100 register
+             * moves per row at the joins.  The row is stored after it is complete, from the registers it lives in. */
+            (void)has_n;
+            lfq_baq_fwd_row<NB, true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, sum);
+            if (store) {                             /* wave-uniform: only the even rows go to HBM */
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    fp[(size_t)j * 64] = LfqBaqPair{O0[j], O1[j]};
                 }
-            } else if (store) {
-                lfq_baq_fwd_row<NB, false, IDAQ, true>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
-            } else {
-                lfq_baq_fwd_row<NB, false, IDAQ, false>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, fp, sum);
             }
         } else {
             /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
@@ -1287,19 +1283,15 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         if (i >= BWF + 1 && i <= b_hi) {                   /* interior row */
             const bool has_n = c_qy > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             /* ys = 1 / s[i]: the same division as the forward pass's 1 / sum (i >= 8) */
-            if (__any(has_n)) {
-                lfq_baq_bwd_row<NB, true, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
-            } else {
-                lfq_baq_bwd_row<NB, false, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
-            }
+            (void)has_n;
+            lfq_baq_bwd_row<NB, true, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
             /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
             ensure_g(odd ? i - 1 : i);
             if (!odd) {
                 lfq_baq_map_row<NB, false, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
-            } else if (f_has_n) {
-                lfq_baq_map_row<NB, true, true, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
             } else {
-                lfq_baq_map_row<NB, true, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
+                (void)f_has_n;
+                lfq_baq_map_row<NB, true, true, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
             }
         } else {
             /* the same arithmetic, cells outside [max(1, i - bw), min(l_ref, i + bw)] masked to 0: slots jmin .. jmax;
