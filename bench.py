@@ -87,6 +87,9 @@ def parse_args():
                     help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
     ap.add_argument("--workers", type=int, default=1,
                     help="--mode chain: region workers (processes) sharing the GPU, as call-parallel runs one per bin")
+    ap.add_argument("--overlap-regions", action="store_true",
+                    help="--mode chain, one worker: start region k + 1 (upload, BAQ kernels) before the pileups and calls of "
+                         "region k, as integration/lofreq_amd_region.c does")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed blocks of --steps steps: the first one is the reported value, all of them go into `repeats`")
     ap.add_argument("--no-full-check", action="store_true",
@@ -378,7 +381,7 @@ def bench_baq(caller, la, n_reads, glen, iters, want_idaq=False):
                     "set; kernel time alone: profiles/r02_baq_stats.md"}
 
 
-def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrier=None):
+def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrier=None, overlap=False):
     """reads -> BAQ (+ IDAQ) -> device pileup(s) -> SNV (+ indel) calls on a resident read set: the reference's
     `lofreq call [--call-indels]` with BAQ on (BASELINE.md end-to-end rows), everything after BAM decoding."""
     import ctypes as C
@@ -403,17 +406,22 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
     best = None
     wall = [0.0, 0.0]
     totals = []
-    for it in range(iters + 2):                     # two warm-up regions: the grow-only buffers settle in the second
-        if it == 2:
-            if start_barrier is not None:
-                start_barrier.wait(timeout=300)     # region workers: every process starts its timed regions together
-            wall[0] = time.time()
+    state = {}
+
+    def start():
+        """region start: the read set goes up, its BAQ (+ IDAQ) kernels are queued (asynchronous)"""
         T = [time.perf_counter()]
         h = vp()
         _lib.check(L.lfq_readset_create(caller.h, C.byref(pr), C.byref(tg), C.byref(h)), "lfq_readset_create")
         T.append(time.perf_counter())
         _lib.check(L.lfq_readset_baq(caller.h, h, 1, 1 if call_indels else 0), "lfq_readset_baq")
         T.append(time.perf_counter())
+        return h, T
+
+    def finish(h, T):
+        """pileups, calls, records of a started region"""
+        T = T + [time.perf_counter()]               # (overlapped mode: the start of the next region sits in between)
+        gap = T[3] - T[2]
         conf = la.VarcallConf(flag=la.LFQ_USE_BAQ | la.LFQ_USE_MQ | la.LFQ_USE_IDAQ)
         n_tests = C.c_int64(0)
         nrec = C.c_int64(0)
@@ -449,17 +457,45 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
         recs, _, st = caller.call_snvs(DeviceTracks(t, col_pos_snv), conf, records_capacity=1 << 18)
         T.append(time.perf_counter())
         L.lfq_readset_destroy(h)
-        d = [T[i + 1] - T[i] for i in range(6)]
+        d = [T[1] - T[0], T[2] - T[1]] + [T[i + 1] - T[i] for i in range(3, 7)]
         d[3] -= t_snv                                # (the SNV pileup's call sits inside the interval of the indel tests)
         d[4] += t_snv
-        tot = sum(d)
+        state.update(t=t, n_tests=n_tests, nrec=nrec, recs=recs)
+        return d, gap
+
+    pending = None
+    t_prev = None
+    for it in range(iters + 2 + (1 if overlap else 0)):     # two warm-up regions: the grow-only buffers settle in the second
+        if it == 2:
+            if start_barrier is not None:
+                start_barrier.wait(timeout=300)     # region workers: every process starts its timed regions together
+            wall[0] = time.time()
+        if overlap:
+            # what integration/lofreq_amd_region.c does: region k + 1 is started (upload and BAQ kernels queued) before the
+            # pileups and calls of region k, whose host parts then run under those kernels; a region's time = the interval
+            # between two region ends
+            nxt = start() if it < iters + 2 else None
+            if pending is None:
+                pending = nxt
+                t_prev = time.perf_counter()
+                continue
+            d, _ = finish(*pending)
+            pending = nxt
+            now = time.perf_counter()
+            tot = now - t_prev
+            t_prev = now
+        else:
+            d, _ = finish(*start())
+            tot = sum(d)
         wall[1] = time.time()
-        if it >= 2:
+        if it >= 2 + (1 if overlap else 0):
             totals.append(tot)
-        if best is None or tot < best["s_total"]:
+        if it >= 2 and (best is None or tot < best["s_total"]):
+            t = state["t"]
             best = {"s_total": tot, "s_upload": d[0], "s_baq": d[1], "s_indel_pileup": d[2], "s_indel_calls": d[3],
-                    "s_snv_pileup": d[4], "s_snv_calls": d[5], "columns": int(t.ncols), "indel_tests": int(n_tests.value),
-                    "snv_records": int(len(recs)), "indel_records": int(nrec.value)}
+                    "s_snv_pileup": d[4], "s_snv_calls": d[5], "columns": int(t.ncols), "indel_tests": int(state["n_tests"].value),
+                    "snv_records": int(len(state["recs"])), "indel_records": int(state["nrec"].value)}
+    t = state["t"]
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
     best.update({"s_mean": sum(totals) / max(len(totals), 1), "iterations": len(totals), "s_each": [round(t, 5) for t in totals[:16]],
                  "wall_begin": wall[0], "wall_end": wall[1]})
@@ -467,6 +503,7 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
                  "reads": n_reads, "read_len": R["rl"], "genome_len": glen, "depth": n_reads * R["rl"] / glen,
                  "reads_per_s": n_reads / best["s_total"], "columns_per_s": best["columns"] / best["s_total"],
                  "call_indels": bool(call_indels),
+                 "regions_overlapped": bool(overlap),
                  "note": "resident read set; BAM decoding (htslib, CPU) not included; reference end-to-end rows "
                          "(BASELINE.md 2): 6736 cols/s without BAQ, 1334 cols/s with BAQ, one CPU thread"})
     return best
@@ -635,7 +672,7 @@ def main():
             res = chain_workers(args.workers, iters)
             per_region = res["s_per_region"]
         else:
-            res = bench_chain(caller, la, 2000000, 1000000, iters)
+            res = bench_chain(caller, la, 2000000, 1000000, iters, overlap=args.overlap_regions)
             caller.close()
             per_region = res["s_mean"]               # mean over the timed regions (s_total: the fastest one, by step)
             res["columns_per_s_best"] = res["columns_per_s"]
@@ -646,7 +683,8 @@ def main():
                 "warmup": 2, "ms_per_step": per_region * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": "chain: regions of 2 M reads x 150 bp over 1 Mb (depth 300), --call-indels, BAQ on; "
-                                       "1 step = 1 region, %d region worker(s)" % args.workers, **res}}
+                                       "1 step = 1 region, %d region worker(s)%s"
+                                       % (args.workers, ", regions overlapped" if args.overlap_regions else ""), **res}}
         print(json.dumps(line))
         return
     if args.mode == "baq":
@@ -953,6 +991,10 @@ def main():
                 sec["chain"] = bench_chain(caller, la, 2000000, 1000000, 2)
             except Exception as e:
                 sec["chain"] = {"error": repr(e)}
+            try:                        # one worker that starts region k + 1 before it finishes region k (lofreq_amd_region.c)
+                sec["chain_overlapped"] = bench_chain(caller, la, 2000000, 1000000, 4, overlap=True)
+            except Exception as e:
+                sec["chain_overlapped"] = {"error": repr(e)}
             try:                        # the same chain with two region workers (processes) sharing this GPU
                 sec["chain_2_workers"] = chain_workers(2, 3)
             except BaseException as e:

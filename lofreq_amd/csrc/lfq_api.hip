@@ -3090,6 +3090,8 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     struct Ev { int64_t pos; int64_t read; int32_t qpos, indel; };
     std::vector<Ev> evs;
     std::vector<Ev> evs_part[8];                    /* per thread, concatenated in read order below */
+    /* (host arrays only: runs while the counter kernel of step 2 does) */
+    auto scan_events = [&]() {
     lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
     std::vector<Ev> &evs = evs_part[part];
     for (int64_t r = r_begin; r < r_end; r++) {
@@ -3148,9 +3150,40 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         evs.insert(evs.end(), evs_part[p].begin(), evs_part[p].end());
     }
     std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
-    tm[1] = lfq_now_ms();
-    std::vector<uint8_t> g_ai, g_ad;        /* per event, when the qualities come from the device */
+    };
+    const uint8_t *g_ai = nullptr, *g_ad = nullptr;     /* per event, when the qualities come from the device */
     std::vector<int32_t> qsum[2];           /* per column: quality sum of the reads without an event, from the kernel */
+    /* 5. consensus indel (plp.c:1236-1270): the largest sum of qualities of one event against the sum over the
+     * reads without an event of that side */
+    auto consensus = [&]() {
+    O.cons_indel.assign(O.cov.size(), 0);
+    for (int64_t col = 0; col < (int64_t)O.cov.size(); col++) {
+        for (int sd = 0; sd < 2; sd++) {
+            const LfqIndelColsOwned::Side &S = O.side[sd];
+            if (S.ev_off[(size_t)col] == S.ev_off[(size_t)col + 1]) {
+                continue;                               /* no event of this side: nothing can exceed the non-event sum */
+            }
+            int64_t best = 0, non = 0;
+            for (int64_t e = S.ev_off[(size_t)col]; e < S.ev_off[(size_t)col + 1]; e++) {
+                int64_t sum = 0;
+                for (int64_t i = S.rd_off[(size_t)e]; i < S.rd_off[(size_t)e + 1]; i++) {
+                    sum += S.rd_q[(size_t)i];
+                }
+                best = std::max(best, sum);
+            }
+            if (!qsum[sd].empty()) {
+                non = qsum[sd][(size_t)col];
+            } else {
+                for (int64_t i = S.ne_off[(size_t)col]; i < S.ne_off[(size_t)col + 1]; i++) {
+                    non += S.ne_q[(size_t)i];
+                }
+            }
+            if (best > non) {
+                O.cons_indel[(size_t)col] = 1;
+            }
+        }
+    }
+    };
 
     if (n == 0 || width == 0) {
         for (int sd = 0; sd < 2; sd++) {
@@ -3159,6 +3192,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             O.side[sd].key_off.assign(1, 0);
             O.side[sd].rd_off.assign(1, 0);
         }
+        consensus();
     } else {
         /* 2. dense counters on the device */
         LFQ_TRY_HIP(hipSetDevice(c->device));
@@ -3230,6 +3264,8 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 rc = LFQ_ERR_HIP;
             }
         }
+        scan_events();
+        tm[1] = lfq_now_ms();
         if (rc == LFQ_OK && hipStreamSynchronize(ps) != hipSuccess) {
             rc = LFQ_ERR_HIP;
         }
@@ -3372,16 +3408,20 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                         rc = LFQ_ERR_HIP;
                     }
                 }
-                if (hipStreamSynchronize(ps) != hipSuccess && rc == LFQ_OK) {
-                    rc = LFQ_ERR_HIP;
-                }
+                /* (waited for behind the event tables below) */
             }
         }
         tm[3] = lfq_now_ms();
-        /* ai / ad of the event reads when lfq_readset_baq left them on the device */
-        if (rc == LFQ_OK && rs->has_idaq && !evs.empty()) {
-            LfqPin<int64_t> idx(c, evs.size());
+        /* ai / ad of the event reads when lfq_readset_baq left them on the device: the gather is queued behind the BAQ
+         * kernels on their stream and lands in pinned memory; nothing waits for it until the event tables and the consensus
+         * flags -- which need neither ai / ad nor the tag bits of the reads -- are built (that host work used to start
+         * when the last BAQ kernel had ended: 7 ms of an idle GPU per region). */
+        LfqPin<int64_t> idx(c, evs.size());
+        LfqPin<uint8_t> g_pin(c, 2 * evs.size());
+        const bool gather_aq = rc == LFQ_OK && rs->has_idaq && !evs.empty();
+        if (gather_aq) {
             LFQ_PIN_OK(idx);
+            LFQ_PIN_OK(g_pin);
             for (size_t i = 0; i < evs.size(); i++) {
                 idx[i] = rd->seq_off[evs[i].read] + evs[i].qpos;
             }
@@ -3390,27 +3430,24 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 rc = LFQ_ERR_NOMEM;
             } else {
                 uint8_t *dg = c->d_tmp[2];
-                g_ai.resize(evs.size());
-                g_ad.resize(evs.size());
                 if (hipMemcpyAsync(dg, idx.data(), (size_t)ne * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess
                     || lfq_launch_gather2(rs->d_ai, rs->d_ad, (const int64_t *)dg, ne, dg + ne * 8, dg + ne * 9, c->stream) != LFQ_OK
-                    || hipMemcpyAsync(g_ai.data(), dg + ne * 8, (size_t)ne, hipMemcpyDeviceToHost, c->stream) != hipSuccess
-                    || hipMemcpyAsync(g_ad.data(), dg + ne * 9, (size_t)ne, hipMemcpyDeviceToHost, c->stream) != hipSuccess
-                    || hipStreamSynchronize(c->stream) != hipSuccess) {
+                    || hipMemcpyAsync(g_pin.data(), dg + ne * 8, (size_t)ne * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
                     rc = LFQ_ERR_HIP;
                 }
+                g_ai = g_pin.data();
+                g_ad = g_pin.data() + ne;
             }
         }
         if (rc != LFQ_OK) {
+            (void)hipStreamSynchronize(ps);
+            (void)hipStreamSynchronize(c->stream);
             return rc;
         }
         /* the quality arrays stay resident (c->d_plp_ne): lfq_call_indels_batch builds its pseudo-columns from them on the device */
         c->plp_ne_total[0] = ne_total[0];
         c->plp_ne_total[1] = ne_total[1];
         tm[4] = lfq_now_ms();
-        if (readset_baq_wait(rs) != LFQ_OK) {       /* the ai / ad bits of rs->fl (t_fl) are read from here on */
-            return LFQ_ERR_HIP;
-        }
         /* 4. event tables: per column and side, events in order of first appearance (uthash iterates in insertion
          * order), their reads in pileup order (add_ins_sequence / add_del_sequence, utils.c) */
         /* Columns with events are few and independent of one another: the event list is cut at position boundaries into a
@@ -3427,6 +3464,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             LfqIndelColsOwned::Side side[2];        /* key_off / rd_off: local running totals, no leading 0 */
             std::vector<int64_t> cols;              /* columns with events, ascending */
             std::vector<int64_t> ev_after[2];       /* local event count of each side after each of them */
+            std::vector<int64_t> rd_ev[2];          /* event index of each entry of side[sd].rd_q (for rd_aq, filled last) */
         };
         const int n_parts = (int)std::max<size_t>(1, std::min<size_t>(8, evs.size() / (size_t)std::max<int64_t>(lfq_knobs().host_par_min / 48, 1)));
         std::vector<PartTables> pt((size_t)n_parts);
@@ -3502,16 +3540,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                             const Ev &e = evs[i];
                             const int64_t s0 = rd->seq_off[e.read];
                             const uint32_t fl = t_fl[e.read];
-                            const uint8_t *qa = sd == 0 ? t_bi : t_bd, *aa = sd == 0 ? t_ai : t_ad;
-                            const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u)), tagged = (fl & (sd == 0 ? 4u : 8u)) != 0;
+                            const uint8_t *qa = sd == 0 ? t_bi : t_bd;
+                            const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u));
                             S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
-                            int aq = -1;                                                 /* :1069-1073, 1113-1117 */
-                            if (tagged && !g_ai.empty()) {
-                                aq = (int)(sd == 0 ? g_ai[i] : g_ad[i]) - 33;
-                            } else if (tagged && aa) {
-                                aq = (int)aa[s0 + e.qpos] - 33;
-                            }
-                            S.rd_aq.push_back((int16_t)aq);
+                            S.rd_aq.push_back((int16_t)-1);                  /* filled when the BAQ kernels are through */
+                            P.rd_ev[sd].push_back((int64_t)i);
                             S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
                             const int32_t sq = t_sq ? t_sq[e.read] : -1;
                             S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
@@ -3550,6 +3583,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
         }
         int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
+        std::vector<int64_t> rd_ev[2];
         for (int t = 0; t < n_parts; t++) {
             PartTables &P = pt[(size_t)t];
             int64_t ev_base[2], rd_base[2], key_base[2];
@@ -3566,6 +3600,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 S.rd_aq.insert(S.rd_aq.end(), L.rd_aq.begin(), L.rd_aq.end());
                 S.rd_mq.insert(S.rd_mq.end(), L.rd_mq.begin(), L.rd_mq.end());
                 S.rd_sq.insert(S.rd_sq.end(), L.rd_sq.begin(), L.rd_sq.end());
+                rd_ev[sd].insert(rd_ev[sd].end(), P.rd_ev[sd].begin(), P.rd_ev[sd].end());
                 for (int64_t v : L.key_off) {
                     S.key_off.push_back(v + key_base[sd]);
                 }
@@ -3587,40 +3622,38 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         for (int sd = 0; sd < 2; sd++) {            /* the event-less columns behind the last event */
             O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(ncols - col_done), O.side[sd].ev_off.back());
         }
-    }
-    tm[5] = lfq_now_ms();
-    /* 5. consensus indel (plp.c:1236-1270): the largest sum of qualities of one event against the sum over the
-     * reads without an event of that side */
-    O.cons_indel.assign(O.cov.size(), 0);
-    for (int64_t col = 0; col < (int64_t)O.cov.size(); col++) {
+        if (have_qsum) {
+            consensus();                            /* (sums from the counter kernel: needs nothing the scatter pass writes) */
+        }
+        /* 4b. the scatter pass, the BAQ kernels and the gather behind them: the alignment qualities of the event reads
+         * (plp.c:1069-1073, 1113-1117); from here on the ai / ad bits of rs->fl (t_fl) are valid */
+        if (hipStreamSynchronize(ps) != hipSuccess || (gather_aq && hipStreamSynchronize(c->stream) != hipSuccess)
+            || readset_baq_wait(rs) != LFQ_OK) {
+            return LFQ_ERR_HIP;
+        }
         for (int sd = 0; sd < 2; sd++) {
-            const LfqIndelColsOwned::Side &S = O.side[sd];
-            if (S.ev_off[(size_t)col] == S.ev_off[(size_t)col + 1]) {
-                continue;                               /* no event of this side: nothing can exceed the non-event sum */
-            }
-            int64_t best = 0, non = 0;
-            for (int64_t e = S.ev_off[(size_t)col]; e < S.ev_off[(size_t)col + 1]; e++) {
-                int64_t sum = 0;
-                for (int64_t i = S.rd_off[(size_t)e]; i < S.rd_off[(size_t)e + 1]; i++) {
-                    sum += S.rd_q[(size_t)i];
+            LfqIndelColsOwned::Side &S = O.side[sd];
+            const uint8_t *aa = sd == 0 ? t_ai : t_ad, *ga = sd == 0 ? g_ai : g_ad;
+            for (size_t j = 0; j < rd_ev[sd].size(); j++) {
+                const Ev &e = evs[(size_t)rd_ev[sd][j]];
+                if (!(t_fl[e.read] & (sd == 0 ? 4u : 8u))) {
+                    continue;                           /* no ai / ad tag on this read: -1 */
                 }
-                best = std::max(best, sum);
-            }
-            if (!qsum[sd].empty()) {
-                non = qsum[sd][(size_t)col];
-            } else {
-                for (int64_t i = S.ne_off[(size_t)col]; i < S.ne_off[(size_t)col + 1]; i++) {
-                    non += S.ne_q[(size_t)i];
+                if (ga) {
+                    S.rd_aq[j] = (int16_t)((int)ga[(size_t)rd_ev[sd][j]] - 33);
+                } else if (aa) {
+                    S.rd_aq[j] = (int16_t)((int)aa[rd->seq_off[e.read] + e.qpos] - 33);
                 }
-            }
-            if (best > non) {
-                O.cons_indel[(size_t)col] = 1;
             }
         }
+        if (!have_qsum) {
+            consensus();
+        }
     }
+    tm[5] = lfq_now_ms();
     tm[6] = lfq_now_ms();
     if (lfq_timing_on) {
-        fprintf(stderr, "[lfq timing] indel pileup: events %.1f  device counts %.1f  columns+scatter %.1f  gather %.1f  tables %.1f  consensus %.1f ms\n",
+        fprintf(stderr, "[lfq timing] indel pileup: counters queued + events %.1f  wait %.1f  columns + scatter queued %.1f  gather queued %.1f  tables + consensus + wait + ai / ad %.1f  - %.1f ms\n",
                 tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], tm[6] - tm[5]);
     }
     /* 6. publish */
