@@ -433,6 +433,13 @@ int lfq_source_qual_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int def_nm_q
  * h_counts_or_null is given. */
 int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
 
+/* The profile HMM's gap-open and gap-extension probabilities, kpa_ext_par_t.d / .e (kprobaln_ext.h:31-34), for every
+ * BAQ call of the context after this one.  Default: kpa_ext_par_lofreq_illumina = { 1e-5, 0.4 } (kprobaln_ext.c:50), what
+ * bam_prob_realn_core_ext uses (bam_md_ext.c:275); a reference built with -DPACBIO_REALN uses kpa_ext_par_lofreq_pacbio =
+ * { 0.1, 0.4 } (kprobaln_ext.c:51, bam_md_ext.c:268-273).  kpa_ext_par_t.bw is not a parameter: the caller overwrites it
+ * per read (bam_md_ext.c:376-379).  0 < gap_open < 0.5, 0 < gap_ext < 1, else LFQ_ERR_INVALID. */
+int lfq_set_baq_hmm_params(lfq_ctx *ctx, float gap_open, float gap_ext);
+
 /* nt layout of the tracks the device pileup returns: on = 1 (default) LFQ_TRACKS_NT_PACKED, on = 0 one byte per
  * observation.  lfq_pack_nt_track: the same packing for a host byte track (packed_out: (n_obs + 7) / 8 * 4 bytes). */
 int lfq_set_pileup_nt_packed(lfq_ctx *ctx, int on);

@@ -123,7 +123,7 @@ EXPORTS = [
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
     "lfq_uniq_detlim_batch", "lfq_uniq_binom_batch", "lfq_uniq_mtc", "lfq_binom_cdf",
     "lfq_shard_exchange_counts", "lfq_shard_rebase_bonferroni", "lfq_shard_gather_records", "lfq_shard_advance_conf",
-    "lfq_set_pileup_nt_packed", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
+    "lfq_set_pileup_nt_packed", "lfq_set_baq_hmm_params", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
     "lfq_readset_create", "lfq_readset_destroy", "lfq_readset_baq", "lfq_readset_source_qual",
     "lfq_readset_pileup_snv", "lfq_readset_pileup_indels", "lfq_readset_fetch_tags",
 ]
@@ -160,6 +160,7 @@ def load():
     L.lfq_batch_finish.argtypes = [vp, C.POINTER(BatchStats)]
     L.lfq_set_dense_strand_counts.argtypes = [vp, C.c_int]
     L.lfq_set_indel_arrays_on_host.argtypes = [vp, C.c_int]
+    L.lfq_set_baq_hmm_params.argtypes = [vp, C.c_float, C.c_float]
     L.lfq_call_snvs_submit.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int]
     L.lfq_call_snvs_wait.argtypes = [vp]
     L.lfq_call_snvs_collect.argtypes = [vp, C.POINTER(Conf), vp, C.c_int64, C.POINTER(C.c_int64), vp, C.POINTER(BatchStats)]

@@ -168,6 +168,11 @@ class SnvCaller:
         """lfq_set_pileup_nt_packed: layout of the nt track the device pileup hands out (default: packed nibbles)"""
         _lib.check(self.L.lfq_set_pileup_nt_packed(self.h, 1 if on else 0), "lfq_set_pileup_nt_packed")
 
+    def set_baq_hmm_params(self, gap_open=1e-5, gap_ext=0.4):
+        """lfq_set_baq_hmm_params: kpa_ext_par_t.d / .e of the BAQ HMM (defaults: kpa_ext_par_lofreq_illumina,
+        kprobaln_ext.c:50; a -DPACBIO_REALN build of the reference uses 0.1 / 0.4, :51)"""
+        _lib.check(self.L.lfq_set_baq_hmm_params(self.h, float(gap_open), float(gap_ext)), "lfq_set_baq_hmm_params")
+
     def set_indel_arrays_on_host(self, on):
         """lfq_set_indel_arrays_on_host: off = the quality arrays of the indel columns stay on the device only"""
         _lib.check(self.L.lfq_set_indel_arrays_on_host(self.h, 1 if on else 0), "lfq_set_indel_arrays_on_host")

@@ -306,6 +306,7 @@ struct lfq_ctx {
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
     int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */
     int batch_recorded;              /* ev[3] has been recorded: a batch of this context may still be running */
+    float baq_par_d, baq_par_e;      /* lfq_set_baq_hmm_params; kpa_ext_par_lofreq_illumina (kprobaln_ext.c:50) by default */
     int plp_nt_bytes;                /* lfq_set_pileup_nt_packed(ctx, 0): the device pileup hands out one nt byte per observation */
     const uint8_t *sub_ref_host;
     double sub_t0, sub_t1;
@@ -786,6 +787,8 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     c->sub_ncols = -1;
     c->dense_strand = 1;
     c->indel_host_arrays = 1;
+    c->baq_par_d = 0.00001f;            /* kpa_ext_par_lofreq_illumina (kprobaln_ext.c:50) */
+    c->baq_par_e = 0.4f;
     hipDeviceProp_t prop;
     c->n_cu = 256;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -1212,6 +1215,16 @@ int lfq_set_pileup_nt_packed(lfq_ctx *c, int on)
         return LFQ_ERR_INVALID;
     }
     c->plp_nt_bytes = on ? 0 : 1;
+    return LFQ_OK;
+}
+
+int lfq_set_baq_hmm_params(lfq_ctx *c, float gap_open, float gap_ext)
+{
+    if (!c || !(gap_open > 0.f) || !(gap_open < 0.5f) || !(gap_ext > 0.f) || !(gap_ext < 1.f)) {
+        return LFQ_ERR_INVALID;             /* (NaN included; 1 - 2 d and 1 - e are transition probabilities) */
+    }
+    c->baq_par_d = gap_open;
+    c->baq_par_e = gap_ext;
     return LFQ_OK;
 }
 
@@ -2692,6 +2705,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         A.rows = max_lq + 1;
         A.W = max_w;
         A.baq_extended = baq_extended ? 1 : 0;
+        A.par_d = c->baq_par_d;
+        A.par_e = c->baq_par_e;
         /* waves per launch from a 4 GiB scratch budget */
         const int64_t per_wave = ((int64_t)A.rows * A.W + 2 * (int64_t)A.W + 2 * ((int64_t)A.rows + 2)) * 64 * 8;
         /* the kernel is a chain of dependent HBM accesses per lane: it needs several wavefronts per SIMD in

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
     const int bw2 = bw * 2 + 1;
     const int Wr = bw2 * 3 + 6;                                          /* this read's row width (<= W) */
-    const float par_d = 0.00001f, par_e = 0.4f;                          /* kpa_ext_par_lofreq_illumina */
+    const float par_d = A.par_d, par_e = A.par_e;                        /* kpa_ext_par_t: lfq_set_baq_hmm_params */
     double m[9];
     const double sM = 1. / (2 * l_query + 2), sI = sM;                   /* :127-132 */
     m[0] = (1 - par_d - par_d) * (1 - sM); m[1] = m[2] = par_d * (1 - sM);
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);            /* <= 7: the host sends only such reads here */
     if (!act) bw = BWF;
     const int bw2 = bw * 2 + 1;
-    const float par_d = 0.00001f, par_e = 0.4f;                          /* kpa_ext_par_lofreq_illumina */
+    const float par_d = A.par_d, par_e = A.par_e;                        /* kpa_ext_par_t: lfq_set_baq_hmm_params */
     double m[9];
     const double sM = 1. / (2 * l_query + 2), sI = sM;                   /* :127-132 */
     m[0] = (1 - par_d - par_d) * (1 - sM); m[1] = m[2] = par_d * (1 - sM);

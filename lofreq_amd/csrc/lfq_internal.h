@@ -242,6 +242,7 @@ struct LfqBaqArgs {
     int64_t n_reads;
     int32_t rows, W;           /* scratch geometry: rows >= max l_qseq + 1, W >= max (2 bw + 1) * 3 + 6 */
     int32_t baq_extended;
+    float par_d, par_e;        /* kpa_ext_par_t.d / .e (kprobaln_ext.c:48-51): gap open, gap extension */
     int32_t first_read;        /* reads [first_read, first_read + n_launch) of the arrays (of `order`, if given) */
     const int32_t *order;      /* read indices, narrow-band reads first; null = identity */
     int32_t max_lref;          /* longest reference window among the narrow-band reads (LDS sizing) */

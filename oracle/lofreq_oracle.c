@@ -1316,6 +1316,16 @@ static int orc_idaq(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *
     return (n_ins ? 1 : 0) | (n_del ? 2 : 0);
 }
 
+/* kpa_ext_par_t.d / .e handed to the HMM by orc_baq_idaq_read: kpa_ext_par_lofreq_illumina (kprobaln_ext.c:50,
+ * bam_md_ext.c:275) unless orc_set_baq_hmm_params says otherwise (a -DPACBIO_REALN build: kpa_ext_par_lofreq_pacbio =
+ * { 0.1, 0.4 }, kprobaln_ext.c:51, bam_md_ext.c:268-273).  Process-wide: set it before the worker threads start. */
+static float g_baq_par_d = 0.00001f, g_baq_par_e = 0.4f;
+void orc_set_baq_hmm_params(float d, float e)
+{
+    g_baq_par_d = d;
+    g_baq_par_e = e;
+}
+
 /* BAQ + IDAQ of one read; iaq / daq may be NULL (then only the lb tag is computed).  Returns bit 0 = lb computed,
  * bit 1 = ai tag present, bit 2 = ad tag present. */
 int orc_baq_idaq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, const uint8_t *qual, int l_qseq,
@@ -1373,7 +1383,7 @@ int orc_baq_idaq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t
         const int lr = xe - xb, bmax = (lr > l_qseq ? lr : l_qseq) + abs(lr - l_qseq) + bw;
         pd = calloc((size_t)(l_qseq + 1) * ((size_t)(2 * bmax + 1) * 3 + 6), sizeof(double));
     }
-    orc_kpa_glocal_pd(r, xe - xb, seq, l_qseq, qual, 0.00001f, 0.4f, bw, state, q, pd, &hmm_bw);   /* kpa_ext_par_lofreq_illumina */
+    orc_kpa_glocal_pd(r, xe - xb, seq, l_qseq, qual, g_baq_par_d, g_baq_par_e, bw, state, q, pd, &hmm_bw);
     if (!baq_extended) {                                        /* :409-426 */
         for (k = 0, x = pos, y = 0; k < n_cigar; ++k) {
             const int op = cigar[k] & 0xf, l = cigar[k] >> 4;

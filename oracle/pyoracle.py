@@ -626,9 +626,19 @@ def _reads_struct(P):
     return R, keep
 
 
-def _baq_range(args):
-    P, r0, r1, extended, idaq = args
+def set_baq_hmm_params(gap_open=1e-5, gap_ext=0.4):
+    """orc_set_baq_hmm_params (this process)"""
     L = lib()
+    L.orc_set_baq_hmm_params.argtypes = [C.c_float, C.c_float]
+    L.orc_set_baq_hmm_params.restype = None
+    L.orc_set_baq_hmm_params(gap_open, gap_ext)
+
+
+def _baq_range(args):
+    P, r0, r1, extended, idaq = args[:5]
+    L = lib()
+    if len(args) > 5 and args[5] is not None:
+        set_baq_hmm_params(*args[5])
     L.orc_baq_idaq_reads.restype = C.c_int
     L.orc_baq_idaq_reads.argtypes = [C.POINTER(Reads), C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 4
     R, keep = _reads_struct(P)
@@ -644,7 +654,7 @@ def _baq_range(args):
     return lb[a:b], (ai[a:b] if idaq else None), (ad[a:b] if idaq else None), fl[r0:r1]
 
 
-def baq_idaq_reads(P, extended=True, idaq=True, procs=1):
+def baq_idaq_reads(P, extended=True, idaq=True, procs=1, hmm=None):
     """the lb (and ai / ad) tags of every read of packed reads P by orc_baq_idaq_read -- what mplp_func computes on the
     fly (plp.c:667-683) -- in `procs` processes.  Sets P["lb"], P["ai"], P["ad"] and bits 2 / 3 of P["flags"]."""
     n = P["n"]
@@ -653,9 +663,11 @@ def baq_idaq_reads(P, extended=True, idaq=True, procs=1):
         from concurrent.futures import ProcessPoolExecutor
         cuts = [n * i // procs for i in range(procs + 1)]
         with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
-            parts = list(ex.map(_baq_range, [(P, cuts[i], cuts[i + 1], extended, idaq) for i in range(procs)]))
+            parts = list(ex.map(_baq_range, [(P, cuts[i], cuts[i + 1], extended, idaq, hmm) for i in range(procs)]))
     else:
-        parts = [_baq_range((P, 0, n, extended, idaq))]
+        parts = [_baq_range((P, 0, n, extended, idaq, hmm))]
+        if hmm is not None:
+            set_baq_hmm_params()                    # back to the defaults in this process
     P["lb"] = np.concatenate([p[0] for p in parts])
     fl = np.concatenate([p[3] for p in parts])
     flags = np.asarray(P.get("flags") if P.get("flags") is not None else np.zeros(max(n, 1), np.uint8)).copy()

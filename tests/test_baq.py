@@ -38,7 +38,7 @@ def test_hmm_restatement_equals_reference_object(oracle, seed):
             indel = 0
         ref, query, qual = _random_case(rng, lq, indel)
         bw = 7 if abs(len(ref) - lq) <= 7 else abs(len(ref) - lq) + 3
-        for d, e in ((0.00001, 0.4), (0.001, 0.1)):
+        for d, e in ((0.00001, 0.4), (0.001, 0.1), (0.1, 0.4)):      # illumina, samtools' default, pacbio (kprobaln_ext.c:48-51)
             a = oracle.kpa_glocal(ref, query, qual, d, e, bw, use_reference=True)
             b = oracle.kpa_glocal(ref, query, qual, d, e, bw, use_reference=False)
             assert a[0] == b[0]

@@ -181,3 +181,45 @@ def test_idaq_random_reads_vs_oracle(caller, oracle):
             assert ad.tobytes() == ead.tobytes(), (r["pos0"], r["cigar"])
             n_tags += 1
     assert n_tags > 100
+
+
+@pytest.mark.parametrize("d,e", [(0.1, 0.4), (0.001, 0.1)])
+def test_baq_idaq_other_hmm_parameters(caller, oracle, d, e):
+    """lfq_set_baq_hmm_params: the HMM of a -DPACBIO_REALN build (kpa_ext_par_lofreq_pacbio = { 0.1, 0.4 },
+    kprobaln_ext.c:51, bam_md_ext.c:268-273) and samtools' own { 0.001, 0.1 } (:48); lb / ai / ad against the oracle, whose
+    HMM with these parameters is pinned bitwise against the reference's kprobaln_ext.c object (tests/test_baq.py)."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(16)
+    genome = "".join(rng.choice(list("ACGT"), 3000))
+    g = list(genome)
+    for p0 in range(30, 2900, 53):
+        g[p0:p0 + 6] = g[p0] * 6
+    genome = "".join(g[:3000])
+    reads = _random_reads(rng, genome, 400, 30, 160)
+    default = la.baq_batch(caller, reads, genome.encode(), extended=True, idaq=True)
+    caller.set_baq_hmm_params(d, e)
+    oracle.set_baq_hmm_params(d, e)
+    try:
+        out = la.baq_batch(caller, reads, genome.encode(), extended=True, idaq=True)
+        n_tags = n_diff = 0
+        for r, (lb, ai, ad), (lb0, _, _) in zip(reads, out, default):
+            elb, eai, ead = oracle.baq_idaq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), True)
+            assert lb.tobytes() == elb.tobytes(), (r["pos0"], r["cigar"])
+            assert (ai is None) == (eai is None) and (ad is None) == (ead is None), (r["pos0"], r["cigar"])
+            if ai is not None:
+                assert ai.tobytes() == eai.tobytes(), (r["pos0"], r["cigar"])
+                n_tags += 1
+            if ad is not None:
+                assert ad.tobytes() == ead.tobytes(), (r["pos0"], r["cigar"])
+                n_tags += 1
+            n_diff += lb.tobytes() != lb0.tobytes()
+        assert n_tags > 100
+        assert n_diff > 50                  # the parameters do reach the kernels
+    finally:
+        caller.set_baq_hmm_params()
+        oracle.set_baq_hmm_params()
+    for bad in ((0.0, 0.4), (0.5, 0.4), (1e-5, 1.0), (float("nan"), 0.4)):
+        with pytest.raises(Exception):
+            caller.set_baq_hmm_params(*bad)
+    again = la.baq_batch(caller, reads, genome.encode(), extended=True, idaq=True)
+    assert all(a[0].tobytes() == b[0].tobytes() for a, b in zip(again, default))
