@@ -42,7 +42,7 @@ typedef enum lfq_status {
     LFQ_ERR_NO_DEVICE = -2,    /* no HIP device or HIP runtime error */
     LFQ_ERR_NOMEM = -3,
     LFQ_ERR_CAPACITY = -4,     /* caller-provided output capacity too small */
-    LFQ_ERR_UNSUPPORTED = -5,  /* option the reference rejects too (def_alt_jq == -1; approx threshold) */
+    LFQ_ERR_UNSUPPORTED = -5,  /* option the reference rejects too (def_alt_jq == -1) */
     LFQ_ERR_HIP = -6
 } lfq_status;
 
@@ -103,6 +103,13 @@ typedef struct lfq_conf {
     int64_t num_snv_tests;     /* the global of lofreq_call.c:84; mutated */
     int64_t bonf_indel;        /* running indel Bonferroni factor (snpcaller.h:52); mutated by the indel calls */
     int64_t num_indel_tests;   /* the global of lofreq_call.c:85; mutated */
+    /* -t / --approx-threshold (snpcaller.h:62, snpcaller.c:1128-1142): a column or indel test with more error
+     * probabilities than this is given up without the exact test when the Poisson tail with the same mean, times the
+     * Bonferroni factor, exceeds sig.  <= 0 (default -1, snpcaller.c:650): off.  The reference needs libgsl for it (a
+     * build without aborts, :1118-1125); here the definition gsl_cdf_poisson_P implements is evaluated -- parity
+     * unpinned, see DESIGN.md.  It never adds a call and, as in the reference, does not change the Bonferroni counts. */
+    int32_t approx_threshold_n;
+    int32_t pad_;
 } lfq_conf;
 
 /* dense per-column output of the counting kernel == plp_to_errprobs()'s integer outputs
@@ -555,6 +562,7 @@ typedef struct lfq_dp_work {
     int64_t n_light_retry;     /* light columns finished by the one-column-per-wavefront kernel */
     int64_t bytes_read_count;  /* track + header bytes the count kernel instantiation of this batch reads (layout bytes) */
     int64_t bytes_written_count; /* dense records + class flags it writes */
+    int64_t n_approx_pruned;   /* tested columns the Poisson gate (lfq_conf.approx_threshold_n) gave up: not in the classes above */
 } lfq_dp_work;
 int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);
 

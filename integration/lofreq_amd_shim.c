@@ -321,6 +321,7 @@ static void conf_to_lfq(const varcall_conf_t *c, lfq_conf *o)
     o->sig = c->sig;             o->flag = c->flag & (LFQ_USE_BAQ | LFQ_USE_MQ | LFQ_USE_SQ | LFQ_USE_IDAQ);
     o->num_snv_tests = num_snv_tests;
     o->bonf_indel = c->bonf_indel;      o->num_indel_tests = num_indel_tests;
+    o->approx_threshold_n = c->approx_threshold_n;          /* -t (lofreq_call.c:1283) */
 }
 
 static void ensure_ctx(void)

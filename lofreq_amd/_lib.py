@@ -27,6 +27,7 @@ class Conf(C.Structure):
         ("bonf_dynamic", C.c_int32), ("min_cov", C.c_int32),
         ("bonf_subst", C.c_int64), ("sig", C.c_float), ("flag", C.c_int32),
         ("num_snv_tests", C.c_int64), ("bonf_indel", C.c_int64), ("num_indel_tests", C.c_int64),
+        ("approx_threshold_n", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -54,7 +55,7 @@ class KernelTimes(C.Structure):
 
 class DpWork(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("cells", "rows", "n_light", "n_mid", "n_big", "n_light_retry",
-                                         "bytes_read_count", "bytes_written_count")]
+                                         "bytes_read_count", "bytes_written_count", "n_approx_pruned")]
 
 
 class BaqReads(C.Structure):

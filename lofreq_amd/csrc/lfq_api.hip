@@ -235,6 +235,8 @@ struct lfq_ctx {
     /* per-batch workspace, grown on demand */
     int64_t ws_cols;
     uint8_t *d_flags;
+    uint8_t *d_approx_mu;      /* -t: one double per column of a segment (lfq_launch_approx_gate), grow-only */
+    int64_t approx_mu_bytes;
     int32_t *d_prefix, *d_counters;
     LfqEntry *d_entries;
     hipStream_t dps;           /* scan + light DP of a segment, beside the next segment's count kernel */
@@ -890,7 +892,7 @@ void lfq_destroy(lfq_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_luts, c->d_flags, c->d_prefix, c->d_entries, c->d_counters, c->d_tiles, c->d_longs, c->d_pool, c->d_unsplit, c->d_retry,
-                    c->d_scratch, c->d_counts, c->d_pvals, c->d_stage};
+                    c->d_scratch, c->d_counts, c->d_pvals, c->d_stage, c->d_approx_mu};
     for (void *b : bufs) {
         if (b) (void)hipFree(b);
     }
@@ -966,7 +968,8 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
     LFQ_TRY(make_params(conf, tr, &P, indel_mode));
     P.detlim_af = indel_mode ? nullptr : c->detlim_af;      /* set only inside lfq_uniq_detlim_batch */
     P.lazy_strand = (c->lazy_now && !indel_mode && !P.general && !P.detlim_af) ? 1 : 0;
-    P.pad2_ = 0;
+    /* -t (snpcaller.c:1131); lofreq uniq hands snpcaller -1 (lofreq_uniq.c:311-312) */
+    P.approx_n = (!P.detlim_af && conf->approx_threshold_n > 0) ? conf->approx_threshold_n : 0;
     LFQ_TRY(ensure_workspace(c, tr->ncols));
 
     LfqTracksDev T;
@@ -1073,6 +1076,12 @@ static int batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks 
 
         LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_cnt[s][1], 0));
         LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, dps));
+        if (P.approx_n > 0) {
+            /* -t: the Poisson gate over the listed columns, then the list without the ones it gave up */
+            LFQ_TRY(grow(&c->d_approx_mu, &c->approx_mu_bytes, (c1 - c0) * 8));
+            LFQ_TRY(lfq_launch_approx_gate(T, P, c->d_luts, d_counts, W, c1 - c0, (double *)c->d_approx_mu, c->d_flags, dps));
+            LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, dps, true));
+        }
         LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], dps));
         if (n_seg == 1 && !indel_mode && c->leader && !kn.no_sb_precompute) {
             /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start now */
@@ -1298,6 +1307,7 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
     memcpy(&c->work.cells, g + LFQ_GC_CELLS, 8);
     memcpy(&c->work.rows, g + LFQ_GC_ROWS, 8);
     c->work.n_light_retry = g[LFQ_GC_SCREEN_RETRY];
+    c->work.n_approx_pruned = g[LFQ_GC_APPROX_PRUNED];
     for (int s = 0; s < c->cur_segments; s++) {
         const int32_t *sc = c->h_counters + s * LFQ_NCOUNTERS;
         c->work.n_light += sc[LFQ_CNT_LIGHT];

@@ -2680,6 +2680,140 @@ __global__ __launch_bounds__(64 * LFQ_FOLD_WAVES) void lfq_dp_fold_kernel(LfqPar
 /* launchers                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 
+/* ------------------------------------------------------------------------------------------ */
+/* -t / --approx-threshold: the Poisson gate in front of the DP (snpcaller.c:1128-1142)          */
+/* ------------------------------------------------------------------------------------------ */
+/* A column with more than approx_n error probabilities is given up without the DP when the tail of the Poisson
+ * distribution with the same mean, 1 - gsl_cdf_poisson_P(K - 1, mu), times the Bonferroni factor exceeds sig.  GSL is
+ * not part of the reference tree: what is evaluated is the definition it implements (cdf/poisson.c, cdf/gamma.c:
+ * P(X <= k) = Q(k + 1, mu), computed as 1 - P(k + 1, mu) below the mean), including the two roundings of "1 - (1 - P)"
+ * in double -- the decision differs from a GSL build's only where the approximation lies within rounding of sig / bonf
+ * (parity unpinned).  The Bonferroni bump of the column is not affected (lofreq_call.c:794-801 runs first).
+ * On this implementation the gate is a parity feature, not a shortcut: mu costs a pass over all tracks of the gated
+ * columns, more than the DP of most of them. */
+
+/* pass 1, one wavefront per listed column: mu = sum of its error probabilities (:1132-1135), < 0 = not gated */
+__global__ __launch_bounds__(256) void lfq_approx_mu_kernel(LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ luts,
+                                                            const lfq_col_counts *__restrict__ counts, LfqWork W,
+                                                            double *__restrict__ mu_out)
+{
+    const int n_list = W.counters[LFQ_CNT_LIGHT] + W.counters[LFQ_CNT_MID] + W.counters[LFQ_CNT_BIG];
+    const int n_waves = (int)gridDim.x * 4;
+    const int lane = lfq_lane();
+    for (int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); i < n_list; i += n_waves) {
+        const LfqEntry en = lfq_load_entry(W.entries, i);
+        if (counts[en.col].n_err_probs <= P.approx_n) {
+            if (lane == 0) {
+                mu_out[i] = -1.0;
+            }
+            continue;
+        }
+        LfqColCtx cx;
+        lfq_col_setup(cx, en, P);
+        double s = 0.;
+        const int64_t n_chunks = (cx.n_obs + 63) / 64;
+        for (int64_t ch = 0; ch < n_chunks; ch++) {
+            const LfqRaw r = lfq_load_chunk(cx, ch, T);
+            const LfqObs o = lfq_eval_obs(r.w & 0xffu, (r.w >> 8) & 0xffu, (r.w >> 16) & 0xffu, r.w >> 24, r.sq,
+                                          cx.ref_code, cx.median_ref_bq, P, luts);
+            s += o.keep ? o.p : 0.;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            s += __shfl_xor(s, d, 64);
+        }
+        if (lane == 0) {
+            mu_out[i] = s;
+        }
+    }
+}
+
+/* lgamma(a + 1) - (a log a - a): small next to its two parts, which cancel against a log(mu) - mu below */
+__device__ __forceinline__ double lfq_stirling_rest(double a)
+{
+    if (a < 16.) {
+        return lgamma(a + 1.) - (a * log(a) - a);
+    }
+    const double r = 1. / a, r2 = r * r;
+    return 0.5 * log(6.283185307179586477 * a) + r * (1. / 12. - r2 * (1. / 360. - r2 * (1. / 1260. - r2 * (1. / 1680.))));
+}
+
+/* 1 - gsl_cdf_poisson_P(k - 1, mu) for k >= 1, mu > 0 */
+__device__ double lfq_poisson_tail(int k, double mu)
+{
+    const double a = (double)k;                     /* (k - 1) + 1 */
+    /* x^a e^-x / Gamma(a + 1) */
+    const double pre = exp(a * log(mu / a) + (a - mu) - lfq_stirling_rest(a));
+    if (mu < a + 1.) {
+        double sum = 1., term = 1., n = a;           /* P(a, x) = pre * sum_{j >= 0} x^j / ((a + 1) .. (a + j)) */
+        for (int i = 0; i < 200000; i++) {
+            n += 1.;
+            term *= mu / n;
+            sum += term;
+            if (term < sum * 1e-17) {
+                break;
+            }
+        }
+        const double Pl = pre * sum;
+        return 1. - (1. - Pl);                      /* gsl_cdf_gamma_Q: 1 - P, then snpcaller.c:1136: 1 - that */
+    }
+    /* Q(a, x) by the continued fraction (modified Lentz); x^a e^-x / Gamma(a) = pre * a */
+    const double tiny = 1e-300;
+    double b = mu + 1. - a, c = 1. / tiny, d = 1. / b, h = d;
+    for (int i = 1; i < 200000; i++) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2.;
+        d = an * d + b;
+        d = fabs(d) < tiny ? tiny : d;
+        c = b + an / c;
+        c = fabs(c) < tiny ? tiny : c;
+        d = 1. / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.) < 2e-16) {
+            break;
+        }
+    }
+    return 1. - h * pre * a;
+}
+
+/* pass 2, one lane per listed column: the gate (:1136-1139); a column given up leaves the work list (flag byte 0) */
+__global__ __launch_bounds__(256) void lfq_approx_gate_kernel(LfqParams P, LfqWork W, const double *__restrict__ mu_in,
+                                                              uint8_t *__restrict__ flags)
+{
+    const int n_list = W.counters[LFQ_CNT_LIGHT] + W.counters[LFQ_CNT_MID] + W.counters[LFQ_CNT_BIG];
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n_list) {
+        return;
+    }
+    const double mu = mu_in[i];
+    if (!(mu > 0.)) {
+        return;                                     /* not gated (mu == 0 cannot happen: a phred value is a probability > 0) */
+    }
+    const LfqEntry en = W.entries[i];
+    LfqColCtx cx;
+    lfq_col_setup(cx, en, P);
+    const double approx = lfq_poisson_tail(en.kmax, mu);
+    if (approx * cx.bonf_d > P.sig) {
+        flags[en.col] = 0;
+        atomicAdd(&W.gcounters[LFQ_GC_APPROX_PRUNED], 1);
+    }
+}
+
+int lfq_launch_approx_gate(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts, const lfq_col_counts *d_counts,
+                           const LfqWork &w, int64_t ncols_seg, double *d_mu, uint8_t *d_flags, void *stream)
+{
+    if (ncols_seg <= 0) {
+        return LFQ_OK;
+    }
+    const unsigned waves = (unsigned)std::min<int64_t>(ncols_seg, 256 * 32);
+    hipLaunchKernelGGL(lfq_approx_mu_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, t, p, d_luts, d_counts,
+                       w, d_mu);
+    hipLaunchKernelGGL(lfq_approx_gate_kernel, dim3((unsigned)((ncols_seg + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       p, w, (const double *)d_mu, d_flags);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
 int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                         const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                         int64_t pvals_capacity, int n_waves, void *stream)

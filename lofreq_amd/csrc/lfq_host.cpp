@@ -392,6 +392,7 @@ void lfq_conf_init(lfq_conf *c)
     c->bonf_indel = 1;
     c->num_indel_tests = 0;
     c->flag |= LFQ_USE_IDAQ;
+    c->approx_threshold_n = -1;      /* snpcaller.c:650 */
 }
 
 /* expl() with the reference's clamp (snpcaller.c:1047-1059 / 1169-1188).  For

@@ -45,7 +45,7 @@ struct LfqParams {
      * count becomes (int)(af * n_err_probs), the others 0, and only the 'N' reference gate applies.  null = off */
     const float *detlim_af;
     int32_t lazy_strand;      /* 1: the count kernel skips the strand planes; lfq_strand_* fill them where a record is emitted */
-    int32_t pad2_;
+    int32_t approx_n;         /* > 0: columns with more error probabilities than this pass the Poisson gate first (snpcaller.c:1131) */
 };
 
 struct LfqTracksDev {
@@ -150,6 +150,7 @@ struct LfqWork {
 #define LFQ_GC_MAXDEPTH 3
 #define LFQ_GC_CELLS 8         /* and 9: uint64, DP cells processed = sum over the kept rows n of min(n, K) (SURVEY 8d secondary) */
 #define LFQ_GC_ROWS 10         /* and 11: uint64, kept rows the DP kernels processed */
+#define LFQ_GC_APPROX_PRUNED 13 /* tested columns the Poisson gate (-t) gave up */
 #define LFQ_GC_SCREEN_RETRY 12 /* light columns the screen kernel handed to the one-column-per-wavefront kernel */
 #define LFQ_CNT_TESTED 0
 #define LFQ_CNT_BIG 1
@@ -365,7 +366,11 @@ int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream);
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream);
 int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,
-                    const lfq_col_counts *d_counts, const LfqWork &w, void *stream);
+                    const lfq_col_counts *d_counts, const LfqWork &w, void *stream, bool relist = false);
+/* -t / --approx-threshold (snpcaller.c:1128-1142): clears the flag byte of the listed columns the Poisson gate gives up;
+ * lfq_launch_scan(..., relist = true) then rebuilds the work list without them.  d_mu: one double per column of the segment */
+int lfq_launch_approx_gate(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts, const lfq_col_counts *d_counts,
+                           const LfqWork &w, int64_t ncols_seg, double *d_mu, uint8_t *d_flags, void *stream);
 int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                         const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                         int64_t pvals_capacity, int n_waves, void *stream);

@@ -625,7 +625,10 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_tiles_kernel(int64_
     }
 }
 
-/* single block: exclusive scan over the tile sums, totals into the counters */
+/* single block: exclusive scan over the tile sums, totals into the counters.  RELIST: the second pass of a batch with the
+ * Poisson gate (lfq_launch_approx_gate cleared the flag bytes of the columns it gave up): only the list sizes change --
+ * the tested count and the Bonferroni carry are those of the first pass */
+template <bool RELIST>
 __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t ntiles,
                                                                         LfqTriple *__restrict__ tile_sums,
                                                                         int32_t *__restrict__ counters,
@@ -647,6 +650,20 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t
         }
         lfq_triple_add(carry, total);
     }
+    if (RELIST) {
+        if (threadIdx.x == 0) {
+            counters[LFQ_CNT_MID] = (int32_t)carry.m;
+            counters[LFQ_CNT_BIG] = (int32_t)carry.b;
+            counters[LFQ_CNT_LIGHT] = (int32_t)(carry.t - carry.m - carry.b);
+        }
+        if (threadIdx.x < 3) {                      /* the K histograms of the light class are counted again */
+            counters[LFQ_CNT_KLE7 + (int)threadIdx.x] = 0;
+        }
+        if (threadIdx.x < LFQ_NKHIST) {
+            counters[LFQ_CNT_KHIST + (int)threadIdx.x] = 0;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         counters[LFQ_CNT_TESTED] = (int32_t)carry.t;
         counters[LFQ_CNT_MID] = (int32_t)carry.m;
@@ -659,6 +676,7 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_sums_kernel(int64_t
     }
 }
 
+template <bool RELIST>
 __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTracksDev T, int64_t c0, int64_t c1,
                                                                          const uint8_t *__restrict__ flags,
                                                                          const lfq_col_counts *__restrict__ counts,
@@ -712,7 +730,8 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
             e.off0 = T.col_off[c];
             e.n_obs = (int32_t)(T.col_off[c + 1] - e.off0);
             e.col = (int32_t)c;
-            e.prefix = (int32_t)(carry_in + ex.t);     /* inclusive, batch-wide */
+            /* inclusive, batch-wide (RELIST: as the first pass left it -- columns the gate gave up still count) */
+            e.prefix = RELIST ? W.tested_prefix[c] : (int32_t)(carry_in + ex.t);
             e.kmax = cn->kmax;
             e.median_ref_bq = (int16_t)cn->median_ref_bq;
             e.ref_code = (uint8_t)((rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : 3);
@@ -720,7 +739,9 @@ __global__ __launch_bounds__(LFQ_SCAN_THREADS) void lfq_scan_apply_kernel(LfqTra
             e.pad2_ = 0;
             W.entries[pos] = e;
         }
-        W.tested_prefix[c] = (int32_t)(carry_in + ex.t);   /* inclusive, batch-wide */
+        if (!RELIST) {
+            W.tested_prefix[c] = (int32_t)(carry_in + ex.t);   /* inclusive, batch-wide */
+        }
     }
     /* one set of global atomics per workgroup (per wavefront they contend: +0.1 ms on a 1 M column batch) */
     __shared__ uint32_t s_k[3 + LFQ_NKHIST];
@@ -884,7 +905,7 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
 }
 
 int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,
-                    const lfq_col_counts *d_counts, const LfqWork &w, void *stream)
+                    const lfq_col_counts *d_counts, const LfqWork &w, void *stream, bool relist)
 {
     const int64_t ncols = c1 - c0;
     if (ncols <= 0) {
@@ -894,10 +915,17 @@ int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t
     LfqTriple *tile_sums = reinterpret_cast<LfqTriple *>(w.block_sums);
     hipLaunchKernelGGL(lfq_scan_tiles_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
                        (hipStream_t)stream, ncols, d_flags + c0, tile_sums);
-    hipLaunchKernelGGL(lfq_scan_sums_kernel, dim3(1), dim3(LFQ_SCAN_THREADS), 0, (hipStream_t)stream, ntiles,
-                       tile_sums, w.counters, w.gcounters);
-    hipLaunchKernelGGL(lfq_scan_apply_kernel, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
-                       (hipStream_t)stream, t, c0, c1, d_flags, d_counts, (const LfqTriple *)tile_sums, w);
+    if (relist) {
+        hipLaunchKernelGGL(lfq_scan_sums_kernel<true>, dim3(1), dim3(LFQ_SCAN_THREADS), 0, (hipStream_t)stream, ntiles,
+                           tile_sums, w.counters, w.gcounters);
+        hipLaunchKernelGGL(lfq_scan_apply_kernel<true>, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
+                           (hipStream_t)stream, t, c0, c1, d_flags, d_counts, (const LfqTriple *)tile_sums, w);
+    } else {
+        hipLaunchKernelGGL(lfq_scan_sums_kernel<false>, dim3(1), dim3(LFQ_SCAN_THREADS), 0, (hipStream_t)stream, ntiles,
+                           tile_sums, w.counters, w.gcounters);
+        hipLaunchKernelGGL(lfq_scan_apply_kernel<false>, dim3((unsigned)ntiles), dim3(LFQ_SCAN_THREADS), 0,
+                           (hipStream_t)stream, t, c0, c1, d_flags, d_counts, (const LfqTriple *)tile_sums, w);
+    }
     LFQ_HIP_TRY(hipGetLastError());
     return LFQ_OK;
 }

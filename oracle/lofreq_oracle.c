@@ -54,6 +54,7 @@ void orc_conf_init(orc_conf *c)
     c->bonf_indel = 1;      /* snpcaller.c:642 */
     c->num_indel_tests = 0;
     c->flag |= ORC_USE_IDAQ; /* snpcaller.c:647 */
+    c->approx_threshold_n = -1; /* snpcaller.c:650 */
 }
 
 /* utils.h:42  PHREDQUAL_TO_PROB */
@@ -254,11 +255,102 @@ double *orc_poissbin(long double *pvalue, const double *ep, int n_ep, int kmax, 
     return pv;
 }
 
-/* snpcaller.c:1075-1205 (GSL approximation branch :1128-1142 not restated: it is
- * compiled out without libgsl and off by default; approx_threshold_n > 0 is rejected
- * upstream exactly like a no-GSL build, :1118-1125). */
+/* ---- the Poisson approximation gate of snpcaller (-t / --approx-threshold, snpcaller.c:1128-1142) ----------
+ * PARITY UNPINNED: the branch needs libgsl (gsl_cdf_poisson_P), which is neither in the reference tree nor in this image,
+ * and the 2.1.4 binary predates the option.  What is restated is the published definition GSL implements:
+ *     gsl_cdf_poisson_P(k, mu) = P(X <= k) = Q(k + 1, mu)      (cdf/poisson.c: a = k + 1; gsl_cdf_gamma_Q(mu, a, 1))
+ *     gsl_cdf_gamma_Q(x, a, 1): x < a ? 1 - gsl_sf_gamma_inc_P(a, x) : gsl_sf_gamma_inc_Q(a, x)   (cdf/gamma.c)
+ * with the regularized incomplete gamma functions evaluated here in long double (series below a + 1, Lentz's continued
+ * fraction above) and rounded to double where GSL returns a double, so that the two subtractions from 1 round the way
+ * they do there.  Pinned against scipy.special.pdtr (tests/test_oracle_kat.py), not against GSL. */
+static long double orc_gamma_inc_p_series(long double a, long double x)    /* P(a, x), x < a + 1 */
+{
+    long double sum = 1.0L, term = 1.0L, n = a;
+    int i;
+    for (i = 0; i < 1000000; i++) {
+        n += 1.0L;
+        term *= x / n;
+        sum += term;
+        if (term < sum * 1e-21L) {
+            break;
+        }
+    }
+    return sum * expl(a * logl(x) - x - lgammal(a + 1.0L));
+}
+
+static long double orc_gamma_inc_q_cf(long double a, long double x)        /* Q(a, x), x >= a + 1 (modified Lentz) */
+{
+    const long double tiny = 1e-4000L;
+    long double b = x + 1.0L - a, c = 1.0L / tiny, d = 1.0L / b, h = d;
+    int i;
+    for (i = 1; i < 1000000; i++) {
+        const long double an = -(long double)i * ((long double)i - a);
+        long double del;
+        b += 2.0L;
+        d = an * d + b;
+        if (fabsl(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (fabsl(c) < tiny) c = tiny;
+        d = 1.0L / d;
+        del = d * c;
+        h *= del;
+        if (fabsl(del - 1.0L) < 1e-20L) {
+            break;
+        }
+    }
+    return h * expl(a * logl(x) - x - lgammal(a));
+}
+
+/* gsl_cdf_poisson_P(k, mu) as a double */
+double orc_poisson_cdf(unsigned int k, double mu)
+{
+    const long double a = (long double)k + 1.0L, x = (long double)mu;
+    if (!(mu > 0.0)) {
+        return NAN;                                         /* GSL: domain error (its handler aborts by default) */
+    }
+    if (x < a) {
+        const double P = (double)orc_gamma_inc_p_series(a, x);
+        return 1.0 - P;                                     /* gsl_cdf_gamma_Q: Q = 1 - P */
+    }
+    if (x < a + 1.0L) {
+        return (double)(1.0L - orc_gamma_inc_p_series(a, x));
+    }
+    return (double)orc_gamma_inc_q_cf(a, x);
+}
+
+/* snpcaller.c:1131-1140: 1 = the column is given up without running the DP */
+int orc_approx_gate(const double *ep, int n_ep, int kmax, long long bonf, double sig, int approx_threshold_n,
+                    long double *approx_out)
+{
+    long double mu = 0.0L, approx;
+    int i;
+    if (approx_out) {
+        *approx_out = NAN;
+    }
+    if (!(approx_threshold_n > 0 && n_ep > approx_threshold_n)) {      /* :1131 */
+        return 0;
+    }
+    for (i = 0; i < n_ep; ++i) {
+        mu += ep[i];                                        /* :1133-1135 */
+    }
+    approx = 1 - orc_poisson_cdf((unsigned int)(kmax - 1), (double)mu);   /* :1136 (double arithmetic, then widened) */
+    if (approx_out) {
+        *approx_out = approx;
+    }
+    return approx * (double)bonf > sig;                     /* :1137 */
+}
+
+/* snpcaller.c:1075-1205 */
+int orc_snpcaller_approx(long double pv_out[3], double logp_out[3], const double *ep, int n_ep,
+                         const int counts[3], long long bonf, double sig, int approx_threshold_n, int *rows_done);
 int orc_snpcaller(long double pv_out[3], double logp_out[3], const double *ep, int n_ep,
                   const int counts[3], long long bonf, double sig, int *rows_done)
+{
+    return orc_snpcaller_approx(pv_out, logp_out, ep, n_ep, counts, bonf, sig, -1, rows_done);
+}
+
+int orc_snpcaller_approx(long double pv_out[3], double logp_out[3], const double *ep, int n_ep,
+                         const int counts[3], long long bonf, double sig, int approx_threshold_n, int *rows_done)
 {
     double *probvec;
     long double pv;
@@ -278,6 +370,9 @@ int orc_snpcaller(long double pv_out[3], double logp_out[3], const double *ep, i
     }
     if (kmax == 0) {
         return 0;                                           /* :1113 */
+    }
+    if (orc_approx_gate(ep, n_ep, kmax, bonf, sig, approx_threshold_n, NULL)) {
+        return 0;                                           /* :1137-1139 */
     }
     probvec = orc_poissbin(&pv, ep, n_ep, kmax, bonf, sig, rows_done);   /* :1144 */
     if (!probvec) {
@@ -593,8 +688,8 @@ int orc_call_batch(const uint8_t *nt, const uint8_t *bq, const uint8_t *baq, con
         r->tested = 1;
         r->bonf_used = conf->bonf_subst;
 
-        rc = orc_snpcaller(r->pvalue, r->logp, ep, r->n_err_probs, r->alt_counts, conf->bonf_subst,
-                           (double)conf->sig, &r->dp_rows);   /* lofreq_call.c:807 */
+        rc = orc_snpcaller_approx(r->pvalue, r->logp, ep, r->n_err_probs, r->alt_counts, conf->bonf_subst,
+                                  (double)conf->sig, conf->approx_threshold_n, &r->dp_rows);   /* lofreq_call.c:807 */
         t3 = orc_now();
         if (timing) {
             timing->t_sort += t2 - t1;
@@ -739,7 +834,7 @@ int orc_call_indels_batch(const orc_indel_batch *b, orc_conf *conf, orc_indel_te
                 }
                 conf->num_indel_tests += 1;
                 counts[0] = (int)(b->rd_off[side][e + 1] - b->rd_off[side][e]);   /* it->count */
-                if (orc_snpcaller(pv, lp, ep, n, counts, conf->bonf_indel, (double)conf->sig, &rows)) {
+                if (orc_snpcaller_approx(pv, lp, ep, n, counts, conf->bonf_indel, (double)conf->sig, conf->approx_threshold_n, &rows)) {
                     free(ep);
                     return -1;
                 }

@@ -33,6 +33,7 @@ class Conf(C.Structure):
         ("bonf_subst", C.c_int64), ("sig", C.c_float), ("flag", C.c_int32),
         ("raw_counts_after_minbq", C.c_int32), ("num_snv_tests", C.c_int64),
         ("bonf_indel", C.c_int64), ("num_indel_tests", C.c_int64),
+        ("approx_threshold_n", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

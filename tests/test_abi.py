@@ -27,7 +27,7 @@ def test_struct_layouts():
     assert _lib.COL_COUNTS_DTYPE.itemsize == 64
     assert _lib.COL_PVALS_DTYPE.itemsize == 128
     assert _lib.SNV_RECORD_DTYPE.itemsize == 64
-    assert C.sizeof(_lib.Conf) == 72
+    assert C.sizeof(_lib.Conf) == 80        # + approx_threshold_n, pad (snpcaller.h:62)
     assert _lib.INDEL_CALL_DTYPE.itemsize == 48 and _lib.INDEL_RECORD_DTYPE.itemsize == 80
     assert C.sizeof(_lib.IndelColumnsC) == 8 * 8 + 2 * 15 * 8 + 8
     assert C.sizeof(_lib.Tracks) == 12 * 8
@@ -42,6 +42,7 @@ def test_conf_defaults_match_reference():
     assert c.min_cov == 1 and c.bonf_dynamic == 1 and c.bonf_subst == 1
     assert c.sig == np.float32(0.01) and c.flag == (la.LFQ_USE_MQ | la.LFQ_USE_BAQ | la.LFQ_USE_IDAQ)
     assert c.bonf_indel == 1 and c.num_indel_tests == 0
+    assert c.approx_threshold_n == -1           # snpcaller.c:650
 
 
 def test_no_cpu_fallback_without_gpu():

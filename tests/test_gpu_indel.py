@@ -115,3 +115,14 @@ def test_indel_golden_reference_binary_vcf(caller):
                                         None if direct else "PASS").rstrip("\n")
                  for r, k in zip(recs, keep) if k]
         assert lines == fx["vcf"], path
+
+
+def test_indel_approx_threshold_gate(caller, oracle):
+    """the same gate in front of the indel tests (lofreq_call.c:319-320, 384-385: snpcaller(..., conf->approx_threshold_n))"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(77)
+    dicts = util.random_indel_columns(rng, 200, 100, 900)
+    _, tests_off, recs_off = _run_both(la, caller, oracle, dicts)
+    _, tests, recs = _run_both(la, caller, oracle, dicts, approx_threshold_n=150)
+    assert len(tests) == len(tests_off) and len(recs) <= len(recs_off)
+    assert caller.dp_work()["n_approx_pruned"] > 0

@@ -548,3 +548,37 @@ def test_deep_tail_against_80bit_truth(caller, oracle):
     print("deep tail vs 80-bit truth over %d p-values: device %.3g, reference log-space chain %.3g" % (n, worst_dev, worst_ref))
     assert n >= 50, n
     assert worst_ref <= 1e-9
+
+
+@pytest.mark.parametrize("thr,kw", [(50, {}), (400, dict(def_alt_bq=-1)), (50, dict(min_jq=12, flag=7)),
+                                    (50, dict(bonf_dynamic=0, bonf_subst=1000000))])
+def test_approx_threshold_gate(caller, oracle, thr, kw):
+    """-t / --approx-threshold (snpcaller.c:1128-1142): columns with more than thr error probabilities pass the Poisson gate
+    first.  Against the oracle's restatement of the gate (pinned to scipy, not to GSL: parity unpinned); counts, the
+    Bonferroni factors (the gate does not touch them) and every record bit-exact / 1e-10 as without the gate.  Marginal
+    planted frequencies and many low qualities (Poisson variance above the Poisson-binomial one), so that the gate gives up
+    columns the exact test calls."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(31 + thr)
+    ncols = 700
+    planted = {c: float(af) for c, af in zip(range(1, ncols, 2), rng.uniform(0.05, 0.4, ncols))}
+    host = util.random_batch(rng, ncols, 20, 1500, planted=planted, low_bq_frac=0.35, with_sq=True)
+    conf_off = la.VarcallConf(**kw)
+    recs_off, _, _ = caller.call_snvs(util.to_pileup_batch(la, host), conf_off, want_counts=True)
+    ores, oconf = util.run_oracle(oracle, host, approx_threshold_n=thr, **kw)
+    conf = la.VarcallConf(approx_threshold_n=thr, **kw)
+    recs, counts, st = caller.call_snvs(util.to_pileup_batch(la, host), conf, want_counts=True)
+    work = caller.dp_work()
+    util.assert_counts_equal(counts, ores, host)
+    assert conf.bonf_subst == oconf.bonf_subst == conf_off.bonf_subst
+    assert conf.num_snv_tests == oconf.num_snv_tests
+    assert st.n_tested == int(ores["tested"].sum())
+    _compare_records(la, recs, ores, host)
+    assert work["n_approx_pruned"] > 50
+    assert work["n_approx_pruned"] + work["n_light"] + work["n_mid"] + work["n_big"] == st.n_tested
+    assert len(recs) < len(recs_off)            # the gate cost calls here (lofreq_call.c:994: "might decrease number of calls")
+    assert {(int(r["col"]), r["alt"]) for r in recs} <= {(int(r["col"]), r["alt"]) for r in recs_off}
+    # deep columns below the threshold are not looked at
+    conf_hi = la.VarcallConf(approx_threshold_n=100000, **kw)
+    recs_hi, _, _ = caller.call_snvs(util.to_pileup_batch(la, host), conf_hi, want_counts=True)
+    assert caller.dp_work()["n_approx_pruned"] == 0 and len(recs_hi) == len(recs_off)

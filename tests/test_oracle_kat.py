@@ -192,3 +192,59 @@ def test_linear_dp_truth_and_reference_noise(oracle):
         ep = np.full(n, 0.001)
         vec, _, _ = oracle.poissbin(ep, k)
         assert abs(vec[k] - truth(ep, k)) < tol
+
+
+def test_poisson_cdf_of_the_approximation_gate_against_scipy(oracle):
+    """-t / --approx-threshold (snpcaller.c:1128-1142) needs gsl_cdf_poisson_P, and GSL is neither in the reference tree
+    nor in this image: the gate is PARITY UNPINNED.  What can be pinned is the function itself -- the oracle's long-double
+    evaluation of P(X <= k), X ~ Poisson(mu), against scipy.special.pdtr / pdtrc (cephes: another implementation of the
+    same definition) over the (k, mu) range a pileup produces."""
+    import ctypes as C
+    from scipy import special
+    L = oracle.lib()
+    L.orc_poisson_cdf.restype = C.c_double
+    L.orc_poisson_cdf.argtypes = [C.c_uint, C.c_double]
+    rng = np.random.default_rng(11)
+    worst_abs = worst_rel_tail = 0.0
+    n_tail = 0
+    for _ in range(4000):
+        mu = float(10 ** rng.uniform(-3, 4.5))
+        k = int(max(0, mu + rng.normal() * 7 * np.sqrt(mu) + rng.integers(0, 6)))
+        cdf = L.orc_poisson_cdf(k, mu)
+        worst_abs = max(worst_abs, abs(cdf - special.pdtr(k, mu)))
+        sf = special.pdtrc(k, mu)
+        if sf > 1e-13:                      # (1 - cdf keeps 16 digits of 1: below that the reference's own value is noise)
+            n_tail += 1
+            worst_rel_tail = max(worst_rel_tail, abs((1.0 - cdf) - sf) / sf - 1.2e-16 / sf)
+    assert worst_abs < 1e-13, worst_abs
+    assert n_tail > 1000 and worst_rel_tail < 1e-10, (n_tail, worst_rel_tail)
+    assert np.isnan(L.orc_poisson_cdf(3, 0.0))          # GSL: domain error
+
+
+def test_approximation_gate_semantics(oracle):
+    """orc_approx_gate: only above the threshold (:1131), mean = plain sum (:1133-1135), never a call the exact test
+    would not make (the gate only gives columns up), off for approx_threshold_n <= 0 (:1131)"""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_approx_gate.restype = C.c_int
+    L.orc_approx_gate.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.c_longlong, C.c_double, C.c_int,
+                                  C.POINTER(C.c_longdouble)]
+    ep = np.sort(np.full(400, 1e-3))
+    p = ep.ctypes.data_as(C.POINTER(C.c_double))
+    out = C.c_longdouble()
+    # mean 0.4: one mismatch is unremarkable (tail 0.33), thirty are not
+    assert L.orc_approx_gate(p, 400, 1, 3, 0.01, 100, C.byref(out)) == 1
+    assert abs(float(out.value) - (1 - np.exp(-0.4))) < 1e-15
+    assert L.orc_approx_gate(p, 400, 30, 3, 0.01, 100, C.byref(out)) == 0
+    assert L.orc_approx_gate(p, 400, 1, 3, 0.01, 400, None) == 0         # n_ep > threshold is strict
+    assert L.orc_approx_gate(p, 400, 1, 3, 0.01, 399, None) == 1
+    assert L.orc_approx_gate(p, 400, 1, 3, 0.01, 0, None) == 0
+    assert L.orc_approx_gate(p, 400, 1, 3, 0.01, -1, None) == 0
+    # a column the gate gives up produces no p-values, its Bonferroni bump stays (lofreq_call.c:794-801 runs before)
+    rng = np.random.default_rng(3)
+    import util
+    host = util.random_batch(rng, 60, 300, 900, planted={c: 0.012 for c in range(2, 60, 3)}, low_bq_frac=0.3)
+    off, _ = util.run_oracle(oracle, host)
+    on, conf_on = util.run_oracle(oracle, host, approx_threshold_n=100)
+    assert np.array_equal(off["tested"], on["tested"]) and conf_on.bonf_subst == 3 * int(on["tested"].sum())
+    assert (on["emitted"] <= off["emitted"]).all()
