@@ -106,7 +106,7 @@ private:
     {
         spin_us_ = lfq_knobs().host_spin_us;
         /* the helpers spin between loops: a node's ranks share its cores (LOCAL_WORLD_SIZE processes) */
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency() / (unsigned)std::max(lfq_knobs().local_world_size, 1));
+        const unsigned hw = std::max(1u, lfq_cpu_budget() / (unsigned)std::max(lfq_knobs().local_world_size, 1));
         const int n = spin_us_ < 0 ? 0 : (int)std::min(7u, hw - 1u);
         for (int i = 0; i < n; i++) {
             th_.emplace_back([this, i] { loop(i); });
@@ -173,7 +173,7 @@ static void lfq_for_reads(int64_t n, F f, int *parts_out = nullptr)
     int parts = 1;
     const int64_t par_min = lfq_knobs().host_par_min;        /* LFQ_HOST_PAR_MIN (200000): below it one thread does it */
     if (n >= par_min) {
-        unsigned hw = std::thread::hardware_concurrency();
+        unsigned hw = lfq_cpu_budget();
         hw = std::max(1u, hw / (unsigned)lfq_knobs().local_world_size);
         parts = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 8u), n / std::max<int64_t>(par_min / 2, 1));
         parts = std::max(parts, 1);

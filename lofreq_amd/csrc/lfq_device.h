@@ -54,13 +54,34 @@ __device__ __forceinline__ double lfq_rl_f64(double x, int i)
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ uint32_t lfq_wave_sum_u32(uint32_t x)
+/* Sums over groups of lanes by DPP (no LDS crossbar, no lgkmcnt wait): quad_perm [1,0,3,2] and [2,3,0,1] give every
+ * lane its quad's sum, row_half_mirror (lane i <-> 7 - i) adds the other quad of the half row, row_mirror (i <-> 15 - i)
+ * the other half.  Uniform control flow only (a disabled lane contributes nothing and receives nothing). */
+template <int CTRL>
+__device__ __forceinline__ uint32_t lfq_dpp_u32(uint32_t x)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        x += (uint32_t)__shfl_xor((int)x, d, 64);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+
+template <int LANES>        /* 4, 8 or 16 adjacent lanes, aligned: every lane of the group gets the group's sum */
+__device__ __forceinline__ uint32_t lfq_group_sum_u32(uint32_t x)
+{
+    x += lfq_dpp_u32<0xB1>(x);
+    x += lfq_dpp_u32<0x4E>(x);
+    if (LANES >= 8) {
+        x += lfq_dpp_u32<0x141>(x);
+    }
+    if (LANES >= 16) {
+        x += lfq_dpp_u32<0x140>(x);
     }
     return x;
+}
+
+__device__ __forceinline__ uint32_t lfq_wave_sum_u32(uint32_t x)
+{
+    x = lfq_group_sum_u32<16>(x);                    /* the four rows, then their sums through the scalar unit */
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 0) + (uint32_t)__builtin_amdgcn_readlane((int)x, 16)
+           + (uint32_t)__builtin_amdgcn_readlane((int)x, 32) + (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -62,6 +63,9 @@ const LfqKnobs &lfq_knobs(void)
         x.segments = (int)std::min((long)LFQ_MAX_SEGMENTS, std::max(1L, geti("LFQ_SEGMENTS", 1)));
         x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
+        x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
+        x.count_lpg4_below = geti("LFQ_COUNT_LPG4_BELOW", 320);
+        x.count_lpg8_below = geti("LFQ_COUNT_LPG8_BELOW", 900);
         x.cu_split = (int)std::max(0L, geti("LFQ_CU_SPLIT", 0));
         x.sync_upload = (int)geti("LFQ_SYNC_UPLOAD", 0);
         x.host_spin_us = geti("LFQ_HOST_SPIN_US", 2000);
@@ -163,6 +167,45 @@ double hypergeom_next(int n11, int n1_, int n_1, int n, HyperAcc &s)
 
 }  // namespace
 
+unsigned lfq_cpu_budget(void)
+{
+    static const unsigned budget = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        n = n ? n : 1u;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            const int a = CPU_COUNT(&set);
+            if (a > 0) {
+                n = std::min<unsigned>(n, (unsigned)a);
+            }
+        }
+        /* cgroup v2: "<quota> <period>" or "max <period>"; v1: cpu.cfs_quota_us / cpu.cfs_period_us */
+        long long quota = -1, period = -1;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32];
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) {
+                quota = atoll(q);
+            }
+            fclose(f);
+        } else {
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+                fclose(g);
+            }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(g, "%lld", &period) != 1) period = -1;
+                fclose(g);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        return std::max(1u, n);
+    }();
+    return budget;
+}
+
 namespace {
 
 /* A small persistent pool for the host finishing step (strand-bias Fisher tests): spawning threads per
@@ -201,7 +244,7 @@ public:
 private:
     LfqPool()
     {
-        unsigned hw = std::thread::hardware_concurrency();
+        unsigned hw = lfq_cpu_budget();
         const LfqKnobs &kn = lfq_knobs();
         hw = std::max(1u, hw / (unsigned)kn.local_world_size);   /* one process per GPU (torchrun): share the cores */
         int n = (int)std::min<unsigned>(hw > 1 ? hw - 1 : 0, 63u);
@@ -641,7 +684,7 @@ int lfq_finalize_pvals(const lfq_conf *conf, const lfq_col_pvals *pvals, int64_t
             cost += records[miss[(size_t)j]].alt_fw + records[miss[(size_t)j]].alt_rv;
         }
         /* waking the pool costs more than a few cheap tables */
-        const int helpers = cost < 20000 ? 0 : (int)std::min<int64_t>(LfqPool::instance().size(), nm / 4);
+        const int helpers = cost < lfq_knobs().sb_par_min_cost ? 0 : (int)std::min<int64_t>(LfqPool::instance().size(), nm / 4);
         LfqPool::instance().run(work, helpers);
         tf[4] = now();
         if (timing) {

@@ -195,6 +195,8 @@ struct LfqKnobs {
     int segments;              /* LFQ_SEGMENTS: batch segments */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
+    long sb_par_min_cost;      /* LFQ_SB_PAR_MIN_COST (20000): summed alt counts of the strand-bias tests of a batch from which they go to the host pool */
+    long count_lpg4_below, count_lpg8_below;   /* LFQ_COUNT_LPG4_BELOW (320), LFQ_COUNT_LPG8_BELOW (900): deepest column up to which 4 / 8 lanes share a column */
     long host_spin_us;         /* LFQ_HOST_SPIN_US (2000): how long the helper threads of the host loops spin for the next loop; -1 = no pool */
     int sync_upload;           /* LFQ_SYNC_UPLOAD: 1 = lfq_readset_create waits for its copies itself (no helper thread), 2 = helper thread whatever the size */
     int host_threads;          /* LFQ_HOST_THREADS: -1 = from the core count */
@@ -209,6 +211,9 @@ struct LfqKnobs {
                                 * stream (count kernels, pileup, BAQ) with the other CUs: spatial partition for two batches in flight */
 };
 const LfqKnobs &lfq_knobs(void);
+/* CPUs this process may actually use: the affinity mask and the cgroup's cpu.max quota, not the machine's core count
+ * (a container that is granted 16 of 256 cores must not start 63 helper threads); >= 1 */
+unsigned lfq_cpu_budget(void);
 
 /* ---- strand-bias precompute (host, lfq_host.cpp) ---------------------------------------------------
  * report_var's Fisher test (lofreq_call.c:117-129) depends only on the DP4 counts, which are final after

@@ -242,28 +242,39 @@ __device__ __forceinline__ void lfq_count_emit(bool strand, lfq_col_counts &r, c
 }
 
 /* Shallow columns (depth up to a few thousand): the per-column epilogue (12 reductions + the record) costs more
- * than the loads, so FOUR columns share a wavefront, 16 lanes each: 4-step reductions inside the DPP row, four
- * records built at once.  Fast path only (nt + bq tracks); everything else runs lfq_count_kernel. */
-template <bool PACKED, bool STRAND>
+ * than the loads, so several columns share a wavefront, LPG lanes each: 64 / LPG records built at once, reductions of
+ * log2(LPG) steps inside the DPP row.  LPG = 16 (four columns) up to a few thousand observations per column, 8 below a
+ * thousand, 4 for exome-like depths: the instructions of one pass over the epilogue are the same for any LPG, so the
+ * cost per column falls with the number of columns that share it until the loads dominate (at 200x: 0.65 -> see
+ * DESIGN.md 3.1).  Fast path only (nt + bq tracks); everything else runs lfq_count_kernel. */
+template <bool PACKED, bool STRAND, int LPG>
 __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, LfqParams P,
                                                               lfq_col_counts *__restrict__ out,
                                                               uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
+    constexpr int G = 64 / LPG;                      /* columns per wavefront */
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
-    const int g = lane >> 4, l = lane & 15;
-    const int64_t stride = (int64_t)gridDim.x * 16;
+    const int g = lane / LPG, l = lane % LPG;
+    const int64_t stride = (int64_t)gridDim.x * 4 * G;
     const bool same_thr = (P.min_alt_bq4 == P.min_bq4);
     const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
     const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
-    for (int64_t colb = c0 + ((int64_t)blockIdx.x * 4 + wave) * 4; colb < c1; colb += stride) {
+    for (int64_t colb = c0 + ((int64_t)blockIdx.x * 4 + wave) * G; colb < c1; colb += stride) {
         const int64_t col = colb + g;
         const bool valid = col < c1;
-        const uint64_t off0 = valid ? T.col_off[col] : 0, off1 = valid ? T.col_off[col + 1] : 0;
+        /* the column's header in one round trip: every load is issued before the first one is waited for (the lanes past
+         * the end read the last column's: no branch around a load) */
+        const int64_t colc = valid ? col : c1 - 1;
+        const uint64_t o0 = T.col_off[colc], o1 = T.col_off[colc + 1];
+        const int cov_h = T.coverage_plp ? T.coverage_plp[colc] : 0;
+        const int nb_h = T.num_bases ? T.num_bases[colc] : 0;
+        const uint32_t rb_h = T.ref_base[colc];
+        const uint64_t off0 = valid ? o0 : 0, off1 = valid ? o1 : 0;
         const int64_t n_obs = (int64_t)(off1 - off0);
-        const int cov = (valid && T.coverage_plp) ? T.coverage_plp[col] : (int)n_obs;
-        const int nb = (valid && T.num_bases) ? T.num_bases[col] : (int)n_obs;
-        const uint32_t rb = valid ? T.ref_base[col] : 'N';
+        const int cov = (valid && T.coverage_plp) ? cov_h : (int)n_obs;
+        const int nb = (valid && T.num_bases) ? nb_h : (int)n_obs;
+        const uint32_t rb = valid ? rb_h : 'N';
         const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
         lfq_col_counts r;
         r.n_err_probs = 0;
@@ -284,12 +295,12 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
         }
         if (valid && !r.gated) {
             if (same_thr) {
-                lfq_count_chunks<true, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4, l, 16);
+                lfq_count_chunks<true, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4, l, LPG);
             } else {
-                lfq_count_chunks<false, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4, l, 16);
+                lfq_count_chunks<false, PACKED, STRAND>(a, T, off0, off1, minbq4, minalt4, l, LPG);
             }
         }
-        /* sums over the 16 lanes of the group (every lane of the wavefront takes part) */
+        /* sums over the LPG lanes of the group (every lane of the wavefront takes part) */
         uint32_t n_raw[4], n_fw[4], n_ge[4], n_ga[4], raw[4], fw[4], c_ge[4], c_ga[4], filt[4];
 #pragma unroll
         for (int x = 0; x < 4; x++) {
@@ -297,18 +308,12 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
             n_fw[x] = a.fw[x];
             n_ge[x] = a.ge[x];
             n_ga[x] = a.ga[x];
-#pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) {
-                n_raw[x] += (uint32_t)__shfl_xor((int)n_raw[x], d, 64);
-                n_fw[x] += (uint32_t)__shfl_xor((int)n_fw[x], d, 64);
-                n_ge[x] += (uint32_t)__shfl_xor((int)n_ge[x], d, 64);
-                if (!same_thr) {
-                    n_ga[x] += (uint32_t)__shfl_xor((int)n_ga[x], d, 64);
-                }
+            n_raw[x] = lfq_group_sum_u32<LPG>(n_raw[x]);
+            if (STRAND) {
+                n_fw[x] = lfq_group_sum_u32<LPG>(n_fw[x]);
             }
-            if (same_thr) {
-                n_ga[x] = n_ge[x];
-            }
+            n_ge[x] = lfq_group_sum_u32<LPG>(n_ge[x]);
+            n_ga[x] = same_thr ? n_ge[x] : lfq_group_sum_u32<LPG>(n_ga[x]);
         }
         lfq_planes_to_classes(n_raw, raw);
         lfq_planes_to_classes(n_fw, fw);
@@ -875,16 +880,27 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
     }
     const int64_t multi_below = lfq_knobs().count_multi_below;   /* deepest column of the batch below this: four columns per wavefront */
     if (!p.general && !p.detlim_af && max_col_obs > 0 && max_col_obs < multi_below) {
-        const unsigned blocks = (unsigned)((c1 - c0 + 15) / 16);
-#define LFQ_LAUNCH_MULTI(PK, ST)                                                                                     \
-        hipLaunchKernelGGL((lfq_count_multi_kernel<PK, ST>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,      \
+        /* lanes per column by the deepest column of the batch: each lane takes chunks of 16 observations */
+        const LfqKnobs &kn = lfq_knobs();
+        const int lpg = max_col_obs <= kn.count_lpg4_below ? 4 : max_col_obs <= kn.count_lpg8_below ? 8 : 16;
+        const int64_t per_block = 4 * (64 / lpg);
+        const unsigned blocks = (unsigned)((c1 - c0 + per_block - 1) / per_block);
+#define LFQ_LAUNCH_MULTI_L(PK, ST, L)                                                                                \
+        hipLaunchKernelGGL((lfq_count_multi_kernel<PK, ST, L>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p,  \
                            d_counts, d_flags, c0, c1)
+#define LFQ_LAUNCH_MULTI(PK, ST)                                                                                     \
+        do {                                                                                                         \
+            if (lpg == 4) LFQ_LAUNCH_MULTI_L(PK, ST, 4);                                                             \
+            else if (lpg == 8) LFQ_LAUNCH_MULTI_L(PK, ST, 8);                                                        \
+            else LFQ_LAUNCH_MULTI_L(PK, ST, 16);                                                                     \
+        } while (0)
         const bool strand_m = !p.lazy_strand;
         if (t.nt_packed) {
             if (strand_m) LFQ_LAUNCH_MULTI(true, true); else LFQ_LAUNCH_MULTI(true, false);
         } else {
             if (strand_m) LFQ_LAUNCH_MULTI(false, true); else LFQ_LAUNCH_MULTI(false, false);
         }
+#undef LFQ_LAUNCH_MULTI_L
 #undef LFQ_LAUNCH_MULTI
         LFQ_HIP_TRY(hipGetLastError());
         return LFQ_OK;
