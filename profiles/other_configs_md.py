@@ -8,9 +8,13 @@ NAMES = ["C2 (10^6 columns x 1000)", "C5 shard (3.75 x 10^6 columns x 200)", "C4
          "--mode chain (regions of 2 M reads x 150 bp -> VCF, --call-indels, BAQ on; 1 step = 1 region)",
          "--mode chain --workers 2 (two region workers = processes on the one GPU)",
          "--mode chain --workers 3", "--mode baq (400 K reads x 150 bp)"]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+if rnd != "r02":            # round 3 on: one more chain line (one worker, regions overlapped) and the IDAQ run of --mode baq
+    NAMES = NAMES[:5] + ["--mode chain --overlap-regions (one worker; region k + 1 started before region k is finished)"] \
+            + NAMES[5:] + ["--mode baq --idaq"]
 lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
-print("# bench.py on the other configurations (1 MI355X; round 2).  C2 / depth 200 / depth 500: --steps 60 --warmup 5 --no-cpu-baseline --no-pmc")
-print("# --no-secondary, pipelined two-context loop; host-abi, chain, baq: the --mode runs.  The headline configuration (C3) is in r02_bench_line.json.")
+print("# bench.py on the other configurations (1 MI355X; round %s).  C2 / depth 200 / depth 500: --steps 60 --warmup 5 --no-cpu-baseline --no-pmc" % rnd[1:].lstrip("0"))
+print("# --no-secondary, pipelined two-context loop; host-abi, chain, baq: the --mode runs.  The headline configuration (C3) is in %s_bench_line.json." % rnd)
 print()
 print("| run | ms/step | value | count ms | scan ms | DP ms (light / mid / big chains) |")
 print("|---|---|---|---|---|---|")

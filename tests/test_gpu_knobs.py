@@ -28,6 +28,10 @@ CASES = [
     ("LFQ_SINGLE_STREAM=1", DP),             # every kernel on one stream (what the counter passes run)
     ("LFQ_NO_SB_PRECOMPUTE=1", DP),          # strand bias computed at collect time only
     ("LFQ_COUNT_MULTI_BELOW=0", DP),         # shallow batches on the one-column-per-wavefront count kernel
+    ("LFQ_COUNT_LPG4_BELOW=100000", DP),     # shared-wavefront count kernel: four lanes per column whatever the depth
+    ("LFQ_COUNT_LPG8_BELOW=100000", DP),     # ... eight (and four for the shallowest batches)
+    ("LFQ_COUNT_LPG4_BELOW=0", DP),          # ... never four
+    ("LFQ_CU_SPLIT=64", DP),                 # DP streams and main stream on disjoint CU masks
     ("LFQ_BAQ_KERNEL=1", BAQ),               # the LDS-row BAQ kernel
     ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
     ("LFQ_PILEUP_ATOMIC=1", PLP),            # read-major pileup kernels (what unsorted reads get)
