@@ -90,6 +90,9 @@ def parse_args():
     ap.add_argument("--overlap-regions", action="store_true",
                     help="--mode chain, one worker: start region k + 1 (upload, BAQ kernels) before the pileups and calls of "
                          "region k, as integration/lofreq_amd_region.c does")
+    ap.add_argument("--pageable", action="store_true",
+                    help="--mode chain, one worker: the caller's read arrays in pageable memory (default: the per-base arrays "
+                         "pinned, as the region binding keeps them)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed blocks of --steps steps: the first one is the reported value, all of them go into `repeats`")
     ap.add_argument("--no-full-check", action="store_true",
@@ -381,13 +384,22 @@ def bench_baq(caller, la, n_reads, glen, iters, want_idaq=False):
                     "set; kernel time alone: profiles/r02_baq_stats.md"}
 
 
-def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrier=None, overlap=False):
+def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrier=None, overlap=False, pinned=True):
     """reads -> BAQ (+ IDAQ) -> device pileup(s) -> SNV (+ indel) calls on a resident read set: the reference's
     `lofreq call [--call-indels]` with BAQ on (BASELINE.md end-to-end rows), everything after BAM decoding."""
     import ctypes as C
     from lofreq_amd import _lib
     from lofreq_amd.pileup import DeviceTracks
     R = make_reads(n_reads, glen)
+    if pinned:
+        # what integration/lofreq_amd_region.c does with its per-base arrays (lfq_host_alloc): the copies of
+        # lfq_readset_create are then DMA transfers queued at once, and the BAQ kernels -- not this thread -- wait for them
+        import torch
+        keep = {}
+        for k in ("seq", "qual", "bi", "bd"):
+            keep[k] = torch.from_numpy(R[k]).pin_memory()
+            R[k] = keep[k].numpy()
+        R["_pinned"] = keep
     L = _lib.load()
     vp = C.c_void_p
     pr = _lib.PileupReads()
@@ -504,6 +516,7 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
                  "reads_per_s": n_reads / best["s_total"], "columns_per_s": best["columns"] / best["s_total"],
                  "call_indels": bool(call_indels),
                  "regions_overlapped": bool(overlap),
+                 "caller_arrays": "pinned (bases, qualities, BI, BD)" if pinned else "pageable",
                  "note": "resident read set; BAM decoding (htslib, CPU) not included; reference end-to-end rows "
                          "(BASELINE.md 2): 6736 cols/s without BAQ, 1334 cols/s with BAQ, one CPU thread"})
     return best
@@ -672,7 +685,7 @@ def main():
             res = chain_workers(args.workers, iters)
             per_region = res["s_per_region"]
         else:
-            res = bench_chain(caller, la, 2000000, 1000000, iters, overlap=args.overlap_regions)
+            res = bench_chain(caller, la, 2000000, 1000000, iters, overlap=args.overlap_regions, pinned=not args.pageable)
             caller.close()
             per_region = res["s_mean"]               # mean over the timed regions (s_total: the fastest one, by step)
             res["columns_per_s_best"] = res["columns_per_s"]

@@ -7,17 +7,31 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct { void *p; int64_t n, cap; size_t elt; } rvec;
+/* The per-base arrays of a region (bases, qualities, BI, BD: 150 bytes per read each) live in pinned memory
+ * (lfq_host_alloc): lfq_readset_create then queues their copies as DMA transfers and returns, the BAQ kernels wait for the
+ * chunks they need on the device, and this thread goes on decoding the next region instead of sitting out the upload
+ * (grow-only, so the cost of pinning is paid in the first regions). */
+typedef struct { void *p; int64_t n, cap; size_t elt; int pinned; } rvec;
 
 static int rv_reserve(rvec *v, int64_t more)
 {
     if (v->n + more > v->cap) {
-        int64_t c = v->cap ? v->cap : 4096;
+        int64_t c = v->cap ? v->cap : (v->pinned ? (int64_t)1 << 22 : 4096);
         void *q;
         while (v->n + more > c) {
             c *= 2;
         }
-        q = realloc(v->p, (size_t)c * v->elt);
+        if (v->pinned) {
+            q = lfq_host_alloc((size_t)c * v->elt);
+            if (q && v->n > 0) {
+                memcpy(q, v->p, (size_t)v->n * v->elt);
+            }
+            if (q) {
+                lfq_host_free(v->p);
+            }
+        } else {
+            q = realloc(v->p, (size_t)c * v->elt);
+        }
         if (!q) {
             return LFQ_ERR_NOMEM;
         }
@@ -81,6 +95,7 @@ static void buf_init(reg_buf *b)
     b->cig_off.elt = b->seq_off.elt = sizeof(int64_t);
     b->cig.elt = sizeof(uint32_t);
     b->seq.elt = b->qual.elt = b->mapq.elt = b->rev.elt = b->bi.elt = b->bd.elt = b->flags.elt = 1;
+    b->seq.pinned = b->qual.pinned = b->bi.pinned = b->bd.pinned = 1;
 }
 
 static void buf_free(reg_buf *b)
@@ -88,7 +103,11 @@ static void buf_free(reg_buf *b)
     rvec *all[] = {&b->pos, &b->cig_off, &b->cig, &b->seq_off, &b->seq, &b->qual, &b->mapq, &b->rev, &b->bi, &b->bd, &b->flags};
     size_t i;
     for (i = 0; i < sizeof(all) / sizeof(all[0]); i++) {
-        free(all[i]->p);
+        if (all[i]->pinned) {
+            lfq_host_free(all[i]->p);
+        } else {
+            free(all[i]->p);
+        }
     }
     free(b->target);
     free(b->col_pos_s);

@@ -92,12 +92,26 @@ struct lfq_readset {
     int up_nchunks;
     std::atomic<int> up_rc;        /* written by the helper thread at the end of each stage */
     LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
+    /* Pinned caller arrays (lfq_host_alloc): the copies are DMA transfers queued by lfq_readset_create itself, and what
+     * waits for them is a STREAM, not the host -- events instead of the helper thread's progress counters */
+    bool up_events;
+    hipEvent_t ev_chunk[4];             /* bases + qualities of the reads up to chunk j have landed */
+    hipEvent_t ev_stage[2];             /* [0]: everything but BI / BD, [1]: all of it */
 };
 
 /* the reads, qualities, CIGARs and the contig are on the device (BI / BD may still be on their way: the BAQ kernels do
- * not read them, and 600 of the 1300 MB of a 2 M-read region then cross PCIe under those kernels) */
-static int readset_upload_wait_inputs(lfq_readset *rs)
+ * not read them, and 600 of the 1300 MB of a 2 M-read region then cross PCIe under those kernels).  Every one of the three
+ * waits below makes the given stream(s) wait when the uploads are tracked by events, and the host otherwise. */
+static int readset_upload_wait_inputs(lfq_readset *rs, std::initializer_list<hipStream_t> streams)
 {
+    if (rs && rs->up_events) {
+        for (hipStream_t st : streams) {
+            if (st && hipStreamWaitEvent(st, rs->ev_stage[0], 0) != hipSuccess) {
+                return LFQ_ERR_HIP;
+            }
+        }
+        return LFQ_OK;
+    }
     if (rs && rs->up_thread) {
         while (rs->up_stage.load(std::memory_order_acquire) < 1) {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -109,12 +123,15 @@ static int readset_upload_wait_inputs(lfq_readset *rs)
 
 /* ... and for a launch over the reads up to (and including) r_last: the small arrays and the chunks of bases and
  * qualities that hold them */
-static int readset_upload_wait_reads(lfq_readset *rs, int64_t r_last)
+static int readset_upload_wait_reads(lfq_readset *rs, int64_t r_last, hipStream_t st)
 {
-    if (rs && rs->up_thread) {
+    if (rs && (rs->up_thread || rs->up_events)) {
         int need = 1;
         while (need < rs->up_nchunks && rs->n * need / rs->up_nchunks <= r_last) {
             need++;
+        }
+        if (rs->up_events) {
+            return hipStreamWaitEvent(st, rs->ev_chunk[need - 1], 0) == hipSuccess ? (int)LFQ_OK : (int)LFQ_ERR_HIP;
         }
         while (rs->up_chunks.load(std::memory_order_acquire) < need) {
             std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -123,8 +140,17 @@ static int readset_upload_wait_reads(lfq_readset *rs, int64_t r_last)
     return rs ? rs->up_rc.load() : (int)LFQ_OK;
 }
 
-static int readset_upload_wait(lfq_readset *rs)
+/* all of it.  st = null: the host waits (and the pinned flag bytes go back to the pool) */
+static int readset_upload_wait(lfq_readset *rs, hipStream_t st = nullptr)
 {
+    if (rs && rs->up_events) {
+        if (st) {
+            return hipStreamWaitEvent(st, rs->ev_stage[1], 0) == hipSuccess ? (int)LFQ_OK : (int)LFQ_ERR_HIP;
+        }
+        if (hipEventSynchronize(rs->ev_stage[1]) != hipSuccess) {
+            return LFQ_ERR_HIP;
+        }
+    }
     if (rs && rs->up_thread) {
         rs->up_thread->join();
         delete rs->up_thread;
@@ -135,6 +161,21 @@ static int readset_upload_wait(lfq_readset *rs)
         rs->up_fl = nullptr;
     }
     return rs ? rs->up_rc.load() : (int)LFQ_OK;
+}
+
+/* is `p` pinned (or registered) host memory?  The runtime copies from such memory by DMA and hipMemcpyAsync returns at once */
+static bool lfq_is_pinned(const void *p)
+{
+    if (!p) {
+        return true;                        /* nothing to copy */
+    }
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();            /* plain malloc'ed memory: an error, by design of that call */
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
 }
 
 /* the host side of an lfq_readset_baq that is still running: merged tag flags (bit 0 BI, 1 BD, 2 ai, 3 ad) into rs->fl */
@@ -160,6 +201,9 @@ void lfq_readset_destroy(lfq_readset *rs)
         (void)readset_baq_wait(rs);
         if (rs->ev_baq) (void)hipEventDestroy(rs->ev_baq);
         (void)hipStreamSynchronize(rs->c->stream);      /* nothing queued may still use what goes back to the cache */
+        for (hipEvent_t e : {rs->ev_chunk[0], rs->ev_chunk[1], rs->ev_chunk[2], rs->ev_chunk[3], rs->ev_stage[0], rs->ev_stage[1]}) {
+            if (e) (void)hipEventDestroy(e);
+        }
         rs_cache_give(rs->c, LFQ_RSC_PINFL, rs->h_fl_pin, rs->cap[LFQ_RSC_PINFL]);
         rs_cache_give(rs->c, LFQ_RSC_TAGFL, rs->d_tagfl, rs->cap[LFQ_RSC_TAGFL]);
         rs_cache_give(rs->c, LFQ_RSC_BLOB, rs->blob, rs->cap[LFQ_RSC_BLOB]);
@@ -315,7 +359,48 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
         rs->up_stage.store(2, std::memory_order_release);
     };
     const int up_mode = lfq_knobs().sync_upload;        /* 0: helper thread from 8 MB on, 1: never, 2: always */
-    if (up_mode == 2 || (up_bytes >= ((int64_t)8 << 20) && up_mode == 0)) {
+    if (up_mode == 0 && up_bytes >= ((int64_t)8 << 20) && lfq_is_pinned(rd->seq) && lfq_is_pinned(rd->qual)
+        && lfq_is_pinned(rs->h_bi) && lfq_is_pinned(rs->h_bd)) {
+        /* the big arrays are pinned: every copy is queued right here (the small pageable ones, if any, are staged by the
+         * runtime inside the call), events mark the stages, and nothing on the host ever waits for the link */
+        int rc = LFQ_OK;
+        for (int j = 0; j < 6 && rc == LFQ_OK; j++) {
+            hipEvent_t *e = j < 4 ? &rs->ev_chunk[j] : &rs->ev_stage[j - 4];
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        }
+        bool stage0_done = false;
+        for (const Copy &x : todo) {
+            if (rc == LFQ_OK && hipMemcpyAsync(x.dst, x.src, (size_t)x.bytes, hipMemcpyHostToDevice, ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (rc == LFQ_OK && x.chunks_after && hipEventRecord(rs->ev_chunk[x.chunks_after - 1], ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (rc == LFQ_OK && x.stage_after && hipEventRecord(rs->ev_stage[x.stage_after - 1], ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (rc == LFQ_OK && x.stage_after == 2 && !stage0_done && hipEventRecord(rs->ev_stage[0], ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;           /* (no BI / BD: the last copy ends both stages) */
+            }
+            stage0_done = stage0_done || x.stage_after != 0;
+        }
+        for (int j = n_chunks; j < 4 && rc == LFQ_OK; j++) {       /* fewer chunks than events: the unused ones are the last one */
+            if (hipEventRecord(rs->ev_chunk[j], ups) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+        }
+        if (rc != LFQ_OK) {
+            (void)hipStreamSynchronize(ups);
+            lfq_readset_destroy(rs);
+            return rc;
+        }
+        rs->up_events = true;
+        rs->up_rc = LFQ_OK;
+        rs->up_chunks.store(n_chunks, std::memory_order_release);
+        rs->up_stage.store(2, std::memory_order_release);
+    } else if (up_mode == 2 || (up_bytes >= ((int64_t)8 << 20) && up_mode == 0)) {
         rs->up_thread = new std::thread(run);           /* readset_upload_wait joins it */
     } else {
         run();
@@ -760,7 +845,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             Ap.tag_flags = nullptr;
             for (int64_t first = 0; rc == LFQ_OK && first < n_plain; first += waves_n * 64) {
                 const int64_t cnt = std::min<int64_t>(waves_n * 64, n_plain - first);
-                rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)]);
+                rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
                 Ap.first_read = (int32_t)first;
                 if (rc == LFQ_OK) {
                     rc = lfq_launch_baq(Ap, cnt, 1, c->stream);
@@ -768,7 +853,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             }
         }
         if (rc == LFQ_OK) {
-            rc = readset_upload_wait_inputs(rs);
+            rc = readset_upload_wait_inputs(rs, {c->stream, c->side[0], c->side[1]});
         }
         if (beside) {
             /* wide-band and band-8 reads on the side streams, beside the narrow-band launches; c->stream ends after them */
@@ -878,7 +963,7 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
         return LFQ_OK;
     }
     LFQ_TRY_HIP(hipSetDevice(c->device));
-    LFQ_TRY(readset_upload_wait(rs));
+    LFQ_TRY(readset_upload_wait(rs, c->stream));
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
     /* per-position counters (kept until the next call) */
     const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
@@ -1180,11 +1265,12 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
     } else {
         /* 2. dense counters on the device */
         LFQ_TRY_HIP(hipSetDevice(c->device));
-        LFQ_TRY(readset_upload_wait(rs));
         /* Steps 2 and 3 read nothing lfq_readset_baq writes (of the flag bytes only the BI / BD bits, which its merge
          * kernel leaves as they are): while its kernels are still running they go to another stream and run beside them --
          * the BAQ kernels hold one wavefront per SIMD and 416 of its 512 registers, these kernels need 40. */
         hipStream_t ps = (rs->baq_pending && c->dps && !lfq_knobs().single_stream) ? c->dps : c->stream;
+        (void)readset_pmax(c, rs, ps);      /* (its small upload is waited for on this stream: before the stream itself waits) */
+        LFQ_TRY(readset_upload_wait(rs, ps));
         auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
         const int64_t o_cnt = 0, o_cur = o_cnt + 9 * al(width * 4), o_off = o_cur + 2 * al(width * 4),
                       total = o_off + 2 * al(width * 8);
