@@ -65,6 +65,7 @@ const LfqKnobs &lfq_knobs(void)
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);
+        x.pileup_tiles = (int)geti("LFQ_PILEUP_TILES", 1);
         x.count_lpg4_below = geti("LFQ_COUNT_LPG4_BELOW", 320);
         x.count_lpg8_below = geti("LFQ_COUNT_LPG8_BELOW", 900);
         x.cu_split = (int)std::max(0L, geti("LFQ_CU_SPLIT", 0));

@@ -379,8 +379,309 @@ __global__ __launch_bounds__(256) void lfq_pileup_columns_kernel(LfqPileupArgs A
     }
 }
 
+/* ---- the same two passes, a TILE of 64 positions per workgroup -----------------------------------------------------
+ * The column-major kernel above fetches the three per-base bytes of every (read, position) pair with byte gathers: 64
+ * lanes = 64 reads = 64 cache lines per load instruction, and the texture path handles a line per cycle -- for the 3 x 10^8
+ * pairs of a 1 Mb x 300x region that alone is 1.5 ms per CU, and the CIGAR of a read is resolved once per position it
+ * covers.  Here a workgroup owns 64 consecutive positions.  Its reads -- the window from the first read that can reach the
+ * tile to the last one that starts inside it, 256 at a time -- are resolved ONCE against the tile (phase A, a read per
+ * thread): which of the 64 positions it covers with a base, which with a deleted / skipped position (two 64-bit masks),
+ * and the stretch of the query those positions map to as aligned 16-byte words into LDS -- up to six loads per track
+ * instead of 64 byte loads.  One indel inside the tile is part of this (two stretches: the row holds the query range from
+ * the first base to the last, and the positions behind the indel use a second offset); two or more, or an insertion too
+ * long for the row, are resolved per position as before (one pair in 10^4).  Phase B is the column-major kernel's inner
+ * loop (a wavefront per position, lanes = reads in read order, ballot + rank), reading its bytes from LDS: no load is
+ * issued between its stores, so nothing waits for them (vmcnt counts loads and stores in one order).  Same order of the
+ * observations, same bytes. */
+#define LFQ_TILE 64
+#define LFQ_TILE_ROW 100        /* bytes of LDS per read and track: 6 aligned 16-byte words + 4 (25 dwords: conflict-free rows) */
+
+/* what phase A finds out about one read against one tile */
+struct LfqTileRead {
+    unsigned long long cm, dm;  /* positions covered with a base / with a deleted or skipped position */
+    int nseg;                   /* stretches of the query the covered positions map to */
+    int off0, off1, split;      /* row byte of position p0 + dp: off0 + dp below `split`, off1 + dp from there on */
+    int nw;                     /* aligned 16-byte words to fetch per track (0: none, or position by position) */
+    int64_t a0;                 /* index of the first of them in the per-base arrays */
+    bool slow;                  /* two indels inside the tile, or an insertion too long for the row */
+};
+
+__device__ __forceinline__ LfqTileRead lfq_tile_resolve(const uint32_t *cg, int nc, int64_t x, int64_t s0, int64_t p0, int tile)
+{
+    LfqTileRead R;
+    R.cm = R.dm = 0;
+    R.off0 = R.off1 = 0;
+    R.split = 64;
+    R.nw = 0;
+    R.a0 = 0;
+    R.slow = false;
+    int y = 0, nseg = 0, q1 = 0, p1 = 0, q2 = 0, p2 = 0, n2 = 0, n1 = 0;
+    for (int k = 0; k < nc && x < p0 + tile; ++k) {
+        const int op = cg[k] & 0xf, l = cg[k] >> 4;
+        if (op == 0 || op == 7 || op == 8 || op == 2 || op == 3) {
+            const int64_t a = x > p0 ? x : p0, b = (x + l < p0 + tile) ? x + l : p0 + tile;
+            if (a < b) {
+                const int n = (int)(b - a), sh = (int)(a - p0);
+                const unsigned long long m = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << sh;
+                if (op == 2 || op == 3) {
+                    R.dm |= m;
+                } else {
+                    const int q = y + (int)(a - x);
+                    R.cm |= m;
+                    if (nseg == 0) {
+                        q1 = q; p1 = sh; n1 = n;
+                        nseg = 1;
+                    } else if (nseg == 1 && q == q1 + n1 && sh == p1 + n1) {
+                        n1 += n;                                /* M next to = / X: the same stretch goes on */
+                    } else if (nseg == 1) {
+                        q2 = q; p2 = sh; n2 = n;
+                        nseg = 2;
+                    } else if (nseg == 2 && q == q2 + n2 && sh == p2 + n2) {
+                        n2 += n;
+                    } else {
+                        nseg++;
+                    }
+                }
+            }
+            x += l;
+            if (op != 2 && op != 3) {
+                y += l;
+            }
+        } else if (op == 1 || op == 4) {
+            y += l;
+        }
+    }
+    R.nseg = nseg;
+    if (nseg == 1 || nseg == 2) {
+        const int64_t g0 = s0 + q1;
+        R.a0 = g0 & ~(int64_t)15;
+        const int span = nseg == 1 ? n1 : (q2 + n2 - q1);       /* query bytes from the first base to the last */
+        R.nw = (int)((g0 - R.a0) + span + 15) >> 4;
+        R.off0 = (int)(g0 - R.a0) - p1;
+        R.off1 = nseg == 1 ? R.off0 : (int)(g0 - R.a0) + (q2 - q1) - p2;
+        R.split = nseg == 1 ? 64 : p2;
+    }
+    if (nseg > 2 || R.nw > 6) {
+        R.slow = true;
+        R.nw = 0;
+        R.off0 = R.off1 = 0;                                    /* the row is indexed by the position itself */
+        R.split = 64;
+    }
+    return R;
+}
+
+/* six aligned words of one per-base array into a read's row (words past the stretch repeat its last word: no branch
+ * around a load, and every load is issued before the first LDS write waits for one) */
+__device__ __forceinline__ void lfq_tile_fetch(uint32_t *row, const uint8_t *src, int64_t a0, int nw)
+{
+    uint4 w[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        w[j] = *reinterpret_cast<const uint4 *>(src + a0 + 16 * (j < nw ? j : nw - 1));
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        row[4 * j + 0] = w[j].x; row[4 * j + 1] = w[j].y; row[4 * j + 2] = w[j].z; row[4 * j + 3] = w[j].w;
+    }
+}
+
+/* the same for two arrays at once */
+__device__ __forceinline__ void lfq_tile_fetch2(uint32_t *row_a, const uint8_t *src_a, uint32_t *row_b, const uint8_t *src_b,
+                                                int64_t a0, int nw)
+{
+    uint4 wa[6], wb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int64_t o = a0 + 16 * (j < nw ? j : nw - 1);
+        wa[j] = *reinterpret_cast<const uint4 *>(src_a + o);
+        wb[j] = *reinterpret_cast<const uint4 *>(src_b + o);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        row_a[4 * j + 0] = wa[j].x; row_a[4 * j + 1] = wa[j].y; row_a[4 * j + 2] = wa[j].z; row_a[4 * j + 3] = wa[j].w;
+        row_b[4 * j + 0] = wb[j].x; row_b[4 * j + 1] = wb[j].y; row_b[4 * j + 2] = wb[j].z; row_b[4 * j + 3] = wb[j].w;
+    }
+}
+
+/* Count pass: 256 reads per round, a read per thread.  Scatter pass: three tracks per read, so 128 reads per round (38 KB of
+ * LDS: four workgroups per CU) with two threads per read -- one fetches the qualities and publishes the masks, the other the
+ * bases and the BAQ bytes. */
+template <bool SCATTER, int RC>
+__global__ __launch_bounds__(256) void lfq_pileup_tiles_kernel(LfqPileupArgs A)
+{
+    constexpr int NTR = SCATTER ? 3 : 1;                            /* qual (+ seq, baq) */
+    __shared__ uint32_t s_raw[NTR][RC][LFQ_TILE_ROW / 4];
+    __shared__ unsigned long long s_cm[RC], s_dm[RC];
+    __shared__ int16_t s_off0[RC], s_off1[RC];
+    __shared__ uint8_t s_split[RC];
+    __shared__ uint8_t s_mq[RC], s_rev[RC], s_sq[RC];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * LFQ_TILE;
+    if (c0 >= A.width) {
+        return;
+    }
+    const int64_t p0 = A.begin + c0;
+    const int tile = (int)((A.width - c0 < LFQ_TILE) ? (A.width - c0) : LFQ_TILE);     /* positions of this tile */
+    /* window [lo, hi): first read with pmax_end > p0 ... first read with pos > the tile's last position */
+    const int64_t lo = lfq_wave_first_above(A.pmax_end, 0, A.n_reads, p0, lane);
+    const int64_t hi = lfq_wave_first_above(A.pos, lo, A.n_reads, p0 + tile - 1, lane);
+    /* the 16 positions of this wavefront: running counts, and for the scatter pass the column's slice */
+    uint32_t n_cov[16], n_kept[16];
+    uint64_t base[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        n_cov[i] = n_kept[i] = 0;
+        base[i] = ~0ull;
+    }
+    if (SCATTER) {
+        int ci = -1;
+        unsigned long long b = ~0ull;
+        if (lane < 16 && wave * 16 + lane < tile) {
+            ci = A.col_index[c0 + wave * 16 + lane];
+            if (ci >= 0) {
+                b = A.col_off[ci];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            base[i] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), i) << 32)
+                      | (uint32_t)__builtin_amdgcn_readlane((int)(b & 0xffffffffull), i);
+        }
+    }
+    const int rt = tid & (RC - 1);                                  /* this thread's read of the round */
+    const bool first = tid < RC;                                    /* fetches the qualities and publishes the masks; the other: bases and BAQ bytes */
+    for (int64_t r0 = lo; r0 < hi; r0 += RC) {
+        /* ---- phase A: every read of the round against the tile ---- */
+        {
+            const int64_t r = r0 + rt;
+            LfqTileRead R;
+            R.cm = R.dm = 0;
+            R.off0 = R.off1 = 0;
+            R.split = 64;
+            if (r < hi) {
+                const int64_t co = A.cigar_off[r], s0 = A.seq_off[r];
+                const int nc = (int)(A.cigar_off[r + 1] - co);
+                const uint32_t *cg = A.cigar + co;
+                R = lfq_tile_resolve(cg, nc, A.pos[r], s0, p0, tile);
+                if (R.nw > 0) {
+                    if (first) {
+                        lfq_tile_fetch(&s_raw[0][rt][0], A.qual, R.a0, R.nw);
+                    } else if (A.baq) {
+                        lfq_tile_fetch2(&s_raw[NTR > 1 ? 1 : 0][rt][0], A.seq, &s_raw[NTR > 2 ? 2 : 0][rt][0], A.baq, R.a0, R.nw);
+                    } else {
+                        lfq_tile_fetch(&s_raw[NTR > 1 ? 1 : 0][rt][0], A.seq, R.a0, R.nw);
+                    }
+                } else if (R.slow) {
+                    /* position by position, here: phase B must not issue a load (see above) */
+                    uint8_t *wq = reinterpret_cast<uint8_t *>(&s_raw[0][rt][0]);
+                    uint8_t *ws = reinterpret_cast<uint8_t *>(&s_raw[NTR > 1 ? 1 : 0][rt][0]);
+                    uint8_t *wb = reinterpret_cast<uint8_t *>(&s_raw[NTR > 2 ? 2 : 0][rt][0]);
+                    for (int dp = 0; dp < tile; dp++) {
+                        if ((R.cm >> dp) & 1ull) {
+                            int qpos = 0;
+                            (void)lfq_plp_locate(cg, nc, A.pos[r], p0 + dp, &qpos);
+                            if (first) {
+                                wq[dp] = A.qual[s0 + qpos];
+                            } else {
+                                ws[dp] = A.seq[s0 + qpos];
+                                if (A.baq) {
+                                    wb[dp] = A.baq[s0 + qpos];
+                                }
+                            }
+                        }
+                    }
+                }
+                if (SCATTER && first && R.cm) {
+                    s_mq[rt] = A.mapq[r];
+                    s_rev[rt] = A.reverse[r] ? 8 : 0;
+                    s_sq[rt] = A.sq ? A.sq[r] : 0;
+                }
+            }
+            if (first) {
+                s_cm[rt] = R.cm;
+                s_dm[rt] = R.dm;
+                s_off0[rt] = (int16_t)R.off0;
+                s_off1[rt] = (int16_t)R.off1;
+                s_split[rt] = (uint8_t)R.split;
+            }
+        }
+        __syncthreads();
+        /* ---- phase B: a wavefront per position, lanes = the reads of a 64-read slice in read order ---- */
+        const int n_here = (int)((hi - r0 < RC) ? (hi - r0) : RC);
+        for (int sc = 0; sc * 64 < n_here; sc++) {
+            const int t = sc * 64 + lane;
+            const unsigned long long cm = s_cm[t], dm = s_dm[t];
+            if (__ballot((cm | dm) != 0) == 0) {
+                continue;
+            }
+            const int off0 = s_off0[t], off1 = s_off1[t], split = s_split[t];
+            const uint8_t *rq = reinterpret_cast<const uint8_t *>(&s_raw[0][t][0]);
+            const uint8_t *rs = reinterpret_cast<const uint8_t *>(&s_raw[NTR > 1 ? 1 : 0][t][0]);
+            const uint8_t *rb = reinterpret_cast<const uint8_t *>(&s_raw[NTR > 2 ? 2 : 0][t][0]);
+            uint32_t mq = 0, rev = 0, sq = 0;
+            if (SCATTER) {
+                mq = s_mq[t]; rev = s_rev[t]; sq = s_sq[t];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int dp = wave * 16 + i;
+                const bool covered = (cm >> dp) & 1ull;
+                const bool any = covered || ((dm >> dp) & 1ull);
+                const int off = dp < split ? off0 : off1;
+                int bq = 0;
+                if (covered) {
+                    bq = rq[off + dp];
+                }
+                const bool kept = covered && bq >= A.min_plp_bq;
+                const uint64_t mk = __ballot(kept);
+                if (!SCATTER) {
+                    n_cov[i] += (uint32_t)__popcll(__ballot(any));
+                } else if (kept) {
+                    const uint64_t slot = base[i] + n_kept[i] + (uint64_t)__popcll(mk & ((1ull << lane) - 1ull));
+                    const uint32_t code = rs[off + dp];
+                    const uint32_t lb = A.baq ? rb[off + dp] : 0u;
+#ifdef LFQ_TILES_NO_STORE       /* timing experiments only: the values still have to be computed */
+                    if (slot == 0x7fffffffffffffffull) {
+#endif
+                    A.t_nt[slot] = (uint8_t)((code > 4 ? 4u : code) | rev);
+                    A.t_bq[slot] = (uint8_t)(bq > 93 ? 93 : bq);                                   /* plp.c:948-952 */
+                    A.t_baq[slot] = A.baq ? (uint8_t)(lb >= 33 ? lb - 33 : 255) : (uint8_t)255;
+                    A.t_mq[slot] = (uint8_t)mq;
+                    if (A.t_sq) {
+                        A.t_sq[slot] = (uint8_t)sq;
+                    }
+#ifdef LFQ_TILES_NO_STORE
+                    }
+#endif
+                }
+                n_kept[i] += (uint32_t)__popcll(mk);
+            }
+        }
+        __syncthreads();
+    }
+    if (!SCATTER && lane < 16 && wave * 16 + lane < tile) {
+        uint32_t cv = 0, kp = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            cv = (lane == i) ? n_cov[i] : cv;
+            kp = (lane == i) ? n_kept[i] : kp;
+        }
+        A.cov[c0 + wave * 16 + lane] = (int32_t)cv;
+        A.nb[c0 + wave * 16 + lane] = (int32_t)kp;
+    }
+}
+
 int lfq_launch_pileup_columns(const LfqPileupArgs &a, int scatter, void *stream)
 {
+    if (a.n_reads > 0 && a.width > 0 && lfq_knobs().pileup_tiles) {
+        const dim3 grid((unsigned)((a.width + LFQ_TILE - 1) / LFQ_TILE)), block(256);
+        if (scatter) {
+            hipLaunchKernelGGL((lfq_pileup_tiles_kernel<true, 128>), grid, block, 0, (hipStream_t)stream, a);
+        } else {
+            hipLaunchKernelGGL((lfq_pileup_tiles_kernel<false, 256>), grid, block, 0, (hipStream_t)stream, a);
+        }
+        return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+    }
     if (a.n_reads <= 0 || a.width <= 0) {
         return LFQ_OK;
     }

@@ -165,3 +165,75 @@ def test_window_search_at_its_round_boundaries(caller, n_reads):
                     icols.num_tails.tolist(), icols.num_ins.tolist(), icols.num_dels.tolist()))
     assert res[0] == res[1]
     assert len(res[0][0]) > 0
+
+
+def _hard_reads(rng, glen, n):
+    """reads that exercise the tile kernel's phase A: two indels within 64 positions, insertions too long for a row,
+    = / X / N / S / H operations, reads that start and end inside a tile, deep piles with ragged starts"""
+    import lofreq_amd as la
+    reads = []
+    starts = np.sort(np.concatenate([rng.integers(0, glen - 400, n), rng.integers(300, 330, n // 3)]))
+    for pos in starts.tolist():
+        kind = rng.integers(0, 8)
+        cigar = []
+        if rng.random() < 0.3:
+            cigar.append(("S", int(rng.integers(1, 12))))
+        body = int(rng.integers(20, 180))
+        if kind == 0:                                           # two indels close together
+            a, b = int(rng.integers(5, 30)), int(rng.integers(2, 25))
+            cigar += [("M", a), ("I" if rng.random() < 0.5 else "D", int(rng.integers(1, 5))), ("M", b),
+                      ("D" if rng.random() < 0.5 else "I", int(rng.integers(1, 6))), ("M", body)]
+        elif kind == 1:                                         # an insertion longer than a row's slack
+            cigar += [("M", int(rng.integers(3, 40))), ("I", int(rng.integers(18, 60))), ("M", body)]
+        elif kind == 2:                                         # = and X next to each other, a skipped region
+            cigar += [("=", int(rng.integers(3, 50))), ("X", 1), ("=", int(rng.integers(3, 50))), ("N", int(rng.integers(1, 90))),
+                      ("M", body)]
+        elif kind == 3:                                         # three indels within a few bases
+            cigar += [("M", 4), ("I", 1), ("M", 3), ("D", 2), ("M", 2), ("I", 2), ("M", body)]
+        elif kind == 4:                                         # a long deletion: whole tiles inside it
+            cigar += [("M", int(rng.integers(10, 40))), ("D", int(rng.integers(60, 200))), ("M", body)]
+        else:
+            cigar += [("M", body)]
+        if rng.random() < 0.2:
+            cigar.append(("S", int(rng.integers(1, 9))))
+        if rng.random() < 0.1:
+            cigar.append(("H", 5))
+        ql = sum(l for o, l in cigar if o in "MIS=X")
+        reads.append({"pos0": int(pos), "cigar": cigar, "seq": rng.integers(0, 5, ql).astype(np.uint8),
+                      "qual": rng.integers(0, 61, ql).astype(np.uint8), "mapq": int(rng.integers(0, 61)),
+                      "reverse": bool(rng.integers(0, 2)), "lb": rng.integers(33, 127, ql).astype(np.uint8)})
+    return reads
+
+
+@pytest.mark.parametrize("begin,end", [(0, 2000), (37, 1201), (250, 400)])
+def test_tile_kernel_hard_reads_against_oracle_pileup(caller, oracle, begin, end):
+    """lfq_pileup_tiles_kernel (both passes) on reads built against its fast path, for regions that start and end inside
+    tiles: every track byte, in pileup order, against the oracle's column builder (oracle/orc_pileup.c)"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(5 + begin)
+    glen = 2000
+    genome = "".join(rng.choice(list("ACGT"), glen)).encode()
+    reads = _hard_reads(rng, glen, 900)
+    ends = [r["pos0"] + sum(l for o, l in r["cigar"] if o in "MDN=X") for r in reads]
+    reads = [r for r, e in zip(reads, ends) if e <= glen]
+    caller.set_pileup_nt_packed(False)
+    try:
+        dt = la.pileup_snv_tracks(caller, reads, genome, begin, end, lb=[r["lb"] for r in reads], min_plp_bq=3)
+        t = dt._tracks()
+        ncols = dt.ncols
+        off = _fetch(t.col_off, (ncols + 1) * 8).view(np.uint64)
+        n_obs = int(off[-1])
+        got = {k: _fetch(p, max(n_obs, 1))[:n_obs] for k, p in (("nt", t.nt), ("bq", t.bq), ("baq", t.baq), ("mq", t.mq))}
+        cov = _fetch(t.coverage_plp, ncols * 4).view(np.int32)
+        nb = _fetch(t.num_bases, ncols * 4).view(np.int32)
+        col_pos = np.asarray(dt.col_pos[:ncols])
+    finally:
+        caller.set_pileup_nt_packed(True)
+    out = oracle.pileup_region(oracle.pack_reads(reads, genome), begin, end, min_plp_bq=3, use_baq=True)
+    h = out["host"]
+    assert np.array_equal(col_pos, out["col_pos"])
+    assert np.array_equal(off, h["col_off"])
+    assert np.array_equal(cov, h["coverage_plp"]) and np.array_equal(nb, h["num_bases"])
+    for k in ("nt", "bq", "baq", "mq"):
+        assert np.array_equal(got[k], h[k][:n_obs]), k
+    assert n_obs > 20000 and int(np.diff(off.astype(np.int64)).max()) > 256      # more than one round of reads per tile
