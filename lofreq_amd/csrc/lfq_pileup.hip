@@ -828,8 +828,303 @@ __global__ __launch_bounds__(256) void lfq_plp_indel_columns_kernel(LfqPlpIndelA
     }
 }
 
+/* ---- the counter pass of the indel fields by tiles of 64 positions (see lfq_pileup_tiles_kernel) ---------------------
+ * Per read and tile, phase A (a read per thread pair) keeps: the two masks; the BI / BD bytes of the query stretch the tile's
+ * positions map to (one indel inside the tile included) as aligned words in LDS; the positions at which an insertion or
+ * deletion FOLLOWS (the last position of a CIGAR operation, resolve_cigar2's peek: at most three per tile here) with their
+ * lengths; the read's last aligned position if it lies in the tile.  A deleted / skipped position takes the qualities of the
+ * next query base (htslib's qpos inside a deletion): the base of the next covered position when the deletion is followed
+ * directly by a match inside the tile.  Everything else -- three stretches, more than three events, a tile that ends inside
+ * a deletion, a deletion followed by an insertion, an insertion too long for the row -- is flagged and resolved per
+ * position in phase B exactly as the column-major kernel does (there is no store in this pass that such a load could
+ * stall).  Phase B: a wavefront per position, lanes = reads in read order; the seven counts by ballots, the two quality
+ * sums per lane, added to the tile's accumulators in LDS once per round. */
+struct LfqTileIndel {
+    unsigned long long cm, dm;
+    int off0, off1, split, nw;
+    int64_t a0;
+    int ev_dp[3], ev_val[3];
+    int tail_dp;
+    bool slow;
+};
+
+__device__ __forceinline__ int lfq_cigar_peek_indel(const uint32_t *cg, int nc, int k)
+{
+    int indel = 0;                                      /* resolve_cigar2: what follows operation k */
+    if (k + 1 < nc) {
+        const int op2 = cg[k + 1] & 0xf, l2 = cg[k + 1] >> 4;
+        if (op2 == 2) {
+            indel = -l2;
+        } else if (op2 == 1) {
+            indel = l2;
+        } else if (op2 == 6 && k + 2 < nc) {
+            int l3 = 0;
+            for (int kk = k + 2; kk < nc; ++kk) {
+                const int o3 = cg[kk] & 0xf;
+                if (o3 == 1) {
+                    l3 += cg[kk] >> 4;
+                } else if (o3 == 2 || o3 == 0 || o3 == 3 || o3 == 7 || o3 == 8) {
+                    break;
+                }
+            }
+            indel = l3 > 0 ? l3 : 0;
+        }
+    }
+    return indel;
+}
+
+__device__ __forceinline__ LfqTileIndel lfq_tile_resolve_indel(const uint32_t *cg, int nc, int64_t x, int64_t s0, int64_t p0, int tile)
+{
+    LfqTileIndel R;
+    R.cm = R.dm = 0;
+    R.off0 = R.off1 = 0;
+    R.split = 64;
+    R.nw = 0;
+    R.a0 = 0;
+    R.slow = false;
+    R.tail_dp = 255;
+    R.ev_dp[0] = R.ev_dp[1] = R.ev_dp[2] = 255;
+    R.ev_val[0] = R.ev_val[1] = R.ev_val[2] = 0;
+    int y = 0, nseg = 0, nev = 0, q1 = 0, p1 = 0, q2 = 0, p2 = 0, n2 = 0, n1 = 0;
+    for (int k = 0; k < nc; ++k) {
+        const int op = cg[k] & 0xf, l = cg[k] >> 4;
+        const bool m = op == 0 || op == 7 || op == 8, d = op == 2 || op == 3;
+        if (m || d) {
+            const int64_t a = x > p0 ? x : p0, b = (x + l < p0 + tile) ? x + l : p0 + tile;
+            if (a < b) {
+                const int n = (int)(b - a), sh = (int)(a - p0);
+                const unsigned long long mk = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << sh;
+                if (d) {
+                    R.dm |= mk;
+                    /* its positions take the qualities of the next query base: that is the next covered position's base
+                     * only if a match follows directly, inside the tile */
+                    const int opn = k + 1 < nc ? (int)(cg[k + 1] & 0xf) : -1;
+                    if (!(opn == 0 || opn == 7 || opn == 8) || x + l >= p0 + tile) {
+                        R.slow = true;
+                    }
+                } else {
+                    const int q = y + (int)(a - x);
+                    R.cm |= mk;
+                    if (nseg == 0) {
+                        q1 = q; p1 = sh; n1 = n;
+                        nseg = 1;
+                    } else if (nseg == 1 && q == q1 + n1 && sh == p1 + n1) {
+                        n1 += n;
+                    } else if (nseg == 1) {
+                        q2 = q; p2 = sh; n2 = n;
+                        nseg = 2;
+                    } else if (nseg == 2 && q == q2 + n2 && sh == p2 + n2) {
+                        n2 += n;
+                    } else {
+                        nseg++;
+                    }
+                }
+            }
+            const int64_t pl = x + l - 1;               /* the operation's last position: what follows it? */
+            if (l > 0 && pl >= p0 && pl < p0 + tile) {
+                const int v = lfq_cigar_peek_indel(cg, nc, k);
+                if (v != 0) {
+                    const int e = (int)(pl - p0);       /* (no indexing by nev: the arrays would go to scratch memory) */
+                    if (nev == 0) {
+                        R.ev_dp[0] = e; R.ev_val[0] = v;
+                    } else if (nev == 1) {
+                        R.ev_dp[1] = e; R.ev_val[1] = v;
+                    } else if (nev == 2) {
+                        R.ev_dp[2] = e; R.ev_val[2] = v;
+                    }
+                    nev++;
+                }
+            }
+            x += l;
+            if (m) {
+                y += l;
+            }
+        } else if (op == 1 || op == 4) {
+            y += l;
+        }
+    }
+    /* x is bam_endpos now: is_tail (plp.c:920-922) */
+    if (x - 1 >= p0 && x - 1 < p0 + tile && ((R.cm >> (int)(x - 1 - p0)) & 1ull)) {
+        R.tail_dp = (int)(x - 1 - p0);
+    }
+    if (nseg == 1 || nseg == 2) {
+        const int64_t g0 = s0 + q1;
+        R.a0 = g0 & ~(int64_t)15;
+        const int span = nseg == 1 ? n1 : (q2 + n2 - q1);
+        R.nw = (int)((g0 - R.a0) + span + 15) >> 4;
+        R.off0 = (int)(g0 - R.a0) - p1;
+        R.off1 = nseg == 1 ? R.off0 : (int)(g0 - R.a0) + (q2 - q1) - p2;
+        R.split = nseg == 1 ? 64 : p2;
+    }
+    if (nseg > 2 || R.nw > 6 || nev > 3 || (nseg == 0 && R.dm)) {
+        R.slow = true;
+    }
+    if (R.slow) {
+        R.nw = 0;
+    }
+    return R;
+}
+
+__global__ __launch_bounds__(256) void lfq_plp_indel_tiles_kernel(LfqPlpIndelArgs A)
+{
+    constexpr int RC = 128;                                         /* reads per round, two threads each: BI row / BD row */
+    __shared__ uint32_t s_row[2][RC][LFQ_TILE_ROW / 4];
+    __shared__ unsigned long long s_cm[RC], s_dm[RC];
+    __shared__ int16_t s_off0[RC], s_off1[RC];
+    __shared__ uint8_t s_split[RC], s_tail[RC], s_fl[RC];           /* s_fl: bit 0 BI, 1 BD, 2 reverse strand, 3 resolved per position */
+    __shared__ uint32_t s_evdp[RC];                                 /* byte j: position of event j, 255 = none */
+    __shared__ int32_t s_evv[3][RC];
+    __shared__ uint32_t s_acc[LFQ_TILE][9];                         /* the tile's nine outputs per position */
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * LFQ_TILE;
+    if (c0 >= A.width) {
+        return;
+    }
+    const int64_t p0 = A.begin + c0;
+    const int tile = (int)((A.width - c0 < LFQ_TILE) ? (A.width - c0) : LFQ_TILE);
+    for (int i = tid; i < LFQ_TILE * 9; i += 256) {
+        (&s_acc[0][0])[i] = 0;
+    }
+    __syncthreads();
+    const int64_t lo = lfq_wave_first_above(A.pmax_end, 0, A.n_reads, p0, lane);
+    const int64_t hi = lfq_wave_first_above(A.pos, lo, A.n_reads, p0 + tile - 1, lane);
+    const int rt = tid & (RC - 1);
+    const bool first = tid < RC;
+    for (int64_t r0 = lo; r0 < hi; r0 += RC) {
+        /* ---- phase A ---- */
+        {
+            const int64_t r = r0 + rt;
+            LfqTileIndel R;
+            R.cm = R.dm = 0;
+            R.off0 = R.off1 = 0;
+            R.split = 64;
+            R.tail_dp = 255;
+            R.ev_dp[0] = R.ev_dp[1] = R.ev_dp[2] = 255;
+            R.ev_val[0] = R.ev_val[1] = R.ev_val[2] = 0;
+            R.slow = false;
+            uint32_t fl = 0;
+            if (r < hi) {
+                const int64_t co = A.cigar_off[r], s0 = A.seq_off[r];
+                R = lfq_tile_resolve_indel(A.cigar + co, (int)(A.cigar_off[r + 1] - co), A.pos[r], s0, p0, tile);
+                const uint32_t tf = A.tag_flags ? A.tag_flags[r] : 3u;
+                fl = ((A.bi && (tf & 1u)) ? 1u : 0u) | ((A.bd && (tf & 2u)) ? 2u : 0u) | (A.reverse[r] ? 4u : 0u) | (R.slow ? 8u : 0u);
+                if (R.nw > 0) {
+                    if (first && (fl & 1u)) {
+                        lfq_tile_fetch(&s_row[0][rt][0], A.bi, R.a0, R.nw);
+                    } else if (!first && (fl & 2u)) {
+                        lfq_tile_fetch(&s_row[1][rt][0], A.bd, R.a0, R.nw);
+                    }
+                }
+            }
+            if (first) {
+                s_cm[rt] = R.cm;
+                s_dm[rt] = R.dm;
+                s_off0[rt] = (int16_t)R.off0;
+                s_off1[rt] = (int16_t)R.off1;
+                s_split[rt] = (uint8_t)R.split;
+                s_tail[rt] = (uint8_t)R.tail_dp;
+                s_fl[rt] = (uint8_t)fl;
+                s_evdp[rt] = (uint32_t)R.ev_dp[0] | ((uint32_t)R.ev_dp[1] << 8) | ((uint32_t)R.ev_dp[2] << 16);
+                s_evv[0][rt] = R.ev_val[0];
+                s_evv[1][rt] = R.ev_val[1];
+                s_evv[2][rt] = R.ev_val[2];
+            }
+        }
+        __syncthreads();
+        /* ---- phase B: positions wave * 16 .. + 15; both 64-read slices of the round in registers ---- */
+        unsigned long long cm[2], dm[2];
+        int off0[2], off1[2], split[2], tail[2], evv0[2], evv1[2], evv2[2];
+        uint32_t fl[2], evdp[2];
+#pragma unroll
+        for (int sc = 0; sc < 2; sc++) {
+            const int t = sc * 64 + lane;
+            cm[sc] = s_cm[t]; dm[sc] = s_dm[t];
+            off0[sc] = s_off0[t]; off1[sc] = s_off1[t]; split[sc] = s_split[t]; tail[sc] = s_tail[t];
+            fl[sc] = s_fl[t]; evdp[sc] = s_evdp[t];
+            evv0[sc] = s_evv[0][t]; evv1[sc] = s_evv[1][t]; evv2[sc] = s_evv[2][t];
+        }
+        for (int i = 0; i < 16; i++) {
+            const int dp = wave * 16 + i;
+            uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0}, qs0 = 0, qs1 = 0;
+#pragma unroll
+            for (int sc = 0; sc < 2; sc++) {
+                const int t = sc * 64 + lane;
+                bool covered = (cm[sc] >> dp) & 1ull;
+                bool any = covered || ((dm[sc] >> dp) & 1ull);
+                int iq = 0, dq = 0, indel = 0;
+                bool is_tail = covered && dp == tail[sc];
+                if (any && !(fl[sc] & 8u)) {
+                    int dpn = dp;
+                    if (!covered) {
+                        dpn = dp + __builtin_ctzll(cm[sc] >> dp);           /* the next covered position: there is one (phase A) */
+                    }
+                    const int idx = (dpn < split[sc] ? off0[sc] : off1[sc]) + dpn;
+                    if (fl[sc] & 1u) {
+                        iq = (int)reinterpret_cast<const uint8_t *>(&s_row[0][t][0])[idx] - 33;
+                    }
+                    if (fl[sc] & 2u) {
+                        dq = (int)reinterpret_cast<const uint8_t *>(&s_row[1][t][0])[idx] - 33;
+                    }
+                    indel = (dp == (int)(evdp[sc] & 255u)) ? evv0[sc]
+                            : (dp == (int)((evdp[sc] >> 8) & 255u)) ? evv1[sc]
+                            : (dp == (int)((evdp[sc] >> 16) & 255u)) ? evv2[sc] : 0;
+                } else if (any) {
+                    /* resolved per position, as the column-major kernel does */
+                    const int64_t r = r0 + t, co = A.cigar_off[r], s0 = A.seq_off[r];
+                    int qpos = 0;
+                    bool tl = false;
+                    const int kind = lfq_plp_locate_indel(A.cigar + co, (int)(A.cigar_off[r + 1] - co), A.pos[r], p0 + dp,
+                                                          (int)(A.seq_off[r + 1] - s0), &qpos, &indel, &tl);
+                    covered = kind == 1;
+                    any = kind != 0;
+                    is_tail = covered && tl;
+                    iq = ((fl[sc] & 1u) && qpos >= 0) ? (int)A.bi[s0 + qpos] - 33 : 0;
+                    dq = ((fl[sc] & 2u) && qpos >= 0) ? (int)A.bd[s0 + qpos] - 33 : 0;
+                }
+                const bool rev = (fl[sc] & 4u) != 0;
+                const bool pass = any && !(iq < A.min_plp_idq || dq < A.min_plp_idq);              /* plp.c:1062 */
+                const bool no_ins = pass && indel <= 0, no_del = pass && indel >= 0;
+                cnt[0] += (uint32_t)__popcll(__ballot(any));
+                cnt[1] += (uint32_t)__popcll(__ballot(is_tail));                                 /* :920-922 */
+                cnt[2] += (uint32_t)__popcll(__ballot(pass && indel == 0));
+                cnt[3] += (uint32_t)__popcll(__ballot(pass && indel > 0));
+                cnt[4] += (uint32_t)__popcll(__ballot(pass && indel < 0));
+                cnt[5] += (uint32_t)__popcll(__ballot(no_ins && !rev));
+                cnt[6] += (uint32_t)__popcll(__ballot(no_del && !rev));
+                qs0 += no_ins ? (uint32_t)iq : 0u;
+                qs1 += no_del ? (uint32_t)dq : 0u;
+            }
+            qs0 = lfq_wave_sum_u32(qs0);
+            qs1 = lfq_wave_sum_u32(qs1);
+            if (lane < 9) {
+                uint32_t v = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : lane == 3 ? cnt[3] : lane == 4 ? cnt[4]
+                             : lane == 5 ? cnt[5] : lane == 6 ? cnt[6] : lane == 7 ? qs0 : qs1;
+                s_acc[dp][lane] += v;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < tile) {
+        const int64_t c = c0 + tid;
+        A.cov[c] = (int32_t)s_acc[tid][0];
+        A.tails[c] = (int32_t)s_acc[tid][1];
+        A.non_indels[c] = (int32_t)s_acc[tid][2];
+        A.n_ins[c] = (int32_t)s_acc[tid][3];
+        A.n_dels[c] = (int32_t)s_acc[tid][4];
+        A.non_ins_fw[c] = (int32_t)s_acc[tid][5];
+        A.non_del_fw[c] = (int32_t)s_acc[tid][6];
+        A.ne_qsum[0][c] = (int32_t)s_acc[tid][7];
+        A.ne_qsum[1][c] = (int32_t)s_acc[tid][8];
+    }
+}
+
 int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *stream)
 {
+    if (!scatter && a.n_reads > 0 && a.width > 0 && lfq_knobs().pileup_tiles) {
+        const dim3 grid((unsigned)((a.width + LFQ_TILE - 1) / LFQ_TILE)), block(256);
+        hipLaunchKernelGGL(lfq_plp_indel_tiles_kernel, grid, block, 0, (hipStream_t)stream, a);
+        return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+    }
     if (a.n_reads <= 0 || a.width <= 0) {
         return LFQ_OK;
     }

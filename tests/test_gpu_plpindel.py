@@ -149,9 +149,11 @@ def _random_indel_reads(rng, n, glen, genome):
     return reads
 
 
-@pytest.mark.parametrize("min_idq,begin,end", [(0, 0, 3000), (25, 0, 3000), (0, 700, 1900)])
-def test_indel_columns_random_reads_vs_plain_restatement(caller, min_idq, begin, end):
-    """every CIGAR operation incl. N, P and D followed by I, missing tags, the min_plp_idq gate, a sub-region:
+@pytest.mark.parametrize("min_idq,begin,end,n_reads", [(0, 0, 3000, 1500), (25, 0, 3000, 1500), (0, 700, 1900, 1500),
+                                                       (10, 101, 2503, 7000)])
+def test_indel_columns_random_reads_vs_plain_restatement(caller, min_idq, begin, end, n_reads):
+    """every CIGAR operation incl. N, P and D followed by I, missing tags, the min_plp_idq gate, a sub-region that starts
+    and ends inside a tile of the counter kernel, piles deeper than one round of its reads:
     all fields against the pure-Python restatement of compile_plp_col's indel part (tests/golden_util.py)"""
     import lofreq_amd as la
     rng = np.random.default_rng(5)
@@ -159,7 +161,7 @@ def test_indel_columns_random_reads_vs_plain_restatement(caller, min_idq, begin,
     genome = rng.integers(0, 4, glen).astype(np.uint8)
     genome[1000:1012] = 2                                   # a homopolymer for hrun
     ref = "".join("ACGT"[c] for c in genome)
-    reads = _random_indel_reads(rng, 1500, glen, genome)
+    reads = _random_indel_reads(rng, n_reads, glen, genome)
     want = gu.py_indel_pileup(reads, ref, min_plp_idq=min_idq)
     cols, col_pos = la.pileup_indel_columns(caller, reads, ref.encode(), begin, end, min_plp_idq=min_idq)
     assert col_pos.tolist() == sorted(p for p in want if begin <= p < end)
