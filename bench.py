@@ -396,7 +396,7 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
         # lfq_readset_create are then DMA transfers queued at once, and the BAQ kernels -- not this thread -- wait for them
         import torch
         keep = {}
-        for k in ("seq", "qual", "bi", "bd"):
+        for k in ("seq", "qual", "bi", "bd", "pos", "cig_off", "cig", "seq_off", "mapq", "rev"):
             keep[k] = torch.from_numpy(R[k]).pin_memory()
             R[k] = keep[k].numpy()
         R["_pinned"] = keep
@@ -516,7 +516,7 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
                  "reads_per_s": n_reads / best["s_total"], "columns_per_s": best["columns"] / best["s_total"],
                  "call_indels": bool(call_indels),
                  "regions_overlapped": bool(overlap),
-                 "caller_arrays": "pinned (bases, qualities, BI, BD)" if pinned else "pageable",
+                 "caller_arrays": "pinned" if pinned else "pageable",
                  "note": "resident read set; BAM decoding (htslib, CPU) not included; reference end-to-end rows "
                          "(BASELINE.md 2): 6736 cols/s without BAQ, 1334 cols/s with BAQ, one CPU thread"})
     return best
