@@ -236,7 +236,7 @@ __device__ __forceinline__ void lfq_count_emit(bool strand, lfq_col_counts &r, c
             flag = (uint8_t)((r.tested ? 1 : 0)
                              | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
         }
-        out[col] = r;
+        out[col] = r;               /* (out: the dense records, or the wavefront's staging rows in LDS with col = the group) */
         flags[col] = flag;
     }
 }
@@ -253,6 +253,8 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
                                                               uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
     constexpr int G = 64 / LPG;                      /* columns per wavefront */
+    __shared__ __attribute__((aligned(16))) lfq_col_counts s_rec[4][G];
+    __shared__ uint8_t s_flag[4][G];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = lfq_lane();
     const int g = lane / LPG, l = lane % LPG;
@@ -323,9 +325,22 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
         for (int x = 0; x < 4; x++) {
             filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];
         }
-        if (l == 0 && valid) {
-            lfq_count_emit(STRAND, r, raw, fw, filt, ref_code, out, flags, col);
+        /* The records of the wavefront's G columns are G x 64 contiguous bytes: lane 0 of every group builds its record in
+         * LDS, then the wavefront writes them out 16 bytes per lane -- one coalesced store instead of five per group that
+         * touch a cache line each (and the class flags as one run of bytes). */
+        if (l == 0) {
+            lfq_count_emit(STRAND, r, raw, fw, filt, ref_code, &s_rec[wave][0], &s_flag[wave][0], g);
         }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (lane < G * 4 && colb + (lane >> 2) < c1) {
+            const uint4 v = reinterpret_cast<const uint4 *>(&s_rec[wave][0])[lane];
+            reinterpret_cast<uint4 *>(out + colb)[lane] = v;
+        }
+        if (lane < G && colb + lane < c1) {
+            flags[colb + lane] = s_flag[wave][lane];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
