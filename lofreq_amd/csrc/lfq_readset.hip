@@ -1335,6 +1335,126 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
         }
         scan_events();
+        /* 4a. the event tables, part by part, while the counter kernel is still on its way (it waits for BI / BD, the end of
+         * the upload): they need the events and the caller's arrays, nothing from the device.  Merged below (4). */
+        struct PartTables {
+            LfqIndelColsOwned::Side side[2];        /* key_off / rd_off: local running totals, no leading 0 */
+            std::vector<int64_t> cols;              /* positions (relative to the region) with events, ascending */
+            std::vector<int64_t> ev_after[2];       /* local event count of each side after each of them */
+            std::vector<int64_t> rd_ev[2];          /* event index of each entry of side[sd].rd_q (for rd_aq, filled last) */
+        };
+        const int n_parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min<long>(std::max<long>(lfq_knobs().host_loop_threads, 1), LFQ_HOST_PARTS), evs.size() / (size_t)std::max<int64_t>(lfq_knobs().host_par_min / 48, 1)));
+        std::vector<PartTables> pt((size_t)n_parts);
+        std::vector<size_t> cut((size_t)n_parts + 1, evs.size());
+        cut[0] = 0;
+        for (int t = 1; t < n_parts; t++) {
+            size_t k = evs.size() * (size_t)t / (size_t)n_parts;
+            while (k < evs.size() && k > 0 && evs[k].pos == evs[k - 1].pos) {
+                k++;
+            }
+            cut[(size_t)t] = std::max(k, cut[(size_t)t - 1]);
+        }
+        auto build = [&](int t) {
+            PartTables &P = pt[(size_t)t];
+            std::vector<std::string> keys;
+            std::vector<std::vector<size_t>> members;
+            std::string key;
+            size_t ei = cut[(size_t)t];
+            const size_t e_end = cut[(size_t)t + 1];
+            while (ei < e_end) {
+                const int64_t ppos = evs[ei].pos - region_begin;
+                size_t e1 = ei;
+                while (e1 < e_end && evs[e1].pos - region_begin == ppos) {
+                    e1++;
+                }
+                P.cols.push_back(ppos);             /* the position; its column index is known once the counters are back */
+                for (int sd = 0; sd < 2; sd++) {
+                    LfqIndelColsOwned::Side &S = P.side[sd];
+                    keys.clear();                       /* (reused across columns: no allocation in the common case) */
+                    for (auto &m : members) {
+                        m.clear();
+                    }
+                    size_t n_keys = 0;
+                    for (size_t i = ei; i < e1; i++) {
+                        const Ev &e = evs[i];
+                        if ((e.indel > 0) != (sd == 0)) {
+                            continue;
+                        }
+                        key.clear();
+                        if (sd == 0) {                                  /* inserted bases, plp.c:1082-1086 */
+                            const int64_t s0 = rd->seq_off[e.read], lq = rd->seq_off[e.read + 1] - s0;
+                            for (int j = 1; j <= e.indel; j++) {
+                                const int64_t q = e.qpos + j;
+                                const uint8_t code = q < lq ? rd->seq[s0 + q] : 4;
+                                key.push_back("ACGTN"[code > 4 ? 4 : code]);
+                            }
+                        } else {                                        /* deleted reference bases, :1127-1131 */
+                            for (int j = 1; j <= -e.indel; j++) {
+                                const int64_t g = e.pos + j;
+                                key.push_back(g < rd->ref_len ? (char)toupper((unsigned char)rd->ref[g]) : 'N');
+                            }
+                        }
+                        size_t ki = 0;
+                        while (ki < n_keys && keys[ki] != key) {
+                            ki++;
+                        }
+                        if (ki == n_keys) {
+                            keys.push_back(key);
+                            if (members.size() <= n_keys) {
+                                members.emplace_back();
+                            }
+                            n_keys++;
+                        }
+                        members[ki].push_back(i);
+                    }
+                    for (size_t ki = 0; ki < n_keys; ki++) {
+                        int fw = 0, rv = 0;
+                        for (size_t i : members[ki]) {
+                            const Ev &e = evs[i];
+                            const int64_t s0 = rd->seq_off[e.read];
+                            const uint32_t fl = t_fl[e.read];
+                            const uint8_t *qa = sd == 0 ? t_bi : t_bd;
+                            const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u));
+                            S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
+                            S.rd_aq.push_back((int16_t)-1);                  /* filled when the BAQ kernels are through */
+                            P.rd_ev[sd].push_back((int64_t)i);
+                            S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
+                            const int32_t sq = t_sq ? t_sq[e.read] : -1;
+                            S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
+                            if (rd->reverse[e.read]) {
+                                rv++;
+                            } else {
+                                fw++;
+                            }
+                        }
+                        S.ev_fw.push_back(fw);
+                        S.ev_rv.push_back(rv);
+                        S.key_chars.insert(S.key_chars.end(), keys[ki].begin(), keys[ki].end());
+                        S.key_off.push_back((int64_t)S.key_chars.size());
+                        S.rd_off.push_back((int64_t)S.rd_q.size());
+                    }
+                    P.ev_after[sd].push_back((int64_t)S.ev_fw.size());
+                }
+                ei = e1;
+            }
+        };
+        {
+            const std::function<void(int)> task = [&](int t) { build(t); };
+            LfqLoopPool &pool = LfqLoopPool::instance();
+            if (n_parts > 1 && pool.try_run(n_parts, task)) {
+                build(0);
+                pool.finish();
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < n_parts; t++) {
+                    th.emplace_back(build, t);
+                }
+                build(0);
+                for (auto &x : th) {
+                    x.join();
+                }
+            }
+        }
         tm[1] = lfq_now_ms();
         if (rc == LFQ_OK && hipStreamSynchronize(ps) != hipSuccess) {
             rc = LFQ_ERR_HIP;
@@ -1530,128 +1650,6 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             S.rd_off.push_back(0);
         }
         const int64_t ncols = (int64_t)O.cov.size();
-        struct PartTables {
-            LfqIndelColsOwned::Side side[2];        /* key_off / rd_off: local running totals, no leading 0 */
-            std::vector<int64_t> cols;              /* columns with events, ascending */
-            std::vector<int64_t> ev_after[2];       /* local event count of each side after each of them */
-            std::vector<int64_t> rd_ev[2];          /* event index of each entry of side[sd].rd_q (for rd_aq, filled last) */
-        };
-        const int n_parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::min<long>(std::max<long>(lfq_knobs().host_loop_threads, 1), LFQ_HOST_PARTS), evs.size() / (size_t)std::max<int64_t>(lfq_knobs().host_par_min / 48, 1)));
-        std::vector<PartTables> pt((size_t)n_parts);
-        std::vector<size_t> cut((size_t)n_parts + 1, evs.size());
-        cut[0] = 0;
-        for (int t = 1; t < n_parts; t++) {
-            size_t k = evs.size() * (size_t)t / (size_t)n_parts;
-            while (k < evs.size() && k > 0 && evs[k].pos == evs[k - 1].pos) {
-                k++;
-            }
-            cut[(size_t)t] = std::max(k, cut[(size_t)t - 1]);
-        }
-        auto build = [&](int t) {
-            PartTables &P = pt[(size_t)t];
-            std::vector<std::string> keys;
-            std::vector<std::vector<size_t>> members;
-            std::string key;
-            size_t ei = cut[(size_t)t];
-            const size_t e_end = cut[(size_t)t + 1];
-            while (ei < e_end) {
-                const int64_t ppos = evs[ei].pos - region_begin;
-                size_t e1 = ei;
-                while (e1 < e_end && evs[e1].pos - region_begin == ppos) {
-                    e1++;
-                }
-                if (h[0][(size_t)ppos] <= 0) {      /* (cannot happen: a read with an event covers its position) */
-                    ei = e1;
-                    continue;
-                }
-                P.cols.push_back(col_of[(size_t)ppos]);
-                for (int sd = 0; sd < 2; sd++) {
-                    LfqIndelColsOwned::Side &S = P.side[sd];
-                    keys.clear();                       /* (reused across columns: no allocation in the common case) */
-                    for (auto &m : members) {
-                        m.clear();
-                    }
-                    size_t n_keys = 0;
-                    for (size_t i = ei; i < e1; i++) {
-                        const Ev &e = evs[i];
-                        if ((e.indel > 0) != (sd == 0)) {
-                            continue;
-                        }
-                        key.clear();
-                        if (sd == 0) {                                  /* inserted bases, plp.c:1082-1086 */
-                            const int64_t s0 = rd->seq_off[e.read], lq = rd->seq_off[e.read + 1] - s0;
-                            for (int j = 1; j <= e.indel; j++) {
-                                const int64_t q = e.qpos + j;
-                                const uint8_t code = q < lq ? rd->seq[s0 + q] : 4;
-                                key.push_back("ACGTN"[code > 4 ? 4 : code]);
-                            }
-                        } else {                                        /* deleted reference bases, :1127-1131 */
-                            for (int j = 1; j <= -e.indel; j++) {
-                                const int64_t g = e.pos + j;
-                                key.push_back(g < rd->ref_len ? (char)toupper((unsigned char)rd->ref[g]) : 'N');
-                            }
-                        }
-                        size_t ki = 0;
-                        while (ki < n_keys && keys[ki] != key) {
-                            ki++;
-                        }
-                        if (ki == n_keys) {
-                            keys.push_back(key);
-                            if (members.size() <= n_keys) {
-                                members.emplace_back();
-                            }
-                            n_keys++;
-                        }
-                        members[ki].push_back(i);
-                    }
-                    for (size_t ki = 0; ki < n_keys; ki++) {
-                        int fw = 0, rv = 0;
-                        for (size_t i : members[ki]) {
-                            const Ev &e = evs[i];
-                            const int64_t s0 = rd->seq_off[e.read];
-                            const uint32_t fl = t_fl[e.read];
-                            const uint8_t *qa = sd == 0 ? t_bi : t_bd;
-                            const bool has_q = qa && (fl & (sd == 0 ? 1u : 2u));
-                            S.rd_q.push_back((int16_t)(has_q ? (int)qa[s0 + e.qpos] - 33 : 0));
-                            S.rd_aq.push_back((int16_t)-1);                  /* filled when the BAQ kernels are through */
-                            P.rd_ev[sd].push_back((int64_t)i);
-                            S.rd_mq.push_back((int16_t)rd->mapq[e.read]);
-                            const int32_t sq = t_sq ? t_sq[e.read] : -1;
-                            S.rd_sq.push_back((int16_t)(sq > 32767 ? 32767 : sq));
-                            if (rd->reverse[e.read]) {
-                                rv++;
-                            } else {
-                                fw++;
-                            }
-                        }
-                        S.ev_fw.push_back(fw);
-                        S.ev_rv.push_back(rv);
-                        S.key_chars.insert(S.key_chars.end(), keys[ki].begin(), keys[ki].end());
-                        S.key_off.push_back((int64_t)S.key_chars.size());
-                        S.rd_off.push_back((int64_t)S.rd_q.size());
-                    }
-                    P.ev_after[sd].push_back((int64_t)S.ev_fw.size());
-                }
-                ei = e1;
-            }
-        };
-        {
-            const std::function<void(int)> task = [&](int t) { build(t); };
-            LfqLoopPool &pool = LfqLoopPool::instance();
-            if (n_parts > 1 && pool.try_run(n_parts, task)) {
-                build(0);
-                pool.finish();
-            } else {
-                std::vector<std::thread> th;
-                for (int t = 1; t < n_parts; t++) {
-                    th.emplace_back(build, t);
-                }
-                build(0);
-                for (auto &x : th) {
-                    x.join();
-                }
-            }
-        }
         int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
         std::vector<int64_t> rd_ev[2];
         for (int t = 0; t < n_parts; t++) {
@@ -1679,7 +1677,10 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 }
             }
             for (size_t i = 0; i < P.cols.size(); i++) {
-                const int64_t col = P.cols[i];
+                const int64_t col = col_of[(size_t)P.cols[i]];
+                if (col < 0) {
+                    return LFQ_ERR_INVALID;         /* (cannot happen: a read with an event covers its position) */
+                }
                 for (int sd = 0; sd < 2; sd++) {
                     LfqIndelColsOwned::Side &S = O.side[sd];
                     /* the event-less columns before this one repeat the running event count */
