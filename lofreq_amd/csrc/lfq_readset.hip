@@ -1455,6 +1455,61 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 }
             }
         }
+        /* ... and appended in order (offsets shifted by what came before); per column with events: where its events end on
+         * either side, and the largest quality sum of one of them */
+        struct EvCol { int64_t pos; int64_t ev_after[2]; int64_t best[2]; bool has[2]; };
+        std::vector<EvCol> ecols;
+        std::vector<int64_t> rd_ev[2];
+        for (int sd = 0; sd < 2; sd++) {
+            LfqIndelColsOwned::Side &S = O.side[sd];
+            S.ev_off.push_back(0);
+            S.key_off.push_back(0);
+            S.rd_off.push_back(0);
+        }
+        for (int t = 0; t < n_parts; t++) {
+            PartTables &P = pt[(size_t)t];
+            int64_t ev_base[2], rd_base[2], key_base[2];
+            for (int sd = 0; sd < 2; sd++) {
+                LfqIndelColsOwned::Side &S = O.side[sd];
+                const LfqIndelColsOwned::Side &L = P.side[sd];
+                ev_base[sd] = (int64_t)S.ev_fw.size();
+                rd_base[sd] = (int64_t)S.rd_q.size();
+                key_base[sd] = (int64_t)S.key_chars.size();
+                S.ev_fw.insert(S.ev_fw.end(), L.ev_fw.begin(), L.ev_fw.end());
+                S.ev_rv.insert(S.ev_rv.end(), L.ev_rv.begin(), L.ev_rv.end());
+                S.key_chars.insert(S.key_chars.end(), L.key_chars.begin(), L.key_chars.end());
+                S.rd_q.insert(S.rd_q.end(), L.rd_q.begin(), L.rd_q.end());
+                S.rd_aq.insert(S.rd_aq.end(), L.rd_aq.begin(), L.rd_aq.end());
+                S.rd_mq.insert(S.rd_mq.end(), L.rd_mq.begin(), L.rd_mq.end());
+                S.rd_sq.insert(S.rd_sq.end(), L.rd_sq.begin(), L.rd_sq.end());
+                rd_ev[sd].insert(rd_ev[sd].end(), P.rd_ev[sd].begin(), P.rd_ev[sd].end());
+                for (int64_t v : L.key_off) {
+                    S.key_off.push_back(v + key_base[sd]);
+                }
+                for (int64_t v : L.rd_off) {
+                    S.rd_off.push_back(v + rd_base[sd]);
+                }
+            }
+            for (size_t i = 0; i < P.cols.size(); i++) {
+                EvCol e;
+                e.pos = P.cols[i];
+                for (int sd = 0; sd < 2; sd++) {
+                    const LfqIndelColsOwned::Side &S = O.side[sd];
+                    const int64_t e0 = ecols.empty() ? 0 : ecols.back().ev_after[sd];
+                    e.ev_after[sd] = ev_base[sd] + P.ev_after[sd][i];
+                    e.best[sd] = 0;
+                    e.has[sd] = e.ev_after[sd] > e0;
+                    for (int64_t ev = e0; ev < e.ev_after[sd]; ev++) {
+                        int64_t sum = 0;
+                        for (int64_t k = S.rd_off[(size_t)ev]; k < S.rd_off[(size_t)ev + 1]; k++) {
+                            sum += S.rd_q[(size_t)k];
+                        }
+                        e.best[sd] = std::max(e.best[sd], sum);
+                    }
+                }
+                ecols.push_back(e);
+            }
+        }
         tm[1] = lfq_now_ms();
         if (rc == LFQ_OK && hipStreamSynchronize(ps) != hipSuccess) {
             rc = LFQ_ERR_HIP;
@@ -1643,58 +1698,31 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         /* Columns with events are few and independent of one another: the event list is cut at position boundaries into a
          * few parts, every part builds the tables of its columns on its own thread, and the parts are appended in order
          * (offsets shifted by what came before; the ev_off entries of the event-less columns in between are range fills). */
-        for (int sd = 0; sd < 2; sd++) {
-            LfqIndelColsOwned::Side &S = O.side[sd];
-            S.ev_off.push_back(0);
-            S.key_off.push_back(0);
-            S.rd_off.push_back(0);
-        }
         const int64_t ncols = (int64_t)O.cov.size();
+        /* the running event counts per column (the event-less columns repeat the count before them), and the consensus
+         * flags of the columns with events: the largest quality sum of one event against the sum over the reads without an
+         * event of that side (plp.c:1236-1270) -- the former collected at merge time, the latter from the counter kernel */
         int64_t col_done = 0;                       /* columns [0, col_done) have their ev_off entries */
-        std::vector<int64_t> rd_ev[2];
-        for (int t = 0; t < n_parts; t++) {
-            PartTables &P = pt[(size_t)t];
-            int64_t ev_base[2], rd_base[2], key_base[2];
+        if (have_qsum) {
+            O.cons_indel.assign((size_t)ncols, 0);
+        }
+        for (const EvCol &e : ecols) {
+            const int64_t col = col_of[(size_t)e.pos];
+            if (col < 0) {
+                return LFQ_ERR_INVALID;             /* (cannot happen: a read with an event covers its position) */
+            }
             for (int sd = 0; sd < 2; sd++) {
                 LfqIndelColsOwned::Side &S = O.side[sd];
-                const LfqIndelColsOwned::Side &L = P.side[sd];
-                ev_base[sd] = (int64_t)S.ev_fw.size();
-                rd_base[sd] = (int64_t)S.rd_q.size();
-                key_base[sd] = (int64_t)S.key_chars.size();
-                S.ev_fw.insert(S.ev_fw.end(), L.ev_fw.begin(), L.ev_fw.end());
-                S.ev_rv.insert(S.ev_rv.end(), L.ev_rv.begin(), L.ev_rv.end());
-                S.key_chars.insert(S.key_chars.end(), L.key_chars.begin(), L.key_chars.end());
-                S.rd_q.insert(S.rd_q.end(), L.rd_q.begin(), L.rd_q.end());
-                S.rd_aq.insert(S.rd_aq.end(), L.rd_aq.begin(), L.rd_aq.end());
-                S.rd_mq.insert(S.rd_mq.end(), L.rd_mq.begin(), L.rd_mq.end());
-                S.rd_sq.insert(S.rd_sq.end(), L.rd_sq.begin(), L.rd_sq.end());
-                rd_ev[sd].insert(rd_ev[sd].end(), P.rd_ev[sd].begin(), P.rd_ev[sd].end());
-                for (int64_t v : L.key_off) {
-                    S.key_off.push_back(v + key_base[sd]);
-                }
-                for (int64_t v : L.rd_off) {
-                    S.rd_off.push_back(v + rd_base[sd]);
+                S.ev_off.insert(S.ev_off.end(), (size_t)(col - col_done), S.ev_off.back());
+                S.ev_off.push_back(e.ev_after[sd]);
+                if (have_qsum && e.has[sd] && e.best[sd] > (int64_t)qsum[sd][(size_t)col]) {
+                    O.cons_indel[(size_t)col] = 1;
                 }
             }
-            for (size_t i = 0; i < P.cols.size(); i++) {
-                const int64_t col = col_of[(size_t)P.cols[i]];
-                if (col < 0) {
-                    return LFQ_ERR_INVALID;         /* (cannot happen: a read with an event covers its position) */
-                }
-                for (int sd = 0; sd < 2; sd++) {
-                    LfqIndelColsOwned::Side &S = O.side[sd];
-                    /* the event-less columns before this one repeat the running event count */
-                    S.ev_off.insert(S.ev_off.end(), (size_t)(col - col_done), S.ev_off.back());
-                    S.ev_off.push_back(ev_base[sd] + P.ev_after[sd][i]);
-                }
-                col_done = col + 1;
-            }
+            col_done = col + 1;
         }
         for (int sd = 0; sd < 2; sd++) {            /* the event-less columns behind the last event */
             O.side[sd].ev_off.insert(O.side[sd].ev_off.end(), (size_t)(ncols - col_done), O.side[sd].ev_off.back());
-        }
-        if (have_qsum) {
-            consensus();                            /* (sums from the counter kernel: needs nothing the scatter pass writes) */
         }
         /* 4b. the scatter pass, the BAQ kernels and the gather behind them: the alignment qualities of the event reads
          * (plp.c:1069-1073, 1113-1117); from here on the ai / ad bits of rs->fl (t_fl) are valid */
