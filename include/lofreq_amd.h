@@ -395,6 +395,9 @@ int lfq_pileup_skip_snv_columns(lfq_ctx *ctx, const uint8_t *skip, int64_t ncols
  * upload stream) and lfq_readset_baq returns when its kernels are queued; every later call on the read set waits for
  * what it needs, lfq_readset_destroy for everything.  The caller sees no difference as long as the host arrays stay
  * as they are until the read set is destroyed (they must outlive it anyway).
+ * Pinned arrays (lfq_host_alloc, hipHostMalloc, hipHostRegister): when the per-base arrays -- seq, qual, BI, BD -- are
+ * pinned, lfq_readset_create queues every copy as a DMA transfer itself and returns, and what waits for the data is the
+ * stream of the kernels that read it, never the calling thread.  Same results either way.
  * A read set belongs to its context: destroy it before lfq_destroy(ctx) (its device allocations go back to the context,
  * which hands them to the next read set -- keep one context per worker from region to region). */
 typedef struct lfq_readset lfq_readset;
