@@ -1214,11 +1214,21 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             }
         }
     }
-    });
-    for (int p = 0; p < LFQ_HOST_PARTS; p++) {
-        evs.insert(evs.end(), evs_part[p].begin(), evs_part[p].end());
-    }
+    /* by position, reads of one position in read order: every part sorts its own events on its thread ... */
     std::stable_sort(evs.begin(), evs.end(), [](const Ev &a, const Ev &b) { return a.pos < b.pos; });
+    });
+    /* ... and the parts, which are consecutive ranges of position-sorted reads and overlap only at their ends, are merged
+     * one after the other (std::inplace_merge keeps equal positions in part order = read order) */
+    const auto by_pos = [](const Ev &a, const Ev &b) { return a.pos < b.pos; };
+    for (int p = 0; p < LFQ_HOST_PARTS; p++) {
+        const size_t mid = evs.size();
+        evs.insert(evs.end(), evs_part[p].begin(), evs_part[p].end());
+        if (mid > 0 && mid < evs.size() && by_pos(evs[mid], evs[mid - 1])) {
+            /* (only the tail of what is there can lie behind the new part's first event) */
+            const auto first = std::upper_bound(evs.begin(), evs.begin() + (std::ptrdiff_t)mid, evs[mid], by_pos);
+            std::inplace_merge(first, evs.begin() + (std::ptrdiff_t)mid, evs.end(), by_pos);
+        }
+    }
     };
     const uint8_t *g_ai = nullptr, *g_ad = nullptr;     /* per event, when the qualities come from the device */
     std::vector<int32_t> qsum[2];           /* per column: quality sum of the reads without an event, from the kernel */
