@@ -1718,8 +1718,10 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         }
         for (const EvCol &e : ecols) {
             const int64_t col = col_of[(size_t)e.pos];
-            if (col < 0) {
-                return LFQ_ERR_INVALID;             /* (cannot happen: a read with an event covers its position) */
+            if (col < 0) {                          /* (cannot happen: a read with an event covers its position) */
+                (void)hipStreamSynchronize(ps);     /* the pinned blocks of this call may still be a copy's source or target */
+                (void)hipStreamSynchronize(c->stream);
+                return LFQ_ERR_INVALID;
             }
             for (int sd = 0; sd < 2; sd++) {
                 LfqIndelColsOwned::Side &S = O.side[sd];
