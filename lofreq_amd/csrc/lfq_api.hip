@@ -605,6 +605,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], st));
     LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_join[2], 0));   /* dps starts after the memset */
 
+    bool big_joined = false;
     for (int s = 0; s < n_seg; s++) {
         const int64_t c0 = ncols * s / n_seg, c1 = ncols * (s + 1) / n_seg;
         LfqWork W;
@@ -682,14 +683,29 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
             LFQ_TRY(lfq_launch_dp_mid(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_mid_waves, side1));
             LFQ_DBG_STAGE("mid");
         }
+        /* The unsplit big columns (lfq_dp_big_kernel: what the prep kernel queued because it is too short or too wide to cut
+         * -- every big column of a 1000x batch) need nothing from the segment / fold / combine kernels of the split ones.  With
+         * one segment per batch the stream the count kernel ran on is idle from here on: they run there, beside that chain
+         * instead of behind it (C2: 0.3 ms that used to start when the chain had ended). */
+        const bool big_on_st = run_big && n_seg == 1 && !single_stream && !kn.big_behind_chain;
+        if (big_on_st) {
+            LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_prep, 0));
+            LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
+                                      n_big_blocks, st));
+            LFQ_DBG_STAGE("big");
+            LFQ_TRY_HIP(hipEventRecord(c->ev_segw, st));
+            big_joined = true;
+        }
         if (run_big) {
             LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, side0));
             LFQ_DBG_STAGE("seg big");
             LFQ_TRY(lfq_launch_dp_combine(1, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side0));
             LFQ_DBG_STAGE("combine big");
-            LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
-                                      n_big_blocks, side0));
-            LFQ_DBG_STAGE("big");
+            if (!big_on_st) {
+                LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
+                                          n_big_blocks, side0));
+                LFQ_DBG_STAGE("big");
+            }
         }
         LFQ_TRY_HIP(hipStreamWaitEvent(side1, c->ev_prep, 0));     /* K = 250..252 of the big class lands in class 1 */
         if (run_mid || run_big) {
@@ -724,6 +740,9 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], dps));
     for (int i = 0; i < 3; i++) {
         LFQ_TRY_HIP(hipStreamWaitEvent(jn, c->ev_join[i], 0));
+    }
+    if (big_joined && jn != st) {
+        LFQ_TRY_HIP(hipStreamWaitEvent(jn, c->ev_segw, 0));        /* the unsplit big columns on `st` */
     }
     if (P.lazy_strand && d_pvals && pvals_capacity > 0) {
         /* DP4 of the columns that made it into the sparse output (lofreq_call.c:853-857) */
@@ -848,7 +867,8 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
         if (hipEventElapsedTime(&ms, c->ev_side[1][s][0], c->ev_side[1][s][1]) == hipSuccess) c->times.ms_dp_mid += ms;
     }
     /* DP time that is NOT hidden under a count kernel: last count kernel's end -> everything done */
-    if (c->cur_segments > 0 && hipEventElapsedTime(&dp_end, c->ev[1], c->ev[3]) == hipSuccess) {
+    /* (the end of the last count kernel, not ev[1]: the stream of the count kernels may carry the unsplit big columns behind it) */
+    if (c->cur_segments > 0 && hipEventElapsedTime(&dp_end, c->ev_cnt[c->cur_segments - 1][1], c->ev[3]) == hipSuccess) {
         c->times.ms_dp = dp_end;
     }
     c->times.n_segments = c->cur_segments;

@@ -195,6 +195,7 @@ struct LfqKnobs {
     int segments;              /* LFQ_SEGMENTS: batch segments */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
+    int big_behind_chain;      /* LFQ_BIG_BEHIND_CHAIN: the unsplit big columns behind the split ones' kernels on their stream (before round 3) */
     int pileup_tiles;          /* LFQ_PILEUP_TILES (1): SNV pileup of sorted reads by tiles of 64 positions; 0 = a wavefront per position */
     long host_loop_threads;    /* LFQ_HOST_LOOP_THREADS (8): threads (caller included) a host loop over reads / positions / events is cut for, at most 16 */
     long sb_par_min_cost;      /* LFQ_SB_PAR_MIN_COST (20000): summed alt counts of the strand-bias tests of a batch from which they go to the host pool */
