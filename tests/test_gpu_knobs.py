@@ -32,6 +32,8 @@ CASES = [
     ("LFQ_COUNT_LPG8_BELOW=100000", DP),     # ... eight (and four for the shallowest batches)
     ("LFQ_COUNT_LPG4_BELOW=0", DP),          # ... never four
     ("LFQ_CU_SPLIT=64", DP),                 # DP streams and main stream on disjoint CU masks
+    ("LFQ_BIG_BEHIND_CHAIN=1", DP),          # unsplit big columns on the segment kernels' stream, behind them
+    ("LFQ_PILEUP_TILES=0", PLP),             # a wavefront per position instead of tiles of 64 positions
     ("LFQ_BAQ_KERNEL=1", BAQ),               # the LDS-row BAQ kernel
     ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
     ("LFQ_PILEUP_ATOMIC=1", PLP),            # read-major pileup kernels (what unsorted reads get)
