@@ -640,9 +640,6 @@ __global__ __launch_bounds__(256) void lfq_pileup_tiles_kernel(LfqPileupArgs A)
                     const uint64_t slot = base[i] + n_kept[i] + (uint64_t)__popcll(mk & ((1ull << lane) - 1ull));
                     const uint32_t code = rs[off + dp];
                     const uint32_t lb = A.baq ? rb[off + dp] : 0u;
-#ifdef LFQ_TILES_NO_STORE       /* timing experiments only: the values still have to be computed */
-                    if (slot == 0x7fffffffffffffffull) {
-#endif
                     A.t_nt[slot] = (uint8_t)((code > 4 ? 4u : code) | rev);
                     A.t_bq[slot] = (uint8_t)(bq > 93 ? 93 : bq);                                   /* plp.c:948-952 */
                     A.t_baq[slot] = A.baq ? (uint8_t)(lb >= 33 ? lb - 33 : 255) : (uint8_t)255;
@@ -650,9 +647,6 @@ __global__ __launch_bounds__(256) void lfq_pileup_tiles_kernel(LfqPileupArgs A)
                     if (A.t_sq) {
                         A.t_sq[slot] = (uint8_t)sq;
                     }
-#ifdef LFQ_TILES_NO_STORE
-                    }
-#endif
                 }
                 n_kept[i] += (uint32_t)__popcll(mk);
             }
