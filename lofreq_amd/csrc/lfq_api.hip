@@ -429,6 +429,7 @@ void lfq_destroy(lfq_ctx *c)
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
         if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);
+        if (c->d_baq_nflag) (void)hipFree(c->d_baq_nflag);
         if (c->d_baq_itab) (void)hipFree(c->d_baq_itab);
         if (c->d_baq_terms) (void)hipFree(c->d_baq_terms);
         if (c->h_tuples) (void)hipHostFree(c->h_tuples);

@@ -815,9 +815,69 @@ __device__ __forceinline__ double lfq_baq_sfin(const double (&O0)[NB + 1], const
     return sum;
 }
 
-template <int NB, bool IDAQ>
+/* Which wavefronts of a launch of lfq_baq_reg_kernel meet an N at all -- among a read's bases or in its reference window?
+ * Nearly none.  One byte per wavefront; the register kernel is instantiated twice, with and without the N case of the
+ * emission in its row bodies (the same arithmetic on the same values where there is no N, about 7 % fewer instructions
+ * per row), both are launched over the same grid, and a wavefront leaves at once in the instantiation that is not its own.
+ * Four bytes at a time: a base code is N iff it is above 3; a reference byte is none of A, C, G, T in either case iff it
+ * differs from all four after clearing bit 5 (lfq_baq_code). */
+__global__ __launch_bounds__(64) void lfq_baq_nflag_kernel(LfqBaqArgs A, int64_t n_launch)
+{
+    const int lane = (int)threadIdx.x;
+    const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
+    bool any_n = false;
+    if (ridx < n_launch) {
+        const int64_t rid = A.order ? (int64_t)A.order[A.first_read + ridx] : A.first_read + ridx;
+        const LfqBaqRead R = A.reads[rid];
+        if (R.l_qseq > 0 && R.l_ref > 0) {
+            const uint8_t *q = A.seq + A.seq_off[rid], *rp = A.ref + R.xb;
+            /* sixteen bytes per load (the base array carries 16 bytes of padding; the window's tail goes byte by byte) */
+            uint32_t bad = 0;
+            int p = 0;
+            for (; p < R.l_qseq; p += 16) {
+                uint4 v;
+                __builtin_memcpy(&v, q + p, 16);
+                const int left = R.l_qseq - p;       /* bytes of this read in the load */
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int nb = left - 4 * t;
+                    const uint32_t keep = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                    bad |= w[t] & keep & 0xFCFCFCFCu;
+                }
+            }
+            any_n = bad != 0;
+            bad = 0;
+#define LFQ_NZ(x_) ((((x_) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | (x_))    /* bit 7 of every byte that is not zero */
+            for (p = 0; p + 16 <= R.l_ref; p += 16) {       /* (the window lies inside the contig) */
+                uint4 v;
+                __builtin_memcpy(&v, rp + p, 16);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t u = w[t] & 0xDFDFDFDFu;
+                    bad |= LFQ_NZ(u ^ 0x41414141u) & LFQ_NZ(u ^ 0x43434343u) & LFQ_NZ(u ^ 0x47474747u) & LFQ_NZ(u ^ 0x54545454u);
+                }
+            }
+#undef LFQ_NZ
+            for (; p < R.l_ref; p++) {
+                any_n = any_n || lfq_baq_code(rp[p]) > 3;
+            }
+            any_n = any_n || (bad & 0x80808080u) != 0;
+        }
+    }
+    const bool wave_n = __any(any_n) != 0;
+    if (lane == 0) {
+        A.nflag[blockIdx.x] = wave_n ? 1 : 0;
+    }
+}
+
+template <int NB, bool IDAQ, bool HN = true>
 __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqArgs A, int64_t n_launch)
 {
+    if (A.nflag && (A.nflag[blockIdx.x] != 0) != HN) {
+        return;                                      /* the other instantiation's wavefront (lfq_baq_nflag_kernel) */
+    }
     typedef typename LfqBaqWinT<NB>::type WinT;
     constexpr int BWF = (NB - 1) / 2;               /* the band this instantiation holds in full */
     /* dynamic LDS: [NB][64] (match, insertion) pairs = the stored forward row the backward sweep needs next, brought in by
@@ -1012,7 +1072,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
              * four variants of the body the compiler kept the row in different registers in each and paid ~100 register
              * moves per row at the joins.  The row is stored after it is complete, from the registers it lives in. */
             (void)has_n;
-            lfq_baq_fwd_row<NB, true, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, sum);
+            lfq_baq_fwd_row<NB, HN, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, sum);
             if (store) {                             /* wave-uniform: only the even rows go to HBM */
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
@@ -1284,14 +1344,14 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             const bool has_n = c_qy > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             /* ys = 1 / s[i]: the same division as the forward pass's 1 / sum (i >= 8) */
             (void)has_n;
-            lfq_baq_bwd_row<NB, true, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
+            lfq_baq_bwd_row<NB, HN, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
             /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
             ensure_g(odd ? i - 1 : i);
             if (!odd) {
                 lfq_baq_map_row<NB, false, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
             } else {
                 (void)f_has_n;
-                lfq_baq_map_row<NB, true, true, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
+                lfq_baq_map_row<NB, true, HN, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
             }
         } else {
             /* the same arithmetic, cells outside [max(1, i - bw), min(l_ref, i + bw)] masked to 0: slots jmin .. jmax;
@@ -1326,7 +1386,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             if (!odd) {
                 lfq_baq_map_row<NB, false, false, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
             } else {
-                lfq_baq_map_row<NB, true, true, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
+                lfq_baq_map_row<NB, true, HN, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
             }
         }
         win = (win << 4) | (WinT)(unsigned)code_in;
@@ -1344,7 +1404,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 /* the row's forward cells once more, as arrays (only at the few rows where an indel of this read has a term due) */
                 double fz0[NB], fz1[NB];
                 if (odd) {
-                    lfq_baq_refwd_row<NB, true>(G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, fz0, fz1);
+                    lfq_baq_refwd_row<NB, HN>(G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, fz0, fz1);
                 } else {
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
@@ -1489,6 +1549,10 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
                 hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             } else if (a.itab) {
                 hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+            } else if (a.nflag) {
+                hipLaunchKernelGGL(lfq_baq_nflag_kernel, dim3(blocks), dim3(64), 0, st, a, n_launch);
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             } else {
                 hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             }

@@ -333,6 +333,8 @@ struct lfq_ctx {
     double *d_baq_scr;
     int32_t *d_baq_expect;
     uint8_t *d_baq_tmp8;
+    uint8_t *d_baq_nflag;            /* one byte per wavefront of the plain narrow-band launches: the wavefront meets an N */
+    int64_t baq_nflag_bytes;
     int32_t *d_baq_itab;
     double *d_baq_terms;
     int64_t baq_scr_bytes, baq_expect_bytes, baq_tmp8_bytes, baq_itab_bytes, baq_terms_bytes;

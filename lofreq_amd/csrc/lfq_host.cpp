@@ -66,6 +66,7 @@ const LfqKnobs &lfq_knobs(void)
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);
         x.pileup_tiles = (int)geti("LFQ_PILEUP_TILES", 1);
+        x.baq_one_variant = has("LFQ_BAQ_ONE_VARIANT") ? 1 : 0;
         x.big_behind_chain = has("LFQ_BIG_BEHIND_CHAIN") ? 1 : 0;
         x.count_lpg4_below = geti("LFQ_COUNT_LPG4_BELOW", 320);
         x.count_lpg8_below = geti("LFQ_COUNT_LPG8_BELOW", 900);

@@ -196,6 +196,7 @@ struct LfqKnobs {
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
     int big_behind_chain;      /* LFQ_BIG_BEHIND_CHAIN: the unsplit big columns behind the split ones' kernels on their stream (before round 3) */
+    int baq_one_variant;       /* LFQ_BAQ_ONE_VARIANT: every wavefront of the plain narrow-band BAQ launches through the instantiation with the N case */
     int pileup_tiles;          /* LFQ_PILEUP_TILES (1): SNV pileup of sorted reads by tiles of 64 positions; 0 = a wavefront per position */
     long host_loop_threads;    /* LFQ_HOST_LOOP_THREADS (8): threads (caller included) a host loop over reads / positions / events is cut for, at most 16 */
     long sb_par_min_cost;      /* LFQ_SB_PAR_MIN_COST (20000): summed alt counts of the strand-bias tests of a batch from which they go to the host pool */
@@ -261,6 +262,7 @@ struct LfqBaqArgs {
     uint8_t *tag_flags;        /* [n] bit 0: the read gets an ai tag, bit 1: an ad tag */
     int32_t *itab;             /* per wavefront: [LFQ_BAQ_MAX_INDELS][4][64] kept indels: type|qpos, k0, rep, term offset */
     double *terms;             /* per wavefront: [LFQ_BAQ_MAX_TERMS][64] posterior terms, summed in the reference's order */
+    uint8_t *nflag;            /* per wavefront of the launch: it meets an N (lfq_baq_nflag_kernel); null = one instantiation for all */
 };
 #define LFQ_BAQ_MAX_INDELS 64
 #define LFQ_BAQ_MAX_TERMS 1024

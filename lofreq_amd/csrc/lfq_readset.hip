@@ -788,6 +788,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         keep(&c->d_baq_scr, &c->baq_scr_bytes, waves * per_wave);
         keep(&c->d_baq_expect, &c->baq_expect_bytes, waves * A.rows * 64 * 4);
         keep(&c->d_baq_tmp8, &c->baq_tmp8_bytes, waves * 2 * A.rows * 64);
+        if (!lfq_knobs().baq_one_variant) {
+            keep(&c->d_baq_nflag, &c->baq_nflag_bytes, (n + 63) / 64 + 64);
+        }
         if (want_idaq) {
             keep(&c->d_baq_itab, &c->baq_itab_bytes, waves * LFQ_BAQ_MAX_INDELS * 4 * 64 * 4);
             keep(&c->d_baq_terms, &c->baq_terms_bytes, waves * (int64_t)LFQ_BAQ_MAX_TERMS * 64 * 8);
@@ -847,6 +850,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                 const int64_t cnt = std::min<int64_t>(waves_n * 64, n_plain - first);
                 rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
                 Ap.first_read = (int32_t)first;
+                /* (first is a multiple of 64: the launches are cut to whole wavefronts) */
+                Ap.nflag = (c->d_baq_nflag && !lfq_knobs().baq_one_variant) ? c->d_baq_nflag + first / 64 : nullptr;
                 if (rc == LFQ_OK) {
                     rc = lfq_launch_baq(Ap, cnt, 1, c->stream);
                 }

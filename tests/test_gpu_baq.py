@@ -223,3 +223,34 @@ def test_baq_idaq_other_hmm_parameters(caller, oracle, d, e):
             caller.set_baq_hmm_params(*bad)
     again = la.baq_batch(caller, reads, genome.encode(), extended=True, idaq=True)
     assert all(a[0].tobytes() == b[0].tobytes() for a, b in zip(again, default))
+
+
+def test_baq_wavefronts_with_and_without_n(caller, oracle):
+    """The plain narrow-band launches run two instantiations of the register kernel, chosen per wavefront by
+    lfq_baq_nflag_kernel (an N among the bases or in the reference window of any of its 64 reads).  Uniform reads in input
+    order, so that whole wavefronts fall on either side: stretches of the contig with N / lower-case / IUPAC letters, a few
+    reads with N bases elsewhere, wavefronts with neither."""
+    import lofreq_amd as la
+    rng = np.random.default_rng(23)
+    glen = 12000
+    g = list(rng.choice(list("ACGT"), glen))
+    for p0 in (500, 3100, 3101, 7777):
+        g[p0] = "N"
+    g[5000:5040] = list("acgtn" * 8)                   # lower case counts as its base, n as N
+    g[9000] = "R"                                      # any other letter is an N to the HMM
+    genome = "".join(g)
+    reads = []
+    for i in range(64 * 20):
+        pos = int(i * (glen - 200) / (64 * 20))
+        seq = [genome[pos + k].upper() if genome[pos + k].upper() in "ACGT" else "A" for k in range(100)]
+        for k in np.nonzero(rng.random(100) < 0.02)[0]:
+            seq[k] = "ACGT"[int(rng.integers(0, 4))]
+        if i in (700, 701, 1100):                      # N bases in wavefronts whose reference windows have none
+            seq[int(rng.integers(0, 100))] = "N"
+        reads.append({"pos0": pos, "cigar": [("M", 100)], "seq": la.encode_seq("".join(seq)),
+                      "qual": np.clip(np.round(rng.normal(32, 8, 100)), 2, 60).astype(np.uint8)})
+    for extended in (True, False):
+        out = la.baq_batch(caller, reads, genome.encode(), extended=extended)
+        for r, o in zip(reads, out):
+            exp = oracle.baq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), extended=extended)
+            assert o.tobytes() == exp.tobytes(), r["pos0"]

@@ -34,6 +34,7 @@ CASES = [
     ("LFQ_CU_SPLIT=64", DP),                 # DP streams and main stream on disjoint CU masks
     ("LFQ_BIG_BEHIND_CHAIN=1", DP),          # unsplit big columns on the segment kernels' stream, behind them
     ("LFQ_PILEUP_TILES=0", PLP),             # a wavefront per position instead of tiles of 64 positions
+    ("LFQ_BAQ_ONE_VARIANT=1", BAQ),          # every wavefront through the register kernel's instantiation with the N case
     ("LFQ_BAQ_KERNEL=1", BAQ),               # the LDS-row BAQ kernel
     ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
     ("LFQ_PILEUP_ATOMIC=1", PLP),            # read-major pileup kernels (what unsorted reads get)
