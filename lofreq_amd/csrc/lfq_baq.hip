@@ -622,8 +622,26 @@ __device__ __forceinline__ W lfq_baq_nibbles(unsigned v)        /* v in each of 
     return w;
 }
 struct alignas(16) LfqBaqPair {
-    double m, i;
+    double x, y;
 };
+/* A stored forward row in HBM (and in its LDS staging buffer): NB slots of 64 lanes x 16 bytes.  Slot t < NB / 2 holds the
+ * match cells 2 t and 2 t + 1, slot NB / 2 the match and the insertion cell NB - 1, the slots after it the insertion cells
+ * 2 t and 2 t + 1: the row arrays live in consecutive registers, so a pair of NEIGHBOURING cells of one array is a 16-byte
+ * store straight from where it was computed (the (match, insertion) pair of one cell cost four register moves per store). */
+template <int NB>
+__device__ __forceinline__ void lfq_baq_store_row(LfqBaqPair *fp, const double (&O0)[NB + 1], const double (&O1)[NB + 1])
+{
+    constexpr int H = NB / 2;
+#pragma unroll
+    for (int t = 0; t < H; t++) {
+        fp[(size_t)t * 64] = LfqBaqPair{O0[2 * t], O0[2 * t + 1]};
+    }
+    fp[(size_t)H * 64] = LfqBaqPair{O0[NB - 1], O1[NB - 1]};
+#pragma unroll
+    for (int t = 0; t < H; t++) {
+        fp[(size_t)(H + 1 + t) * 64] = LfqBaqPair{O1[2 * t], O1[2 * t + 1]};
+    }
+}
 /* One wavefront per SIMD: the interior row needs ~330 registers (45 + 30 doubles of rows, the transition matrix,
  * the prefetch batches), which the unified 512-entry file of gfx950 holds (256 VGPRs + AGPRs as the overflow).  At two
  * wavefronts per SIMD (256 in all) the row loops spill into scratch, whose reloads queue behind the forward matrix's
@@ -631,16 +649,26 @@ struct alignas(16) LfqBaqPair {
  * still 203 spilled at 256, 364 B of scratch per lane -- not taken.) */
 #define LFQ_BAQ_WAVES 1
 
+#define LFQ_NZ(x_) ((((x_) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | (x_))    /* bit 7 of every byte that is not zero */
+/* lfq_baq_code of the four ASCII bytes of a dword as four 4-bit fields, without a branch: a byte is A, C, G or T in either
+ * case iff it equals the letter after clearing bit 5 */
+__device__ __forceinline__ uint32_t lfq_baq_codes4(uint32_t v)
+{
+    const uint32_t u = v & 0xDFDFDFDFu;
+    const uint32_t na = LFQ_NZ(u ^ 0x41414141u), nc = LFQ_NZ(u ^ 0x43434343u);
+    const uint32_t ng = LFQ_NZ(u ^ 0x47474747u), nt = LFQ_NZ(u ^ 0x54545454u);
+    const uint32_t ec = ~nc & 0x80808080u, eg = ~ng & 0x80808080u, et = ~nt & 0x80808080u;
+    const uint32_t none = na & nc & ng & nt & 0x80808080u;
+    const uint32_t cb = (ec >> 7) | (eg >> 6) | (et >> 7) | (et >> 6) | (none >> 5);   /* 1, 2, 3, 4 (A: 0) per byte */
+    const uint32_t y = (cb | (cb >> 4)) & 0x00FF00FFu;
+    return (y | (y >> 8)) & 0xFFFFu;
+}
 /* sixteen 4-bit base codes out of four ASCII dwords (byte t of dword d = code 4 d + t) */
 __device__ __forceinline__ unsigned long long lfq_baq_pack16(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3)
 {
-    const uint32_t d[4] = {d0, d1, d2, d3};
-    unsigned long long w = 0;
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-        w |= (unsigned long long)lfq_baq_code((int)((d[t >> 2] >> (8 * (t & 3))) & 0xffu)) << (4 * t);
-    }
-    return w;
+    const uint32_t lo = lfq_baq_codes4(d0) | (lfq_baq_codes4(d1) << 16);
+    const uint32_t hi = lfq_baq_codes4(d2) | (lfq_baq_codes4(d3) << 16);
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
 }
 
 /* the ASCII bytes of reference positions p .. p + 3 of a read's window (1-based; 'N' outside 1 .. l_ref) */
@@ -848,7 +876,6 @@ __global__ __launch_bounds__(64) void lfq_baq_nflag_kernel(LfqBaqArgs A, int64_t
             }
             any_n = bad != 0;
             bad = 0;
-#define LFQ_NZ(x_) ((((x_) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | (x_))    /* bit 7 of every byte that is not zero */
             for (p = 0; p + 16 <= R.l_ref; p += 16) {       /* (the window lies inside the contig) */
                 uint4 v;
                 __builtin_memcpy(&v, rp + p, 16);
@@ -895,8 +922,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     double *F = A.scratch + (size_t)blockIdx.x * ((size_t)rows * W + 2 * (size_t)W + 2 * ((size_t)rows + 2)) * 64;
     double *S = F + (size_t)rows * W * 64 + 2 * (size_t)W * 64;
     int32_t *expect = A.expect + (size_t)blockIdx.x * rows * 64;
-    /* forward row i in the scratch: (match, insertion) of slot j as one 16-byte pair at pair index j and the deletion
-     * cells are not stored: the few an indel's quality needs are recomputed from the row's match cells */
+    /* forward row i in the scratch: the match and insertion cells as 16-byte pairs in the slot order of lfq_baq_store_row;
+     * the deletion cells are not stored: the few an indel's quality needs are recomputed from the row's match cells */
 #define FP(i_) ((LfqBaqPair *)(F + (size_t)(i_) * W * 64) + lane)
 #define SQ(i_) S[(size_t)(i_) * 64 + lane]
 #define RQ(i_) S[(size_t)(rows + 2 + (i_)) * 64 + lane]
@@ -1017,9 +1044,9 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             if (j < bw2 && k >= 1 && k <= end) {
                 O0[j] = O0[j] / sum;
                 O1[j] = O1[j] / sum;
-                FP(1)[(size_t)j * 64] = LfqBaqPair{O0[j], O1[j]};
             }
         }
+        lfq_baq_store_row<NB>(FP(1), O0, O1);        /* cells the row does not have: 0., never looked at */
     }
     /* codes of reference positions i - bw .. i - bw + NB of the row about to be computed, 4 bits each (slot j = nibble j,
      * nibble NB = the code that becomes slot NB - 1 of the next row); the code that enters after row i (position
@@ -1074,10 +1101,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             (void)has_n;
             lfq_baq_fwd_row<NB, HN, IDAQ>(O0, O1, O2, win, qyi, e_eq, e_ne, rs, m, sum);
             if (store) {                             /* wave-uniform: only the even rows go to HBM */
-#pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    fp[(size_t)j * 64] = LfqBaqPair{O0[j], O1[j]};
-                }
+                lfq_baq_store_row<NB>(fp, O0, O1);
             }
         } else {
             /* the same arithmetic with the cells beyond the end of the reference masked out.  Cells before its start
@@ -1095,15 +1119,15 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
                 const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
                 const double f2 = m[2] * m_prev + m[8] * d_prev;
-                if (valid && store) {
-                    fp[(size_t)j * 64] = LfqBaqPair{f0, f1};
-                }
                 m_prev = f0;
                 d_prev = f2;
                 sum += valid ? f0 + f1 + f2 : 0.;    /* + 0. leaves the sum as it is */
                 O0[j] = valid ? f0 : 0.;
                 O1[j] = valid ? f1 : 0.;
                 O2[j] = valid ? f2 : 0.;
+            }
+            if (store) {                             /* the whole row, 0. where it has no cell (every reader masks those) */
+                lfq_baq_store_row<NB>(fp, O0, O1);
             }
         }
         win = (win >> 4) | ((WinT)(unsigned)code_in << (4 * NB));
@@ -1295,10 +1319,17 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         if (need != g_have) {
             __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(0): the row has landed in LDS */
 #pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const LfqBaqPair v = s_g[j * 64 + lane];
-                G0[j] = v.m;
-                G1[j] = v.i;
+            for (int t = 0; t < NB / 2; t++) {       /* the slots of lfq_baq_store_row */
+                const LfqBaqPair v = s_g[t * 64 + lane], w = s_g[(NB / 2 + 1 + t) * 64 + lane];
+                G0[2 * t] = v.x;
+                G0[2 * t + 1] = v.y;
+                G1[2 * t] = w.x;
+                G1[2 * t + 1] = w.y;
+            }
+            {
+                const LfqBaqPair v = s_g[(NB / 2) * 64 + lane];
+                G0[NB - 1] = v.x;
+                G1[NB - 1] = v.y;
             }
             g_have = need;
             const int next = need == 2 ? 1 : need - 2;
