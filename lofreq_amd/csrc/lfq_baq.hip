@@ -17,6 +17,7 @@
  *
  * -ffp-contract=off (Makefile): no FMA contraction, every operation rounds like the reference's SSE2 build.
  */
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -912,6 +913,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
      * row i, later the BAQ bytes */
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     LfqBaqPair *const s_g = reinterpret_cast<LfqBaqPair *>(s_dyn);
+    __attribute__((address_space(3))) unsigned char *const s_g_lds = (__attribute__((address_space(3))) unsigned char *)s_dyn;
     uint16_t *const s_rowq = reinterpret_cast<uint16_t *>(s_dyn + (size_t)NB * 64 * sizeof(LfqBaqPair));
     const int lane = (int)threadIdx.x;
     const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
@@ -1078,7 +1080,11 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     if (l_query == 1) {
         s_fin = lfq_baq_sfin<NB>(O0, O1, 1., sM, sI, l_query, l_ref, bw);
     }
-    for (int i = 2; i <= Lmax; ++i) {
+    /* One row of the forward pass; INTERIOR: all 15 cells for every read of the wavefront.  The interior rows run in a loop
+     * of their own below: with both bodies in one loop the row arrays met in different registers at its end and every row
+     * paid ~30 register copies for it. */
+    auto fwd_step = [&](const int i, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
         double sum = 0.;
         const double qli = ql_next;
         const double rs = rs_next;                   /* pending scale of row i-1 */
@@ -1093,7 +1099,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #else
         const bool store = (i & 1) == 0;             /* odd rows >= 3 are recomputed by the backward sweep (lfq_baq_refwd_row) */
 #endif
-        if (i >= BWF + 1 && i <= f_hi) {                   /* interior row: all 15 cells, for every read of the wavefront */
+        if constexpr (INTERIOR) {                    /* interior row: all 15 cells, for every read of the wavefront */
             const bool has_n = qyi > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             /* ONE instantiation of the row (the N case always handled: a handful of instructions per slot): with two or
              * four variants of the body the compiler kept the row in different registers in each and paid ~100 register
@@ -1148,6 +1154,17 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         if (__any(i == l_query)) {                   /* some read's last row: its s[l_query + 1] while the row is there */
             const double v = lfq_baq_sfin<NB>(O0, O1, rs_next, sM, sI, l_query, l_ref, bw);
             s_fin = i == l_query ? v : s_fin;
+        }
+    };
+    for (int i = 2; i <= Lmax;) {
+        if (i >= BWF + 1 && i <= f_hi) {
+            do {
+                fwd_step(i, std::true_type{});
+                ++i;
+            } while (i <= f_hi);
+        } else {
+            fwd_step(i, std::false_type{});
+            ++i;
         }
     }
 
@@ -1312,7 +1329,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)j * 64),
-                                             (__attribute__((address_space(3))) void *)(s_g + j * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(s_g_lds + j * 64 * sizeof(LfqBaqPair)), 16, 0, 0);
         }
     };
     auto ensure_g = [&](int need) {                  /* need: wave-uniform */
@@ -1339,8 +1356,9 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
             }
         }
     };
-    dma_row(((Lmax & 1) == 0 || Lmax == 1) ? Lmax : Lmax - 1);
-    for (int i = Lmax; i >= 1; --i) {
+    const int Lsw = __builtin_amdgcn_readfirstlane(Lmax);   /* the same in every lane: the sweep's counter is scalar */
+    dma_row(((Lsw & 1) == 0 || Lsw == 1) ? Lsw : Lsw - 1);
+    for (int i = Lsw; i >= 1; --i) {
         const int t4 = i & 3;
         const double c_r = t4 == 0 ? rA0 : (t4 == 1 ? rA1 : (t4 == 2 ? rA2 : rA3));           /* 1 / s[i] */
         const int c_ex = t4 == 0 ? eA0 : (t4 == 1 ? eA1 : (t4 == 2 ? eA2 : eA3));
