@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     /* One row of the forward pass; INTERIOR: all 15 cells for every read of the wavefront.  The interior rows run in a loop
      * of their own below: with both bodies in one loop the row arrays met in different registers at its end and every row
      * paid ~30 register copies for it. */
-    auto fwd_step = [&](const int i, auto interior_tag) {
+    auto fwd_step = [&](const int i, auto interior_tag) __attribute__((always_inline)) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         double sum = 0.;
         const double qli = ql_next;
@@ -1324,189 +1324,57 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
      * free again and the stored row after it is requested. */
     double G0[NB], G1[NB];
     int g_have = -1;
-    auto dma_row = [&](int row) {
-        const LfqBaqPair *gp = FP(row);
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)j * 64),
-                                             (__attribute__((address_space(3))) void *)(s_g_lds + j * 64 * sizeof(LfqBaqPair)), 16, 0, 0);
-        }
-    };
-    auto ensure_g = [&](int need) {                  /* need: wave-uniform */
-        if (need != g_have) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(0): the row has landed in LDS */
-#pragma unroll
-            for (int t = 0; t < NB / 2; t++) {       /* the slots of lfq_baq_store_row */
-                const LfqBaqPair v = s_g[t * 64 + lane], w = s_g[(NB / 2 + 1 + t) * 64 + lane];
-                G0[2 * t] = v.x;
-                G0[2 * t + 1] = v.y;
-                G1[2 * t] = w.x;
-                G1[2 * t + 1] = w.y;
-            }
-            {
-                const LfqBaqPair v = s_g[(NB / 2) * 64 + lane];
-                G0[NB - 1] = v.x;
-                G1[NB - 1] = v.y;
-            }
-            g_have = need;
-            const int next = need == 2 ? 1 : need - 2;
-            if (next >= 1) {
-                __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): the reads above are done with the buffer */
-                dma_row(next);
-            }
-        }
-    };
+    /* (macros, not lambdas: a closure called from inside the row lambda below kept the row arrays in scratch memory) */
+#define LFQ_BAQ_DMA_ROW(row_) do { \
+        const LfqBaqPair *gp_ = FP(row_); \
+        _Pragma("unroll") \
+        for (int j_ = 0; j_ < NB; j_++) { \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp_ + (size_t)j_ * 64), \
+                                             (__attribute__((address_space(3))) void *)(s_g_lds + j_ * 64 * sizeof(LfqBaqPair)), 16, 0, 0); \
+        } \
+    } while (0)
+#define LFQ_BAQ_ENSURE_G(need_) do {                 /* need_: wave-uniform */ \
+        const int need__ = (need_); \
+        if (need__ != g_have) { \
+            __builtin_amdgcn_s_waitcnt(0x0F70);      /* vmcnt(0): the row has landed in LDS */ \
+            _Pragma("unroll") \
+            for (int t_ = 0; t_ < NB / 2; t_++) {    /* the slots of lfq_baq_store_row */ \
+                const LfqBaqPair v_ = s_g[t_ * 64 + lane], w_ = s_g[(NB / 2 + 1 + t_) * 64 + lane]; \
+                G0[2 * t_] = v_.x; \
+                G0[2 * t_ + 1] = v_.y; \
+                G1[2 * t_] = w_.x; \
+                G1[2 * t_ + 1] = w_.y; \
+            } \
+            { \
+                const LfqBaqPair v_ = s_g[(NB / 2) * 64 + lane]; \
+                G0[NB - 1] = v_.x; \
+                G1[NB - 1] = v_.y; \
+            } \
+            g_have = need__; \
+            const int next_ = need__ == 2 ? 1 : need__ - 2; \
+            if (next_ >= 1) { \
+                __builtin_amdgcn_s_waitcnt(0xC07F);  /* lgkmcnt(0): the reads above are done with the buffer */ \
+                LFQ_BAQ_DMA_ROW(next_); \
+            } \
+        } \
+    } while (0)
     const int Lsw = __builtin_amdgcn_readfirstlane(Lmax);   /* the same in every lane: the sweep's counter is scalar */
-    dma_row(((Lsw & 1) == 0 || Lsw == 1) ? Lsw : Lsw - 1);
-    for (int i = Lsw; i >= 1; --i) {
-        const int t4 = i & 3;
-        const double c_r = t4 == 0 ? rA0 : (t4 == 1 ? rA1 : (t4 == 2 ? rA2 : rA3));           /* 1 / s[i] */
-        const int c_ex = t4 == 0 ? eA0 : (t4 == 1 ? eA1 : (t4 == 2 ? eA2 : eA3));
-        if (t4 == 0) {                               /* row i - 1 opens the next batch */
-            rA0 = rB0; rA1 = rB1; rA2 = rB2; rA3 = rB3;
-            eA0 = eB0; eA1 = eB1; eA2 = eB2; eA3 = eB3;
-            LFQ_BAQ_BATCH((i >> 2) - 2, rB0, rB1, rB2, rB3, eB0, eB1, eB2, eB3);
-        }
-        const int rq_up = ROWQ(i + 1), c_iq = ROWQ(i) >> 8;
-        const int c_qy = rq_up & 0xff;               /* query[i + 1] */
-        const double c_ql = s_q2p[rq_up >> 8];
-        const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);
-        const bool on = i <= l_query;
-        const double e_eq = 1. - c_ql, e_ne = c_ql * LFQ_BAQ_EM;
-        double sum = 0., max = 0.;
-        int max_u = -1;                              /* 4 j + state of the maximum */
-        const double rsi = c_r;
-        /* The forward cells the MAP step needs.  A stored row (even, or row 1): G is this row.  An odd row >= 3: its cells
-         * are recomputed slot by slot inside the MAP loop from the stored row below (G = row i - 1) with the forward
-         * pass's own operations (lfq_baq_map_row<ODD>).  The forward window of row i (positions i - bw ..) is the backward
-         * window one base further down; the pending scale of row i - 1 is 1 / s[i - 1], which sits in the same batch of
-         * four (i odd: i & 3 is 1 or 3). */
-        const bool odd = (i & 1) != 0 && i >= 3;
-        const WinT fwin = (win << 4) | (WinT)(unsigned)code_in;
-        const int rq_i = ROWQ(i);
-        const int f_qy = rq_i & 0xff;
-        const double f_ql = s_q2p[rq_i >> 8];
-        const double f_eq = 1. - f_ql, f_ne = f_ql * LFQ_BAQ_EM;
-        const double f_rs = (i & 3) == 1 ? rA0 : rA2;
-        const bool f_has_n = __any(f_qy > 3 || (fwin & lfq_baq_nibbles<NB, WinT>(4u)) != 0) != 0;
-        if (i >= BWF + 1 && i <= b_hi) {                   /* interior row */
-            const bool has_n = c_qy > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
-            /* ys = 1 / s[i]: the same division as the forward pass's 1 / sum (i >= 8) */
-            (void)has_n;
-            lfq_baq_bwd_row<NB, HN, IDAQ>(O0, O1, O2, win, c_qy, e_eq, e_ne, c_r, m);
-            /* MAP of row i: the cells in ascending k, match before insertion; the first maximum wins (z > max) */
-            ensure_g(odd ? i - 1 : i);
-            if (!odd) {
-                lfq_baq_map_row<NB, false, false, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
-            } else {
-                (void)f_has_n;
-                lfq_baq_map_row<NB, true, HN, false>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, 0, NB - 1, sum, max, max_u);
-            }
+    LFQ_BAQ_DMA_ROW(((Lsw & 1) == 0 || Lsw == 1) ? Lsw : Lsw - 1);
+    /* one row of the backward sweep: lfq_baq_sweep_row.inc; the interior rows in a loop of their own, like the forward
+     * pass's */
+    for (int i = Lsw; i >= 1;) {
+        if (i >= BWF + 1 && i <= b_hi) {
+            do {
+#define LFQ_BAQ_ROW_INTERIOR 1
+#include "lfq_baq_sweep_row.inc"
+#undef LFQ_BAQ_ROW_INTERIOR
+                --i;
+            } while (i >= BWF + 1);
         } else {
-            /* the same arithmetic, cells outside [max(1, i - bw), min(l_ref, i + bw)] masked to 0: slots jmin .. jmax;
-             * a read that is not at this row yet (i > l_query) has none, one at its last row takes the start values */
-            const int jmin = bw - i + 1 > 0 ? bw - i + 1 : 0;
-            const int jmax = on ? (l_ref - i + bw < 2 * bw ? l_ref - i + bw : 2 * bw) : -1;
-            const int jz = l_ref - i + bw;           /* k >= l_ref: no emission beyond the last reference base (:226) */
-            const bool last = i == l_query;
-            const double y = (i > 1);
-            const double ys = i == 1 ? 1. / s_row1 : c_r;                /* 1. / s[i]; RQ(1) is row 1's pending scale, 1. */
-            const int xl = l_query - bw > 0 ? l_query - bw : 0;
-            double d01 = 0.;
-#pragma unroll
-            for (int j = NB - 1; j >= 0; --j) {
-                const bool valid = j >= jmin && j <= jmax;
-                const int r = (int)((unsigned)(win >> (4 * j)) & 15u);
-                const double em = (r > 3 || c_qy > 3) ? 1. : (r == c_qy ? e_eq : e_ne);
-                const double o101 = j > 0 ? O1[j > 0 ? j - 1 : 0] : 0.;
-                const double e = (j >= jz ? 0 : em) * O0[j];
-                const double b0 = e * m[0] + LFQ_BAQ_EI * m[1] * o101 + m[2] * d01;
-                const double b1 = e * m[3] + LFQ_BAQ_EI * m[4] * o101;
-                const double b2 = (e * m[6] + m[8] * d01) * y;
-                /* the last row of a read: the start values (:206-214) on the cells within the band limits */
-                const int k = i - bw + j;
-                const bool in = valid && k >= xl && k <= xl + 2 * bw;
-                d01 = valid ? b2 : 0.;
-                O0[j] = last ? (in ? b_init0 : 0.) : (valid ? b0 * ys : 0.);
-                O1[j] = last ? (in ? b_init1 : 0.) : (valid ? b1 * ys : 0.);
-                O2[j] = last ? 0. : (valid ? b2 * ys : 0.);
-            }
-            ensure_g(odd ? i - 1 : i);
-            if (!odd) {
-                lfq_baq_map_row<NB, false, false, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
-            } else {
-                lfq_baq_map_row<NB, true, HN, true>(O0, O1, G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, rsi, jmin, jmax, sum, max, max_u);
-            }
-        }
-        win = (win << 4) | (WinT)(unsigned)code_in;
-        if ((i & 15) == 0) {
-            nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
-            const int p = i - 32 - bw;               /* rows i - 32 .. i - 17 */
-            pd0 = lfq_baq_ref4(refw, p, l_ref); pd1 = lfq_baq_ref4(refw, p + 4, l_ref);
-            pd2 = lfq_baq_ref4(refw, p + 8, l_ref); pd3 = lfq_baq_ref4(refw, p + 12, l_ref);
-        }
-        if (on) {
-            const int max_k = max_u < 0 ? -1 : ((i - bw - 1) << 2) + max_u;
-            /* (the table sits in the scratch: the loop over it runs only at the few rows where this read has a term due,
-             * not as a chain of dependent loads in every row) */
-            if (IDAQ && i >= it_lo && i <= it_hi) {
-                /* the row's forward cells once more, as arrays (only at the few rows where an indel of this read has a term due) */
-                double fz0[NB], fz1[NB];
-                if (odd) {
-                    lfq_baq_refwd_row<NB, HN>(G0, G1, fwin, f_qy, f_eq, f_ne, f_rs, m, fz0, fz1);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NB; j++) {
-                        fz0[j] = G0[j];
-                        fz1[j] = G1[j];
-                    }
-                }
-                int beg = 1, end = l_ref, x;
-                x = i - bw; beg = beg > x ? beg : x;
-                x = i + bw; end = end < x ? end : x;
-                for (int e = 0; e < n_tab; e++) {   /* pd cells of this row that an indel needs (:147-163, :207-224) */
-                    const int t0 = IT(e, 0), is_del = t0 & 1, qpos = t0 >> 1;
-                    const int jj = is_del ? i - qpos : i - qpos - 1;
-                    if (jj < 0 || jj >= IT(e, 2)) continue;
-                    const int kk = IT(e, 1) + jj;
-                    const int xx = i - bw > 0 ? i - bw : 0;
-                    const int u = (kk - xx + 1) * 3;
-                    if (u < 3 || u >= bw2 * 3 + 3) continue;                  /* u_within_limits */
-                    const int st = is_del ? 2 : 1;
-                    double term = 0.;            /* outside the band of row i the reference's matrices hold 0 (calloc) */
-                    if (kk >= beg && kk <= end) {
-                        const int js = kk - (i - bw);
-                        double bcell = 0.;
-#pragma unroll
-                        for (int j = 0; j < NB; j++) {   /* the row is in registers: pick the slot without indexing them */
-                            bcell = (j == js) ? (st == 2 ? O2[j] : O1[j]) : bcell;
-                        }
-                        /* the forward cell: the insertion cell is among the row's cells loaded for the MAP step; a
-                         * deletion cell is recomputed from the row's match cells, f2(k) = m2 f0(k-1) + m8 f2(k-1) from
-                         * 0 at the left end of the band -- the operations of the forward pass on the values it stored
-                         * (row 1 has no deletion cells: kprobaln_ext.c:141-157 leaves them 0) */
-                        double fcell = 0., mp_ = 0., dp_ = 0.;
-#pragma unroll
-                        for (int j = 0; j < NB; j++) {
-                            const double f2j = m[2] * mp_ + m[8] * dp_;
-                            fcell = (j == js) ? (st == 2 ? (i > 1 ? f2j : 0.) : fz1[j]) : fcell;
-                            mp_ = fz0[j];
-                            dp_ = f2j;
-                        }
-                        term = (fcell * rsi) * bcell * SQ(i);
-                    }
-                    TM(IT(e, 3) + jj) = term;
-                }
-            }
-            max /= sum;
-            int qk = (int)(-4.343 * log(1. - max) + .499);
-            qk = qk > 100 ? 99 : qk;
-            int bq = c_iq;
-            if (c_ex != INT32_MIN) {
-                const bool off = (max_k & 3) != 0 || (max_k >> 2) != c_ex;
-                bq = A.baq_extended ? (off ? 0 : qk) : qk;
-            }
-            s_rowq[(size_t)(i + 1) * 64 + lane] = (uint16_t)bq;      /* out[i - 1]: the slot of row i + 1 is free now */
+#define LFQ_BAQ_ROW_INTERIOR 0
+#include "lfq_baq_sweep_row.inc"
+#undef LFQ_BAQ_ROW_INTERIOR
+            --i;
         }
     }
 #define OUTE(i0_) s_rowq[(size_t)((i0_) + 2) * 64 + lane]
@@ -1577,6 +1445,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 #undef OUTE
 #undef LFQ_BAQ_BATCH
 #undef LFQ_BAQ_CLAMP
+#undef LFQ_BAQ_DMA_ROW
+#undef LFQ_BAQ_ENSURE_G
 }
 
 /* lds: 0 = the all-HBM kernel (any band), 1 = band <= 7 (rows in registers / LDS), 2 = band 8 (rows in registers) */
