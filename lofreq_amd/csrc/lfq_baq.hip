@@ -926,7 +926,10 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     int32_t *expect = A.expect + (size_t)blockIdx.x * rows * 64;
     /* forward row i in the scratch: the match and insertion cells as 16-byte pairs in the slot order of lfq_baq_store_row;
      * the deletion cells are not stored: the few an indel's quality needs are recomputed from the row's match cells */
-#define FP(i_) ((LfqBaqPair *)(F + (size_t)(i_) * W * 64) + lane)
+    /* (only row 1 and the even rows are stored: row i sits at index i >> 1, NB pairs apart -- a wavefront's forward matrix is
+     * one dense run of (rows / 2 + 1) x NB KiB at the start of its scratch slot, which is sized for the all-HBM kernel's rows;
+     * the pitch of the rows -- 15, 16, 25.5 KiB, every row or every second -- makes no difference in time) */
+#define FP(i_) ((LfqBaqPair *)(F + (size_t)((i_) >> 1) * (2 * NB) * 64) + lane)
 #define SQ(i_) S[(size_t)(i_) * 64 + lane]
 #define RQ(i_) S[(size_t)(rows + 2 + (i_)) * 64 + lane]
 #define ROWQ(i_) ((int)s_rowq[(size_t)(i_) * 64 + lane])
@@ -1140,8 +1143,12 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         if ((i & 15) == 15) {                        /* the next 16 codes have had 16 rows to arrive; request the ones after */
             nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
             const int p = i + 18 + NB - bw;          /* row i + 17's code: position (i + 17) - bw + NB + 1 */
+#ifdef LFQ_BAQ_TEST_NOPD                            /* timing experiment: no loads in the forward loop (wrong results) */
+            pd0 = 0x41434754u + (uint32_t)p; pd1 = pd0 ^ 0x02020202u; pd2 = pd0; pd3 = pd1;
+#else
             pd0 = lfq_baq_ref4(refw, p, l_ref); pd1 = lfq_baq_ref4(refw, p + 4, l_ref);
             pd2 = lfq_baq_ref4(refw, p + 8, l_ref); pd3 = lfq_baq_ref4(refw, p + 12, l_ref);
+#endif
         }
         if (i <= l_query) {
             if (IDAQ) {
