@@ -214,15 +214,31 @@ static void lfq_for_reads(int64_t n, F f, int *parts_out = nullptr)
     }
 }
 
+/* std::vector whose resize() leaves new elements of a trivial type uninitialised: the per-region column arrays (tens of MB)
+ * are resized by one thread and then written in full by the pool's threads -- value-initialising them first was a serial
+ * memset of every array, milliseconds per region. */
+template <class T>
+struct LfqNoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef LfqNoInitAlloc<U> other; };
+    LfqNoInitAlloc() = default;
+    template <class U> LfqNoInitAlloc(const LfqNoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class A0, class... Args> void construct(U *p, A0 &&a0, Args &&...args)
+    {
+        ::new ((void *)p) U(std::forward<A0>(a0), std::forward<Args>(args)...);
+    }
+};
+template <class T> using LfqVec = std::vector<T, LfqNoInitAlloc<T>>;
+
 struct LfqIndelColsOwned {
     lfq_indel_columns cols;
-    std::vector<uint8_t> ref_base, cons_indel;
-    std::vector<int32_t> cov, tails, non_indels, n_ins, n_dels, hrun;
+    LfqVec<uint8_t> ref_base, cons_indel;
+    LfqVec<int32_t> cov, tails, non_indels, n_ins, n_dels, hrun;
     struct Side {
-        std::vector<int32_t> non_fw, non_rv, ev_fw, ev_rv;
-        std::vector<int64_t> ne_off, ev_off, key_off, rd_off;
-        std::vector<int16_t> ne_q, ne_mq, rd_q, rd_aq, rd_mq, rd_sq;
-        std::vector<char> key_chars;
+        LfqVec<int32_t> non_fw, non_rv, ev_fw, ev_rv;
+        LfqVec<int64_t> ne_off, ev_off, key_off, rd_off;
+        LfqVec<int16_t> ne_q, ne_mq, rd_q, rd_aq, rd_mq, rd_sq;
+        LfqVec<char> key_chars;
     } side[2];
     void reset()
     {

@@ -59,6 +59,7 @@ static void rs_cache_give(lfq_ctx *c, int kind, void *p, size_t cap)
     }
 }
 
+#define LFQ_UP_CHUNKS 6
 struct lfq_readset {
     lfq_ctx *c;
     size_t cap[5];                      /* capacities of blob, tag_blob, d_pmax, d_tagfl, h_fl_pin (rs_cache_*) */
@@ -88,14 +89,16 @@ struct lfq_readset {
      * every step calls readset_upload_wait before its first device operation on the read set */
     std::thread *up_thread;
     std::atomic<int> up_stage;          /* 1: everything but BI / BD has landed (what lfq_readset_baq reads), 2: all of it */
-    std::atomic<int> up_chunks;         /* bases + qualities of the reads [0, n * up_chunks / up_nchunks) have landed */
+    std::atomic<int> up_chunks;         /* bases + qualities of the reads [0, up_bound[up_chunks]) have landed */
     int up_nchunks;
+    int64_t up_bound[LFQ_UP_CHUNKS + 1]; /* chunk j = reads [up_bound[j], up_bound[j + 1]); the first one is small: one round
+                                          * of the BAQ kernel over the SIMDs, so that its first launch starts early */
     std::atomic<int> up_rc;        /* written by the helper thread at the end of each stage */
     LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
     /* Pinned caller arrays (lfq_host_alloc): the copies are DMA transfers queued by lfq_readset_create itself, and what
      * waits for them is a STREAM, not the host -- events instead of the helper thread's progress counters */
     bool up_events;
-    hipEvent_t ev_chunk[4];             /* bases + qualities of the reads up to chunk j have landed */
+    hipEvent_t ev_chunk[LFQ_UP_CHUNKS]; /* bases + qualities of the reads up to chunk j have landed */
     hipEvent_t ev_stage[2];             /* [0]: everything but BI / BD, [1]: all of it */
 };
 
@@ -127,7 +130,7 @@ static int readset_upload_wait_reads(lfq_readset *rs, int64_t r_last, hipStream_
 {
     if (rs && (rs->up_thread || rs->up_events)) {
         int need = 1;
-        while (need < rs->up_nchunks && rs->n * need / rs->up_nchunks <= r_last) {
+        while (need < rs->up_nchunks && rs->up_bound[need] <= r_last) {
             need++;
         }
         if (rs->up_events) {
@@ -201,7 +204,8 @@ void lfq_readset_destroy(lfq_readset *rs)
         (void)readset_baq_wait(rs);
         if (rs->ev_baq) (void)hipEventDestroy(rs->ev_baq);
         (void)hipStreamSynchronize(rs->c->stream);      /* nothing queued may still use what goes back to the cache */
-        for (hipEvent_t e : {rs->ev_chunk[0], rs->ev_chunk[1], rs->ev_chunk[2], rs->ev_chunk[3], rs->ev_stage[0], rs->ev_stage[1]}) {
+        for (hipEvent_t e : {rs->ev_chunk[0], rs->ev_chunk[1], rs->ev_chunk[2], rs->ev_chunk[3], rs->ev_chunk[4], rs->ev_chunk[5],
+                             rs->ev_stage[0], rs->ev_stage[1]}) {
             if (e) (void)hipEventDestroy(e);
         }
         rs_cache_give(rs->c, LFQ_RSC_PINFL, rs->h_fl_pin, rs->cap[LFQ_RSC_PINFL]);
@@ -311,10 +315,24 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     add(rs->d_lb, rd->baq, nb);
     add(rs->d_sqb, rd->sq, n);
     add(rs->d_fl, rs->up_fl->data(), n);
-    const int n_chunks = nb >= ((int64_t)64 << 20) ? 4 : 1;
+    /* chunks of reads: a small first one -- the reads of one round of the BAQ register kernel over the SIMDs (one wavefront
+     * of 64 reads each), what lfq_readset_baq's first launch takes -- and the rest in equal parts */
+    const int64_t first_reads = (int64_t)c->n_cu * 4 * 64;
+    const int n_chunks = nb >= ((int64_t)64 << 20) ? (n >= 8 * first_reads ? LFQ_UP_CHUNKS : 4) : 1;
     rs->up_nchunks = n_chunks;
+    rs->up_bound[0] = 0;
+    if (n_chunks == LFQ_UP_CHUNKS) {
+        rs->up_bound[1] = first_reads;
+        for (int j = 2; j <= n_chunks; j++) {
+            rs->up_bound[j] = first_reads + (n - first_reads) * (j - 1) / (n_chunks - 1);
+        }
+    } else {
+        for (int j = 1; j <= n_chunks; j++) {
+            rs->up_bound[j] = n * j / n_chunks;
+        }
+    }
     for (int j = 0; j < n_chunks; j++) {
-        const int64_t b0 = rd->seq_off[n * j / n_chunks], b1 = rd->seq_off[n * (j + 1) / n_chunks];
+        const int64_t b0 = rd->seq_off[rs->up_bound[j]], b1 = rd->seq_off[rs->up_bound[j + 1]];
         add(rs->d_seq + b0, rd->seq + b0, b1 - b0);
         add(rs->d_qual + b0, rd->qual ? rd->qual + b0 : nullptr, b1 - b0);
         if (!todo.empty()) {
@@ -364,8 +382,8 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
         /* the big arrays are pinned: every copy is queued right here (the small pageable ones, if any, are staged by the
          * runtime inside the call), events mark the stages, and nothing on the host ever waits for the link */
         int rc = LFQ_OK;
-        for (int j = 0; j < 6 && rc == LFQ_OK; j++) {
-            hipEvent_t *e = j < 4 ? &rs->ev_chunk[j] : &rs->ev_stage[j - 4];
+        for (int j = 0; j < LFQ_UP_CHUNKS + 2 && rc == LFQ_OK; j++) {
+            hipEvent_t *e = j < LFQ_UP_CHUNKS ? &rs->ev_chunk[j] : &rs->ev_stage[j - LFQ_UP_CHUNKS];
             if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
@@ -386,7 +404,7 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
             }
             stage0_done = stage0_done || x.stage_after != 0;
         }
-        for (int j = n_chunks; j < 4 && rc == LFQ_OK; j++) {       /* fewer chunks than events: the unused ones are the last one */
+        for (int j = n_chunks; j < LFQ_UP_CHUNKS && rc == LFQ_OK; j++) {   /* fewer chunks than events: the unused ones are the last one */
             if (hipEventRecord(rs->ev_chunk[j], ups) != hipSuccess) {
                 rc = LFQ_ERR_HIP;
             }
@@ -846,8 +864,12 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             Ap.terms = nullptr;
             Ap.ai_out = Ap.ad_out = nullptr;
             Ap.tag_flags = nullptr;
-            for (int64_t first = 0; rc == LFQ_OK && first < n_plain; first += waves_n * 64) {
-                const int64_t cnt = std::min<int64_t>(waves_n * 64, n_plain - first);
+            /* (while the reads are still arriving the first launch takes one round only: it starts when the small first
+             * chunk of lfq_readset_create has landed, and the link stays ahead of the kernel from there on) */
+            const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n > round
+                               && n_plain > 4 * round * 64;
+            for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt) {
+                cnt = std::min<int64_t>((early && first == 0 ? round : waves_n) * 64, n_plain - first);
                 rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
                 Ap.first_read = (int32_t)first;
                 /* (first is a multiple of 64: the launches are cut to whole wavefronts) */
@@ -1536,13 +1558,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
             rc = LFQ_ERR_NOMEM;
         }
         int64_t *const pos_off[2] = {pos_off_ins.data(), pos_off_del.data()};
-        std::vector<int32_t> col_of;                /* column index of an event position */
+        LfqVec<int32_t> col_of;                     /* column index of an event position (-1: none) */
         int64_t ne_total[2] = {0, 0};
         const bool host_arrays = c->indel_host_arrays || !have_qsum;   /* device-only needs the sums from the kernel */
         if (rc == LFQ_OK) {
-            std::fill(pos_off[0], pos_off[0] + width, (int64_t)-1);
-            std::fill(pos_off[1], pos_off[1] + width, (int64_t)-1);
-            col_of.assign((size_t)width, -1);
+            col_of.resize((size_t)width);           /* (col_of and pos_off: every position is written by the second pass) */
             std::vector<uint8_t> has_ev((size_t)width, 0);
             for (const Ev &e : evs) {
                 has_ev[(size_t)(e.pos - region_begin)] = 1;
@@ -1594,6 +1614,9 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                 size_t ci = (size_t)part_cov[part];
                 int64_t run[2] = {part_ne[0][part], part_ne[1][part]};
                 for (int64_t p = p0; p < p1; p++) {
+                    col_of[(size_t)p] = -1;
+                    pos_off[0][(size_t)p] = -1;
+                    pos_off[1][(size_t)p] = -1;
                     if (h[0][(size_t)p] <= 0) {
                         continue;
                     }
