@@ -91,8 +91,8 @@ struct lfq_readset {
     std::atomic<int> up_stage;          /* 1: everything but BI / BD has landed (what lfq_readset_baq reads), 2: all of it */
     std::atomic<int> up_chunks;         /* bases + qualities of the reads [0, up_bound[up_chunks]) have landed */
     int up_nchunks;
-    int64_t up_bound[LFQ_UP_CHUNKS + 1]; /* chunk j = reads [up_bound[j], up_bound[j + 1]); the first one is small: one round
-                                          * of the BAQ kernel over the SIMDs, so that its first launch starts early */
+    int64_t up_bound[LFQ_UP_CHUNKS + 1]; /* chunk j = reads [up_bound[j], up_bound[j + 1]); the first ones are small: 1, 2, 4
+                                          * rounds of the BAQ kernel over the SIMDs, so that its first launch starts early */
     std::atomic<int> up_rc;        /* written by the helper thread at the end of each stage */
     LfqPin<uint8_t> *up_fl;             /* the flag bytes on their way out (pinned; handed back once the copies are done) */
     /* Pinned caller arrays (lfq_host_alloc): the copies are DMA transfers queued by lfq_readset_create itself, and what
@@ -315,16 +315,20 @@ int lfq_readset_create(lfq_ctx *c, const lfq_pileup_reads *rd, const lfq_pileup_
     add(rs->d_lb, rd->baq, nb);
     add(rs->d_sqb, rd->sq, n);
     add(rs->d_fl, rs->up_fl->data(), n);
-    /* chunks of reads: a small first one -- the reads of one round of the BAQ register kernel over the SIMDs (one wavefront
-     * of 64 reads each), what lfq_readset_baq's first launch takes -- and the rest in equal parts */
+    /* chunks of reads: small first ones -- the reads of one round of the BAQ register kernel over the SIMDs (one wavefront
+     * of 64 reads each), what lfq_readset_baq's first launch takes, then two and four -- and the rest in equal parts */
     const int64_t first_reads = (int64_t)c->n_cu * 4 * 64;
-    const int n_chunks = nb >= ((int64_t)64 << 20) ? (n >= 8 * first_reads ? LFQ_UP_CHUNKS : 4) : 1;
+    const int n_chunks = nb >= ((int64_t)64 << 20) ? (n >= 16 * first_reads ? LFQ_UP_CHUNKS : 4) : 1;
     rs->up_nchunks = n_chunks;
     rs->up_bound[0] = 0;
     if (n_chunks == LFQ_UP_CHUNKS) {
+        /* 1, 2, 4 rounds (the link delivers reads about twice as fast as the kernel takes them: while a launch runs, the
+         * reads of one twice its size arrive), the rest in three equal parts */
         rs->up_bound[1] = first_reads;
-        for (int j = 2; j <= n_chunks; j++) {
-            rs->up_bound[j] = first_reads + (n - first_reads) * (j - 1) / (n_chunks - 1);
+        rs->up_bound[2] = 3 * first_reads;
+        rs->up_bound[3] = 7 * first_reads;
+        for (int j = 4; j <= n_chunks; j++) {
+            rs->up_bound[j] = 7 * first_reads + (n - 7 * first_reads) * (j - 3) / (n_chunks - 3);
         }
     } else {
         for (int j = 1; j <= n_chunks; j++) {
@@ -866,10 +870,12 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             Ap.tag_flags = nullptr;
             /* (while the reads are still arriving the first launch takes one round only: it starts when the small first
              * chunk of lfq_readset_create has landed, and the link stays ahead of the kernel from there on) */
-            const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n > round
-                               && n_plain > 4 * round * 64;
+            const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n >= 8 * round
+                               && n_plain > 16 * round * 64;
+            int64_t ramp = early ? round : waves_n;             /* wavefronts of the next launch: 1, 2, 4 rounds, then all slots */
             for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt) {
-                cnt = std::min<int64_t>((early && first == 0 ? round : waves_n) * 64, n_plain - first);
+                cnt = std::min<int64_t>(std::min(ramp, waves_n) * 64, n_plain - first);
+                ramp = ramp < 4 * round ? ramp * 2 : waves_n;
                 rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
                 Ap.first_read = (int32_t)first;
                 /* (first is a multiple of 64: the launches are cut to whole wavefronts) */

@@ -13,7 +13,7 @@ while i - 1 in idx or (i > 0 and rows[i][1] - rows[i - 1][2] < 2e6 and i - 1 >= 
     i -= 1
 start = idx[-1]
 for j in reversed(idx):
-    if rows[start][1] - rows[j][1] < 80e6:
+    if rows[start][1] - rows[j][1] < 32e6:
         start = j
 t0 = rows[start][1]
 last = None
