@@ -870,7 +870,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             Ap.tag_flags = nullptr;
             /* (while the reads are still arriving the first launch takes one round only: it starts when the small first
              * chunk of lfq_readset_create has landed, and the link stays ahead of the kernel from there on) */
-            const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n >= 8 * round
+            const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n >= 4 * round
                                && n_plain > 16 * round * 64;
             int64_t ramp = early ? round : waves_n;             /* wavefronts of the next launch: 1, 2, 4 rounds, then all slots */
             for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt) {
