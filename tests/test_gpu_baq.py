@@ -254,3 +254,40 @@ def test_baq_wavefronts_with_and_without_n(caller, oracle):
         for r, o in zip(reads, out):
             exp = oracle.baq_read(r["pos0"], r["cigar"], r["seq"], r["qual"], genome.encode(), extended=extended)
             assert o.tobytes() == exp.tobytes(), r["pos0"]
+
+
+def test_readset_baq_large_set_chunked_upload(caller):
+    """More than sixteen rounds of reads (one round = a wavefront of 64 reads on every SIMD) from pinned arrays:
+    lfq_readset_create sends bases and qualities in chunks of 1, 2, 4 rounds and thirds of the rest, lfq_readset_baq ramps
+    its launches the same way and every launch waits for its chunk on the device.  The same reads in pieces small enough
+    for one plain copy and full-size launches must give the same lb / ai / ad bytes and tag flags."""
+    import torch
+    from bench import make_reads
+    from lofreq_amd.pileup import ReadSet
+    R = make_reads(1_150_000, 600_000, indel_frac=0.04)
+    n, rl = R["n"], R["rl"]
+    assert n >= 16 * 65536 and n * rl >= 64 << 20
+    keep, P = {}, dict(R)
+    for k in ("seq", "qual", "bi", "bd", "pos", "cig_off", "cig", "seq_off", "mapq", "rev"):
+        keep[k] = torch.from_numpy(R[k]).pin_memory()
+        P[k] = keep[k].numpy()
+    rs = ReadSet.from_arrays(caller, P)
+    rs.baq(extended=True, idaq=True)
+    lb, ai, ad, fl = rs.fetch_tags(idaq=True)
+    rs.close()
+    assert (lb != 0).mean() > 0.9
+    for a in range(0, n, 300_000):
+        b = min(n, a + 300_000)
+        c0, c1 = int(R["cig_off"][a]), int(R["cig_off"][b])
+        Q = {"n": b - a, "ref": R["ref"], "pos": R["pos"][a:b], "cig_off": R["cig_off"][a:b + 1] - c0, "cig": R["cig"][c0:c1],
+             "seq_off": R["seq_off"][a:b + 1] - a * rl, "mapq": R["mapq"][a:b], "rev": R["rev"][a:b]}
+        for k in ("seq", "qual", "bi", "bd"):
+            Q[k] = R[k][a * rl:b * rl]
+        ps = ReadSet.from_arrays(caller, Q)
+        ps.baq(extended=True, idaq=True)
+        plb, pai, pad, pfl = ps.fetch_tags(idaq=True)
+        ps.close()
+        assert plb.tobytes() == lb[a * rl:b * rl].tobytes(), a
+        assert pai.tobytes() == ai[a * rl:b * rl].tobytes(), a
+        assert pad.tobytes() == ad[a * rl:b * rl].tobytes(), a
+        assert pfl[:b - a].tobytes() == fl[a:b].tobytes(), a
