@@ -381,7 +381,7 @@ def bench_baq(caller, la, n_reads, glen, iters, want_idaq=False):
             # seq + qual + one reference window in, lb out
             "algorithmic_bytes": 3 * n_bases + R["n"] * (150 + 14),
             "note": "wall time of lfq_readset_baq (host geometry of the CIGARs + kernel + sync) on a resident read "
-                    "set; kernel time alone: profiles/r02_baq_stats.md"}
+                    "set; kernel time alone: profiles/r03_baq_rocprof_stats.md"}
 
 
 def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrier=None, overlap=False, pinned=True):
