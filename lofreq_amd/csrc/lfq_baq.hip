@@ -27,6 +27,21 @@
 #define LFQ_BAQ_EI .25
 #define LFQ_BAQ_EM .33333333333
 
+/* a read's geometry record completed from the resident arrays (32 bytes per read used to cross the link for this) */
+__device__ __forceinline__ LfqBaqRead lfq_baq_read_of(const LfqBaqArgs &A, int64_t rid)
+{
+    const LfqBaqGeom g = A.geom[rid];
+    LfqBaqRead R;
+    R.pos = A.pos[rid];
+    R.l_qseq = (int32_t)(A.seq_off[rid + 1] - A.seq_off[rid]);
+    R.xb = g.xb;
+    R.l_ref = g.l_ref;
+    R.bw = g.bw;
+    R.cigar_off = A.cigar_off[rid];
+    R.n_cigar = (int32_t)(A.cigar_off[rid + 1] - R.cigar_off);
+    return R;
+}
+
 __device__ __forceinline__ int lfq_baq_u(int bw, int i, int k)      /* set_u, kprobaln_ext.c:46 */
 {
     int x = i - bw;
@@ -64,7 +79,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
     const bool live = ridx < n_launch;
     const int64_t rid = A.order ? (int64_t)A.order[A.first_read + (live ? ridx : 0)] : A.first_read + (live ? ridx : 0);
-    const LfqBaqRead R = A.reads[rid];
+    const LfqBaqRead R = lfq_baq_read_of(A, rid);
 #define LQ(u_) s_row[(size_t)(u_) * 64 + lane]
     const int W = A.W, rows = A.rows;
     /* this wavefront's scratch */
@@ -857,7 +872,7 @@ __global__ __launch_bounds__(64) void lfq_baq_nflag_kernel(LfqBaqArgs A, int64_t
     bool any_n = false;
     if (ridx < n_launch) {
         const int64_t rid = A.order ? (int64_t)A.order[A.first_read + ridx] : A.first_read + ridx;
-        const LfqBaqRead R = A.reads[rid];
+        const LfqBaqRead R = lfq_baq_read_of(A, rid);
         if (R.l_qseq > 0 && R.l_ref > 0) {
             const uint8_t *q = A.seq + A.seq_off[rid], *rp = A.ref + R.xb;
             /* sixteen bytes per load (the base array carries 16 bytes of padding; the window's tail goes byte by byte) */
@@ -919,7 +934,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
     const bool live = ridx < n_launch;
     const int64_t rid = A.order ? (int64_t)A.order[A.first_read + (live ? ridx : 0)] : A.first_read + (live ? ridx : 0);
-    const LfqBaqRead R = A.reads[rid];
+    const LfqBaqRead R = lfq_baq_read_of(A, rid);
     const int W = A.W, rows = A.rows;
     double *F = A.scratch + (size_t)blockIdx.x * ((size_t)rows * W + 2 * (size_t)W + 2 * ((size_t)rows + 2)) * 64;
     double *S = F + (size_t)rows * W * 64 + 2 * (size_t)W * 64;

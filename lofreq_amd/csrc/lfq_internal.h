@@ -229,17 +229,23 @@ unsigned lfq_cpu_budget(void);
 void lfq_sb_precompute(const int32_t *tuples, int64_t n);
 
 /* ---- BAQ (lfq_baq.hip) ----------------------------------------------------------------------------------- */
-struct LfqBaqRead {            /* 32 bytes, built on the host from the CIGAR (bam_md_ext.c:312-380) */
-    int32_t pos;               /* bam1_core_t.pos */
-    int32_t l_qseq;
+struct LfqBaqGeom {            /* 12 bytes per read, built on the host from the CIGAR (bam_md_ext.c:312-380) and uploaded */
     int32_t xb, l_ref;         /* reference window [xb, xb + l_ref) */
     int32_t bw;                /* band width handed to the HMM */
+};
+struct LfqBaqRead {            /* what a kernel works with: the geometry + the read's entries of the resident arrays */
+    int32_t pos;               /* bam1_core_t.pos */
+    int32_t l_qseq;
+    int32_t xb, l_ref;
+    int32_t bw;
     int32_t n_cigar;
     int64_t cigar_off;
 };
 
 struct LfqBaqArgs {
-    const LfqBaqRead *reads;
+    const LfqBaqGeom *geom;    /* [n] */
+    const int32_t *pos;        /* [n] */
+    const int64_t *cigar_off;  /* [n+1] */
     const int64_t *seq_off;    /* [n+1] */
     const uint32_t *cigar;
     const uint8_t *seq, *qual; /* 0..4 / phred */

@@ -585,7 +585,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     /* geometry of every read: alignment window and band width (bam_md_ext.c:312-380, :396-399) */
     /* (pinned, grow-only host buffers: 28 bytes per read are written once by the threads below and go out by DMA; a
      * std::vector would zero 56 MB for 2 M reads first and be copied through a staging buffer afterwards) */
-    const int64_t h_bytes = (n * (int64_t)sizeof(LfqBaqRead) + 255) / 256 * 256, ord_bytes = (n * 4 + 255) / 256 * 256;
+    const int64_t h_bytes = (n * (int64_t)sizeof(LfqBaqGeom) + 255) / 256 * 256, ord_bytes = (n * 4 + 255) / 256 * 256;
     if (h_bytes + ord_bytes > c->pin_bytes) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         c->h_pin = nullptr;
@@ -593,7 +593,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         LFQ_TRY_HIP(hipHostMalloc((void **)&c->h_pin, (size_t)(h_bytes + ord_bytes), hipHostMallocDefault));
         c->pin_bytes = h_bytes + ord_bytes;
     }
-    LfqBaqRead *h = (LfqBaqRead *)c->h_pin;
+    LfqBaqGeom *h = (LfqBaqGeom *)c->h_pin;
     int32_t *order = (int32_t *)(c->h_pin + h_bytes);
     /* (from the context's pinned pool: fresh memory would be page-faulted in by the threads below while the upload
      * thread is pinning the caller's arrays -- the two fight over the address-space lock) */
@@ -612,7 +612,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     int max_lq = 0, max_w = 0, lrn = 0, lqn = 0;    /* of this part */
     int64_t n_nar = 0, n_b8 = 0, n_pl = 0;
     for (int64_t r = r_begin; r < r_end; r++) {
-        LfqBaqRead &o = h[(size_t)r];
+        LfqBaqGeom &o = h[(size_t)r];
         const int l_qseq = (int)(rd->seq_off[r + 1] - rd->seq_off[r]);
         const uint32_t *cg = rd->cigar + rd->cigar_off[r];
         const int n_cigar = (int)(rd->cigar_off[r + 1] - rd->cigar_off[r]);
@@ -641,13 +641,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             xb += (xe - xb - l_qseq - bw) / 2, xe -= (xe - xb - l_qseq - bw) / 2;
         }
         if (xe > rd->ref_len) xe = (int)rd->ref_len;      /* the reference stops at the string's NUL */
-        o.pos = rd->pos[r];
-        o.l_qseq = l_qseq;
         o.xb = xb;
         o.l_ref = xe - xb;
         o.bw = bw;
-        o.n_cigar = n_cigar;
-        o.cigar_off = rd->cigar_off[r];
         int wr = 0;
         if (l_qseq > 0 && o.l_ref > 0) {
             int b2 = std::max(o.l_ref, l_qseq);
@@ -743,7 +739,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     /* per-call device data: geometry, launch order, the quality table (the reads themselves are resident) */
     uint8_t *d_blob = nullptr;
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    const int64_t o_reads = 0, o_q2p = o_reads + al(n * (int64_t)sizeof(LfqBaqRead)), o_ord = o_q2p + al(1024),
+    const int64_t o_reads = 0, o_q2p = o_reads + al(n * (int64_t)sizeof(LfqBaqGeom)), o_ord = o_q2p + al(1024),
                   total = o_ord + al(n * 4);
     LFQ_TRY(grow(&c->d_tmp[0], &c->tmp_bytes[0], total));
     d_blob = c->d_tmp[0];
@@ -753,7 +749,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             rc = LFQ_ERR_HIP;
         }
     };
-    up(o_reads, h, n * (int64_t)sizeof(LfqBaqRead));
+    up(o_reads, h, n * (int64_t)sizeof(LfqBaqGeom));
     up(o_q2p, h_q2p, 1024);
     up(o_ord, order, n * 4);
     if (rc == LFQ_OK && (hipMemsetAsync(rs->d_lb, 0, (size_t)std::max<int64_t>(n_bases, 1), c->stream) != hipSuccess
@@ -769,7 +765,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     if (rc == LFQ_OK && max_lq > 0) {
         LfqBaqArgs A;
         memset(&A, 0, sizeof(A));
-        A.reads = (const LfqBaqRead *)(d_blob + o_reads);
+        A.geom = (const LfqBaqGeom *)(d_blob + o_reads);
+        A.pos = (const int32_t *)rs->d_pos;
+        A.cigar_off = (const int64_t *)rs->d_coff;
         A.seq_off = (const int64_t *)rs->d_soff;
         A.cigar = (const uint32_t *)rs->d_cig;
         A.seq = rs->d_seq;
