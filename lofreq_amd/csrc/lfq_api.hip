@@ -452,8 +452,6 @@ void lfq_destroy(lfq_ctx *c)
     }
     for (int i = 0; i < 3; i++) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-        if (i < 2 && c->ev_baqn[i]) (void)hipEventDestroy(c->ev_baqn[i]);
-        if (i == 0 && c->baq_tab_stream) (void)hipStreamDestroy(c->baq_tab_stream);
         if (i == 0 && c->ev_segw) (void)hipEventDestroy(c->ev_segw);
         if (i == 0 && c->ev_prep) (void)hipEventDestroy(c->ev_prep);
         if (i == 0 && c->ev_mid) (void)hipEventDestroy(c->ev_mid);

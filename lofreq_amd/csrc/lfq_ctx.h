@@ -275,8 +275,6 @@ struct lfq_ctx {
     hipEvent_t ev_light[LFQ_MAX_SEGMENTS][2];  /* light kernel (dps) */
     hipEvent_t ev_side[2][LFQ_MAX_SEGMENTS][2];/* big / mid kernels (side streams) */
     hipEvent_t ev_join[3];
-    hipEvent_t ev_baqn[2];     /* lfq_readset_baq: fork / join of the launch that runs beside the last plain one (created on first use) */
-    hipStream_t baq_tab_stream; /* ... and its stream (the DP stream carries the indel counter pass meanwhile) */
     int cur_segments;
     uint64_t *d_tiles;
     double *d_scratch;

@@ -857,7 +857,6 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         /* The reads may still be crossing PCIe (lfq_readset_create): a launch waits for the chunks of bases and qualities
          * that hold its reads -- the plain narrow-band launches walk the reads in input order, so the first one starts
          * after a quarter of them --, everything else for all of them. */
-        bool tab_beside = false;                    /* the reads with an indel table went beside the last plain launch */
         if (beside && hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
             rc = LFQ_ERR_HIP;       /* the side streams start after the uploads / memsets queued on c->stream so far */
         }
@@ -875,42 +874,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt) {
                 cnt = std::min<int64_t>(std::min(ramp, waves_n) * 64, n_plain - first);
                 ramp = ramp < 4 * round ? ramp * 2 : waves_n;
-                /* The narrow-band reads with an indel table (a few per cent: a launch of a round or two by itself at the
-                 * end, its last round mostly empty) run BESIDE the last plain launch when its scratch slots leave room:
-                 * in the slots behind it, on a stream of its own, forked here -- behind the earlier launches, which use
-                 * every slot -- and joined below. */
-                const int64_t n_tab = n_narrow - n_plain, last_waves = (cnt + 63) / 64;
-                if (first + cnt >= n_plain && n_tab > 0 && last_waves + (n_tab + 63) / 64 <= waves_n && !lfq_knobs().single_stream) {
-                    for (int q = 0; q < 2; q++) {
-                        if (!c->ev_baqn[q] && hipEventCreateWithFlags(&c->ev_baqn[q], hipEventDisableTiming) != hipSuccess) {
-                            c->ev_baqn[q] = nullptr;
-                        }
-                    }
-                    if (!c->baq_tab_stream && hipStreamCreateWithFlags(&c->baq_tab_stream, hipStreamNonBlocking) != hipSuccess) {
-                        c->baq_tab_stream = nullptr;
-                    }
-                    if (c->ev_baqn[0] && c->ev_baqn[1] && c->baq_tab_stream) {
-                        LfqBaqArgs At = at_slot(last_waves);
-                        At.first_read = (int32_t)n_plain;
-                        if (hipEventRecord(c->ev_baqn[0], c->stream) != hipSuccess
-                            || hipStreamWaitEvent(c->baq_tab_stream, c->ev_baqn[0], 0) != hipSuccess) {
-                            rc = LFQ_ERR_HIP;
-                        }
-                        if (rc == LFQ_OK) {
-                            rc = readset_upload_wait_inputs(rs, {c->baq_tab_stream});
-                        }
-                        if (rc == LFQ_OK) {
-                            rc = lfq_launch_baq(At, n_tab, 1, c->baq_tab_stream);
-                        }
-                        if (rc == LFQ_OK && hipEventRecord(c->ev_baqn[1], c->baq_tab_stream) != hipSuccess) {
-                            rc = LFQ_ERR_HIP;
-                        }
-                        tab_beside = rc == LFQ_OK;
-                    }
-                }
-                if (rc == LFQ_OK) {
-                    rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
-                }
+                rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
                 Ap.first_read = (int32_t)first;
                 /* (first is a multiple of 64: the launches are cut to whole wavefronts) */
                 Ap.nflag = (c->d_baq_nflag && !lfq_knobs().baq_one_variant) ? c->d_baq_nflag + first / 64 : nullptr;
@@ -949,12 +913,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                 rc = LFQ_ERR_HIP;
             }
         }
-        for (int64_t first = n_plain; rc == LFQ_OK && !tab_beside && first < n_narrow; first += waves_n * 64) {
+        for (int64_t first = n_plain; rc == LFQ_OK && first < n_narrow; first += waves_n * 64) {
             A.first_read = (int32_t)first;
             rc = lfq_launch_baq(A, std::min<int64_t>(waves_n * 64, n_narrow - first), 1, c->stream);
-        }
-        if (tab_beside && rc == LFQ_OK && hipStreamWaitEvent(c->stream, c->ev_baqn[1], 0) != hipSuccess) {
-            rc = LFQ_ERR_HIP;
         }
         if (beside) {
             if (rc == LFQ_OK && (hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess
