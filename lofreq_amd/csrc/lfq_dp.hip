@@ -87,6 +87,30 @@ __device__ __forceinline__ LfqEntry lfq_load_entry(const LfqEntry *list, int i)
     return e;
 }
 
+/* the quality tables (8 KB) into a workgroup's LDS: every thread's loads issued before the first store (a loop of
+ * load - wait - store paid two to four memory round trips at the start of every DP kernel); 128 threads or more */
+__device__ __forceinline__ void lfq_luts_to_lds(LfqLuts *dst, const LfqLuts *__restrict__ src)
+{
+    static_assert(sizeof(LfqLuts) % 16 == 0, "copied as 16-byte words");
+    constexpr int N = (int)(sizeof(LfqLuts) / 16);
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    const int t = (int)threadIdx.x, nt = (int)blockDim.x;
+    uint4 tmp[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = t + k * nt;
+        tmp[k] = s[i < N ? i : N - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = t + k * nt;
+        if (i < N) {
+            d[i] = tmp[k];
+        }
+    }
+}
+
 /* ---- DP work accounting (SURVEY 8d secondary figure) -----------------------------------------------
  * cells(column) = sum over the kept rows n = 1..N* of min(n, K), N* = the row this implementation stopped at.
  * Batch-wide uint64 counters next to the sparse-output counter; read back by lfq_batch_finish. */
@@ -110,16 +134,27 @@ struct LfqRaw {
 
 __device__ __forceinline__ LfqRaw lfq_load_chunk_at(uint64_t off0, int64_t n_obs, int64_t ch, const LfqTracksDev &T)
 {
+    /* Every lane loads -- a lane past the end of the column from the column's last observation -- and the bytes of the
+     * lanes past the end are replaced afterwards.  With the loads inside `if (idx < n_obs)` the bytes were packed, hence
+     * waited for, inside the branch: a caller that asks for several chunks before it uses the first (the big-class prep
+     * kernel: four per wavefront) paid one memory round trip per chunk instead of one for all of them. */
     const int64_t idx = ch * 64 + lfq_lane();
     LfqRaw r;
     r.w = 0x00000004u;          /* N base: ignored */
     r.sq = 255u;
-    if (idx < n_obs) {
-        const uint64_t g = off0 + (uint64_t)idx;
-        const uint32_t nt = lfq_nt_at(T, g), bq = T.bq[g], baq = T.baq ? T.baq[g] : 255u, mq = T.mq[g];
-        r.w = nt | (bq << 8) | (baq << 16) | (mq << 24);
-        r.sq = T.sq ? T.sq[g] : 255u;
-    }
+    const bool in = idx < n_obs;
+    /* (no column in a work list is empty: n_obs >= 1 and the clamped index is one of its observations) */
+    const uint64_t g = off0 + (uint64_t)(in ? idx : (n_obs > 0 ? n_obs - 1 : 0));
+    /* (no branch around a load either: the layout of the nt track and the absent tracks select addresses and values,
+     * an absent track is read from the bq track's bytes and replaced) */
+    const bool pk = T.nt_packed != 0;
+    const uint8_t *p_baq = T.baq ? T.baq : T.bq, *p_sq = T.sq ? T.sq : T.bq;
+    const uint32_t nb = T.nt[pk ? ((g >> 3) * 4 + (g & 3u)) : g];                 /* lfq_nt_at */
+    const uint32_t bq = T.bq[g], baq_b = p_baq[g], mq = T.mq[g], sq_b = p_sq[g];
+    const uint32_t nt = pk ? ((g & 4u) ? (nb >> 4) : (nb & 15u)) : nb;
+    const uint32_t baq = T.baq ? baq_b : 255u, sq = T.sq ? sq_b : 255u;
+    r.w = in ? (nt | (bq << 8) | (baq << 16) | (mq << 24)) : 0x00000004u;
+    r.sq = in ? sq : 255u;
     return r;
 }
 
@@ -940,13 +975,7 @@ __global__ __launch_bounds__(256) void lfq_dp_wave_kernel(LfqTracksDev T, LfqPar
          * win the issue arbitration (MI355X_MICROARCH "two waves per SIMD", item 2) */
         __builtin_amdgcn_s_setprio(3);
     }
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
+    lfq_luts_to_lds(&s_luts, g_luts);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_work = W.counters[count_idx];
@@ -1021,13 +1050,7 @@ __global__ __launch_bounds__(256) void lfq_dp_retry_kernel(LfqTracksDev T, LfqPa
 {
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
+    lfq_luts_to_lds(&s_luts, g_luts);
     __syncthreads();
     const int lane = lfq_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1111,13 +1134,7 @@ __global__ __launch_bounds__(256) void lfq_dp_screen_kernel(LfqTracksDev T, LfqP
 {
     constexpr int MAXK = KREG - 1;
     __shared__ LfqLuts s_luts;
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
+    lfq_luts_to_lds(&s_luts, g_luts);
     __syncthreads();
     const int lane = lfq_lane();
     const int n_work = W.counters[LFQ_CNT_LIGHT];
@@ -1507,13 +1524,7 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
     constexpr int NW = LFQ_HEAVY_WAVES;
     __shared__ LfqBigShared sh;
     __builtin_amdgcn_s_setprio(3);
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&sh.luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
+    lfq_luts_to_lds(&sh.luts, g_luts);
     if (threadIdx.x < 64) {
         sh.zero_v[threadIdx.x] = 0.0;
         sh.zero_e[threadIdx.x] = 0;
@@ -1587,22 +1598,24 @@ __global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
     __shared__ LfqLuts s_luts;
     __shared__ double s_mu[LFQ_PREP_WAVES];
     __shared__ int s_col;
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
+    lfq_luts_to_lds(&s_luts, g_luts);
     __builtin_amdgcn_s_setprio(3);
     const int n_big = W.counters[LFQ_CNT_BIG];
+    bool first = true;
+    __syncthreads();                                /* the tables are in LDS */
     for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_col = atomicAdd(&W.counters[LFQ_CNT_HEAD_PREP], 1);
+        /* a workgroup's first column is its own index (there are about as many workgroups as big columns: no atomic
+         * round trip before the first load), the following ones are claimed behind those */
+        int h = (int)blockIdx.x;
+        if (!first) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                s_col = (int)gridDim.x + atomicAdd(&W.counters[LFQ_CNT_HEAD_PREP], 1);
+            }
+            __syncthreads();
+            h = s_col;
         }
-        __syncthreads();
-        const int h = s_col;
+        first = false;
         if (h >= n_big) {
             break;
         }
@@ -1739,13 +1752,7 @@ __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqPara
     __shared__ LfqLuts s_luts;
     __shared__ LfqRow s_rows[4][64];
     __builtin_amdgcn_s_setprio(3);
-    {
-        const double *src = reinterpret_cast<const double *>(g_luts);
-        double *dst = reinterpret_cast<double *>(&s_luts);
-        for (int i = threadIdx.x; i < (int)(sizeof(LfqLuts) / sizeof(double)); i += blockDim.x) {
-            dst[i] = src[i];
-        }
-    }
+    lfq_luts_to_lds(&s_luts, g_luts);
     __syncthreads();
     constexpr int C_LO = MODE ? 2 : 0, C_N = MODE ? 3 : 2;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
