@@ -1607,6 +1607,9 @@ __global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
         /* a workgroup's first column is its own index (there are about as many workgroups as big columns: no atomic
          * round trip before the first load), the following ones are claimed behind those */
         int h = (int)blockIdx.x;
+        if (!first && n_big <= (int)gridDim.x) {
+            break;                                  /* every column was some workgroup's first: nothing to claim */
+        }
         if (!first) {
             __syncthreads();
             if (threadIdx.x == 0) {
