@@ -1472,7 +1472,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
 }
 
 /* lds: 0 = the all-HBM kernel (any band), 1 = band <= 7 (rows in registers / LDS), 2 = band 8 (rows in registers) */
-int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
+int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream, int nmode)
 {
     if (n_launch <= 0) {
         return LFQ_OK;
@@ -1491,9 +1491,13 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream)
             } else if (a.itab) {
                 hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             } else if (a.nflag) {
-                hipLaunchKernelGGL(lfq_baq_nflag_kernel, dim3(blocks), dim3(64), 0, st, a, n_launch);
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+                if (nmode != 2) {
+                    hipLaunchKernelGGL(lfq_baq_nflag_kernel, dim3(blocks), dim3(64), 0, st, a, n_launch);
+                    hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+                }
+                if (nmode != 1) {
+                    hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+                }
             } else {
                 hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             }

@@ -277,7 +277,9 @@ struct LfqBaqArgs {
 #define LFQ_BAQ_LDS_BAND 15      /* cells (reference positions) per row of such a read: 2 * 7 + 1 */
 #define LFQ_BAQ_LDS_MAX_LREF 300 /* ... and whose reference window is this short: codes (32 B per base pair and wavefront) + row
                                   * scalars (128 B per query base) + 1 KiB stay below 64 KiB of LDS per wavefront */
-int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream);
+/* nmode (launches with a.nflag): 0 = flag kernel and both instantiations; 1 = flag kernel and the instantiation without the
+ * N case; 2 = only the one with it (the flagged wavefronts of an earlier nmode 1 call with the same arguments) */
+int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream, int nmode = 0);
 
 /* ---- device-side pileup (lfq_pileup.hip) ------------------------------------------------------------------ */
 struct LfqPileupArgs {

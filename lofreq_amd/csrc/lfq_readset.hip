@@ -871,6 +871,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n >= 4 * round
                                && n_plain > 16 * round * 64;
             int64_t ramp = early ? round : waves_n;             /* wavefronts of the next launch: 1, 2, 4 rounds, then all slots */
+            std::vector<std::pair<LfqBaqArgs, int64_t>> with_n;
             for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt) {
                 cnt = std::min<int64_t>(std::min(ramp, waves_n) * 64, n_plain - first);
                 ramp = ramp < 4 * round ? ramp * 2 : waves_n;
@@ -879,7 +880,20 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                 /* (first is a multiple of 64: the launches are cut to whole wavefronts) */
                 Ap.nflag = (c->d_baq_nflag && !lfq_knobs().baq_one_variant) ? c->d_baq_nflag + first / 64 : nullptr;
                 if (rc == LFQ_OK) {
-                    rc = lfq_launch_baq(Ap, cnt, 1, c->stream);
+                    rc = lfq_launch_baq(Ap, cnt, 1, c->stream, Ap.nflag ? 1 : 0);
+                    if (Ap.nflag) {
+                        with_n.push_back({Ap, cnt});
+                    }
+                }
+            }
+            /* The instantiation with the N case for every launch's flagged wavefronts, behind all of them: a wavefront of
+             * this kernel needs an empty SIMD even to find that it has nothing to do, and a launch that came up while the
+             * indel counter pass of the chain kept every SIMD busy waited for that kernel to drain (1.2 ms per region for
+             * wavefronts that leave at once).  Here the other streams are idle or done; the scratch slots of a launch's
+             * wavefronts are free again (every earlier launch has finished: stream order). */
+            for (const auto &w : with_n) {
+                if (rc == LFQ_OK) {
+                    rc = lfq_launch_baq(w.first, w.second, 1, c->stream, 2);
                 }
             }
         }
