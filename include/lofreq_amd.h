@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define LFQ_ABI_VERSION 1
+/* 2: lfq_conf grew to 80 bytes (approx_threshold_n), lfq_dp_work gained n_approx_pruned, lfq_filter_records_ex.
+ * A caller compiled against another version must not run: compare lfq_abi_version() with this value once, as the
+ * bindings in integration/ and the Python loader do. */
+#define LFQ_ABI_VERSION 2
 
 typedef enum lfq_status {
     LFQ_OK = 0,

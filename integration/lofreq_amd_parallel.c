@@ -26,7 +26,8 @@ typedef int (*nccl_destroy_fn)(void *);
 
 struct lfq_par {
     int world, rank;
-    int files;                      /* 1: the files transport is installed */
+    int files;                      /* 1: the files transport is asked for */
+    int installed;                  /* 1: ... and installed (lfq_shard_set_host_allgather) */
     lfq_ctx *ctx;
     void *comm;                     /* ncclComm_t */
     void *rccl;                     /* dlopen handle */
@@ -34,7 +35,14 @@ struct lfq_par {
     char rdv[900];
     long seq;                       /* collectives done so far (files transport) */
     double timeout_s;
+    uint64_t job;                   /* this run's nonce: every rendezvous file starts with it (see job_nonce) */
 };
+
+/* Every file that passes through the rendezvous path starts with this header.  A file another run left behind under
+ * the same LFQ_PAR_RENDEZVOUS (a crashed run's <rdv>.id / <rdv>.ag*, the closing barrier's files of a finished one)
+ * carries another nonce and is waited past like a file that is not there yet. */
+typedef struct { uint64_t magic, job; } rdv_hdr;
+#define RDV_MAGIC 0x3152415051464cULL       /* "LFQPAR1" */
 
 static double now_s(void)
 {
@@ -50,16 +58,17 @@ static void nap(void)
 }
 
 /* write `n` bytes to `path` so that a reader never sees a partial file: temp name + rename */
-static int put_file(const char *path, const void *buf, size_t n)
+static int put_file(uint64_t job, const char *path, const void *buf, size_t n)
 {
     char tmp[1024];
+    rdv_hdr h = {RDV_MAGIC, job};
     FILE *f;
     snprintf(tmp, sizeof(tmp), "%s.tmp%ld", path, (long)getpid());
     f = fopen(tmp, "wb");
     if (!f) {
         return -1;
     }
-    if (n > 0 && fwrite(buf, 1, n, f) != n) {
+    if (fwrite(&h, sizeof(h), 1, f) != 1 || (n > 0 && fwrite(buf, 1, n, f) != n)) {
         fclose(f);
         unlink(tmp);
         return -1;
@@ -71,18 +80,20 @@ static int put_file(const char *path, const void *buf, size_t n)
     return 0;
 }
 
-/* wait until `path` exists with exactly `n` bytes, then read it */
-static int get_file(const char *path, void *buf, size_t n, double timeout_s)
+/* wait until `path` exists with this run's header and exactly `n` payload bytes, then read it */
+static int get_file(uint64_t job, const char *path, void *buf, size_t n, double timeout_s)
 {
     const double t0 = now_s();
     for (;;) {
         struct stat st;
-        if (stat(path, &st) == 0 && (size_t)st.st_size == n) {
+        if (stat(path, &st) == 0 && (size_t)st.st_size == n + sizeof(rdv_hdr)) {
             FILE *f = fopen(path, "rb");
             if (f) {
-                const size_t got = n ? fread(buf, 1, n, f) : 0;
+                rdv_hdr h = {0, 0};
+                const size_t hg = fread(&h, sizeof(h), 1, f);
+                const size_t got = (hg == 1 && n) ? fread(buf, 1, n, f) : 0;
                 fclose(f);
-                if (got == n) {
+                if (hg == 1 && h.magic == RDV_MAGIC && h.job == job && got == n) {
                     return 0;
                 }
             }
@@ -105,7 +116,7 @@ static int files_allgather(void *user, int world, int rank, const void *send, vo
         return -1;
     }
     snprintf(path, sizeof(path), "%s.ag%ld.%d", p->rdv, k, rank);
-    if (put_file(path, send, bytes) != 0) {
+    if (put_file(p->job, path, send, bytes) != 0) {
         return -1;
     }
     for (r = 0; r < world; r++) {
@@ -114,7 +125,7 @@ static int files_allgather(void *user, int world, int rank, const void *send, vo
             continue;
         }
         snprintf(path, sizeof(path), "%s.ag%ld.%d", p->rdv, k, r);
-        if (get_file(path, (char *)recv + (size_t)r * bytes, bytes, p->timeout_s) != 0) {
+        if (get_file(p->job, path, (char *)recv + (size_t)r * bytes, bytes, p->timeout_s) != 0) {
             return -1;
         }
     }
@@ -135,6 +146,61 @@ static int env_int(const char *name, int dflt)
     }
     v = strtol(e, &end, 10);
     return (end == e || *end) ? dflt : (int)v;
+}
+
+/* The run's nonce.  LFQ_PAR_JOB, when the launcher exports one with the other LFQ_PAR_* variables (any string that is
+ * new per run: its pid and start time will do), is the strong form: nothing of another run can be mistaken for this
+ * one's.  Without it rank 0 draws a nonce, removes what an earlier run left of <rdv>.job / <rdv>.id and publishes the
+ * nonce in <rdv>.job; the other ranks take the <rdv>.job they find unless it is older than the time any rank 0 waits
+ * for them (LFQ_PAR_TIMEOUT_S) -- a crashed run's files younger than that can still be picked up by a rank that
+ * starts before its rank 0 does: export LFQ_PAR_JOB where that matters. */
+static int job_nonce(lfq_par *p)
+{
+    const char *e = getenv("LFQ_PAR_JOB");
+    char path[1024];
+    snprintf(path, sizeof(path), "%s.job", p->rdv);
+    if (e && *e) {
+        uint64_t h = 1469598103934665603ULL;                /* FNV-1a of the string */
+        for (; *e; e++) {
+            h = (h ^ (uint64_t)(unsigned char)*e) * 1099511628211ULL;
+        }
+        p->job = h;
+        return 0;
+    }
+    if (p->rank == 0) {
+        struct timespec ts;
+        char old[1024];
+        clock_gettime(CLOCK_REALTIME, &ts);
+        p->job = ((uint64_t)getpid() << 40) ^ ((uint64_t)ts.tv_sec << 20) ^ (uint64_t)ts.tv_nsec;
+        snprintf(old, sizeof(old), "%s.id", p->rdv);
+        unlink(old);
+        unlink(path);
+        return put_file(0, path, &p->job, sizeof(p->job));
+    } else {
+        const double t0 = now_s();
+        for (;;) {
+            struct stat st;
+            if (stat(path, &st) == 0 && (double)(time(NULL) - st.st_mtime) <= p->timeout_s
+                && get_file(0, path, &p->job, sizeof(p->job), 0.0) == 0) {
+                return 0;
+            }
+            if (now_s() - t0 > p->timeout_s) {
+                return -1;
+            }
+            nap();
+        }
+    }
+}
+
+/* what a run that died left of THIS rank under the rendezvous path (a finished one leaves its closing barrier's file) */
+static void unlink_stale(const lfq_par *p)
+{
+    char path[1024];
+    long k;
+    for (k = 0; k < 64; k++) {
+        snprintf(path, sizeof(path), "%s.ag%ld.%d", p->rdv, k, p->rank);
+        unlink(path);
+    }
 }
 
 int lfq_par_world(const lfq_par *p) { return p ? p->world : 1; }
@@ -183,6 +249,10 @@ int lfq_par_init(lfq_par **out, int need_gpu)
     strcpy(p->rdv, rdv);
     p->files = (tr && strcmp(tr, "files") == 0) ? 1 : 0;
 
+    if (lfq_abi_version() != LFQ_ABI_VERSION) {        /* lfq_conf / record layouts belong to the version */
+        free(p);
+        return LFQ_ERR_UNSUPPORTED;
+    }
     if (need_gpu) {
         if (!p->files && !getenv("LFQ_DEVICE")) {
             const int n = lfq_device_count();
@@ -201,7 +271,15 @@ int lfq_par_init(lfq_par **out, int need_gpu)
         }
     }
     if (p->files) {
+        unlink_stale(p);
+    }
+    if (job_nonce(p) != 0) {
+        lfq_par_destroy(p);
+        return LFQ_ERR_INVALID;                     /* the rendezvous path is not writable, or rank 0 never came */
+    }
+    if (p->files) {
         lfq_shard_set_host_allgather(files_allgather, p);
+        p->installed = 1;
     } else {
         /* ncclUniqueId of rank 0 through <rdv>.id, then ncclCommInitRank on every rank (blocks until all are in) */
         lfq_nccl_id id;
@@ -219,11 +297,11 @@ int lfq_par_init(lfq_par **out, int need_gpu)
         snprintf(path, sizeof(path), "%s.id", p->rdv);
         memset(&id, 0, sizeof(id));
         if (rank == 0) {
-            if (get_id(&id) != 0 || put_file(path, &id, sizeof(id)) != 0) {
+            if (get_id(&id) != 0 || put_file(p->job, path, &id, sizeof(id)) != 0) {
                 lfq_par_destroy(p);
                 return LFQ_ERR_HIP;
             }
-        } else if (get_file(path, &id, sizeof(id), p->timeout_s) != 0) {
+        } else if (get_file(p->job, path, &id, sizeof(id), p->timeout_s) != 0) {
             lfq_par_destroy(p);
             return LFQ_ERR_HIP;
         }
@@ -242,7 +320,7 @@ void lfq_par_destroy(lfq_par *p)
     if (!p) {
         return;
     }
-    if (p->files) {
+    if (p->installed) {
         char path[1024];
         long k;
         int64_t one = 1, *all = (int64_t *)malloc(sizeof(int64_t) * (size_t)p->world);
@@ -261,10 +339,16 @@ void lfq_par_destroy(lfq_par *p)
     if (p->comm && p->comm_destroy) {
         p->comm_destroy(p->comm);
     }
-    if (p->rank == 0 && !p->files) {
+    if (p->rank == 0) {
         char path[1024];
-        snprintf(path, sizeof(path), "%s.id", p->rdv);
-        unlink(path);
+        if (!p->files) {
+            snprintf(path, sizeof(path), "%s.id", p->rdv);
+            unlink(path);
+        }
+        if (!getenv("LFQ_PAR_JOB") && p->job) {
+            snprintf(path, sizeof(path), "%s.job", p->rdv);
+            unlink(path);
+        }
     }
     if (p->ctx) {
         lfq_destroy(p->ctx);
@@ -302,9 +386,13 @@ int lfq_par_merge_snvs(lfq_par *p, lfq_conf *conf, lfq_col_pvals *pvals, int64_t
     }
     free(all);
     /* (2) the shard-local running factors become the single-process ones, then the exact emit test (lofreq_call.c:832) */
-    rc = lfq_shard_rebase_bonferroni(pvals, n_pvals, prefix[0]);
-    if (rc != LFQ_OK) {
-        return rc;
+    /* only with the dynamic factor: under `-b N` every column already carries the fixed N (lofreq_call.c:794 is the
+       only place the factor moves), and adding 3 * prefix would over-correct every rank but the first */
+    if (conf->bonf_dynamic) {
+        rc = lfq_shard_rebase_bonferroni(pvals, n_pvals, prefix[0]);
+        if (rc != LFQ_OK) {
+            return rc;
+        }
     }
     cap = 3 * n_pvals + 1;
     mine = (lfq_snv_record *)malloc(sizeof(lfq_snv_record) * (size_t)cap);

@@ -123,6 +123,9 @@ int lfq_region_open(lfq_region **out, lfq_ctx *ctx, lfq_conf *conf, const lfq_re
     if (!out || !ctx || !conf || !opts || !emit) {
         return LFQ_ERR_INVALID;
     }
+    if (lfq_abi_version() != LFQ_ABI_VERSION) {       /* lfq_conf and the read / column structs belong to the version */
+        return LFQ_ERR_UNSUPPORTED;
+    }
     r = (lfq_region *)calloc(1, sizeof(*r));
     if (!r) {
         return LFQ_ERR_NOMEM;
@@ -268,12 +271,17 @@ static int region_start(lfq_region *r, reg_buf *b)
     if (r->o.use_baq || r->o.use_idaq) {                                /* plp.c:667-683 */
         rc = lfq_readset_baq(r->ctx, b->rs, r->o.baq_extended, r->o.use_idaq ? 1 : 0);
         if (rc != LFQ_OK) {
+            /* the read set waits for its queued copies before it goes: the caller may refill this buffer's arrays */
+            lfq_readset_destroy(b->rs);
+            b->rs = NULL;
             return rc;
         }
     }
     if (r->o.use_sq) {                                                  /* plp.c:727-735; DEFAULT_MIN_BQ = 6 */
         rc = lfq_readset_source_qual(r->ctx, b->rs, r->o.def_nm_q, 6, NULL, NULL);
         if (rc != LFQ_OK) {
+            lfq_readset_destroy(b->rs);
+            b->rs = NULL;
             return rc;
         }
     }
@@ -359,8 +367,10 @@ static int region_finish(lfq_region *r, reg_buf *b)
     }
     if (rc == LFQ_OK && b->have_tracks) {
         t = b->t;
-        if (cols && cols->cons_indel && cols->ncols == t.ncols && t.ncols > 0) {
-            rc = lfq_pileup_skip_snv_columns(r->ctx, cols->cons_indel, cols->ncols);
+        if (cols && cols->cons_indel && t.ncols > 0) {
+            /* both pileups cover [beg, end]: another column count is an internal error, and going on would emit SNVs
+             * at columns whose consensus is an indel (lofreq_call.c:928-931) */
+            rc = cols->ncols == t.ncols ? lfq_pileup_skip_snv_columns(r->ctx, cols->cons_indel, cols->ncols) : LFQ_ERR_INVALID;
         }
         if (rc == LFQ_OK && t.ncols > 0) {
             if (3 * t.ncols > r->srec_cap) {

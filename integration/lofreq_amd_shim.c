@@ -330,6 +330,10 @@ static void ensure_ctx(void)
         /* one `lofreq call -r <bin>` per worker of the parallel wrapper (lofreq2_call_pparallel.py:640-667): each
          * process takes a GPU of its own -- LFQ_DEVICE, LOCAL_RANK, or the first free worker slot of the node */
         const int dev = lfq_pick_device(0, NULL);
+        if (lfq_abi_version() != LFQ_ABI_VERSION) {     /* struct layouts (lfq_conf, lfq_dp_work) belong to the version */
+            LOG_FATAL("lofreq_amd: library ABI %d, shim compiled against %d\n", lfq_abi_version(), LFQ_ABI_VERSION);
+            exit(1);
+        }
         if (dev < 0 || lfq_create(&g_ctx, dev) != LFQ_OK) {
             LOG_FATAL("%s\n", "lofreq_amd: no usable MI355X / HIP device");
             exit(1);

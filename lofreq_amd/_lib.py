@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFQ_AMD_LIB") or os.path.join(_HERE, "liblofreq_amd.so")   # LFQ_AMD_LIB: another build of the same library (A/B runs)
 
 LFQ_OK = 0
+LFQ_ABI_VERSION = 2      # include/lofreq_amd.h; load() refuses a library built from another header
 LFQ_ERR_CAPACITY = -4
 LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ, LFQ_USE_IDAQ = 1, 2, 4, 8
 LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP, LFQ_PV_UNDERFLOW = 0, 1, 2, 3
@@ -150,6 +151,9 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.lfq_abi_version.restype = C.c_int
+    if L.lfq_abi_version() != LFQ_ABI_VERSION:
+        raise RuntimeError("lofreq_amd: %s has ABI version %d, this package expects %d (struct layouts differ) -- rebuild it"
+                           % (LIB_PATH, L.lfq_abi_version(), LFQ_ABI_VERSION))
     L.lfq_strerror.restype = C.c_char_p
     L.lfq_strerror.argtypes = [C.c_int]
     L.lfq_conf_init.argtypes = [C.POINTER(Conf)]

@@ -42,6 +42,10 @@ int main(int argc, char **argv)
         return 4;
     }
     lfq_conf_init(&conf);
+    if (getenv("LFQ_TEST_FIXED_BONF")) {        /* `lofreq call -b N`: a fixed factor, nothing to rebase */
+        conf.bonf_dynamic = 0;
+        conf.bonf_subst = atoll(getenv("LFQ_TEST_FIXED_BONF"));
+    }
     rc = lfq_par_merge_snvs(p, &conf, pv, hdr[2], hdr[0], hdr[1], &rec, &n_rec);
     if (rc != LFQ_OK) {
         fprintf(stderr, "lfq_par_merge_snvs: %d\n", rc);

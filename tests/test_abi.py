@@ -19,7 +19,7 @@ def test_exports_match_header():
     for name in sorted(declared):
         assert hasattr(L, name), "symbol %s declared in include/lofreq_amd.h but not exported" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert L.lfq_abi_version() == 1
+    assert L.lfq_abi_version() == _lib.LFQ_ABI_VERSION == int(re.search(r"#define LFQ_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_struct_layouts():

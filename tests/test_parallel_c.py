@@ -83,6 +83,16 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
     assert len(local) > len(want)
 
     rdv = str(tmp_path / "rdv")
+    # what a crashed run under the same rendezvous path leaves behind: files of the right size for the first two
+    # collectives (16 B of header + 16 / 8 B of payload) and a <rdv>.job older than any rank 0 would wait -- this run
+    # must wait past all of them (they carry another run's nonce)
+    for r in range(world):
+        for k, n in ((0, 32), (1, 24)):
+            with open("%s.ag%d.%d" % (rdv, k, r), "wb") as f:
+                f.write(np.array([0x3152415051464c, 12345], np.uint64).tobytes() + b"\x07" * (n - 16))
+    with open(rdv + ".job", "wb") as f:
+        f.write(np.array([0x3152415051464c, 0, 12345], np.uint64).tobytes())
+    os.utime(rdv + ".job", (1.0e9, 1.0e9))
     procs = []
     for r, (pv, n_tested, n_indel) in enumerate(shards):
         g = pv.copy()
@@ -113,6 +123,47 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
     assert raw[off + 8:off + 8 + n_txt].decode() == "".join("%d\tchr%d\n" % (r, r + 1) for r in range(world))
     left = [f for f in os.listdir(tmp_path) if f.startswith("rdv.ag")]
     assert len(left) <= world, left                    # only the closing barrier's files stay behind
+
+
+def test_fixed_bonferroni_is_not_rebased(harness, tmp_path):
+    """`-b N` (bonf_dynamic = 0): every column carries the same factor N wherever it was called (lofreq_call.c:794 is
+    the only place the factor moves), so the merge must leave the factors alone -- ranks > 0 used to add 3 x prefix"""
+    world, n_cols, fixed = 2, 50000, 30000
+    rng = np.random.default_rng(77)
+    shards = []
+    for r in range(world):
+        pv, n_tested = _fake_shard(rng, n_cols, 0)
+        pv["bonf"] = fixed
+        for a in range(3):      # around log(sig / N): the factor decides
+            pv["logp"][:, a] = np.log(0.01 / fixed) + rng.normal(0, 1.5, len(pv))
+        pv["col"] += r * n_cols
+        shards.append((pv, n_tested))
+    conf = la.VarcallConf()
+    conf.bonf_dynamic, conf.bonf_subst = 0, fixed
+    want = np.concatenate([la.finalize_pvals(conf, s[0]) for s in shards])
+    over = shards[1][0].copy()
+    over["bonf"] += 3 * shards[0][1]
+    assert len(la.finalize_pvals(conf, over)) < len(la.finalize_pvals(conf, shards[1][0]))   # the old behaviour loses calls
+    rdv = str(tmp_path / "rdv")
+    procs = []
+    for r, (pv, n_tested) in enumerate(shards):
+        path = str(tmp_path / ("in%d" % r))
+        with open(path, "wb") as f:
+            f.write(np.array([n_tested, 0, len(pv)], np.int64).tobytes())
+            f.write(pv.tobytes())
+        env = dict(os.environ, LFQ_PAR_WORLD=str(world), LFQ_PAR_RANK=str(r), LFQ_PAR_RENDEZVOUS=rdv,
+                   LFQ_PAR_TRANSPORT="files", LFQ_PAR_TIMEOUT_S="60", LFQ_TEST_FIXED_BONF=str(fixed))
+        procs.append(subprocess.Popen([harness, path, str(tmp_path / ("out%d" % r))], env=env, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err.decode()
+    raw = open(tmp_path / "out0", "rb").read()
+    cs = C.sizeof(_lib.Conf)
+    got_conf = _lib.Conf.from_buffer_copy(raw[:cs])
+    n_rec = int(np.frombuffer(raw[cs:cs + 8], np.int64)[0])
+    recs = np.frombuffer(raw[cs + 8:cs + 8 + 64 * n_rec], _lib.SNV_RECORD_DTYPE)
+    assert n_rec == len(want) and recs.tobytes() == want.tobytes()
+    assert got_conf.bonf_subst == fixed and got_conf.num_snv_tests == 3 * sum(s[1] for s in shards)
 
 
 def test_single_process_is_a_no_op(harness, tmp_path):
