@@ -56,6 +56,7 @@ int lfq_create(lfq_ctx **ctx, int device_ordinal)
     return LFQ_OK;
 }
 void lfq_destroy(lfq_ctx *ctx) { free(ctx); }
+int lfq_abi_version(void) { return LFQ_ABI_VERSION; }
 int lfq_pick_device(int n_devices, int *slot) { (void)n_devices; if (slot) *slot = -1; return 0; }
 const char *lfq_strerror(int status) { (void)status; return "mock"; }
 void lfq_conf_init(lfq_conf *c)
