@@ -505,6 +505,76 @@ void lfq_holm_bonf_corr(double *pvals, int64_t n, double alpha, int64_t num_test
 int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thresh,
                        int apply_defaults, uint8_t *keep);
 
+/* --- `lofreq filter`, every mode (lofreq_filter.c:861-1331): what lfq_filter_records / lfq_filter_indel_records do for
+ * the one configuration `lofreq call` passes, for any configuration of the command.  The reference works on the variants
+ * of a VCF file in file order, SNVs and indels mixed; here a variant is the handful of fields the filters look at. */
+typedef enum lfq_mtc_type {        /* mtc_type_t, multtest.h:33-39 */
+    LFQ_MTC_NONE = 0,
+    LFQ_MTC_BONF = 1,
+    LFQ_MTC_HOLMBONF = 2,
+    LFQ_MTC_FDR = 3
+} lfq_mtc_type;
+
+typedef struct lfq_filter_conf {    /* filter_conf_t, lofreq_filter.c:59-112 */
+    int32_t only_snvs, only_indels;          /* --only-snvs / --only-indels: the other kind is dropped, not filtered */
+    int32_t dp_min, dp_max;                  /* -v / -V; < 1 = off */
+    float af_min, af_max;                    /* -a / -A; <= 0 = off */
+    int32_t sb_thresh;                       /* -B: filter if SB > thresh (and the compound rule); 0 = off */
+    int32_t sb_mtc_type;                     /* -b: lfq_mtc_type; conflicts with sb_thresh */
+    double sb_alpha;                         /* -c */
+    int64_t sb_ntests;                       /* 0 = the number of variants tested; set on return */
+    int32_t sb_no_compound;                  /* --sb-no-compound: without "85 % of the alt bases on one strand" (:57, 214-236) */
+    int32_t sb_incl_indels;                  /* --sb-incl-indels */
+    int32_t snvqual_thresh;                  /* -Q: filter SNVs with -1 < QUAL < thresh; 0 = off */
+    int32_t snvqual_mtc_type;                /* -q */
+    double snvqual_alpha;                    /* -r */
+    int64_t snvqual_ntests;                  /* -s; 0 = the number of SNVs; set on return */
+    int32_t indelqual_thresh;                /* -K */
+    int32_t indelqual_mtc_type;              /* -k */
+    double indelqual_alpha;                  /* -l */
+    int64_t indelqual_ntests;                /* -m */
+} lfq_filter_conf;
+
+/* main_filter's initial values (:1091-1097): everything off, the three alphas at DEFAULT_SIG 0.01 */
+void lfq_filter_conf_init(lfq_filter_conf *conf);
+/* what main_filter does after its options are parsed unless --no-defaults is given (:1184-1197): strand bias by FDR at
+ * alpha 0.001 if neither -B nor -b was set, DP >= 10 if -v was not set.  Call it after setting the options. */
+void lfq_filter_conf_defaults(lfq_filter_conf *conf);
+
+typedef struct lfq_filter_var {     /* one variant as mtc_quals_from_vcf_file (:790-858) and the apply_* functions read it */
+    int32_t is_indel;
+    int32_t qual;                   /* QUAL; -1 = missing (counts as INT_MAX in the corrections, :824-831) */
+    int32_t dp;                     /* INFO DP */
+    int32_t sb;                     /* INFO SB (0 if absent, :845) */
+    int32_t alt_fw, alt_rv;         /* DP4[2], DP4[3] */
+    float af;                       /* INFO AF as strtof of its text (%f: six decimals) -- lfq_filter_var_from_* do that */
+    int32_t pad_;
+} lfq_filter_var;
+
+/* bits of a variant's result */
+#define LFQ_FILT_AF_MIN 1u
+#define LFQ_FILT_AF_MAX 2u
+#define LFQ_FILT_DP_MIN 4u
+#define LFQ_FILT_DP_MAX 8u
+#define LFQ_FILT_SNVQUAL 16u
+#define LFQ_FILT_INDELQUAL 32u
+#define LFQ_FILT_SB 64u
+#define LFQ_FILT_DROPPED 128u       /* --only-snvs / --only-indels: not written at all */
+
+/* fail[i] = the filters variant i fails, in the bit order the reference appends their ids to FILTER (:1255-1297);
+ * 0 = PASS.  conf's *_ntests are filled in as the reference fills them in (:407-415).  Returns LFQ_ERR_INVALID for the
+ * option conflicts main_filter rejects (:1205-1227). */
+int lfq_filter_vars(lfq_filter_conf *conf, const lfq_filter_var *vars, int64_t n, uint32_t *fail);
+/* the id one bit stands for (min_dp_10, sb_fdr, snvqual_bonf, min_snvqual_53, ...; cfg_filter_to_vcf_header,
+ * :682-786); returns its length, 0 if that filter is off */
+int lfq_filter_id(const lfq_filter_conf *conf, uint32_t bit, char *buf, int buflen);
+/* the FILTER column of a variant: ids joined by ';' (vcf_var_add_to_filter, vcf.c:524-563), "PASS" for 0 */
+int lfq_filter_string(const lfq_filter_conf *conf, uint32_t fail_bits, char *buf, int buflen);
+/* the ##FILTER header lines the configuration adds, in the reference's order; returns the text's length */
+int lfq_filter_header_lines(const lfq_filter_conf *conf, char *buf, int buflen);
+void lfq_filter_var_from_snv(const lfq_snv_record *rec, lfq_filter_var *out);
+void lfq_filter_var_from_indel(const lfq_indel_record *rec, lfq_filter_var *out);
+
 /* --- `lofreq uniq --use-det-lim` (uniq_snv, lofreq_uniq.c:222-333): the second consumer of the
  * column boundary.  For every column (the pileup of the OTHER sample at a variant's position, built with uniq's
  * own mpileup settings: no BAQ, MAPQ >= 1, lofreq_uniq.c:461-465) and the variant's allele frequency af[col]:

@@ -128,7 +128,23 @@ EXPORTS = [
     "lfq_set_pileup_nt_packed", "lfq_set_baq_hmm_params", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
     "lfq_readset_create", "lfq_readset_destroy", "lfq_readset_baq", "lfq_readset_source_qual",
     "lfq_readset_pileup_snv", "lfq_readset_pileup_indels", "lfq_readset_fetch_tags",
+    "lfq_filter_conf_init", "lfq_filter_conf_defaults", "lfq_filter_vars", "lfq_filter_id", "lfq_filter_string",
+    "lfq_filter_header_lines", "lfq_filter_var_from_snv", "lfq_filter_var_from_indel",
 ]
+
+class FilterConf(C.Structure):
+    """lfq_filter_conf (filter_conf_t, lofreq_filter.c:59-112)"""
+    _fields_ = [("only_snvs", C.c_int32), ("only_indels", C.c_int32), ("dp_min", C.c_int32), ("dp_max", C.c_int32),
+                ("af_min", C.c_float), ("af_max", C.c_float), ("sb_thresh", C.c_int32), ("sb_mtc_type", C.c_int32),
+                ("sb_alpha", C.c_double), ("sb_ntests", C.c_int64), ("sb_no_compound", C.c_int32),
+                ("sb_incl_indels", C.c_int32), ("snvqual_thresh", C.c_int32), ("snvqual_mtc_type", C.c_int32),
+                ("snvqual_alpha", C.c_double), ("snvqual_ntests", C.c_int64), ("indelqual_thresh", C.c_int32),
+                ("indelqual_mtc_type", C.c_int32), ("indelqual_alpha", C.c_double), ("indelqual_ntests", C.c_int64)]
+
+
+FILTER_VAR_DTYPE = np.dtype([("is_indel", "i4"), ("qual", "i4"), ("dp", "i4"), ("sb", "i4"), ("alt_fw", "i4"),
+                             ("alt_rv", "i4"), ("af", "f4"), ("pad_", "i4")], align=True)
+assert FILTER_VAR_DTYPE.itemsize == 32
 
 _lib = None
 
@@ -229,6 +245,18 @@ def load():
     L.lfq_format_indel_record.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p,
                                           C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_char_p]
+    L.lfq_filter_conf_init.argtypes = [C.POINTER(FilterConf)]
+    L.lfq_filter_conf_init.restype = None
+    L.lfq_filter_conf_defaults.argtypes = [C.POINTER(FilterConf)]
+    L.lfq_filter_conf_defaults.restype = None
+    L.lfq_filter_vars.argtypes = [C.POINTER(FilterConf), vp, C.c_int64, vp]
+    L.lfq_filter_id.argtypes = [C.POINTER(FilterConf), C.c_uint32, C.c_char_p, C.c_int]
+    L.lfq_filter_string.argtypes = [C.POINTER(FilterConf), C.c_uint32, C.c_char_p, C.c_int]
+    L.lfq_filter_header_lines.argtypes = [C.POINTER(FilterConf), C.c_char_p, C.c_int]
+    L.lfq_filter_var_from_snv.argtypes = [vp, vp]
+    L.lfq_filter_var_from_snv.restype = None
+    L.lfq_filter_var_from_indel.argtypes = [vp, vp]
+    L.lfq_filter_var_from_indel.restype = None
     _lib = L
     return L
 

@@ -22,6 +22,7 @@
 #include <functional>
 #include <mutex>
 #include <sched.h>
+#include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -988,6 +989,296 @@ int lfq_filter_records(const lfq_snv_record *records, int64_t n, int snvqual_thr
         }
     }
     return LFQ_OK;
+}
+
+#define LFQ_HOST_TRY(expr) do { const int rc_ = (expr); if (rc_ != LFQ_OK) return rc_; } while (0)
+/* ---- `lofreq filter`, every mode (lofreq_filter.c) ------------------------------------------------------------------ */
+void lfq_filter_conf_init(lfq_filter_conf *c)
+{
+    if (!c) {
+        return;
+    }
+    memset(c, 0, sizeof(*c));
+    c->dp_min = c->dp_max = -1;                      /* lofreq_filter.c:1093-1097 */
+    c->af_min = c->af_max = -1;
+    c->sb_alpha = c->snvqual_alpha = c->indelqual_alpha = 0.01;     /* DEFAULT_SIG, defaults.h:68 */
+}
+
+void lfq_filter_conf_defaults(lfq_filter_conf *c)
+{
+    if (!c) {
+        return;
+    }
+    if (c->sb_mtc_type == LFQ_MTC_NONE && !c->sb_thresh) {           /* lofreq_filter.c:1184-1197 */
+        c->sb_mtc_type = LFQ_MTC_FDR;
+        c->sb_alpha = 0.001;
+    }
+    if (c->dp_min < 0) {
+        c->dp_min = 10;
+    }
+}
+
+namespace {
+
+/* the three apply_*_filter_mtc functions (lofreq_filter.c:376-677) are one: correct the probabilities of the selected
+ * variants, report which come out below alpha */
+int filter_mtc(std::vector<double> &p, int mtc_type, double alpha, int64_t *ntests, std::vector<uint8_t> &signif)
+{
+    const int64_t n = (int64_t)p.size();
+    signif.assign((size_t)n, 0);
+    if (n <= 0) {
+        return LFQ_OK;
+    }
+    if (!*ntests) {
+        *ntests = n;                                 /* :407-409; a smaller predefined count only earns a warning there */
+    }
+    if (mtc_type == LFQ_MTC_BONF) {
+        lfq_bonf_corr(p.data(), n, *ntests);
+    } else if (mtc_type == LFQ_MTC_HOLMBONF) {
+        lfq_holm_bonf_corr(p.data(), n, alpha, *ntests);
+    } else if (mtc_type == LFQ_MTC_FDR) {
+        std::vector<int64_t> rej((size_t)n);
+        const int64_t nrej = lfq_fdr(p.data(), n, alpha, *ntests, rej.data());
+        std::fill(p.begin(), p.end(), DBL_MAX);      /* :437-445 */
+        for (int64_t i = 0; i < nrej; i++) {
+            p[(size_t)rej[(size_t)i]] = -1;
+        }
+    } else {
+        return LFQ_ERR_INVALID;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        signif[(size_t)i] = p[(size_t)i] < alpha ? 1 : 0;
+    }
+    return LFQ_OK;
+}
+
+bool alt_mostly_on_one_strand(const lfq_filter_var &v)         /* :214-236 */
+{
+    const float ratio = std::max(v.alt_fw, v.alt_rv) / (float)(v.alt_fw + v.alt_rv);
+    return ratio > 0.85;
+}
+
+const char *mtc_name(int t)                          /* mtc_str, multtest.c:205-214 */
+{
+    return t == LFQ_MTC_BONF ? "bonf" : (t == LFQ_MTC_HOLMBONF ? "holmbonf" : (t == LFQ_MTC_FDR ? "fdr" : "none"));
+}
+
+}  // namespace
+
+int lfq_filter_vars(lfq_filter_conf *c, const lfq_filter_var *vars, int64_t n, uint32_t *fail)
+{
+    if (!c || n < 0 || (n > 0 && (!vars || !fail))) {
+        return LFQ_ERR_INVALID;
+    }
+    /* main_filter's checks (:1177-1227) */
+    if ((c->only_indels && c->only_snvs) || (c->dp_max > 0 && c->dp_max < c->dp_min)
+        || (c->af_max > 0 && c->af_max < c->af_min) || c->af_max > 1.0
+        || (c->sb_thresh && c->sb_mtc_type != LFQ_MTC_NONE) || (c->snvqual_thresh && c->snvqual_mtc_type != LFQ_MTC_NONE)
+        || (c->indelqual_thresh && c->indelqual_mtc_type != LFQ_MTC_NONE)) {
+        return LFQ_ERR_INVALID;
+    }
+    /* first pass (:1246-1281): the corrections see EVERY variant of the file, also the ones --only-snvs / --only-indels
+     * drop afterwards; order sb, indel quality, SNV quality */
+    std::vector<uint8_t> sb_sig, iq_sig, sq_sig;
+    std::vector<int64_t> sb_ix, iq_ix, sq_ix;
+    /* A quirk of the reference that decides FILTER columns: apply_af_filter tests `errno == ERANGE` after its strtof
+     * without clearing errno first (:252-261), and switches AF filtering off for the rest of the run if it is set.  The
+     * first pass leaves it set whenever one of its pow(10, -q / 10) underflows (QUAL or SB beyond ~3070: glibc reports
+     * the subnormal / zero result) -- with a correction requested and such a variant in the file, -a / -A do nothing.
+     * Same libm here, so the same calls are watched. */
+    errno = 0;
+    auto qual_of = [](const lfq_filter_var &v) { return v.qual == -1 ? INT_MAX : v.qual; };      /* :824-831 */
+    if (c->sb_mtc_type != LFQ_MTC_NONE) {
+        std::vector<double> p;
+        for (int64_t i = 0; i < n; i++) {
+            if (!c->sb_incl_indels && vars[i].is_indel) {
+                continue;
+            }
+            p.push_back(phred_to_prob(vars[i].sb));
+            sb_ix.push_back(i);
+        }
+        LFQ_HOST_TRY(filter_mtc(p, c->sb_mtc_type, c->sb_alpha, &c->sb_ntests, sb_sig));
+    }
+    if (c->indelqual_mtc_type != LFQ_MTC_NONE) {
+        std::vector<double> p;
+        for (int64_t i = 0; i < n; i++) {
+            if (vars[i].is_indel) {
+                p.push_back(phred_to_prob(qual_of(vars[i])));
+                iq_ix.push_back(i);
+            }
+        }
+        LFQ_HOST_TRY(filter_mtc(p, c->indelqual_mtc_type, c->indelqual_alpha, &c->indelqual_ntests, iq_sig));
+    }
+    if (c->snvqual_mtc_type != LFQ_MTC_NONE) {
+        std::vector<double> p;
+        for (int64_t i = 0; i < n; i++) {
+            if (!vars[i].is_indel) {
+                p.push_back(phred_to_prob(qual_of(vars[i])));
+                sq_ix.push_back(i);
+            }
+        }
+        LFQ_HOST_TRY(filter_mtc(p, c->snvqual_mtc_type, c->snvqual_alpha, &c->snvqual_ntests, sq_sig));
+    }
+    const bool af_off = errno == ERANGE;
+    /* second pass (:1323-1386) */
+    for (int64_t i = 0; i < n; i++) {
+        const lfq_filter_var &v = vars[i];
+        uint32_t f = 0;
+        if ((c->only_snvs && v.is_indel) || (c->only_indels && !v.is_indel)) {
+            fail[i] = LFQ_FILT_DROPPED;
+            continue;
+        }
+        if (!af_off && c->af_min > 0.0 && v.af < c->af_min) f |= LFQ_FILT_AF_MIN;          /* apply_af_filter */
+        if (!af_off && c->af_max > 0.0 && v.af > c->af_max) f |= LFQ_FILT_AF_MAX;
+        if (c->dp_min > 0 && v.dp < c->dp_min) f |= LFQ_FILT_DP_MIN;            /* apply_dp_filter */
+        if (c->dp_max > 0 && v.dp > c->dp_max) f |= LFQ_FILT_DP_MAX;
+        if (!v.is_indel && c->snvqual_thresh && v.qual > -1 && v.qual < c->snvqual_thresh) f |= LFQ_FILT_SNVQUAL;
+        if (v.is_indel && c->indelqual_thresh && v.qual > -1 && v.qual < c->indelqual_thresh) f |= LFQ_FILT_INDELQUAL;
+        if (c->sb_thresh && (!v.is_indel || c->sb_incl_indels) && v.sb > c->sb_thresh
+            && (c->sb_no_compound || alt_mostly_on_one_strand(v))) {
+            f |= LFQ_FILT_SB;                                                   /* apply_sb_threshold */
+        }
+        fail[i] = f;
+    }
+    /* quality corrections: a variant that is NOT significant is filtered (:1337-1339, 1347-1349) */
+    for (size_t k = 0; k < sq_ix.size(); k++) {
+        if (!sq_sig[k] && fail[sq_ix[k]] != LFQ_FILT_DROPPED) fail[sq_ix[k]] |= LFQ_FILT_SNVQUAL;
+    }
+    for (size_t k = 0; k < iq_ix.size(); k++) {
+        if (!iq_sig[k] && fail[iq_ix[k]] != LFQ_FILT_DROPPED) fail[iq_ix[k]] |= LFQ_FILT_INDELQUAL;
+    }
+    /* strand bias: the other way round -- significant bias, and the compound rule, filters (:660-666, 1361-1367) */
+    for (size_t k = 0; k < sb_ix.size(); k++) {
+        const int64_t i = sb_ix[k];
+        if (sb_sig[k] && fail[i] != LFQ_FILT_DROPPED && (c->sb_no_compound || alt_mostly_on_one_strand(vars[i]))) {
+            fail[i] |= LFQ_FILT_SB;
+        }
+    }
+    return LFQ_OK;
+}
+
+int lfq_filter_id(const lfq_filter_conf *c, uint32_t bit, char *buf, int buflen)
+{
+    if (!c || !buf || buflen < 1) {
+        return 0;
+    }
+    int k = 0;
+    buf[0] = 0;
+    switch (bit) {                                    /* cfg_filter_to_vcf_header, :682-786 */
+    case LFQ_FILT_AF_MIN: if (c->af_min > 0) k = snprintf(buf, (size_t)buflen, "min_af_%f", c->af_min); break;
+    case LFQ_FILT_AF_MAX: if (c->af_max > 0) k = snprintf(buf, (size_t)buflen, "max_af_%f", c->af_max); break;
+    case LFQ_FILT_DP_MIN: if (c->dp_min > 0) k = snprintf(buf, (size_t)buflen, "min_dp_%d", c->dp_min); break;
+    case LFQ_FILT_DP_MAX: if (c->dp_max > 0) k = snprintf(buf, (size_t)buflen, "max_dp_%d", c->dp_max); break;
+    case LFQ_FILT_SB:
+        if (c->sb_thresh > 0) k = snprintf(buf, (size_t)buflen, "max_sb_%d", c->sb_thresh);
+        else if (c->sb_mtc_type != LFQ_MTC_NONE) k = snprintf(buf, (size_t)buflen, "sb_%s", mtc_name(c->sb_mtc_type));
+        break;
+    case LFQ_FILT_SNVQUAL:
+        if (c->snvqual_thresh > 0) k = snprintf(buf, (size_t)buflen, "min_snvqual_%d", c->snvqual_thresh);
+        else if (c->snvqual_mtc_type != LFQ_MTC_NONE) k = snprintf(buf, (size_t)buflen, "snvqual_%s", mtc_name(c->snvqual_mtc_type));
+        break;
+    case LFQ_FILT_INDELQUAL:
+        if (c->indelqual_thresh > 0) k = snprintf(buf, (size_t)buflen, "min_indelqual_%d", c->indelqual_thresh);
+        else if (c->indelqual_mtc_type != LFQ_MTC_NONE) k = snprintf(buf, (size_t)buflen, "indelqual_%s", mtc_name(c->indelqual_mtc_type));
+        break;
+    default: break;
+    }
+    return k < 0 ? 0 : (k >= buflen ? buflen - 1 : k);
+}
+
+int lfq_filter_string(const lfq_filter_conf *c, uint32_t f, char *buf, int buflen)
+{
+    if (!c || !buf || buflen < 5) {
+        return 0;
+    }
+    /* the order main_filter applies them in: af, dp, quality, sb (:1323-1370) */
+    static const uint32_t order[] = {LFQ_FILT_AF_MIN, LFQ_FILT_AF_MAX, LFQ_FILT_DP_MIN, LFQ_FILT_DP_MAX, LFQ_FILT_SNVQUAL,
+                                     LFQ_FILT_INDELQUAL, LFQ_FILT_SB};
+    int used = 0;
+    buf[0] = 0;
+    for (uint32_t b : order) {
+        if (!(f & b)) {
+            continue;
+        }
+        char id[96];
+        const int k = lfq_filter_id(c, b, id, (int)sizeof(id));
+        if (k <= 0 || used + k + 2 > buflen) {
+            continue;
+        }
+        if (used) {
+            buf[used++] = ';';
+        }
+        memcpy(buf + used, id, (size_t)k + 1);
+        used += k;
+    }
+    if (!used) {
+        used = snprintf(buf, (size_t)buflen, "PASS");
+    }
+    return used;
+}
+
+int lfq_filter_header_lines(const lfq_filter_conf *c, char *buf, int buflen)
+{
+    if (!c || !buf || buflen < 1) {
+        return 0;
+    }
+    std::string s;
+    char id[96], line[512];
+    auto add = [&](const char *fmt, auto... a) {
+        snprintf(line, sizeof(line), fmt, a...);
+        s += line;
+    };
+    if (lfq_filter_id(c, LFQ_FILT_AF_MIN, id, sizeof(id))) add("##FILTER=<ID=%s,Description=\"Minimum allele frequency %f\">\n", id, c->af_min);
+    if (lfq_filter_id(c, LFQ_FILT_AF_MAX, id, sizeof(id))) add("##FILTER=<ID=%s,Description=\"Maximum allele frequency %f\">\n", id, c->af_max);
+    if (lfq_filter_id(c, LFQ_FILT_DP_MIN, id, sizeof(id))) add("##FILTER=<ID=%s,Description=\"Minimum Coverage %d\">\n", id, c->dp_min);
+    if (lfq_filter_id(c, LFQ_FILT_DP_MAX, id, sizeof(id))) add("##FILTER=<ID=%s,Description=\"Maximum Coverage %d\">\n", id, c->dp_max);
+    if (lfq_filter_id(c, LFQ_FILT_SB, id, sizeof(id))) {
+        if (c->sb_thresh > 0) add("##FILTER=<ID=%s,Description=\"Maximum Strand-Bias Phred %d\">\n", id, c->sb_thresh);
+        else add("##FILTER=<ID=%s,Description=\"Strand-Bias Multiple Testing Correction: %s corr. pvalue > %f\">\n", id, mtc_name(c->sb_mtc_type), c->sb_alpha);
+    }
+    if (lfq_filter_id(c, LFQ_FILT_SNVQUAL, id, sizeof(id))) {
+        if (c->snvqual_thresh > 0) add("##FILTER=<ID=%s,Description=\"Minimum SNV Quality (Phred) %d\">\n", id, c->snvqual_thresh);
+        else add("##FILTER=<ID=%s,Description=\"SNV Quality Multiple Testing Correction: %s corr. pvalue < %f\">\n", id, mtc_name(c->snvqual_mtc_type), c->snvqual_alpha);
+    }
+    if (lfq_filter_id(c, LFQ_FILT_INDELQUAL, id, sizeof(id))) {
+        if (c->indelqual_thresh > 0) add("##FILTER=<ID=%s,Description=\"Minimum Indel Quality (Phred) %d\">\n", id, c->indelqual_thresh);
+        else add("##FILTER=<ID=%s,Description=\"Indel Quality Multiple Testing Correction: %s corr. pvalue < %f\">\n", id, mtc_name(c->indelqual_mtc_type), c->indelqual_alpha);
+    }
+    const int k = (int)std::min<size_t>(s.size(), (size_t)buflen - 1);
+    memcpy(buf, s.data(), (size_t)k);
+    buf[k] = 0;
+    return (int)s.size();
+}
+
+static float af_through_text(float af)               /* the filter reads AF back from the "%f" text (apply_af_filter, :252) */
+{
+    char t[64];
+    snprintf(t, sizeof(t), "%f", af);
+    return strtof(t, nullptr);
+}
+
+void lfq_filter_var_from_snv(const lfq_snv_record *r, lfq_filter_var *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->is_indel = 0;
+    o->qual = r->qual;
+    o->dp = r->dp;
+    o->sb = r->sb;
+    o->alt_fw = r->alt_fw;
+    o->alt_rv = r->alt_rv;
+    o->af = af_through_text(r->alt_raw_count / (float)r->dp);     /* report_var's AF, lofreq_call.c:835 */
+}
+
+void lfq_filter_var_from_indel(const lfq_indel_record *r, lfq_filter_var *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->is_indel = 1;
+    o->qual = r->qual;
+    o->dp = r->dp;
+    o->sb = r->sb;
+    o->alt_fw = r->alt_fw;
+    o->alt_rv = r->alt_rv;
+    o->af = af_through_text(r->af);
 }
 
 }  // extern "C"

@@ -702,6 +702,93 @@ def main_uniq():
     run_uniq_binom("uniq_binom", 82, 400, 1500, mq_mix)
 
 
+# ---- lofreq filter, every mode (lofreq_filter.c) ---------------------------------------------------------------
+
+FILTER_CASES = [
+    [],                                                       # the defaults: SB by FDR at 0.001 + compound rule, DP >= 10
+    ["--no-defaults"],
+    ["--no-defaults", "-v", "40", "-V", "900"],
+    ["--no-defaults", "-a", "0.02", "-A", "0.6"],
+    ["--no-defaults", "-Q", "60", "-K", "45"],
+    ["--no-defaults", "-q", "bonf", "-r", "0.0001"],
+    ["--no-defaults", "-q", "holm", "-r", "0.00001", "-s", "5000"],
+    ["--no-defaults", "-q", "fdr", "-r", "0.000001", "-s", "100000"],
+    ["--no-defaults", "-k", "bonf", "-l", "0.001", "-m", "300"],
+    ["--no-defaults", "-k", "fdr", "-l", "0.00001"],
+    ["--no-defaults", "-B", "30"],
+    ["--no-defaults", "-B", "30", "--sb-no-compound"],
+    ["--no-defaults", "-B", "30", "--sb-incl-indels"],
+    ["--no-defaults", "-b", "bonf", "-c", "0.001"],
+    ["--no-defaults", "-b", "holm", "-c", "0.01", "--sb-no-compound", "--sb-incl-indels"],
+    ["-b", "fdr", "-c", "0.05", "-v", "25", "-q", "fdr", "-k", "holm", "-a", "0.004"],
+    ["--no-defaults", "--only-snvs", "-Q", "80"],
+    ["--no-defaults", "--only-indels", "-k", "bonf"],
+]
+
+
+def run_filter(name, seed, n, quals=(20, 44, 45, 46, 59, 60, 61, 75, 90, 140, 400, 3000, 49314), sbs=(0, 0, 1, 3, 12, 29, 30, 31, 45, 80, 200, 2147483647), case_list=None):
+    """a VCF of `n` seeded variants (SNVs and indels; QUAL, DP, AF, SB, DP4 over the ranges the filters cut at, one missing
+    QUAL) through the binary's `lofreq filter --print-all` for every option set of FILTER_CASES: the FILTER column of every
+    variant and the ##FILTER lines it added; and without --print-all: which variants are written"""
+    rng = np.random.default_rng(seed)
+    lines, pos = [], 100
+    for i in range(n):
+        pos += int(rng.integers(1, 40))
+        is_indel = rng.random() < 0.3
+        dp = int(rng.choice([5, 9, 10, 11, 24, 25, 60, 300, 899, 900, 901, 4000]))
+        alt = int(max(1, round(dp * float(rng.choice([0.003, 0.01, 0.02, 0.05, 0.3, 0.6, 0.95])))))
+        alt = min(alt, dp)
+        skew = float(rng.choice([0.5, 0.5, 0.8, 0.86, 0.97, 1.0]))
+        afw = int(round(alt * skew)) if rng.random() < 0.5 else alt - int(round(alt * skew))
+        arv = alt - afw
+        rfw = int((dp - alt) * float(rng.choice([0.5, 0.5, 0.3])))
+        rrv = dp - alt - rfw
+        sb = int(rng.choice(list(sbs)))
+        qual = int(rng.choice(list(quals)))
+        qs = "." if i == 7 else str(qual)
+        if is_indel:
+            ref, al = ("AC", "A") if rng.random() < 0.5 else ("A", "AGG")
+            info = "DP=%d;AF=%f;SB=%d;DP4=%d,%d,%d,%d;INDEL;HRUN=%d" % (dp, alt / float(dp), sb, rfw, rrv, afw, arv, int(rng.integers(1, 6)))
+        else:
+            ref, al = "A", "G"
+            info = "DP=%d;AF=%f;SB=%d;DP4=%d,%d,%d,%d" % (dp, alt / float(dp), sb, rfw, rrv, afw, arv)
+        lines.append("chr1\t%d\t.\t%s\t%s\t%s\t.\t%s" % (pos, ref, al, qs, info))
+    head = "##fileformat=VCFv4.0\n##source=lofreq call\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    cases = []
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "in.vcf"), "w").write(head + "\n".join(lines) + "\n")
+        for args in (case_list or FILTER_CASES):
+            res = {"args": args}
+            for tag, extra in (("all", ["--print-all"]), ("passed", [])):
+                p = subprocess.run([LOFREQ, "filter", "-i", "in.vcf", "-o", "out.vcf"] + args + extra, cwd=tmp,
+                                   capture_output=True, text=True)
+                assert p.returncode == 0, (args, p.stderr)
+                out = open(os.path.join(tmp, "out.vcf")).read().splitlines()
+                os.remove(os.path.join(tmp, "out.vcf"))
+                body = [l.split("\t") for l in out if not l.startswith("#")]
+                if tag == "all":
+                    res["filter_lines"] = [l for l in out if l.startswith("##FILTER")]
+                    res["pos"] = [int(f[1]) for f in body]
+                    res["filter"] = [f[6] for f in body]
+                else:
+                    res["passed_pos"] = [int(f[1]) for f in body]
+            cases.append(res)
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "vcf": lines, "cases": cases}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d variants, %d option sets, %d bytes" % (name, n, len(cases), os.path.getsize(path)))
+
+
+def main_filter():
+    run_filter("filter_modes", 91, 90)
+    # no QUAL / SB large enough for pow(10, -q / 10) to underflow: with a correction requested the AF filter still works
+    # here (in filter_modes it is switched off by the errno the first pass leaves behind, lofreq_filter.c:252-261)
+    run_filter("filter_modes_small", 92, 40, quals=(20, 45, 60, 75, 140, 400), sbs=(0, 1, 12, 30, 31, 80, 200),
+               case_list=[["-q", "fdr", "-a", "0.02", "-A", "0.5"], ["--no-defaults", "-b", "bonf", "-a", "0.02"],
+                      ["--no-defaults", "-k", "holm", "-A", "0.5", "-V", "500"]])
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -728,6 +815,8 @@ def main():
         return main_uniq()
     if "--deep10k-only" in sys.argv:
         return main_deep10k()
+    if "--filter-only" in sys.argv:
+        return main_filter()
     if not os.path.exists(LOFREQ):
         sys.exit("reference binary missing: run `make -C oracle ref` in the build container")
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
