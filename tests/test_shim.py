@@ -33,17 +33,22 @@ def harness(tmp_path_factory):
     (d / "stub" / "htslib" / "bgzf.h").write_text("#include <stdio.h>\ntypedef struct BGZF BGZF;\n")
     exe = str(d / "shim_harness")
     base = ["gcc", "-std=gnu99", "-O1", "-g", "-Wall", "-Wno-unused-function",
-            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "lofreq"), "-I" + os.path.join(REF, "uthash"),
-            "-I" + str(d / "stub"),
-            os.path.join(ROOT, "integration", "lofreq_amd_shim.c"), os.path.join(ROOT, "tests", "shim_harness.c"),
+            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration"), "-I" + os.path.join(REF, "lofreq"),
+            "-I" + os.path.join(REF, "uthash"), "-I" + str(d / "stub"),
+            os.path.join(ROOT, "integration", "lofreq_amd_shim.c"), os.path.join(ROOT, "integration", "lofreq_amd_colbatch.c"),
+            os.path.join(ROOT, "tests", "shim_harness.c"),
             os.path.join(REF, "lofreq", "utils.c"), os.path.join(REF, "lofreq", "log.c"), "-lm", "-o", exe]
     # the shim itself must compile without a single warning against the reference headers
     chk = subprocess.run(["gcc", "-std=gnu99", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter",
-                          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "lofreq"),
-                          "-I" + os.path.join(REF, "uthash"), "-I" + str(d / "stub"),
+                          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration"),
+                          "-I" + os.path.join(REF, "lofreq"), "-I" + os.path.join(REF, "uthash"), "-I" + str(d / "stub"),
                           os.path.join(ROOT, "integration", "lofreq_amd_shim.c")], capture_output=True, text=True)
     assert chk.returncode == 0, chk.stderr
     assert "lofreq_amd_shim.c" not in chk.stderr, chk.stderr
+    # ... and the packing core against include/lofreq_amd.h alone: no LoFreq header, no htslib
+    chk = subprocess.run(["gcc", "-std=gnu99", "-fsyntax-only", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "integration", "lofreq_amd_colbatch.c")], capture_output=True, text=True)
+    assert chk.returncode == 0 and not chk.stderr.strip(), chk.stderr
     asan = subprocess.run(base[:1] + ["-fsanitize=address", "-fno-omit-frame-pointer"] + base[1:], capture_output=True, text=True)
     if asan.returncode != 0:                        # no libasan in this image: the harness's poisoning still catches stale reads
         subprocess.run(base, check=True, capture_output=True, text=True)
@@ -194,10 +199,10 @@ def test_shim_skips_snvs_at_consensus_indel_columns(harness, tmp_path):
     assert nc == ncols - n_ref_n - len([c for c in skip if fx["columns"][c]["ref"] != "N"])
 
 
-def _indel_blob(cols):
+def _indel_blob(cols, pos=None):
     out = []
     for i, c in enumerate(cols):
-        out.append(_i32(100 + i, ord(c["ref"]), ord(c["ref"]), c["coverage_plp"], c["coverage_plp"], c["num_tails"],
+        out.append(_i32(pos[i] if pos is not None else 100 + i, ord(c["ref"]), ord(c["ref"]), c["coverage_plp"], c["coverage_plp"], c["num_tails"],
                         c["num_non_indels"], c["num_ins"], c["num_dels"], c["hrun"], 1))
         for _nt in range(5):
             out.append(_i32(0, 0, 0, 0))
