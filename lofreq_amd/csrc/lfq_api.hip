@@ -162,34 +162,10 @@ bool acquire_streams(int device, lfq_ctx *c)
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         bool ok = true;
-        const int split = lfq_knobs().cu_split;
-        hipDeviceProp_t prop;
-        int n_cu = 256;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
-            n_cu = prop.multiProcessorCount;
-        }
-        if (split > 0 && split < n_cu) {
-            /* Spatial partition (LFQ_CU_SPLIT): the three DP streams own `split` CUs, the main stream the rest, so that
-             * with two batches in flight the HBM-bound count kernel of batch k + 1 and the latency / issue-bound DP
-             * chains of batch k do not take wave slots and issue cycles from each other.  Bit i of a queue's CU mask is
-             * CU i / n_xcc of XCC i mod n_xcc on this part (the mask is dealt round-robin over the XCDs), so a prefix of
-             * the mask is the same number of CUs on every XCD. */
-            const int words = (n_cu + 31) / 32;
-            std::vector<uint32_t> m_dp((size_t)words, 0u), m_main((size_t)words, 0u);
-            for (int i = 0; i < n_cu; i++) {
-                (i < split ? m_dp : m_main)[(size_t)(i >> 5)] |= 1u << (i & 31);
-            }
-            ok = hipExtStreamCreateWithCUMask(&d.stream, (uint32_t)words, m_main.data()) == hipSuccess;
-            ok = ok && hipExtStreamCreateWithCUMask(&d.dps, (uint32_t)words, m_dp.data()) == hipSuccess;
-            for (int i = 0; ok && i < 2; i++) {
-                ok = hipExtStreamCreateWithCUMask(&d.side[i], (uint32_t)words, m_dp.data()) == hipSuccess;
-            }
-        } else {
-            ok = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess;
-            ok = ok && hipStreamCreateWithPriority(&d.dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
-            for (int i = 0; ok && i < 2; i++) {
-                ok = hipStreamCreateWithPriority(&d.side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
-            }
+        ok = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&d.dps, hipStreamNonBlocking, prio_hi) == hipSuccess;
+        for (int i = 0; ok && i < 2; i++) {
+            ok = hipStreamCreateWithPriority(&d.side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
         }
         if (!ok) {
             return false;
@@ -595,13 +571,10 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         LFQ_TRY_HIP(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
     }
 
-    /* Segments: the count kernel is HBM-bound and leaves the VALUs mostly idle, the DP kernels are
-     * latency/issue-bound and touch little memory.  Cutting the batch into segments lets the DP of
-     * segment s run (on other streams) under the count kernel of segment s+1.  The running Bonferroni
-     * prefix is carried from segment to segment on the device (LFQ_GC_TESTED). */
-    int n_seg = 1;   /* measured on C3: with the current kernels overlapping count and DP loses (both want wave slots
-                      * and VALU issue); kept switchable for experiments via LFQ_SEGMENTS */
-    n_seg = kn.segments;
+    /* One launch sequence per batch.  (Cutting a batch into segments so that the DP of one runs under the count kernel of
+     * the next was measured in rounds 1-3 and loses -- both want wave slots and VALU issue, profiles/NOTES.md; the loop
+     * below is what is left of it, with one segment.) */
+    const int n_seg = 1;
     c->cur_segments = n_seg;
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[2], st));
     LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_join[2], 0));   /* dps starts after the memset */
@@ -688,7 +661,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
          * -- every big column of a 1000x batch) need nothing from the segment / fold / combine kernels of the split ones.  With
          * one segment per batch the stream the count kernel ran on is idle from here on: they run there, beside that chain
          * instead of behind it (C2: 0.3 ms that used to start when the chain had ended). */
-        const bool big_on_st = run_big && n_seg == 1 && !single_stream && !kn.big_behind_chain;
+        const bool big_on_st = run_big && !single_stream;
         if (big_on_st) {
             LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_prep, 0));
             LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,

@@ -9,11 +9,11 @@
  * Mapping: ONE READ PER LANE.  The recurrence inside a row is sequential (the deletion state of cell k needs
  * cell k-1 of the same row, kprobaln_ext.c:166), and results have to be bit-identical to the reference's
  * doubles, so a lane walks its read's rows and cells in exactly the reference's order; 64 reads advance in
- * lock-step per wavefront.  Narrow-band reads (the default band of 7) keep the row the recurrences read in LDS,
- * updated in place, and send the forward matrix to HBM write-once for the MAP step (lfq_baq_kernel<true>);
- * everything else keeps every row in HBM, interleaved per wavefront ([row][cell][lane]: every access of a wave is
- * one coalesced 512-byte line), with two rotating backward rows (lfq_baq_kernel<false>).  The MAP step of a row
- * is done as soon as the backward row exists, so no backward matrix is stored.  See DESIGN.md 6b.
+ * lock-step per wavefront.  Narrow-band reads (the default band of 7, and band 8) keep the row the recurrences work on
+ * in REGISTERS and send every second forward row to HBM for the MAP step (lfq_baq_reg_kernel); everything else keeps
+ * every row in HBM, interleaved per wavefront ([row][cell][lane]: every access of a wave is one coalesced 512-byte
+ * line), with two rotating backward rows (lfq_baq_kernel).  The MAP step of a row is done as soon as the backward
+ * row exists, so no backward matrix is stored.  See DESIGN.md 6b.
  *
  * -ffp-contract=off (Makefile): no FMA contraction, every operation rounds like the reference's SSE2 build.
  */
@@ -65,22 +65,15 @@ __device__ __forceinline__ double lfq_baq_emit(int r, int qy, double ql)
     return (r > 3 || qy > 3) ? 1. : (r == qy ? 1. - ql : ql * LFQ_BAQ_EM);
 }
 
-/* LDS = true: the row the recurrences read (row i-1 of the forward pass, row i+1 of the backward pass) lives in
- * LDS and is updated IN PLACE, for reads whose rows fit LFQ_BAQ_LDS_CELLS cells (the default band of 7: every read
- * whose alignment does not shift by more than 7 bases).  The forward matrix still goes to HBM (stores only) for the backward pass's MAP
- * step; nothing of the backward matrix touches HBM.  LDS = false: the general kernel, every row in HBM. */
-#define LFQ_BAQ_LDS_W LFQ_BAQ_LDS_CELLS
-template <bool LDS>
+/* The general kernel: any band, every row in HBM (what reads with a band beyond 8 or a reference window beyond
+ * LFQ_BAQ_LDS_MAX_LREF get; the narrow bands run lfq_baq_reg_kernel below). */
 __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_launch)
 {
-    __shared__ double s_row[LDS ? LFQ_BAQ_LDS_W * 64 : 1];
-    extern __shared__ uint8_t s_ref[];          /* LDS variant: [l_ref / 2 + 1][64] base codes 0..4 of the reference window, two per byte */
     const int lane = (int)threadIdx.x;
     const int64_t ridx = (int64_t)blockIdx.x * 64 + lane;
     const bool live = ridx < n_launch;
     const int64_t rid = A.order ? (int64_t)A.order[A.first_read + (live ? ridx : 0)] : A.first_read + (live ? ridx : 0);
     const LfqBaqRead R = lfq_baq_read_of(A, rid);
-#define LQ(u_) s_row[(size_t)(u_) * 64 + lane]
     const int W = A.W, rows = A.rows;
     /* this wavefront's scratch */
     double *F = A.scratch + (size_t)blockIdx.x * ((size_t)rows * W + 2 * (size_t)W + 2 * ((size_t)rows + 2)) * 64;
@@ -99,15 +92,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     const uint8_t *query = A.seq + s0 - 1, *iqual = A.qual + s0 - 1;     /* 1-based like the reference */
     const uint8_t *refw = A.ref + R.xb - 1;
     uint8_t *out = A.lb_out + s0;
-    if (LDS) {
-        /* a global load inside the cell loops is an exposed L2 round trip per cell at this occupancy: the window's
-         * base codes go to LDS once (index 1..l_ref like refw) */
-        for (int k = 0; k <= R.l_ref; k += 2) {      /* two codes per byte: k even in the low nibble */
-            const int lo = k >= 1 ? lfq_baq_code(refw[k]) : 0, hi = k + 1 <= R.l_ref ? lfq_baq_code(refw[k + 1]) : 0;
-            s_ref[(size_t)(k >> 1) * 64 + lane] = (uint8_t)(lo | (hi << 4));
-        }
-    }
-#define RC(k_) (LDS ? (int)((s_ref[(size_t)((k_) >> 1) * 64 + lane] >> (((k_) & 1) * 4)) & 15) : lfq_baq_code(refw[k_]))
+#define RC(k_) lfq_baq_code(refw[k_])
     int bw = l_ref > l_query ? l_ref : l_query;                          /* kprobaln_ext.c:99-101 */
     if (bw > R.bw) bw = R.bw;
     if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
@@ -121,17 +106,6 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     m[6] = 1 - par_e; m[7] = 0.; m[8] = par_e;
     const double bM = (1 - par_d) / l_ref, bI = par_d / l_ref;
 
-    /* LDS variant: the HBM copy of the forward matrix only serves the MAP step (match / insertion cells) and the
-     * idaq terms (deletion cells of reads that have a deletion): deletion cells of other reads are not written */
-    bool keep_f2 = true;
-    if (LDS) {
-        keep_f2 = false;
-        const uint32_t *cg0 = A.cigar + R.cigar_off;
-        for (int k = 0; k < R.n_cigar; ++k) {
-            keep_f2 = keep_f2 || ((cg0[k] & 0xf) == 2);
-        }
-        keep_f2 = keep_f2 && A.itab != nullptr;
-    }
     /* ---- forward (:134-190) ----
      * Rows >= 2 are stored UNSCALED; the reference's `fi[k] *= 1/sum` (:181) is applied by whoever reads the
      * cell (the same multiplication of the same two doubles: identical value), which saves one read + write
@@ -141,9 +115,6 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     for (int u = 0; u < Wr; u++) {
         FQ(0, u) = 0.;
         FQ(1, u) = 0.;
-        if (LDS) {
-            LQ(u) = 0.;
-        }
     }
     FQ(0, lfq_baq_u(bw, 0, 0)) = 1.;
     SQ(0) = 1.;
@@ -166,9 +137,6 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         for (int k = b_; k <= e_; ++k) {
             const double v = FQ(1, k) / sum;
             FQ(1, k) = v;
-            if (LDS) {
-                LQ(k) = v;
-            }
         }
     }
     /* the per-row scalars are loaded one row ahead (a global load is an exposed round trip at this occupancy);
@@ -189,50 +157,14 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         x = i - bw; beg = beg > x ? beg : x;
         x = i + bw; end = end < x ? end : x;
         const int b_ = lfq_baq_u(bw, i, beg), e_ = lfq_baq_u(bw, i, end) + 2;
-        if (!LDS) {                                   /* (the LDS variant never reads HBM cells outside the band) */
-            for (int u = (b_ >= 3 ? b_ - 3 : 0); u < b_; u++) {
-                FQ(i, u) = 0.;
-            }
-            for (int u = e_ + 1; u < Wr && u <= e_ + 3; u++) {
-                FQ(i, u) = 0.;
-            }
+        for (int u = (b_ >= 3 ? b_ - 3 : 0); u < b_; u++) {
+            FQ(i, u) = 0.;
         }
+        for (int u = e_ + 1; u < Wr && u <= e_ + 3; u++) {
+            FQ(i, u) = 0.;
+        }
+    
         double m_prev = 0., d_prev = 0.;             /* cell k-1 of this row (unscaled, like the reference at that point) */
-        if (LDS) {
-            /* in place: u(i-1, k) = u(i, k) + 3 sh, so cell k overwrites what cell k+1 would read as its (k-1)
-             * neighbour when sh == 0 -- those three values travel in registers (a0..a2) */
-            const int sh = (i - bw > 0) ? 1 : 0;
-            const int ub = lfq_baq_u(bw, i, beg), v11b = ub + 3 * sh - 3;
-            double a0 = LQ(v11b + 0) * rs, a1 = LQ(v11b + 1) * rs, a2 = LQ(v11b + 2) * rs;
-            /* the three old cells at v10 of the NEXT k are requested before this k's values are written: they lie
-             * above everything this k writes (u + 3 sh + 3 > u + 2), so the order does not matter */
-            double n0 = LQ(ub + 3 * sh + 0), n1 = LQ(ub + 3 * sh + 1), n2 = LQ(ub + 3 * sh + 2);
-            for (int k = beg; k <= end; ++k) {
-                const int u = lfq_baq_u(bw, i, k), v10 = u + 3 * sh;
-                const double e = lfq_baq_emit(RC(k), qyi, qli);
-                const double c0 = n0 * rs, c1 = n1 * rs, c2 = n2 * rs;
-                if (k < end) {
-                    n0 = LQ(v10 + 3);
-                    n1 = LQ(v10 + 4);
-                    n2 = LQ(v10 + 5);
-                }
-                const double f0 = e * (m[0] * a0 + m[3] * a1 + m[6] * a2);
-                const double f1 = LFQ_BAQ_EI * (m[1] * c0 + m[4] * c1);
-                const double f2 = m[2] * m_prev + m[8] * d_prev;
-                FQ(i, u + 0) = f0;
-                FQ(i, u + 1) = f1;
-                if (keep_f2) {
-                    FQ(i, u + 2) = f2;
-                }
-                LQ(u + 0) = f0;
-                LQ(u + 1) = f1;
-                LQ(u + 2) = f2;
-                a0 = c0; a1 = c1; a2 = c2;
-                m_prev = f0;
-                d_prev = f2;
-                sum += f0 + f1 + f2;
-            }
-        } else
         for (int k = beg; k <= end; ++k) {
             const int u = lfq_baq_u(bw, i, k), v11 = lfq_baq_u(bw, i - 1, k - 1), v10 = lfq_baq_u(bw, i - 1, k);
             const double e = lfq_baq_emit(RC(k), qyi, qli);
@@ -366,24 +298,15 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
     /* ---- backward (:206-238), with the MAP step of a row (:254-281) as soon as the row exists ---- */
     int cur = 0;
     for (int u = 0; u < Wr; u++) {
-        if (LDS) {
-            LQ(u) = 0.;
-        } else {
-            BQ(0, u) = 0.;
-        }
+        BQ(0, u) = 0.;
     }
     {
         const double sl = SQ(l_query), sl1 = SQ(l_query + 1);
         for (int k = 1; k <= l_ref; ++k) {
             const int u = lfq_baq_u(bw, l_query, k);
             if (u < 3 || u >= bw2 * 3 + 3) continue;
-            if (LDS) {
-                LQ(u + 0) = sM / sl / sl1;
-                LQ(u + 1) = sI / sl / sl1;
-            } else {
-                BQ(0, u + 0) = sM / sl / sl1;
-                BQ(0, u + 1) = sI / sl / sl1;
-            }
+            BQ(0, u + 0) = sM / sl / sl1;
+            BQ(0, u + 1) = sI / sl / sl1;
         }
     }
     /* scalars of row i, loaded one row ahead: query[i+1], qual2prob[iqual[i+1]], s[i], 1/s[i], expect[i-1], iqual[i] */
@@ -400,51 +323,6 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
             p_ex = expect[(size_t)(i - 2) * 64 + lane];
             p_iq = iqual[i - 1];
         }
-        /* LDS variant: the forward cells the MAP step of this row needs are requested now and land while the
-         * backward row is computed (band <= 17 cells: registers, static indices) */
-        double fz0[LDS ? LFQ_BAQ_LDS_BAND : 1], fz1[LDS ? LFQ_BAQ_LDS_BAND : 1];
-        if (LDS) {
-            int fb = 1, fe = l_ref, x;
-            x = i - bw; fb = fb > x ? fb : x;
-            x = i + bw; fe = fe < x ? fe : x;
-            const int u0 = lfq_baq_u(bw, i, fb);
-#pragma unroll
-            for (int j = 0; j < LFQ_BAQ_LDS_BAND; j++) {
-                const bool in = fb + j <= fe;
-                fz0[j] = in ? FQ(i, u0 + 3 * j + 0) : 0.;
-                fz1[j] = in ? FQ(i, u0 + 3 * j + 1) : 0.;
-            }
-        }
-        if (i < l_query && LDS) {
-            /* row i from row i+1, in place: u(i+1, k) = u(i, k) - 3 sh.  With sh == 0 the cell's own slot holds
-             * what the next (lower) cell needs as its (k+1) neighbour: that value travels in `keep` */
-            int beg = 1, end = l_ref, x;
-            const double y = (i > 1), qli1 = c_ql;
-            const int qyi1 = c_qy;
-            x = i - bw; beg = beg > x ? beg : x;
-            x = i + bw; end = end < x ? end : x;
-            const int sh = (i + 1 - bw > 0) ? 1 : 0;
-            double d01 = 0., keep = 0.;
-            for (int k = end; k >= beg; --k) {
-                const int u = lfq_baq_u(bw, i, k), v10 = u - 3 * sh, v11 = v10 + 3;
-                const double o11 = (sh == 0 && k < end) ? keep : LQ(v11);
-                const double o10 = LQ(v10), o101 = LQ(v10 + 1);
-                const double e = (k >= l_ref ? 0 : lfq_baq_emit(RC(k + 1), qyi1, qli1)) * o11;
-                const double b0 = e * m[0] + LFQ_BAQ_EI * m[1] * o101 + m[2] * d01;
-                const double b1 = e * m[3] + LFQ_BAQ_EI * m[4] * o101;
-                const double b2 = (e * m[6] + m[8] * d01) * y;
-                LQ(u + 0) = b0;
-                LQ(u + 1) = b1;
-                LQ(u + 2) = b2;
-                keep = o10;
-                d01 = b2;
-            }
-            const int b_ = lfq_baq_u(bw, i, beg), e_ = lfq_baq_u(bw, i, end) + 2;
-            const double ys = 1. / c_s;
-            for (int k = b_; k <= e_; ++k) {
-                LQ(k) = LQ(k) * ys;
-            }
-        } else
         if (i < l_query) {
             const int nxt = cur ^ 1;                  /* row i goes to `nxt`, row i+1 is in `cur` */
             for (int u = 0; u < Wr; u++) {
@@ -480,18 +358,6 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
         int beg = 1, end = l_ref, x, max_k = -1;
         x = i - bw; beg = beg > x ? beg : x;
         x = i + bw; end = end < x ? end : x;
-        if (LDS) {
-            const int u0 = lfq_baq_u(bw, i, beg);
-#pragma unroll
-            for (int j = 0; j < LFQ_BAQ_LDS_BAND; j++) {
-                const int k = beg + j, u = u0 + 3 * j;
-                if (k <= end) {
-                    double z;
-                    z = (fz0[j] * rsi) * LQ(u + 0); if (z > max) max = z, max_k = (k - 1) << 2 | 0; sum += z;
-                    z = (fz1[j] * rsi) * LQ(u + 1); if (z > max) max = z, max_k = (k - 1) << 2 | 1; sum += z;
-                }
-            }
-        } else
         for (int k = beg; k <= end; ++k) {
             const int u = lfq_baq_u(bw, i, k);
             double z;
@@ -505,13 +371,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
             const int u = lfq_baq_u(bw, i, IT(e, 1) + j);
             if (u < 3 || u >= bw2 * 3 + 3) continue;                           /* u_within_limits */
             const int st = is_del ? 2 : 1;
-            if (LDS) {
-                /* outside the band of row i the reference's matrices hold 0 (calloc); the in-place row does not */
-                const int kk = IT(e, 1) + j;
-                TM(IT(e, 3) + j) = (kk >= beg && kk <= end) ? (FQ(i, u + st) * rsi) * LQ(u + st) * c_s : 0.;
-            } else {
-                TM(IT(e, 3) + j) = (FQ(i, u + st) * rsi) * BQ(cur, u + st) * c_s;
-            }
+            TM(IT(e, 3) + j) = (FQ(i, u + st) * rsi) * BQ(cur, u + st) * c_s;
         }
         max /= sum;
         int qk = (int)(-4.343 * log(1. - max) + .499);
@@ -619,7 +479,7 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
  *   - 1 / s[i] and expect[i-1] of the backward pass: four rows per batch, requested four to eight rows ahead;
  *   - the BAQ byte of a row goes into the LDS slot of a row that is done, the extended-BAQ passes run there and
  *     the read's bytes leave in one burst.
- * The LDS-row kernel above (LFQ_BAQ_KERNEL=1) is the previous implementation, kept for A/B runs. */
+ */
 #define LFQ_BAQ_NB 15              /* slots of the default band: 2 * 7 + 1 */
 #define LFQ_BAQ_NB_WIDE 17         /* band 8: what a read with a deletion of odd length gets (bam_md_ext.c:353-356) */
 
@@ -1479,36 +1339,28 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream,
     }
     const unsigned blocks = (unsigned)((n_launch + 63) / 64);
     if (lds) {
-        const size_t ref_bytes = ((size_t)a.max_lref / 2 + 2) * 64;
-        if (lfq_knobs().baq_kernel == 0) {           /* default: rows in registers; LFQ_BAQ_KERNEL=1: the LDS-row kernel (A/B) */
-            /* (base | quality) of every row, later the BAQ bytes (see the kernel) */
-            const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2 + (size_t)(lds == 2 ? LFQ_BAQ_NB_WIDE : LFQ_BAQ_NB) * 64 * 16;
-            const hipStream_t st = (hipStream_t)stream;
-            if (lds == 2 && a.itab) {
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
-            } else if (lds == 2) {
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
-            } else if (a.itab) {
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
-            } else if (a.nflag) {
-                if (nmode != 2) {
-                    hipLaunchKernelGGL(lfq_baq_nflag_kernel, dim3(blocks), dim3(64), 0, st, a, n_launch);
-                    hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
-                }
-                if (nmode != 1) {
-                    hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
-                }
-            } else {
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+        /* (base | quality) of every row, later the BAQ bytes (see the kernel) */
+        const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2 + (size_t)(lds == 2 ? LFQ_BAQ_NB_WIDE : LFQ_BAQ_NB) * 64 * 16;
+        const hipStream_t st = (hipStream_t)stream;
+        if (lds == 2 && a.itab) {
+            hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+        } else if (lds == 2) {
+            hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+        } else if (a.itab) {
+            hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+        } else if (a.nflag) {
+            if (nmode != 2) {
+                hipLaunchKernelGGL(lfq_baq_nflag_kernel, dim3(blocks), dim3(64), 0, st, a, n_launch);
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             }
-            return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+            if (nmode != 1) {
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
+            }
+        } else {
+            hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
         }
-        if (lds == 2) {
-            return LFQ_ERR_INVALID;                  /* the LDS-row kernel holds band 7 only: the host sends it nothing else */
-        }
-        hipLaunchKernelGGL(lfq_baq_kernel<true>, dim3(blocks), dim3(64), ref_bytes, (hipStream_t)stream, a, n_launch);
     } else {
-        hipLaunchKernelGGL(lfq_baq_kernel<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, a, n_launch);
+        hipLaunchKernelGGL(lfq_baq_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, a, n_launch);
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

@@ -2898,21 +2898,18 @@ int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_
     if (n_blocks <= 0) {
         return LFQ_OK;
     }
-    const int fold = lfq_knobs().fold_kernel;       /* LFQ_FOLD_KERNEL=0: A/B, every column through the block kernel */
+    /* the tree fold first; the block kernel behind it takes what the fold flagged (tilt out of range, K beyond its
+     * classes) and skips the columns it finished */
     if (mode == 0) {
-        if (fold) {
-            hipLaunchKernelGGL(lfq_dp_fold_kernel<0>, dim3((unsigned)n_blocks * 4), dim3(64 * LFQ_FOLD_WAVES), 0,
-                               (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
-        }
+        hipLaunchKernelGGL(lfq_dp_fold_kernel<0>, dim3((unsigned)n_blocks * 4), dim3(64 * LFQ_FOLD_WAVES), 0,
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
         hipLaunchKernelGGL(lfq_dp_combine_kernel<0>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
-                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, fold);
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, 1);
     } else {
-        if (fold) {
-            hipLaunchKernelGGL(lfq_dp_fold_kernel<1>, dim3((unsigned)n_blocks), dim3(64 * LFQ_FOLD_WAVES), 0,
-                               (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
-        }
+        hipLaunchKernelGGL(lfq_dp_fold_kernel<1>, dim3((unsigned)n_blocks), dim3(64 * LFQ_FOLD_WAVES), 0,
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
         hipLaunchKernelGGL(lfq_dp_combine_kernel<1>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
-                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, fold);
+                           (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, 1);
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
@@ -2936,7 +2933,7 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
             force = kreg_hint > 0 ? kreg_hint : 8;
         }
         /* lower-bound evaluation where the filters allow it (see the kernel) */
-        const bool lb = !p.general && p.def_alt_bq == 0 && p.def_alt_jp < 0.0 && !kn.screen_exact;
+        const bool lb = !p.general && p.def_alt_bq == 0 && p.def_alt_jp < 0.0;
 #define LFQ_LAUNCH_SCREEN(KR)                                                                                        \
     do {                                                                                                             \
         if (lb) {                                                                                                    \

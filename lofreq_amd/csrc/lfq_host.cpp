@@ -54,24 +54,19 @@ const LfqKnobs &lfq_knobs(void)
             x.light_kernel = !strcmp(lk, "wave") ? 2 : 0;
         }
         x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 4));
-        x.screen_exact = has("LFQ_SCREEN_EXACT");
         x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));
         x.phase1_chunks = (int)std::max(1L, geti("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
         x.seg_max = (int)std::min((long)LFQ_SEG_MAX, std::max(2L, geti("LFQ_SEG_MAX", LFQ_SEG_MAX)));
-        x.fold_kernel = geti("LFQ_FOLD_KERNEL", 1) != 0;
         x.seg_budget_mid = (int)std::max(1L, geti("LFQ_SEG_BUDGET_MID", 4096));
         x.seg_budget_big = (int)std::max(1L, geti("LFQ_SEG_BUDGET_BIG", 4096));
-        x.segments = (int)std::min((long)LFQ_MAX_SEGMENTS, std::max(1L, geti("LFQ_SEGMENTS", 1)));
         x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);
         x.pileup_tiles = (int)geti("LFQ_PILEUP_TILES", 1);
         x.baq_one_variant = has("LFQ_BAQ_ONE_VARIANT") ? 1 : 0;
-        x.big_behind_chain = has("LFQ_BIG_BEHIND_CHAIN") ? 1 : 0;
         x.count_lpg4_below = geti("LFQ_COUNT_LPG4_BELOW", 320);
         x.count_lpg8_below = geti("LFQ_COUNT_LPG8_BELOW", 900);
-        x.cu_split = (int)std::max(0L, geti("LFQ_CU_SPLIT", 0));
         x.sync_upload = (int)geti("LFQ_SYNC_UPLOAD", 0);
         x.host_spin_us = geti("LFQ_HOST_SPIN_US", 2000);
         x.host_threads = (int)geti("LFQ_HOST_THREADS", -1);
@@ -81,7 +76,6 @@ const LfqKnobs &lfq_knobs(void)
         x.pileup_atomic = has("LFQ_PILEUP_ATOMIC");
         x.baq_lds = geti("LFQ_BAQ_LDS", 1) != 0;
         x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
-        x.baq_kernel = (int)geti("LFQ_BAQ_KERNEL", 0);
         return x;
     }();
     return k;

@@ -143,7 +143,7 @@ struct LfqWork {
 #define LFQ_MID_K 64          /* K+1 cells no longer fit one cell per lane */
 #define LFQ_BIG_K 250         /* K+1 (+alignment) cells no longer fit one 64x4 strip: strip pipeline */
 #define LFQ_NCOUNTERS 320
-#define LFQ_MAX_SEGMENTS 8      /* a batch is cut into segments so that the DP of one overlaps the count of the next */
+#define LFQ_MAX_SEGMENTS 1      /* launch sequences per batch (per-segment counters and events are laid out for this many) */
 #define LFQ_GC_PVALS 0         /* records appended to the sparse output */
 #define LFQ_GC_OVERFLOW 1
 #define LFQ_GC_TESTED 2        /* running total of tested columns (carry between segments) */
@@ -186,16 +186,12 @@ struct LfqKnobs {
     int light_kernel;          /* LFQ_LIGHT_KERNEL=wave: 2 = one light column per wavefront instead of the screen kernel (the
                                 * kernel that serves K >= 32 anyway); 0 = screen (one light column per lane) */
     int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (4): the screen is latency-bound per column, more wavefronts only crowd the two critical chains */
-    int screen_exact;          /* LFQ_SCREEN_EXACT: the screen kernel evaluates the full quality merge instead of its lower bound */
     int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
     int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
-    int fold_kernel;           /* LFQ_FOLD_KERNEL (1): segments folded by one wavefront per column (0: block kernel only) */
     int seg_max;               /* LFQ_SEG_MAX */
     int seg_budget_mid, seg_budget_big;   /* LFQ_SEG_BUDGET_MID (4096), LFQ_SEG_BUDGET_BIG (4096) */
-    int segments;              /* LFQ_SEGMENTS: batch segments */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
-    int big_behind_chain;      /* LFQ_BIG_BEHIND_CHAIN: the unsplit big columns behind the split ones' kernels on their stream (before round 3) */
     int baq_one_variant;       /* LFQ_BAQ_ONE_VARIANT: every wavefront of the plain narrow-band BAQ launches through the instantiation with the N case */
     int pileup_tiles;          /* LFQ_PILEUP_TILES (1): SNV pileup of sorted reads by tiles of 64 positions; 0 = a wavefront per position */
     long host_loop_threads;    /* LFQ_HOST_LOOP_THREADS (8): threads (caller included) a host loop over reads / positions / events is cut for, at most 16 */
@@ -210,9 +206,6 @@ struct LfqKnobs {
     int pileup_atomic;         /* LFQ_PILEUP_ATOMIC: read-major pileup kernels even for sorted reads */
     int baq_lds;               /* LFQ_BAQ_LDS (1) */
     long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
-    int baq_kernel;            /* LFQ_BAQ_KERNEL: A/B switch between BAQ kernel generations */
-    int cu_split;              /* LFQ_CU_SPLIT=n: the DP streams of a device are created with a CU mask of n CUs, the main
-                                * stream (count kernels, pileup, BAQ) with the other CUs: spatial partition for two batches in flight */
 };
 const LfqKnobs &lfq_knobs(void);
 /* CPUs this process may actually use: the affinity mask and the cgroup's cpu.max quota, not the machine's core count

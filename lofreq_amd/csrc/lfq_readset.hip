@@ -605,7 +605,6 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
     int64_t part_narrow[LFQ_HOST_PARTS + 1] = {0}, part_band8[LFQ_HOST_PARTS + 1] = {0}, part_plain[LFQ_HOST_PARTS + 1] = {0};
     LfqPin<uint8_t> has_id(c, (size_t)n);                            /* the read has an I or D operation (what idaq looks at) */
     LFQ_PIN_OK(has_id);
-    const bool reg_kernel = lfq_knobs().baq_kernel == 0;    /* the register kernel also has a band-8 instantiation */
     int part_lrn[LFQ_HOST_PARTS] = {0}, part_lqn[LFQ_HOST_PARTS] = {0};
     int parts = 1;
     lfq_for_reads(n, [&](int64_t r_begin, int64_t r_end, int part) {
@@ -660,7 +659,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             n_pl += (want_idaq && indel_op) ? 0 : 1;
             lrn = std::max(lrn, o.l_ref);
             lqn = std::max(lqn, l_qseq);
-        } else if (use_lds && reg_kernel && wr == LFQ_BAQ_BAND8_CELLS && o.l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
+        } else if (use_lds && wr == LFQ_BAQ_BAND8_CELLS && o.l_ref <= LFQ_BAQ_LDS_MAX_LREF) {
             n_b8++;                                     /* band 8: a deletion of odd length (bam_md_ext.c:353-356) */
             lqn = std::max(lqn, l_qseq);
         }
@@ -700,7 +699,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                 } else {
                     order[(size_t)pi++] = (int32_t)r;
                 }
-            } else if (use_lds && reg_kernel && width[(size_t)r] == LFQ_BAQ_BAND8_CELLS && short_ref) {
+            } else if (use_lds && width[(size_t)r] == LFQ_BAQ_BAND8_CELLS && short_ref) {
                 order[(size_t)bi++] = (int32_t)r;
             } else {
                 order[(size_t)wi--] = (int32_t)r;

@@ -1,5 +1,6 @@
-"""-m gpu: the code paths that only run under an environment knob (fallbacks for inputs the default route cannot take,
-and A/B switches that are still in the tree) get the parity tests of their area, each in a process of its own with the
+"""-m gpu: the code paths that only run under an environment knob (fallbacks for inputs the default route cannot take:
+no pool space, unsorted reads, wide bands, shallow / deep launch shapes; the measured-and-rejected A/B paths of rounds
+1-3 were deleted in round 4, profiles/NOTES.md) get the parity tests of their area, each in a process of its own with the
 knob set -- so that nothing that can be selected at run time is untested.  The knobs are read once per process
 (lfq_knobs(), lfq_internal.h); DESIGN.md lists them."""
 import os
@@ -20,22 +21,16 @@ CHAIN = ["tests/test_gpu_plpindel.py", "-k", "chain or device_only or device_pac
 CASES = [
     ("LFQ_SPLIT_POOL_CELLS=0", DP),          # no row split: every long column on the unsplit kernels
     ("LFQ_SPLIT_POOL_CELLS=60000", DP),      # a pool that runs out: split and unsplit columns in one batch
-    ("LFQ_FOLD_KERNEL=0", DP),               # segments combined by the block kernel only
     ("LFQ_LIGHT_KERNEL=wave", DP),           # one light column per wavefront (what K >= 32 gets anyway)
-    ("LFQ_SCREEN_EXACT=1", DP),              # the screen kernel with the full quality merge instead of its lower bound
     ("LFQ_SCREEN_ROUNDS=2", DP),             # nearly every light column through the retry kernel
-    ("LFQ_SEGMENTS=3", DP),                  # batch segments: running Bonferroni prefix carried on the device
     ("LFQ_SINGLE_STREAM=1", DP),             # every kernel on one stream (what the counter passes run)
     ("LFQ_NO_SB_PRECOMPUTE=1", DP),          # strand bias computed at collect time only
     ("LFQ_COUNT_MULTI_BELOW=0", DP),         # shallow batches on the one-column-per-wavefront count kernel
     ("LFQ_COUNT_LPG4_BELOW=100000", DP),     # shared-wavefront count kernel: four lanes per column whatever the depth
     ("LFQ_COUNT_LPG8_BELOW=100000", DP),     # ... eight (and four for the shallowest batches)
     ("LFQ_COUNT_LPG4_BELOW=0", DP),          # ... never four
-    ("LFQ_CU_SPLIT=64", DP),                 # DP streams and main stream on disjoint CU masks
-    ("LFQ_BIG_BEHIND_CHAIN=1", DP),          # unsplit big columns on the segment kernels' stream, behind them
     ("LFQ_PILEUP_TILES=0", PLP),             # a wavefront per position instead of tiles of 64 positions
     ("LFQ_BAQ_ONE_VARIANT=1", BAQ),          # every wavefront through the register kernel's instantiation with the N case
-    ("LFQ_BAQ_KERNEL=1", BAQ),               # the LDS-row BAQ kernel
     ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
     ("LFQ_PILEUP_ATOMIC=1", PLP),            # read-major pileup kernels (what unsorted reads get)
     ("LFQ_INDEL_HOST_PACK=1", CHAIN),        # indel pseudo-columns packed on the host
