@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- pileup columns/sec of the per-column SNV calling path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config C3|C2] [--mode resident|host-abi|chain|baq]
+    python bench.py --gpus N --steps K --warmup W [--config C3|C2|C4|C5] [--mode resident|host-abi|chain|baq]
 
 A step is one pass of the hot path (count -> running-Bonferroni scan -> Poisson-binomial DP -> host emit test /
 filter / VCF records) over one batch of synthetic pileup columns that are ALREADY RESIDENT IN HBM (generated on
@@ -63,7 +63,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100,
                     help="untimed steps before the timed ones (default 100 = 0.3 s: the first 200-step block after 10 was 1 %% slower than the blocks behind it)")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + sorted(GENOME_CONFIGS), default="C3",
+                    help="C3 (default, the metric) / C2: resident synthetic pileups; C4 / C5: a whole genome of reads through the "
+                         "reads -> VCF chain, region- / BED-sharded over --gpus (strong scaling)")
+    ap.add_argument("--vcf-out", default=None, help="C4 / C5: rank 0 writes the VCF text of the last step here")
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="C4 / C5: a smaller genome of the same shape (tests)")
     ap.add_argument("--idaq", action="store_true", help="--mode baq: also the indel alignment qualities (ai / ad)")
     ap.add_argument("--mode", choices=["resident", "host-abi", "chain", "baq"], default="resident",
                     help="resident (default, the metric): tracks in HBM; host-abi: host buffers through the C ABI; "
@@ -523,6 +527,281 @@ def bench_chain(caller, la, n_reads, glen, iters, call_indels=True, start_barrie
     return best
 
 
+# ---- BASELINE.json configs[3] / configs[4]: a whole genome of reads, region-sharded ---------------------------------------
+
+GENOME_CONFIGS = {
+    # C4: E. coli-sized genome, 500x, SNV + --call-indels, default filter; bins = plan_regions over the contig
+    "C4": dict(idx=3, genome=4_600_000, depth=500, call_indels=True, targets=False, bins=32,
+               what="synthetic 4.6 Mb genome, 500x reads (150 bp), SNV + --call-indels, BAQ / IDAQ on, default filter, "
+                    "dynamic Bonferroni, region-sharded (BASELINE.json configs[3])"),
+    # C5: exome-like ragged BED targets (~45 % of a 64 Mb window = 29 Mb), 200x on the targets, SNVs only
+    "C5": dict(idx=4, genome=64_000_000, depth=200, call_indels=False, targets=True, bins=32,
+               what="synthetic exome: ragged BED targets (150..3500 bp) over a 64 Mb window, 200x reads on the targets, "
+                    "SNV-only, BAQ on, default filter, Bonferroni summed over all bins (call-parallel's \"auto\": "
+                    "lofreq2_call_pparallel.py:131-185, 685-707), BED-sharded (BASELINE.json configs[4])"),
+}
+
+
+def make_tile(cfg, tile_len, seed=11):
+    """the reads of ONE bin (every bin of the synthetic genome carries the same reads: the work is a genome's, the host
+    memory a bin's); planted SNVs every 997th position at 0.5 / 1 / 5 / 50 %; C5: only reads that overlap a target"""
+    rl = 150
+    n = int(tile_len * cfg["depth"] / rl)
+    rng = np.random.default_rng(seed + 1)
+    target = None
+    if cfg["targets"]:
+        # exome-like: reads only where they overlap a target (what `-l bed` fetches); no indels; cheap generators
+        target = np.zeros(tile_len, np.uint8)
+        x = 300
+        while x < tile_len - 4000:
+            l = int(rng.choice([150, 300, 600, 1200, 2000, 3500], p=[0.2, 0.25, 0.2, 0.15, 0.12, 0.08]))
+            target[x:x + l] = 1
+            x += l + int(rng.integers(200, 1900))
+        cs = np.concatenate([[0], np.cumsum(target, dtype=np.int64)])
+        pos = np.sort(rng.integers(0, tile_len - rl - 20, n)).astype(np.int32)
+        pos = np.ascontiguousarray(pos[(cs[pos + rl] - cs[pos]) > 0])
+        n = len(pos)
+        genome = rng.integers(0, 4, tile_len).astype(np.uint8)
+        seq = genome[pos[:, None] + np.arange(rl, dtype=np.int32)[None, :]]
+        mism = rng.random(seq.shape, dtype=np.float32) < 0.003
+        seq[mism] = (seq[mism] + 1) % 4
+        R = {"n": n, "rl": rl, "glen": tile_len, "ref": np.frombuffer(b"ACGT", np.uint8)[genome].tobytes(), "pos": pos,
+             "cig_off": np.arange(n + 1, dtype=np.int64), "cig": np.full(n, rl << 4, np.uint32),
+             "seq_off": np.arange(n + 1, dtype=np.int64) * rl, "seq": seq.reshape(-1),
+             "qual": rng.integers(28, 42, n * rl, dtype=np.uint8), "mapq": np.full(n, 60, np.uint8),
+             "rev": (rng.random(n) < 0.5).astype(np.uint8)}
+    else:
+        R = make_reads(n, tile_len, rl=rl, seed=seed, indel_frac=0.04 if cfg["call_indels"] else 0.0)
+    pos, seq = R["pos"], R["seq"].reshape(R["n"], rl)
+    plain = (R["cig_off"][1:] - R["cig_off"][:-1]) == 1
+    for k, p in enumerate(range(500, tile_len - rl - 20, 997)):
+        af = (0.005, 0.01, 0.05, 0.5)[k % 4]
+        lo, hi = np.searchsorted(pos, p - rl + 1), np.searchsorted(pos, p, side="right")
+        idx = np.arange(lo, hi)
+        idx = idx[plain[idx] & (rng.random(len(idx)) < af)]
+        seq[idx, p - pos[idx]] = (seq[idx, p - pos[idx]] + 1 + k % 3) % 4
+    if cfg["call_indels"]:
+        # planted indels: every 4999th position an insertion or a deletion of 1..3 bases at 5 % or 30 % of the reads
+        gcode = (np.frombuffer(R["ref"], np.uint8) >> 1) & 3                     # 'A','C','G','T' -> 0, 1, 3, 2 ...
+        gcode = np.where(gcode == 3, 2, np.where(gcode == 2, 3, gcode)).astype(np.uint8)     # ... -> 0, 1, 2, 3
+        ncig = (R["cig_off"][1:] - R["cig_off"][:-1]).astype(np.int64)
+        cigs = np.zeros((R["n"], 3), np.uint32)
+        cigs[np.arange(3)[None, :] < ncig[:, None]] = R["cig"]
+        ar = np.arange(rl)
+        for k, p in enumerate(range(2500, tile_len - 2 * rl, 4999)):
+            ln, is_ins, af = 1 + k % 3, (k & 1) == 0, (0.05, 0.3)[(k >> 1) & 1]
+            lo, hi = np.searchsorted(pos, p - rl + 26), np.searchsorted(pos, p - 20, side="right")
+            idx = np.arange(lo, hi)
+            idx = idx[(ncig[idx] == 1) & (rng.random(len(idx)) < af)]
+            if not len(idx):
+                continue
+            c = (p - pos[idx] + 1).astype(np.int64)                               # bases of the read in front of the event
+            src = pos[idx, None] + ar[None, :]
+            if is_ins:
+                after = ar[None, :] >= (c + ln)[:, None]
+                s_new = gcode[np.where(after, src - ln, src)]
+                inside = (ar[None, :] >= c[:, None]) & ~after
+                s_new[inside] = ((ar[None, :] - c[:, None] + k) % 4).astype(np.uint8)[inside]
+                cigs[idx, 1] = (ln << 4) | 1
+                cigs[idx, 2] = ((rl - c - ln).astype(np.uint32) << 4)
+            else:
+                s_new = gcode[np.where(ar[None, :] >= c[:, None], src + ln, src)]
+                cigs[idx, 1] = (ln << 4) | 2
+                cigs[idx, 2] = ((rl - c).astype(np.uint32) << 4)
+            cigs[idx, 0] = c.astype(np.uint32) << 4
+            ncig[idx] = 3
+            seq[idx] = s_new
+        R["cig_off"] = np.concatenate([[0], np.cumsum(ncig)]).astype(np.int64)
+        R["cig"] = np.ascontiguousarray(cigs[np.arange(3)[None, :] < ncig[:, None]])
+        R["n_indel_reads"] = int((ncig == 3).sum())
+    R["seq"] = np.ascontiguousarray(seq.reshape(-1))
+    R["target"] = target
+    return R
+
+
+def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev, comm_ranks):
+    """One step = the whole synthetic genome: every bin (plan_regions, dealt to the ranks) goes reads -> BAQ (+ IDAQ) ->
+    device pileup(s) -> SNV (+ indel) tests on its owner's GPU; then the shard exchange (per-bin test counts ->
+    exact Bonferroni prefix per bin, records to rank 0: shard.finish_bins / finish_indel_bins) and the VCF text of the whole
+    genome on rank 0.  Strong scaling: the genome is the same whatever N is."""
+    import ctypes as C
+    import torch
+    from lofreq_amd import _lib
+    from lofreq_amd.pileup import DeviceTracks
+    cfg = GENOME_CONFIGS[cfg_name]
+    glen, nb = int(round(cfg["genome"] * args.genome_scale / cfg["bins"])) * cfg["bins"], cfg["bins"]
+    # call-parallel's cut (lofreq2_call_pparallel.py:590-613) with the number of bins an 8-GPU node gets (>= 2 per GPU,
+    # strictly below total / 16), whatever N is: the bins -- and with them the output -- do not depend on N
+    bins, owner = shard.plan_regions([("synth", 0, glen)], lambda c, b, e: float(cfg["depth"]) * (e - b), world,
+                                     bins_per_worker=max(1, 16 // world))
+    assert len(bins) == nb and len({e - b for _, b, e in bins}) == 1, (len(bins), nb)
+    tile_len = bins[0][2] - bins[0][1]
+    R = make_tile(cfg, tile_len)
+    keep = {}
+    for k in ("seq", "qual", "bi", "bd", "pos", "cig_off", "cig", "seq_off", "mapq", "rev"):      # pinned, as the region binding keeps them
+        if k in R:
+            keep[k] = torch.from_numpy(R[k]).pin_memory()
+            R[k] = keep[k].numpy()
+    L = _lib.load()
+    flag = la.LFQ_USE_BAQ | la.LFQ_USE_MQ | (la.LFQ_USE_IDAQ if cfg["call_indels"] else 0)
+    my = [(i, b, e) for i, ((_, b, e), o) in enumerate(zip(bins, owner)) if o == rank]
+    cap = tile_len
+    d_counts = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
+    d_pvals = torch.zeros(cap * 128, dtype=torch.uint8, device=dev)
+    L.lfq_set_indel_arrays_on_host(caller.h, 0)
+    target = R["target"]
+
+    def start():
+        rs = la.ReadSet.from_arrays(caller, R)
+        rs.baq(extended=True, idaq=cfg["call_indels"])
+        return rs
+
+    def finish(rs, i, b):
+        """pileups + tests of a started bin -> (snv entry for finish_bins, indel entry or None, indel lines' makings)"""
+        ient = None
+        skip = None
+        if cfg["call_indels"]:
+            outp = C.POINTER(_lib.IndelColumnsC)()
+            col_pos = np.zeros(tile_len, np.int64)
+            _lib.check(L.lfq_readset_pileup_indels(caller.h, rs.h, 0, tile_len, 0, C.byref(outp), col_pos.ctypes.data),
+                       "lfq_readset_pileup_indels")
+            dt = rs.pileup_snv(0, tile_len)
+            ci = la.VarcallConf(flag=flag)
+            rec = np.zeros(1 << 18, dtype=_lib.INDEL_RECORD_DTYPE)
+            nrec, nt = C.c_int64(0), C.c_int64(0)
+            _lib.check(L.lfq_call_indels_batch(caller.h, C.byref(ci.c), outp, rec.ctypes.data, len(rec), C.byref(nrec), C.byref(nt)),
+                       "lfq_call_indels_batch")
+            oc = outp.contents
+            rec = rec[: nrec.value].copy()
+            # what the VCF line of a record needs besides the record: reference base and the event's key
+            lines = []
+            rb = np.frombuffer(C.string_at(oc.ref_base, oc.ncols), np.uint8)
+            for r in rec:
+                sd = oc.side[int(r["side"])]
+                ko = np.frombuffer(C.string_at(sd.key_off + 8 * int(r["event"]), 16), np.int64)
+                key = C.string_at(sd.key_chars + int(ko[0]), int(ko[1] - ko[0])).decode()
+                base = chr(int(rb[int(r["col"])]))
+                lines.append((base + key, base) if r["side"] == 0 else (base, base + key))     # (alt, ref) / (alt, ref)
+            rec["col"] = col_pos[rec["col"]]                      # column of the bin -> offset in the bin
+            ient = (i, b, rec, int(nt.value), lines)
+            skip = np.frombuffer(C.string_at(oc.cons_indel, oc.ncols), np.uint8).copy()
+        else:
+            dt = rs.pileup_snv(0, tile_len)
+        if target is not None:
+            off = 1 - target[dt.col_pos]                          # `-l bed`: the columns outside the targets are not called
+            skip = off if skip is None else (skip | off)
+        if skip is not None:
+            la.skip_snv_columns(caller, skip)
+        conf = la.VarcallConf(flag=flag)
+        n = int(dt.ncols)
+        caller.snv_batch_device(dt, conf, d_counts, d_pvals, cap)
+        st = caller.batch_finish()
+        pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE).copy()
+        pv["col"] = dt.col_pos[pv["col"]]
+        ncalled = n if target is None else int(target[dt.col_pos].sum())
+        rs.close()
+        return (i, b, pv, int(st.n_tested)), ient, ncalled
+
+    def step():
+        snv, ind, ncols = [], [], 0
+        pending = None
+        for k, (i, b, e) in enumerate(my):          # bin k + 1 is started (upload, BAQ kernels) before bin k is finished
+            rs = start()
+            if pending is not None:
+                s_, i_, n_ = finish(*pending)
+                snv.append(s_); ncols += n_
+                if i_ is not None:
+                    ind.append(i_)
+            pending = (rs, i, b)
+        if pending is not None:
+            s_, i_, n_ = finish(*pending)
+            snv.append(s_); ncols += n_
+            if i_ is not None:
+                ind.append(i_)
+        conf = la.VarcallConf(flag=flag)
+        recs, total = shard.finish_bins(conf, snv, nb, dist if world > 1 else None, xdev)
+        text = None
+        itext = []
+        if cfg["call_indels"]:
+            # the exact factor of every indel test needs every bin's count; the surviving records are formatted where
+            # their event keys live (the owner) and travel as text, like the per-bin VCFs call-parallel concatenates
+            counts = np.zeros(nb, np.int64)
+            for i, _, _, nt, _ in ind:
+                counts[i] = nt
+            allc, _ = shard.exchange_counts(counts, dist if world > 1 else None, xdev)
+            per_bin = allc.sum(axis=0)
+            prefix = np.concatenate([[0], np.cumsum(per_bin)[:-1]])
+            tot_i = int(per_bin.sum())
+            conf.c.bonf_indel = 1 + tot_i
+            conf.c.num_indel_tests += tot_i
+            thr_i = la.snvqual_thresh(conf.sig, conf.bonf_indel)
+            for i, b, rec, nt, ra in ind:
+                rec = rec.copy()
+                rec["bonf"] += int(prefix[i])
+                ok = rec["pvalue"] * rec["bonf"].astype(np.longdouble) < np.float32(conf.sig)
+                ok &= la.filter_indel_records(rec, thr_i, apply_defaults=True).astype(bool)
+                for r, (alt, ref), k_ in zip(rec, ra, ok):
+                    if k_:
+                        p0 = b + int(r["col"])
+                        buf = C.create_string_buffer(1024 + len(ref) + len(alt))
+                        L.lfq_format_indel_record(buf, len(buf), b"synth", p0, ref.encode(), alt.encode(), int(r["qual"]), int(r["dp"]),
+                                                  C.c_float(float(r["af"])), int(r["sb"]), int(r["ref_fw"]), int(r["ref_rv"]),
+                                                  int(r["alt_fw"]), int(r["alt_rv"]), int(r["hrun"]), b"PASS")
+                        itext.append((p0, buf.value.decode()))
+            if world > 1:
+                gathered = [None] * world if rank == 0 else None
+                dist.gather_object(itext, gathered, dst=0)
+                if rank == 0:
+                    itext = [x for part in gathered for x in part]
+        if rank == 0:
+            thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
+            keepm = la.filter_records(recs, thr, apply_defaults=True)
+            stext = la.format_vcf(recs, "synth", keep=keepm, filter_str="PASS").splitlines(True)
+            spos = [int(r["col"]) for r, k_ in zip(recs, keepm) if k_]
+            merged = sorted([(p, 0, t) for p, t in itext] + [(p, 1, t) for p, t in zip(spos, stext)], key=lambda x: (x[0], x[1]))
+            text = "".join(t for _, _, t in merged)
+        return conf, ncols, text, (len(recs) if recs is not None else 0, len(itext))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        conf, ncols_mine, text, nrecs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_cols = torch.tensor([float(ncols_mine)], dtype=torch.float64, device=xdev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_cols)
+    dt, called = float(tmax.item()), int(tot_cols.item())
+    L.lfq_set_indel_arrays_on_host(caller.h, 1)
+    if rank != 0:
+        return None
+    import hashlib
+    return {
+        "metric": "pileup columns/sec at depth %d, reads -> VCF (BAQ + device pileup + calls)" % cfg["depth"],
+        "value": called * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic (one bin's reads, reused for every bin of the genome)",
+        "roofline": None, "cpu_baseline": None,
+        "config": {"workload": "%s: %s" % (cfg_name, cfg["what"]), "genome_len": glen, "called_columns": called, "bins": nb,
+                   "bins_rank0": len(my), "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": int(R["n"]) * nb,
+                   "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
+                   "snv_tests": int(conf.num_snv_tests), "indel_tests": int(conf.num_indel_tests),
+                   "snv_records_before_filter": nrecs[0], "indel_records": nrecs[1],
+                   "vcf_lines": text.count("\n"), "vcf_sha256": hashlib.sha256(text.encode()).hexdigest(),
+                   "note": "1 step = the whole genome; roofline / cpu_baseline belong to the default (C3) line: the dominant kernel "
+                           "here is lfq_baq_reg_kernel, FP64-issue-bound (DESIGN 6b, profiles/r04_*)"},
+    }, text
+
+
 def _chain_worker(idx, iters, barrier, queue):
     """one region worker of `--mode chain --workers W`: its own process, context and read set on GPU 0"""
     try:
@@ -631,7 +910,12 @@ def spawn_ranks(n):
 
 def main():
     args = parse_args()
-    cfg_idx, cfg_depth, cfg_cols, cfg_filter, cfg_sample = CONFIGS[args.config]
+    genome_cfg = args.config in GENOME_CONFIGS
+    if genome_cfg:
+        if args.steps == 200 and args.warmup == 100:       # the defaults are C3's: a genome step takes ~0.3-0.6 s
+            args.steps, args.warmup = 5, 1
+        args.scaling = "strong"
+    cfg_idx, cfg_depth, cfg_cols, cfg_filter, cfg_sample = CONFIGS["C3" if genome_cfg else args.config]
     depth = args.depth or cfg_depth
     ncols = args.cols or cfg_cols
     seed = seed_of(3 if args.config == "C3" else 2)
@@ -679,6 +963,17 @@ def main():
     caller = la.SnvCaller(local_rank)
     caller.set_dense_strand_counts(False)         # DP4 only for the columns that emit (what layer 2 does by itself)
 
+    if genome_cfg:
+        out = bench_genome(args, args.config, caller, la, shard, dist, world, rank, dev, xdev, comm_ranks)
+        if rank == 0:
+            line, text = out
+            if args.vcf_out:
+                open(args.vcf_out, "w").write(text)
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        caller.close()
+        return
     if args.mode == "chain":
         iters = max(args.steps // 100, 2)
         if args.workers > 1:

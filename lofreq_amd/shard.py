@@ -218,6 +218,38 @@ def finish_indel_shard(conf, bonf_indel_start, records, n_tests_local, col_offse
     return gather_records(rec, col_offset, dist, device), total
 
 
+def finish_indel_bins(conf, bonf_indel_start, my_bins, n_bins_total, dist=None, device=None):
+    """finish_indel_shard for call-parallel style bins: this rank ran `call_indels` on `my_bins` = [(bin_index,
+    col_offset, indel records, n_tests), ...], every bin from the same `bonf_indel_start` (a bin's local running factor
+    is then never larger than the single-process one: its records are a superset).  One all-gather of the per-bin test
+    counts gives every bin its exact prefix (the tests of the bins before it in genome order, whoever ran them); every
+    record is re-tested with the exact factor (lofreq_call.c:326, :384), the survivors are gathered and put into genome
+    order on rank 0.  conf ends up as after the single-process loop (:693-696).  -> (records on rank 0 or None, total tests)"""
+    counts = np.zeros(int(n_bins_total), np.int64)
+    for b, _, _, n_tests in my_bins:
+        counts[b] = int(n_tests)
+    allc, _ = exchange_counts(counts, dist, device)
+    per_bin = allc.sum(axis=0)
+    prefix = np.concatenate([[0], np.cumsum(per_bin)[:-1]])
+    parts = []
+    for b, col_offset, records, _ in my_bins:
+        rec = records.copy()
+        if conf.bonf_dynamic:
+            rec["bonf"] += int(prefix[b])
+            rec = rec[rec["pvalue"] * rec["bonf"].astype(np.longdouble) < np.float32(conf.sig)]
+        rec["col"] += int(col_offset)
+        parts.append(rec)
+    mine = np.concatenate(parts) if parts else np.zeros(0, _lib.INDEL_RECORD_DTYPE)
+    allrecs = gather_records(mine, 0, dist, device)
+    if allrecs is not None and len(allrecs):
+        allrecs = allrecs[np.argsort(allrecs["col"], kind="stable")]
+    total = int(per_bin.sum())
+    if conf.bonf_dynamic:
+        conf.c.bonf_indel = int(bonf_indel_start) + total
+    conf.c.num_indel_tests += total
+    return allrecs, total
+
+
 def finish_bins(conf, my_bins, n_bins_total, dist=None, device=None):
     """Sharded step over call-parallel style bins (plan_regions): this rank ran the kernels of `my_bins` =
     [(bin_index, col_offset, sparse pvals, n_tested), ...], every bin as its own batch starting from the same

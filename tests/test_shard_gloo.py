@@ -157,6 +157,50 @@ def test_sharded_indels_equal_single_process(tmp_path, world):
         assert (got[k] == exp[k]).all(), k
 
 
+def _indel_bins_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    ncols, tpc, first, recs = _indel_scenario(la)
+    # seven bins of unequal length, dealt round-robin: a rank's bins are NOT contiguous in the genome
+    edges = np.linspace(0, ncols, 8).astype(int)
+    edges[3] += 5
+    mine = []
+    for b in range(7):
+        if b % world != rank:
+            continue
+        lo, hi = int(edges[b]), int(edges[b + 1])
+        r = recs[(recs["col"] >= lo) & (recs["col"] < hi)].copy()
+        r["col"] -= lo
+        r["bonf"] -= int(first[lo])                 # every bin starts from bonf_indel 1
+        r = r[r["pvalue"] * r["bonf"].astype(np.longdouble) < np.float32(0.01)]     # the bin's own emit test
+        mine.append((b, lo, r, int(tpc[lo:hi].sum())))
+    conf = la.VarcallConf()
+    got, total = shard.finish_indel_bins(conf, 1, mine, 7, dist, None)
+    if rank == 0:
+        np.save(out, got.view(np.uint8))
+        np.save(out + ".meta", np.array([total, conf.bonf_indel, conf.num_indel_tests]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_indel_bins_equal_single_process(tmp_path, world):
+    import lofreq_amd as la
+    out = str(tmp_path / "ibins.npy")
+    mp.spawn(_indel_bins_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out).view(la.INDEL_RECORD_DTYPE)
+    total, bonf, ntests = np.load(out + ".meta.npy")
+    ncols, tpc, first, recs = _indel_scenario(la)
+    exp = recs[recs["pvalue"] * recs["bonf"].astype(np.longdouble) < np.float32(0.01)]
+    assert total == ntests == int(tpc.sum()) and bonf == 1 + int(tpc.sum())
+    assert len(got) == len(exp) > 5
+    for k in la.INDEL_RECORD_DTYPE.names:
+        assert (got[k] == exp[k]).all(), k
+
+
 # ---- call-parallel style bins (shard.plan_regions / finish_bins) --------------------------------------------
 
 def _exome_like(rng, length=3_000_000, n_targets=1200):
