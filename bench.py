@@ -68,6 +68,9 @@ def parse_args():
                          "reads -> VCF chain, region- / BED-sharded over --gpus (strong scaling)")
     ap.add_argument("--vcf-out", default=None, help="C4 / C5: rank 0 writes the VCF text of the last step here")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="C4 / C5: a smaller genome of the same shape (tests)")
+    ap.add_argument("--host-threads", type=int, default=2,
+                    help="C4 / C5: host threads per rank, one context each, that work through the rank's bins (the host part "
+                         "of one bin -- CIGAR geometry, event tables, test descriptors -- then runs under the kernels of another)")
     ap.add_argument("--idaq", action="store_true", help="--mode baq: also the indel alignment qualities (ai / ad)")
     ap.add_argument("--mode", choices=["resident", "host-abi", "chain", "baq"], default="resident",
                     help="resident (default, the metric): tracks in HBM; host-abi: host buffers through the C ABI; "
@@ -646,17 +649,21 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
     flag = la.LFQ_USE_BAQ | la.LFQ_USE_MQ | (la.LFQ_USE_IDAQ if cfg["call_indels"] else 0)
     my = [(i, b, e) for i, ((_, b, e), o) in enumerate(zip(bins, owner)) if o == rank]
     cap = tile_len
-    d_counts = torch.zeros(cap * 64, dtype=torch.uint8, device=dev)
-    d_pvals = torch.zeros(cap * 128, dtype=torch.uint8, device=dev)
-    L.lfq_set_indel_arrays_on_host(caller.h, 0)
+    n_thr = max(1, min(args.host_threads, len(my)))
+    callers = [caller] + [la.SnvCaller(dev.index) for _ in range(n_thr - 1)]
+    outs = []
+    for c_ in callers:
+        c_.set_dense_strand_counts(False)
+        L.lfq_set_indel_arrays_on_host(c_.h, 0)
+        outs.append((torch.zeros(cap * 64, dtype=torch.uint8, device=dev), torch.zeros(cap * 128, dtype=torch.uint8, device=dev)))
     target = R["target"]
 
-    def start():
+    def start(caller):
         rs = la.ReadSet.from_arrays(caller, R)
         rs.baq(extended=True, idaq=cfg["call_indels"])
         return rs
 
-    def finish(rs, i, b):
+    def finish(caller, d_counts, d_pvals, rs, i, b):
         """pileups + tests of a started bin -> (snv entry for finish_bins, indel entry or None, indel lines' makings)"""
         ient = None
         skip = None
@@ -702,22 +709,40 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         rs.close()
         return (i, b, pv, int(st.n_tested)), ient, ncalled
 
-    def step():
-        snv, ind, ncols = [], [], 0
-        pending = None
-        for k, (i, b, e) in enumerate(my):          # bin k + 1 is started (upload, BAQ kernels) before bin k is finished
-            rs = start()
+    def work(t, res):
+        """host thread t: its bins one after the other on its own context; bin k + 1 is started (upload, BAQ kernels queued)
+        before bin k is finished"""
+        try:
+            c_, (dc, dp) = callers[t], outs[t]
+            pending = None
+            for (i, b, e) in my[t::n_thr]:
+                rs = start(c_)
+                if pending is not None:
+                    res.append(finish(c_, dc, dp, *pending))
+                pending = (rs, i, b)
             if pending is not None:
-                s_, i_, n_ = finish(*pending)
-                snv.append(s_); ncols += n_
-                if i_ is not None:
-                    ind.append(i_)
-            pending = (rs, i, b)
-        if pending is not None:
-            s_, i_, n_ = finish(*pending)
+                res.append(finish(c_, dc, dp, *pending))
+        except BaseException as ex:                  # the step must not hang on a dead thread
+            res.append(ex)
+
+    def step():
+        import threading
+        results = [[] for _ in range(n_thr)]
+        th = [threading.Thread(target=work, args=(t, results[t])) for t in range(1, n_thr)]
+        for x in th:
+            x.start()
+        work(0, results[0])
+        for x in th:
+            x.join()
+        snv, ind, ncols = [], [], 0
+        for s_, i_, n_ in sorted((r for res in results for r in ([r_ for r_ in res if not isinstance(r_, BaseException)])), key=lambda r: r[0][0]):
             snv.append(s_); ncols += n_
             if i_ is not None:
                 ind.append(i_)
+        for res in results:
+            for r_ in res:
+                if isinstance(r_, BaseException):
+                    raise r_
         conf = la.VarcallConf(flag=flag)
         recs, total = shard.finish_bins(conf, snv, nb, dist if world > 1 else None, xdev)
         text = None
@@ -782,6 +807,8 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         dist.all_reduce(tot_cols)
     dt, called = float(tmax.item()), int(tot_cols.item())
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
+    for c_ in callers[1:]:
+        c_.close()
     if rank != 0:
         return None
     import hashlib
@@ -792,7 +819,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         "dtype": "f64", "data": "synthetic (one bin's reads, reused for every bin of the genome)",
         "roofline": None, "cpu_baseline": None,
         "config": {"workload": "%s: %s" % (cfg_name, cfg["what"]), "genome_len": glen, "called_columns": called, "bins": nb,
-                   "bins_rank0": len(my), "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": int(R["n"]) * nb,
+                   "bins_rank0": len(my), "host_threads_per_rank": n_thr, "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": int(R["n"]) * nb,
                    "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
                    "snv_tests": int(conf.num_snv_tests), "indel_tests": int(conf.num_indel_tests),
                    "snv_records_before_filter": nrecs[0], "indel_records": nrecs[1],
@@ -912,8 +939,10 @@ def main():
     args = parse_args()
     genome_cfg = args.config in GENOME_CONFIGS
     if genome_cfg:
-        if args.steps == 200 and args.warmup == 100:       # the defaults are C3's: a genome step takes ~0.3-0.6 s
-            args.steps, args.warmup = 5, 1
+        if args.steps == 200:                              # the defaults are C3's: a genome step takes ~0.3-0.6 s
+            args.steps = 5
+        if args.warmup == 100:
+            args.warmup = 1
         args.scaling = "strong"
     cfg_idx, cfg_depth, cfg_cols, cfg_filter, cfg_sample = CONFIGS["C3" if genome_cfg else args.config]
     depth = args.depth or cfg_depth
