@@ -1003,6 +1003,8 @@ def main():
             dist.destroy_process_group()
         caller.close()
         return
+    if args.mode in ("chain", "baq", "host-abi") and world > 1:
+        raise SystemExit("bench.py: --mode %s measures one GPU; the sharded reads -> VCF runs are --config C4 / C5" % args.mode)
     if args.mode == "chain":
         iters = max(args.steps // 100, 2)
         if args.workers > 1:
@@ -1260,10 +1262,15 @@ def main():
                         "note": "`value` / `ms_per_step` are the first block (the contract's K steps after W warm-up steps); "
                                 "the other blocks are the same K steps timed again"},
             "config": {
-                "workload": "%s: synthetic %.0f Mb genome per GPU, uniform %dx depth, SNV-only, %s, dynamic Bonferroni "
-                            "(BASELINE.json configs[%d])"
-                            % (args.config, ncols / 1e6, depth,
-                               "default filter applied" if cfg_filter else "--no-default-filter", cfg_idx),
+                # a --depth / --cols override is a shape of its own, not the BASELINE config whose defaults it started from
+                "workload": ("%s: synthetic %.0f Mb genome per GPU, uniform %dx depth, SNV-only, %s, dynamic Bonferroni "
+                             "(BASELINE.json configs[%d])"
+                             % (args.config, ncols / 1e6, depth,
+                                "default filter applied" if cfg_filter else "--no-default-filter", cfg_idx))
+                            if not (args.depth or args.cols) else
+                            ("custom shape (no BASELINE config): synthetic %.2f Mb genome per GPU, uniform %dx depth, SNV-only, %s, "
+                             "dynamic Bonferroni" % (ncols / 1e6, depth,
+                                                     "default filter applied" if cfg_filter else "--no-default-filter")),
                 "columns_per_gpu": my_cols, "bins_rank0": len(my_bins) if my_bins is not None else 1, "depth": depth, "planted_snv_period": args.plant_period,
                 "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
                 "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),

@@ -12,6 +12,16 @@ rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 if rnd != "r02":            # round 3 on: one more chain line (one worker, regions overlapped) and the IDAQ run of --mode baq
     NAMES = NAMES[:5] + ["--mode chain --overlap-regions (one worker; region k + 1 started before region k is finished)"] \
             + NAMES[5:] + ["--mode baq --idaq"]
+if rnd not in ("r02", "r03"):   # round 4 on: the depth-200 / depth-500 shapes are labelled as what they are, C4 / C5 are the genome runs
+    NAMES = ["C2 (10^6 columns x 1000)", "custom shape: 3.75 x 10^6 columns x 200, SNV-only, resident tracks",
+             "custom shape: 4.6 x 10^6 columns x 500, SNV-only, resident tracks",
+             "--config C4 (4.6 Mb x 500x genome of reads -> VCF, --call-indels, 32 bins; 1 step = the genome)",
+             "--config C5 (29 Mb of BED targets x 200x, reads -> VCF, 32 bins; 1 step = the genome)",
+             "--mode host-abi (200 k columns x 1000 from host memory)",
+             "--mode chain (regions of 2 M reads x 150 bp -> VCF, --call-indels, BAQ on; 1 step = 1 region)",
+             "--mode chain --overlap-regions (one worker; region k + 1 started before region k is finished)",
+             "--mode chain --workers 2 (two region workers = processes on the one GPU)",
+             "--mode baq (400 K reads x 150 bp)", "--mode baq --idaq"]
 lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
 print("# bench.py on the other configurations (1 MI355X; round %s).  C2 / depth 200 / depth 500: --steps 60 --warmup 5 --no-cpu-baseline --no-pmc" % rnd[1:].lstrip("0"))
 print("# --no-secondary, pipelined two-context loop; host-abi, chain, baq: the --mode runs.  The headline configuration (C3) is in %s_bench_line.json." % rnd)
