@@ -654,6 +654,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
     outs = []
     for c_ in callers:
         c_.set_dense_strand_counts(False)
+        c_.set_dense_counts(False)                  # only the sparse output of a bin is read
         L.lfq_set_indel_arrays_on_host(c_.h, 0)
         outs.append((torch.zeros(cap * 64, dtype=torch.uint8, device=dev), torch.zeros(cap * 128, dtype=torch.uint8, device=dev)))
     target = R["target"]
@@ -903,8 +904,10 @@ def full_check(args, caller, la, batch, d_counts, d_pvals, pv_cap, seed, depth, 
     import pyoracle as orc
     orc.build()
     conf = la.VarcallConf()
+    caller.set_dense_counts(True)                 # every column's entry is compared, not only the tested ones'
     caller.snv_batch_device(batch, conf, d_counts, d_pvals, pv_cap)
     st = caller.batch_finish()
+    caller.set_dense_counts(False)
     counts = d_counts[: ncols * 64].cpu().numpy().view(la.COL_COUNTS_DTYPE).copy()
     procs = args.full_check_procs or fc.default_procs()
     est_s = ncols * depth * 1.7e-7 / procs              # ~1.6 ms per 10 000x column on one core of the bench hosts
@@ -991,6 +994,7 @@ def main():
 
     caller = la.SnvCaller(local_rank)
     caller.set_dense_strand_counts(False)         # DP4 only for the columns that emit (what layer 2 does by itself)
+    caller.set_dense_counts(False)                # ... and dense entries only for the tested columns (likewise)
 
     if genome_cfg:
         out = bench_genome(args, args.config, caller, la, shard, dist, world, rank, dev, xdev, comm_ranks)
@@ -1127,6 +1131,7 @@ def main():
     if pipelined:
         callers = [caller, la.SnvCaller(local_rank)]
         callers[1].set_dense_strand_counts(False)
+        callers[1].set_dense_counts(False)
         # the sharded step (layer 1 + exchange) pipelines the same way: every context has its own device-side outputs
         out_bufs = [(d_counts, d_pvals), (torch.zeros_like(d_counts), torch.zeros_like(d_pvals))]
 
@@ -1227,7 +1232,8 @@ def main():
         # The DP kernels run concurrently on three streams; their span is the `dp` block below.
         count_name = "lfq_count_kernel<%s, false>" % ("false" if args.nt_bytes else "true")
         if depth < 4096:
-            count_name = "lfq_count_multi_kernel<%s, false>" % ("false" if args.nt_bytes else "true")
+            lpg = 4 if depth <= 320 else 8 if depth <= 900 else 16     # lfq_launch_count's choice at the default knobs
+            count_name = ("lfq_count_multi_kernel<false, false, %d>" if args.nt_bytes else "lfq_count_shallow_kernel<false, %d>") % lpg
         dom_ms = kt["ms_count"] / n_launch
         moved = (work["bytes_read_count"] + work["bytes_written_count"]) / n_launch     # layout bytes, this launch
         alg_bytes = my_cols * (4.0 * depth + 80.0) / n_launch
@@ -1285,7 +1291,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": moved,
                 "bytes_note": "bytes this instantiation moves by layout: observations x (0.5 nt + 1 bq) + 9 B header in, "
-                              "64 B record + 1 B class flag out per column; reported by the library per batch",
+                              "1 B class flag out per column + 64 B record out per column (per TESTED column where the "
+                              "shared-wavefront kernel runs on the context's own dense array: nothing reads the others); "
+                              "reported by the library per batch",
                 "avg_launch_ms": dom_ms,
                 "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and dom_ms > 0 else None,
                 "traffic_over_layout_bytes": (traffic / moved) if traffic and moved else None,

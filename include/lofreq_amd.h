@@ -37,7 +37,7 @@ extern "C" {
 /* 2: lfq_conf grew to 80 bytes (approx_threshold_n), lfq_dp_work gained n_approx_pruned, lfq_filter_records_ex.
  * A caller compiled against another version must not run: compare lfq_abi_version() with this value once, as the
  * bindings in integration/ and the Python loader do. */
-#define LFQ_ABI_VERSION 2
+#define LFQ_ABI_VERSION 3
 
 typedef enum lfq_status {
     LFQ_OK = 0,
@@ -446,6 +446,14 @@ int lfq_source_qual_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int def_nm_q
  * h_counts_or_null is given. */
 int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
 
+/* One step further for a caller of lfq_snv_batch_device that reads only the sparse output: with on = 0 the dense entry of a
+ * column that is not tested (tested == 0: nothing downstream looks at it) need not be written at all -- d_counts then keeps
+ * whatever it held there (the shared-wavefront count kernel, i.e. batches of the packed nt layout whose deepest column has at
+ * most a few thousand observations, skips those stores; at 200x the dense entries are a fifth of the bytes it moves, at the
+ * price HBM asks for writes among reads).  Takes effect only together with lfq_set_dense_strand_counts(ctx, 0).
+ * Default: on = 1.  (lfq_call_snvs_batch / _submit without h_counts use the context's own array and always run this way.) */
+int lfq_set_dense_counts(lfq_ctx *ctx, int on);
+
 /* The profile HMM's gap-open and gap-extension probabilities, kpa_ext_par_t.d / .e (kprobaln_ext.h:31-34), for every
  * BAQ call of the context after this one.  Default: kpa_ext_par_lofreq_illumina = { 1e-5, 0.4 } (kprobaln_ext.c:50), what
  * bam_prob_realn_core_ext uses (bam_md_ext.c:275); a reference built with -DPACBIO_REALN uses kpa_ext_par_lofreq_pacbio =
@@ -637,7 +645,7 @@ typedef struct lfq_dp_work {
     int64_t n_light, n_mid, n_big;   /* tested columns per scheduling class */
     int64_t n_light_retry;     /* light columns finished by the one-column-per-wavefront kernel */
     int64_t bytes_read_count;  /* track + header bytes the count kernel instantiation of this batch reads (layout bytes) */
-    int64_t bytes_written_count; /* dense records + class flags it writes */
+    int64_t bytes_written_count; /* dense records (of the tested columns only where lfq_set_dense_counts(0) applies) + class flags it writes */
     int64_t n_approx_pruned;   /* tested columns the Poisson gate (lfq_conf.approx_threshold_n) gave up: not in the classes above */
 } lfq_dp_work;
 int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);

@@ -160,6 +160,10 @@ class SnvCaller:
         _lib.check(rc, "lfq_call_snvs_batch")
         return rec[: n.value].copy(), counts, st
 
+    def set_dense_counts(self, on):
+        """lfq_set_dense_counts: off = snv_batch_device may leave the dense entries of untested columns unwritten"""
+        _lib.check(self.L.lfq_set_dense_counts(self.h, 1 if on else 0), "lfq_set_dense_counts")
+
     def set_dense_strand_counts(self, on):
         """lfq_set_dense_strand_counts: off = strand counts only for the columns of the sparse output (layer 1, submit)"""
         _lib.check(self.L.lfq_set_dense_strand_counts(self.h, 1 if on else 0), "lfq_set_dense_strand_counts")

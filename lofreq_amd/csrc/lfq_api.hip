@@ -313,6 +313,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     c->device = device_ordinal;
     c->sub_ncols = -1;
     c->dense_strand = 1;
+    c->dense_counts = 1;
     c->indel_host_arrays = 1;
     c->baq_par_d = 0.00001f;            /* kpa_ext_par_lofreq_illumina (kprobaln_ext.c:50) */
     c->baq_par_e = 0.4f;
@@ -494,6 +495,10 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
     LFQ_TRY(lfq_make_params(conf, tr, &P, indel_mode));
     P.detlim_af = indel_mode ? nullptr : c->detlim_af;      /* set only inside lfq_uniq_detlim_batch */
     P.lazy_strand = (c->lazy_now && !indel_mode && !P.general && !P.detlim_af) ? 1 : 0;
+    /* the context's own dense array (layer 2 without h_counts): nobody sees the entries of untested columns; a caller's
+     * array: only if it said so (lfq_set_dense_counts) */
+    P.sparse_counts = (P.lazy_strand && (d_counts == c->d_counts || !c->dense_counts)) ? 1 : 0;
+    P.pad_ = 0;
     /* -t (snpcaller.c:1131); lofreq uniq hands snpcaller -1 (lofreq_uniq.c:311-312) */
     P.approx_n = (!P.detlim_af && conf->approx_threshold_n > 0) ? conf->approx_threshold_n : 0;
     LFQ_TRY(ensure_workspace(c, tr->ncols));
@@ -596,6 +601,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
 
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
         LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st));
+        c->cur_sparse_counts = P.sparse_counts && lfq_count_is_shallow(T, P, max_depth);
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
 
         LFQ_TRY_HIP(hipStreamWaitEvent(dps, c->ev_cnt[s][1], 0));
@@ -800,6 +806,15 @@ int lfq_pack_nt_track(const uint8_t *nt_bytes, int64_t n_obs, uint8_t *packed_ou
     return LFQ_OK;
 }
 
+int lfq_set_dense_counts(lfq_ctx *c, int on)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    c->dense_counts = on ? 1 : 0;
+    return LFQ_OK;
+}
+
 int lfq_set_dense_strand_counts(lfq_ctx *c, int on)
 {
     if (!c) {
@@ -828,6 +843,9 @@ int lfq_batch_finish(lfq_ctx *c, lfq_batch_stats *stats)
     const int64_t batch_obs = (c->cur_col_off && c->cur_ncols > 0) ? (int64_t)(h_ends[1] - h_ends[0]) : 0;
     c->cur_count_read = batch_obs * c->cur_obs_bytes_x2 / 2 + c->cur_ncols * c->cur_col_bytes;
     c->cur_count_written = c->cur_ncols * (int64_t)(sizeof(lfq_col_counts) + 1);
+    if (c->cur_sparse_counts) {                     /* the shared-wavefront kernel stored the tested columns' entries only */
+        c->cur_count_written = c->cur_ncols + (int64_t)c->h_counters[LFQ_MAX_SEGMENTS * LFQ_NCOUNTERS + LFQ_GC_TESTED] * (int64_t)sizeof(lfq_col_counts);
+    }
     const int32_t *g = c->h_counters + LFQ_MAX_SEGMENTS * LFQ_NCOUNTERS;
     memset(&c->times, 0, sizeof(c->times));
     float ms = 0.f;

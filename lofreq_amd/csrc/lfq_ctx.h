@@ -303,6 +303,7 @@ struct lfq_ctx {
     int64_t cur_count_read, cur_count_written;   /* layout bytes of this batch's count kernel (lfq_dp_work) */
     const uint64_t *cur_col_off;                 /* device: CSR offsets of the batch in flight */
     int cur_obs_bytes_x2, cur_col_bytes;
+    int cur_sparse_counts;           /* this batch's count kernel stored the dense entries of the tested columns only */
     int n_cu;
     /* strand-bias precompute (lfq_internal.h): DP4 tuples land in host-mapped memory right after the scan;
      * a leader thread waits for that and runs the Fisher tests on the host pool while the DP kernels run */
@@ -331,6 +332,7 @@ struct lfq_ctx {
     int indel_host_arrays;           /* lfq_set_indel_arrays_on_host */
     int16_t *d_plp_ne;               /* quality arrays of the columns above, resident: [q0 | mq0 | q1 | mq1] */
     int64_t plp_ne_total[2];
+    int dense_counts;                /* lfq_set_dense_counts: 0 = a caller's dense array may keep stale entries for untested columns */
     int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
     int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */

@@ -46,6 +46,9 @@ struct LfqParams {
     const float *detlim_af;
     int32_t lazy_strand;      /* 1: the count kernel skips the strand planes; lfq_strand_* fill them where a record is emitted */
     int32_t approx_n;         /* > 0: columns with more error probabilities than this pass the Poisson gate first (snpcaller.c:1131) */
+    int32_t sparse_counts;    /* 1: the shared-wavefront count kernel writes the dense entry of a column only if it is tested (nothing
+                               * on the device reads the others: lfq_set_dense_counts) */
+    int32_t pad_;
 };
 
 struct LfqTracksDev {
@@ -374,6 +377,7 @@ int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, in
                             int32_t *n_mapped, int cap_entries, int min_alt, void *stream);
 int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);
 int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream);
+bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max_col_obs);
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream);
 int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,

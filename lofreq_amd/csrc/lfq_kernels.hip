@@ -241,12 +241,103 @@ __device__ __forceinline__ void lfq_count_emit(bool strand, lfq_col_counts &r, c
     }
 }
 
+/* The chunks of one column of lfq_count_shallow_kernel (packed nt layout): lane l of the column's LPG lanes takes the chunks
+ * l, l + LPG, ...  What the general loop (lfq_count_chunks) spends around the counting proper -- 64-bit chunk addresses, the
+ * range of every chunk from 64-bit offsets, a second pass with byte masks whenever any lane of the wavefront is at a
+ * column's first or last chunk: 75 of 125 VALU instructions per chunk -- is done once per column here: chunk indices are
+ * 32-bit and relative to the column, the addresses are a wavefront-uniform base (buffer loads: the base in scalar
+ * registers) plus a 32-bit lane offset, the masks of the first and the last chunk come out of a table in LDS (s_tab[h]:
+ * the nibbles of observations [0, h) of a chunk), and every chunk takes the same path.
+ * Two halves:
+ *   lfq_group_issue    the loads of AHEAD chunks of the lane, i0, i0 + LPG, ... (a chunk index past the column's end reads on
+ *                      into the next column -- never past `pass_last`, the last chunk of the wavefront's 64 columns -- and
+ *                      counts nothing);
+ *   lfq_group_consume  counts them.
+ * A batch whose deepest column has more than AHEAD * LPG chunks takes several such rounds per group (`rounds`, the same for
+ * every wavefront: a kernel argument). */
+#ifndef LFQ_COUNT_AHEAD
+#define LFQ_COUNT_AHEAD 4
+#endif
+typedef uint32_t lfq_v2u __attribute__((ext_vector_type(2)));
+typedef uint32_t lfq_v4u __attribute__((ext_vector_type(4)));
+template <int AHEAD>
+struct LfqGroupLoads {
+    lfq_v2u n2[AHEAD];
+    lfq_v4u b4[AHEAD];
+};
+
+template <bool SAME_THR, bool STRAND>
+__device__ __forceinline__ void lfq_count_chunk_packed(LfqAcc &a, lfq_v2u n2, lfq_v4u b4, uint32_t vx, uint32_t vy,
+                                                       uint32_t minbq4, uint32_t minalt4)
+{
+    lfq_count_nib8<SAME_THR, STRAND>(a, n2.x, b4.x, b4.y, vx, minbq4, minalt4);
+    lfq_count_nib8<SAME_THR, STRAND>(a, n2.y, b4.z, b4.w, vy, minbq4, minalt4);
+}
+
+/* h: the column's header out of LDS -- start (64 bit), length (0: gated or past the end), - */
+template <int LPG, int AHEAD>
+__device__ __forceinline__ void lfq_group_issue(LfqGroupLoads<AHEAD> &L, const LfqTracksDev &T, uint4 h, int i0, uint64_t pass_last)
+{
+    const uint32_t c0_lo = (h.x >> 4) | (h.y << 28);                  /* chunk of the column's start, low half */
+    /* lane 0's column starts lowest (columns ascend with the group) */
+    const uint32_t f_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.x), f_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.y);
+    const uint64_t c_head = ((uint64_t)f_lo | ((uint64_t)f_hi << 32)) >> 4;
+    const uint64_t c_first = c_head < pass_last ? c_head : pass_last;   /* (empty columns at the very end start one past it) */
+    const uint32_t rel = c0_lo - (uint32_t)c_first + (uint32_t)i0;    /* (the columns of a wavefront are neighbours: small) */
+    const uint32_t rel_last = (uint32_t)(pass_last - c_first);
+    const __amdgpu_buffer_rsrc_t nt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(T.nt + (c_first << 3)), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(T.bq + (c_first << 4)), 0, -1, 0x00020000);
+    const int n_ch = (int)(((h.x & 15u) + h.z + 15u) >> 4);
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {
+        /* (a step no column of the wavefront's group reaches is skipped as a whole: wave-uniform, the same test as in
+         * lfq_group_consume) */
+        if (k == 0 || __any(i0 + k * LPG < n_ch)) {
+            const uint32_t at = min(rel + (uint32_t)(k * LPG), rel_last);
+            L.n2[k] = __builtin_amdgcn_raw_buffer_load_b64(nt_rsrc, (int)(at << 3), 0, 0);
+            L.b4[k] = __builtin_amdgcn_raw_buffer_load_b128(bq_rsrc, (int)(at << 4), 0, 0);
+        }
+    }
+}
+
+template <bool SAME_THR, bool STRAND, int LPG, int AHEAD>
+__device__ __forceinline__ void lfq_group_consume(LfqAcc &a, const LfqGroupLoads<AHEAD> &L, const LfqTracksDev &T, uint4 h,
+                                                  uint32_t minbq4, uint32_t minalt4, int i0, const uint2 *s_tab)
+{
+    constexpr uint32_t FULL = 0x88888888u;
+    const int lo = (int)(h.x & 15u);
+    const int n_ch = (int)(((uint32_t)lo + h.z + 15u) >> 4);         /* chunks the column touches */
+    const int last = n_ch - 1;
+    const uint2 t_lo = s_tab[lo];
+    const uint2 t_hi = s_tab[n_ch > 0 ? lo + (int)h.z - 16 * last : 0];
+    const uint32_t lo_x = ~t_lo.x & FULL, lo_y = ~t_lo.y & FULL;    /* observations [lo, 16) of the first chunk */
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {
+        const int idx = i0 + k * LPG;
+        uint32_t vx = idx < last ? FULL : (idx == last ? t_hi.x : 0u);
+        uint32_t vy = idx < last ? FULL : (idx == last ? t_hi.y : 0u);
+        if (k == 0) {                                /* idx == 0: lane 0's first chunk, first round */
+            vx &= idx == 0 ? lo_x : FULL;
+            vy &= idx == 0 ? lo_y : FULL;
+        }
+        if (k == 0 || __any(idx < n_ch)) {
+            lfq_count_chunk_packed<SAME_THR, STRAND>(a, L.n2[k], L.b4[k], vx, vy, minbq4, minalt4);
+        }
+    }
+}
+
 /* Shallow columns (depth up to a few thousand): the per-column epilogue (12 reductions + the record) costs more
  * than the loads, so several columns share a wavefront, LPG lanes each: 64 / LPG records built at once, reductions of
  * log2(LPG) steps inside the DPP row.  LPG = 16 (four columns) up to a few thousand observations per column, 8 below a
  * thousand, 4 for exome-like depths: the instructions of one pass over the epilogue are the same for any LPG, so the
  * cost per column falls with the number of columns that share it until the loads dominate (at 200x: 0.65 -> see
  * DESIGN.md 3.1).  Fast path only (nt + bq tracks); everything else runs lfq_count_kernel. */
+#ifndef LFQ_COUNT_AHEAD
+#define LFQ_COUNT_AHEAD 4
+#endif
+#ifndef LFQ_COUNT_WAVES
+#define LFQ_COUNT_WAVES 4
+#endif
 template <bool PACKED, bool STRAND, int LPG>
 __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, LfqParams P,
                                                               lfq_col_counts *__restrict__ out,
@@ -339,6 +430,186 @@ __global__ __launch_bounds__(256) void lfq_count_multi_kernel(LfqTracksDev T, Lf
         }
         if (lane < G && colb + lane < c1) {
             flags[colb + lane] = s_flag[wave][lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* The shared-wavefront kernel for the packed nt layout: a wavefront takes 64 consecutive columns per pass and works on
+ * them in three phases, each with the lane <-> work mapping that suits it.
+ *   header    lane j <-> column j: offsets, reference base, coverage gates -- coalesced loads, once; the column's start and
+ *             length into LDS.
+ *   counting  64 / LPG columns at a time, LPG lanes each (lfq_count_group_packed); a group gets its column's range out of
+ *             LDS (no global round trip per group), and its plane sums go back there.
+ *   records   lane j <-> column j again: ONE pass over the epilogue (classes, alt counts, K, class flag: ~150
+ *             instructions, as many as the counting of a 1000x column costs a lane) builds 64 records instead of 64 / LPG,
+ *             and the wavefront writes them as 4 KiB in a row.
+ * lfq_count_multi_kernel ran header and epilogue once per 64 / LPG columns: at 1000x (LPG 16) half of its instructions,
+ * in a kernel bound by what it issues. */
+template <bool STRAND, int LPG>
+__global__ __launch_bounds__(256, STRAND ? 3 : LFQ_COUNT_WAVES) void lfq_count_shallow_kernel(LfqTracksDev T, LfqParams P,
+                                                                                lfq_col_counts *__restrict__ out,
+                                                                                uint8_t *__restrict__ flags, int64_t c0, int64_t c1,
+                                                                                int rounds)
+{
+    constexpr int G = 64 / LPG;                      /* columns counted at a time */
+    constexpr int NSUM = STRAND ? 4 : 3;             /* uint4 plane sums per column: ge, ga, raw (, fw) */
+    __shared__ __attribute__((aligned(16))) uint4 s_hdr[4][64];          /* start (64 bit), length, - */
+    __shared__ __attribute__((aligned(16))) uint4 s_sum[4][64][NSUM];
+    __shared__ __attribute__((aligned(16))) lfq_col_counts s_rec[4][64];
+    __shared__ uint2 s_tab[17];                      /* nibbles of the observations [0, h) of a chunk (lfq_count_group_packed) */
+    if (threadIdx.x < 17) {
+        const int h = (int)threadIdx.x;
+        s_tab[h] = make_uint2((lfq_bytes_mask(0, h, 0) >> 4) | lfq_bytes_mask(0, h, 1),
+                              (lfq_bytes_mask(0, h, 2) >> 4) | lfq_bytes_mask(0, h, 3));
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = lfq_lane();
+    const int g = lane / LPG, l = lane % LPG;
+    const int64_t stride = (int64_t)gridDim.x * 4 * 64;
+    const bool same_thr = (P.min_alt_bq4 == P.min_bq4);
+    const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
+    const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
+    for (int64_t colb = c0 + ((int64_t)blockIdx.x * 4 + wave) * 64; colb < c1; colb += stride) {
+        /* ---- header: lane <-> column ---- */
+        const int64_t col = colb + lane;
+        const bool valid = col < c1;
+        const int64_t colc = valid ? col : c1 - 1;
+        const uint64_t off0 = T.col_off[colc], off1 = T.col_off[colc + 1];
+        const int cov_h = T.coverage_plp ? T.coverage_plp[colc] : 0;
+        const int nb_h = T.num_bases ? T.num_bases[colc] : 0;
+        const uint32_t rb = T.ref_base[colc];
+        const int64_t n_obs = (int64_t)(off1 - off0);
+        const int cov = T.coverage_plp ? cov_h : (int)n_obs;
+        const int nb = T.num_bases ? nb_h : (int)n_obs;
+        const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
+        const bool gated = (ref_code < 0) || (!P.detlim_af && (((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov)));
+        s_hdr[wave][lane] = make_uint4((uint32_t)off0, (uint32_t)(off0 >> 32), (valid && !gated) ? (uint32_t)n_obs : 0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        /* ---- counting: LPG lanes <-> column ---- */
+        const int n_here = (int)((c1 - colb) < 64 ? (c1 - colb) : 64);
+        const int n_sub = (n_here + G - 1) / G;
+        /* the last chunk the wavefront's columns touch (a load may run past its own column, not past this one) */
+        const uint64_t end_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off1, n_here - 1);
+        const uint64_t end_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off1 >> 32), n_here - 1);
+        const uint64_t beg_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off0);
+        const uint64_t beg_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off0 >> 32));
+        const uint64_t pass_beg = beg_lo | (beg_hi << 32), pass_end = end_lo | (end_hi << 32);
+        if (pass_end > pass_beg) {                   /* (nothing to read otherwise: not even a chunk that is surely there) */
+            const uint64_t pass_last = (pass_end - 1) >> 4;
+#define LFQ_SHALLOW_ZERO(a_)                                                                                            \
+            _Pragma("unroll")                                                                                           \
+            for (int x = 0; x < 4; x++) {                                                                               \
+                a_.raw[x] = a_.fw[x] = a_.ge[x] = a_.ga[x] = 0;                                                         \
+            }
+#define LFQ_SHALLOW_CONSUME(a_, L_, h_, i0_)                                                                            \
+            do {                                                                                                        \
+                if (same_thr) {                                                                                         \
+                    lfq_group_consume<true, STRAND, LPG, LFQ_COUNT_AHEAD>(a_, L_, T, h_, minbq4, minalt4, i0_, s_tab);  \
+                } else {                                                                                                \
+                    lfq_group_consume<false, STRAND, LPG, LFQ_COUNT_AHEAD>(a_, L_, T, h_, minbq4, minalt4, i0_, s_tab); \
+                }                                                                                                       \
+            } while (0)
+#define LFQ_SHALLOW_SUMS(a_, cw_)                                                                                       \
+            do {                                                                                                        \
+                uint32_t n_ge[4], n_ga[4], n_raw[4], n_fw[4];                                                           \
+                _Pragma("unroll")                                                                                       \
+                for (int x = 0; x < 4; x++) {                                                                           \
+                    n_ge[x] = lfq_group_sum_u32<LPG>(a_.ge[x]);                                                         \
+                    n_ga[x] = same_thr ? n_ge[x] : lfq_group_sum_u32<LPG>(a_.ga[x]);                                    \
+                    n_raw[x] = lfq_group_sum_u32<LPG>(a_.raw[x]);                                                       \
+                    if (STRAND) {                                                                                       \
+                        n_fw[x] = lfq_group_sum_u32<LPG>(a_.fw[x]);                                                     \
+                    }                                                                                                   \
+                }                                                                                                       \
+                if (l == 0) {                                                                                           \
+                    s_sum[wave][cw_][0] = make_uint4(n_ge[0], n_ge[1], n_ge[2], n_ge[3]);                               \
+                    s_sum[wave][cw_][1] = make_uint4(n_ga[0], n_ga[1], n_ga[2], n_ga[3]);                               \
+                    s_sum[wave][cw_][2] = make_uint4(n_raw[0], n_raw[1], n_raw[2], n_raw[3]);                           \
+                    if (STRAND) {                                                                                       \
+                        s_sum[wave][cw_][3] = make_uint4(n_fw[0], n_fw[1], n_fw[2], n_fw[3]);                           \
+                    }                                                                                                   \
+                }                                                                                                       \
+            } while (0)
+            {
+#pragma unroll 1
+                for (int sub = 0; sub < n_sub; sub++) {
+                    const int cw = sub * G + g;
+                    const uint4 h = s_hdr[wave][cw];
+                    LfqAcc a;
+                    LFQ_SHALLOW_ZERO(a);
+#pragma unroll 1
+                    for (int rd = 0; rd < rounds; rd++) {
+                        const int i0 = l + rd * (LFQ_COUNT_AHEAD * LPG);
+                        if (rd > 0 && !__any(i0 < (int)(((h.x & 15u) + h.z + 15u) >> 4))) {
+                            break;                   /* no column of this group reaches into the round */
+                        }
+                        LfqGroupLoads<LFQ_COUNT_AHEAD> L;
+                        lfq_group_issue<LPG, LFQ_COUNT_AHEAD>(L, T, h, i0, pass_last);
+                        LFQ_SHALLOW_CONSUME(a, L, h, i0);
+                    }
+                    LFQ_SHALLOW_SUMS(a, cw);
+                }
+            }
+#undef LFQ_SHALLOW_ZERO
+#undef LFQ_SHALLOW_CONSUME
+#undef LFQ_SHALLOW_SUMS
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        /* ---- records: lane <-> column ---- */
+        bool is_tested = false;
+        if (valid) {
+            lfq_col_counts r;
+            r.n_err_probs = 0;
+            for (int i = 0; i < 3; i++) {
+                r.alt_counts[i] = r.alt_raw_counts[i] = r.alt_fw[i] = 0;
+            }
+            r.ref_fw = r.ref_rv = 0;
+            r.kmax = 0;
+            r.tested = 0;
+            r.pad_[0] = r.pad_[1] = 0;
+            r.median_ref_bq = -1;
+            r.coverage = cov;
+            r.gated = gated;
+            uint32_t n_ge[4] = {0, 0, 0, 0}, n_ga[4] = {0, 0, 0, 0}, n_raw[4] = {0, 0, 0, 0}, n_fw[4] = {0, 0, 0, 0};
+            if (!gated && pass_end > pass_beg) {
+                const uint4 v0 = s_sum[wave][lane][0], v1 = s_sum[wave][lane][1];
+                n_ge[0] = v0.x; n_ge[1] = v0.y; n_ge[2] = v0.z; n_ge[3] = v0.w;
+                n_ga[0] = v1.x; n_ga[1] = v1.y; n_ga[2] = v1.z; n_ga[3] = v1.w;
+                const uint4 v2 = s_sum[wave][lane][2];
+                n_raw[0] = v2.x; n_raw[1] = v2.y; n_raw[2] = v2.z; n_raw[3] = v2.w;
+                if (STRAND) {
+                    const uint4 v3 = s_sum[wave][lane][3];
+                    n_fw[0] = v3.x; n_fw[1] = v3.y; n_fw[2] = v3.z; n_fw[3] = v3.w;
+                }
+            }
+            uint32_t raw[4], fw[4], c_ge[4], c_ga[4], filt[4];
+            lfq_planes_to_classes(n_raw, raw);
+            lfq_planes_to_classes(n_fw, fw);
+            lfq_planes_to_classes(n_ge, c_ge);
+            lfq_planes_to_classes(n_ga, c_ga);
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];
+            }
+            lfq_count_emit(STRAND, r, raw, fw, filt, ref_code, &s_rec[wave][0], flags + colb, lane);
+            is_tested = r.tested != 0;
+        }
+        /* (sparse mode: only the tested columns' entries are ever read again -- work lists, DP kernels, records --, and the
+         * entries are a fifth of what this kernel moves at 200x, at the price HBM asks for writes among reads) */
+        const unsigned long long keep = P.sparse_counts ? __ballot(is_tested) : ~0ull;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        /* 64 records = 4 KiB in a row: four stores of 1 KiB per wavefront */
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int q = t * 64 + lane;             /* 16-byte piece q of the wavefront's records: column q / 4 */
+            if (colb + (q >> 2) < c1 && ((keep >> (q >> 2)) & 1ull) != 0) {
+                reinterpret_cast<uint4 *>(out + colb)[q] = reinterpret_cast<const uint4 *>(&s_rec[wave][0])[q];
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -887,6 +1158,12 @@ int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *strea
     return LFQ_OK;
 }
 
+/* does a batch with this deepest column take lfq_count_shallow_kernel (the only one that honours LfqParams::sparse_counts) */
+bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max_col_obs)
+{
+    return !p.general && !p.detlim_af && max_col_obs > 0 && max_col_obs < lfq_knobs().count_multi_below && t.nt_packed;
+}
+
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
                      lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream)
 {
@@ -898,6 +1175,23 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         /* lanes per column by the deepest column of the batch: each lane takes chunks of 16 observations */
         const LfqKnobs &kn = lfq_knobs();
         const int lpg = max_col_obs <= kn.count_lpg4_below ? 4 : max_col_obs <= kn.count_lpg8_below ? 8 : 16;
+        if (t.nt_packed) {
+            /* 64 columns per wavefront and pass; enough blocks for every SIMD's wavefronts, several passes each */
+            const int64_t blocks64 = (c1 - c0 + 255) / 256;
+            const unsigned nb = (unsigned)std::min<int64_t>(blocks64, (int64_t)256 * 8 * 4);
+            /* chunks the deepest column can touch (an unaligned start adds one), in rounds of AHEAD per lane */
+            const int rounds = (int)((max_col_obs / 16 + 2 + LFQ_COUNT_AHEAD * lpg - 1) / (LFQ_COUNT_AHEAD * lpg));
+#define LFQ_LAUNCH_SHALLOW(ST)                                                                                       \
+            do {                                                                                                     \
+                if (lpg == 4) hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
+                else if (lpg == 8) hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 8>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
+                else hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 16>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
+            } while (0)
+            if (!p.lazy_strand) LFQ_LAUNCH_SHALLOW(true); else LFQ_LAUNCH_SHALLOW(false);
+#undef LFQ_LAUNCH_SHALLOW
+            LFQ_HIP_TRY(hipGetLastError());
+            return LFQ_OK;
+        }
         const int64_t per_block = 4 * (64 / lpg);
         const unsigned blocks = (unsigned)((c1 - c0 + per_block - 1) / per_block);
 #define LFQ_LAUNCH_MULTI_L(PK, ST, L)                                                                                \

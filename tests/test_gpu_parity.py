@@ -582,3 +582,38 @@ def test_approx_threshold_gate(caller, oracle, thr, kw):
     conf_hi = la.VarcallConf(approx_threshold_n=100000, **kw)
     recs_hi, _, _ = caller.call_snvs(util.to_pileup_batch(la, host), conf_hi, want_counts=True)
     assert caller.dp_work()["n_approx_pruned"] == 0 and len(recs_hi) == len(recs_off)
+
+
+@pytest.mark.parametrize("depth", [150, 600, 1000])
+def test_sparse_dense_entries(oracle, depth):
+    """lfq_set_dense_counts(0): the shared-wavefront count kernel stores the dense entry of a TESTED column only -- those
+    bit-identical to the dense run, the others untouched (a sentinel survives) --, class flags, work lists and the sparse
+    output are those of the dense run (same p-value records, same tested count)."""
+    import lofreq_amd as la
+    import torch
+    seed, ncols = 0x1234ABCD ^ (depth << 20), 40000 + depth        # not a multiple of 64: a last pass with idle lanes
+    c = la.SnvCaller(0)
+    try:
+        c.set_dense_strand_counts(False)
+        batch = c.synth_batch(seed, depth, ncols, plant_period=97)
+        dev = torch.device("cuda", 0)
+        out = []
+        for dense in (True, False):
+            c.set_dense_counts(dense)
+            d_counts = torch.full((ncols * 64,), 0xA5, dtype=torch.uint8, device=dev)
+            d_pvals = torch.zeros(ncols * 128, dtype=torch.uint8, device=dev)
+            c.snv_batch_device(batch, la.VarcallConf(), d_counts, d_pvals, ncols)
+            st = c.batch_finish()
+            counts = d_counts.cpu().numpy().view(la.COL_COUNTS_DTYPE).copy()
+            pv = d_pvals.cpu().numpy().view(la.COL_PVALS_DTYPE)[: st.n_pvals].copy()
+            out.append((counts, pv[np.argsort(pv["col"], kind="stable")], int(st.n_tested), c.dp_work()))
+        (cd, pd_, nd, wd), (cs, ps, ns, ws) = out
+        assert nd == ns and nd > 0 and pd_.tobytes() == ps.tobytes()
+        tested = cd["tested"] != 0
+        assert int(tested.sum()) == nd and 0 < nd < ncols
+        assert cs[tested].tobytes() == cd[tested].tobytes()
+        assert np.all(cs[~tested].view(np.uint8) == 0xA5), "an untested column's entry was written"
+        assert ws["bytes_written_count"] == ncols + 64 * nd and wd["bytes_written_count"] == 65 * ncols
+    finally:
+        c.close()
+        torch.cuda.empty_cache()
