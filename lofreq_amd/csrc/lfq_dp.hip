@@ -487,16 +487,20 @@ __device__ __forceinline__ void lfq_strip_store_cells(const LfqStrip<C> &S, int 
 }
 
 /* How many NEW row segments to cut `rem_chunks` remaining chunks of a K-cell column into (0 = do not split).
- * Bounds: LFQ_SEG_MAX segments in total, no segment shorter than LFQ_SEG_MIN_CHUNKS chunks, and the
- * (segments - 1) convolutions of K^2/2 terms must stay below a quarter of the rows * K recurrence work. */
+ * Bounds: LFQ_SEG_MAX segments in total, no segment shorter than LFQ_SEG_MIN_CHUNKS chunks (LFQ_SEG_MIN_CHUNKS_SHORT for a
+ * column of less than LFQ_SEG_SHORT_BELOW chunks: a 1000x column with hundreds of alt bases is a chain of a thousand dependent
+ * rows of a third of a microsecond on a wavefront of its own, the longest thing in a 1000x batch), and the
+ * (segments - 1) convolutions of K^2/2 terms must stay below a quarter of the rows * K recurrence work -- except that up to
+ * three segments are always allowed: two convolutions are microseconds, and a segment that starts from the identity has
+ * min(row, K) cells like the column itself, so short segments of a wide column are less work than the column in one piece. */
 __device__ __forceinline__ int lfq_split_plan(int K, int64_t rem_chunks, int phase1, int seg_max)
 {
     if (K > LFQ_SPLIT_MAX_K) {
         return 0;
     }
     int64_t n_new = seg_max - phase1;
-    n_new = min(n_new, rem_chunks / LFQ_SEG_MIN_CHUNKS);
-    n_new = min(n_new, rem_chunks * 64 / (2 * (int64_t)max(K, 1)) + 1 - phase1);
+    n_new = min(n_new, rem_chunks / (rem_chunks < LFQ_SEG_SHORT_BELOW ? LFQ_SEG_MIN_CHUNKS_SHORT : LFQ_SEG_MIN_CHUNKS));
+    n_new = min(n_new, max(rem_chunks * 64 / (2 * (int64_t)max(K, 1)) + 1 - phase1, (int64_t)3 - phase1));
     return n_new >= 2 ? (int)n_new : 0;
 }
 

@@ -116,6 +116,10 @@ struct LfqLong {              /* 128 bytes */
  * per cell (the per-row overhead is shared), which is what counts once the segments provide the parallelism. */
 #define LFQ_SEG_CLASSES 5
 #define LFQ_SEG_MIN_CHUNKS 16     /* no segment shorter than this many 64-row chunks */
+#ifndef LFQ_SEG_MIN_CHUNKS_SHORT
+#define LFQ_SEG_MIN_CHUNKS_SHORT 4  /* ... of a column of less than LFQ_SEG_SHORT_BELOW chunks (lfq_split_plan) */
+#endif
+#define LFQ_SEG_SHORT_BELOW 48
 #define LFQ_PHASE1_CHUNKS 8       /* mid class: rows run unsplit before a surviving column is cut up (measured: 4..8 best) */
 #define LFQ_SPLIT_MAX_K 2016      /* 63 * 32: one wavefront at 32 cells per lane; the combine kernel keeps two
                                    * (K+1)-cell distributions in LDS */
