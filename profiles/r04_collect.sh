@@ -31,3 +31,14 @@ out=$R/gpurun_out/prof_r04_c4; rm -rf $out; mkdir -p $out
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace -d $out -o trace -- python $R/bench.py --config C4 --steps 4 --warmup 1 > $out/bench.log 2>&1)
 python profiles/gpu_busy.py $out 0.6 > gpurun_out/r04_c4_gpu_busy.md 2>&1
 ls gpurun_out | grep r04
+# kernel timelines of one C2 and one C3 step (no pipelining: one step's kernels at a time)
+for cfg in C2 C3; do
+  out=$R/gpurun_out/prof_r04_tl_$cfg; rm -rf $out; mkdir -p $out
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace -d $out -o t -- python $R/bench.py --config $cfg --steps 6 --warmup 3 --repeats 1 --no-pipeline --no-cpu-baseline --no-pmc --no-secondary --no-full-check > /dev/null 2>&1)
+  python profiles/timeline.py $out > gpurun_out/r04_timeline_$cfg.txt 2>&1
+done
+# the shared-wavefront count kernel: counters at C2, rate against the size of the launch
+CTRS="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS FETCH_SIZE WRITE_SIZE" bash profiles/pmc_kernels.sh r04shallow lfq_count --config C2 > gpurun_out/r04_count_shallow_pmc.md 2>&1
+bash profiles/count_vs_columns.sh > gpurun_out/r04_count_vs_columns.txt 2>&1
+python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" > gpurun_out/r04_gpu_tests.txt
+ls gpurun_out | grep r04
