@@ -68,7 +68,7 @@ def parse_args():
                          "reads -> VCF chain, region- / BED-sharded over --gpus (strong scaling)")
     ap.add_argument("--vcf-out", default=None, help="C4 / C5: rank 0 writes the VCF text of the last step here")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="C4 / C5: a smaller genome of the same shape (tests)")
-    ap.add_argument("--host-threads", type=int, default=2,
+    ap.add_argument("--host-threads", type=int, default=4,
                     help="C4 / C5: host threads per rank, one context each, that work through the rank's bins (the host part "
                          "of one bin -- CIGAR geometry, event tables, test descriptors -- then runs under the kernels of another)")
     ap.add_argument("--idaq", action="store_true", help="--mode baq: also the indel alignment qualities (ai / ad)")
