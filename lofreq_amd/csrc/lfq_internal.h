@@ -327,6 +327,15 @@ int lfq_launch_plp_indel_columns(const LfqPlpIndelArgs &a, int scatter, void *st
 int lfq_launch_flag_merge(uint8_t *fl, const uint8_t *tag, int64_t n, void *stream);
 int lfq_launch_skip_columns(int32_t *nb, const uint8_t *skip, int64_t n, void *stream);
 int lfq_launch_pack_nt(const uint8_t *nt_bytes, uint8_t *nt_packed, int64_t n_obs, void *stream);
+/* columns of the SNV pileup from the per-position counters (lfq_pileup.hip): tile sums + their scan + the totals
+ * (totals[0] columns, [1] observations, [2] deepest column), then the per-column arrays */
+#define LFQ_PLP_COMPACT_TILE 4096
+int lfq_launch_plp_compact_sums(const int32_t *cov, const int32_t *nb, int64_t width, int64_t *tile_cols, uint64_t *tile_obs,
+                                int32_t *tile_max, int64_t *totals, void *stream);
+int lfq_launch_plp_compact_apply(const int32_t *cov, const int32_t *nb, int64_t width, int64_t begin, const uint8_t *ref,
+                                 int64_t ref_len, const int64_t *tile_cols, const uint64_t *tile_obs, const int64_t *totals,
+                                 int32_t *col_index, uint64_t *col_off, uint8_t *ref_base, int32_t *cov_c, int32_t *nb_c,
+                                 int64_t *col_pos, void *stream);
 int lfq_launch_gather2(const uint8_t *a, const uint8_t *b, const int64_t *idx, int64_t n, uint8_t *oa, uint8_t *ob, void *stream);
 
 /* indel pseudo-columns built on the device from the resident quality arrays of lfq_readset_pileup_indels */

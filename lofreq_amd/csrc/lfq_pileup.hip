@@ -1241,3 +1241,202 @@ int lfq_launch_skip_columns(int32_t *nb, const uint8_t *skip, int64_t n, void *s
     hipLaunchKernelGGL(lfq_skip_columns_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nb, skip, n);
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* columns of the SNV pileup from the per-position counters, on the device                     */
+/* ------------------------------------------------------------------------------------------ */
+/* The count pass leaves coverage and kept bases per reference position; the tracks need, per COVERED position, a column
+ * index, the offset of its first observation, its reference base and the two counts -- an exclusive scan over the
+ * positions and a compaction.  That was a round trip: 8 MB of counters to the host, two threaded passes over the
+ * positions, 21 MB back, two stream synchronisations, with the GPU idle in between (2 - 4 ms per 1 Mb region).  Three small
+ * kernels instead (tiles of 4096 positions: sums per tile, scan of the tile sums + the totals, apply); the host waits
+ * once, for three numbers (it sizes the tracks from them). */
+#define LFQ_PC_THREADS 256
+#define LFQ_PC_ITEMS 16
+#define LFQ_PC_TILE (LFQ_PC_THREADS * LFQ_PC_ITEMS)
+
+__device__ __forceinline__ void lfq_pc_block_scan(int32_t &n, unsigned long long &o, int32_t *s_n, unsigned long long *s_o)
+{
+    /* inclusive scan of (n, o) over the threads of the block (Hillis-Steele in LDS: 8 steps for 256 threads) */
+    const int t = (int)threadIdx.x;
+    s_n[t] = n;
+    s_o[t] = o;
+    __syncthreads();
+    for (int d = 1; d < LFQ_PC_THREADS; d <<= 1) {
+        const int32_t pn = t >= d ? s_n[t - d] : 0;
+        const unsigned long long po = t >= d ? s_o[t - d] : 0ull;
+        __syncthreads();
+        s_n[t] += pn;
+        s_o[t] += po;
+        __syncthreads();
+    }
+    n = s_n[t];
+    o = s_o[t];
+}
+
+__global__ __launch_bounds__(LFQ_PC_THREADS) void lfq_plp_compact_tiles_kernel(const int32_t *__restrict__ cov,
+                                                                              const int32_t *__restrict__ nb, int64_t width,
+                                                                              int64_t *__restrict__ tile_cols,
+                                                                              unsigned long long *__restrict__ tile_obs,
+                                                                              int32_t *__restrict__ tile_max)
+{
+    __shared__ int32_t s_n[LFQ_PC_THREADS];
+    __shared__ unsigned long long s_o[LFQ_PC_THREADS];
+    __shared__ int32_t s_m[LFQ_PC_THREADS];
+    const int64_t p0 = (int64_t)blockIdx.x * LFQ_PC_TILE + (int64_t)threadIdx.x * LFQ_PC_ITEMS;
+    int32_t n = 0, mx = 0;
+    unsigned long long o = 0;
+    for (int i = 0; i < LFQ_PC_ITEMS; i++) {
+        const int64_t p = p0 + i;
+        if (p < width && cov[p] > 0) {
+            const int32_t b = nb[p];
+            n++;
+            o += (unsigned long long)b;
+            mx = max(mx, b);
+        }
+    }
+    s_m[threadIdx.x] = mx;
+    lfq_pc_block_scan(n, o, s_n, s_o);
+    for (int d = LFQ_PC_THREADS / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s_m[threadIdx.x] = max(s_m[threadIdx.x], s_m[threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == LFQ_PC_THREADS - 1) {
+        tile_cols[blockIdx.x] = n;
+        tile_obs[blockIdx.x] = o;
+    }
+    if (threadIdx.x == 0) {
+        tile_max[blockIdx.x] = s_m[0];
+    }
+}
+
+/* one block: exclusive scan of the tile sums in place; totals[0] = columns, [1] = observations, [2] = deepest column */
+__global__ __launch_bounds__(LFQ_PC_THREADS) void lfq_plp_compact_sums_kernel(int64_t ntiles, int64_t *__restrict__ tile_cols,
+                                                                             unsigned long long *__restrict__ tile_obs,
+                                                                             const int32_t *__restrict__ tile_max,
+                                                                             int64_t *__restrict__ totals)
+{
+    __shared__ int32_t s_n[LFQ_PC_THREADS];
+    __shared__ unsigned long long s_o[LFQ_PC_THREADS];
+    __shared__ int32_t s_m[LFQ_PC_THREADS];
+    int64_t base_n = 0;
+    unsigned long long base_o = 0;
+    int32_t mx = 0;
+    for (int64_t t0 = 0; t0 < ntiles; t0 += LFQ_PC_THREADS) {
+        const int64_t t = t0 + threadIdx.x;
+        const int32_t n_in = t < ntiles ? (int32_t)tile_cols[t] : 0;
+        const unsigned long long o_in = t < ntiles ? tile_obs[t] : 0ull;
+        if (t < ntiles) {
+            mx = max(mx, tile_max[t]);
+        }
+        int32_t n = n_in;
+        unsigned long long o = o_in;
+        lfq_pc_block_scan(n, o, s_n, s_o);
+        if (t < ntiles) {
+            tile_cols[t] = base_n + n - n_in;
+            tile_obs[t] = base_o + o - o_in;
+        }
+        base_n += s_n[LFQ_PC_THREADS - 1];
+        base_o += s_o[LFQ_PC_THREADS - 1];
+        __syncthreads();
+    }
+    s_m[threadIdx.x] = mx;
+    __syncthreads();
+    for (int d = LFQ_PC_THREADS / 2; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s_m[threadIdx.x] = max(s_m[threadIdx.x], s_m[threadIdx.x + d]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = base_n;
+        totals[1] = (int64_t)base_o;
+        totals[2] = s_m[0];
+    }
+}
+
+__global__ __launch_bounds__(LFQ_PC_THREADS) void lfq_plp_compact_apply_kernel(const int32_t *__restrict__ cov,
+                                                                              const int32_t *__restrict__ nb, int64_t width,
+                                                                              int64_t begin, const uint8_t *__restrict__ ref,
+                                                                              int64_t ref_len,
+                                                                              const int64_t *__restrict__ tile_cols,
+                                                                              const unsigned long long *__restrict__ tile_obs,
+                                                                              const int64_t *__restrict__ totals,
+                                                                              int32_t *__restrict__ col_index,
+                                                                              uint64_t *__restrict__ col_off,
+                                                                              uint8_t *__restrict__ ref_base,
+                                                                              int32_t *__restrict__ cov_c,
+                                                                              int32_t *__restrict__ nb_c,
+                                                                              int64_t *__restrict__ col_pos)
+{
+    __shared__ int32_t s_n[LFQ_PC_THREADS];
+    __shared__ unsigned long long s_o[LFQ_PC_THREADS];
+    const int64_t p0 = (int64_t)blockIdx.x * LFQ_PC_TILE + (int64_t)threadIdx.x * LFQ_PC_ITEMS;
+    int32_t n = 0;
+    unsigned long long o = 0;
+    for (int i = 0; i < LFQ_PC_ITEMS; i++) {
+        const int64_t p = p0 + i;
+        if (p < width && cov[p] > 0) {
+            n++;
+            o += (unsigned long long)nb[p];
+        }
+    }
+    const int32_t n_own = n;
+    const unsigned long long o_own = o;
+    lfq_pc_block_scan(n, o, s_n, s_o);
+    int64_t ci = tile_cols[blockIdx.x] + (n - n_own);
+    unsigned long long run = tile_obs[blockIdx.x] + (o - o_own);
+    for (int i = 0; i < LFQ_PC_ITEMS; i++) {
+        const int64_t p = p0 + i;
+        if (p >= width) {
+            break;
+        }
+        const int32_t cv = cov[p];
+        if (cv <= 0) {
+            col_index[p] = -1;
+            continue;
+        }
+        const int32_t b = nb[p];
+        const int64_t gp = begin + p;
+        uint8_t rb = gp < ref_len ? ref[gp] : (uint8_t)'N';                 /* plp.c:818-823 */
+        if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
+            rb = 'N';
+        }
+        col_index[p] = (int32_t)ci;
+        col_off[ci] = run;
+        ref_base[ci] = rb;
+        cov_c[ci] = cv;
+        nb_c[ci] = b;
+        col_pos[ci] = gp;
+        run += (unsigned long long)b;
+        ci++;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        col_off[totals[0]] = (uint64_t)totals[1];
+    }
+}
+
+int lfq_launch_plp_compact_sums(const int32_t *cov, const int32_t *nb, int64_t width, int64_t *tile_cols, uint64_t *tile_obs,
+                                int32_t *tile_max, int64_t *totals, void *stream)
+{
+    const int64_t ntiles = (width + LFQ_PC_TILE - 1) / LFQ_PC_TILE;
+    hipLaunchKernelGGL(lfq_plp_compact_tiles_kernel, dim3((unsigned)ntiles), dim3(LFQ_PC_THREADS), 0, (hipStream_t)stream, cov, nb,
+                       width, tile_cols, (unsigned long long *)tile_obs, tile_max);
+    hipLaunchKernelGGL(lfq_plp_compact_sums_kernel, dim3(1), dim3(LFQ_PC_THREADS), 0, (hipStream_t)stream, ntiles, tile_cols,
+                       (unsigned long long *)tile_obs, tile_max, totals);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}
+
+int lfq_launch_plp_compact_apply(const int32_t *cov, const int32_t *nb, int64_t width, int64_t begin, const uint8_t *ref,
+                                 int64_t ref_len, const int64_t *tile_cols, const uint64_t *tile_obs, const int64_t *totals,
+                                 int32_t *col_index, uint64_t *col_off, uint8_t *ref_base, int32_t *cov_c, int32_t *nb_c,
+                                 int64_t *col_pos, void *stream)
+{
+    const int64_t ntiles = (width + LFQ_PC_TILE - 1) / LFQ_PC_TILE;
+    hipLaunchKernelGGL(lfq_plp_compact_apply_kernel, dim3((unsigned)ntiles), dim3(LFQ_PC_THREADS), 0, (hipStream_t)stream, cov, nb,
+                       width, begin, ref, ref_len, tile_cols, (const unsigned long long *)tile_obs, totals, col_index, col_off,
+                       ref_base, cov_c, nb_c, col_pos);
+    return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
+}

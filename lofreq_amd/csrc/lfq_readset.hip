@@ -1000,7 +1000,6 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
         || (rs->n > 0 && (!rs->qual || !rs->mapq || !rs->reverse))) {
         return LFQ_ERR_INVALID;
     }
-    const lfq_readset *rd = rs;
     memset(out, 0, sizeof(*out));
     const int64_t n = rs->n, width = region_end - region_begin;
     if (n == 0 || width == 0) {
@@ -1010,8 +1009,10 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     LFQ_TRY(readset_upload_wait(rs, c->stream));
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
     /* per-position counters (kept until the next call) */
+    const int64_t n_tiles = (width + LFQ_PLP_COMPACT_TILE - 1) / LFQ_PLP_COMPACT_TILE;
     const int64_t o_cov = 0, o_nb = o_cov + al(width * 4), o_cur = o_nb + al(width * 4), o_cidx = o_cur + al(width * 4),
-                  total = o_cidx + al(width * 4);
+                  o_tcol = o_cidx + al(width * 4), o_tobs = o_tcol + al(n_tiles * 8), o_tmax = o_tobs + al(n_tiles * 8),
+                  o_tot = o_tmax + al(n_tiles * 4), o_cpos = o_tot + 256, total = o_cpos + al(width * 8);
     /* Everything goes to the main stream, behind the BAQ kernels if they are still running (the scatter pass reads their
      * lb bytes; pass 0 beside them was measured: 2 ms alone, 14 ms squeezed between wavefronts that hold 416 of a SIMD's
      * 512 registers, with the host waiting for its result).  Nothing waits for the scatter pass: the tracks are complete
@@ -1044,71 +1045,15 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.pmax_end = readset_pmax(c, rs, ps);
     const bool sorted = A.pmax_end != nullptr;
     LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, ps) : lfq_launch_pileup_count(A, ps));
-    /* prefix sums on the host: 8 bytes per reference position of the region, once per region */
-    LfqPin<int32_t> cov(c, (size_t)width), nb(c, (size_t)width), cidx(c, (size_t)width, -1);
-    LFQ_PIN_OK(cov);
-    LFQ_PIN_OK(nb);
-    LFQ_PIN_OK(cidx);
-    LFQ_TRY_HIP(hipMemcpyAsync(cov.data(), A.cov, (size_t)width * 4, hipMemcpyDeviceToHost, ps));
-    LFQ_TRY_HIP(hipMemcpyAsync(nb.data(), A.nb, (size_t)width * 4, hipMemcpyDeviceToHost, ps));
+    /* columns from the counters on the device (lfq_launch_plp_compact_*): the host waits once, for three numbers */
+    LfqPin<int64_t> tot(c, 4);
+    LFQ_PIN_OK(tot);
+    LFQ_TRY(lfq_launch_plp_compact_sums(A.cov, A.nb, width, (int64_t *)(d + o_tcol), (uint64_t *)(d + o_tobs),
+                                        (int32_t *)(d + o_tmax), (int64_t *)(d + o_tot), ps));
+    LFQ_TRY_HIP(hipMemcpyAsync(tot.data(), d + o_tot, 24, hipMemcpyDeviceToHost, ps));
     LFQ_TRY_HIP(hipStreamSynchronize(ps));
-    /* two passes over the positions, both split over a few threads: covered positions and bases per part, then every
-     * part fills its slice */
-    int64_t part_cols[LFQ_HOST_PARTS + 1] = {0}, part_obs[LFQ_HOST_PARTS + 1] = {0}, part_max[LFQ_HOST_PARTS] = {0};
-    int parts = 1;
-    lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
-        int64_t nc = 0, no = 0, mx = 0;
-        for (int64_t p = p0; p < p1; p++) {
-            if (cov[(size_t)p] > 0) {
-                nc++;
-                no += nb[(size_t)p];
-                mx = std::max<int64_t>(mx, nb[(size_t)p]);
-            }
-        }
-        part_cols[part + 1] = nc;
-        part_obs[part + 1] = no;
-        part_max[part] = mx;
-    }, &parts);
-    int64_t max_obs = 0;
-    for (int q = 0; q < parts; q++) {
-        part_cols[q + 1] += part_cols[q];
-        part_obs[q + 1] += part_obs[q];
-        max_obs = std::max(max_obs, part_max[q]);
-    }
-    LfqPin<uint64_t> off(c, (size_t)part_cols[parts] + 1);
-    LfqPin<int32_t> h_cov(c, (size_t)part_cols[parts]), h_nb(c, (size_t)part_cols[parts]);
-    LfqPin<uint8_t> h_ref(c, (size_t)part_cols[parts]);
-    LFQ_PIN_OK(off);
-    LFQ_PIN_OK(h_cov);
-    LFQ_PIN_OK(h_nb);
-    LFQ_PIN_OK(h_ref);
-    off[0] = 0;
-    lfq_for_reads(width, [&](int64_t p0, int64_t p1, int part) {
-        size_t ci = (size_t)part_cols[part];
-        uint64_t run = (uint64_t)part_obs[part];
-        for (int64_t p = p0; p < p1; p++) {
-            if (cov[(size_t)p] <= 0) {
-                continue;
-            }
-            cidx[(size_t)p] = (int32_t)ci;
-            if (col_pos_out) {
-                col_pos_out[ci] = region_begin + p;
-            }
-            h_cov[ci] = cov[(size_t)p];
-            h_nb[ci] = nb[(size_t)p];
-            const int64_t gp = region_begin + p;
-            char rb = (gp < rd->ref_len) ? rd->ref[gp] : 'N';           /* plp.c:818-823 */
-            if (!(rb == 'A' || rb == 'C' || rb == 'T' || rb == 'G' || rb == 'N')) {
-                rb = 'N';
-            }
-            h_ref[ci] = (uint8_t)rb;
-            run += (uint64_t)nb[(size_t)p];
-            off[ci + 1] = run;
-            ci++;
-        }
-    });
-    const int64_t ncols = (int64_t)h_cov.size();
-    const int64_t n_obs = (int64_t)off.back(), trk = al(n_obs + 32);
+    const int64_t ncols = tot[0], n_obs = tot[1], max_obs = tot[2];
+    const int64_t trk = al(n_obs + 32);
     const bool nt_packed = !c->plp_nt_bytes;
     const int64_t t_off = 0, t_ref = t_off + al((ncols + 1) * 8), t_cov = t_ref + al(ncols + 16), t_nb = t_cov + al(ncols * 4 + 16),
                   t_nt = t_nb + al(ncols * 4 + 16), t_bq = t_nt + trk, t_baq = t_bq + trk, t_mq = t_baq + trk,
@@ -1116,16 +1061,22 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     LFQ_TRY(grow(&c->d_plp_out, &c->plp_out_bytes, t_total));
     uint8_t *t = c->d_plp_out;
     LFQ_TRY_HIP(hipMemsetAsync(t + t_nt, 0, (size_t)(t_total - t_nt), ps));            /* the 16-byte tails are read */
-    LFQ_TRY_HIP(hipMemcpyAsync(t + t_off, off.data(), (size_t)(ncols + 1) * 8, hipMemcpyHostToDevice, ps));
-    if (ncols > 0) {
-        LFQ_TRY_HIP(hipMemcpyAsync(t + t_ref, h_ref.data(), (size_t)ncols, hipMemcpyHostToDevice, ps));
-        LFQ_TRY_HIP(hipMemcpyAsync(t + t_cov, h_cov.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, ps));
-        LFQ_TRY_HIP(hipMemcpyAsync(t + t_nb, h_nb.data(), (size_t)ncols * 4, hipMemcpyHostToDevice, ps));
+    LFQ_TRY(lfq_launch_plp_compact_apply(A.cov, A.nb, width, region_begin, rs->d_ref, rs->ref_len, (const int64_t *)(d + o_tcol),
+                                         (const uint64_t *)(d + o_tobs), (const int64_t *)(d + o_tot), (int32_t *)(d + o_cidx),
+                                         (uint64_t *)(t + t_off), t + t_ref, (int32_t *)(t + t_cov), (int32_t *)(t + t_nb),
+                                         (int64_t *)(d + o_cpos), ps));
+    /* the columns' positions for the caller: copied on the DP stream (idle here) behind the apply kernel, so that the wait
+     * for the copy below is not a wait for the scatter pass */
+    hipStream_t aux = (c->dps && !lfq_knobs().single_stream) ? c->dps : ps;
+    hipEvent_t ev_apply = nullptr;
+    if (col_pos_out && ncols > 0) {
+        LFQ_TRY_HIP(hipEventCreateWithFlags(&ev_apply, hipEventDisableTiming));
+        if (hipEventRecord(ev_apply, ps) != hipSuccess || (aux != ps && hipStreamWaitEvent(aux, ev_apply, 0) != hipSuccess)
+            || hipMemcpyAsync(col_pos_out, d + o_cpos, (size_t)ncols * 8, hipMemcpyDeviceToHost, aux) != hipSuccess) {
+            (void)hipEventDestroy(ev_apply);
+            return LFQ_ERR_HIP;
+        }
     }
-    LFQ_TRY_HIP(hipMemcpyAsync(d + o_cidx, cidx.data(), (size_t)width * 4, hipMemcpyHostToDevice, ps));
-    /* the pinned blocks these copies read go back to the pool when this function returns: they are waited for here (a
-     * few megabytes on a stream that carries nothing else); the scatter pass below touches no host memory */
-    LFQ_TRY_HIP(hipStreamSynchronize(ps));
     A.col_index = (const int32_t *)(d + o_cidx);
     A.col_off = (const uint64_t *)(t + t_off);
     A.t_nt = t + t_nt;
@@ -1139,7 +1090,14 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
          * pass writes bytes (two lanes, often of two wavefronts, would share a byte), one streaming pass packs them */
         LFQ_TRY(lfq_launch_pack_nt(t + t_nt, t + t_ntp, n_obs, c->stream));
     }
-    /* (no wait: what consumes the tracks -- lfq_call_snvs_batch, lfq_pileup_skip_snv_columns, the uniq calls -- is
+    if (ev_apply) {                                 /* the positions have landed in the caller's array */
+        const hipError_t e = hipStreamSynchronize(aux);
+        (void)hipEventDestroy(ev_apply);
+        if (e != hipSuccess) {
+            return LFQ_ERR_HIP;
+        }
+    }
+    /* (no wait for the tracks: what consumes them -- lfq_call_snvs_batch, lfq_pileup_skip_snv_columns, the uniq calls -- is
      * queued on the same stream; lfq_readset_destroy and lfq_synchronize wait for it) */
     out->nt = nt_packed ? t + t_ntp : t + t_nt;
     out->flags = nt_packed ? LFQ_TRACKS_NT_PACKED : 0;
