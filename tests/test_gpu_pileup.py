@@ -244,3 +244,54 @@ def test_tile_kernel_hard_reads_against_oracle_pileup(caller, oracle, begin, end
         for k in ("nt", "bq", "baq", "mq"):
             assert np.array_equal(got[k], h[k][:n_obs]), k
     assert n_obs > 20000 and int(np.diff(off.astype(np.int64)).max()) > 256      # more than one round of reads per tile
+
+
+@pytest.mark.parametrize("begin,end", [(0, 21000), (4095, 12289), (5000, 5001), (8200, 20500)])
+def test_columns_assembled_on_the_device_over_tiles_and_gaps(caller, oracle, begin, end):
+    """lfq_plp_compact_* (column index, offsets, reference bytes, compacted counts from the per-position counters): regions of
+    several 4096-position tiles that start and end inside tiles, with stretches no read covers (whole tiles among them) and
+    reference letters other than ACGT -- every column array and every track byte against the oracle's column builder"""
+    import lofreq_amd as la
+    rng = np.random.default_rng(77 + begin)
+    glen = 21000
+    g = rng.choice(list("ACGT"), glen)
+    g[rng.integers(0, glen, 300)] = rng.choice(list("NRYacgtn"), 300)     # plp.c:818-823: anything but ACGTN reads as N
+    genome = "".join(g).encode()
+    reads = []
+    for lo, hi, n in ((0, 3000, 300), (3900, 4300, 150), (9000, 9050, 40), (12280, 12300, 30), (16500, 20800, 500)):
+        for pos in np.sort(rng.integers(lo, hi, n)).tolist():
+            body = int(rng.integers(30, 150))
+            cigar = [("M", body)] if rng.random() < 0.8 else [("M", body // 2), ("D", int(rng.integers(1, 30))), ("M", body - body // 2)]
+            ql = sum(l for o, l in cigar if o in "MIS=X")
+            reads.append({"pos0": int(pos), "cigar": cigar, "seq": rng.integers(0, 5, ql).astype(np.uint8),
+                          "qual": rng.integers(0, 61, ql).astype(np.uint8), "mapq": int(rng.integers(0, 61)),
+                          "reverse": bool(rng.integers(0, 2)), "lb": rng.integers(33, 127, ql).astype(np.uint8)})
+    reads.sort(key=lambda r: r["pos0"])
+    reads = [r for r in reads if r["pos0"] + sum(l for o, l in r["cigar"] if o in "MDN=X") <= glen]
+    caller.set_pileup_nt_packed(False)
+    try:
+        dt = la.pileup_snv_tracks(caller, reads, genome, begin, end, lb=[r["lb"] for r in reads], min_plp_bq=3)
+        t = dt._tracks()
+        ncols = dt.ncols
+        off = _fetch(t.col_off, (ncols + 1) * 8).view(np.uint64)
+        n_obs = int(off[-1])
+        got = {k: _fetch(p, max(n_obs, 1))[:n_obs] for k, p in (("nt", t.nt), ("bq", t.bq), ("baq", t.baq), ("mq", t.mq))}
+        cov = _fetch(t.coverage_plp, max(ncols, 1) * 4).view(np.int32)[:ncols]
+        nb = _fetch(t.num_bases, max(ncols, 1) * 4).view(np.int32)[:ncols]
+        ref = _fetch(t.ref_base, max(ncols, 1))[:ncols]
+        col_pos = np.asarray(dt.col_pos[:ncols])
+        max_obs = int(t.max_col_obs)
+    finally:
+        caller.set_pileup_nt_packed(True)
+    out = oracle.pileup_region(oracle.pack_reads(reads, genome), begin, end, min_plp_bq=3, use_baq=True)
+    h = out["host"]
+    assert ncols == len(out["col_pos"]) and np.array_equal(col_pos, out["col_pos"])
+    assert np.array_equal(off, h["col_off"])
+    assert np.array_equal(cov, h["coverage_plp"]) and np.array_equal(nb, h["num_bases"])
+    assert np.array_equal(ref, np.frombuffer(bytes(h["ref_base"][:ncols]), dtype=np.uint8))
+    assert max_obs == (int(nb.max()) if ncols else 0)
+    if not os.environ.get("LFQ_PILEUP_ATOMIC"):
+        for k in ("nt", "bq", "baq", "mq"):
+            assert np.array_equal(got[k], h[k][:n_obs]), k
+    if end - begin > 1:
+        assert 0 < ncols < end - begin                  # gaps inside the region
