@@ -25,7 +25,8 @@ def _compare_records(la, recs, ores, host, tol=None):      # None: per record, 1
                                  n_obs=int(host["col_off"][c + 1] - host["col_off"][c]))
 
 
-@pytest.mark.parametrize("seed,depth_lo,depth_hi,ncols", [(1, 0, 300, 400), (2, 900, 1100, 200), (3, 1, 70, 300)])
+@pytest.mark.parametrize("seed,depth_lo,depth_hi,ncols", [(1, 0, 300, 400), (2, 900, 1100, 200), (3, 1, 70, 300),
+                                                         (4, 2500, 4000, 60), (5, 250, 320, 200)])      # several rounds of the shared-wavefront count kernel
 def test_default_conf_random(caller, oracle, seed, depth_lo, depth_hi, ncols):
     import lofreq_amd as la
     rng = np.random.default_rng(seed)
@@ -584,7 +585,7 @@ def test_approx_threshold_gate(caller, oracle, thr, kw):
     assert caller.dp_work()["n_approx_pruned"] == 0 and len(recs_hi) == len(recs_off)
 
 
-@pytest.mark.parametrize("depth", [150, 600, 1000])
+@pytest.mark.parametrize("depth", [150, 300, 600, 1000, 3000])
 def test_sparse_dense_entries(oracle, depth):
     """lfq_set_dense_counts(0): the shared-wavefront count kernel stores the dense entry of a TESTED column only -- those
     bit-identical to the dense run, the others untouched (a sentinel survives) --, class flags, work lists and the sparse
