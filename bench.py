@@ -85,9 +85,10 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the host-abi / chain measurements of config.secondary")
     ap.add_argument("--nt-bytes", action="store_true",
                     help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
-    ap.add_argument("--in-flight", type=int, default=1, choices=[1, 2],
-                    help="N = 1, pipelined loop: batches whose kernels may be on the GPU at the same time (2: the count "
-                         "kernel of batch k + 1 beside the DP kernels of batch k; 1: one batch's kernels at a time)")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="pipelined loop: batches whose kernels may be on the GPU at the same time (2: batch k + 1 is "
+                         "submitted before batch k is waited for, its count kernel starts when batch k is past its row-bound "
+                         "DP kernels; 1: one batch's kernels at a time; 0 = default: the warm-up times both and keeps the faster)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: one context, every step waits for its own host finish before the next batch is launched "
                          "(default: two contexts; the host finish of step k runs under the kernels of step k + 1)")
@@ -1165,10 +1166,12 @@ def main():
                 callers[k % 2].call_snvs_wait()
             # (layer 1: lfq_batch_finish waits for the batch's event itself)
 
+        in_flight = {"n": args.in_flight or 1, "note": "as given" if args.in_flight else None}
+
         def run_steps(n):
             acc = None
             out = None
-            if args.in_flight >= 2:
+            if in_flight["n"] >= 2:
                 # two batches in flight: batch k + 1 is launched BEFORE batch k is waited for, so its count kernel
                 # (HBM-bound, on the main stream) runs beside the DP kernels of batch k (issue-bound, high-priority
                 # streams); n submits and n finishes, every batch complete inside the timed region
@@ -1194,6 +1197,25 @@ def main():
             return out, acc
 
         run_steps(max(args.warmup, 2))              # both contexts warm (workspace allocations)
+        if not args.in_flight:
+            # how many batches to keep in flight is the caller's choice and depends on the shape (two pay where the DP tail is
+            # short latency-bound work next to a short count kernel: 1000x; not at 10 000x, where the count kernel of the
+            # next batch slows the folds of this one by more than it gains): measured here, outside the timed region
+            trial = {}
+            for m in (1, 2, 1, 2):
+                in_flight["n"] = m
+                torch.cuda.synchronize(dev)
+                t0_ = time.perf_counter()
+                run_steps(12)
+                torch.cuda.synchronize(dev)
+                trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0_) / 12)
+            if world > 1:                           # one choice for all ranks
+                tt = torch.tensor([trial[1], trial[2]], dtype=torch.float64, device=xdev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                trial = {1: float(tt[0]), 2: float(tt[1])}
+            in_flight["n"] = 2 if trial[2] < 0.97 * trial[1] else 1
+            in_flight["note"] = "chosen in the warm-up: %.3f ms per step with one batch in flight, %.3f with two" % (
+                1e3 * trial[1], 1e3 * trial[2])
 
     def timed_block():
         """EXACTLY --steps steps between two barrier + synchronize pairs -> (seconds: max over ranks, last step, kernel times)"""
@@ -1283,7 +1305,8 @@ def main():
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
-                "pipeline": "two contexts: host finish of step k under the kernels of step k + 1" if pipelined else "none",
+                "pipeline": ("two contexts: host finish of step k under the kernels of step k + 1; batches in flight: %d (%s)"
+                             % (in_flight["n"], in_flight["note"])) if pipelined else "none",
                 "host_ms_per_step_not_hidden": ms_per_step - kt["ms_total"],
             },
             "roofline": {

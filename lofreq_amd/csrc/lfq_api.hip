@@ -17,6 +17,11 @@ namespace {
  * (lfq_call_snvs_wait) wants anyway.  Completion is tracked per context with events, never by draining a stream. */
 struct LfqDeviceStreams {
     hipStream_t stream = nullptr, dps = nullptr, side[2] = {nullptr, nullptr};
+    /* "the last batch on this device is past its row-bound kernels" (lfq_batch_device_impl: behind the segment kernels of
+     * the big and mid chains and behind the light chain): what the NEXT batch's count kernel waits for when its batch was
+     * submitted while that one was still running */
+    hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};
+    bool tail_recorded = false;
     int refs = 0;
 };
 std::mutex g_streams_m;
@@ -167,6 +172,10 @@ bool acquire_streams(int device, lfq_ctx *c)
         for (int i = 0; ok && i < 2; i++) {
             ok = hipStreamCreateWithPriority(&d.side[i], hipStreamNonBlocking, prio_hi) == hipSuccess;
         }
+        for (int i = 0; ok && i < 3; i++) {
+            ok = hipEventCreateWithFlags(&d.ev_tail[i], hipEventDisableTiming) == hipSuccess;
+        }
+        d.tail_recorded = false;
         if (!ok) {
             return false;
         }
@@ -189,8 +198,42 @@ void release_streams(int device)
         for (int i = 0; i < 2; i++) {
             if (d.side[i]) (void)hipStreamDestroy(d.side[i]);
         }
+        for (int i = 0; i < 3; i++) {
+            if (d.ev_tail[i]) (void)hipEventDestroy(d.ev_tail[i]);
+        }
         d = LfqDeviceStreams();
     }
+}
+
+/* the shared tail events of the context's device: make `st` wait for the previous batch's / record this batch's */
+int tail_wait(lfq_ctx *c, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_streams_m);
+    LfqDeviceStreams &d = g_streams[c->device];
+    static const bool off = getenv("LFQ_NO_TAIL_WAIT") != nullptr;     /* A/B: the count kernel starts as soon as the previous one ends */
+    if (c->stream != d.stream || !d.tail_recorded || off) {
+        return LFQ_OK;
+    }
+    for (int i = 0; i < 3; i++) {
+        if (hipStreamWaitEvent(st, d.ev_tail[i], 0) != hipSuccess) {
+            return LFQ_ERR_HIP;
+        }
+    }
+    return LFQ_OK;
+}
+
+int tail_record(lfq_ctx *c, int i, hipStream_t on)
+{
+    std::lock_guard<std::mutex> lk(g_streams_m);
+    LfqDeviceStreams &d = g_streams[c->device];
+    if (c->stream != d.stream) {
+        return LFQ_OK;
+    }
+    if (hipEventRecord(d.ev_tail[i], on) != hipSuccess) {
+        return LFQ_ERR_HIP;
+    }
+    d.tail_recorded = true;
+    return LFQ_OK;
 }
 
 void fill_luts(LfqLuts *L)
@@ -535,6 +578,11 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
     }
     c->cur_col_bytes = 8 + 1 + (T.coverage_plp ? 4 : 0) + (T.num_bases ? 4 : 0) + (P.detlim_af ? 4 : 0);
     LFQ_TRY(lfq_order_after_batch(c, st));
+    /* a batch submitted while the device's previous one (another context's) is still running starts its count kernel when
+     * that one is past its row-bound kernels: the count kernel streams through HBM beside the folds, combines and retries of
+     * the other batch -- a few hundred wavefronts of LDS and FP64 work -- not beside its segment and screen kernels, which
+     * it would slow down by as much as it gains (profiles/NOTES.md, two batches in flight) */
+    LFQ_TRY(tail_wait(c, st));
     LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
     if (ncols > 0) {
         LFQ_TRY_HIP(hipMemsetAsync(c->d_retry, 0, (size_t)ncols, st));
@@ -679,6 +727,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         if (run_big) {
             LFQ_TRY(lfq_launch_dp_seg(1, T, P, c->d_luts, W, c->n_cu * 8, side0));
             LFQ_DBG_STAGE("seg big");
+            LFQ_TRY(tail_record(c, 0, side0));
             LFQ_TRY(lfq_launch_dp_combine(1, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side0));
             LFQ_DBG_STAGE("combine big");
             if (!big_on_st) {
@@ -691,6 +740,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         if (run_mid || run_big) {
             LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, side1));
             LFQ_DBG_STAGE("seg mid");
+            LFQ_TRY(tail_record(c, 1, side1));
             LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side1));
             LFQ_DBG_STAGE("combine mid");
         }
@@ -704,6 +754,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
             }
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], dps));
+        LFQ_TRY(tail_record(c, 2, dps));
         for (int i = 0; i < 2; i++) {
             LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][1], side_i[i]));
         }
