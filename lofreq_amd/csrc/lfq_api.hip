@@ -210,8 +210,7 @@ int tail_wait(lfq_ctx *c, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_streams_m);
     LfqDeviceStreams &d = g_streams[c->device];
-    static const bool off = getenv("LFQ_NO_TAIL_WAIT") != nullptr;     /* A/B: the count kernel starts as soon as the previous one ends */
-    if (c->stream != d.stream || !d.tail_recorded || off) {
+    if (c->stream != d.stream || !d.tail_recorded) {
         return LFQ_OK;
     }
     for (int i = 0; i < 3; i++) {

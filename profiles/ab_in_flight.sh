@@ -1,3 +1,5 @@
+# one batch in flight / two (the second one's count kernel gated on the first one's DP tail) / two, ungated -- the last
+# variant needs a build with the A/B switch LFQ_NO_TAIL_WAIT in tail_wait() (lfq_api.hip), which was removed after this run
 for cfg in "--config C2" "--cols 3750000 --depth 200" "--cols 4600000 --depth 500" "--config C3 --steps 60"; do
   for v in "1 X=0" "2 X=0" "2 LFQ_NO_TAIL_WAIT=1"; do
     set -- $v
