@@ -89,6 +89,10 @@ def parse_args():
                     help="pipelined loop: batches whose kernels may be on the GPU at the same time (2: batch k + 1 is "
                          "submitted before batch k is waited for, its count kernel starts when batch k is past its row-bound "
                          "DP kernels; 1: one batch's kernels at a time; 0 = default: the warm-up times both and keeps the faster)")
+    ap.add_argument("--gate", choices=["auto", "tail", "end", "none"], default="auto",
+                    help="with two batches in flight: what the second one's count kernel waits for on the device "
+                         "(lfq_set_batch_gate): the first one's row-bound DP kernels (tail), all of its kernels (end: batch "
+                         "after batch with no host round trip between them), nothing (none); auto = timed in the warm-up")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: one context, every step waits for its own host finish before the next batch is launched "
                          "(default: two contexts; the host finish of step k runs under the kernels of step k + 1)")
@@ -218,6 +222,12 @@ def live_pmc(child_args, count_kernel):
     f = pmc_pass("FETCH_SIZE", child_args)
     w = pmc_pass("WRITE_SIZE", child_args) if f is not None else None
     v = pmc_pass("SQ_INSTS_VALU", child_args) if f is not None else None
+    if f and count_kernel not in f:
+        # the instantiation's template arguments as the runtime names them (the caller knows the family, not the spelling)
+        fam = [k for k in f if k.startswith(count_kernel.split("<")[0] + "<")]
+        if len(fam) == 1:
+            count_kernel = fam[0]
+    out["kernel"] = count_kernel
     if f and w and count_kernel in f and count_kernel in w:
         fk, n = f[count_kernel]
         wk, _ = w[count_kernel]
@@ -1123,10 +1133,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # N = 1: the layer-2 call in its two halves on two contexts (lfq_call_snvs_submit / _wait / _collect): when the
-    # kernels of step k are done, step k + 1 is launched on the other context and only then step k is finished on
-    # the host (sparse D2H, exact emit test, strand bias, filter, VCF text).  Every step still does all of its work
-    # inside the timed region; the two steps' kernels never run at the same time.
+    # N = 1: the layer-2 call in its two halves on two contexts (lfq_call_snvs_submit / _wait / _collect): the host
+    # finish of step k (sparse D2H, exact emit test, strand bias, filter, VCF text) runs under the kernels of step k + 1.
+    # Every step still does all of its work inside the timed region.  Whether step k + 1 is submitted after the kernels
+    # of step k are done (one batch in flight) or before (two; its count kernel then gated on the device), and whether
+    # the two steps' kernels ever run at the same time (gates "tail" / "none") or not ("end"), is in_flight below.
     pipelined = my_bins is None and not args.no_pipeline
     layer2 = world == 1 and not args.shard_path
     if pipelined:
@@ -1166,15 +1177,27 @@ def main():
                 callers[k % 2].call_snvs_wait()
             # (layer 1: lfq_batch_finish waits for the batch's event itself)
 
-        in_flight = {"n": args.in_flight or 1, "note": "as given" if args.in_flight else None}
+        # how the loop keeps the device fed: `n` batches in flight and, with two, what the second one's count kernel waits for
+        # on the device (lfq_set_batch_gate)
+        in_flight = {"n": args.in_flight or 1, "gate": args.gate if args.gate != "auto" else "tail",
+                     "note": "as given" if args.in_flight else None}
+
+        def set_mode(n, gate):
+            in_flight["n"], in_flight["gate"] = n, gate
+            for c_ in callers:
+                c_.set_batch_gate(gate)
+
+        set_mode(in_flight["n"], in_flight["gate"])
 
         def run_steps(n):
             acc = None
             out = None
             if in_flight["n"] >= 2:
-                # two batches in flight: batch k + 1 is launched BEFORE batch k is waited for, so its count kernel
-                # (HBM-bound, on the main stream) runs beside the DP kernels of batch k (issue-bound, high-priority
-                # streams); n submits and n finishes, every batch complete inside the timed region
+                # two batches in flight: batch k + 1 is launched BEFORE batch k is waited for; n submits and n finishes,
+                # every batch complete inside the timed region.  Gate "end": its count kernel starts when batch k's last
+                # kernel is done (an event on the device, no host latency between the batches; one batch's kernels at a
+                # time); "tail": when batch k is past its row-bound DP kernels (it runs beside the folds and the join);
+                # "none": as soon as the count kernel of batch k is done (beside all of batch k's DP kernels)
                 confs = {0: submit(0)}
                 if n > 1:
                     confs[1] = submit(1)
@@ -1197,25 +1220,35 @@ def main():
             return out, acc
 
         run_steps(max(args.warmup, 2))              # both contexts warm (workspace allocations)
-        if not args.in_flight:
-            # how many batches to keep in flight is the caller's choice and depends on the shape (two pay where the DP tail is
-            # short latency-bound work next to a short count kernel: 1000x; not at 10 000x, where the count kernel of the
-            # next batch slows the folds of this one by more than it gains): measured here, outside the timed region
+        if not args.in_flight or (args.in_flight == 2 and args.gate == "auto"):
+            # how many batches to keep in flight, and gated how, is the caller's choice and depends on the shape (overlap pays
+            # where the DP tail is short latency-bound work next to a short count kernel: 1000x; the device-side gate at the
+            # end of the previous batch takes the host's wake-up + launch latency out of every step): measured here,
+            # outside the timed region
+            modes = [(2, "tail"), (2, "end"), (2, "none")] if args.in_flight == 2 else \
+                    [(1, "tail"), (2, "tail"), (2, "end"), (2, "none")]
             trial = {}
-            for m in (1, 2, 1, 2):
-                in_flight["n"] = m
+            for m in modes + modes:
+                set_mode(*m)
+                run_steps(2)
                 torch.cuda.synchronize(dev)
                 t0_ = time.perf_counter()
                 run_steps(12)
                 torch.cuda.synchronize(dev)
                 trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0_) / 12)
             if world > 1:                           # one choice for all ranks
-                tt = torch.tensor([trial[1], trial[2]], dtype=torch.float64, device=xdev)
+                tt = torch.tensor([trial[m] for m in modes], dtype=torch.float64, device=xdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                trial = {1: float(tt[0]), 2: float(tt[1])}
-            in_flight["n"] = 2 if trial[2] < 0.97 * trial[1] else 1
-            in_flight["note"] = "chosen in the warm-up: %.3f ms per step with one batch in flight, %.3f with two" % (
-                1e3 * trial[1], 1e3 * trial[2])
+                trial = {m: float(tt[i]) for i, m in enumerate(modes)}
+            # (a mode has to beat the one before it in the list by 1 % to be taken: ties go to the simpler loop)
+            best = modes[0]
+            for m in modes[1:]:
+                if trial[m] < 0.99 * trial[best]:
+                    best = m
+            set_mode(*best)
+            in_flight["note"] = "chosen in the warm-up: " + ", ".join(
+                "%.3f ms per step with %s" % (1e3 * trial[m], "one batch in flight" if m[0] == 1 else "two, gate " + m[1])
+                for m in modes)
 
     def timed_block():
         """EXACTLY --steps steps between two barrier + synchronize pairs -> (seconds: max over ranks, last step, kernel times)"""
@@ -1252,7 +1285,10 @@ def main():
         n_launch = max(int(round(kt["n_segments"])), 1)       # count-kernel launches per step
         # Dominant kernel = the one with the largest duration per step: the count kernel (one launch, HBM-bound).
         # The DP kernels run concurrently on three streams; their span is the `dp` block below.
-        count_name = "lfq_count_kernel<%s, false>" % ("false" if args.nt_bytes else "true")
+        # (packed nt, lazy strand counts, one BQ threshold, 4 columns per workgroup; LFQ_COUNT_PERSIST: the resident form)
+        count_name = ("lfq_count_persist_kernel<%s, false, true>" if os.environ.get("LFQ_COUNT_PERSIST", "0") not in ("", "0")
+                      else "lfq_count_fast_kernel<%s, false, true, " + os.environ.get("LFQ_COUNT_WAVES_PER_WG", "4") + ">") % (
+                          "false" if args.nt_bytes else "true")
         if depth < 4096:
             lpg = 4 if depth <= 320 else 8 if depth <= 900 else 16     # lfq_launch_count's choice at the default knobs
             count_name = ("lfq_count_multi_kernel<false, false, %d>" if args.nt_bytes else "lfq_count_shallow_kernel<false, %d>") % lpg
@@ -1271,6 +1307,8 @@ def main():
                 child += ["--nt-bytes"]
             pmc = live_pmc(child, count_name)
         traffic = pmc["traffic"] if pmc else None
+        if pmc and pmc.get("kernel"):
+            count_name = pmc["kernel"]
         dp_ms = kt["ms_dp"]
         valu_busy = None
         if pmc and pmc.get("valu_insts_dp") and dp_ms > 0:
@@ -1305,9 +1343,17 @@ def main():
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
-                "pipeline": ("two contexts: host finish of step k under the kernels of step k + 1; batches in flight: %d (%s)"
-                             % (in_flight["n"], in_flight["note"])) if pipelined else "none",
-                "host_ms_per_step_not_hidden": ms_per_step - kt["ms_total"],
+                "pipeline": ("two contexts: host finish of step k under the kernels of step k + 1; batches in flight: %d%s (%s)"
+                             % (in_flight["n"], "" if in_flight["n"] == 1 else ", gate " + in_flight["gate"], in_flight["note"]))
+                            if pipelined else "none",
+                "batches_in_flight": in_flight["n"] if pipelined else 1,
+                "batch_gate": (in_flight["gate"] if in_flight["n"] == 2 else None) if pipelined else None,
+                # with two batches in flight and a gate other than "end" the kernels of consecutive steps overlap: the
+                # per-step kernel times then sum to more than the step, and ms_step - ms_kernels is not a host time
+                "kernel_times_overlap": bool(pipelined and in_flight["n"] == 2 and in_flight["gate"] != "end"),
+                "ms_kernels": kt["ms_total"],
+                "host_ms_per_step_not_hidden": (ms_per_step - kt["ms_total"])
+                                               if not (pipelined and in_flight["n"] == 2 and in_flight["gate"] != "end") else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": count_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1357,6 +1403,14 @@ def main():
                                                                 depth, my_cols, cfg_filter, recs, text)
             except Exception as e:
                 line["config"]["vcf_concordance"] = {"error": repr(e), "identical": False}
+        # the concordance of the timed batch once more as scalars (a reader that keeps only scalar fields of `config` still
+        # sees what was compared and whether it was identical)
+        vc = line["config"].get("vcf_concordance") or {}
+        line["config"]["vcf_identical"] = vc.get("identical")
+        line["config"]["records_compared"] = vc.get("records_compared", vc.get("gpu_records"))
+        line["config"]["columns_compared"] = vc.get("columns_compared", vc.get("sample_columns"))
+        line["config"]["max_dlogp_upto_600"] = vc.get("max_dlogp_upto_600")
+        line["config"]["max_dlogp_beyond_600"] = vc.get("max_dlogp_beyond_600")
         if world == 1 and not args.no_secondary:
             sec = {}
             try:

@@ -37,7 +37,8 @@ extern "C" {
 /* 2: lfq_conf grew to 80 bytes (approx_threshold_n), lfq_dp_work gained n_approx_pruned, lfq_filter_records_ex.
  * A caller compiled against another version must not run: compare lfq_abi_version() with this value once, as the
  * bindings in integration/ and the Python loader do. */
-#define LFQ_ABI_VERSION 3
+/* 4: lfq_set_batch_gate; lfq_call_snvs_collect refuses h_counts for a batch whose dense entries are sparse. */
+#define LFQ_ABI_VERSION 4
 
 typedef enum lfq_status {
     LFQ_OK = 0,
@@ -451,7 +452,8 @@ int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
  * whatever it held there (the shared-wavefront count kernel, i.e. batches of the packed nt layout whose deepest column has at
  * most a few thousand observations, skips those stores; at 200x the dense entries are a fifth of the bytes it moves, at the
  * price HBM asks for writes among reads).  Takes effect only together with lfq_set_dense_strand_counts(ctx, 0).
- * Default: on = 1.  (lfq_call_snvs_batch / _submit without h_counts use the context's own array and always run this way.) */
+ * Default: on = 1.  (lfq_call_snvs_batch without h_counts runs this way by itself on the context's own array;
+ * lfq_call_snvs_submit only after lfq_set_dense_counts(ctx, 0), and lfq_call_snvs_collect then refuses h_counts.) */
 int lfq_set_dense_counts(lfq_ctx *ctx, int on);
 
 /* The profile HMM's gap-open and gap-extension probabilities, kpa_ext_par_t.d / .e (kprobaln_ext.h:31-34), for every
@@ -478,6 +480,21 @@ int lfq_call_snvs_submit(lfq_ctx *ctx, const lfq_conf *conf, const lfq_tracks *t
  * wait(A); submit(B, next batch); collect(A) -- the host finish of batch k runs under the kernels of batch k + 1,
  * and the two batches' kernels never compete for the same CUs. */
 int lfq_call_snvs_wait(lfq_ctx *ctx);
+/* What the count kernel of this context's NEXT batch waits for on the device when the previous batch of the same GPU (any
+ * context) is still running -- only matters to a caller that submits batch k + 1 before it waits for batch k:
+ *   LFQ_GATE_TAIL  (default) that batch is past its row-bound DP kernels: the count kernel runs beside its folds, combines
+ *                  and join (pays where the DP tail is long next to a short count kernel: 1000x);
+ *   LFQ_GATE_END   all of that batch's kernels are done: batch after batch on the device with no host round trip between
+ *                  them -- `submit(k + 1); wait(k); collect(k)` then hides every host latency without putting two batches'
+ *                  kernels on the machine at once (the loop of lofreq_call.c:735-879 has no such gap to hide: it is serial);
+ *   LFQ_GATE_NONE  nothing: it starts as soon as its stream is free.
+ * Results do not depend on the choice.  LFQ_ERR_INVALID for another value. */
+#define LFQ_GATE_TAIL 0
+#define LFQ_GATE_END 1
+#define LFQ_GATE_NONE 2
+int lfq_set_batch_gate(lfq_ctx *ctx, int gate);
+/* h_counts_or_null: the dense entries, ncols of them.  Needs a batch whose dense entries are complete: LFQ_ERR_INVALID when
+ * the batch was submitted after lfq_set_dense_counts(ctx, 0) (the entries of its untested columns were never written). */
 int lfq_call_snvs_collect(lfq_ctx *ctx, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,
                           int64_t *n_records, lfq_col_counts *h_counts_or_null, lfq_batch_stats *stats_out);
 

@@ -315,8 +315,15 @@ static int ensure_ctx(lfq_colbatch *b)
         /* one `lofreq call -r <bin>` per worker of the parallel wrapper (lofreq2_call_pparallel.py:640-667): each
          * process takes a GPU of its own -- LFQ_DEVICE, LOCAL_RANK, or the first free worker slot of the node */
         const int dev = lfq_pick_device(0, NULL);
+        int rc;
         if (dev < 0) return LFQ_ERR_NO_DEVICE;
-        return lfq_create(&b->ctx, dev);
+        rc = lfq_create(&b->ctx, dev);
+        if (rc != LFQ_OK) return rc;
+        /* only the records are read here, never the dense per-column entries: strand counts where a record comes out
+         * (DP4 / SB, lofreq_call.c:117-129) and no entries for untested columns */
+        rc = lfq_set_dense_strand_counts(b->ctx, 0);
+        if (rc == LFQ_OK) rc = lfq_set_dense_counts(b->ctx, 0);
+        return rc;
     }
     return LFQ_OK;
 }

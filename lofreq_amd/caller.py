@@ -164,6 +164,12 @@ class SnvCaller:
         """lfq_set_dense_counts: off = snv_batch_device may leave the dense entries of untested columns unwritten"""
         _lib.check(self.L.lfq_set_dense_counts(self.h, 1 if on else 0), "lfq_set_dense_counts")
 
+    GATES = {"tail": 0, "end": 1, "none": 2}       # LFQ_GATE_TAIL / _END / _NONE (include/lofreq_amd.h)
+
+    def set_batch_gate(self, gate):
+        """lfq_set_batch_gate: what this context's next count kernel waits for when the device's previous batch still runs"""
+        _lib.check(self.L.lfq_set_batch_gate(self.h, self.GATES[gate]), "lfq_set_batch_gate")
+
     def set_dense_strand_counts(self, on):
         """lfq_set_dense_strand_counts: off = strand counts only for the columns of the sparse output (layer 1, submit)"""
         _lib.check(self.L.lfq_set_dense_strand_counts(self.h, 1 if on else 0), "lfq_set_dense_strand_counts")

@@ -22,6 +22,11 @@ struct LfqDeviceStreams {
      * submitted while that one was still running */
     hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};
     bool tail_recorded = false;
+    /* "the last batch on this device is done with its kernels" (behind the join and the strand kernel of the sparse
+     * records, in front of the small copies to pinned memory): what the next batch's count kernel waits for under
+     * LFQ_GATE_END -- batches one after another on the device with no host round trip between them */
+    hipEvent_t ev_end = nullptr;
+    bool end_recorded = false;
     int refs = 0;
 };
 std::mutex g_streams_m;
@@ -175,7 +180,9 @@ bool acquire_streams(int device, lfq_ctx *c)
         for (int i = 0; ok && i < 3; i++) {
             ok = hipEventCreateWithFlags(&d.ev_tail[i], hipEventDisableTiming) == hipSuccess;
         }
+        ok = ok && hipEventCreateWithFlags(&d.ev_end, hipEventDisableTiming) == hipSuccess;
         d.tail_recorded = false;
+        d.end_recorded = false;
         if (!ok) {
             return false;
         }
@@ -201,6 +208,7 @@ void release_streams(int device)
         for (int i = 0; i < 3; i++) {
             if (d.ev_tail[i]) (void)hipEventDestroy(d.ev_tail[i]);
         }
+        if (d.ev_end) (void)hipEventDestroy(d.ev_end);
         d = LfqDeviceStreams();
     }
 }
@@ -210,7 +218,16 @@ int tail_wait(lfq_ctx *c, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_streams_m);
     LfqDeviceStreams &d = g_streams[c->device];
-    if (c->stream != d.stream || !d.tail_recorded) {
+    if (c->stream != d.stream || c->batch_gate == LFQ_GATE_NONE) {
+        return LFQ_OK;
+    }
+    if (c->batch_gate == LFQ_GATE_END) {
+        if (d.end_recorded && hipStreamWaitEvent(st, d.ev_end, 0) != hipSuccess) {
+            return LFQ_ERR_HIP;
+        }
+        return LFQ_OK;
+    }
+    if (!d.tail_recorded) {
         return LFQ_OK;
     }
     for (int i = 0; i < 3; i++) {
@@ -232,6 +249,20 @@ int tail_record(lfq_ctx *c, int i, hipStream_t on)
         return LFQ_ERR_HIP;
     }
     d.tail_recorded = true;
+    return LFQ_OK;
+}
+
+int end_record(lfq_ctx *c, hipStream_t on)
+{
+    std::lock_guard<std::mutex> lk(g_streams_m);
+    LfqDeviceStreams &d = g_streams[c->device];
+    if (c->stream != d.stream) {
+        return LFQ_OK;
+    }
+    if (hipEventRecord(d.ev_end, on) != hipSuccess) {
+        return LFQ_ERR_HIP;
+    }
+    d.end_recorded = true;
     return LFQ_OK;
 }
 
@@ -368,7 +399,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     c->own_streams = ok ? 1 : 0;
     ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
     /* counter blocks: one per segment + one batch-wide */
-    ok = ok && hipMalloc((void **)&c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_counters, ((LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS + LFQ_COUNT_HEADS * 32) * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t) + 16,
                              hipHostMallocDefault) == hipSuccess;      /* + first / last CSR offset (lfq_batch_finish) */
     for (int i = 0; ok && i < 4; i++) {
@@ -537,9 +568,10 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
     LFQ_TRY(lfq_make_params(conf, tr, &P, indel_mode));
     P.detlim_af = indel_mode ? nullptr : c->detlim_af;      /* set only inside lfq_uniq_detlim_batch */
     P.lazy_strand = (c->lazy_now && !indel_mode && !P.general && !P.detlim_af) ? 1 : 0;
-    /* the context's own dense array (layer 2 without h_counts): nobody sees the entries of untested columns; a caller's
-     * array: only if it said so (lfq_set_dense_counts) */
-    P.sparse_counts = (P.lazy_strand && (d_counts == c->d_counts || !c->dense_counts)) ? 1 : 0;
+    /* the context's own dense array inside lfq_call_snvs_batch without h_counts: nobody sees the entries of untested
+     * columns; otherwise (a caller's array, or a submit whose collect may still ask for h_counts) only if the caller said
+     * so (lfq_set_dense_counts) */
+    P.sparse_counts = (P.lazy_strand && ((d_counts == c->d_counts && c->lazy_forced) || !c->dense_counts)) ? 1 : 0;
     P.pad_ = 0;
     /* -t (snpcaller.c:1131); lofreq uniq hands snpcaller -1 (lofreq_uniq.c:311-312) */
     P.approx_n = (!P.detlim_af && conf->approx_threshold_n > 0) ? conf->approx_threshold_n : 0;
@@ -582,7 +614,8 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
      * the other batch -- a few hundred wavefronts of LDS and FP64 work -- not beside its segment and screen kernels, which
      * it would slow down by as much as it gains (profiles/NOTES.md, two batches in flight) */
     LFQ_TRY(tail_wait(c, st));
-    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
+    /* (the batch's counters and, behind them, the work heads of the resident count kernel) */
+    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, ((LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS + LFQ_COUNT_HEADS * 32) * sizeof(int32_t), st));
     if (ncols > 0) {
         LFQ_TRY_HIP(hipMemsetAsync(c->d_retry, 0, (size_t)ncols, st));
     }
@@ -647,7 +680,8 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         W.unsplit = c->d_unsplit + c0;
 
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
-        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st));
+        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st,
+                                 c->d_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS, c->n_cu));
         c->cur_sparse_counts = P.sparse_counts && lfq_count_is_shallow(T, P, max_depth);
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
 
@@ -714,7 +748,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
          * -- every big column of a 1000x batch) need nothing from the segment / fold / combine kernels of the split ones.  With
          * one segment per batch the stream the count kernel ran on is idle from here on: they run there, beside that chain
          * instead of behind it (C2: 0.3 ms that used to start when the chain had ended). */
-        const bool big_on_st = run_big && !single_stream;
+        const bool big_on_st = run_big && !single_stream && !kn.big_on_side;
         if (big_on_st) {
             LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_prep, 0));
             LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,
@@ -735,6 +769,9 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
                 LFQ_DBG_STAGE("big");
             }
         }
+        if (!run_big) {
+            LFQ_TRY(tail_record(c, 0, side0));  /* (every batch records all three tail events, wherever its chains stand) */
+        }
         LFQ_TRY_HIP(hipStreamWaitEvent(side1, c->ev_prep, 0));     /* K = 250..252 of the big class lands in class 1 */
         if (run_mid || run_big) {
             LFQ_TRY(lfq_launch_dp_seg(0, T, P, c->d_luts, W, c->n_cu * 8, side1));
@@ -742,6 +779,9 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
             LFQ_TRY(tail_record(c, 1, side1));
             LFQ_TRY(lfq_launch_dp_combine(0, P, d_counts, W, d_pvals, pvals_capacity, c->n_cu, side1));
             LFQ_DBG_STAGE("combine mid");
+        }
+        if (!(run_mid || run_big)) {
+            LFQ_TRY(tail_record(c, 1, side1));
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][0], dps));
         if (!kn.skip_light) {
@@ -778,6 +818,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         /* DP4 of the columns that made it into the sparse output (lofreq_call.c:853-857) */
         LFQ_TRY(lfq_launch_strand_pvals(T, d_pvals, gcounters + LFQ_GC_PVALS, pvals_capacity, c->n_cu, jn));
     }
+    LFQ_TRY(end_record(c, jn));     /* LFQ_GATE_END: the next batch's count kernel may start here */
     /* the batch's counters and the two ends of its CSR offsets travel to pinned memory as part of the batch:
      * lfq_batch_finish then only waits for ev[3] (a synchronous hipMemcpy there takes the null stream, and the null
      * stream's turn can sit behind unrelated work queued on the device) */
@@ -853,6 +894,15 @@ int lfq_pack_nt_track(const uint8_t *nt_bytes, int64_t n_obs, uint8_t *packed_ou
             packed_out[4 * full + k] = (uint8_t)((last[k] & 15) | ((last[4 + k] & 15) << 4));
         }
     }
+    return LFQ_OK;
+}
+
+int lfq_set_batch_gate(lfq_ctx *c, int gate)
+{
+    if (!c || (gate != LFQ_GATE_TAIL && gate != LFQ_GATE_END && gate != LFQ_GATE_NONE)) {
+        return LFQ_ERR_INVALID;
+    }
+    c->batch_gate = gate;
     return LFQ_OK;
 }
 
@@ -1100,6 +1150,11 @@ int lfq_call_snvs_collect(lfq_ctx *c, lfq_conf *conf, lfq_snv_record *records, i
     }
     *n_records = 0;
     const int64_t ncols = c->sub_ncols;
+    if (ncols > 0 && h_counts_or_null && c->cur_sparse_counts) {
+        /* the count kernel skipped the entries of the untested columns (lfq_set_dense_counts(ctx, 0)): there is no complete
+         * dense array to hand out.  The batch stays collectable without h_counts. */
+        return LFQ_ERR_INVALID;
+    }
     c->sub_ncols = -1;
     if (ncols == 0) {
         if (stats_out) memset(stats_out, 0, sizeof(*stats_out));

@@ -335,6 +335,7 @@ struct lfq_ctx {
     int dense_counts;                /* lfq_set_dense_counts: 0 = a caller's dense array may keep stale entries for untested columns */
     int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
     int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
+    int batch_gate;                  /* lfq_set_batch_gate: what this context's next count kernel waits for (LFQ_GATE_*) */
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
     int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */
     int batch_recorded;              /* ev[3] has been recorded: a batch of this context may still be running */

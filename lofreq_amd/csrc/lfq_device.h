@@ -84,6 +84,16 @@ __device__ __forceinline__ uint32_t lfq_wave_sum_u32(uint32_t x)
            + (uint32_t)__builtin_amdgcn_readlane((int)x, 32) + (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
 }
 
+/* the wavefront's sum in lane 63 (other lanes: partial sums): the four row sums, then row_bcast15 into rows 1 and 3 and
+ * row_bcast31 into rows 2 and 3 -- six DPP adds, nothing through the scalar unit */
+__device__ __forceinline__ uint32_t lfq_wave_sum_lane63_u32(uint32_t x)
+{
+    x = lfq_group_sum_u32<16>(x);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* per-observation evaluation == the body of plp_to_errprobs' inner loop (snpcaller.c:399-496) */
 /* ------------------------------------------------------------------------------------------ */

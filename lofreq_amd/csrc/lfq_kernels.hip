@@ -615,20 +615,15 @@ __global__ __launch_bounds__(256, STRAND ? 3 : LFQ_COUNT_WAVES) void lfq_count_s
     }
 }
 
+/* One column on one wavefront: the integer outputs of plp_to_errprobs (snpcaller.c:346-498) + the gates of call_snvs /
+ * call_vars in front of it.  s_hist: the wavefront's 128 bins for the median-BQ override of the general path. */
 template <bool PACKED, bool STRAND>
-__global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
-                                                        const LfqLuts *__restrict__ luts,
-                                                        lfq_col_counts *__restrict__ out,
-                                                        uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
+__device__ __forceinline__ void lfq_count_column(const LfqTracksDev &T, const LfqParams &P,
+                                                 const LfqLuts *__restrict__ luts,
+                                                 lfq_col_counts *__restrict__ out,
+                                                 uint8_t *__restrict__ flags, int64_t col, int lane,
+                                                 uint32_t *s_hist)
 {
-    __shared__ uint32_t s_hist[4][128];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = lfq_lane();
-    /* one column per wavefront (a persistent, looping form was measured: fewer waves in flight, slower) */
-    const int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave;
-    if (col >= c1) {
-        return;
-    }
     const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
     const int64_t n_obs = (int64_t)(off1 - off0);
     const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
@@ -674,13 +669,13 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         int median = -1;
         if (P.def_alt_bq == -1) {
             for (int i = lane; i < 128; i += LFQ_WAVE) {
-                s_hist[wave][i] = 0;
+                s_hist[i] = 0;
             }
             __builtin_amdgcn_wave_barrier();
             for (int64_t i = lane; i < n_obs; i += LFQ_WAVE) {
                 const uint32_t ntb = lfq_nt_at(T, off0 + (uint64_t)i);
                 if ((int)(ntb & 7u) == ref_code) {
-                    atomicAdd(&s_hist[wave][T.bq[off0 + i] & 127u], 1u);
+                    atomicAdd(&s_hist[T.bq[off0 + i] & 127u], 1u);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -688,14 +683,14 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
             /* int_median (utils.c:436-457) from the histogram: lane-serial, <= 128 bins */
             uint32_t total = 0;
             for (int i = 0; i < 128; i++) {
-                total += s_hist[wave][i];
+                total += s_hist[i];
             }
             if (total) {
                 const uint32_t r_hi = total / 2, r_lo = (total & 1u) ? r_hi : r_hi - 1;
                 int q_lo = -1, q_hi = -1;
                 uint32_t run = 0;
                 for (int i = 0; i < 128; i++) {
-                    run += s_hist[wave][i];
+                    run += s_hist[i];
                     if (q_lo < 0 && run > r_lo) q_lo = i;
                     if (q_hi < 0 && run > r_hi) q_hi = i;
                 }
@@ -785,6 +780,245 @@ __global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParam
         }
         out[col] = r;
         flags[col] = flag;
+    }
+}
+
+/* one column per wavefront: every configuration (merged-quality filters, the median-BQ override, lofreq uniq's detection
+ * limit).  The default filters take lfq_count_fast_kernel below. */
+template <bool PACKED, bool STRAND>
+__global__ __launch_bounds__(256) void lfq_count_kernel(LfqTracksDev T, LfqParams P,
+                                                        const LfqLuts *__restrict__ luts,
+                                                        lfq_col_counts *__restrict__ out,
+                                                        uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
+{
+    __shared__ uint32_t s_hist[4][128];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t col = c0 + (int64_t)blockIdx.x * 4 + wave;
+    if (col >= c1) {
+        return;
+    }
+    lfq_count_column<PACKED, STRAND>(T, P, luts, out, flags, col, lfq_lane(), s_hist[wave]);
+}
+
+/* ---- the default filters (min_jq = min_alt_jq = 0, def_alt_bq != -1): only the nt and bq tracks decide the counts ----
+ * The same column on a wavefront as lfq_count_column's fast branch, as a function of its own: no quality tables, no
+ * per-observation evaluation, no LDS, the two thresholds' relation a template parameter, chunk indices 32-bit and relative
+ * to the column, the byte masks only for a column's first and last chunk, two chunks' loads in flight per lane.  What it
+ * buys is registers (36-44 instead of 58-72): half of a SIMD's register file stays free beside eight of these wavefronts,
+ * which is what lets the DP kernels of the previous batch run beside the count kernel of the next one. */
+struct LfqCountArgs {           /* what the default filters need of LfqTracksDev and LfqParams: a third of the scalar registers */
+    const uint8_t *nt, *bq;
+    const uint64_t *col_off;
+    const uint8_t *ref_base;
+    const int32_t *coverage_plp, *num_bases;
+    int32_t min_bq4, min_alt_bq4, min_cov, pad_;
+};
+
+template <bool PACKED, bool STRAND, bool SAME_THR>
+__device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq_col_counts *__restrict__ out,
+                                                      uint8_t *__restrict__ flags, int64_t col, int lane)
+{
+    const LfqCountArgs &P = T;
+    const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
+    const int64_t n_obs = (int64_t)(off1 - off0);
+    const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
+    const int nb = T.num_bases ? T.num_bases[col] : (int)n_obs;
+    const uint32_t rb = T.ref_base[col];
+    const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
+    /* gates: lofreq_call.c:892/754 (ref N; non-ACGT refs are N, plp.c:819-823), :930, :747 */
+    const bool gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < P.min_cov);
+
+    LfqAcc a;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        a.raw[x] = a.fw[x] = a.ge[x] = a.ga[x] = 0;
+    }
+    if (!gated && n_obs > 0) {
+        const uint32_t minbq4 = 0x01010101u * (uint32_t)P.min_bq4;
+        const uint32_t minalt4 = 0x01010101u * (uint32_t)P.min_alt_bq4;
+        const int64_t cbeg = (int64_t)(off0 >> 4);
+        const int n_ch = (int)((int64_t)((off1 + 15) >> 4) - cbeg);          /* chunks of 16 observations the column touches */
+        const int lo = (int)(off0 & 15u);                                     /* first observation inside chunk 0 */
+        const int hi_last = (int)((int64_t)off1 - ((cbeg + n_ch - 1) << 4));   /* observations of the last chunk: 1..16 */
+        const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq) + cbeg;
+        /* one chunk: full masks inside the column, byte masks at its two ends (a wavefront meets them in its first and in
+         * its last trip only) */
+#define LFQ_FAST_CHUNK(I, NTV, B4)                                                                                   \
+        do {                                                                                                         \
+            const int i_ = (I);                                                                                      \
+            if (__builtin_expect(i_ != 0 && i_ != n_ch - 1, 1)) {                                                    \
+                if (PACKED) {                                                                                        \
+                    lfq_count_nib8<SAME_THR, STRAND>(a, (NTV).x, (B4).x, (B4).y, 0x88888888u, minbq4, minalt4);      \
+                    lfq_count_nib8<SAME_THR, STRAND>(a, (NTV).y, (B4).z, (B4).w, 0x88888888u, minbq4, minalt4);      \
+                } else {                                                                                             \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).x, (B4).x, 0x80808080u, minbq4, minalt4);             \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).y, (B4).y, 0x80808080u, minbq4, minalt4);             \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).z, (B4).z, 0x80808080u, minbq4, minalt4);             \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).w, (B4).w, 0x80808080u, minbq4, minalt4);             \
+                }                                                                                                    \
+            } else {                                                                                                 \
+                const int l_ = i_ == 0 ? lo : 0, h_ = i_ == n_ch - 1 ? hi_last : 16;                                 \
+                if (PACKED) {                                                                                        \
+                    lfq_count_nib8<SAME_THR, STRAND>(a, (NTV).x, (B4).x, (B4).y,                                     \
+                                                     (lfq_bytes_mask(l_, h_, 0) >> 4) | lfq_bytes_mask(l_, h_, 1), minbq4, minalt4); \
+                    lfq_count_nib8<SAME_THR, STRAND>(a, (NTV).y, (B4).z, (B4).w,                                     \
+                                                     (lfq_bytes_mask(l_, h_, 2) >> 4) | lfq_bytes_mask(l_, h_, 3), minbq4, minalt4); \
+                } else {                                                                                             \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).x, (B4).x, lfq_bytes_mask(l_, h_, 0), minbq4, minalt4); \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).y, (B4).y, lfq_bytes_mask(l_, h_, 1), minbq4, minalt4); \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).z, (B4).z, lfq_bytes_mask(l_, h_, 2), minbq4, minalt4); \
+                    lfq_count_dword<SAME_THR, STRAND>(a, (NTV).w, (B4).w, lfq_bytes_mask(l_, h_, 3), minbq4, minalt4); \
+                }                                                                                                    \
+            }                                                                                                        \
+        } while (0)
+        int i = lane;
+        if (PACKED) {
+            const uint2 *nt8 = reinterpret_cast<const uint2 *>(T.nt) + cbeg;
+            for (; i + LFQ_WAVE < n_ch; i += 2 * LFQ_WAVE) {
+                const uint2 na = nt8[i], nb2 = nt8[i + LFQ_WAVE];
+                const uint4 ba = bq16[i], bb = bq16[i + LFQ_WAVE];
+                const uint4 na4 = make_uint4(na.x, na.y, 0u, 0u), nb4 = make_uint4(nb2.x, nb2.y, 0u, 0u);
+                LFQ_FAST_CHUNK(i, na4, ba);
+                LFQ_FAST_CHUNK(i + LFQ_WAVE, nb4, bb);
+            }
+            if (i < n_ch) {
+                const uint2 na = nt8[i];
+                const uint4 ba = bq16[i];
+                const uint4 na4 = make_uint4(na.x, na.y, 0u, 0u);
+                LFQ_FAST_CHUNK(i, na4, ba);
+            }
+        } else {
+            const uint4 *nt16 = reinterpret_cast<const uint4 *>(T.nt) + cbeg;
+            for (; i + LFQ_WAVE < n_ch; i += 2 * LFQ_WAVE) {
+                const uint4 na = nt16[i], nb4 = nt16[i + LFQ_WAVE];
+                const uint4 ba = bq16[i], bb = bq16[i + LFQ_WAVE];
+                LFQ_FAST_CHUNK(i, na, ba);
+                LFQ_FAST_CHUNK(i + LFQ_WAVE, nb4, bb);
+            }
+            if (i < n_ch) {
+                const uint4 na = nt16[i];
+                const uint4 ba = bq16[i];
+                LFQ_FAST_CHUNK(i, na, ba);
+            }
+        }
+#undef LFQ_FAST_CHUNK
+    }
+
+    /* the column's sums end up in lane 63, which writes the record */
+    uint32_t n_raw[4], n_fw[4], n_ge[4], n_ga[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        n_raw[x] = lfq_wave_sum_lane63_u32(a.raw[x]);
+        n_fw[x] = STRAND ? lfq_wave_sum_lane63_u32(a.fw[x]) : 0u;
+        n_ge[x] = lfq_wave_sum_lane63_u32(a.ge[x]);
+        n_ga[x] = SAME_THR ? n_ge[x] : lfq_wave_sum_lane63_u32(a.ga[x]);
+    }
+    if (lane == LFQ_WAVE - 1) {
+        uint32_t raw[4], fw[4], c_ge[4], c_ga[4], filt[4];
+        lfq_planes_to_classes(n_raw, raw);
+        lfq_planes_to_classes(n_fw, fw);
+        lfq_planes_to_classes(n_ge, c_ge);
+        lfq_planes_to_classes(n_ga, c_ga);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];     /* alt bases must pass both thresholds */
+        }
+        lfq_col_counts r;
+        r.n_err_probs = 0;
+        for (int k = 0; k < 3; k++) {
+            r.alt_counts[k] = r.alt_raw_counts[k] = r.alt_fw[k] = 0;
+        }
+        r.ref_fw = r.ref_rv = 0;
+        r.kmax = 0;
+        r.tested = 0;
+        r.pad_[0] = r.pad_[1] = 0;
+        r.median_ref_bq = -1;
+        r.coverage = cov;
+        r.gated = gated;
+        uint8_t flag = 0;
+        if (!gated) {
+            /* the three non-reference nucleotides in A,C,G,T order (snpcaller.c:391-397) */
+            const int x0 = (ref_code == 0) ? 1 : 0;
+            const int x1 = (ref_code <= 1) ? 2 : 1;
+            const int x2 = (ref_code <= 2) ? 3 : 2;
+#define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
+            r.ref_fw = (int)LFQ_PICK(fw, ref_code);
+            r.ref_rv = STRAND ? (int)(LFQ_PICK(raw, ref_code) - LFQ_PICK(fw, ref_code)) : 0;   /* lazy: lfq_strand_* */
+            r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
+            r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
+            r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
+            r.alt_raw_counts[0] = (int)LFQ_PICK(raw, x0);
+            r.alt_raw_counts[1] = (int)LFQ_PICK(raw, x1);
+            r.alt_raw_counts[2] = (int)LFQ_PICK(raw, x2);
+            r.alt_fw[0] = (int)LFQ_PICK(fw, x0);
+            r.alt_fw[1] = (int)LFQ_PICK(fw, x1);
+            r.alt_fw[2] = (int)LFQ_PICK(fw, x2);
+#undef LFQ_PICK
+            r.n_err_probs = (int)(filt[0] + filt[1] + filt[2] + filt[3]);
+            const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
+            r.kmax = kmax;
+            r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
+            /* scheduling class: as in lfq_count_column */
+            const int suspicious = max(12, r.n_err_probs / 512 + 8);
+            flag = (uint8_t)((r.tested ? 1 : 0)
+                             | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
+        }
+        out[col] = r;
+        flags[col] = flag;
+    }
+}
+
+/* one column per wavefront, WAVES columns per workgroup (4: the default.  8 / 16 exist for a caller that keeps two batches
+ * in flight, LFQ_COUNT_WAVES_PER_WG: a retiring workgroup then frees two / four wave slots per SIMD at once, room for the
+ * 512-thread workgroups of the other batch's DP kernels, which single slots never give) */
+template <bool PACKED, bool STRAND, bool SAME_THR, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lfq_count_fast_kernel(LfqCountArgs T,
+                                                                    lfq_col_counts *__restrict__ out,
+                                                                    uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t col = c0 + (int64_t)blockIdx.x * WAVES + wave;
+    if (col >= c1) {
+        return;
+    }
+    lfq_count_column_fast<PACKED, STRAND, SAME_THR>(T, out, flags, col, lfq_lane());
+}
+
+/* The same work as a RESIDENT kernel: exactly n_cu x W workgroups whatever the batch (LFQ_COUNT_PERSIST = W), each wavefront
+ * claiming slices of `slice` consecutive columns from LFQ_COUNT_HEADS heads (a head owns a contiguous range of the columns;
+ * a wavefront starts at its workgroup's head and moves on to the next when one is exhausted; one 128-byte line per head).  Its
+ * point is what it leaves free: with W = 6 two wave slots per SIMD, half of the registers and all of the LDS stay available
+ * to the DP kernels of the previous batch for the whole launch, so that the two run beside each other instead of the count
+ * kernel's single-slot refills starving every DP workgroup that needs more than one slot (profiles/NOTES.md). */
+template <bool PACKED, bool STRAND, bool SAME_THR>
+__global__ __launch_bounds__(256) void lfq_count_persist_kernel(LfqCountArgs T,
+                                                                lfq_col_counts *__restrict__ out,
+                                                                uint8_t *__restrict__ flags, int64_t c0, int64_t c1,
+                                                                int32_t *__restrict__ heads, int slice)
+{
+    const int lane = lfq_lane();
+    const int64_t n = c1 - c0;
+    int h = (int)(blockIdx.x % LFQ_COUNT_HEADS);
+    for (int tried = 0; tried < LFQ_COUNT_HEADS; tried++, h = (h + 1 == LFQ_COUNT_HEADS) ? 0 : h + 1) {
+        const int64_t h0 = n * h / LFQ_COUNT_HEADS, h1 = n * (h + 1) / LFQ_COUNT_HEADS;
+        int32_t *head = heads + h * 32;
+        if (tried > 0 && (int64_t)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= h1 - h0) {
+            continue;               /* somebody else's head, already exhausted: no atomic on it */
+        }
+        for (;;) {
+            int32_t at = 0;
+            if (lane == 0) {
+                at = atomicAdd(head, slice);
+            }
+            at = __builtin_amdgcn_readfirstlane(at);
+            if ((int64_t)at >= h1 - h0) {
+                break;
+            }
+            const int64_t e = min((int64_t)at + slice, h1 - h0);
+            for (int64_t i = at; i < e; i++) {
+                lfq_count_column_fast<PACKED, STRAND, SAME_THR>(T, out, flags, c0 + h0 + i, lane);
+            }
+        }
     }
 }
 
@@ -1165,7 +1399,8 @@ bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max
 }
 
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream)
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream, int32_t *d_heads,
+                     int n_cu)
 {
     if (c1 <= c0) {
         return LFQ_OK;
@@ -1214,11 +1449,73 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         LFQ_HIP_TRY(hipGetLastError());
         return LFQ_OK;
     }
+    const bool strand = !p.lazy_strand || p.general;       /* the general path evaluates every observation anyway */
+    const LfqKnobs &kn = lfq_knobs();
+    if (!p.general && !p.detlim_af) {
+        /* default filters: the lean kernel, by layout x strand counts x "one threshold" */
+        const bool same_thr = p.min_alt_bq4 == p.min_bq4;
+        LfqCountArgs ca;
+        ca.nt = t.nt;
+        ca.bq = t.bq;
+        ca.col_off = t.col_off;
+        ca.ref_base = t.ref_base;
+        ca.coverage_plp = t.coverage_plp;
+        ca.num_bases = t.num_bases;
+        ca.min_bq4 = p.min_bq4;
+        ca.min_alt_bq4 = p.min_alt_bq4;
+        ca.min_cov = p.min_cov;
+        ca.pad_ = 0;
+        const int variant = (t.nt_packed ? 4 : 0) | (strand ? 2 : 0) | (same_thr ? 1 : 0);
+        if (kn.count_persist > 0 && d_heads && n_cu > 0) {
+            const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)n_cu * kn.count_persist, (c1 - c0 + 3) / 4);
+            const int slice = kn.count_slice;
+#define LFQ_LAUNCH_P(PK, ST, SM)                                                                                     \
+    hipLaunchKernelGGL((lfq_count_persist_kernel<PK, ST, SM>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, ca, \
+                       d_counts, d_flags, c0, c1, d_heads, slice)
+            switch (variant) {
+            case 0: LFQ_LAUNCH_P(false, false, false); break;
+            case 1: LFQ_LAUNCH_P(false, false, true); break;
+            case 2: LFQ_LAUNCH_P(false, true, false); break;
+            case 3: LFQ_LAUNCH_P(false, true, true); break;
+            case 4: LFQ_LAUNCH_P(true, false, false); break;
+            case 5: LFQ_LAUNCH_P(true, false, true); break;
+            case 6: LFQ_LAUNCH_P(true, true, false); break;
+            default: LFQ_LAUNCH_P(true, true, true); break;
+            }
+#undef LFQ_LAUNCH_P
+            LFQ_HIP_TRY(hipGetLastError());
+            return LFQ_OK;
+        }
+        const int wpw = kn.count_waves_per_wg;
+        const unsigned blocks = (unsigned)((c1 - c0 + wpw - 1) / wpw);
+#define LFQ_LAUNCH_F(PK, ST, SM, W)                                                                                  \
+    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
+                       d_counts, d_flags, c0, c1)
+#define LFQ_LAUNCH_FW(PK, ST, SM)                                                                                    \
+    do {                                                                                                             \
+        if (wpw == 16) LFQ_LAUNCH_F(PK, ST, SM, 16);                                                                 \
+        else if (wpw == 8) LFQ_LAUNCH_F(PK, ST, SM, 8);                                                              \
+        else LFQ_LAUNCH_F(PK, ST, SM, 4);                                                                            \
+    } while (0)
+        switch (variant) {
+        case 0: LFQ_LAUNCH_FW(false, false, false); break;
+        case 1: LFQ_LAUNCH_FW(false, false, true); break;
+        case 2: LFQ_LAUNCH_FW(false, true, false); break;
+        case 3: LFQ_LAUNCH_FW(false, true, true); break;
+        case 4: LFQ_LAUNCH_FW(true, false, false); break;
+        case 5: LFQ_LAUNCH_FW(true, false, true); break;
+        case 6: LFQ_LAUNCH_FW(true, true, false); break;
+        default: LFQ_LAUNCH_FW(true, true, true); break;
+        }
+#undef LFQ_LAUNCH_FW
+#undef LFQ_LAUNCH_F
+        LFQ_HIP_TRY(hipGetLastError());
+        return LFQ_OK;
+    }
     const unsigned blocks = (unsigned)((c1 - c0 + 3) / 4);
 #define LFQ_LAUNCH_COUNT(PK, ST)                                                                                     \
     hipLaunchKernelGGL((lfq_count_kernel<PK, ST>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, p, d_luts,       \
                        d_counts, d_flags, c0, c1)
-    const bool strand = !p.lazy_strand || p.general;       /* the general path evaluates every observation anyway */
     if (t.nt_packed) {
         if (strand) LFQ_LAUNCH_COUNT(true, true); else LFQ_LAUNCH_COUNT(true, false);
     } else {

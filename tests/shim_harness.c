@@ -56,6 +56,8 @@ int lfq_create(lfq_ctx **ctx, int device_ordinal)
     return LFQ_OK;
 }
 void lfq_destroy(lfq_ctx *ctx) { free(ctx); }
+int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on) { (void)ctx; (void)on; return LFQ_OK; }
+int lfq_set_dense_counts(lfq_ctx *ctx, int on) { (void)ctx; (void)on; return LFQ_OK; }
 int lfq_abi_version(void) { return LFQ_ABI_VERSION; }
 int lfq_pick_device(int n_devices, int *slot) { (void)n_devices; if (slot) *slot = -1; return 0; }
 const char *lfq_strerror(int status) { (void)status; return "mock"; }
