@@ -22,6 +22,7 @@ run "default" 2 end X=0
 run "default" 2 tail X=0
 run "default" 2 none X=0
 run "default, big kernel on the side stream" 2 none LFQ_BIG_ON_SIDE=1
+[ "$CFG" = C3 ] || exit 0       # (the forms below are those of the one-column-per-wavefront kernel: depth >= 4096)
 for w in 8 16; do
   run "$w columns per workgroup" 1 tail LFQ_COUNT_WAVES_PER_WG=$w
   run "$w columns per workgroup" 2 tail LFQ_COUNT_WAVES_PER_WG=$w
