@@ -85,10 +85,10 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the host-abi / chain measurements of config.secondary")
     ap.add_argument("--nt-bytes", action="store_true",
                     help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
-    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
-                    help="pipelined loop: batches whose kernels may be on the GPU at the same time (2: batch k + 1 is "
-                         "submitted before batch k is waited for, its count kernel starts when batch k is past its row-bound "
-                         "DP kernels; 1: one batch's kernels at a time; 0 = default: the warm-up times both and keeps the faster)")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="pipelined loop: batches submitted and not yet waited for (1: step k + 1 is submitted when the kernels "
+                         "of step k are done; 2-4: that many are queued on the device, --gate says what a queued batch's count "
+                         "kernel waits for; 0 = default: the warm-up times the candidates and keeps the fastest)")
     ap.add_argument("--gate", choices=["auto", "tail", "end", "none"], default="auto",
                     help="with two batches in flight: what the second one's count kernel waits for on the device "
                          "(lfq_set_batch_gate): the first one's row-bound DP kernels (tail), all of its kernels (end: batch "
@@ -1141,46 +1141,53 @@ def main():
     pipelined = my_bins is None and not args.no_pipeline
     layer2 = world == 1 and not args.shard_path
     if pipelined:
-        callers = [caller, la.SnvCaller(local_rank)]
-        callers[1].set_dense_strand_counts(False)
-        callers[1].set_dense_counts(False)
+        # one context per batch in flight: three in the automatic mode (two batches in flight take two, three take three)
+        NCTX = max(args.in_flight, 2) if args.in_flight else 3
+        callers = [caller] + [la.SnvCaller(local_rank) for _ in range(NCTX - 1)]
+        for c_ in callers[1:]:
+            c_.set_dense_strand_counts(False)
+            c_.set_dense_counts(False)
         # the sharded step (layer 1 + exchange) pipelines the same way: every context has its own device-side outputs
-        out_bufs = [(d_counts, d_pvals), (torch.zeros_like(d_counts), torch.zeros_like(d_pvals))]
+        out_bufs = [(d_counts, d_pvals)] + [(torch.zeros_like(d_counts), torch.zeros_like(d_pvals)) for _ in range(NCTX - 1)]
 
         def submit(k):
             conf = la.VarcallConf()
             if layer2:
-                callers[k % 2].call_snvs_submit(batch, conf)
+                callers[k % NCTX].call_snvs_submit(batch, conf)
             else:
-                dc, dp = out_bufs[k % 2]
-                callers[k % 2].snv_batch_device(batch, conf, dc, dp, pv_cap)
+                dc, dp = out_bufs[k % NCTX]
+                callers[k % NCTX].snv_batch_device(batch, conf, dc, dp, pv_cap)
             return conf
 
         def finish(k, conf):
             if layer2:
-                recs, st = callers[k % 2].call_snvs_collect(conf, records_capacity=1 << 16)
+                recs, st = callers[k % NCTX].call_snvs_collect(conf, records_capacity=1 << 16)
             else:
                 # host + exchange half of the sharded step, under the kernels of the next one: the running Bonferroni
                 # factor needs every rank's tested-column count, rank 0 gets everybody's records
-                st = callers[k % 2].batch_finish()
-                pv = out_bufs[k % 2][1][: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
+                st = callers[k % NCTX].batch_finish()
+                pv = out_bufs[k % NCTX][1][: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
                 recs, _total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin, dist if world > 1 else None, xdev)
             text = None
             if rank == 0:
                 thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
                 keep = la.filter_records(recs, thr, apply_defaults=cfg_filter)
                 text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
-            return conf, st, recs, text, callers[k % 2].kernel_times()
+            return conf, st, recs, text, callers[k % NCTX].kernel_times()
 
         def wait(k):
             if layer2:
-                callers[k % 2].call_snvs_wait()
+                callers[k % NCTX].call_snvs_wait()
             # (layer 1: lfq_batch_finish waits for the batch's event itself)
 
         # how the loop keeps the device fed: `n` batches in flight and, with two, what the second one's count kernel waits for
         # on the device (lfq_set_batch_gate)
         in_flight = {"n": args.in_flight or 1, "gate": args.gate if args.gate != "auto" else "tail",
                      "note": "as given" if args.in_flight else None}
+
+        # LFQ_BENCH_TRACE_STEPS=1: the host's side of every step of the timed blocks (wait / finish / submit, seconds) and the
+        # batch's kernel time go to stderr afterwards -- where a slow step lost its time
+        step_trace = [] if os.environ.get("LFQ_BENCH_TRACE_STEPS") else None
 
         def set_mode(n, gate):
             in_flight["n"], in_flight["gate"] = n, gate
@@ -1198,23 +1205,32 @@ def main():
                 # kernel is done (an event on the device, no host latency between the batches; one batch's kernels at a
                 # time); "tail": when batch k is past its row-bound DP kernels (it runs beside the folds and the join);
                 # "none": as soon as the count kernel of batch k is done (beside all of batch k's DP kernels)
-                confs = {0: submit(0)}
-                if n > 1:
-                    confs[1] = submit(1)
+                depth = in_flight["n"]
+                confs = {j: submit(j) for j in range(min(depth, n))}
                 for k in range(n):
+                    tr0 = time.perf_counter()
                     wait(k)
+                    tr1 = time.perf_counter()
                     out = finish(k, confs.pop(k))
-                    if k + 2 < n:
-                        confs[k + 2] = submit(k + 2)
+                    tr2 = time.perf_counter()
+                    if k + depth < n:
+                        confs[k + depth] = submit(k + depth)
+                    if step_trace is not None:
+                        step_trace.append((tr1 - tr0, tr2 - tr1, time.perf_counter() - tr2, out[4]["ms_total"]))
                     acc = out[4] if acc is None else {x: acc[x] + out[4][x] for x in acc}
                 return out, acc
             pending = submit(0)
             for k in range(n):
+                tr0 = time.perf_counter()
                 wait(k)
                 if not layer2:
-                    callers[k % 2].synchronize()      # layer 1 has no separate wait: the kernels of step k are done here
+                    callers[k % NCTX].synchronize()      # layer 1 has no separate wait: the kernels of step k are done here
+                tr1 = time.perf_counter()
                 nxt = submit(k + 1) if k + 1 < n else None
+                tr2 = time.perf_counter()
                 out = finish(k, pending)
+                if step_trace is not None:
+                    step_trace.append((tr1 - tr0, time.perf_counter() - tr2, tr2 - tr1, out[4]["ms_total"]))
                 acc = out[4] if acc is None else {x: acc[x] + out[4][x] for x in acc}
                 pending = nxt
             return out, acc
@@ -1225,8 +1241,11 @@ def main():
             # where the DP tail is short latency-bound work next to a short count kernel: 1000x; the device-side gate at the
             # end of the previous batch takes the host's wake-up + launch latency out of every step): measured here,
             # outside the timed region
-            modes = [(2, "tail"), (2, "end"), (2, "none")] if args.in_flight == 2 else \
-                    [(1, "tail"), (2, "tail"), (2, "end"), (2, "none")]
+            # (first in the list = the default: batches one after another on the device, three queued, so that a host thread
+            # that loses the CPU for a few milliseconds -- the boxes grant 16 of 256 cores and have neighbours -- does not
+            # leave the device idle; another mode has to beat it by 2 %)
+            modes = [(2, "end"), (2, "tail"), (2, "none")] if args.in_flight == 2 else \
+                    [(3, "end"), (2, "end"), (2, "tail"), (1, "tail")]
             trial = {}
             for m in modes + modes:
                 set_mode(*m)
@@ -1240,19 +1259,23 @@ def main():
                 tt = torch.tensor([trial[m] for m in modes], dtype=torch.float64, device=xdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 trial = {m: float(tt[i]) for i, m in enumerate(modes)}
-            # (a mode has to beat the one before it in the list by 1 % to be taken: ties go to the simpler loop)
+            # (a mode has to beat the best one before it in the list by 2 % to be taken)
             best = modes[0]
             for m in modes[1:]:
-                if trial[m] < 0.99 * trial[best]:
+                if trial[m] < 0.98 * trial[best]:
                     best = m
             set_mode(*best)
             in_flight["note"] = "chosen in the warm-up: " + ", ".join(
-                "%.3f ms per step with %s" % (1e3 * trial[m], "one batch in flight" if m[0] == 1 else "two, gate " + m[1])
+                "%.3f ms per step with %s" % (1e3 * trial[m], "one batch in flight" if m[0] == 1 else "%d, gate %s" % m)
                 for m in modes)
 
     def timed_block():
         """EXACTLY --steps steps between two barrier + synchronize pairs -> (seconds: max over ranks, last step, kernel times)"""
         acc = None
+        if os.environ.get("LFQ_BENCH_NO_GC"):
+            import gc
+            gc.collect()
+            gc.disable()
         barrier()
         t0 = time.perf_counter()
         if pipelined:
@@ -1274,7 +1297,12 @@ def main():
     block_s = [elapsed]
     for _ in range(max(args.repeats, 1) - 1):
         block_s.append(timed_block()[0])
-    work = (callers[(args.steps - 1) % 2] if pipelined else caller).dp_work()
+    work = (callers[(args.steps - 1) % NCTX] if pipelined else caller).dp_work()
+    if pipelined and step_trace:
+        tail = step_trace[-len(block_s) * args.steps:]
+        for i, (w, f, sb, kms) in enumerate(tail):
+            sys.stderr.write("[step %3d] wait %.3f  finish %.3f  submit %.3f  sum %.3f ms   kernels %.3f ms\n"
+                             % (i, 1e3 * w, 1e3 * f, 1e3 * sb, 1e3 * (w + f + sb), kms))
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -1347,13 +1375,13 @@ def main():
                              % (in_flight["n"], "" if in_flight["n"] == 1 else ", gate " + in_flight["gate"], in_flight["note"]))
                             if pipelined else "none",
                 "batches_in_flight": in_flight["n"] if pipelined else 1,
-                "batch_gate": (in_flight["gate"] if in_flight["n"] == 2 else None) if pipelined else None,
+                "batch_gate": (in_flight["gate"] if in_flight["n"] >= 2 else None) if pipelined else None,
                 # with two batches in flight and a gate other than "end" the kernels of consecutive steps overlap: the
                 # per-step kernel times then sum to more than the step, and ms_step - ms_kernels is not a host time
-                "kernel_times_overlap": bool(pipelined and in_flight["n"] == 2 and in_flight["gate"] != "end"),
+                "kernel_times_overlap": bool(pipelined and in_flight["n"] >= 2 and in_flight["gate"] != "end"),
                 "ms_kernels": kt["ms_total"],
                 "host_ms_per_step_not_hidden": (ms_per_step - kt["ms_total"])
-                                               if not (pipelined and in_flight["n"] == 2 and in_flight["gate"] != "end") else None,
+                                               if not (pipelined and in_flight["n"] >= 2 and in_flight["gate"] != "end") else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": count_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1434,7 +1462,8 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     if pipelined:
-        callers[1].close()
+        for c_ in callers[1:]:
+            c_.close()
     caller.close()
 
 
