@@ -1439,6 +1439,9 @@ def main():
         line["config"]["columns_compared"] = vc.get("columns_compared", vc.get("sample_columns"))
         line["config"]["max_dlogp_upto_600"] = vc.get("max_dlogp_upto_600")
         line["config"]["max_dlogp_beyond_600"] = vc.get("max_dlogp_beyond_600")
+        line["config"]["max_dlogp_beyond_600_over_bound"] = vc.get("max_dlogp_beyond_600_over_bound")
+        line["config"]["max_dlogp_device_vs_80bit_truth"] = vc.get("max_dlogp_device_vs_80bit_truth")
+        line["config"]["n_pvalues_vs_80bit_truth"] = vc.get("n_pvalues_vs_80bit_truth")
         if world == 1 and not args.no_secondary:
             sec = {}
             try:

@@ -399,7 +399,7 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
     c->own_streams = ok ? 1 : 0;
     ok = ok && hipMalloc((void **)&c->d_luts, sizeof(LfqLuts)) == hipSuccess;
     /* counter blocks: one per segment + one batch-wide */
-    ok = ok && hipMalloc((void **)&c->d_counters, ((LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS + LFQ_COUNT_HEADS * 32) * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_counters, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t) + 16,
                              hipHostMallocDefault) == hipSuccess;      /* + first / last CSR offset (lfq_batch_finish) */
     for (int i = 0; ok && i < 4; i++) {
@@ -614,8 +614,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
      * the other batch -- a few hundred wavefronts of LDS and FP64 work -- not beside its segment and screen kernels, which
      * it would slow down by as much as it gains (profiles/NOTES.md, two batches in flight) */
     LFQ_TRY(tail_wait(c, st));
-    /* (the batch's counters and, behind them, the work heads of the resident count kernel) */
-    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, ((LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS + LFQ_COUNT_HEADS * 32) * sizeof(int32_t), st));
+    LFQ_TRY_HIP(hipMemsetAsync(c->d_counters, 0, (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS * sizeof(int32_t), st));
     if (ncols > 0) {
         LFQ_TRY_HIP(hipMemsetAsync(c->d_retry, 0, (size_t)ncols, st));
     }
@@ -680,8 +679,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         W.unsplit = c->d_unsplit + c0;
 
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
-        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st,
-                                 c->d_counters + (LFQ_MAX_SEGMENTS + 1) * LFQ_NCOUNTERS, c->n_cu));
+        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st));
         c->cur_sparse_counts = P.sparse_counts && lfq_count_is_shallow(T, P, max_depth);
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
 
@@ -748,7 +746,8 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
          * -- every big column of a 1000x batch) need nothing from the segment / fold / combine kernels of the split ones.  With
          * one segment per batch the stream the count kernel ran on is idle from here on: they run there, beside that chain
          * instead of behind it (C2: 0.3 ms that used to start when the chain had ended). */
-        const bool big_on_st = run_big && !single_stream && !kn.big_on_side;
+        /* (not for a context whose batches are queued without a gate: the next batch's count kernel is queued on `st`) */
+        const bool big_on_st = run_big && !single_stream && !kn.big_on_side && c->batch_gate != LFQ_GATE_NONE;
         if (big_on_st) {
             LFQ_TRY_HIP(hipStreamWaitEvent(st, c->ev_prep, 0));
             LFQ_TRY(lfq_launch_dp_big(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, c->d_scratch, per_block,

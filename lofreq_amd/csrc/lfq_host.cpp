@@ -62,11 +62,11 @@ const LfqKnobs &lfq_knobs(void)
         x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
         {
-            const long w = geti("LFQ_COUNT_WAVES_PER_WG", 4);
-            x.count_waves_per_wg = (w == 8 || w == 16) ? (int)w : 4;
+            const long w = geti("LFQ_COUNT_WAVES_PER_WG", 16);
+            x.count_waves_per_wg = (w == 4 || w == 8) ? (int)w : 16;
         }
-        x.count_persist = (int)std::min(8L, std::max(0L, geti("LFQ_COUNT_PERSIST", 0)));
-        x.count_slice = (int)std::min(64L, std::max(1L, geti("LFQ_COUNT_SLICE", 2)));
+        x.count_unroll = geti("LFQ_COUNT_UNROLL", 2) == 4 ? 4 : 2;
+        x.count_prio = has("LFQ_COUNT_PRIO");
         x.big_on_side = has("LFQ_BIG_ON_SIDE");
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);

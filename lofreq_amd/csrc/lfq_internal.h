@@ -150,7 +150,6 @@ struct LfqWork {
 #define LFQ_MID_K 64          /* K+1 cells no longer fit one cell per lane */
 #define LFQ_BIG_K 250         /* K+1 (+alignment) cells no longer fit one 64x4 strip: strip pipeline */
 #define LFQ_NCOUNTERS 320
-#define LFQ_COUNT_HEADS 64      /* work heads of lfq_count_persist_kernel, one 128-byte line each, behind the batch counters */
 #define LFQ_MAX_SEGMENTS 1      /* launch sequences per batch (per-segment counters and events are laid out for this many) */
 #define LFQ_GC_PVALS 0         /* records appended to the sparse output */
 #define LFQ_GC_OVERFLOW 1
@@ -200,10 +199,11 @@ struct LfqKnobs {
     int seg_budget_mid, seg_budget_big;   /* LFQ_SEG_BUDGET_MID (4096), LFQ_SEG_BUDGET_BIG (4096) */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
-    int count_waves_per_wg;    /* LFQ_COUNT_WAVES_PER_WG (4; 8, 16): columns per workgroup of the one-column-per-wavefront count kernel */
-    int count_persist;         /* LFQ_COUNT_PERSIST (0): > 0 = the resident count kernel with this many workgroups per CU */
-    int count_slice;           /* LFQ_COUNT_SLICE (2): columns a wavefront of the resident count kernel claims at a time */
-    int big_on_side;           /* LFQ_BIG_ON_SIDE: the unsplit big columns behind the big chain instead of on the count kernel's stream */
+    int count_waves_per_wg;    /* LFQ_COUNT_WAVES_PER_WG (16; 4, 8): columns per workgroup of the one-column-per-wavefront count kernel */
+    int count_unroll;          /* LFQ_COUNT_UNROLL (2; 4 with 16 columns per workgroup): chunks in flight per lane */
+    int count_prio;            /* LFQ_COUNT_PRIO: s_setprio 3 in the count kernel (16 columns per workgroup) */
+    int big_on_side;           /* LFQ_BIG_ON_SIDE: the unsplit big columns behind the big chain instead of on the count kernel's stream
+                                * (a context with LFQ_GATE_NONE runs that way by itself) */
     int baq_one_variant;       /* LFQ_BAQ_ONE_VARIANT: every wavefront of the plain narrow-band BAQ launches through the instantiation with the N case */
     int pileup_tiles;          /* LFQ_PILEUP_TILES (1): SNV pileup of sorted reads by tiles of 64 positions; 0 = a wavefront per position */
     long host_loop_threads;    /* LFQ_HOST_LOOP_THREADS (8): threads (caller included) a host loop over reads / positions / events is cut for, at most 16 */
@@ -396,10 +396,8 @@ int lfq_launch_gather_heavy(const LfqWork &w, const lfq_col_counts *d_counts, in
 int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *stream);
 int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream);
 bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max_col_obs);
-/* d_heads: LFQ_COUNT_HEADS x 32 zeroed int32 (the resident form's work heads, LFQ_COUNT_PERSIST) or null; n_cu: the device's CUs */
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream,
-                     int32_t *d_heads = nullptr, int n_cu = 0);
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream);
 int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,
                     const lfq_col_counts *d_counts, const LfqWork &w, void *stream, bool relist = false);
 /* -t / --approx-threshold (snpcaller.c:1128-1142): clears the flag byte of the listed columns the Poisson gate gives up;

@@ -814,7 +814,7 @@ struct LfqCountArgs {           /* what the default filters need of LfqTracksDev
     int32_t min_bq4, min_alt_bq4, min_cov, pad_;
 };
 
-template <bool PACKED, bool STRAND, bool SAME_THR>
+template <bool PACKED, bool STRAND, bool SAME_THR, int UNROLL>
 __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq_col_counts *__restrict__ out,
                                                       uint8_t *__restrict__ flags, int64_t col, int lane)
 {
@@ -874,14 +874,21 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
         int i = lane;
         if (PACKED) {
             const uint2 *nt8 = reinterpret_cast<const uint2 *>(T.nt) + cbeg;
-            for (; i + LFQ_WAVE < n_ch; i += 2 * LFQ_WAVE) {
-                const uint2 na = nt8[i], nb2 = nt8[i + LFQ_WAVE];
-                const uint4 ba = bq16[i], bb = bq16[i + LFQ_WAVE];
-                const uint4 na4 = make_uint4(na.x, na.y, 0u, 0u), nb4 = make_uint4(nb2.x, nb2.y, 0u, 0u);
-                LFQ_FAST_CHUNK(i, na4, ba);
-                LFQ_FAST_CHUNK(i + LFQ_WAVE, nb4, bb);
+            for (; i + (UNROLL - 1) * LFQ_WAVE < n_ch; i += UNROLL * LFQ_WAVE) {
+                uint2 nv[UNROLL];
+                uint4 bv[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {          /* UNROLL chunks' loads in flight per lane */
+                    nv[u] = nt8[i + u * LFQ_WAVE];
+                    bv[u] = bq16[i + u * LFQ_WAVE];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const uint4 n4 = make_uint4(nv[u].x, nv[u].y, 0u, 0u);
+                    LFQ_FAST_CHUNK(i + u * LFQ_WAVE, n4, bv[u]);
+                }
             }
-            if (i < n_ch) {
+            for (; i < n_ch; i += LFQ_WAVE) {
                 const uint2 na = nt8[i];
                 const uint4 ba = bq16[i];
                 const uint4 na4 = make_uint4(na.x, na.y, 0u, 0u);
@@ -889,13 +896,19 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
             }
         } else {
             const uint4 *nt16 = reinterpret_cast<const uint4 *>(T.nt) + cbeg;
-            for (; i + LFQ_WAVE < n_ch; i += 2 * LFQ_WAVE) {
-                const uint4 na = nt16[i], nb4 = nt16[i + LFQ_WAVE];
-                const uint4 ba = bq16[i], bb = bq16[i + LFQ_WAVE];
-                LFQ_FAST_CHUNK(i, na, ba);
-                LFQ_FAST_CHUNK(i + LFQ_WAVE, nb4, bb);
+            for (; i + (UNROLL - 1) * LFQ_WAVE < n_ch; i += UNROLL * LFQ_WAVE) {
+                uint4 nv[UNROLL], bv[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    nv[u] = nt16[i + u * LFQ_WAVE];
+                    bv[u] = bq16[i + u * LFQ_WAVE];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    LFQ_FAST_CHUNK(i + u * LFQ_WAVE, nv[u], bv[u]);
+                }
             }
-            if (i < n_ch) {
+            for (; i < n_ch; i += LFQ_WAVE) {
                 const uint4 na = nt16[i];
                 const uint4 ba = bq16[i];
                 LFQ_FAST_CHUNK(i, na, ba);
@@ -968,58 +981,25 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
     }
 }
 
-/* one column per wavefront, WAVES columns per workgroup (4: the default.  8 / 16 exist for a caller that keeps two batches
- * in flight, LFQ_COUNT_WAVES_PER_WG: a retiring workgroup then frees two / four wave slots per SIMD at once, room for the
- * 512-thread workgroups of the other batch's DP kernels, which single slots never give) */
-template <bool PACKED, bool STRAND, bool SAME_THR, int WAVES>
+/* one column per wavefront, WAVES columns per workgroup.  16 is the default (LFQ_COUNT_WAVES_PER_WG: 4, 8, 16): a 1024-thread
+ * workgroup retires sixteen columns at once -- a quarter of the workgroups to dispatch (C3: 2.42 against 2.46 ms per
+ * launch) and, for a caller that keeps several batches queued without a gate, four wave slots per SIMD freed at a time,
+ * room for any workgroup of the other batch's DP kernels (a 256-thread workgroup's single slots starve the 512-thread
+ * ones: profiles/NOTES.md).  UNROLL: chunks in flight per lane; PRIO: s_setprio of the whole kernel (A/B knobs). */
+template <bool PACKED, bool STRAND, bool SAME_THR, int WAVES, int UNROLL, int PRIO>
 __global__ __launch_bounds__(64 * WAVES) void lfq_count_fast_kernel(LfqCountArgs T,
                                                                     lfq_col_counts *__restrict__ out,
                                                                     uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
+    if (PRIO > 0) {
+        __builtin_amdgcn_s_setprio(PRIO);
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t col = c0 + (int64_t)blockIdx.x * WAVES + wave;
     if (col >= c1) {
         return;
     }
-    lfq_count_column_fast<PACKED, STRAND, SAME_THR>(T, out, flags, col, lfq_lane());
-}
-
-/* The same work as a RESIDENT kernel: exactly n_cu x W workgroups whatever the batch (LFQ_COUNT_PERSIST = W), each wavefront
- * claiming slices of `slice` consecutive columns from LFQ_COUNT_HEADS heads (a head owns a contiguous range of the columns;
- * a wavefront starts at its workgroup's head and moves on to the next when one is exhausted; one 128-byte line per head).  Its
- * point is what it leaves free: with W = 6 two wave slots per SIMD, half of the registers and all of the LDS stay available
- * to the DP kernels of the previous batch for the whole launch, so that the two run beside each other instead of the count
- * kernel's single-slot refills starving every DP workgroup that needs more than one slot (profiles/NOTES.md). */
-template <bool PACKED, bool STRAND, bool SAME_THR>
-__global__ __launch_bounds__(256) void lfq_count_persist_kernel(LfqCountArgs T,
-                                                                lfq_col_counts *__restrict__ out,
-                                                                uint8_t *__restrict__ flags, int64_t c0, int64_t c1,
-                                                                int32_t *__restrict__ heads, int slice)
-{
-    const int lane = lfq_lane();
-    const int64_t n = c1 - c0;
-    int h = (int)(blockIdx.x % LFQ_COUNT_HEADS);
-    for (int tried = 0; tried < LFQ_COUNT_HEADS; tried++, h = (h + 1 == LFQ_COUNT_HEADS) ? 0 : h + 1) {
-        const int64_t h0 = n * h / LFQ_COUNT_HEADS, h1 = n * (h + 1) / LFQ_COUNT_HEADS;
-        int32_t *head = heads + h * 32;
-        if (tried > 0 && (int64_t)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= h1 - h0) {
-            continue;               /* somebody else's head, already exhausted: no atomic on it */
-        }
-        for (;;) {
-            int32_t at = 0;
-            if (lane == 0) {
-                at = atomicAdd(head, slice);
-            }
-            at = __builtin_amdgcn_readfirstlane(at);
-            if ((int64_t)at >= h1 - h0) {
-                break;
-            }
-            const int64_t e = min((int64_t)at + slice, h1 - h0);
-            for (int64_t i = at; i < e; i++) {
-                lfq_count_column_fast<PACKED, STRAND, SAME_THR>(T, out, flags, c0 + h0 + i, lane);
-            }
-        }
-    }
+    lfq_count_column_fast<PACKED, STRAND, SAME_THR, UNROLL>(T, out, flags, col, lfq_lane());
 }
 
 /* base_count() (plp.c:128-132) for every column: the bases of each nucleotide, whatever their quality -- what
@@ -1399,8 +1379,7 @@ bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max
 }
 
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream, int32_t *d_heads,
-                     int n_cu)
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream)
 {
     if (c1 <= c0) {
         return LFQ_OK;
@@ -1466,36 +1445,19 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         ca.min_cov = p.min_cov;
         ca.pad_ = 0;
         const int variant = (t.nt_packed ? 4 : 0) | (strand ? 2 : 0) | (same_thr ? 1 : 0);
-        if (kn.count_persist > 0 && d_heads && n_cu > 0) {
-            const unsigned blocks = (unsigned)std::min<int64_t>((int64_t)n_cu * kn.count_persist, (c1 - c0 + 3) / 4);
-            const int slice = kn.count_slice;
-#define LFQ_LAUNCH_P(PK, ST, SM)                                                                                     \
-    hipLaunchKernelGGL((lfq_count_persist_kernel<PK, ST, SM>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, ca, \
-                       d_counts, d_flags, c0, c1, d_heads, slice)
-            switch (variant) {
-            case 0: LFQ_LAUNCH_P(false, false, false); break;
-            case 1: LFQ_LAUNCH_P(false, false, true); break;
-            case 2: LFQ_LAUNCH_P(false, true, false); break;
-            case 3: LFQ_LAUNCH_P(false, true, true); break;
-            case 4: LFQ_LAUNCH_P(true, false, false); break;
-            case 5: LFQ_LAUNCH_P(true, false, true); break;
-            case 6: LFQ_LAUNCH_P(true, true, false); break;
-            default: LFQ_LAUNCH_P(true, true, true); break;
-            }
-#undef LFQ_LAUNCH_P
-            LFQ_HIP_TRY(hipGetLastError());
-            return LFQ_OK;
-        }
         const int wpw = kn.count_waves_per_wg;
         const unsigned blocks = (unsigned)((c1 - c0 + wpw - 1) / wpw);
-#define LFQ_LAUNCH_F(PK, ST, SM, W)                                                                                  \
-    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
+#define LFQ_LAUNCH_F(PK, ST, SM, W, U, PR)                                                                           \
+    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W, U, PR>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
                        d_counts, d_flags, c0, c1)
 #define LFQ_LAUNCH_FW(PK, ST, SM)                                                                                    \
     do {                                                                                                             \
-        if (wpw == 16) LFQ_LAUNCH_F(PK, ST, SM, 16);                                                                 \
-        else if (wpw == 8) LFQ_LAUNCH_F(PK, ST, SM, 8);                                                              \
-        else LFQ_LAUNCH_F(PK, ST, SM, 4);                                                                            \
+        if (wpw == 16 && kn.count_unroll == 4 && kn.count_prio) LFQ_LAUNCH_F(PK, ST, SM, 16, 4, 3);                  \
+        else if (wpw == 16 && kn.count_unroll == 4) LFQ_LAUNCH_F(PK, ST, SM, 16, 4, 0);                              \
+        else if (wpw == 16 && kn.count_prio) LFQ_LAUNCH_F(PK, ST, SM, 16, 2, 3);                                     \
+        else if (wpw == 16) LFQ_LAUNCH_F(PK, ST, SM, 16, 2, 0);                                                      \
+        else if (wpw == 8) LFQ_LAUNCH_F(PK, ST, SM, 8, 2, 0);                                                        \
+        else LFQ_LAUNCH_F(PK, ST, SM, 4, 2, 0);                                                                      \
     } while (0)
         switch (variant) {
         case 0: LFQ_LAUNCH_FW(false, false, false); break;

@@ -1,5 +1,5 @@
 """Whole-batch oracle runs on all host cores -- TEST INFRASTRUCTURE ONLY (the checker of bench.py's full-size
-concordance block and of tests/test_gpu_parity.py::test_config_c3_full_batch; never the thing measured).
+concordance block and of tests/test_gpu_parity.py::test_config_full_batch; never the thing measured).
 
 The reference's own full-size check is a whole-VCF comparison (tests/parallel.sh:40-51).  Here the synthetic workload
 of include/lofreq_synth.h is regenerated on the host range by range (oracle/synth_ref.c), every range runs through the
@@ -38,7 +38,16 @@ def _run_chunk(args):
         res, _ = orc.call_batch(host["nt"], host["bq"], host["baq"], host["mq"], None, host["col_off"],
                                 host["ref_base"], conf)
         em = np.nonzero(res["emitted"].any(axis=1))[0]
+        # the exact tails of the emitting columns (80-bit linear-space recurrence, orc_tail_truth): what the DEVICE's
+        # p-values are held to, next to the oracle's own (log-space, i.e. the reference's noise) values
+        truth = np.full((len(em), 3), np.nan)
+        for i, c in enumerate(em):
+            try:
+                truth[i] = orc.col_tail_truth(host, int(c), conf)[1]
+            except RuntimeError:
+                pass
         out.append({
+            "emit_truth_log": truth,
             "begin": begin, "n": n,
             "n_err_probs": res["n_err_probs"].copy(), "alt_counts": res["alt_counts"].copy(),
             "alt_raw_counts": res["alt_raw_counts"].copy(), "tested": res["tested"].astype(np.uint8),
@@ -129,12 +138,16 @@ LDBL_MIN = np.finfo(np.longdouble).tiny
 
 def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu_vcf_text=None, conf_kw=None,
                 default_filter=False, procs=None, columns=None, chrom="synth", pv_tol=1e-10, pv_deep_log=600.0,
-                pv_deep_tol=1e-9, chunk_cols=None):
+                pv_noise_a=0.16, pv_truth_tol=2e-11, chunk_cols=None):
     """Compare one device batch of the synthetic workload with the oracle.
 
     gpu_counts  COL_COUNTS_DTYPE[ncols] (dense device output: n_err_probs, alt_counts, alt_raw_counts, tested)
     gpu_recs    SNV_RECORD_DTYPE[] of the same batch (column order)
     columns     None = every column; else a sorted array of column indices (each its own one-column range)
+    p-values: against the oracle 1e-10 up to |log p| = pv_deep_log and, beyond, the noise bound of the reference's own
+    log-space arithmetic, max(pv_tol, pv_noise_a * ulp(|log p|) * depth) (tests/util.py::pv_deep_bound, measured in
+    tests/test_oracle_kat.py); against the exact 80-bit recurrence (every record whose tail is inside the long-double
+    range) pv_truth_tol.
     -> dict (JSON-able summary; "identical" is the verdict)"""
     t0 = time.perf_counter()
     tested = np.asarray(gpu_counts["tested"]).astype(np.int64)
@@ -162,18 +175,18 @@ def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu
                 bad_counts.append((int(b), f))
         if not np.array_equal(g["tested"].astype(np.uint8), r["tested"]):
             bad_counts.append((int(b), "tested"))
-        for c, row, ref in zip(r["emit_cols"], r["emit_rows"], r["emit_ref"]):
+        for c, row, ref, tr in zip(r["emit_cols"], r["emit_rows"], r["emit_ref"], r["emit_truth_log"]):
             for a in range(3):
                 if row["emitted"][a]:
-                    exp.append((int(c), a, row, int(ref)))
+                    exp.append((int(c), a, row, int(ref), float(tr[a])))
     in_scope = gpu_recs if columns is None else gpu_recs[np.isin(gpu_recs["col"], columns)]
     # records field by field
     mism = []
-    max_d = {"le": [0.0, 0], "gt": [0.0, 0]}
+    max_d = {"le": [0.0, 0], "gt": [0.0, 0, 0.0], "truth": [0.0, 0]}
     n_sentinel = 0
     if len(exp) != len(in_scope):
         mism.append("record count: oracle %d, device %d" % (len(exp), len(in_scope)))
-    for (c, a, row, ref), g in zip(exp, in_scope):
+    for (c, a, row, ref, truth_log), g in zip(exp, in_scope):
         rcode = b"ACGT".index(bytes([ref]))
         alt = int(row["alt_base"][a])
         acode = b"ACGT".index(bytes([alt]))
@@ -192,13 +205,23 @@ def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu
             if pv_o != pv_g:
                 mism.append("col %d allele %d: sentinel p-value" % (c, a))
             continue
-        d = abs(_log_of(pv_g) - _log_of(pv_o))
-        deep = abs(_log_of(pv_o)) > pv_deep_log
+        lp = _log_of(pv_o)
+        d = abs(_log_of(pv_g) - lp)
+        deep = abs(lp) > pv_deep_log
+        tol = max(pv_tol, pv_noise_a * float(np.spacing(abs(lp))) * depth) if deep else pv_tol
         st = max_d["gt" if deep else "le"]
         st[0] = max(st[0], d)
         st[1] += 1
-        if d > (pv_deep_tol if deep else pv_tol):
-            mism.append("col %d allele %d: |dlog p| %.3g" % (c, a, d))
+        if deep:
+            st[2] = max(st[2], d / tol)
+        if d > tol:
+            mism.append("col %d allele %d: |dlog p| %.3g (bound %.3g)" % (c, a, d, tol))
+        if np.isfinite(truth_log) and truth_log > -11300.0:         # (below: the 80-bit recurrence's own range ends)
+            dt = abs(_log_of(pv_g) - truth_log)
+            max_d["truth"][0] = max(max_d["truth"][0], dt)
+            max_d["truth"][1] += 1
+            if dt > pv_truth_tol:
+                mism.append("col %d allele %d: device %.3g off the exact tail" % (c, a, dt))
     # final filter + VCF text, as `lofreq call` ends (lofreq_call.c:1506-1538)
     vcf_identical = None
     n_lines = None
@@ -208,7 +231,7 @@ def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu
             conf_end.bonf_subst = 1
         thr = L.orc_snvqual_thresh(conf_end.sig, conf_end.bonf_subst) if conf_end.bonf_dynamic else 0
         rows = []
-        for (c, a, row, ref) in exp:
+        for (c, a, row, ref, _t) in exp:
             rcode = b"ACGT".index(bytes([ref]))
             acode = b"ACGT".index(bytes([int(row["alt_base"][a])]))
             rows.append((c, ref, int(row["alt_base"][a]), int(row["qual"][a]), depth, int(row["alt_raw_counts"][a]),
@@ -239,6 +262,10 @@ def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu
         "sentinel_pvalues": n_sentinel,
         "max_dlogp_upto_600": max_d["le"][0], "n_pvalues_upto_600": max_d["le"][1],
         "max_dlogp_beyond_600": max_d["gt"][0], "n_pvalues_beyond_600": max_d["gt"][1],
+        "max_dlogp_beyond_600_over_bound": max_d["gt"][2],
+        "bound_beyond_600": "max(%g, %g * ulp(|log p|) * depth): the reference's own log-space noise (tests/test_oracle_kat.py)" % (pv_tol, pv_noise_a),
+        "max_dlogp_device_vs_80bit_truth": max_d["truth"][0], "n_pvalues_vs_80bit_truth": max_d["truth"][1],
+        "tol_device_vs_80bit_truth": pv_truth_tol,
         "vcf_lines": n_lines, "vcf_text_identical": vcf_identical,
         "identical": (not bad_counts) and (not mism), "mismatches": (["counts: %s" % (bad_counts[:5],)] if bad_counts else []) + mism[:10],
         "oracle_s": t_oracle, "oracle_processes": procs or default_procs(), "total_s": time.perf_counter() - t0,

@@ -38,6 +38,8 @@ def pytest_terminal_summary(terminalreporter):
         return
     rows = [(k, v) for k, v in util.PV_ERR_MAX.items() if v[1]]
     if rows:
-        terminalreporter.write_line("p-value parity, max |dlog p| observed (tolerance 1e-10 up to |log p| = 600, 1e-9 beyond):")
+        terminalreporter.write_line("p-value parity, max |dlog p| observed (tolerance 1e-10 up to |log p| = 600; beyond, the noise "
+                                    "bound of the reference's own arithmetic, %g * ulp(|log p|) * N):" % util.PV_NOISE_A)
         for k, v in rows:
-            terminalreporter.write_line("    %-16s %.3g over %d records" % (k, v[0], v[1]))
+            terminalreporter.write_line("    %-16s %.3g over %d records%s" % (
+                k, v[0], v[1], (", at most %.2f of the bound" % v[2]) if len(v) > 2 else ""))

@@ -1,4 +1,4 @@
-"""CPU tests of oracle/full_check.py (the whole-batch checker of bench.py and test_config_c3_full_batch): ranges run in
+"""CPU tests of oracle/full_check.py (the whole-batch checker of bench.py and test_config_full_batch): ranges run in
 separate processes from their tested-column prefix reproduce ONE sequential run of the restated call_snvs loop
 (lofreq_call.c:735-879) over the whole batch -- running Bonferroni factor included -- and a deviation is reported."""
 import numpy as np

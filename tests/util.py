@@ -149,38 +149,51 @@ def log_of(pv):
     return float(np.log(np.longdouble(pv)))
 
 
-# Tolerance per record (north_star: 1e-10 relative).  The reference's log-space recurrence carries its own rounding
-# noise of about ulp(|log p|) * sqrt(N) -- measured against an 80-bit exact recurrence in
-# test_oracle_kat.py::test_linear_dp_truth_and_reference_noise: 2.6e-11 at log p = -144, 2.7e-10 at log p = -3670
-# (N = 1e4) -- so beyond |log p| = 600 (p < 1e-260) no independent implementation can agree with it to 1e-10 and the
-# bar there is 1e-9; everything else, i.e. every p-value that decides a call or a QUAL below 2600, is held to 1e-10.
+# Tolerance per record (north_star: 1e-10 relative) -- a BOUND, not a constant.  Every p-value with |log p| <= 600, i.e.
+# every one that decides a call or a QUAL below 2600, is held to 1e-10.  Beyond that the reference's own log-space
+# recurrence is the limit: each of its N row updates rounds numbers of magnitude ~|log p|, and against an exact (80-bit,
+# linear-space) recurrence it is off by up to a * ulp(|log p|) * N.  The constant is MEASURED in
+# test_oracle_kat.py::test_linear_dp_truth_and_reference_noise (the oracle = the reference's arithmetic against
+# orc_tail_truth).  Identical error probabilities are the worst case -- the roundings of consecutive rows line up and add
+# linearly: a = 0.06 .. 0.12 for N = 1e4 .. 4.5e4, |log p| = 144 .. 3670 (2.7e-10 at N = 1e4, log p = -3670; 6.3e-10 at
+# N = 45 000, log p = -988) --, ragged ones stay two orders of magnitude below (a random walk).  PV_NOISE_A = 0.16 is the
+# worst measured value with a margin of 1.3, asserted there.  No independent implementation can agree with the reference
+# better than the reference's own noise; the DEVICE's values are held to 2e-11 of the exact recurrence by
+# test_deep_tail_against_80bit_truth and, for every record of the full C3 / C2 batches, by oracle/full_check.py.
 PV_DEEP_LOG = 600.0
-PV_DEEP_TOL = 1e-9
-PV_ERR_MAX = {"|log p| <= 600": [0.0, 0], "|log p| > 600": [0.0, 0]}     # [max observed |dlog|, records compared]
+PV_NOISE_A = 0.16
+PV_ERR_MAX = {"|log p| <= 600": [0.0, 0], "|log p| > 600": [0.0, 0, 0.0]}     # [max observed |dlog|, records compared(, max |dlog| / bound)]
 
 
-def pv_tol_for(pv_ref):
-    return PV_DEEP_TOL if abs(log_of(pv_ref)) > PV_DEEP_LOG else PV_LOG_TOL
+def pv_deep_bound(logp, n_obs):
+    """the bar for a p-value beyond |log p| = 600 of a column with n_obs error probabilities"""
+    return max(PV_LOG_TOL, PV_NOISE_A * float(np.spacing(abs(float(logp)))) * max(float(n_obs), 1.0))
+
+
+def pv_tol_for(pv_ref, n_obs=10000):
+    lp = log_of(pv_ref)
+    return pv_deep_bound(lp, n_obs) if abs(lp) > PV_DEEP_LOG else PV_LOG_TOL
 
 
 def assert_pvalue_close(pv_gpu, pv_ref, tol=None, ctx="", n_obs=None):
-    """Sentinels must match exactly; finite values within `tol` relative (default: per record, by |log p|).
-    n_obs: the column's depth when it is beyond the 1e4 the bars above were measured at -- the reference's noise grows
-    like sqrt(N) (measured: 4.7e-10 against the 80-bit recurrence at N = 45 000, K = 13 500, log p = -8096), and so does
-    the deep-tail bar; only tests/stress_gpu.py has such columns."""
+    """Sentinels must match exactly; finite values within `tol` (default: per record -- 1e-10 up to |log p| = 600, the
+    noise bound of the reference's own arithmetic beyond, pv_deep_bound).
+    n_obs: the column's depth (number of error probabilities; an upper bound such as the coverage will do).  Where a
+    caller does not know it, 10 000 is assumed -- deeper columns than that only exist in tests that pass it."""
     pv_gpu, pv_ref = np.longdouble(pv_gpu), np.longdouble(pv_ref)
     if pv_ref == LDBL_MAX or pv_ref == LDBL_MIN or pv_gpu == LDBL_MAX or pv_gpu == LDBL_MIN:
         assert pv_gpu == pv_ref, "sentinel mismatch %s: gpu=%r ref=%r" % (ctx, pv_gpu, pv_ref)
         return
-    d = abs(log_of(pv_gpu) - log_of(pv_ref))
-    deep = abs(log_of(pv_ref)) > PV_DEEP_LOG
+    lp = log_of(pv_ref)
+    d = abs(log_of(pv_gpu) - lp)
+    deep = abs(lp) > PV_DEEP_LOG
     if tol is None:
-        tol = PV_DEEP_TOL if deep else PV_LOG_TOL
-        if deep and n_obs is not None and n_obs > 1e4:
-            tol = tol * (n_obs / 1e4) ** 0.5
+        tol = pv_deep_bound(lp, 10000 if n_obs is None else n_obs) if deep else PV_LOG_TOL
     st = PV_ERR_MAX["|log p| > 600" if deep else "|log p| <= 600"]
     st[0] = max(st[0], d)
     st[1] += 1
+    if deep:
+        st[2] = max(st[2], d / tol)
     assert d <= tol, "p-value mismatch %s: gpu=%r ref=%r |dlog|=%g (tolerance %g)" % (ctx, pv_gpu, pv_ref, d, tol)
 
 
