@@ -1141,8 +1141,8 @@ def main():
     pipelined = my_bins is None and not args.no_pipeline
     layer2 = world == 1 and not args.shard_path
     if pipelined:
-        # one context per batch in flight: three in the automatic mode (two batches in flight take two, three take three)
-        NCTX = max(args.in_flight, 2) if args.in_flight else 3
+        # one context per batch in flight: four in the automatic mode
+        NCTX = max(args.in_flight, 2) if args.in_flight else 4
         callers = [caller] + [la.SnvCaller(local_rank) for _ in range(NCTX - 1)]
         for c_ in callers[1:]:
             c_.set_dense_strand_counts(False)
@@ -1241,11 +1241,13 @@ def main():
             # where the DP tail is short latency-bound work next to a short count kernel: 1000x; the device-side gate at the
             # end of the previous batch takes the host's wake-up + launch latency out of every step): measured here,
             # outside the timed region
-            # (first in the list = the default: batches one after another on the device, three queued, so that a host thread
+            # (first in the list = the default: batches one after another on the device, four queued, so that a host thread
             # that loses the CPU for a few milliseconds -- the boxes grant 16 of 256 cores and have neighbours -- does not
-            # leave the device idle; another mode has to beat it by 2 %)
+            # leave the device idle; another mode has to beat the best one before it by 2 %.  "none": the count kernel of
+            # batch k + 1 beside the DP kernels of batch k -- pays at 10 000x now that the count kernel runs 1024-thread
+            # workgroups and the queue is deep enough to keep count kernels back to back; "tail" pays at 1000x)
             modes = [(2, "end"), (2, "tail"), (2, "none")] if args.in_flight == 2 else \
-                    [(3, "end"), (2, "end"), (2, "tail"), (1, "tail")]
+                    [(4, "end"), (4, "none"), (3, "tail"), (1, "tail")]
             trial = {}
             for m in modes + modes:
                 set_mode(*m)
