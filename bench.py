@@ -633,6 +633,102 @@ def make_tile(cfg, tile_len, seed=11):
     return R
 
 
+def genome_baq_roofline(args, cfg_name, cfg, caller, la, R, dev):
+    """roofline of the dominant kernel of a reads -> VCF run, lfq_baq_reg_kernel: one bin's BAQ (+ IDAQ) call on a resident
+    read set (uploads done), HIP events around its kernels on the stream they are launched on (lfq_last_baq_times), the
+    traffic and instruction counters from rocprofv3 --pmc passes over a child of this command.  The kernel is bound by what it
+    issues (FP64, one wavefront per SIMD), not by HBM: `frac` (algorithmic bytes against the HBM peak) is small by nature;
+    `issue` says how busy the vector units were."""
+    import torch
+    rs = la.ReadSet.from_arrays(caller, R)
+    rs.baq(extended=True, idaq=cfg["call_indels"])
+    torch.cuda.synchronize(dev)
+    ms, t = [], None
+    for _ in range(3):
+        rs.baq(extended=True, idaq=cfg["call_indels"])
+        t = caller.baq_times()
+        ms.append(t["ms_kernels"])
+    rs.close()
+    call_ms = float(np.median(ms))
+    n_indel = int(R.get("n_indel_reads", 0)) if cfg["call_indels"] else 0
+    # seq + qual in, one reference window per read in (read length + 2 x 7 band), lb out; ai / ad out for the reads with an indel
+    alg = 3 * t["n_bases"] + t["n_reads"] * (150 + 14) + 2 * 150 * n_indel
+    achieved = alg / (call_ms * 1e-3) / 1e9
+    pmc = None
+    if not args.no_pmc:
+        child = ["--config", cfg_name, "--genome-scale", str(args.genome_scale)]
+        f = pmc_pass("FETCH_SIZE", child)
+        w = pmc_pass("WRITE_SIZE", child) if f is not None else None
+        v = pmc_pass("SQ_INSTS_VALU", child) if f is not None else None
+        if f and w and v:
+            baq = lambda d: sum(x[0] for k, x in d.items() if k.startswith("lfq_baq_"))
+            calls = 2.0                             # the child runs two calls
+            pmc = {"fetch_kib": baq(f) / calls, "write_kib": baq(w) / calls, "valu_insts": baq(v) / calls,
+                   "source": "rocprofv3 --pmc passes spawned by this run (two BAQ calls of one bin; all lfq_baq_* kernels of a call summed)"}
+    traffic = (2.0 * pmc["fetch_kib"] + pmc["write_kib"]) * 1024.0 if pmc else None
+    return {
+        "bound": "hbm", "kernel": "lfq_baq_reg_kernel (all instantiations of one bin's call: %d launches)" % t["n_launches"],
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "bytes_per_launch": alg, "launch": "one lfq_readset_baq call = one bin = %d reads" % t["n_reads"],
+        "avg_launch_ms": call_ms, "ms_of_the_three_calls": ms,
+        "traffic_frac": (traffic / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "traffic_over_algorithmic_bytes": (traffic / alg) if traffic else None,
+        "issue": ({"valu_wave_instructions": pmc["valu_insts"],
+                   "frac_of_issue_slots": pmc["valu_insts"] / (N_SIMD * CLK_HZ / 4.0 * call_ms * 1e-3),
+                   "note": "SQ_INSTS_VALU / (1024 SIMDs x clock / 4 x the call's kernel time): the kernel's real bound "
+                           "(FP64 recurrence, -ffp-contract=off, one wavefront per SIMD: DESIGN 6b)"} if pmc else None),
+        "pmc": pmc,
+        "note": "bound by FP64 issue at one wavefront per SIMD, not by HBM; reads / s in the kernel: %.3g" % (t["n_reads"] / (call_ms * 1e-3)),
+    }
+
+
+def genome_cpu_baseline(cfg, sample_len):
+    """the oracle's reads -> VCF chain (tests/oracle_chain.py: BAQ / IDAQ per read, compile_plp_col, call_indels + call_snvs,
+    the epilogue of main_call) on ONE pinned core over a sample of the same workload: the first `sample_len` bases of a bin"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_chain as oc
+    import pyoracle as orc
+    orc.build()
+    pinned = None
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        pinned = sorted(old_aff)[0]
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        pass
+    try:
+        R = make_tile(cfg, sample_len)
+        P = dict(R)
+        t0 = time.perf_counter()
+        orc.baq_idaq_reads(P, extended=True, idaq=cfg["call_indels"], procs=1)
+        t1 = time.perf_counter()
+        kw = dict(flag=1 | 2 | (8 if cfg["call_indels"] else 0))
+        if cfg["targets"]:
+            tg = R["target"]
+            edges = np.flatnonzero(np.diff(np.concatenate([[0], tg, [0]])))
+            targets = [("synth", int(a), int(b)) for a, b in zip(edges[0::2], edges[1::2])]
+            out = oc.call_targets(orc, P, R["ref"], targets, kw)
+            ncols = int(tg.sum())
+        else:
+            out = oc.call_region(orc, P, R["ref"], 0, sample_len, kw, call_indels=cfg["call_indels"], no_default_filter=False)
+            ncols = len(out["col_pos"])
+        t2 = time.perf_counter()
+    finally:
+        if old_aff is not None:
+            try:
+                os.sched_setaffinity(0, old_aff)
+            except OSError:
+                pass
+    return {"value": ncols / (t2 - t0), "unit": "columns/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+            "host_cpus": os.cpu_count(), "pinned_to_core": pinned,
+            "sample": "the first %d bases of a bin of the same workload (%d reads, %d called columns): %.1f s on one pinned core; "
+                      "BAQ%s %.1f s / pileup + calls %.1f s"
+                      % (sample_len, int(R["n"]), ncols, t2 - t0, " + IDAQ" if cfg["call_indels"] else "", t1 - t0, t2 - t1),
+            "reads_per_s": int(R["n"]) / (t2 - t0), "vcf_lines_of_the_sample": len(out["lines"])}
+
+
 def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev, comm_ranks):
     """One step = the whole synthetic genome: every bin (plan_regions, dealt to the ranks) goes reads -> BAQ (+ IDAQ) ->
     device pileup(s) -> SNV (+ indel) tests on its owner's GPU; then the shard exchange (per-bin test counts ->
@@ -669,6 +765,13 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         L.lfq_set_indel_arrays_on_host(c_.h, 0)
         outs.append((torch.zeros(cap * 64, dtype=torch.uint8, device=dev), torch.zeros(cap * 128, dtype=torch.uint8, device=dev)))
     target = R["target"]
+    if args.pmc_child:              # counter passes: two BAQ (+ IDAQ) calls of one bin, nothing else
+        rs = la.ReadSet.from_arrays(caller, R)
+        for _ in range(2):
+            rs.baq(extended=True, idaq=cfg["call_indels"])
+        torch.cuda.synchronize(dev)
+        rs.close()
+        return None
 
     def start(caller):
         rs = la.ReadSet.from_arrays(caller, R)
@@ -818,6 +921,17 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_cols)
     dt, called = float(tmax.item()), int(tot_cols.item())
+    roof = base = None
+    if rank == 0 and world == 1:
+        try:
+            roof = genome_baq_roofline(args, cfg_name, cfg, caller, la, R, dev)
+        except Exception as e:          # the measured line survives a failed counter pass
+            roof = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            try:
+                base = genome_cpu_baseline(cfg, min(tile_len, args.cpu_sample_cols or (60000 if cfg["call_indels"] else 400000)))
+            except Exception as e:
+                base = {"error": repr(e)}
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
     for c_ in callers[1:]:
         c_.close()
@@ -829,15 +943,16 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         "value": called * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (one bin's reads, reused for every bin of the genome)",
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roof, "cpu_baseline": base,
         "config": {"workload": "%s: %s" % (cfg_name, cfg["what"]), "genome_len": glen, "called_columns": called, "bins": nb,
                    "bins_rank0": len(my), "host_threads_per_rank": n_thr, "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": int(R["n"]) * nb,
                    "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
                    "snv_tests": int(conf.num_snv_tests), "indel_tests": int(conf.num_indel_tests),
                    "snv_records_before_filter": nrecs[0], "indel_records": nrecs[1],
                    "vcf_lines": text.count("\n"), "vcf_sha256": hashlib.sha256(text.encode()).hexdigest(),
-                   "note": "1 step = the whole genome; roofline / cpu_baseline belong to the default (C3) line: the dominant kernel "
-                           "here is lfq_baq_reg_kernel, FP64-issue-bound (DESIGN 6b, profiles/r04_*)"},
+                   "speedup_vs_cpu_1thread": (called * args.steps / dt / base["value"]) if (base and base.get("value")) else None,
+                   "note": "1 step = the whole genome; the dominant kernel is lfq_baq_reg_kernel, FP64-issue-bound (DESIGN 6b): "
+                           "`roofline` is one bin's BAQ call on a resident read set"},
     }, text
 
 
@@ -1009,7 +1124,7 @@ def main():
 
     if genome_cfg:
         out = bench_genome(args, args.config, caller, la, shard, dist, world, rank, dev, xdev, comm_ranks)
-        if rank == 0:
+        if rank == 0 and out is not None:
             line, text = out
             if args.vcf_out:
                 open(args.vcf_out, "w").write(text)
@@ -1188,6 +1303,7 @@ def main():
         # LFQ_BENCH_TRACE_STEPS=1: the host's side of every step of the timed blocks (wait / finish / submit, seconds) and the
         # batch's kernel time go to stderr afterwards -- where a slow step lost its time
         step_trace = [] if os.environ.get("LFQ_BENCH_TRACE_STEPS") else None
+        alone_kt = {}           # kernel times of a warm-up block in which the batches' kernels did not overlap
 
         def set_mode(n, gate):
             in_flight["n"], in_flight["gate"] = n, gate
@@ -1254,9 +1370,11 @@ def main():
                 run_steps(2)
                 torch.cuda.synchronize(dev)
                 t0_ = time.perf_counter()
-                run_steps(12)
+                _, acc_ = run_steps(12)
                 torch.cuda.synchronize(dev)
                 trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0_) / 12)
+                if m[1] == "end" or m[0] == 1:      # one batch's kernels at a time: the kernels' own durations
+                    alone_kt.update({x: acc_[x] / 12 for x in acc_})
             if world > 1:                           # one choice for all ranks
                 tt = torch.tensor([trial[m] for m in modes], dtype=torch.float64, device=xdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1339,7 +1457,10 @@ def main():
         traffic = pmc["traffic"] if pmc else None
         if pmc and pmc.get("kernel"):
             count_name = pmc["kernel"]
-        dp_ms = kt["ms_dp"]
+        overlapped = bool(pipelined and in_flight["n"] >= 2 and in_flight["gate"] != "end")
+        # kernels of consecutive batches beside each other: a kernel's duration is then what it takes while sharing the machine;
+        # the DP span and the count kernel's own rate are those of the warm-up block that ran batch after batch
+        dp_ms = alone_kt["ms_dp"] if (overlapped and alone_kt.get("ms_dp")) else kt["ms_dp"]
         valu_busy = None
         if pmc and pmc.get("valu_insts_dp") and dp_ms > 0:
             # wave-instructions issued by the DP kernels / what 1024 SIMDs can issue in the DP span (one VALU
@@ -1397,6 +1518,16 @@ def main():
                 "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and dom_ms > 0 else None,
                 "traffic_over_layout_bytes": (traffic / moved) if traffic and moved else None,
                 "frac_of_measured_copy_peak": achieved / 6290.0,
+                # the count kernel of batch k + 1 ran beside the DP kernels of batch k in the timed region (gate "none" /
+                # "tail"): `achieved` above is its rate while sharing the machine; this is its rate in the warm-up block
+                # that ran the same batches one after another (gate "end")
+                "kernel_alone": ({"avg_launch_ms": alone_kt["ms_count"] / n_launch,
+                                  "achieved": moved / (alone_kt["ms_count"] / n_launch * 1e-3) / 1e9,
+                                  "frac": moved / (alone_kt["ms_count"] / n_launch * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                 if (pipelined and overlapped and alone_kt.get("ms_count")) else None),
+                # the whole step against the same peak: the bytes the count kernel moves / the step's wall time
+                "step": {"achieved": moved * n_launch / (ms_per_step * 1e-3) / 1e9,
+                         "frac": moved * n_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "pmc": {k: pmc[k] for k in ("fetch_kib", "write_kib", "source")} if pmc else None,
                 "algorithmic_8d": {"bytes_per_launch": alg_bytes, "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
                                    "note": "SURVEY 8(d): 4*depth+80 B per column; the default filter configuration needs only the "
@@ -1404,6 +1535,7 @@ def main():
             },
             "dp": {
                 "cells": work["cells"], "rows": work["rows"], "span_ms": dp_ms,
+                "span_ms_timed_region": kt["ms_dp"],
                 "cells_per_s": work["cells"] / (dp_ms * 1e-3) if dp_ms > 0 else None,
                 "valu_busy": valu_busy,
                 "valu_insts_per_step": pmc.get("valu_insts_dp") if pmc else None,

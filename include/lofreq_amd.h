@@ -37,7 +37,7 @@ extern "C" {
 /* 2: lfq_conf grew to 80 bytes (approx_threshold_n), lfq_dp_work gained n_approx_pruned, lfq_filter_records_ex.
  * A caller compiled against another version must not run: compare lfq_abi_version() with this value once, as the
  * bindings in integration/ and the Python loader do. */
-/* 4: lfq_set_batch_gate; lfq_call_snvs_collect refuses h_counts for a batch whose dense entries are sparse. */
+/* 4: lfq_set_batch_gate, lfq_last_baq_times; lfq_call_snvs_collect refuses h_counts for a batch whose dense entries are sparse. */
 #define LFQ_ABI_VERSION 4
 
 typedef enum lfq_status {
@@ -649,6 +649,14 @@ typedef struct lfq_kernel_times {
     int32_t n_segments; /* count-kernel launches in this batch */
 } lfq_kernel_times;
 int lfq_last_kernel_times(lfq_ctx *ctx, lfq_kernel_times *t);
+/* the BAQ kernels of the context's last lfq_readset_baq call (waits for them): first narrow-band launch -> everything done,
+ * on the device's clock; the main-stream launches in between; the call's reads and bases.  All 0 before the first call. */
+typedef struct lfq_baq_times {
+    float ms_kernels;
+    int32_t n_launches;
+    int64_t n_reads, n_bases;
+} lfq_baq_times;
+int lfq_last_baq_times(lfq_ctx *ctx, lfq_baq_times *t);
 
 /* --- DP work of the last batch (device counters; SURVEY 8d "ALGORITHMIC DP work", the secondary roofline) ---
  * cells = sum over the tested columns of sum_{n = 1..N*} min(n, K): N* = the kept row at which this implementation's

@@ -54,6 +54,10 @@ class KernelTimes(C.Structure):
                 ("ms_dp_big", C.c_float), ("n_segments", C.c_int32)]
 
 
+class BaqTimes(C.Structure):
+    _fields_ = [("ms_kernels", C.c_float), ("n_launches", C.c_int32), ("n_reads", C.c_int64), ("n_bases", C.c_int64)]
+
+
 class DpWork(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("cells", "rows", "n_light", "n_mid", "n_big", "n_light_retry",
                                          "bytes_read_count", "bytes_written_count", "n_approx_pruned")]
@@ -119,7 +123,7 @@ EXPORTS = [
     "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_call_snvs_submit", "lfq_call_snvs_wait", "lfq_call_snvs_collect", "lfq_set_dense_strand_counts", "lfq_set_dense_counts", "lfq_set_batch_gate", "lfq_set_indel_arrays_on_host", "lfq_finalize_pvals",
     "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_format_vcf", "lfq_snvqual_thresh", "lfq_sb_phred",
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
-    "lfq_synth_fill_device", "lfq_synth_fill_device_layout", "lfq_last_kernel_times", "lfq_last_dp_work",
+    "lfq_synth_fill_device", "lfq_synth_fill_device_layout", "lfq_last_kernel_times", "lfq_last_baq_times", "lfq_last_dp_work",
     "lfq_indel_batch_device", "lfq_call_indel_tests_batch", "lfq_call_indels_batch", "lfq_format_indel_record",
     "lfq_filter_indel_records", "lfq_baq_batch", "lfq_baq_idaq_batch", "lfq_pileup_snv_tracks",
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
@@ -182,6 +186,7 @@ def load():
     L.lfq_set_dense_strand_counts.argtypes = [vp, C.c_int]
     L.lfq_set_dense_counts.argtypes = [vp, C.c_int]
     L.lfq_set_batch_gate.argtypes = [vp, C.c_int]
+    L.lfq_last_baq_times.argtypes = [vp, C.POINTER(BaqTimes)]
     L.lfq_set_indel_arrays_on_host.argtypes = [vp, C.c_int]
     L.lfq_set_baq_hmm_params.argtypes = [vp, C.c_float, C.c_float]
     L.lfq_call_snvs_submit.argtypes = [vp, C.POINTER(Conf), C.POINTER(Tracks), C.c_int]

@@ -164,6 +164,12 @@ class SnvCaller:
         """lfq_set_dense_counts: off = snv_batch_device may leave the dense entries of untested columns unwritten"""
         _lib.check(self.L.lfq_set_dense_counts(self.h, 1 if on else 0), "lfq_set_dense_counts")
 
+    def baq_times(self):
+        """lfq_last_baq_times: the BAQ kernels of this context's last read-set BAQ call -> dict (ms_kernels, n_launches, n_reads, n_bases)"""
+        t = _lib.BaqTimes()
+        _lib.check(self.L.lfq_last_baq_times(self.h, C.byref(t)), "lfq_last_baq_times")
+        return {"ms_kernels": float(t.ms_kernels), "n_launches": int(t.n_launches), "n_reads": int(t.n_reads), "n_bases": int(t.n_bases)}
+
     GATES = {"tail": 0, "end": 1, "none": 2}       # LFQ_GATE_TAIL / _END / _NONE (include/lofreq_amd.h)
 
     def set_batch_gate(self, gate):

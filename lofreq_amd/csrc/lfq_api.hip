@@ -476,6 +476,8 @@ void lfq_destroy(lfq_ctx *c)
         }
         if (c->h_pin2) (void)hipHostFree(c->h_pin2);
         if (c->d_detlim) (void)hipFree(c->d_detlim);
+        if (c->ev_baq_t[0]) (void)hipEventDestroy(c->ev_baq_t[0]);
+        if (c->ev_baq_t[1]) (void)hipEventDestroy(c->ev_baq_t[1]);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);
         if (c->d_baq_expect) (void)hipFree(c->d_baq_expect);
         if (c->d_baq_tmp8) (void)hipFree(c->d_baq_tmp8);

@@ -335,6 +335,9 @@ struct lfq_ctx {
     int dense_counts;                /* lfq_set_dense_counts: 0 = a caller's dense array may keep stale entries for untested columns */
     int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
     int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
+    hipEvent_t ev_baq_t[2];          /* around the BAQ kernels of the last lfq_readset_baq / lfq_baq_batch call (timing; created on first use) */
+    int32_t baq_launches;            /* kernel launches between them on the context's stream */
+    int64_t baq_reads, baq_bases;    /* reads / bases of that call */
     int batch_gate;                  /* lfq_set_batch_gate: what this context's next count kernel waits for (LFQ_GATE_*) */
     int lazy_now;                    /* this batch: strand counts only for the columns of the sparse output */
     int64_t sub_ncols;               /* batch submitted with lfq_call_snvs_submit and not collected yet: its columns, else -1 */

@@ -859,6 +859,16 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         if (beside && hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
             rc = LFQ_ERR_HIP;       /* the side streams start after the uploads / memsets queued on c->stream so far */
         }
+        /* timing events around the call's BAQ kernels (lfq_last_baq_times) */
+        if (!c->ev_baq_t[0] && (hipEventCreate(&c->ev_baq_t[0]) != hipSuccess || hipEventCreate(&c->ev_baq_t[1]) != hipSuccess)) {
+            rc = LFQ_ERR_HIP;
+        }
+        if (rc == LFQ_OK && hipEventRecord(c->ev_baq_t[0], c->stream) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        }
+        c->baq_launches = 0;
+        c->baq_reads = n;
+        c->baq_bases = n_bases;
         {
             LfqBaqArgs Ap = A;                      /* the plain instantiation: no indel table */
             Ap.itab = nullptr;
@@ -880,6 +890,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                 Ap.nflag = (c->d_baq_nflag && !lfq_knobs().baq_one_variant) ? c->d_baq_nflag + first / 64 : nullptr;
                 if (rc == LFQ_OK) {
                     rc = lfq_launch_baq(Ap, cnt, 1, c->stream, Ap.nflag ? 1 : 0);
+                    c->baq_launches++;
                     if (Ap.nflag) {
                         with_n.push_back({Ap, cnt});
                     }
@@ -929,6 +940,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         for (int64_t first = n_plain; rc == LFQ_OK && first < n_narrow; first += waves_n * 64) {
             A.first_read = (int32_t)first;
             rc = lfq_launch_baq(A, std::min<int64_t>(waves_n * 64, n_narrow - first), 1, c->stream);
+            c->baq_launches++;
         }
         if (beside) {
             if (rc == LFQ_OK && (hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess
@@ -945,6 +957,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
                 rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n - first), 0, c->stream);
             }
         }
+    }
+    if (rc == LFQ_OK && c->ev_baq_t[1] && hipEventRecord(c->ev_baq_t[1], c->stream) != hipSuccess) {
+        rc = LFQ_ERR_HIP;
     }
     tmb[3] = lfq_now_ms();
     /* which reads got an ai / ad tag (bam_md_ext.c:238-243) joins the resident flags as bits 2, 3 on the device; the
@@ -976,6 +991,27 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         rs->h_ai = rs->h_ad = nullptr;          /* superseded by the device result */
     }
     return rc;
+}
+
+int lfq_last_baq_times(lfq_ctx *c, lfq_baq_times *t)
+{
+    if (!c || !t) {
+        return LFQ_ERR_INVALID;
+    }
+    memset(t, 0, sizeof(*t));
+    if (!c->ev_baq_t[0] || !c->ev_baq_t[1]) {
+        return LFQ_OK;                  /* no BAQ call on this context yet */
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY_HIP(hipEventSynchronize(c->ev_baq_t[1]));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_baq_t[0], c->ev_baq_t[1]) == hipSuccess) {
+        t->ms_kernels = ms;
+    }
+    t->n_launches = c->baq_launches;
+    t->n_reads = c->baq_reads;
+    t->n_bases = c->baq_bases;
+    return LFQ_OK;
 }
 
 int lfq_pileup_snv_tracks(lfq_ctx *c, const lfq_pileup_reads *rd, int64_t region_begin, int64_t region_end,
