@@ -780,6 +780,9 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         A.baq_extended = baq_extended ? 1 : 0;
         A.par_d = c->baq_par_d;
         A.par_e = c->baq_par_e;
+        A.stagger_ticks = lfq_knobs().baq_stagger_us * 100;       /* wall_clock64: 100 MHz */
+        A.stagger_phases = lfq_knobs().baq_stagger_phases;
+        A.stagger_waves = c->n_cu * 4;
         /* waves per launch from a 4 GiB scratch budget */
         const int64_t per_wave = ((int64_t)A.rows * A.W + 2 * (int64_t)A.W + 2 * ((int64_t)A.rows + 2)) * 64 * 8;
         /* the kernel is a chain of dependent HBM accesses per lane: it needs several wavefronts per SIMD in
