@@ -470,6 +470,7 @@ void lfq_destroy(lfq_ctx *c)
         }
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         if (c->ev_up) (void)hipEventDestroy(c->ev_up);
+        if (c->ev_apply) (void)hipEventDestroy(c->ev_apply);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         for (int i = 0; i < LFQ_PIN_SLOTS; i++) {
             if (c->pin_pool[i].p) (void)hipHostFree(c->pin_pool[i].p);

@@ -781,16 +781,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
     if (A.nflag && (A.nflag[blockIdx.x] != 0) != HN) {
         return;                                      /* the other instantiation's wavefront (lfq_baq_nflag_kernel) */
     }
-    if (A.stagger_ticks > 0 && (int)blockIdx.x < A.stagger_waves) {
-        /* first round of the launch: start in phases (see LfqBaqArgs) */
-        const int ph = (int)(blockIdx.x % (unsigned)A.stagger_phases);
-        if (ph > 0) {
-            const unsigned long long until = wall_clock64() + (unsigned long long)ph * (unsigned long long)A.stagger_ticks;
-            while (wall_clock64() < until) {
-                __builtin_amdgcn_s_sleep(64);
-            }
-        }
-    }
     typedef typename LfqBaqWinT<NB>::type WinT;
     constexpr int BWF = (NB - 1) / 2;               /* the band this instantiation holds in full */
     /* dynamic LDS: [NB][64] (match, insertion) pairs = the stored forward row the backward sweep needs next, brought in by

@@ -322,6 +322,7 @@ struct lfq_ctx {
     struct { void *p; size_t cap; } rs_cache[5];
     hipStream_t up_stream;           /* lfq_readset_create's uploads and the staging copies of host tracks (created on first use) */
     hipEvent_t ev_up;                /* end of the staging copies of a batch of host tracks */
+    hipEvent_t ev_apply;             /* lfq_readset_pileup_snv: the column positions are final (created on first use) */
     uint8_t *h_pin;                  /* pinned host staging of the BAQ geometry + launch order (grow-only) */
     int64_t pin_bytes;
     uint8_t *h_pin2;                 /* pinned landing area of the indel pileup's per-position counters (grow-only) */

@@ -82,8 +82,6 @@ const LfqKnobs &lfq_knobs(void)
         x.indel_host_pack = has("LFQ_INDEL_HOST_PACK");
         x.pileup_atomic = has("LFQ_PILEUP_ATOMIC");
         x.baq_lds = geti("LFQ_BAQ_LDS", 1) != 0;
-        x.baq_stagger_us = (int)std::max(0L, geti("LFQ_BAQ_STAGGER_US", 0));
-        x.baq_stagger_phases = (int)std::min(8L, std::max(2L, geti("LFQ_BAQ_STAGGER_PHASES", 2)));
         x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
         return x;
     }();

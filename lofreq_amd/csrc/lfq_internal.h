@@ -217,8 +217,6 @@ struct LfqKnobs {
     int indel_host_pack;       /* LFQ_INDEL_HOST_PACK */
     int pileup_atomic;         /* LFQ_PILEUP_ATOMIC: read-major pileup kernels even for sorted reads */
     int baq_lds;               /* LFQ_BAQ_LDS (1) */
-    int baq_stagger_us;        /* LFQ_BAQ_STAGGER_US: delay between the start phases of a narrow-band BAQ launch's first round */
-    int baq_stagger_phases;    /* LFQ_BAQ_STAGGER_PHASES (2) */
     long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
 };
 const LfqKnobs &lfq_knobs(void);
@@ -276,10 +274,6 @@ struct LfqBaqArgs {
     int32_t *itab;             /* per wavefront: [LFQ_BAQ_MAX_INDELS][4][64] kept indels: type|qpos, k0, rep, term offset */
     double *terms;             /* per wavefront: [LFQ_BAQ_MAX_TERMS][64] posterior terms, summed in the reference's order */
     uint8_t *nflag;            /* per wavefront of the launch: it meets an N (lfq_baq_nflag_kernel); null = one instantiation for all */
-    /* Phase stagger of the register kernel (LFQ_BAQ_STAGGER_US, LFQ_BAQ_STAGGER_PHASES): the first `stagger_waves` wavefronts
-     * of a launch -- one per SIMD -- start (blockIdx % phases) * ticks late (100 MHz wall clock), so that the SIMDs are not
-     * all in the write-bound forward pass and then all in the issue-bound sweep at the same time */
-    int32_t stagger_ticks, stagger_phases, stagger_waves, pad_;
 };
 #define LFQ_BAQ_MAX_INDELS 64
 #define LFQ_BAQ_MAX_TERMS 1024

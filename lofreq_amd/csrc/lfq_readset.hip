@@ -780,9 +780,6 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         A.baq_extended = baq_extended ? 1 : 0;
         A.par_d = c->baq_par_d;
         A.par_e = c->baq_par_e;
-        A.stagger_ticks = lfq_knobs().baq_stagger_us * 100;       /* wall_clock64: 100 MHz */
-        A.stagger_phases = lfq_knobs().baq_stagger_phases;
-        A.stagger_waves = c->n_cu * 4;
         /* waves per launch from a 4 GiB scratch budget */
         const int64_t per_wave = ((int64_t)A.rows * A.W + 2 * (int64_t)A.W + 2 * ((int64_t)A.rows + 2)) * 64 * 8;
         /* the kernel is a chain of dependent HBM accesses per lane: it needs several wavefronts per SIMD in
@@ -1104,17 +1101,28 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
                                          (const uint64_t *)(d + o_tobs), (const int64_t *)(d + o_tot), (int32_t *)(d + o_cidx),
                                          (uint64_t *)(t + t_off), t + t_ref, (int32_t *)(t + t_cov), (int32_t *)(t + t_nb),
                                          (int64_t *)(d + o_cpos), ps));
-    /* the columns' positions for the caller: copied on the DP stream (idle here) behind the apply kernel, so that the wait
-     * for the copy below is not a wait for the scatter pass */
-    hipStream_t aux = (c->dps && !lfq_knobs().single_stream) ? c->dps : ps;
-    hipEvent_t ev_apply = nullptr;
-    if (col_pos_out && ncols > 0) {
-        LFQ_TRY_HIP(hipEventCreateWithFlags(&ev_apply, hipEventDisableTiming));
-        if (hipEventRecord(ev_apply, ps) != hipSuccess || (aux != ps && hipStreamWaitEvent(aux, ev_apply, 0) != hipSuccess)
-            || hipMemcpyAsync(col_pos_out, d + o_cpos, (size_t)ncols * 8, hipMemcpyDeviceToHost, aux) != hipSuccess) {
-            (void)hipEventDestroy(ev_apply);
+    /* the columns' positions for the caller: copied on the context's own upload stream behind the apply kernel, so that the
+     * wait for the copy below is not a wait for the scatter pass -- and not for another context's DP chain either (the DP
+     * stream, which carried this copy before, is shared by the contexts of a device) */
+    hipStream_t aux = ps;
+    if (!lfq_knobs().single_stream) {
+        if (!c->up_stream && hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) {
+            c->up_stream = nullptr;
             return LFQ_ERR_HIP;
         }
+        aux = c->up_stream;
+    }
+    bool copy_pending = false;
+    if (col_pos_out && ncols > 0) {
+        if (!c->ev_apply) {
+            LFQ_TRY_HIP(hipEventCreateWithFlags(&c->ev_apply, hipEventDisableTiming));     /* kept: destroyed with the context */
+        }
+        if (hipEventRecord(c->ev_apply, ps) != hipSuccess || (aux != ps && hipStreamWaitEvent(aux, c->ev_apply, 0) != hipSuccess)
+            || hipMemcpyAsync(col_pos_out, d + o_cpos, (size_t)ncols * 8, hipMemcpyDeviceToHost, aux) != hipSuccess) {
+            (void)hipStreamSynchronize(aux);
+            return LFQ_ERR_HIP;
+        }
+        copy_pending = true;
     }
     A.col_index = (const int32_t *)(d + o_cidx);
     A.col_off = (const uint64_t *)(t + t_off);
@@ -1123,19 +1131,18 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     A.t_baq = t + t_baq;
     A.t_mq = t + t_mq;
     A.t_sq = rs->has_sqb ? t + t_sq : nullptr;
-    LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 1, c->stream) : lfq_launch_pileup_scatter(A, c->stream));
-    if (nt_packed) {
+    int rc_sc = sorted ? lfq_launch_pileup_columns(A, 1, c->stream) : lfq_launch_pileup_scatter(A, c->stream);
+    if (rc_sc == LFQ_OK && nt_packed) {
         /* the layout the count kernel reads 1.5 instead of 2 bytes per observation of (LFQ_TRACKS_NT_PACKED): the scatter
          * pass writes bytes (two lanes, often of two wavefronts, would share a byte), one streaming pass packs them */
-        LFQ_TRY(lfq_launch_pack_nt(t + t_nt, t + t_ntp, n_obs, c->stream));
+        rc_sc = lfq_launch_pack_nt(t + t_nt, t + t_ntp, n_obs, c->stream);
     }
-    if (ev_apply) {                                 /* the positions have landed in the caller's array */
-        const hipError_t e = hipStreamSynchronize(aux);
-        (void)hipEventDestroy(ev_apply);
-        if (e != hipSuccess) {
-            return LFQ_ERR_HIP;
+    if (copy_pending) {                             /* on every path: the copy into the caller's array is not left in flight */
+        if (hipStreamSynchronize(aux) != hipSuccess && rc_sc == LFQ_OK) {
+            rc_sc = LFQ_ERR_HIP;
         }
     }
+    LFQ_TRY(rc_sc);
     /* (no wait for the tracks: what consumes them -- lfq_call_snvs_batch, lfq_pileup_skip_snv_columns, the uniq calls -- is
      * queued on the same stream; lfq_readset_destroy and lfq_synchronize wait for it) */
     out->nt = nt_packed ? t + t_ntp : t + t_nt;
