@@ -153,12 +153,25 @@ static int env_int(const char *name, int dflt)
  * one's.  Without it rank 0 draws a nonce, removes what an earlier run left of <rdv>.job / <rdv>.id and publishes the
  * nonce in <rdv>.job; the other ranks take the <rdv>.job they find unless it is older than the time any rank 0 waits
  * for them (LFQ_PAR_TIMEOUT_S) -- a crashed run's files younger than that can still be picked up by a rank that
- * starts before its rank 0 does: export LFQ_PAR_JOB where that matters. */
+ * starts before its rank 0 does: export LFQ_PAR_JOB where that matters.  In between: what the usual launchers already give
+ * every rank of ONE launch and no other -- SLURM's job and step ids, torchrun's run id together with its rendezvous endpoint
+ * -- is taken as the job string when LFQ_PAR_JOB is not set, so that a launch under them never looks at <rdv>.job at all. */
 static int job_nonce(lfq_par *p)
 {
     const char *e = getenv("LFQ_PAR_JOB");
-    char path[1024];
+    char path[1024], from_launcher[512];
     snprintf(path, sizeof(path), "%s.job", p->rdv);
+    if (!(e && *e)) {
+        const char *sj = getenv("SLURM_JOB_ID"), *ss = getenv("SLURM_STEP_ID");
+        const char *tr = getenv("TORCHELASTIC_RUN_ID"), *ma = getenv("MASTER_ADDR"), *mp = getenv("MASTER_PORT");
+        if (sj && *sj && ss && *ss) {
+            snprintf(from_launcher, sizeof(from_launcher), "slurm:%s.%s", sj, ss);
+            e = from_launcher;
+        } else if (tr && *tr && strcmp(tr, "none") != 0 && mp && *mp) {     /* ("none": torchrun's default id, the same every run) */
+            snprintf(from_launcher, sizeof(from_launcher), "torchrun:%s@%s:%s", tr, ma ? ma : "", mp);
+            e = from_launcher;
+        }
+    }
     if (e && *e) {
         uint64_t h = 1469598103934665603ULL;                /* FNV-1a of the string */
         for (; *e; e++) {

@@ -5,6 +5,15 @@
  * final `lofreq filter` step.  Per *reported variant* work only -- negligible cost.
  *
  * No HIP in this file.  Reference citations are relative to src/lofreq/.
+ *
+ * Provenance of two blocks that follow their originals statement by statement, because their results are integers in the
+ * VCF (SB, FILTER) that must come out bit-identical, so the order of the floating-point operations IS the specification
+ * (tests/test_ref_parts.py compares them bitwise with the reference's own objects):
+ *   - Fisher's exact test (log_choose .. lfq_fisher_exact, lfq_sb_phred): after LoFreq's fet.c:13-99, which its header marks
+ *     "Taken from samtools 0.1.18 (r982:295)" -- Heng Li's kfunc.c kt_fisher_exact (MIT licence), implemented with ideas from
+ *     http://www.langsrud.com/fisher.htm;
+ *   - the multiple-testing corrections (lfq_bonf_corr, lfq_holm_bonf_corr, lfq_fdr): after LoFreq's multtest.c:66-189
+ *     (LoFreq, MIT licence; its FDR follows the Benjamini-Hochberg step-up procedure).
  */
 #include <errno.h>
 #include <fenv.h>
@@ -123,7 +132,7 @@ void sort_indexed(std::vector<IndexedP> &v)
     std::stable_sort(v.begin(), v.end(), [](const IndexedP &a, const IndexedP &b) { return eps_cmp(a.p, b.p) < 0; });
 }
 
-/* ---- Fisher's exact test, fet.c (samtools 0.1.18 kfunc) ---- */
+/* ---- Fisher's exact test: fet.c:13-99 = samtools 0.1.18 (r982:295) kfunc.c, Heng Li, MIT licence; see the file header ---- */
 
 double log_choose(int n, int k)                             /* fet.c:13-17 */
 {
