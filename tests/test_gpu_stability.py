@@ -99,3 +99,57 @@ def test_submit_collect_two_batches_in_flight(caller, oracle):
     assert _lib.load().lfq_call_snvs_collect(caller.h, __import__("ctypes").byref(confs[0].c), None, 0,
                                              __import__("ctypes").byref(n), None, None) < 0
     other.close()
+
+
+def test_submit_collect_dense_counts_without_strands(oracle):
+    """lfq_set_dense_strand_counts(ctx, 0) + lfq_call_snvs_submit + lfq_call_snvs_collect(h_counts): the dense entries of a
+    shallow, nt-packed batch are COMPLETE (every column, strand fields 0) -- the shared-wavefront count kernel skips the
+    entries of untested columns only after lfq_set_dense_counts(ctx, 0), and then collect refuses h_counts instead of
+    handing out what the array held before (the batch stays collectable without it).  All three gates give the same records."""
+    import ctypes as C
+    import lofreq_amd as la
+    from lofreq_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(23)
+    host = util.random_batch(rng, 500, 100, 700, alt_rate=0.0004, planted={7: 0.3, 100: 0.5, 200: 0.2}, ref_n_frac=0.05)
+    ores, _ = util.run_oracle(oracle, host)
+    assert 50 < int((ores["tested"] == 0).sum()) < 450                       # tested and untested columns side by side
+    own = la.SnvCaller(0)
+    try:
+        batch = util.to_pileup_batch(la, host).packed()
+        # a first batch that fills the context's dense array with OTHER columns' entries: stale data to be caught
+        other = util.to_pileup_batch(la, util.random_batch(rng, 500, 100, 700, alt_rate=0.01)).packed()
+        own.call_snvs(other, la.VarcallConf(), want_counts=True)
+        own.set_dense_strand_counts(False)
+        want = None
+        for gate in ("tail", "end", "none"):
+            own.set_batch_gate(gate)
+            conf = la.VarcallConf()
+            own.call_snvs_submit(batch, conf)
+            rec = np.empty(3 * batch.ncols, dtype=_lib.SNV_RECORD_DTYPE)
+            counts = np.full(batch.ncols, 0x5A, dtype=np.uint8).repeat(64).view(_lib.COL_COUNTS_DTYPE)
+            n, st = C.c_int64(0), _lib.BatchStats()
+            rc = L.lfq_call_snvs_collect(own.h, C.byref(conf.c), C.c_void_p(rec.ctypes.data), len(rec), C.byref(n),
+                                         C.c_void_p(counts.ctypes.data), C.byref(st))
+            own._sub = None
+            assert rc == 0
+            for f in ("n_err_probs", "alt_counts", "alt_raw_counts"):
+                assert np.array_equal(counts[f], ores[f]), f
+            assert np.array_equal(counts["tested"].astype(np.int32), ores["tested"])
+            assert not counts["ref_fw"].any() and not counts["alt_fw"].any()     # strands only in the records
+            recs = rec[: n.value].copy()
+            assert n.value > 0 and (want is None or recs.tobytes() == want.tobytes())
+            want = recs
+        # sparse entries: h_counts is refused, the batch is still there
+        own.set_dense_counts(False)
+        conf = la.VarcallConf()
+        own.call_snvs_submit(batch, conf)
+        n = C.c_int64(0)
+        counts = np.zeros(batch.ncols, dtype=_lib.COL_COUNTS_DTYPE)
+        rec = np.empty(3 * batch.ncols, dtype=_lib.SNV_RECORD_DTYPE)
+        assert L.lfq_call_snvs_collect(own.h, C.byref(conf.c), C.c_void_p(rec.ctypes.data), len(rec), C.byref(n),
+                                       C.c_void_p(counts.ctypes.data), None) == -1          # LFQ_ERR_INVALID
+        recs, st = own.call_snvs_collect(conf, records_capacity=3 * batch.ncols)
+        assert recs.tobytes() == want.tobytes()
+    finally:
+        own.close()
