@@ -68,6 +68,9 @@ def parse_args():
                          "reads -> VCF chain, region- / BED-sharded over --gpus (strong scaling)")
     ap.add_argument("--vcf-out", default=None, help="C4 / C5: rank 0 writes the VCF text of the last step here")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="C4 / C5: a smaller genome of the same shape (tests)")
+    ap.add_argument("--distinct-bins", type=int, default=4,
+                    help="C4 / C5: distinct sets of reads (generated from different seeds) that the genome's bins cycle through; "
+                         "every bin its own set = the number of bins (32: minutes of generation and ~10 GB of pinned host memory)")
     ap.add_argument("--host-threads", type=int, default=4,
                     help="C4 / C5: host threads per rank, one context each, that work through the rank's bins (the host part "
                          "of one bin -- CIGAR geometry, event tables, test descriptors -- then runs under the kernels of another)")
@@ -746,12 +749,20 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
                                      bins_per_worker=max(1, 16 // world))
     assert len(bins) == nb and len({e - b for _, b, e in bins}) == 1, (len(bins), nb)
     tile_len = bins[0][2] - bins[0][1]
-    R = make_tile(cfg, tile_len)
-    keep = {}
-    for k in ("seq", "qual", "bi", "bd", "pos", "cig_off", "cig", "seq_off", "mapq", "rev"):      # pinned, as the region binding keeps them
-        if k in R:
-            keep[k] = torch.from_numpy(R[k]).pin_memory()
-            R[k] = keep[k].numpy()
+    # the reads: `--distinct-bins` sets from different seeds, bin i takes set i mod that many (by its index in the genome, so
+    # that the output does not depend on which rank owns it)
+    n_tiles = max(1, min(args.distinct_bins, nb))
+    tiles, keep_all = [], []
+    for k in range(n_tiles):
+        Rk = make_tile(cfg, tile_len, seed=11 + 101 * k)
+        keep = {}
+        for key in ("seq", "qual", "bi", "bd", "pos", "cig_off", "cig", "seq_off", "mapq", "rev"):      # pinned, as the region binding keeps them
+            if key in Rk:
+                keep[key] = torch.from_numpy(Rk[key]).pin_memory()
+                Rk[key] = keep[key].numpy()
+        keep_all.append(keep)
+        tiles.append(Rk)
+    R = tiles[0]
     L = _lib.load()
     flag = la.LFQ_USE_BAQ | la.LFQ_USE_MQ | (la.LFQ_USE_IDAQ if cfg["call_indels"] else 0)
     my = [(i, b, e) for i, ((_, b, e), o) in enumerate(zip(bins, owner)) if o == rank]
@@ -764,7 +775,6 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         c_.set_dense_counts(False)                  # only the sparse output of a bin is read
         L.lfq_set_indel_arrays_on_host(c_.h, 0)
         outs.append((torch.zeros(cap * 64, dtype=torch.uint8, device=dev), torch.zeros(cap * 128, dtype=torch.uint8, device=dev)))
-    target = R["target"]
     if args.pmc_child:              # counter passes: two BAQ (+ IDAQ) calls of one bin, nothing else
         rs = la.ReadSet.from_arrays(caller, R)
         for _ in range(2):
@@ -773,8 +783,8 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         rs.close()
         return None
 
-    def start(caller):
-        rs = la.ReadSet.from_arrays(caller, R)
+    def start(caller, i):
+        rs = la.ReadSet.from_arrays(caller, tiles[i % n_tiles])
         rs.baq(extended=True, idaq=cfg["call_indels"])
         return rs
 
@@ -782,6 +792,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         """pileups + tests of a started bin -> (snv entry for finish_bins, indel entry or None, indel lines' makings)"""
         ient = None
         skip = None
+        target = tiles[i % n_tiles]["target"]
         if cfg["call_indels"]:
             outp = C.POINTER(_lib.IndelColumnsC)()
             col_pos = np.zeros(tile_len, np.int64)
@@ -831,7 +842,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             c_, (dc, dp) = callers[t], outs[t]
             pending = None
             for (i, b, e) in my[t::n_thr]:
-                rs = start(c_)
+                rs = start(c_, i)
                 if pending is not None:
                     res.append(finish(c_, dc, dp, *pending))
                 pending = (rs, i, b)
@@ -942,10 +953,11 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         "metric": "pileup columns/sec at depth %d, reads -> VCF (BAQ + device pileup + calls)" % cfg["depth"],
         "value": called * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic (one bin's reads, reused for every bin of the genome)",
+        "dtype": "f64", "data": "synthetic (%d distinct sets of reads, generated from different seeds, cycled over the genome's %d bins)" % (n_tiles, nb),
         "roofline": roof, "cpu_baseline": base,
         "config": {"workload": "%s: %s" % (cfg_name, cfg["what"]), "genome_len": glen, "called_columns": called, "bins": nb,
-                   "bins_rank0": len(my), "host_threads_per_rank": n_thr, "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": int(R["n"]) * nb,
+                   "bins_rank0": len(my), "host_threads_per_rank": n_thr, "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": sum(int(tiles[i % n_tiles]["n"]) for i in range(nb)),
+                   "distinct_bins": n_tiles,
                    "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
                    "snv_tests": int(conf.num_snv_tests), "indel_tests": int(conf.num_indel_tests),
                    "snv_records_before_filter": nrecs[0], "indel_records": nrecs[1],

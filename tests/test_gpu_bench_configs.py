@@ -20,7 +20,8 @@ def _run(cfg, gpus, vcf, scale):
     if gpus > 1:
         env["LFQ_BENCH_ONE_GPU"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--gpus", str(gpus), "--steps", "1",
-                        "--warmup", "1", "--genome-scale", str(scale), "--vcf-out", vcf], cwd=ROOT, env=env,
+                        "--warmup", "1", "--genome-scale", str(scale), "--vcf-out", vcf, "--no-pmc"] + ([] if gpus == 1 else ["--no-cpu-baseline"]),
+                       cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=800)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -38,5 +39,11 @@ def test_sharded_genome_equals_one_process(tmp_path, cfg, scale):
     for k in ("snv_tests", "indel_tests", "called_columns", "vcf_sha256", "vcf_lines"):
         assert a["config"][k] == b["config"][k], k
     assert a["config"]["snv_tests"] > 0 and a["value"] > 0
+    # the bins cycle through four distinct sets of reads; the one-GPU line is a measured one: the dominant kernel's launch timed
+    # with HIP events, the oracle chain timed on a sample of a bin
+    assert a["config"]["distinct_bins"] == 4 and "4 distinct sets of reads" in a["data"]
+    assert a["roofline"]["avg_launch_ms"] > 0 and 0 < a["roofline"]["frac"] < 1 and a["roofline"]["traffic"] is None
+    assert a["cpu_baseline"]["value"] > 0 and a["cpu_baseline"]["cores"] == 1 and a["cpu_baseline"]["kind"] == "port"
+    assert b["roofline"] is None and b["cpu_baseline"] is None
     if cfg == "C4":
         assert a["config"]["indel_tests"] > 100 and "INDEL" in one
