@@ -1377,16 +1377,16 @@ def main():
             modes = [(2, "end"), (2, "tail"), (2, "none")] if args.in_flight == 2 else \
                     [(4, "end"), (4, "none"), (3, "tail"), (1, "tail")]
             trial = {}
-            for m in modes + modes:
+            for m in modes * 3:                     # (three rounds, the fastest of each mode: a box's first seconds are noisy)
                 set_mode(*m)
                 run_steps(2)
                 torch.cuda.synchronize(dev)
                 t0_ = time.perf_counter()
-                _, acc_ = run_steps(12)
+                _, acc_ = run_steps(16)
                 torch.cuda.synchronize(dev)
-                trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0_) / 12)
+                trial[m] = min(trial.get(m, 1e9), (time.perf_counter() - t0_) / 16)
                 if m[1] == "end" or m[0] == 1:      # one batch's kernels at a time: the kernels' own durations
-                    alone_kt.update({x: acc_[x] / 12 for x in acc_})
+                    alone_kt.update({x: acc_[x] / 16 for x in acc_})
             if world > 1:                           # one choice for all ranks
                 tt = torch.tensor([trial[m] for m in modes], dtype=torch.float64, device=xdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1506,7 +1506,7 @@ def main():
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
-                "pipeline": ("two contexts: host finish of step k under the kernels of step k + 1; batches in flight: %d%s (%s)"
+                "pipeline": ("a context per queued batch: host finish of step k under the kernels of the steps behind it; batches in flight: %d%s (%s)"
                              % (in_flight["n"], "" if in_flight["n"] == 1 else ", gate " + in_flight["gate"], in_flight["note"]))
                             if pipelined else "none",
                 "batches_in_flight": in_flight["n"] if pipelined else 1,
