@@ -74,8 +74,6 @@ const LfqKnobs &lfq_knobs(void)
             const long w = geti("LFQ_COUNT_WAVES_PER_WG", 16);
             x.count_waves_per_wg = (w == 4 || w == 8) ? (int)w : 16;
         }
-        x.count_unroll = geti("LFQ_COUNT_UNROLL", 2) == 4 ? 4 : 2;
-        x.count_prio = has("LFQ_COUNT_PRIO");
         x.big_on_side = has("LFQ_BIG_ON_SIDE");
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);

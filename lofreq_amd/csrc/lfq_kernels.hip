@@ -814,7 +814,7 @@ struct LfqCountArgs {           /* what the default filters need of LfqTracksDev
     int32_t min_bq4, min_alt_bq4, min_cov, pad_;
 };
 
-template <bool PACKED, bool STRAND, bool SAME_THR, int UNROLL>
+template <bool PACKED, bool STRAND, bool SAME_THR>
 __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq_col_counts *__restrict__ out,
                                                       uint8_t *__restrict__ flags, int64_t col, int lane)
 {
@@ -840,6 +840,8 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
         const int n_ch = (int)((int64_t)((off1 + 15) >> 4) - cbeg);          /* chunks of 16 observations the column touches */
         const int lo = (int)(off0 & 15u);                                     /* first observation inside chunk 0 */
         const int hi_last = (int)((int64_t)off1 - ((cbeg + n_ch - 1) << 4));   /* observations of the last chunk: 1..16 */
+        constexpr int UNROLL = 2;                   /* chunks in flight per lane (4 was measured: 72 registers, one workgroup
+                                                     * per CU -- 1.5 % faster alone, slower beside another batch's DP kernels) */
         const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq) + cbeg;
         /* one chunk: full masks inside the column, byte masks at its two ends (a wavefront meets them in its first and in
          * its last trip only) */
@@ -985,21 +987,18 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
  * workgroup retires sixteen columns at once -- a quarter of the workgroups to dispatch (C3: 2.42 against 2.46 ms per
  * launch) and, for a caller that keeps several batches queued without a gate, four wave slots per SIMD freed at a time,
  * room for any workgroup of the other batch's DP kernels (a 256-thread workgroup's single slots starve the 512-thread
- * ones: profiles/NOTES.md).  UNROLL: chunks in flight per lane; PRIO: s_setprio of the whole kernel (A/B knobs). */
-template <bool PACKED, bool STRAND, bool SAME_THR, int WAVES, int UNROLL, int PRIO>
+ * ones: profiles/NOTES.md). */
+template <bool PACKED, bool STRAND, bool SAME_THR, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void lfq_count_fast_kernel(LfqCountArgs T,
                                                                     lfq_col_counts *__restrict__ out,
                                                                     uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
-    if (PRIO > 0) {
-        __builtin_amdgcn_s_setprio(PRIO);
-    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t col = c0 + (int64_t)blockIdx.x * WAVES + wave;
     if (col >= c1) {
         return;
     }
-    lfq_count_column_fast<PACKED, STRAND, SAME_THR, UNROLL>(T, out, flags, col, lfq_lane());
+    lfq_count_column_fast<PACKED, STRAND, SAME_THR>(T, out, flags, col, lfq_lane());
 }
 
 /* base_count() (plp.c:128-132) for every column: the bases of each nucleotide, whatever their quality -- what
@@ -1447,17 +1446,14 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         const int variant = (t.nt_packed ? 4 : 0) | (strand ? 2 : 0) | (same_thr ? 1 : 0);
         const int wpw = kn.count_waves_per_wg;
         const unsigned blocks = (unsigned)((c1 - c0 + wpw - 1) / wpw);
-#define LFQ_LAUNCH_F(PK, ST, SM, W, U, PR)                                                                           \
-    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W, U, PR>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
+#define LFQ_LAUNCH_F(PK, ST, SM, W)                                                                                  \
+    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
                        d_counts, d_flags, c0, c1)
 #define LFQ_LAUNCH_FW(PK, ST, SM)                                                                                    \
     do {                                                                                                             \
-        if (wpw == 16 && kn.count_unroll == 4 && kn.count_prio) LFQ_LAUNCH_F(PK, ST, SM, 16, 4, 3);                  \
-        else if (wpw == 16 && kn.count_unroll == 4) LFQ_LAUNCH_F(PK, ST, SM, 16, 4, 0);                              \
-        else if (wpw == 16 && kn.count_prio) LFQ_LAUNCH_F(PK, ST, SM, 16, 2, 3);                                     \
-        else if (wpw == 16) LFQ_LAUNCH_F(PK, ST, SM, 16, 2, 0);                                                      \
-        else if (wpw == 8) LFQ_LAUNCH_F(PK, ST, SM, 8, 2, 0);                                                        \
-        else LFQ_LAUNCH_F(PK, ST, SM, 4, 2, 0);                                                                      \
+        if (wpw == 16) LFQ_LAUNCH_F(PK, ST, SM, 16);                                                                 \
+        else if (wpw == 8) LFQ_LAUNCH_F(PK, ST, SM, 8);                                                              \
+        else LFQ_LAUNCH_F(PK, ST, SM, 4);                                                                            \
     } while (0)
         switch (variant) {
         case 0: LFQ_LAUNCH_FW(false, false, false); break;

@@ -29,6 +29,9 @@ CASES = [
     ("LFQ_COUNT_LPG4_BELOW=100000", DP),     # shared-wavefront count kernel: four lanes per column whatever the depth
     ("LFQ_COUNT_LPG8_BELOW=100000", DP),     # ... eight (and four for the shallowest batches)
     ("LFQ_COUNT_LPG4_BELOW=0", DP),          # ... never four
+    ("LFQ_COUNT_WAVES_PER_WG=4 LFQ_COUNT_MULTI_BELOW=0", DP),    # the lean count kernel with 4 columns per workgroup (default 16) ...
+    ("LFQ_COUNT_WAVES_PER_WG=8 LFQ_COUNT_MULTI_BELOW=0", DP),    # ... and 8, on every batch
+    ("LFQ_BIG_ON_SIDE=1", DP),               # the unsplit big columns behind the big chain (what a context with LFQ_GATE_NONE runs)
     ("LFQ_PILEUP_TILES=0", PLP),             # a wavefront per position instead of tiles of 64 positions
     ("LFQ_BAQ_ONE_VARIANT=1", BAQ),          # every wavefront through the register kernel's instantiation with the N case
     ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
@@ -41,8 +44,7 @@ CASES = [
 
 @pytest.mark.parametrize("knob,sel", CASES, ids=[c[0] for c in CASES])
 def test_knob_selected_paths(knob, sel):
-    k, v = knob.split("=")
-    env = dict(os.environ, **{k: v})
+    env = dict(os.environ, **dict(kv.split("=") for kv in knob.split()))
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=800)
     tail = (p.stdout + p.stderr)[-1500:]

@@ -136,7 +136,9 @@ def test_submit_collect_dense_counts_without_strands(oracle):
             for f in ("n_err_probs", "alt_counts", "alt_raw_counts"):
                 assert np.array_equal(counts[f], ores[f]), f
             assert np.array_equal(counts["tested"].astype(np.int32), ores["tested"])
-            assert not counts["ref_fw"].any() and not counts["alt_fw"].any()     # strands only in the records
+            # strand fields: 0 except where the library counted them for its own use (the heavy columns' strand-bias precompute)
+            light = counts["kmax"] < 12
+            assert not counts["ref_fw"][light].any() and not counts["alt_fw"][light].any() and light.sum() > 300
             recs = rec[: n.value].copy()
             assert n.value > 0 and (want is None or recs.tobytes() == want.tobytes())
             want = recs
