@@ -1055,7 +1055,7 @@ def full_check(args, caller, la, batch, d_counts, d_pvals, pv_cap, seed, depth, 
         planted = np.arange(0, ncols, max(args.plant_period, 1))
         columns = np.union1d(planted, np.arange(0, ncols, stride))
     out = fc.check_batch(orc, seed, depth, args.plant_period, ncols, counts, recs, gpu_vcf_text=text,
-                         default_filter=default_filter, procs=procs, columns=columns)
+                         default_filter=default_filter, procs=procs, columns=columns, lazy_raw=True)
     out["scope"] = "every column of the timed batch" if columns is None else \
         "planted columns + every %d-th column (host too small for all of them)" % stride
     out["tested_columns"] = int(st.n_tested)
@@ -1445,10 +1445,14 @@ def main():
         n_launch = max(int(round(kt["n_segments"])), 1)       # count-kernel launches per step
         # Dominant kernel = the one with the largest duration per step: the count kernel (one launch, HBM-bound).
         # The DP kernels run concurrently on three streams; their span is the `dp` block below.
-        # (packed nt, lazy strand counts, one BQ threshold, 4 columns per workgroup; LFQ_COUNT_PERSIST: the resident form)
-        count_name = ("lfq_count_persist_kernel<%s, false, true>" if os.environ.get("LFQ_COUNT_PERSIST", "0") not in ("", "0")
-                      else "lfq_count_fast_kernel<%s, false, true, " + os.environ.get("LFQ_COUNT_WAVES_PER_WG", "4") + ">") % (
-                          "false" if args.nt_bytes else "true")
+        # packed nt + lazy record counts: lfq_count_lean_kernel<one BQ threshold, columns per workgroup, chunks in flight per lane>;
+        # the byte layout: lfq_count_fast_kernel<packed, strand planes, one BQ threshold, columns per workgroup>
+        wpw = os.environ.get("LFQ_COUNT_WAVES_PER_WG", "16")
+        wpw = wpw if wpw in ("4", "8") else "16"
+        ahead = os.environ.get("LFQ_COUNT_AHEAD_DEEP", "2")
+        ahead = ahead if ahead in ("3", "4") else "2"
+        count_name = ("lfq_count_fast_kernel<false, false, true, %s>" % wpw) if args.nt_bytes else \
+            ("lfq_count_lean_kernel<true, %s, %s>" % (wpw, ahead))
         if depth < 4096:
             lpg = 4 if depth <= 320 else 8 if depth <= 900 else 16     # lfq_launch_count's choice at the default knobs
             count_name = ("lfq_count_multi_kernel<false, false, %d>" if args.nt_bytes else "lfq_count_shallow_kernel<false, %d>") % lpg

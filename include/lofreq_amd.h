@@ -439,11 +439,13 @@ int lfq_readset_fetch_tags(lfq_ctx *ctx, lfq_readset *rs, uint8_t *lb_out, uint8
 int lfq_source_qual_batch(lfq_ctx *ctx, const lfq_baq_reads *reads, int def_nm_q, int min_bq,
                           const uint8_t *ign_or_null, int32_t *sq_out, uint8_t *sq_byte_or_null);
 
-/* Strand counts (ref_fw / ref_rv / alt_fw) are only ever read for reported variants (DP4 and SB, lofreq_call.c:117-129,
- * 853-857), and counting them for every column costs the dominant kernel a quarter of its instructions.  With
- * on = 0, lfq_snv_batch_device and lfq_call_snvs_submit leave them 0 in the dense lfq_col_counts entries and
- * count them only for the columns of the sparse output (lfq_col_pvals.counts is complete either way, and so are
- * the records).  Default: on = 1.  lfq_call_snvs_batch decides by itself: dense strand counts exactly when
+/* Strand counts (ref_fw / ref_rv / alt_fw) and the unfiltered alt counts (alt_raw_counts, the AF numerator) are only ever
+ * read for reported variants (DP4, SB and AF: lofreq_call.c:117-129, 835, 853-857), and counting them for every column
+ * costs the dominant kernel half of its instructions.  With on = 0, lfq_snv_batch_device and lfq_call_snvs_submit
+ * count them only for the columns of the sparse output (lfq_col_pvals.counts is complete either way, and so are the
+ * records); in the dense lfq_col_counts entries the strand fields are then 0 and alt_raw_counts is either the true
+ * value or 0 (which kernel ran decides; the decision fields n_err_probs, alt_counts, kmax, tested, gated, coverage are
+ * always there).  Default: on = 1.  lfq_call_snvs_batch decides by itself: complete dense entries exactly when
  * h_counts_or_null is given. */
 int lfq_set_dense_strand_counts(lfq_ctx *ctx, int on);
 

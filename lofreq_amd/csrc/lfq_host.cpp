@@ -74,6 +74,10 @@ const LfqKnobs &lfq_knobs(void)
             const long w = geti("LFQ_COUNT_WAVES_PER_WG", 16);
             x.count_waves_per_wg = (w == 4 || w == 8) ? (int)w : 16;
         }
+        {
+            const long u = geti("LFQ_COUNT_AHEAD_DEEP", 2);
+            x.count_ahead_deep = (u == 3 || u == 4) ? (int)u : 2;
+        }
         x.big_on_side = has("LFQ_BIG_ON_SIDE");
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);

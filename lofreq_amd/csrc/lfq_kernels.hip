@@ -58,6 +58,13 @@ struct LfqAcc {
     uint32_t raw[4], fw[4], ge[4], ga[4];
 };
 
+/* popcount + accumulate as the ONE instruction the hardware has for it (left to itself the compiler counts into a fresh
+ * register and folds pairs of counts with v_add3_u32: 1.5 instructions per count) */
+__device__ __forceinline__ void lfq_bcnt_acc(uint32_t &acc, uint32_t x)
+{
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+
 template <bool SAME_THR, bool STRAND = true>
 __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_t bqw, uint32_t vm,
                                                 uint32_t minbq4, uint32_t minalt4)
@@ -69,28 +76,28 @@ __device__ __forceinline__ void lfq_count_dword(LfqAcc &a, uint32_t ntw, uint32_
     const uint32_t p1 = p0 & s0;
     const uint32_t p2 = p0 & s1;
     const uint32_t p3 = p1 & s1;
-    a.raw[0] += __popc(p0);
-    a.raw[1] += __popc(p1);
-    a.raw[2] += __popc(p2);
-    a.raw[3] += __popc(p3);
+    lfq_bcnt_acc(a.raw[0], p0);
+    lfq_bcnt_acc(a.raw[1], p1);
+    lfq_bcnt_acc(a.raw[2], p2);
+    lfq_bcnt_acc(a.raw[3], p3);
     if (STRAND) {                                  /* lazy-strand mode: only the columns that emit get these (lfq_strand_*) */
-        a.fw[0] += __popc(p0 & ~s3);
-        a.fw[1] += __popc(p1 & ~s3);
-        a.fw[2] += __popc(p2 & ~s3);
-        a.fw[3] += __popc(p3 & ~s3);
+        lfq_bcnt_acc(a.fw[0], p0 & ~s3);
+        lfq_bcnt_acc(a.fw[1], p1 & ~s3);
+        lfq_bcnt_acc(a.fw[2], p2 & ~s3);
+        lfq_bcnt_acc(a.fw[3], p3 & ~s3);
     }
     const uint32_t hi = bqw | 0x80808080u;
     const uint32_t g = hi - minbq4;                /* bit 7: bq >= min_bq (bq < 128) */
-    a.ge[0] += __popc(p0 & g);
-    a.ge[1] += __popc(p1 & g);
-    a.ge[2] += __popc(p2 & g);
-    a.ge[3] += __popc(p3 & g);
+    lfq_bcnt_acc(a.ge[0], p0 & g);
+    lfq_bcnt_acc(a.ge[1], p1 & g);
+    lfq_bcnt_acc(a.ge[2], p2 & g);
+    lfq_bcnt_acc(a.ge[3], p3 & g);
     if (!SAME_THR) {
         const uint32_t g2 = (hi - minalt4) & g;    /* ... and >= min_alt_bq */
-        a.ga[0] += __popc(p0 & g2);
-        a.ga[1] += __popc(p1 & g2);
-        a.ga[2] += __popc(p2 & g2);
-        a.ga[3] += __popc(p3 & g2);
+        lfq_bcnt_acc(a.ga[0], p0 & g2);
+        lfq_bcnt_acc(a.ga[1], p1 & g2);
+        lfq_bcnt_acc(a.ga[2], p2 & g2);
+        lfq_bcnt_acc(a.ga[3], p3 & g2);
     }
 }
 
@@ -108,30 +115,65 @@ __device__ __forceinline__ void lfq_count_nib8(LfqAcc &a, uint32_t ntw, uint32_t
     const uint32_t p1 = p0 & s0;
     const uint32_t p2 = p0 & s1;
     const uint32_t p3 = p1 & s1;
-    a.raw[0] += __popc(p0);
-    a.raw[1] += __popc(p1);
-    a.raw[2] += __popc(p2);
-    a.raw[3] += __popc(p3);
+    lfq_bcnt_acc(a.raw[0], p0);
+    lfq_bcnt_acc(a.raw[1], p1);
+    lfq_bcnt_acc(a.raw[2], p2);
+    lfq_bcnt_acc(a.raw[3], p3);
     if (STRAND) {                                  /* the strand flag is bit 3 of the nibble itself */
-        a.fw[0] += __popc(p0 & ~ntw);
-        a.fw[1] += __popc(p1 & ~ntw);
-        a.fw[2] += __popc(p2 & ~ntw);
-        a.fw[3] += __popc(p3 & ~ntw);
+        lfq_bcnt_acc(a.fw[0], p0 & ~ntw);
+        lfq_bcnt_acc(a.fw[1], p1 & ~ntw);
+        lfq_bcnt_acc(a.fw[2], p2 & ~ntw);
+        lfq_bcnt_acc(a.fw[3], p3 & ~ntw);
     }
     const uint32_t ha = bqa | 0x80808080u, hb = bqb | 0x80808080u;
     const uint32_t ga = ha - minbq4, gb = hb - minbq4;             /* bit 7 of a byte: bq >= min_bq (bq < 128) */
     const uint32_t g = ((ga >> 4) & 0x08080808u) | (gb & 0x80808080u);
-    a.ge[0] += __popc(p0 & g);
-    a.ge[1] += __popc(p1 & g);
-    a.ge[2] += __popc(p2 & g);
-    a.ge[3] += __popc(p3 & g);
+    lfq_bcnt_acc(a.ge[0], p0 & g);
+    lfq_bcnt_acc(a.ge[1], p1 & g);
+    lfq_bcnt_acc(a.ge[2], p2 & g);
+    lfq_bcnt_acc(a.ge[3], p3 & g);
     if (!SAME_THR) {
         const uint32_t ga2 = ha - minalt4, gb2 = hb - minalt4;
         const uint32_t g2 = (((ga2 >> 4) & 0x08080808u) | (gb2 & 0x80808080u)) & g;       /* ... and >= min_alt_bq */
-        a.ga[0] += __popc(p0 & g2);
-        a.ga[1] += __popc(p1 & g2);
-        a.ga[2] += __popc(p2 & g2);
-        a.ga[3] += __popc(p3 & g2);
+        lfq_bcnt_acc(a.ga[0], p0 & g2);
+        lfq_bcnt_acc(a.ga[1], p1 & g2);
+        lfq_bcnt_acc(a.ga[2], p2 & g2);
+        lfq_bcnt_acc(a.ga[3], p3 & g2);
+    }
+}
+
+/* The lean form of lfq_count_nib8 for the default filters when only the DECISION counts are wanted of every column
+ * (n_err_probs, alt_counts, kmax, tested: the planes restricted to bq >= min_bq) -- the raw and the forward-strand counts
+ * reach nothing but the records of the ~1e-3 of the columns that emit one, and lfq_strand_* count them there.
+ *   - the gate by ONE add per bq dword: byte + (128 - min) has bit 7 set exactly when byte >= min; bytes are <= 127 (the
+ *     contract: 0..93, include/lofreq_amd.h), so no byte carries into its neighbour; kge / kga = 0x01010101 * (128 - min)
+ *   - both dwords' gates into the nibble domain by a shift and a bit-field insert, the dirt outside bit 3 of each nibble
+ *     removed by the one three-input operation that also applies "in range" (vm) and "not N"
+ *   - every plane = one AND, every count = one v_bcnt with its accumulator
+ * 15 instructions per 8 observations with one threshold (the general form above compiles to 34), 27 with two. */
+template <bool SAME_THR>
+__device__ __forceinline__ void lfq_count_nib8_lean(uint32_t (&ge)[4], uint32_t (&ga)[4], uint32_t ntw, uint32_t bqa,
+                                                    uint32_t bqb, uint32_t vm, uint32_t kge, uint32_t kga)
+{
+    const uint32_t s0 = ntw << 3, s1 = ntw << 2, s2 = ntw << 1;
+    const uint32_t a = bqa + kge, b = bqb + kge;
+    /* (v_bitop3_b32 spelled out: the compiler's own choice for these is three instructions longer per call) */
+    const uint32_t g = __builtin_amdgcn_bitop3_b32(0x80808080u, b, a >> 4, 0xCA);        /* bit 7 of each byte from b, the rest from a >> 4 */
+    const uint32_t p0 = __builtin_amdgcn_bitop3_b32(g, s2, vm, 0x20);                    /* g & ~s2 & vm: passes, not N, in range */
+    const uint32_t p1 = p0 & s0;
+    const uint32_t p2 = p0 & s1;
+    const uint32_t p3 = __builtin_amdgcn_bitop3_b32(p0, s0, s1, 0x80);
+    lfq_bcnt_acc(ge[0], p0);
+    lfq_bcnt_acc(ge[1], p1);
+    lfq_bcnt_acc(ge[2], p2);
+    lfq_bcnt_acc(ge[3], p3);
+    if (!SAME_THR) {                               /* kga: the larger of the two thresholds, so these are subsets */
+        const uint32_t a2 = bqa + kga, b2 = bqb + kga;
+        const uint32_t g2 = __builtin_amdgcn_bitop3_b32(0x80808080u, b2, a2 >> 4, 0xCA);
+        lfq_bcnt_acc(ga[0], p0 & g2);
+        lfq_bcnt_acc(ga[1], p1 & g2);
+        lfq_bcnt_acc(ga[2], p2 & g2);
+        lfq_bcnt_acc(ga[3], p3 & g2);
     }
 }
 
@@ -270,6 +312,12 @@ template <bool SAME_THR, bool STRAND>
 __device__ __forceinline__ void lfq_count_chunk_packed(LfqAcc &a, lfq_v2u n2, lfq_v4u b4, uint32_t vx, uint32_t vy,
                                                        uint32_t minbq4, uint32_t minalt4)
 {
+    if (!STRAND) {              /* lazy record counts: the decision planes only (a.raw stays 0: alt_raw_counts = 0 in the entry) */
+        const uint32_t kge = 0x80808080u - minbq4, kga = 0x80808080u - minalt4;      /* 0x01010101 * (128 - min) */
+        lfq_count_nib8_lean<SAME_THR>(a.ge, a.ga, n2.x, b4.x, b4.y, vx, kge, kga);
+        lfq_count_nib8_lean<SAME_THR>(a.ge, a.ga, n2.y, b4.z, b4.w, vy, kge, kga);
+        return;
+    }
     lfq_count_nib8<SAME_THR, STRAND>(a, n2.x, b4.x, b4.y, vx, minbq4, minalt4);
     lfq_count_nib8<SAME_THR, STRAND>(a, n2.y, b4.z, b4.w, vy, minbq4, minalt4);
 }
@@ -983,6 +1031,146 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
     }
 }
 
+/* ---- default filters + packed nt + lazy record counts: only the decision counts of every column ----
+ * What the batches of lfq_call_vars / lfq_call_snvs_batch run when no dense strand counts are asked for (P.lazy_strand): the
+ * planes restricted to bq >= min_bq are all that n_err_probs, alt_counts, kmax and `tested` need; alt_raw_counts and the
+ * strand fields are 0 in the dense entry and counted by lfq_strand_heavy_kernel / lfq_strand_pvals_kernel for the columns
+ * whose records can use them.  The interior chunks of the column run through a loop without a test for the column's two
+ * ragged ends (lfq_count_nib8_lean, 15 instructions per 8 observations); the two end chunks go to lanes 63 and 62, which
+ * have the fewest interior ones. */
+template <bool SAME_THR, int UNROLL>
+__device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq_col_counts *__restrict__ out,
+                                                      uint8_t *__restrict__ flags, int64_t col, int lane)
+{
+    const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
+    const int64_t n_obs = (int64_t)(off1 - off0);
+    const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
+    const int nb = T.num_bases ? T.num_bases[col] : (int)n_obs;
+    const uint32_t rb = T.ref_base[col];
+    const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
+    /* gates: lofreq_call.c:892/754 (ref N; non-ACGT refs are N, plp.c:819-823), :930, :747 */
+    const bool gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < T.min_cov);
+
+    uint32_t ge[4] = {0u, 0u, 0u, 0u}, ga[4] = {0u, 0u, 0u, 0u};
+    if (!gated && n_obs > 0) {
+        const uint32_t kge = 0x01010101u * (uint32_t)(128 - T.min_bq4);          /* thresholds are clamped to 0..128 */
+        const uint32_t kga = 0x01010101u * (uint32_t)(128 - T.min_alt_bq4);
+        const int64_t cbeg = (int64_t)(off0 >> 4);
+        const int n_ch = (int)((int64_t)((off1 + 15) >> 4) - cbeg);          /* chunks of 16 observations the column touches */
+        const uint2 *nt8 = reinterpret_cast<const uint2 *>(T.nt) + cbeg;
+        const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq) + cbeg;
+        const int n_in = n_ch - 1;                                            /* interior chunks: 1 .. n_ch - 2 */
+        int i = 1 + lane;
+        for (; i + (UNROLL - 1) * LFQ_WAVE < n_in; i += UNROLL * LFQ_WAVE) {  /* UNROLL chunks' loads in flight per lane */
+            uint2 nv[UNROLL];
+            uint4 bv[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                nv[u] = nt8[i + u * LFQ_WAVE];
+                bv[u] = bq16[i + u * LFQ_WAVE];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                lfq_count_nib8_lean<SAME_THR>(ge, ga, nv[u].x, bv[u].x, bv[u].y, 0x88888888u, kge, kga);
+                lfq_count_nib8_lean<SAME_THR>(ge, ga, nv[u].y, bv[u].z, bv[u].w, 0x88888888u, kge, kga);
+            }
+        }
+        {                                                                     /* what is left: up to UNROLL - 1 chunks per lane */
+            uint2 nv[UNROLL - 1];
+            uint4 bv[UNROLL - 1];
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; u++) {
+                const int at = i + u * LFQ_WAVE < n_in ? i + u * LFQ_WAVE : 0;    /* (chunk 0: there, and masked out below) */
+                nv[u] = nt8[at];
+                bv[u] = bq16[at];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; u++) {
+                const uint32_t vm = i + u * LFQ_WAVE < n_in ? 0x88888888u : 0u;
+                lfq_count_nib8_lean<SAME_THR>(ge, ga, nv[u].x, bv[u].x, bv[u].y, vm, kge, kga);
+                lfq_count_nib8_lean<SAME_THR>(ge, ga, nv[u].y, bv[u].z, bv[u].w, vm, kge, kga);
+            }
+        }
+        if (lane >= LFQ_WAVE - 2) {                                           /* the ends: byte masks */
+            const bool first = lane == LFQ_WAVE - 1;
+            const int ci = first ? 0 : n_ch - 1;
+            if (first || n_ch > 1) {
+                const int l_ = first ? (int)(off0 & 15u) : 0;
+                const int h_ = ci == n_ch - 1 ? (int)((int64_t)off1 - ((cbeg + ci) << 4)) : 16;     /* 1..16 */
+                const uint2 n0 = nt8[ci];
+                const uint4 b0 = bq16[ci];
+                lfq_count_nib8_lean<SAME_THR>(ge, ga, n0.x, b0.x, b0.y,
+                                              (lfq_bytes_mask(l_, h_, 0) >> 4) | lfq_bytes_mask(l_, h_, 1), kge, kga);
+                lfq_count_nib8_lean<SAME_THR>(ge, ga, n0.y, b0.z, b0.w,
+                                              (lfq_bytes_mask(l_, h_, 2) >> 4) | lfq_bytes_mask(l_, h_, 3), kge, kga);
+            }
+        }
+    }
+
+    /* the column's sums end up in lane 63, which writes the record */
+    uint32_t n_ge[4], n_ga[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        n_ge[x] = lfq_wave_sum_lane63_u32(ge[x]);
+        n_ga[x] = SAME_THR ? n_ge[x] : lfq_wave_sum_lane63_u32(ga[x]);
+    }
+    if (lane == LFQ_WAVE - 1) {
+        uint32_t c_ge[4], c_ga[4], filt[4];
+        lfq_planes_to_classes(n_ge, c_ge);
+        lfq_planes_to_classes(n_ga, c_ga);
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            filt[x] = (x == ref_code) ? c_ge[x] : c_ga[x];     /* alt bases must pass both thresholds */
+        }
+        lfq_col_counts r;
+        r.n_err_probs = 0;
+        for (int k = 0; k < 3; k++) {
+            r.alt_counts[k] = r.alt_raw_counts[k] = r.alt_fw[k] = 0;
+        }
+        r.ref_fw = r.ref_rv = 0;
+        r.kmax = 0;
+        r.tested = 0;
+        r.pad_[0] = r.pad_[1] = 0;
+        r.median_ref_bq = -1;
+        r.coverage = cov;
+        r.gated = gated;
+        uint8_t flag = 0;
+        if (!gated) {
+            /* the three non-reference nucleotides in A,C,G,T order (snpcaller.c:391-397) */
+            const int x0 = (ref_code == 0) ? 1 : 0;
+            const int x1 = (ref_code <= 1) ? 2 : 1;
+            const int x2 = (ref_code <= 2) ? 3 : 2;
+#define LFQ_PICK(arr, x) ((x) == 0 ? arr[0] : (x) == 1 ? arr[1] : (x) == 2 ? arr[2] : arr[3])
+            r.alt_counts[0] = (int)LFQ_PICK(filt, x0);
+            r.alt_counts[1] = (int)LFQ_PICK(filt, x1);
+            r.alt_counts[2] = (int)LFQ_PICK(filt, x2);
+#undef LFQ_PICK
+            r.n_err_probs = (int)(filt[0] + filt[1] + filt[2] + filt[3]);
+            const int kmax = max(r.alt_counts[0], max(r.alt_counts[1], r.alt_counts[2]));
+            r.kmax = kmax;
+            r.tested = kmax > 0;                     /* lofreq_call.c:768-780 */
+            /* scheduling class: as in lfq_count_column */
+            const int suspicious = max(12, r.n_err_probs / 512 + 8);
+            flag = (uint8_t)((r.tested ? 1 : 0)
+                             | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
+        }
+        out[col] = r;
+        flags[col] = flag;
+    }
+}
+
+template <bool SAME_THR, int WAVES, int UNROLL>
+__global__ __launch_bounds__(64 * WAVES, 8) void lfq_count_lean_kernel(LfqCountArgs T, lfq_col_counts *__restrict__ out,
+                                                                    uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t col = c0 + (int64_t)blockIdx.x * WAVES + wave;
+    if (col >= c1) {
+        return;
+    }
+    lfq_count_column_lean<SAME_THR, UNROLL>(T, out, flags, col, lfq_lane());
+}
+
 /* one column per wavefront, WAVES columns per workgroup.  16 is the default (LFQ_COUNT_WAVES_PER_WG: 4, 8, 16): a 1024-thread
  * workgroup retires sixteen columns at once -- a quarter of the workgroups to dispatch (C3: 2.42 against 2.46 ms per
  * launch) and, for a caller that keeps several batches queued without a gate, four wave slots per SIMD freed at a time,
@@ -1446,6 +1634,30 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         const int variant = (t.nt_packed ? 4 : 0) | (strand ? 2 : 0) | (same_thr ? 1 : 0);
         const int wpw = kn.count_waves_per_wg;
         const unsigned blocks = (unsigned)((c1 - c0 + wpw - 1) / wpw);
+        if (t.nt_packed && !strand) {
+            /* lazy record counts on the packed layout: the decision counts only */
+#define LFQ_LAUNCH_L(SM, W, U)                                                                                       \
+    hipLaunchKernelGGL((lfq_count_lean_kernel<SM, W, U>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, d_counts, \
+                       d_flags, c0, c1)
+#define LFQ_LAUNCH_LU(SM, W)                                                                                         \
+    do {                                                                                                             \
+        if (kn.count_ahead_deep == 4) LFQ_LAUNCH_L(SM, W, 4);                                                        \
+        else if (kn.count_ahead_deep == 3) LFQ_LAUNCH_L(SM, W, 3);                                                   \
+        else LFQ_LAUNCH_L(SM, W, 2);                                                                                 \
+    } while (0)
+#define LFQ_LAUNCH_LW(SM)                                                                                            \
+    do {                                                                                                             \
+        if (wpw == 16) LFQ_LAUNCH_LU(SM, 16);                                                                        \
+        else if (wpw == 8) LFQ_LAUNCH_LU(SM, 8);                                                                     \
+        else LFQ_LAUNCH_LU(SM, 4);                                                                                   \
+    } while (0)
+            if (same_thr) LFQ_LAUNCH_LW(true); else LFQ_LAUNCH_LW(false);
+#undef LFQ_LAUNCH_LW
+#undef LFQ_LAUNCH_LU
+#undef LFQ_LAUNCH_L
+            LFQ_HIP_TRY(hipGetLastError());
+            return LFQ_OK;
+        }
 #define LFQ_LAUNCH_F(PK, ST, SM, W)                                                                                  \
     hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
                        d_counts, d_flags, c0, c1)
@@ -1460,8 +1672,6 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         case 1: LFQ_LAUNCH_FW(false, false, true); break;
         case 2: LFQ_LAUNCH_FW(false, true, false); break;
         case 3: LFQ_LAUNCH_FW(false, true, true); break;
-        case 4: LFQ_LAUNCH_FW(true, false, false); break;
-        case 5: LFQ_LAUNCH_FW(true, false, true); break;
         case 6: LFQ_LAUNCH_FW(true, true, false); break;
         default: LFQ_LAUNCH_FW(true, true, true); break;
         }
@@ -1606,6 +1816,7 @@ __global__ __launch_bounds__(256) void lfq_strand_heavy_kernel(LfqTracksDev T, L
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             counts[col].alt_fw[a] = alt_fw[a];
+            counts[col].alt_raw_counts[a] = alt_raw[a];
             int4 t = make_int4(0, 0, 0, 0);
             if (alt_raw[a] >= min_alt) {
                 t = make_int4(ref_fw, ref_rv, alt_fw[a], alt_raw[a] - alt_fw[a]);
@@ -1630,6 +1841,9 @@ __global__ __launch_bounds__(256) void lfq_strand_pvals_kernel(LfqTracksDev T, l
             pvals[i].counts.alt_fw[0] = alt_fw[0];
             pvals[i].counts.alt_fw[1] = alt_fw[1];
             pvals[i].counts.alt_fw[2] = alt_fw[2];
+            pvals[i].counts.alt_raw_counts[0] = alt_raw[0];
+            pvals[i].counts.alt_raw_counts[1] = alt_raw[1];
+            pvals[i].counts.alt_raw_counts[2] = alt_raw[2];
         }
     }
 }

@@ -138,10 +138,13 @@ LDBL_MIN = np.finfo(np.longdouble).tiny
 
 def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu_vcf_text=None, conf_kw=None,
                 default_filter=False, procs=None, columns=None, chrom="synth", pv_tol=1e-10, pv_deep_log=600.0,
-                pv_noise_a=0.16, pv_truth_tol=2e-11, chunk_cols=None):
+                pv_noise_a=0.16, pv_truth_tol=2e-11, chunk_cols=None, lazy_raw=False):
     """Compare one device batch of the synthetic workload with the oracle.
 
     gpu_counts  COL_COUNTS_DTYPE[ncols] (dense device output: n_err_probs, alt_counts, alt_raw_counts, tested)
+    lazy_raw    the batch ran with lfq_set_dense_strand_counts(ctx, 0): a column's dense alt_raw_counts are the oracle's or
+                all 0 (the library counts them, like the strand fields, only where a record can use them -- and every
+                record's alt_raw_count is compared below); "dense_raw_columns" says how many were filled
     gpu_recs    SNV_RECORD_DTYPE[] of the same batch (column order)
     columns     None = every column; else a sorted array of column indices (each its own one-column range)
     p-values: against the oracle 1e-10 up to |log p| = pv_deep_log and, beyond, the noise bound of the reference's own
@@ -164,15 +167,21 @@ def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu
 
     L = orc.lib()
     n_cols_cmp = 0
+    n_raw_filled = 0
     bad_counts = []
     exp = []                                    # (col, allele index, row, ref base)
     for r in res:
         b, n = r["begin"], r["n"]
         g = gpu_counts[b:b + n]
         n_cols_cmp += n
-        for f in ("n_err_probs", "alt_counts", "alt_raw_counts"):
+        for f in ("n_err_probs", "alt_counts"):
             if not np.array_equal(g[f], r[f]):
                 bad_counts.append((int(b), f))
+        same_raw = (np.asarray(g["alt_raw_counts"]) == np.asarray(r["alt_raw_counts"])).reshape(n, -1).all(axis=1)
+        zero_raw = (np.asarray(g["alt_raw_counts"]) == 0).reshape(n, -1).all(axis=1)
+        if not (same_raw | zero_raw).all() if lazy_raw else not same_raw.all():
+            bad_counts.append((int(b), "alt_raw_counts"))
+        n_raw_filled += int(same_raw.sum())
         if not np.array_equal(g["tested"].astype(np.uint8), r["tested"]):
             bad_counts.append((int(b), "tested"))
         for c, row, ref, tr in zip(r["emit_cols"], r["emit_rows"], r["emit_ref"], r["emit_truth_log"]):
@@ -257,7 +266,7 @@ def check_batch(orc, seed, depth, plant_period, ncols, gpu_counts, gpu_recs, gpu
         if not vcf_identical:
             mism.append("VCF text differs (%d oracle lines, %d device lines)" % (n_lines, gpu_vcf_text.count("\n")))
     return {
-        "columns_compared": int(n_cols_cmp), "counts_identical": not bad_counts,
+        "columns_compared": int(n_cols_cmp), "counts_identical": not bad_counts, "dense_raw_columns": int(n_raw_filled),
         "reference_records": len(exp), "gpu_records": int(len(in_scope)), "records_compared": min(len(exp), len(in_scope)),
         "sentinel_pvalues": n_sentinel,
         "max_dlogp_upto_600": max_d["le"][0], "n_pvalues_upto_600": max_d["le"][1],

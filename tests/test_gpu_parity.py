@@ -510,7 +510,7 @@ def test_config_full_batch(caller, oracle, cfg, depth):
         stride = 10 if procs >= 12 else 50
         cols = np.union1d(np.arange(0, ncols, period), np.arange(0, ncols, stride))
     out = fc.check_batch(oracle, seed, depth, period, ncols, counts, recs, gpu_vcf_text=text, columns=cols, procs=procs,
-                         default_filter=(cfg == 2))
+                         default_filter=(cfg == 2), lazy_raw=True)
     print("C%d full batch: %s" % (cfg, {k: v for k, v in out.items() if k != "mismatches"}))
     assert out["identical"], out["mismatches"]
     # every emitted record's p-value against the exact (80-bit) tail too, not a sample: the sentinels have no finite tail
