@@ -323,7 +323,7 @@ __device__ __forceinline__ void lfq_count_chunk_packed(LfqAcc &a, lfq_v2u n2, lf
 }
 
 /* h: the column's header out of LDS -- start (64 bit), length (0: gated or past the end), - */
-template <int LPG, int AHEAD>
+template <int LPG, int AHEAD, bool ALWAYS = false>
 __device__ __forceinline__ void lfq_group_issue(LfqGroupLoads<AHEAD> &L, const LfqTracksDev &T, uint4 h, int i0, uint64_t pass_last)
 {
     const uint32_t c0_lo = (h.x >> 4) | (h.y << 28);                  /* chunk of the column's start, low half */
@@ -340,7 +340,8 @@ __device__ __forceinline__ void lfq_group_issue(LfqGroupLoads<AHEAD> &L, const L
     for (int k = 0; k < AHEAD; k++) {
         /* (a step no column of the wavefront's group reaches is skipped as a whole: wave-uniform, the same test as in
          * lfq_group_consume) */
-        if (k == 0 || __any(i0 + k * LPG < n_ch)) {
+        /* (ALWAYS: the caller keeps two steps' loads in flight and wants their number known when it waits for the older ones) */
+        if (ALWAYS || k == 0 || __any(i0 + k * LPG < n_ch)) {
             const uint32_t at = min(rel + (uint32_t)(k * LPG), rel_last);
             L.n2[k] = __builtin_amdgcn_raw_buffer_load_b64(nt_rsrc, (int)(at << 3), 0, 0);
             L.b4[k] = __builtin_amdgcn_raw_buffer_load_b128(bq_rsrc, (int)(at << 4), 0, 0);
@@ -582,24 +583,51 @@ __global__ __launch_bounds__(256, STRAND ? 3 : LFQ_COUNT_WAVES) void lfq_count_s
                 }                                                                                                       \
             } while (0)
             {
-#pragma unroll 1
-                for (int sub = 0; sub < n_sub; sub++) {
-                    const int cw = sub * G + g;
-                    const uint4 h = s_hdr[wave][cw];
-                    LfqAcc a;
-                    LFQ_SHALLOW_ZERO(a);
-#pragma unroll 1
-                    for (int rd = 0; rd < rounds; rd++) {
-                        const int i0 = l + rd * (LFQ_COUNT_AHEAD * LPG);
-                        if (rd > 0 && !__any(i0 < (int)(((h.x & 15u) + h.z + 15u) >> 4))) {
-                            break;                   /* no column of this group reaches into the round */
-                        }
-                        LfqGroupLoads<LFQ_COUNT_AHEAD> L;
-                        lfq_group_issue<LPG, LFQ_COUNT_AHEAD>(L, T, h, i0, pass_last);
-                        LFQ_SHALLOW_CONSUME(a, L, h, i0);
-                    }
-                    LFQ_SHALLOW_SUMS(a, cw);
+                /* The steps of a pass -- the G columns `sub` at a time, AHEAD chunks per lane and round `rd` -- as ONE sequence
+                 * with the loads of step s + 1 requested before step s is counted: a wavefront alone has nothing in flight
+                 * while it counts, and four of them per SIMD do not cover that (per wavefront and pass: 16 x (latency +
+                 * counting) one after the other).  Two sets of load registers, the loop unrolled by two so that each set is
+                 * a fixed set of registers; the step after (sub, rd) is the next round of the same columns if any of them
+                 * reaches into it, else the first round of the next G columns. */
+                int sub = 0, rd = 0;
+                uint4 hA = s_hdr[wave][g], hB = hA;
+                int i0A = l, i0B = l;
+                LfqGroupLoads<LFQ_COUNT_AHEAD> LA, LB;
+                LfqAcc a;
+                LFQ_SHALLOW_ZERO(a);
+                lfq_group_issue<LPG, LFQ_COUNT_AHEAD, true>(LA, T, hA, i0A, pass_last);
+#define LFQ_SHALLOW_STEP(Lc_, hc_, i0c_, Ln_, hn_, i0n_)                                                                \
+                {                                                                                                       \
+                    int sub_n = sub, rd_n = rd + 1;                                                                     \
+                    hn_ = hc_;                                                                                          \
+                    i0n_ = l + rd_n * (LFQ_COUNT_AHEAD * LPG);                                                          \
+                    if (rd_n >= rounds || !__any(i0n_ < (int)(((hc_.x & 15u) + hc_.z + 15u) >> 4))) {                   \
+                        sub_n = sub + 1;                                                                                \
+                        rd_n = 0;                                                                                       \
+                        i0n_ = l;                                                                                       \
+                        hn_ = s_hdr[wave][(sub_n < n_sub ? sub_n : sub) * G + g];                                       \
+                    }                                                                                                   \
+                    const bool have_n = sub_n < n_sub;                                                                  \
+                    /* (behind the pass's last step too: the last columns' chunks once more, counted by nobody -- a branch   \
+                     * around the loads would cost the compiler its count of what is in flight, and with it the prefetch) */ \
+                    lfq_group_issue<LPG, LFQ_COUNT_AHEAD, true>(Ln_, T, hn_, i0n_, pass_last);                          \
+                    LFQ_SHALLOW_CONSUME(a, Lc_, hc_, i0c_);                                                             \
+                    if (!have_n || rd_n == 0) {                                                                         \
+                        LFQ_SHALLOW_SUMS(a, sub * G + g);                                                               \
+                        LFQ_SHALLOW_ZERO(a);                                                                            \
+                    }                                                                                                   \
+                    if (!have_n) {                                                                                      \
+                        break;                                                                                          \
+                    }                                                                                                   \
+                    sub = sub_n;                                                                                        \
+                    rd = rd_n;                                                                                          \
                 }
+#pragma unroll 1
+                for (;;) {
+                    LFQ_SHALLOW_STEP(LA, hA, i0A, LB, hB, i0B)
+                    LFQ_SHALLOW_STEP(LB, hB, i0B, LA, hA, i0A)
+                }
+#undef LFQ_SHALLOW_STEP
             }
 #undef LFQ_SHALLOW_ZERO
 #undef LFQ_SHALLOW_CONSUME
