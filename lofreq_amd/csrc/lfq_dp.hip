@@ -26,6 +26,8 @@
  *                                         global scratch beyond 8 strips
  *   lfq_dp_wave_kernel<1> (one light column per wavefront) is kept as the A/B reference of the quad kernel.
  */
+#include <atomic>
+
 #include "lfq_device.h"
 
 #define LFQ_LN2_HI 6.93147180369123816490e-01
@@ -1595,7 +1597,7 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
  * kp == 0: the record is emitted here.  Otherwise the column is cut into row segments (a record in the
  * class list of its kp) or, if it is too short / too wide / the pool is full, queued for the unsplit
  * strip-pipeline kernel. */
-__global__ __launch_bounds__(LFQ_PREP_WAVES * 64) void lfq_dp_big_prep_kernel(
+__global__ __launch_bounds__(LFQ_PREP_WAVES * 64, 3) void lfq_dp_big_prep_kernel(
     LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
     LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity)
 {
@@ -1930,13 +1932,20 @@ __device__ __forceinline__ bool lfq_comb_plan(LfqCombShared &sh, int K)
     return true;
 }
 
+/* Footprint: this kernel mostly finds nothing to do (the tree fold finishes every column of the usual batches), but it is
+ * a link of the chain, and when the count kernel of the next batch fills the machine its workgroups only start where
+ * they fit into what ONE retiring count workgroup frees: 2 wavefronts per SIMD x <= 168 registers (at 204 they waited
+ * for a CU with no count workgroup at all -- 1.2-1.6 ms for 20 us of work, the longest link of the chain).  The LDS
+ * block is requested at launch (dynamic) so that the compiler's occupancy estimate, which its 82 KB would pin at two
+ * wavefronts per SIMD, does not overrule the register bound. */
 template <int MODE>
-__global__ __launch_bounds__(LFQ_COMB_THREADS) void lfq_dp_combine_kernel(LfqParams P,
-                                                                          const lfq_col_counts *__restrict__ counts,
-                                                                          LfqWork W, lfq_col_pvals *__restrict__ pvals,
-                                                                          int64_t pvals_capacity, int only_flagged)
+__global__ __launch_bounds__(LFQ_COMB_THREADS, 3) void lfq_dp_combine_kernel(LfqParams P,
+                                                                             const lfq_col_counts *__restrict__ counts,
+                                                                             LfqWork W, lfq_col_pvals *__restrict__ pvals,
+                                                                             int64_t pvals_capacity, int only_flagged)
 {
-    __shared__ LfqCombShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lfq_comb_lds[];
+    LfqCombShared &sh = *reinterpret_cast<LfqCombShared *>(lfq_comb_lds);
     const int tid = threadIdx.x;
     const int lane = lfq_lane();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2904,15 +2913,33 @@ int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_
     }
     /* the tree fold first; the block kernel behind it takes what the fold flagged (tilt out of range, K beyond its
      * classes) and skips the columns it finished */
+    {                                                   /* > 64 KB of dynamic LDS has to be allowed once per device */
+        static std::atomic<unsigned long long> allowed{0ull};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            return LFQ_ERR_HIP;
+        }
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(allowed.load(std::memory_order_acquire) & bit)) {
+            const int bytes = (int)sizeof(LfqCombShared);
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lfq_dp_combine_kernel<0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&lfq_dp_combine_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+                return LFQ_ERR_HIP;
+            }
+            allowed.fetch_or(bit, std::memory_order_release);
+        }
+    }
     if (mode == 0) {
         hipLaunchKernelGGL(lfq_dp_fold_kernel<0>, dim3((unsigned)n_blocks * 4), dim3(64 * LFQ_FOLD_WAVES), 0,
                            (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
-        hipLaunchKernelGGL(lfq_dp_combine_kernel<0>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
+        hipLaunchKernelGGL(lfq_dp_combine_kernel<0>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), sizeof(LfqCombShared),
                            (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, 1);
     } else {
         hipLaunchKernelGGL(lfq_dp_fold_kernel<1>, dim3((unsigned)n_blocks), dim3(64 * LFQ_FOLD_WAVES), 0,
                            (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity);
-        hipLaunchKernelGGL(lfq_dp_combine_kernel<1>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), 0,
+        hipLaunchKernelGGL(lfq_dp_combine_kernel<1>, dim3((unsigned)n_blocks), dim3(LFQ_COMB_THREADS), sizeof(LfqCombShared),
                            (hipStream_t)stream, p, d_counts, w, d_pvals, pvals_capacity, 1);
     }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
