@@ -37,7 +37,14 @@
 #define LFQ_EXP_UNDERFLOW_X (-708.3964185322641)
 #define LFQ_DBL_EPS 2.220446049250313e-16
 
+#ifndef LFQ_HEAVY_WAVES
 #define LFQ_HEAVY_WAVES 8
+#endif
+/* wavefronts per SIMD the 512-thread kernels of the long-column chains are compiled for (their register bound: 3 -> 168,
+ * 4 -> 128): what a workgroup of theirs needs per SIMD, 2 x that, has to fit beside the next batch's count kernel */
+#ifndef LFQ_DP512_WAVES
+#define LFQ_DP512_WAVES 3
+#endif
 
 struct LfqColCtx {
     int col;
@@ -1522,7 +1529,7 @@ __device__ __forceinline__ void lfq_big_column(LfqColCtx &cx, const lfq_col_coun
     }
 }
 
-__global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
+__global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, LFQ_DP512_WAVES) void lfq_dp_big_kernel(
     LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
     LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity, double *__restrict__ scratch,
     int64_t scratch_per_block)
@@ -1597,7 +1604,7 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64) void lfq_dp_big_kernel(
  * kp == 0: the record is emitted here.  Otherwise the column is cut into row segments (a record in the
  * class list of its kp) or, if it is too short / too wide / the pool is full, queued for the unsplit
  * strip-pipeline kernel. */
-__global__ __launch_bounds__(LFQ_PREP_WAVES * 64, 3) void lfq_dp_big_prep_kernel(
+__global__ __launch_bounds__(LFQ_PREP_WAVES * 64, LFQ_DP512_WAVES) void lfq_dp_big_prep_kernel(
     LfqTracksDev T, LfqParams P, const LfqLuts *__restrict__ g_luts, const lfq_col_counts *__restrict__ counts,
     LfqWork W, lfq_col_pvals *__restrict__ pvals, int64_t pvals_capacity)
 {
@@ -1815,7 +1822,9 @@ __global__ __launch_bounds__(256) void lfq_dp_seg_kernel(LfqTracksDev T, LfqPara
 /* combine: fold the segment distributions of a split column, then finish it like the big kernel */
 /* ------------------------------------------------------------------------------------------ */
 
+#ifndef LFQ_COMB_THREADS
 #define LFQ_COMB_THREADS 512
+#endif
 #define LFQ_FOLD_MAX_CLASS 3        /* cells-per-lane classes 0..3 (K <= 1008) are folded by lfq_dp_fold_kernel */
 #define LFQ_COMB_CELLS 2048
 #define LFQ_COMB_PER_THREAD (LFQ_COMB_CELLS / LFQ_COMB_THREADS)
@@ -1939,7 +1948,7 @@ __device__ __forceinline__ bool lfq_comb_plan(LfqCombShared &sh, int K)
  * block is requested at launch (dynamic) so that the compiler's occupancy estimate, which its 82 KB would pin at two
  * wavefronts per SIMD, does not overrule the register bound. */
 template <int MODE>
-__global__ __launch_bounds__(LFQ_COMB_THREADS, 3) void lfq_dp_combine_kernel(LfqParams P,
+__global__ __launch_bounds__(LFQ_COMB_THREADS, LFQ_DP512_WAVES) void lfq_dp_combine_kernel(LfqParams P,
                                                                              const lfq_col_counts *__restrict__ counts,
                                                                              LfqWork W, lfq_col_pvals *__restrict__ pvals,
                                                                              int64_t pvals_capacity, int only_flagged)

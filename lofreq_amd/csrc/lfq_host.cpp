@@ -72,7 +72,7 @@ const LfqKnobs &lfq_knobs(void)
         x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
         {
             const long w = geti("LFQ_COUNT_WAVES_PER_WG", 16);
-            x.count_waves_per_wg = (w == 4 || w == 8) ? (int)w : 16;
+            x.count_waves_per_wg = (w == 4 || w == 8 || w == 12) ? (int)w : 16;
         }
         {
             const long u = geti("LFQ_COUNT_AHEAD_DEEP", 2);

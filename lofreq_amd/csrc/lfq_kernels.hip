@@ -1070,6 +1070,9 @@ template <bool SAME_THR, int UNROLL>
 __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq_col_counts *__restrict__ out,
                                                       uint8_t *__restrict__ flags, int64_t col, int lane)
 {
+#ifdef LFQ_COUNT_STAMP      /* profiling build (profiles/wave_stamps.py): when a wavefront started, got its header, left its loop */
+    const uint64_t st0 = wall_clock64();
+#endif
     const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
     const int64_t n_obs = (int64_t)(off1 - off0);
     const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
@@ -1080,6 +1083,9 @@ __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq
     const bool gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < T.min_cov);
 
     uint32_t ge[4] = {0u, 0u, 0u, 0u}, ga[4] = {0u, 0u, 0u, 0u};
+#ifdef LFQ_COUNT_STAMP
+    uint64_t st1 = st0, st2 = st0;
+#endif
     if (!gated && n_obs > 0) {
         const uint32_t kge = 0x01010101u * (uint32_t)(128 - T.min_bq4);          /* thresholds are clamped to 0..128 */
         const uint32_t kga = 0x01010101u * (uint32_t)(128 - T.min_alt_bq4);
@@ -1088,6 +1094,9 @@ __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq
         const uint2 *nt8 = reinterpret_cast<const uint2 *>(T.nt) + cbeg;
         const uint4 *bq16 = reinterpret_cast<const uint4 *>(T.bq) + cbeg;
         const int n_in = n_ch - 1;                                            /* interior chunks: 1 .. n_ch - 2 */
+#ifdef LFQ_COUNT_STAMP
+        st1 = wall_clock64() + (uint64_t)(n_ch & 0);
+#endif
         int i = 1 + lane;
         for (; i + (UNROLL - 1) * LFQ_WAVE < n_in; i += UNROLL * LFQ_WAVE) {  /* UNROLL chunks' loads in flight per lane */
             uint2 nv[UNROLL];
@@ -1135,6 +1144,9 @@ __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq
         }
     }
 
+#ifdef LFQ_COUNT_STAMP
+    st2 = wall_clock64() + (uint64_t)((ge[0] + ge[1] + ge[2] + ge[3]) & 0u);
+#endif
     /* the column's sums end up in lane 63, which writes the record */
     uint32_t n_ge[4], n_ga[4];
 #pragma unroll
@@ -1182,6 +1194,18 @@ __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq
             flag = (uint8_t)((r.tested ? 1 : 0)
                              | ((kmax >= LFQ_BIG_K) ? 4 : (kmax >= LFQ_MID_K || kmax >= suspicious) ? 2 : 0));
         }
+#ifdef LFQ_COUNT_STAMP
+        {
+            const uint64_t st3 = wall_clock64() + (uint64_t)(flag & 0);
+            r.alt_raw_counts[0] = (int)(uint32_t)st0;
+            r.alt_raw_counts[1] = (int)(uint32_t)(st0 >> 32);
+            r.alt_raw_counts[2] = (int)(uint32_t)(st1 - st0);
+            r.alt_fw[0] = (int)(uint32_t)(st2 - st0);
+            r.alt_fw[1] = (int)(uint32_t)(st3 - st0);
+            r.alt_fw[2] = (int)__builtin_amdgcn_s_getreg((4 /* HW_ID */) | (0 << 6) | (31 << 11));
+            r.ref_fw = (int)__builtin_amdgcn_s_getreg((20 /* XCC_ID */) | (0 << 6) | (31 << 11));
+        }
+#endif
         out[col] = r;
         flags[col] = flag;
     }
@@ -1676,6 +1700,7 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
 #define LFQ_LAUNCH_LW(SM)                                                                                            \
     do {                                                                                                             \
         if (wpw == 16) LFQ_LAUNCH_LU(SM, 16);                                                                        \
+        else if (wpw == 12) LFQ_LAUNCH_LU(SM, 12);                                                                   \
         else if (wpw == 8) LFQ_LAUNCH_LU(SM, 8);                                                                     \
         else LFQ_LAUNCH_LU(SM, 4);                                                                                   \
     } while (0)
@@ -1687,11 +1712,11 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
             return LFQ_OK;
         }
 #define LFQ_LAUNCH_F(PK, ST, SM, W)                                                                                  \
-    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, \
-                       d_counts, d_flags, c0, c1)
+    hipLaunchKernelGGL((lfq_count_fast_kernel<PK, ST, SM, W>), dim3((unsigned)((c1 - c0 + W - 1) / W)), dim3(64 * W), 0,     \
+                       (hipStream_t)stream, ca, d_counts, d_flags, c0, c1)
 #define LFQ_LAUNCH_FW(PK, ST, SM)                                                                                    \
     do {                                                                                                             \
-        if (wpw == 16) LFQ_LAUNCH_F(PK, ST, SM, 16);                                                                 \
+        if (wpw >= 12) LFQ_LAUNCH_F(PK, ST, SM, 16);                                                                 \
         else if (wpw == 8) LFQ_LAUNCH_F(PK, ST, SM, 8);                                                              \
         else LFQ_LAUNCH_F(PK, ST, SM, 4);                                                                            \
     } while (0)
