@@ -43,7 +43,7 @@
 /* wavefronts per SIMD the 512-thread kernels of the long-column chains are compiled for (their register bound: 3 -> 168,
  * 4 -> 128): what a workgroup of theirs needs per SIMD, 2 x that, has to fit beside the next batch's count kernel */
 #ifndef LFQ_DP512_WAVES
-#define LFQ_DP512_WAVES 3
+#define LFQ_DP512_WAVES 2
 #endif
 
 struct LfqColCtx {

@@ -43,5 +43,11 @@ python profiles/gpu_busy.py $out 0.6 > gpurun_out/r05_c4_gpu_busy_final.md 2>&1
 out=$R/gpurun_out/prof_r05_tl_C2; rm -rf $out; mkdir -p $out
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace -d $out -o t -- python $R/bench.py --config C2 --steps 6 --warmup 3 --repeats 1 --no-pipeline --no-cpu-baseline --no-pmc --no-secondary --no-full-check > /dev/null 2>&1)
 python profiles/timeline.py $out > gpurun_out/r05_timeline_C2.txt 2>&1
+# steady state of the queued run (what the driver's line is timed in): per-kernel durations and one period, C3 and C2
+for cfg in C3 C2; do
+  o=$R/gpurun_out/prof_r05_ov_$cfg; rm -rf $o; mkdir -p $o
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace -d $o -o t -- python $R/bench.py --config $cfg --in-flight 4 --gate none --steps 16 --warmup 4 --repeats 1 --no-cpu-baseline --no-pmc --no-secondary --no-full-check > $o/bench.log 2>&1)
+  { echo "# $cfg, four batches queued, no gate: profiles/overlap_timeline.py over a rocprofv3 --kernel-trace of bench.py --in-flight 4 --gate none"; python profiles/overlap_timeline.py $o 8; } > gpurun_out/r05_overlap_$cfg.txt 2>&1
+done
 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error|log p|records" > gpurun_out/r05_gpu_tests.txt
 ls gpurun_out | grep r05
