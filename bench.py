@@ -71,6 +71,10 @@ def parse_args():
     ap.add_argument("--distinct-bins", type=int, default=4,
                     help="C4 / C5: distinct sets of reads (generated from different seeds) that the genome's bins cycle through; "
                          "every bin its own set = the number of bins (32: minutes of generation and ~10 GB of pinned host memory)")
+    ap.add_argument("--upload-reads", action="store_true",
+                    help="C4 / C5: the timed steps upload every bin's reads from (pinned) host memory again -- the PCIe-inclusive "
+                         "rate; default: the read sets are resident in HBM when the timed region starts (uploaded in the "
+                         "warm-up), and the PCIe-inclusive rate of a few extra steps is reported beside `value`")
     ap.add_argument("--host-threads", type=int, default=4,
                     help="C4 / C5: host threads per rank, one context each, that work through the rank's bins (the host part "
                          "of one bin -- CIGAR geometry, event tables, test descriptors -- then runs under the kernels of another)")
@@ -783,8 +787,21 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         rs.close()
         return None
 
-    def start(caller, i):
-        rs = la.ReadSet.from_arrays(caller, tiles[i % n_tiles])
+    # Read sets resident in HBM (the default): a host thread keeps, per set of reads it meets, TWO resident copies and takes them in
+    # turn -- the BAQ of its next bin is queued while the pileups of the bin before still read theirs.  Nothing computed is kept
+    # between bins: every bin runs BAQ / IDAQ, both pileups and the tests on the raw reads again.  `upload["on"]`: a fresh
+    # lfq_readset_create (pinned host arrays -> HBM) per bin instead, what a caller that streams a BAM pays on top.
+    upload = {"on": bool(args.upload_reads)}
+    pools = [dict() for _ in callers]
+
+    def start(caller, i, t=0, seq=0):
+        if upload["on"]:
+            rs = la.ReadSet.from_arrays(caller, tiles[i % n_tiles])
+        else:
+            key = (i % n_tiles, seq & 1)
+            rs = pools[t].get(key)
+            if rs is None:
+                rs = pools[t][key] = la.ReadSet.from_arrays(caller, tiles[i % n_tiles])
         rs.baq(extended=True, idaq=cfg["call_indels"])
         return rs
 
@@ -832,7 +849,8 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE).copy()
         pv["col"] = dt.col_pos[pv["col"]]
         ncalled = n if target is None else int(target[dt.col_pos].sum())
-        rs.close()
+        if not any(rs is x for pool in pools for x in pool.values()):
+            rs.close()
         return (i, b, pv, int(st.n_tested)), ient, ncalled
 
     def work(t, res):
@@ -841,8 +859,8 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         try:
             c_, (dc, dp) = callers[t], outs[t]
             pending = None
-            for (i, b, e) in my[t::n_thr]:
-                rs = start(c_, i)
+            for seq, (i, b, e) in enumerate(my[t::n_thr]):
+                rs = start(c_, i, t, seq)
                 if pending is not None:
                     res.append(finish(c_, dc, dp, *pending))
                 pending = (rs, i, b)
@@ -926,6 +944,25 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         conf, ncols_mine, text, nrecs = step()
     barrier()
     dt = time.perf_counter() - t0
+    dt_upload = None
+    if not upload["on"]:
+        # the PCIe-inclusive rate beside it: the same steps with every bin's reads uploaded again (never `value`)
+        upload["on"] = True
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        n_up = max(1, min(args.steps, 3))
+        for _ in range(n_up):
+            _, _, text_up, _ = step()
+        barrier()
+        dt_upload = (time.perf_counter() - t1) / n_up
+        upload["on"] = False
+        if rank == 0 and text_up != text:
+            raise RuntimeError("resident and uploaded read sets give different VCFs")
+    for pool in pools:
+        for rs_ in pool.values():
+            rs_.close()
+        pool.clear()
     tot_cols = torch.tensor([float(ncols_mine)], dtype=torch.float64, device=xdev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=xdev)
     if world > 1:
@@ -958,6 +995,11 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         "config": {"workload": "%s: %s" % (cfg_name, cfg["what"]), "genome_len": glen, "called_columns": called, "bins": nb,
                    "bins_rank0": len(my), "host_threads_per_rank": n_thr, "bin_len": tile_len, "reads_per_bin": int(R["n"]), "reads_per_step": sum(int(tiles[i % n_tiles]["n"]) for i in range(nb)),
                    "distinct_bins": n_tiles,
+                   "reads": ("uploaded from pinned host memory for every bin inside the timed region (--upload-reads)" if args.upload_reads else
+                             "resident in HBM when the timed region starts (two copies per host thread and set, uploaded in the warm-up); "
+                             "every bin runs BAQ, pileups and tests on the raw reads again"),
+                   "ms_per_step_with_upload": (1e3 * dt_upload if dt_upload is not None else None),
+                   "value_with_upload": (called / dt_upload if dt_upload else None),
                    "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
                    "snv_tests": int(conf.num_snv_tests), "indel_tests": int(conf.num_indel_tests),
                    "snv_records_before_filter": nrecs[0], "indel_records": nrecs[1],

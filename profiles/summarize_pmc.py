@@ -33,8 +33,8 @@ def main(root, tag):
              "Separate `rocprofv3 --pmc <one counter> --kernel-trace` passes of `bench.py --pmc-child` (2 steps, LFQ_SINGLE_STREAM=1)",
              "(C3, 1 MI355X).  One counter per pass: FETCH_SIZE and WRITE_SIZE together exceed what the hardware collects at once",
              "(rocprofv3 aborts with error 38 and then sits until it is killed -- the 'hang' of the earlier attempts).",
-             "`lfq_count_fast_kernel<packed nt, strand planes, one BQ threshold, columns per workgroup>` (round 5; `lfq_count_kernel<packed nt, strand planes>` before): `<true, false, ...>` is what `bench.py` runs (1.5 B per observation read,",
-             "strand counts only for the columns that emit); `<false, true>` = byte layout with dense strand counts.", "",
+             "`lfq_count_lean_kernel<one BQ threshold, columns per workgroup, chunks in flight per lane>` is what `bench.py` runs (packed nt: 1.5 B per",
+             "observation read; record-only counts left to the columns that emit); `lfq_count_fast_kernel` = byte layout / dense strand counts.", "",
              "Counter columns are sums over the launches; bytes are per launch.", "",
              "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch (corrected) | SQ_INSTS_VALU | "
              "SQ_WAVE_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE |", "|---|---|---|---|---|---|---|---|---|"]
@@ -45,7 +45,7 @@ def main(root, tag):
         d = allc[k]
         f, n = d.get("FETCH_SIZE", (0, 1))
         w, _ = d.get("WRITE_SIZE", (0, 1))
-        wide = k.startswith("lfq_count_kernel") or k.startswith("lfq_count_fast_kernel") or k.startswith("lfq_synth_kernel")
+        wide = k.startswith(("lfq_count_kernel", "lfq_count_fast_kernel", "lfq_count_lean_kernel", "lfq_synth_kernel"))
         byt = ((2.0 if wide else 1.0) * f + w) * 1024.0 / max(n, 1)
         traffic[k] = byt
         lines.append("| %s | %d | %.0f | %.0f | %.4g %s | %.4g | %.4g | %.4g | %.4g |" % (
