@@ -75,6 +75,7 @@ def parse_args():
                     help="C4 / C5: the timed steps upload every bin's reads from (pinned) host memory again -- the PCIe-inclusive "
                          "rate; default: the read sets are resident in HBM when the timed region starts (uploaded in the "
                          "warm-up), and the PCIe-inclusive rate of a few extra steps is reported beside `value`")
+    ap.add_argument("--no-upload-rate", action="store_true", help="C4 / C5: skip the extra steps that time the PCIe-inclusive rate")
     ap.add_argument("--host-threads", type=int, default=4,
                     help="C4 / C5: host threads per rank, one context each, that work through the rank's bins (the host part "
                          "of one bin -- CIGAR geometry, event tables, test descriptors -- then runs under the kernels of another)")
@@ -945,7 +946,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
     barrier()
     dt = time.perf_counter() - t0
     dt_upload = None
-    if not upload["on"]:
+    if not upload["on"] and not args.no_upload_rate:
         # the PCIe-inclusive rate beside it: the same steps with every bin's reads uploaded again (never `value`)
         upload["on"] = True
         step()
