@@ -806,9 +806,18 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         rs.baq(extended=True, idaq=cfg["call_indels"])
         return rs
 
+    phase_ms = {}
+
+    def lap(name, t_prev):
+        t_now = time.perf_counter()
+        if trace is not None:
+            phase_ms[name] = phase_ms.get(name, 0.0) + 1e3 * (t_now - t_prev)
+        return t_now
+
     def finish(caller, d_counts, d_pvals, rs, i, b):
         """pileups + tests of a started bin -> (snv entry for finish_bins, indel entry or None, indel lines' makings)"""
         ient = None
+        tp = time.perf_counter()
         skip = None
         target = tiles[i % n_tiles]["target"]
         if cfg["call_indels"]:
@@ -816,12 +825,15 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             col_pos = np.zeros(tile_len, np.int64)
             _lib.check(L.lfq_readset_pileup_indels(caller.h, rs.h, 0, tile_len, 0, C.byref(outp), col_pos.ctypes.data),
                        "lfq_readset_pileup_indels")
+            tp = lap("pileup_indels", tp)
             dt = rs.pileup_snv(0, tile_len)
+            tp = lap("pileup_snv", tp)
             ci = la.VarcallConf(flag=flag)
             rec = np.zeros(1 << 18, dtype=_lib.INDEL_RECORD_DTYPE)
             nrec, nt = C.c_int64(0), C.c_int64(0)
             _lib.check(L.lfq_call_indels_batch(caller.h, C.byref(ci.c), outp, rec.ctypes.data, len(rec), C.byref(nrec), C.byref(nt)),
                        "lfq_call_indels_batch")
+            tp = lap("call_indels", tp)
             oc = outp.contents
             rec = rec[: nrec.value].copy()
             # what the VCF line of a record needs besides the record: reference base and the event's key
@@ -836,8 +848,10 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             rec["col"] = col_pos[rec["col"]]                      # column of the bin -> offset in the bin
             ient = (i, b, rec, int(nt.value), lines)
             skip = np.frombuffer(C.string_at(oc.cons_indel, oc.ncols), np.uint8).copy()
+            tp = lap("indel python", tp)
         else:
             dt = rs.pileup_snv(0, tile_len)
+            tp = lap("pileup_snv", tp)
         if target is not None:
             off = 1 - target[dt.col_pos]                          # `-l bed`: the columns outside the targets are not called
             skip = off if skip is None else (skip | off)
@@ -845,13 +859,16 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             la.skip_snv_columns(caller, skip)
         conf = la.VarcallConf(flag=flag)
         n = int(dt.ncols)
+        tp = lap("skip columns", tp)
         caller.snv_batch_device(dt, conf, d_counts, d_pvals, cap)
         st = caller.batch_finish()
+        tp = lap("snv calls", tp)
         pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE).copy()
         pv["col"] = dt.col_pos[pv["col"]]
         ncalled = n if target is None else int(target[dt.col_pos].sum())
         if not any(rs is x for pool in pools for x in pool.values()):
             rs.close()
+        lap("records d2h", tp)
         return (i, b, pv, int(st.n_tested)), ient, ncalled
 
     def work(t, res):
@@ -861,7 +878,9 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             c_, (dc, dp) = callers[t], outs[t]
             pending = None
             for seq, (i, b, e) in enumerate(my[t::n_thr]):
+                t_s = time.perf_counter()
                 rs = start(c_, i, t, seq)
+                lap("start (readset + BAQ launch)", t_s)
                 if pending is not None:
                     res.append(finish(c_, dc, dp, *pending))
                 pending = (rs, i, b)
@@ -870,8 +889,11 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         except BaseException as ex:                  # the step must not hang on a dead thread
             res.append(ex)
 
+    trace = [] if os.environ.get("LFQ_BENCH_TRACE_STEPS") else None
+
     def step():
         import threading
+        ts = [time.perf_counter()]
         results = [[] for _ in range(n_thr)]
         th = [threading.Thread(target=work, args=(t, results[t])) for t in range(1, n_thr)]
         for x in th:
@@ -879,6 +901,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         work(0, results[0])
         for x in th:
             x.join()
+        ts.append(time.perf_counter())
         snv, ind, ncols = [], [], 0
         for s_, i_, n_ in sorted((r for res in results for r in ([r_ for r_ in res if not isinstance(r_, BaseException)])), key=lambda r: r[0][0]):
             snv.append(s_); ncols += n_
@@ -890,6 +913,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
                     raise r_
         conf = la.VarcallConf(flag=flag)
         recs, total = shard.finish_bins(conf, snv, nb, dist if world > 1 else None, xdev)
+        ts.append(time.perf_counter())
         text = None
         itext = []
         if cfg["call_indels"]:
@@ -923,6 +947,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
                 dist.gather_object(itext, gathered, dst=0)
                 if rank == 0:
                     itext = [x for part in gathered for x in part]
+        ts.append(time.perf_counter())
         if rank == 0:
             thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
             keepm = la.filter_records(recs, thr, apply_defaults=True)
@@ -930,6 +955,12 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             spos = [int(r["col"]) for r, k_ in zip(recs, keepm) if k_]
             merged = sorted([(p, 0, t) for p, t in itext] + [(p, 1, t) for p, t in zip(spos, stext)], key=lambda x: (x[0], x[1]))
             text = "".join(t for _, _, t in merged)
+        if trace is not None:
+            ts.append(time.perf_counter())
+            trace.append([1e3 * (b_ - a_) for a_, b_ in zip(ts, ts[1:])])
+            sys.stderr.write("[genome step] bins (threads) %.1f  finish_bins %.1f  indel exchange + text %.1f  SNV text + merge %.1f ms\n" % tuple(trace[-1]))
+            sys.stderr.write("   per bin, ms (sum over the threads / bins): " + "  ".join("%s %.2f" % (k, v / nb) for k, v in phase_ms.items()) + "\n")
+            phase_ms.clear()
         return conf, ncols, text, (len(recs) if recs is not None else 0, len(itext))
 
     def barrier():

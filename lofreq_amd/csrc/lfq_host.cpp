@@ -93,6 +93,7 @@ const LfqKnobs &lfq_knobs(void)
         x.indel_host_pack = has("LFQ_INDEL_HOST_PACK");
         x.pileup_atomic = has("LFQ_PILEUP_ATOMIC");
         x.baq_lds = geti("LFQ_BAQ_LDS", 1) != 0;
+        x.baq_idaq_beside = (int)geti("LFQ_BAQ_IDAQ_BESIDE", 0);
         x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
         return x;
     }();

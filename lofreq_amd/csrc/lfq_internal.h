@@ -216,6 +216,7 @@ struct LfqKnobs {
     int indel_host_pack;       /* LFQ_INDEL_HOST_PACK */
     int pileup_atomic;         /* LFQ_PILEUP_ATOMIC: read-major pileup kernels even for sorted reads */
     int baq_lds;               /* LFQ_BAQ_LDS (1) */
+    int baq_idaq_beside;       /* LFQ_BAQ_IDAQ_BESIDE (0): the narrow-band reads with indels on a side stream beside the plain launches (a lone BAQ + IDAQ call 6.2 -> 5.3 ms per 400 K reads, the reads -> VCF chain 37.7 -> 39.0 ms per region: off) */
     long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
 };
 const LfqKnobs &lfq_knobs(void);

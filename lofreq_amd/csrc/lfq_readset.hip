@@ -790,8 +790,8 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         if (lfq_knobs().baq_scratch_mb >= 0) {
             budget_b = (int64_t)lfq_knobs().baq_scratch_mb << 20;
         }
-        /* + 2: the three classes of reads round up to whole wavefronts separately */
-        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64 + 2, budget_b / per_wave));
+        /* + 3: the four groups of reads (plain narrow, narrow with indels, band 8, wide) round up to whole wavefronts separately */
+        int64_t waves = std::max<int64_t>(1, std::min<int64_t>((n + 63) / 64 + 3, budget_b / per_wave));
         auto keep = [&](auto **slot, int64_t *have, int64_t need) {
             if (need > *have) {
                 if (*slot) (void)hipFree(*slot);
@@ -835,9 +835,18 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
          * to a whole number of rounds over the SIMDs: a launch of 7.3 rounds takes as long as one of 8. */
         const int64_t n_wide = n - n_narrow - n_band8;
         const int64_t waves_wide = (n_wide + 63) / 64, waves_b8 = (n_band8 + 63) / 64;
-        const bool beside = n_narrow > 0 && waves_wide + waves_b8 > 0 && waves_wide + waves_b8 < waves / 4
-                            && c->side[0] != nullptr && c->side[1] != nullptr && !lfq_knobs().single_stream;
-        int64_t waves_n = beside ? waves - waves_wide - waves_b8 : waves;      /* slots of a narrow launch */
+        const bool side_ok = n_narrow > 0 && c->side[0] != nullptr && c->side[1] != nullptr && !lfq_knobs().single_stream;
+        const bool beside = side_ok && waves_wide + waves_b8 > 0 && waves_wide + waves_b8 < waves / 4;
+        /* The narrow-band reads with an indel operation (the IDAQ instantiation: 4 % of the bench's reads) as well, when every
+         * group has scratch slots of its own: behind the plain launches on the same stream they were a launch of a third of
+         * a round with the machine to itself (0.8 ms per 479 K reads); beside them they fill the plain launch's last round. */
+        const int64_t waves_i = (n_narrow - n_plain + 63) / 64;
+        const bool beside_i = side_ok && lfq_knobs().baq_idaq_beside && n_plain > 0 && waves_i > 0 && waves_i < waves / 4
+                              && (n_plain + 63) / 64 + waves_i + (beside ? waves_wide + waves_b8 : 0) <= waves;
+        /* (they share the band-8 launch's stream: the first side stream tends to be multiplexed onto the hardware queue of
+         * c->stream, where a launch waits for the one before it whatever stream it came from) */
+        const bool use_side0 = beside && n_wide > 0, use_side1 = (beside && n_band8 > 0) || beside_i;
+        int64_t waves_n = waves - (beside ? waves_wide + waves_b8 : 0) - (beside_i ? waves_i : 0);      /* slots of a narrow launch */
         const int64_t round = (int64_t)c->n_cu * 4;
         if ((n_narrow + 63) / 64 > waves_n && waves_n > round) {       /* more than one launch: whole rounds each */
             waves_n = waves_n / round * round;
@@ -856,7 +865,7 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         /* The reads may still be crossing PCIe (lfq_readset_create): a launch waits for the chunks of bases and qualities
          * that hold its reads -- the plain narrow-band launches walk the reads in input order, so the first one starts
          * after a quarter of them --, everything else for all of them. */
-        if (beside && hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
+        if ((use_side0 || use_side1) && hipEventRecord(c->ev_join[0], c->stream) != hipSuccess) {
             rc = LFQ_ERR_HIP;       /* the side streams start after the uploads / memsets queued on c->stream so far */
         }
         /* timing events around the call's BAQ kernels (lfq_last_baq_times) */
@@ -910,44 +919,46 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         if (rc == LFQ_OK) {
             rc = readset_upload_wait_inputs(rs, {c->stream, c->side[0], c->side[1]});
         }
-        if (beside) {
-            /* wide-band and band-8 reads on the side streams, beside the narrow-band launches; c->stream ends after them */
-            if (rc == LFQ_OK && n_wide > 0) {
+        if (use_side0 || use_side1) {
+            /* wide-band, band-8 and (beside_i) the narrow-band reads with indels on the side streams, beside the plain narrow-band
+             * launches; c->stream ends after them */
+            if (rc == LFQ_OK && use_side0 && hipStreamWaitEvent(c->side[0], c->ev_join[0], 0) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (rc == LFQ_OK && beside && n_wide > 0) {
                 LfqBaqArgs Aw = at_slot(waves_n + waves_b8);
                 Aw.first_read = (int32_t)(n_narrow + n_band8);
-                if (hipStreamWaitEvent(c->side[0], c->ev_join[0], 0) != hipSuccess) {
-                    rc = LFQ_ERR_HIP;
-                }
-                if (rc == LFQ_OK) {
-                    rc = lfq_launch_baq(Aw, n_wide, 0, c->side[0]);
-                }
+                rc = lfq_launch_baq(Aw, n_wide, 0, c->side[0]);
             }
-            if (rc == LFQ_OK && n_band8 > 0) {
+            if (rc == LFQ_OK && use_side1 && hipStreamWaitEvent(c->side[1], c->ev_join[0], 0) != hipSuccess) {
+                rc = LFQ_ERR_HIP;
+            }
+            if (rc == LFQ_OK && beside_i) {
+                LfqBaqArgs Ai = at_slot(waves_n + (beside ? waves_b8 + waves_wide : 0));
+                Ai.first_read = (int32_t)n_plain;
+                rc = lfq_launch_baq(Ai, n_narrow - n_plain, 1, c->side[1]);
+                c->baq_launches++;
+            }
+            if (rc == LFQ_OK && beside && n_band8 > 0) {
                 LfqBaqArgs Ab = at_slot(waves_n);
                 Ab.first_read = (int32_t)n_narrow;
-                if (hipStreamWaitEvent(c->side[1], c->ev_join[0], 0) != hipSuccess) {
-                    rc = LFQ_ERR_HIP;
-                }
-                if (rc == LFQ_OK) {
-                    rc = lfq_launch_baq(Ab, n_band8, 2, c->side[1]);
-                }
+                rc = lfq_launch_baq(Ab, n_band8, 2, c->side[1]);
             }
-            if (rc == LFQ_OK && (hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess
-                                 || hipEventRecord(c->ev_join[2], c->side[1]) != hipSuccess)) {
+            if (rc == LFQ_OK && ((use_side0 && hipEventRecord(c->ev_join[1], c->side[0]) != hipSuccess)
+                                 || (use_side1 && hipEventRecord(c->ev_join[2], c->side[1]) != hipSuccess))) {
                 rc = LFQ_ERR_HIP;
             }
         }
-        for (int64_t first = n_plain; rc == LFQ_OK && first < n_narrow; first += waves_n * 64) {
+        for (int64_t first = n_plain; rc == LFQ_OK && !beside_i && first < n_narrow; first += waves_n * 64) {
             A.first_read = (int32_t)first;
             rc = lfq_launch_baq(A, std::min<int64_t>(waves_n * 64, n_narrow - first), 1, c->stream);
             c->baq_launches++;
         }
-        if (beside) {
-            if (rc == LFQ_OK && (hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess
-                                 || hipStreamWaitEvent(c->stream, c->ev_join[2], 0) != hipSuccess)) {
-                rc = LFQ_ERR_HIP;
-            }
-        } else {
+        if (rc == LFQ_OK && ((use_side0 && hipStreamWaitEvent(c->stream, c->ev_join[1], 0) != hipSuccess)
+                             || (use_side1 && hipStreamWaitEvent(c->stream, c->ev_join[2], 0) != hipSuccess))) {
+            rc = LFQ_ERR_HIP;
+        }
+        if (!beside) {
             for (int64_t first = n_narrow; rc == LFQ_OK && first < n_narrow + n_band8; first += waves * 64) {
                 A.first_read = (int32_t)first;
                 rc = lfq_launch_baq(A, std::min<int64_t>(waves * 64, n_narrow + n_band8 - first), 2, c->stream);
