@@ -78,6 +78,7 @@ const LfqKnobs &lfq_knobs(void)
             const long u = geti("LFQ_COUNT_AHEAD_DEEP", 2);
             x.count_ahead_deep = (u == 3 || u == 4) ? (int)u : 2;
         }
+        x.count_cols_per_wave = (int)std::min(std::max(geti("LFQ_COUNT_COLS_PER_WAVE", 1), 1L), 16L);
         x.big_on_side = has("LFQ_BIG_ON_SIDE");
         x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);

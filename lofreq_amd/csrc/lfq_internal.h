@@ -201,6 +201,8 @@ struct LfqKnobs {
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */
     int count_waves_per_wg;    /* LFQ_COUNT_WAVES_PER_WG (16; 4, 8): columns per workgroup of the one-column-per-wavefront count kernel */
     int count_ahead_deep;      /* LFQ_COUNT_AHEAD_DEEP (2; 3, 4): chunks of 16 observations in flight per lane of the lean count kernel */
+    int count_cols_per_wave;   /* LFQ_COUNT_COLS_PER_WAVE (1; 2, 4): columns a wavefront of the lean count kernel takes one after the other,
+                                * all their headers requested when it starts */
     int big_on_side;           /* LFQ_BIG_ON_SIDE: the unsplit big columns behind the big chain instead of on the count kernel's stream
                                 * (a context with LFQ_GATE_NONE runs that way by itself) */
     int baq_one_variant;       /* LFQ_BAQ_ONE_VARIANT: every wavefront of the plain narrow-band BAQ launches through the instantiation with the N case */

@@ -1066,18 +1066,38 @@ __device__ __forceinline__ void lfq_count_column_fast(const LfqCountArgs &T, lfq
  * whose records can use them.  The interior chunks of the column run through a loop without a test for the column's two
  * ragged ends (lfq_count_nib8_lean, 15 instructions per 8 observations); the two end chunks go to lanes 63 and 62, which
  * have the fewest interior ones. */
+/* a column's header: all of it through the scalar unit (the column index is the wavefront's), so that the header of a
+ * wavefront's NEXT column can be requested before the current one is counted and costs no vector register */
+struct LfqColHdr {
+    uint64_t off0, off1;
+    int32_t cov, nb;                 /* valid when the tracks carry them */
+    uint32_t rb_word;                /* the aligned dword that holds the reference base */
+};
+
+__device__ __forceinline__ LfqColHdr lfq_load_col_hdr(const LfqCountArgs &T, int64_t col)
+{
+    LfqColHdr h;
+    h.off0 = T.col_off[col];
+    h.off1 = T.col_off[col + 1];
+    h.cov = T.coverage_plp ? T.coverage_plp[col] : 0;
+    h.nb = T.num_bases ? T.num_bases[col] : 0;
+    const uint8_t *p = T.ref_base + col;                 /* (pointer arithmetic, no integer round trip: the load stays a scalar one) */
+    h.rb_word = *reinterpret_cast<const uint32_t *>(p - (reinterpret_cast<uintptr_t>(p) & 3u));
+    return h;
+}
+
 template <bool SAME_THR, int UNROLL>
 __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq_col_counts *__restrict__ out,
-                                                      uint8_t *__restrict__ flags, int64_t col, int lane)
+                                                      uint8_t *__restrict__ flags, int64_t col, int lane, const LfqColHdr &H)
 {
 #ifdef LFQ_COUNT_STAMP      /* profiling build (profiles/wave_stamps.py): when a wavefront started, got its header, left its loop */
     const uint64_t st0 = wall_clock64();
 #endif
-    const uint64_t off0 = T.col_off[col], off1 = T.col_off[col + 1];
+    const uint64_t off0 = H.off0, off1 = H.off1;
     const int64_t n_obs = (int64_t)(off1 - off0);
-    const int cov = T.coverage_plp ? T.coverage_plp[col] : (int)n_obs;
-    const int nb = T.num_bases ? T.num_bases[col] : (int)n_obs;
-    const uint32_t rb = T.ref_base[col];
+    const int cov = T.coverage_plp ? H.cov : (int)n_obs;
+    const int nb = T.num_bases ? H.nb : (int)n_obs;
+    const uint32_t rb = (H.rb_word >> (8u * (uint32_t)(reinterpret_cast<uintptr_t>(T.ref_base + col) & 3u))) & 0xFFu;
     const int ref_code = (rb == 'A') ? 0 : (rb == 'C') ? 1 : (rb == 'G') ? 2 : (rb == 'T') ? 3 : -1;
     /* gates: lofreq_call.c:892/754 (ref N; non-ACGT refs are N, plp.c:819-823), :930, :747 */
     const bool gated = (ref_code < 0) || ((int64_t)nb * 2 < (int64_t)cov) || (nb < T.min_cov);
@@ -1211,16 +1231,38 @@ __device__ __forceinline__ void lfq_count_column_lean(const LfqCountArgs &T, lfq
     }
 }
 
-template <bool SAME_THR, int WAVES, int UNROLL>
+/* CPW columns per wavefront, one after the other (a workgroup: CPW runs of WAVES neighbouring columns).  The headers of all
+ * of them are requested at once when the wavefront starts -- scalar loads, they cost no vector register --, so that only the first
+ * column waits for its header: two dependent scalar round trips, 3.3 of the 14.9 us a wavefront of one column lives.  A wavefront
+ * that lives on round trips moves its bytes in proportion to how few of them it needs, and beside another batch's DP kernels the
+ * count kernel has fewer wavefronts resident, not slower ones (profiles/wave_stamps.py).  The loop over the columns is unrolled:
+ * as a loop it kept lane-dependent values and constants in vector registers across the columns (46 instead of 30 registers). */
+template <bool SAME_THR, int WAVES, int UNROLL, int CPW>
 __global__ __launch_bounds__(64 * WAVES, 8) void lfq_count_lean_kernel(LfqCountArgs T, lfq_col_counts *__restrict__ out,
                                                                     uint8_t *__restrict__ flags, int64_t c0, int64_t c1)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t col = c0 + (int64_t)blockIdx.x * WAVES + wave;
-    if (col >= c1) {
+    const int64_t first = c0 + (int64_t)blockIdx.x * (WAVES * CPW) + wave;
+    if (first >= c1) {
         return;
     }
-    lfq_count_column_lean<SAME_THR, UNROLL>(T, out, flags, col, lfq_lane());
+    LfqColHdr h[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; j++) {
+        const int64_t col = first + (int64_t)j * WAVES;
+        h[j] = lfq_load_col_hdr(T, col < c1 ? col : first);
+    }
+#pragma unroll
+    for (int j = 0; j < CPW; j++) {
+        const int64_t col = first + (int64_t)j * WAVES;
+        if (col < c1) {
+            /* (the lane index afresh for every column, from the execution mask: nothing lane-dependent, not even the index
+             * itself, stays in a vector register from one column to the next -- the kernel has to stay within 32) */
+            int lane_j;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_j));
+            lfq_count_column_lean<SAME_THR, UNROLL>(T, out, flags, col, lane_j, h[j]);
+        }
+    }
 }
 
 /* one column per wavefront, WAVES columns per workgroup.  16 is the default (LFQ_COUNT_WAVES_PER_WG: 4, 8, 16): a 1024-thread
@@ -1685,12 +1727,19 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         ca.pad_ = 0;
         const int variant = (t.nt_packed ? 4 : 0) | (strand ? 2 : 0) | (same_thr ? 1 : 0);
         const int wpw = kn.count_waves_per_wg;
-        const unsigned blocks = (unsigned)((c1 - c0 + wpw - 1) / wpw);
+        const int cpw = kn.count_cols_per_wave >= 4 ? 4 : kn.count_cols_per_wave >= 2 ? 2 : 1;
+        const unsigned blocks = (unsigned)((c1 - c0 + (int64_t)wpw * cpw - 1) / ((int64_t)wpw * cpw));
         if (t.nt_packed && !strand) {
             /* lazy record counts on the packed layout: the decision counts only */
-#define LFQ_LAUNCH_L(SM, W, U)                                                                                       \
-    hipLaunchKernelGGL((lfq_count_lean_kernel<SM, W, U>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, d_counts, \
+#define LFQ_LAUNCH_LC(SM, W, U, CP)                                                                                  \
+    hipLaunchKernelGGL((lfq_count_lean_kernel<SM, W, U, CP>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, d_counts, \
                        d_flags, c0, c1)
+#define LFQ_LAUNCH_L(SM, W, U)                                                                                       \
+    do {                                                                                                             \
+        if (cpw == 4) LFQ_LAUNCH_LC(SM, W, U, 4);                                                                    \
+        else if (cpw == 2) LFQ_LAUNCH_LC(SM, W, U, 2);                                                               \
+        else LFQ_LAUNCH_LC(SM, W, U, 1);                                                                             \
+    } while (0)
 #define LFQ_LAUNCH_LU(SM, W)                                                                                         \
     do {                                                                                                             \
         if (kn.count_ahead_deep == 4) LFQ_LAUNCH_L(SM, W, 4);                                                        \
@@ -1708,6 +1757,7 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
 #undef LFQ_LAUNCH_LW
 #undef LFQ_LAUNCH_LU
 #undef LFQ_LAUNCH_L
+#undef LFQ_LAUNCH_LC
             LFQ_HIP_TRY(hipGetLastError());
             return LFQ_OK;
         }

@@ -21,8 +21,13 @@ def stats(counts, label):
     hdr, loop, rec = raw[:, 2].astype(np.int64), fw[:, 0], fw[:, 1]
     hw = counts["alt_fw"][:, 2].astype(np.uint32)
     xcc = counts["ref_fw"].astype(np.uint32) & 0xF
+    ok = counts["kmax"] < 12                        # (the heavy columns' record-only fields were overwritten by the strand kernel)
+    raw, fw, t0, hdr, loop, rec, hw, xcc = raw[ok], fw[ok], t0[ok], hdr[ok], loop[ok], rec[ok], hw[ok], xcc[ok]
+    cyc = counts["ref_rv"].astype(np.uint32).astype(np.int64)[ok]
     t0 = (t0 - t0.min()).astype(np.int64)
     span = (t0 + rec).max()
+    mhz = cyc / np.maximum(rec, 1) * 100.0          # cycles per 10 ns tick -> MHz
+    print("   shader clock over a wavefront's life: mean %.0f MHz, p10 %.0f, p90 %.0f" % (mhz.mean(), np.percentile(mhz, 10), np.percentile(mhz, 90)))
     print("== %s: %d wavefronts, kernel span %.3f ms" % (label, len(t0), span / 1e5))
     for name, v in (("start -> header known", hdr), ("header -> loop done", loop - hdr), ("loop done -> record", rec - loop),
                     ("wavefront life", rec)):
