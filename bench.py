@@ -779,6 +779,10 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         c_.set_dense_strand_counts(False)
         c_.set_dense_counts(False)                  # only the sparse output of a bin is read
         L.lfq_set_indel_arrays_on_host(c_.h, 0)
+        if n_thr > 1 and not os.environ.get("LFQ_BENCH_SHARED_STREAM"):
+            # a host thread per context: a thread's waits cover its own bins only, one thread's BAQ kernels run beside
+            # another's pileups (the device's shared launch stream ran the four threads' launches in one line)
+            c_.set_private_stream(True)
         outs.append((torch.zeros(cap * 64, dtype=torch.uint8, device=dev), torch.zeros(cap * 128, dtype=torch.uint8, device=dev)))
     if args.pmc_child:              # counter passes: two BAQ (+ IDAQ) calls of one bin, nothing else
         rs = la.ReadSet.from_arrays(caller, R)
@@ -1167,6 +1171,12 @@ def main():
         # `python bench.py --gpus N` on its own: launch the N ranks (one process per GPU) the way the driver does --
         # the reference's parallel wrapper forks its own workers too (lofreq2_call_pparallel.py:590-667)
         raise SystemExit(spawn_ranks(args.gpus))
+    if genome_cfg:
+        # C4 / C5: four host threads, a context each, every context with a launch stream of its own (lfq_set_private_stream):
+        # with the three shared DP streams and the upload streams that is more streams than the runtime's default four
+        # hardware queues, and streams that share a queue wait for each other's launches (C4 286-302 ms per genome with four
+        # queues, 270-273 with eight; the shared stream: 288-297 / 292-305).  Read by the HIP runtime when it starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 

@@ -38,7 +38,8 @@ extern "C" {
  * A caller compiled against another version must not run: compare lfq_abi_version() with this value once, as the
  * bindings in integration/ and the Python loader do. */
 /* 4: lfq_set_batch_gate, lfq_last_baq_times; lfq_call_snvs_collect refuses h_counts for a batch whose dense entries are sparse. */
-#define LFQ_ABI_VERSION 4
+/* 5: lfq_set_private_stream. */
+#define LFQ_ABI_VERSION 5
 
 typedef enum lfq_status {
     LFQ_OK = 0,
@@ -495,6 +496,14 @@ int lfq_call_snvs_wait(lfq_ctx *ctx);
 #define LFQ_GATE_END 1
 #define LFQ_GATE_NONE 2
 int lfq_set_batch_gate(lfq_ctx *ctx, int gate);
+/* The stream this context's own launches go to (count kernels, BAQ, pileups; the DP chains always run on the device's three
+ * shared DP streams).  By default every context of a GPU shares ONE: batches submitted through several contexts then run in
+ * submission order, which is what a single thread that pipelines batches wants (and what the batch gates order).  A caller
+ * that drives several contexts from several HOST THREADS (one region / bin per thread, as call-parallel's workers do) sets
+ * on = 1 per context: the context gets a stream of its own, a thread's waits then cover its own work only and one thread's
+ * BAQ kernels run beside another's pileups.  The batch gates do not apply to such a context.  Call it while the context is
+ * idle (it synchronizes).  Results do not depend on the choice. */
+int lfq_set_private_stream(lfq_ctx *ctx, int on);
 /* h_counts_or_null: the dense entries, ncols of them.  Needs a batch whose dense entries are complete: LFQ_ERR_INVALID when
  * the batch was submitted after lfq_set_dense_counts(ctx, 0) (the entries of its untested columns were never written). */
 int lfq_call_snvs_collect(lfq_ctx *ctx, lfq_conf *conf, lfq_snv_record *records, int64_t records_capacity,

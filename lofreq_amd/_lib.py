@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFQ_AMD_LIB") or os.path.join(_HERE, "liblofreq_amd.so")   # LFQ_AMD_LIB: another build of the same library (A/B runs)
 
 LFQ_OK = 0
-LFQ_ABI_VERSION = 4      # include/lofreq_amd.h; load() refuses a library built from another header
+LFQ_ABI_VERSION = 5      # include/lofreq_amd.h; load() refuses a library built from another header
 LFQ_ERR_CAPACITY = -4
 LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ, LFQ_USE_IDAQ = 1, 2, 4, 8
 LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP, LFQ_PV_UNDERFLOW = 0, 1, 2, 3
@@ -120,7 +120,7 @@ assert SNV_RECORD_DTYPE.itemsize == 64, SNV_RECORD_DTYPE.itemsize
 # every symbol include/lofreq_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lfq_abi_version", "lfq_strerror", "lfq_conf_init", "lfq_create", "lfq_destroy", "lfq_synchronize",
-    "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_call_snvs_submit", "lfq_call_snvs_wait", "lfq_call_snvs_collect", "lfq_set_dense_strand_counts", "lfq_set_dense_counts", "lfq_set_batch_gate", "lfq_set_indel_arrays_on_host", "lfq_finalize_pvals",
+    "lfq_snv_batch_device", "lfq_batch_finish", "lfq_call_snvs_batch", "lfq_call_snvs_submit", "lfq_call_snvs_wait", "lfq_call_snvs_collect", "lfq_set_dense_strand_counts", "lfq_set_dense_counts", "lfq_set_batch_gate", "lfq_set_private_stream", "lfq_set_indel_arrays_on_host", "lfq_finalize_pvals",
     "lfq_pvalue_from_log", "lfq_format_snv_record", "lfq_format_vcf", "lfq_snvqual_thresh", "lfq_sb_phred",
     "lfq_fisher_exact", "lfq_fdr", "lfq_bonf_corr", "lfq_holm_bonf_corr", "lfq_filter_records",
     "lfq_synth_fill_device", "lfq_synth_fill_device_layout", "lfq_last_kernel_times", "lfq_last_baq_times", "lfq_last_dp_work",
@@ -186,6 +186,7 @@ def load():
     L.lfq_set_dense_strand_counts.argtypes = [vp, C.c_int]
     L.lfq_set_dense_counts.argtypes = [vp, C.c_int]
     L.lfq_set_batch_gate.argtypes = [vp, C.c_int]
+    L.lfq_set_private_stream.argtypes = [vp, C.c_int]
     L.lfq_last_baq_times.argtypes = [vp, C.POINTER(BaqTimes)]
     L.lfq_set_indel_arrays_on_host.argtypes = [vp, C.c_int]
     L.lfq_set_baq_hmm_params.argtypes = [vp, C.c_float, C.c_float]

@@ -176,6 +176,10 @@ class SnvCaller:
         """lfq_set_batch_gate: what this context's next count kernel waits for when the device's previous batch still runs"""
         _lib.check(self.L.lfq_set_batch_gate(self.h, self.GATES[gate]), "lfq_set_batch_gate")
 
+    def set_private_stream(self, on):
+        """lfq_set_private_stream: a launch stream of this context's own (one context per host thread) instead of the device's shared one"""
+        _lib.check(self.L.lfq_set_private_stream(self.h, 1 if on else 0), "lfq_set_private_stream")
+
     def set_dense_strand_counts(self, on):
         """lfq_set_dense_strand_counts: off = strand counts only for the columns of the sparse output (layer 1, submit)"""
         _lib.check(self.L.lfq_set_dense_strand_counts(self.h, 1 if on else 0), "lfq_set_dense_strand_counts")

@@ -331,7 +331,7 @@ int ensure_workspace(lfq_ctx *c, int64_t ncols)
         cap = 0;
         LFQ_TRY(grow(&c->d_entries, &cap, want));
         cap = 0;
-        LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 4096 + 8 * (LFQ_MAX_SEGMENTS + 1))));
+        LFQ_TRY(grow(&c->d_tiles, &cap, 2 * (want / 1024 + 8 * (LFQ_MAX_SEGMENTS + 1))));
         cap = 0;
         LFQ_TRY(grow(&c->d_unsplit, &cap, want));
         cap = 0;
@@ -435,6 +435,9 @@ int lfq_create(lfq_ctx **out, int device_ordinal)
         fill_luts(&h);
         ok = hipMemcpy(c->d_luts, &h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess;
     }
+    if (ok && lfq_knobs().private_stream) {         /* LFQ_PRIVATE_STREAM: every context as after lfq_set_private_stream(ctx, 1) */
+        ok = lfq_set_private_stream(c, 1) == LFQ_OK;
+    }
     if (!ok) {
         lfq_destroy(c);
         return LFQ_ERR_HIP;
@@ -469,6 +472,7 @@ void lfq_destroy(lfq_ctx *c)
             if (c->rs_cache[k].p) (void)(k == 4 ? hipHostFree(c->rs_cache[k].p) : hipFree(c->rs_cache[k].p));
         }
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+        if (c->priv_stream) (void)hipStreamDestroy(c->priv_stream);
         if (c->ev_up) (void)hipEventDestroy(c->ev_up);
         if (c->ev_apply) (void)hipEventDestroy(c->ev_apply);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -674,7 +678,7 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         W.entries = c->d_entries + c0;
         W.counters = c->d_counters + s * LFQ_NCOUNTERS;
         W.gcounters = gcounters;
-        W.block_sums = (int32_t *)(c->d_tiles + 2 * (c0 / 4096 + 8 * s));
+        W.block_sums = (int32_t *)(c->d_tiles + 2 * (c0 / 1024 + 8 * s));
         W.long_cap = c->long_cap / n_seg;
         W.pool_cells = c->pool_cells / n_seg;
         W.longs = c->d_longs + (int64_t)s * W.long_cap;
@@ -682,7 +686,9 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         W.unsplit = c->d_unsplit + c0;
 
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][0], st));
-        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st));
+        /* (a context that queues batches without a gate on the device's shared stream: its shallow count kernel takes half of a CU) */
+        const bool ungated = c->batch_gate == LFQ_GATE_NONE && st == c->stream && !c->priv_stream_on && !single_stream;
+        LFQ_TRY(lfq_launch_count(T, c0, c1, P, c->d_luts, d_counts, c->d_flags, max_depth, st, ungated ? kn.count_shallow_wgs_none : 0));
         c->cur_sparse_counts = P.sparse_counts && lfq_count_is_shallow(T, P, max_depth);
         LFQ_TRY_HIP(hipEventRecord(c->ev_cnt[s][1], st));
 
@@ -695,8 +701,12 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
             LFQ_TRY(lfq_launch_scan(T, c0, c1, c->d_flags, d_counts, W, dps, true));
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_scan[s], dps));
-        if (n_seg == 1 && !indel_mode && c->leader && !kn.no_sb_precompute) {
-            /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start now */
+        /* DP4 tuples of the mid / big class alleles with >= 16 alt bases -> host; Fisher tests start when they arrive.  On the
+         * dps stream behind the scan: in front of the screen kernel (the host starts 0.1-0.4 ms earlier) or behind it
+         * (LFQ_HEAVY_AFTER_SCREEN: one launch less between the scan and the light chain, which is what a shallow batch's
+         * period is made of when batches are gated on the chains' tails) */
+        const bool sb_heavy = n_seg == 1 && !indel_mode && c->leader && !kn.no_sb_precompute;
+        auto launch_heavy = [&]() -> int {
             if (P.lazy_strand) {        /* the count kernel left the strands out: count them for the heavy columns here */
                 LFQ_TRY(lfq_launch_strand_heavy(T, W, d_counts, c->d_tuples_mapped, c->d_nheavy_mapped, c->heavy_cap, 16, dps));
             } else {
@@ -709,6 +719,14 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
                 c->sb_pending++;
             }
             c->lcv->notify_all();
+            return LFQ_OK;
+        };
+        const bool heavy_late = sb_heavy && kn.heavy_after_screen && !kn.skip_light && kn.light_kernel != 2;
+        if (sb_heavy && !heavy_late) {
+            LFQ_TRY(launch_heavy());
+        }
+        if (kn.tail_light == 2) {
+            LFQ_TRY(tail_record(c, 2, dps));
         }
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
@@ -790,12 +808,23 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
             if (kn.light_kernel == 2) {                 /* A/B switch: the one-column-per-wavefront kernel */
                 LFQ_TRY(lfq_launch_dp_light(T, P, c->d_luts, d_counts, W, d_pvals, pvals_capacity, n_light_waves, dps));
             } else {
+                const int kh = indel_mode ? c->kreg_hint_indel : c->kreg_hint;
                 LFQ_TRY(lfq_launch_dp_quad(T, P, c->d_luts, d_counts, W, c->d_retry + c0, d_pvals, pvals_capacity,
-                                           n_light_waves, indel_mode ? c->kreg_hint_indel : c->kreg_hint, dps));
+                                           n_light_waves, kh, dps, 1));
+                if (kn.tail_light == 1) {       /* the retry kernel beside the next batch's count kernel, like the folds */
+                    LFQ_TRY(tail_record(c, 2, dps));
+                }
+                if (heavy_late) {
+                    LFQ_TRY(launch_heavy());
+                }
+                LFQ_TRY(lfq_launch_dp_quad(T, P, c->d_luts, d_counts, W, c->d_retry + c0, d_pvals, pvals_capacity,
+                                           n_light_waves, kh, dps, 2));
             }
         }
         LFQ_TRY_HIP(hipEventRecord(c->ev_light[s][1], dps));
-        LFQ_TRY(tail_record(c, 2, dps));
+        if (kn.tail_light == 0 || (kn.tail_light == 1 && (kn.skip_light || kn.light_kernel == 2))) {
+            LFQ_TRY(tail_record(c, 2, dps));
+        }
         for (int i = 0; i < 2; i++) {
             LFQ_TRY_HIP(hipEventRecord(c->ev_side[i][s][1], side_i[i]));
         }
@@ -805,7 +834,9 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
      * the count kernel of the NEXT batch (another context on the same device streams) then starts as soon as this
      * batch's count kernel is done and streams through HBM while this batch's DP kernels -- latency / issue-bound,
      * < 1 GB of traffic, on the high-priority streams -- run beside it. */
-    hipStream_t jn = (st != c->stream || single_stream) ? st : dps;
+    /* (LFQ_JOIN_ON_SIDE: on the big chain's stream, which is the last to end anyway -- the dps stream is then free for the NEXT
+     * batch's scan as soon as this batch's retry kernel is done, instead of when its last fold is) */
+    hipStream_t jn = (st != c->stream || single_stream) ? st : (kn.join_on_side ? side0 : dps);
     LFQ_TRY_HIP(hipEventRecord(c->ev[1], st));                     /* all count kernels done */
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[0], side0));
     LFQ_TRY_HIP(hipEventRecord(c->ev_join[1], side1));
@@ -905,6 +936,28 @@ int lfq_set_batch_gate(lfq_ctx *c, int gate)
         return LFQ_ERR_INVALID;
     }
     c->batch_gate = gate;
+    return LFQ_OK;
+}
+
+int lfq_set_private_stream(lfq_ctx *c, int on)
+{
+    if (!c || !c->own_streams) {
+        return LFQ_ERR_INVALID;
+    }
+    LFQ_TRY_HIP(hipSetDevice(c->device));
+    LFQ_TRY(lfq_synchronize(c));
+    LFQ_TRY_HIP(hipStreamSynchronize(c->stream));
+    if (on) {
+        if (!c->priv_stream) {
+            LFQ_TRY_HIP(hipStreamCreateWithFlags(&c->priv_stream, hipStreamNonBlocking));
+        }
+        c->stream = c->priv_stream;
+        c->priv_stream_on = 1;
+    } else {
+        std::lock_guard<std::mutex> lk(g_streams_m);
+        c->stream = g_streams[c->device].stream;
+        c->priv_stream_on = 0;
+    }
     return LFQ_OK;
 }
 

@@ -320,6 +320,8 @@ struct lfq_ctx {
      * lfq_readset_create / _baq takes them over when they are large enough -- a worker goes from region to region, and
      * hipMalloc + hipFree of 2 GB per region are milliseconds and a device synchronisation each */
     struct { void *p; size_t cap; } rs_cache[5];
+    int priv_stream_on;
+    hipStream_t priv_stream;         /* lfq_set_private_stream: this context's own launch stream (null = the device's shared one) */
     hipStream_t up_stream;           /* lfq_readset_create's uploads and the staging copies of host tracks (created on first use) */
     hipEvent_t ev_up;                /* end of the staging copies of a batch of host tracks */
     hipEvent_t ev_apply;             /* lfq_readset_pileup_snv: the column positions are final (created on first use) */

@@ -2956,7 +2956,7 @@ int lfq_launch_dp_combine(int mode, const LfqParams &p, const lfq_col_counts *d_
 
 int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                        const lfq_col_counts *d_counts, const LfqWork &w, uint8_t *d_retry, lfq_col_pvals *d_pvals,
-                       int64_t pvals_capacity, int n_waves, int kreg_hint, void *stream)
+                       int64_t pvals_capacity, int n_waves, int kreg_hint, void *stream, int phase)
 {
     if (t.ncols <= 0 || n_waves <= 0) {
         return LFQ_OK;
@@ -2965,7 +2965,7 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
     hipStream_t st = (hipStream_t)stream;
     const LfqKnobs &kn = lfq_knobs();
     int force = 0;
-    {
+    if (phase != 2) {
         /* one light column per lane: ONE variant is launched, chosen on the host from the K histogram the scan of this
          * context's previous batch left behind (a batch cannot wait for its own scan without stalling the host).  Any
          * choice is correct: a column with more alt bases than the variant has cells goes to the retry kernel. */
@@ -2997,7 +2997,9 @@ int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts 
         }
 #undef LFQ_LAUNCH_SCREEN
     }
-    hipLaunchKernelGGL(lfq_dp_retry_kernel, grid, block, 0, st, t, p, d_luts, d_counts, w, d_retry, d_pvals,
-                       pvals_capacity);
+    if (phase != 1) {
+        hipLaunchKernelGGL(lfq_dp_retry_kernel, grid, block, 0, st, t, p, d_luts, d_counts, w, d_retry, d_pvals,
+                           pvals_capacity);
+    }
     return hipGetLastError() == hipSuccess ? LFQ_OK : LFQ_ERR_HIP;
 }

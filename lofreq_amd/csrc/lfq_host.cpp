@@ -96,6 +96,13 @@ const LfqKnobs &lfq_knobs(void)
         x.baq_lds = geti("LFQ_BAQ_LDS", 1) != 0;
         x.baq_idaq_beside = (int)geti("LFQ_BAQ_IDAQ_BESIDE", 0);
         x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
+        x.tail_light = (int)std::min(2L, std::max(0L, geti("LFQ_TAIL_LIGHT", 1)));
+        x.count_shallow_wgs_none = (int)std::min(4L, std::max(0L, geti("LFQ_COUNT_SHALLOW_WGS_NONE", 2)));
+        x.count_lean_lds_pad = (int)std::min(160000L, std::max(0L, geti("LFQ_COUNT_LEAN_LDS_PAD", 0)));
+        x.count_shallow_lds_pad = (int)std::min(120000L, std::max(0L, geti("LFQ_COUNT_SHALLOW_LDS_PAD", 0)));
+        x.join_on_side = (int)geti("LFQ_JOIN_ON_SIDE", 1);
+        x.private_stream = (int)geti("LFQ_PRIVATE_STREAM", 0);
+        x.heavy_after_screen = (int)geti("LFQ_HEAVY_AFTER_SCREEN", 1);
         return x;
     }();
     return k;

@@ -220,6 +220,17 @@ struct LfqKnobs {
     int baq_lds;               /* LFQ_BAQ_LDS (1) */
     int baq_idaq_beside;       /* LFQ_BAQ_IDAQ_BESIDE (0): the narrow-band reads with indels on a side stream beside the plain launches (a lone BAQ + IDAQ call 6.2 -> 5.3 ms per 400 K reads, the reads -> VCF chain 37.7 -> 39.0 ms per region: off) */
     long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
+    int tail_light;            /* LFQ_TAIL_LIGHT (1): where the light chain records the device's tail event (what the next batch's count
+                                * kernel waits for under LFQ_GATE_TAIL): 0 = behind the retry kernel, 1 = behind the screen kernel (the
+                                * retry kernel is a few hundred latency-bound wavefronts: beside the count kernel like the folds), 2 = behind the scan */
+    int count_shallow_wgs_none; /* LFQ_COUNT_SHALLOW_WGS_NONE (2): workgroups per CU of the shared-wavefront count kernel of a context whose batches are
+                                * queued without a gate (0 = as many as fit: four) -- the other half of every SIMD is what another batch's DP kernels run in */
+    int count_lean_lds_pad;    /* LFQ_COUNT_LEAN_LDS_PAD (0): bytes of unused dynamic LDS per workgroup of the lean count kernel */
+    int count_shallow_lds_pad; /* LFQ_COUNT_SHALLOW_LDS_PAD (0): bytes of unused dynamic LDS per workgroup of the shared-wavefront count kernel */
+    int join_on_side;          /* LFQ_JOIN_ON_SIDE (1): a batch's join (strand counts of its records, counters to the host) on the big chain's stream instead of the light chain's */
+    int private_stream;        /* LFQ_PRIVATE_STREAM (0): lfq_create gives every context a launch stream of its own (lfq_set_private_stream) */
+    int heavy_after_screen;    /* LFQ_HEAVY_AFTER_SCREEN (1): the strand counts of the heavy columns (host Fisher precompute) behind the screen
+                                * kernel instead of in front of it: one launch less between the scan and the light chain */
 };
 const LfqKnobs &lfq_knobs(void);
 /* CPUs this process may actually use: the affinity mask and the cgroup's cpu.max quota, not the machine's core count
@@ -399,7 +410,8 @@ int lfq_launch_maxdepth(const LfqTracksDev &t, int32_t *d_gcounters, void *strea
 int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream);
 bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max_col_obs);
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream);
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream, int shallow_wgs_per_cu = 0);
+/* (shallow_wgs_per_cu: workgroups per CU the shared-wavefront count kernel may have resident, 0 = as many as fit) */
 int lfq_launch_scan(const LfqTracksDev &t, int64_t c0, int64_t c1, const uint8_t *d_flags,
                     const lfq_col_counts *d_counts, const LfqWork &w, void *stream, bool relist = false);
 /* -t / --approx-threshold (snpcaller.c:1128-1142): clears the flag byte of the listed columns the Poisson gate gives up;
@@ -414,7 +426,8 @@ int lfq_launch_dp_light(const LfqTracksDev &t, const LfqParams &p, const LfqLuts
  * whole wavefronts */
 int lfq_launch_dp_quad(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                        const lfq_col_counts *d_counts, const LfqWork &w, uint8_t *d_retry, lfq_col_pvals *d_pvals,
-                       int64_t pvals_capacity, int n_waves, int kreg_hint, void *stream);
+                       int64_t pvals_capacity, int n_waves, int kreg_hint, void *stream, int phase = 0);
+/* (phase: 0 = screen + retry, 1 = the screen kernel only, 2 = the retry kernel only) */
 int lfq_launch_dp_mid(const LfqTracksDev &t, const LfqParams &p, const LfqLuts *d_luts,
                       const lfq_col_counts *d_counts, const LfqWork &w, lfq_col_pvals *d_pvals,
                       int64_t pvals_capacity, int n_waves, void *stream);

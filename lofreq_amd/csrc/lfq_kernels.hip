@@ -1331,7 +1331,9 @@ int lfq_launch_ntcount(const LfqTracksDev &t, int32_t *d_out, void *stream)
 /* scan kernels: running Bonferroni prefix + work-list compaction                              */
 /* ------------------------------------------------------------------------------------------ */
 
-#define LFQ_SCAN_THREADS 1024
+#ifndef LFQ_SCAN_THREADS
+#define LFQ_SCAN_THREADS 1024      /* (256 .. 1024: the workspace holds a tile sum per 1024 columns, lfq_api.hip) */
+#endif
 #define LFQ_SCAN_ITEMS 4
 #define LFQ_SCAN_TILE (LFQ_SCAN_THREADS * LFQ_SCAN_ITEMS)
 
@@ -1660,7 +1662,7 @@ bool lfq_count_is_shallow(const LfqTracksDev &t, const LfqParams &p, int64_t max
 }
 
 int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqParams &p, const LfqLuts *d_luts,
-                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream)
+                     lfq_col_counts *d_counts, uint8_t *d_flags, int64_t max_col_obs, void *stream, int shallow_wgs_per_cu)
 {
     if (c1 <= c0) {
         return LFQ_OK;
@@ -1676,11 +1678,21 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
             const unsigned nb = (unsigned)std::min<int64_t>(blocks64, (int64_t)256 * 8 * 4);
             /* chunks the deepest column can touch (an unaligned start adds one), in rounds of AHEAD per lane */
             const int rounds = (int)((max_col_obs / 16 + 2 + LFQ_COUNT_AHEAD * lpg - 1) / (LFQ_COUNT_AHEAD * lpg));
+            /* Unused dynamic LDS per workgroup = fewer workgroups per CU (33 / 37 KB each: four fit).  A context whose batches are
+             * queued without a gate asks for two: its count kernel then leaves half of every SIMD's registers and wave slots to
+             * the DP kernels of the batch before -- which otherwise start only where a count workgroup retires -- and is itself
+             * no slower (C2, four batches queued: 0.66 -> 0.56-0.59 ms per step, count kernel 0.33-0.38 ms either way).
+             * LFQ_COUNT_SHALLOW_LDS_PAD: the bytes directly (experiments). */
+            unsigned lds_pad = (unsigned)kn.count_shallow_lds_pad;
+            /* (not where four lanes share a column -- depth <= 320 --: 3.75 M x 200 0.86 ms per step with four workgroups, 1.14 with two) */
+            if (lds_pad == 0 && shallow_wgs_per_cu >= 1 && shallow_wgs_per_cu <= 3 && lpg > 4) {
+                lds_pad = shallow_wgs_per_cu == 1 ? 60000u : shallow_wgs_per_cu == 2 ? 44000u : 17000u;
+            }
 #define LFQ_LAUNCH_SHALLOW(ST)                                                                                       \
             do {                                                                                                     \
-                if (lpg == 4) hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
-                else if (lpg == 8) hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 8>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
-                else hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 16>), dim3(nb), dim3(256), 0, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
+                if (lpg == 4) hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 4>), dim3(nb), dim3(256), lds_pad, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
+                else if (lpg == 8) hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 8>), dim3(nb), dim3(256), lds_pad, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
+                else hipLaunchKernelGGL((lfq_count_shallow_kernel<ST, 16>), dim3(nb), dim3(256), lds_pad, (hipStream_t)stream, t, p, d_counts, d_flags, c0, c1, rounds); \
             } while (0)
             if (!p.lazy_strand) LFQ_LAUNCH_SHALLOW(true); else LFQ_LAUNCH_SHALLOW(false);
 #undef LFQ_LAUNCH_SHALLOW
@@ -1731,8 +1743,11 @@ int lfq_launch_count(const LfqTracksDev &t, int64_t c0, int64_t c1, const LfqPar
         const unsigned blocks = (unsigned)((c1 - c0 + (int64_t)wpw * cpw - 1) / ((int64_t)wpw * cpw));
         if (t.nt_packed && !strand) {
             /* lazy record counts on the packed layout: the decision counts only */
+            /* (LFQ_COUNT_LEAN_LDS_PAD: unused dynamic LDS per workgroup -- the kernel has no LDS of its own, so this alone says
+             * how many workgroups a CU holds and how many wave slots stay free for another batch's DP kernels) */
+            const unsigned lean_pad = (unsigned)kn.count_lean_lds_pad;
 #define LFQ_LAUNCH_LC(SM, W, U, CP)                                                                                  \
-    hipLaunchKernelGGL((lfq_count_lean_kernel<SM, W, U, CP>), dim3(blocks), dim3(64 * W), 0, (hipStream_t)stream, ca, d_counts, \
+    hipLaunchKernelGGL((lfq_count_lean_kernel<SM, W, U, CP>), dim3(blocks), dim3(64 * W), lean_pad, (hipStream_t)stream, ca, d_counts, \
                        d_flags, c0, c1)
 #define LFQ_LAUNCH_L(SM, W, U)                                                                                       \
     do {                                                                                                             \

@@ -158,3 +158,45 @@ def test_submit_collect_dense_counts_without_strands(oracle):
         assert recs.tobytes() == want.tobytes()
     finally:
         own.close()
+
+
+def test_private_stream_same_results(oracle):
+    """lfq_set_private_stream (ABI 5): a context with a launch stream of its own gives what the device's shared stream gives, on
+    every chain (BAQ + IDAQ, source quality, both pileups, SNV and indel calls, two batches in flight); switching back works; an
+    unknown context is an error code."""
+    import lofreq_amd as la
+    from lofreq_amd import _lib
+    L = _lib.load()
+    assert L.lfq_set_private_stream(None, 1) < 0
+    fx, reads = gu.load_plpindel(gu.plpindel_fixtures()[0])
+    ref = fx["genome"].encode()
+    rng = np.random.default_rng(11)
+    host = util.random_batch(rng, 600, 50, 1500)
+
+    def run(c):
+        tags = la.baq_batch(c, reads, ref, extended=True, idaq=True)
+        sq, sqb = la.source_qual_batch(c, reads, ref)
+        cols, _ = la.pileup_indel_columns(c, reads, ref, 0, len(ref))
+        dt = la.pileup_snv_tracks(c, reads, ref, 0, len(ref), lb=[t[0] for t in tags], sq=sqb)
+        recs, _, _ = c.call_snvs(dt, la.VarcallConf())
+        irecs, _ = la.call_indels(c, cols, la.VarcallConf())
+        b = util.to_pileup_batch(la, host)
+        conf_a, conf_b = la.VarcallConf(), la.VarcallConf()
+        c.call_snvs_submit(b, conf_a)
+        ra, _ = c.call_snvs_collect(conf_a)
+        c.call_snvs_submit(b, conf_b)
+        rb, _ = c.call_snvs_collect(conf_b)
+        return (b"".join(t[0].tobytes() for t in tags), sq.tobytes(), recs.tobytes(), irecs["qual"].tobytes(), ra.tobytes(), rb.tobytes())
+
+    shared, private = la.SnvCaller(0), la.SnvCaller(0)
+    try:
+        private.set_private_stream(True)
+        want = run(shared)
+        assert run(private) == want
+        private.set_private_stream(False)
+        assert run(private) == want
+        private.set_private_stream(True)
+        assert run(private) == want
+    finally:
+        shared.close()
+        private.close()
