@@ -32,6 +32,12 @@ CASES = [
     ("LFQ_COUNT_WAVES_PER_WG=4 LFQ_COUNT_MULTI_BELOW=0", DP),    # the lean count kernel with 4 columns per workgroup (default 16) ...
     ("LFQ_COUNT_WAVES_PER_WG=8 LFQ_COUNT_MULTI_BELOW=0", DP),    # ... and 8, on every batch
     ("LFQ_BIG_ON_SIDE=1", DP),               # the unsplit big columns behind the big chain (what a context with LFQ_GATE_NONE runs)
+    ("LFQ_JOIN_ON_SIDE=0 LFQ_TAIL_LIGHT=0 LFQ_HEAVY_AFTER_SCREEN=0", DP),   # the stream plan of round 4: join on the light chain's stream, tail event behind the retry kernel
+    ("LFQ_TAIL_LIGHT=2", DP),                # tail event of the light chain behind the scan
+    ("LFQ_COUNT_SHALLOW_LDS_PAD=44000", DP), # shared-wavefront count kernel with two workgroups per CU (what a context with LFQ_GATE_NONE launches)
+    ("LFQ_COUNT_LEAN_LDS_PAD=54000 LFQ_COUNT_WAVES_PER_WG=8 LFQ_COUNT_AHEAD_DEEP=4 LFQ_COUNT_MULTI_BELOW=0", DP),    # lean count kernel capped to three workgroups per CU
+    ("LFQ_PRIVATE_STREAM=1", DP),            # every context with a launch stream of its own (lfq_set_private_stream) ...
+    ("LFQ_PRIVATE_STREAM=1", CHAIN),         # ... on the read-set chain as well
     ("LFQ_PILEUP_TILES=0", PLP),             # a wavefront per position instead of tiles of 64 positions
     ("LFQ_BAQ_ONE_VARIANT=1", BAQ),          # every wavefront through the register kernel's instantiation with the N case
     ("LFQ_BAQ_LDS=0", BAQ),                  # every read through the all-HBM BAQ kernel (what wide bands get)
