@@ -76,7 +76,7 @@ def parse_args():
                          "rate; default: the read sets are resident in HBM when the timed region starts (uploaded in the "
                          "warm-up), and the PCIe-inclusive rate of a few extra steps is reported beside `value`")
     ap.add_argument("--no-upload-rate", action="store_true", help="C4 / C5: skip the extra steps that time the PCIe-inclusive rate")
-    ap.add_argument("--host-threads", type=int, default=4,
+    ap.add_argument("--host-threads", type=int, default=6,
                     help="C4 / C5: host threads per rank, one context each, that work through the rank's bins (the host part "
                          "of one bin -- CIGAR geometry, event tables, test descriptors -- then runs under the kernels of another)")
     ap.add_argument("--idaq", action="store_true", help="--mode baq: also the indel alignment qualities (ai / ad)")

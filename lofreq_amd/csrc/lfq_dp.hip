@@ -609,7 +609,7 @@ __device__ double lfq_tailsum(const double *probvec, int start, int K, bool *fe_
  * is proven to be below the 80-bit underflow threshold (the reference returns LDBL_MIN for them);
  * `force_fe` marks every computed tail as "the reference's log_sum chain underflows" (see the shortcut
  * in lfq_dp_big_kernel); `have_probvec` is false when the kp-recurrence was pruned or not needed. */
-__device__ __noinline__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, const double *probvec, int kp,
+__device__ __forceinline__ void lfq_emit_pvals(const LfqColCtx &cx, const lfq_col_counts &cnt, const double *probvec, int kp,
                                bool have_probvec, unsigned uf_mask, const double *uf_bound, bool force_fe,
                                int rows, const LfqWork &W, lfq_col_pvals *__restrict__ pvals,
                                int64_t pvals_capacity)
@@ -1386,7 +1386,7 @@ __device__ __forceinline__ void lfq_big_bounds_impl(const LfqColCtx &cx, const l
     *kp_out = kp;
 }
 
-__device__ __noinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_counts &cnt, const LfqTracksDev &T,
+__device__ __forceinline__ void lfq_big_bounds(const LfqColCtx &cx, const lfq_col_counts &cnt, const LfqTracksDev &T,
                                             const LfqParams &P, const LfqLuts *luts, double *mu_sh, int NW,
                                             unsigned *uf_mask_out, double *uf_bound, int *kp_out)
 {
@@ -1574,13 +1574,13 @@ __global__ __launch_bounds__(LFQ_HEAVY_WAVES * 64, LFQ_DP512_WAVES) void lfq_dp_
             continue;                   /* already emitted by the prep kernel */
         }
         if (kp < 128 * NW - 1) {
-            lfq_big_column<2>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
+            lfq_big_column<2>(cx, &counts[en.col], kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
                               n_chunks);
         } else {
             /* 4 cells per lane: up to K = 2044 in one pass; deeper columns run in passes.  (8 cells per
              * lane would halve the passes but doubles the kernel's register footprint, which decides
              * whether these workgroups can be resident beside the light kernel.) */
-            lfq_big_column<4>(cx, &cnt, kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
+            lfq_big_column<4>(cx, &counts[en.col], kp, uf_mask, uf_bound, force_fe, bnd, T, P, sh, W, pvals, pvals_capacity, 0,
                               n_chunks);
         }
     }
