@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """How busy was the GPU?  From a rocprofv3 --kernel-trace database: the union of all kernel intervals over the last
 `frac` of the trace (the warm-up is at the front), the idle gaps between them, and the kernels that fill the window.
-    python profiles/gpu_busy.py <dir with the .db> [frac = 0.5]"""
+    python profiles/gpu_busy.py <dir with the .db> [frac = 0.5]
+(a value above 1 = the last that many MILLISECONDS of the trace: the timed steps of a run whose set-up is longer than they are)"""
 import glob
 import sqlite3
 import sys
@@ -17,7 +18,7 @@ ks = [t for t in tabs if "kernel_symbol" in t][0]
 rows = list(con.execute("select s.display_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start" % (kd, ks)))
 t_end = max(r[2] for r in rows)
 t_beg = min(r[1] for r in rows)
-w0 = t_end - frac * (t_end - t_beg)
+w0 = t_end - (frac * (t_end - t_beg) if frac <= 1.0 else frac * 1e6)
 rows = [r for r in rows if r[1] >= w0]
 w0 = rows[0][1]
 busy, cur_s, cur_e, gaps = 0, None, None, []

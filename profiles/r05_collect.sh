@@ -38,7 +38,7 @@ bash profiles/baq_pmc.sh r05_baq > gpurun_out/r05_baq_pmc.log 2>&1
 # how busy the GPU is in a C4 run
 out=$R/gpurun_out/prof_r05_c4; rm -rf $out; mkdir -p $out
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace -d $out -o trace -- python $R/bench.py --config C4 --steps 4 --warmup 1 --no-pmc --no-cpu-baseline --no-upload-rate > $out/bench.log 2>&1)
-python profiles/gpu_busy.py $out 0.6 > gpurun_out/r05_c4_gpu_busy_final.md 2>&1
+python profiles/gpu_busy.py $out 1100 > gpurun_out/r05_c4_gpu_busy_final.md 2>&1
 # kernel timeline of one C2 step (no pipelining: one step's kernels at a time)
 out=$R/gpurun_out/prof_r05_tl_C2; rm -rf $out; mkdir -p $out
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace -d $out -o t -- python $R/bench.py --config C2 --steps 6 --warmup 3 --repeats 1 --no-pipeline --no-cpu-baseline --no-pmc --no-secondary --no-full-check > /dev/null 2>&1)
