@@ -1046,6 +1046,18 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
     }, text
 
 
+def _rccl_options(dist):
+    """The step's exchange is a few 8-byte .. kilobyte collectives between count kernels that keep every wave slot of the
+    device taken: on a stream of normal priority an RCCL workgroup waits for a slot like a DP workgroup would (measured
+    with a one-rank communicator, LFQ_BENCH_FORCE_DIST=1: profiles/NOTES.md) -- the communicator's stream gets the
+    priority the DP streams have.  LFQ_BENCH_RCCL_PRIO=0 for the A/B run."""
+    if os.environ.get("LFQ_BENCH_RCCL_PRIO", "1") == "0":
+        return None
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    return opts
+
+
 def _chain_worker(idx, iters, barrier, queue):
     """one region worker of `--mode chain --workers W`: its own process, context and read set on GPU 0"""
     try:
@@ -1196,6 +1208,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     xdev = "cpu" if one_gpu else dev              # where the exchanged tensors live
     comm_ranks = 1
+    # LFQ_BENCH_FORCE_DIST=1 (with --shard-path at N = 1): a one-rank RCCL communicator and every collective of the N > 1
+    # step inside the timed region -- what the exchange costs a rank per step, measurable on a one-GPU box
+    force_dist = world == 1 and os.environ.get("LFQ_BENCH_FORCE_DIST") == "1" and not genome_cfg
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["LFQ_SHARD_FORCE_COLLECTIVES"] = "1"       # (read when lofreq_amd.shard is imported, below)
+        dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1, pg_options=_rccl_options(dist))
     if world > 1:
         if not one_gpu and torch.cuda.device_count() < world:
             raise SystemExit("bench.py: %d ranks but %d visible GPUs (LFQ_BENCH_ONE_GPU=1 puts every rank on cuda:0 "
@@ -1203,7 +1223,7 @@ def main():
         if one_gpu:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, pg_options=_rccl_options(dist))
         # the communicator's own idea of the job: a sum of ones over its ranks (RCCL all-reduce over xGMI on GPUs)
         ones = torch.ones(1, dtype=torch.int64, device=xdev)
         dist.all_reduce(ones)
@@ -1213,6 +1233,27 @@ def main():
 
     import lofreq_amd as la
     from lofreq_amd import shard
+
+    # The per-step test counts are host integers on every rank: they travel over a host-side group (gloo) instead of
+    # being staged through a GPU whose wave slots the count kernels hold (profiles/NOTES.md: three blocking RCCL
+    # collectives cost a rank ~1 ms per step); the records go to rank 0 by ONE asynchronous RCCL gather per step.
+    # LFQ_BENCH_EXCHANGE=rccl: everything through the RCCL communicator (the A/B run).
+    exchange = {"counts": None, "records": None}
+    if (world > 1 or force_dist) and dist.get_backend() == "nccl":
+        exchange = {"counts": "rccl all-gather", "records": "rccl gather (asynchronous, collected one step later)"}
+        if os.environ.get("LFQ_BENCH_EXCHANGE", "host") != "rccl":
+            try:
+                import socket
+                try:
+                    socket.gethostbyname(socket.gethostname())
+                except OSError:
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: the loopback interface will do
+                shard.set_host_group(dist.new_group(backend="gloo"))
+                exchange["counts"] = "gloo all-gather (host integers)"
+            except Exception as e:                                         # no host transport: RCCL for the counts too
+                sys.stderr.write("bench.py: no gloo group for the test counts (%r); using RCCL\n" % (e,))
+    elif world > 1:
+        exchange = {"counts": "gloo all-gather", "records": "gloo gather"}
 
     caller = la.SnvCaller(local_rank)
     caller.set_dense_strand_counts(False)         # DP4 only for the columns that emit (what layer 2 does by itself)
@@ -1320,7 +1361,7 @@ def main():
             st = caller.batch_finish()
             pv = d_pvals[: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
             recs, total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin,      # records carry their ref base
-                                             dist if world > 1 else None, xdev)
+                                             dist if (world > 1 or force_dist) else None, xdev)
         text = None
         if rank == 0:
             # QUAL threshold from the final dynamic Bonferroni factor (lofreq_call.c:1519-1538), then `lofreq filter`
@@ -1370,21 +1411,41 @@ def main():
                 callers[k % NCTX].snv_batch_device(batch, conf, dc, dp, pv_cap)
             return conf
 
-        def finish(k, conf):
+        def finish_start(k, conf):
+            """Step k up to the point where its records are known (layer 2) or on their way to rank 0 (sharded step)."""
             if layer2:
                 recs, st = callers[k % NCTX].call_snvs_collect(conf, records_capacity=1 << 16)
-            else:
-                # host + exchange half of the sharded step, under the kernels of the next one: the running Bonferroni
-                # factor needs every rank's tested-column count, rank 0 gets everybody's records
-                st = callers[k % NCTX].batch_finish()
-                pv = out_bufs[k % NCTX][1][: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
-                recs, _total = shard.finish_shard(conf, pv, st.n_tested, None, col_begin, dist if world > 1 else None, xdev)
+                return conf, st, recs, callers[k % NCTX].kernel_times()
+            # host + exchange half of the sharded step, under the kernels of the next ones: the running Bonferroni
+            # factor needs every rank's tested-column count (one all-gather), rank 0 gets everybody's records (one gather,
+            # started here and collected by finish_end one step later: the host never waits for the device in between)
+            st = callers[k % NCTX].batch_finish()
+            pv = out_bufs[k % NCTX][1][: st.n_pvals * 128].cpu().numpy().view(la.COL_PVALS_DTYPE)
+            h, _total = shard.finish_shard_start(conf, pv, st.n_tested, None, col_begin,
+                                                 dist if (world > 1 or force_dist) else None, xdev)
+            return conf, st, h, callers[k % NCTX].kernel_times()
+
+        def finish_end(item):
+            conf, st, recs, kt_ = item
+            if not layer2:
+                recs = shard.finish_shard_wait(recs)
             text = None
             if rank == 0:
                 thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
                 keep = la.filter_records(recs, thr, apply_defaults=cfg_filter)
                 text = la.format_vcf(recs, "synth", keep=keep, filter_str="PASS")
-            return conf, st, recs, text, callers[k % NCTX].kernel_times()
+            return conf, st, recs, text, kt_
+
+        # the sharded step's VCF of step k is written while step k + 1 runs (every step's inside the timed region: the last
+        # one is collected before run_steps returns)
+        lagged = not layer2 and os.environ.get("LFQ_BENCH_EXCHANGE_LAG", "1") != "0"
+
+        def finish(k, conf, prev):
+            """-> (what the step before left to collect or None, the finished step or None)"""
+            cur = finish_start(k, conf)
+            if not lagged:
+                return None, finish_end(cur)
+            return cur, (finish_end(prev) if prev is not None else None)
 
         def wait(k):
             if layer2:
@@ -1419,19 +1480,25 @@ def main():
                 # "none": as soon as the count kernel of batch k is done (beside all of batch k's DP kernels)
                 depth = in_flight["n"]
                 confs = {j: submit(j) for j in range(min(depth, n))}
+                prev = None
                 for k in range(n):
                     tr0 = time.perf_counter()
                     wait(k)
                     tr1 = time.perf_counter()
-                    out = finish(k, confs.pop(k))
+                    prev, done = finish(k, confs.pop(k), prev)
+                    out = done or out
                     tr2 = time.perf_counter()
                     if k + depth < n:
                         confs[k + depth] = submit(k + depth)
+                    kt_ = (prev or done)[3 if prev else 4]
                     if step_trace is not None:
-                        step_trace.append((tr1 - tr0, tr2 - tr1, time.perf_counter() - tr2, out[4]["ms_total"]))
-                    acc = out[4] if acc is None else {x: acc[x] + out[4][x] for x in acc}
+                        step_trace.append((tr1 - tr0, tr2 - tr1, time.perf_counter() - tr2, kt_["ms_total"]))
+                    acc = dict(kt_) if acc is None else {x: acc[x] + kt_[x] for x in acc}
+                if prev is not None:
+                    out = finish_end(prev)
                 return out, acc
             pending = submit(0)
+            prev = None
             for k in range(n):
                 tr0 = time.perf_counter()
                 wait(k)
@@ -1440,11 +1507,15 @@ def main():
                 tr1 = time.perf_counter()
                 nxt = submit(k + 1) if k + 1 < n else None
                 tr2 = time.perf_counter()
-                out = finish(k, pending)
+                prev, done = finish(k, pending, prev)
+                out = done or out
+                kt_ = (prev or done)[3 if prev else 4]
                 if step_trace is not None:
-                    step_trace.append((tr1 - tr0, time.perf_counter() - tr2, tr2 - tr1, out[4]["ms_total"]))
-                acc = out[4] if acc is None else {x: acc[x] + out[4][x] for x in acc}
+                    step_trace.append((tr1 - tr0, time.perf_counter() - tr2, tr2 - tr1, kt_["ms_total"]))
+                acc = dict(kt_) if acc is None else {x: acc[x] + kt_[x] for x in acc}
                 pending = nxt
+            if prev is not None:
+                out = finish_end(prev)
             return out, acc
 
         run_steps(max(args.warmup, 2))              # both contexts warm (workspace allocations)
@@ -1589,8 +1660,9 @@ def main():
                              "dynamic Bonferroni" % (ncols / 1e6, depth,
                                                      "default filter applied" if cfg_filter else "--no-default-filter")),
                 "columns_per_gpu": my_cols, "bins_rank0": len(my_bins) if my_bins is not None else 1, "depth": depth, "planted_snv_period": args.plant_period,
-                "sharding": "region shard per GPU, test-count all-gather + record gather (RCCL)",
-                "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if world > 1 else None),
+                "sharding": "region shard per GPU; per step one test-count all-gather and one record gather to rank 0 (`exchange`)",
+                "rccl_ranks": comm_ranks, "exchange_backend": (dist.get_backend() if (world > 1 or force_dist) else None),
+                "exchange": exchange,
                 "records_per_step": int(len(recs)), "tested_columns_rank0": int(st.n_tested),
                 "nt_layout": "bytes" if args.nt_bytes else "packed nibbles (LFQ_TRACKS_NT_PACKED)",
                 "kernel_ms": kt,
@@ -1696,7 +1768,7 @@ def main():
                 sec["chain_2_workers"] = {"error": repr(e)}
             line["config"]["secondary"] = sec
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
     if pipelined:
         for c_ in callers[1:]:

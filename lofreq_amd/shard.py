@@ -10,6 +10,15 @@ contiguous genomic ranges, one per worker, no data-path exchange; what *is* exch
       ``bcftools concat``, :164-185).
 Over RCCL/xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  Payloads are tens of bytes to a
 few KB: latency-bound, so one collective of each kind and nothing else.
+
+What a collective costs a rank whose GPU is running count kernels back to back (measured with a one-rank
+communicator, profiles/NOTES.md round 5): every device-side piece of it -- the staging copies of a
+host-resident count, the RCCL kernel -- waits for a wave slot like any other kernel, ~1 ms per step for
+three blocking collectives.  Hence (i) `set_host_group`: the test counts, which are host integers on both
+ends, travel over a host-side group (gloo) when the caller provides one, and (ii) the record gather can be
+split into `gather_records_start` / `gather_records_wait` (fixed-capacity pieces, so that no second
+all-gather of the piece sizes is needed; RCCL, asynchronous): a caller that pipelines steps collects step
+k's records while step k + 1 runs and never blocks on the device in between.
 """
 import numpy as np
 
@@ -121,6 +130,17 @@ def plan_regions(regions, cost_fn, world_size, bins_per_worker=BIN_PER_THREAD, b
 _FORCE_COLLECTIVES = __import__("os").environ.get("LFQ_SHARD_FORCE_COLLECTIVES") == "1"
 
 
+# A host-side process group (gloo) for the counts, which are host integers on every rank: see the module docstring.
+_HOST_GROUP = None
+
+
+def set_host_group(group):
+    """`group` = a torch.distributed group whose backend takes CPU tensors (gloo), spanning the same ranks as the
+    default group, or None: exchange_counts then goes through it instead of staging 8 bytes per rank through the GPU."""
+    global _HOST_GROUP
+    _HOST_GROUP = group
+
+
 def exchange_counts(local_counts, dist=None, device=None):
     """One all-gather of a small int64 vector per rank ({tested SNV columns, indel tests}).
     -> (array [world, len(local_counts)], exclusive prefix of this rank as an array)."""
@@ -129,6 +149,12 @@ def exchange_counts(local_counts, dist=None, device=None):
         return v.reshape(1, -1), np.zeros_like(v)
     import torch
     ws, rank = dist.get_world_size(), dist.get_rank()
+    if _HOST_GROUP is not None:
+        mine = torch.from_numpy(v.copy())
+        allc = torch.zeros(ws * len(v), dtype=torch.int64)
+        dist.all_gather_into_tensor(allc, mine, group=_HOST_GROUP)
+        allc = allc.numpy().reshape(ws, len(v))
+        return allc, allc[:rank].sum(axis=0)
     mine = torch.from_numpy(v.copy()).to(device or "cpu")
     allc = torch.zeros(ws * len(v), dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(allc, mine)
@@ -180,23 +206,155 @@ def gather_records(records, col_offset, dist=None, device=None):
     return np.concatenate(parts) if parts else rec[:0]
 
 
+class PendingGather:
+    """A record gather that has been started (gather_records_start) and not yet collected."""
+    __slots__ = ("records", "work", "big", "mine", "stage", "host", "ev", "cap", "rdtype", "ws", "rank")
+
+
+_GATHER_HDR = 16        # bytes in front of a piece's records: int64 record count, int64 reserved (keeps the records aligned)
+_PINNED = {}            # size -> free pinned staging buffers (hipHostMalloc per step would cost more than the exchange)
+
+
+def _pinned_get(nbytes):
+    import torch
+    free = _PINNED.setdefault(int(nbytes), [])
+    return free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+
+
+def _pinned_put(t):
+    if t is not None:
+        _PINNED.setdefault(int(t.numel()), []).append(t)
+
+
+_XSTREAM = {}           # device -> the stream the gather's copies and its communicator wait are queued on
+
+
+def _exchange_stream(dev):
+    """A high-priority stream of its own for the record gather's device-side pieces: the caller's current stream carries
+    the blocking copies of its next step's results, which must not queue up behind them."""
+    import torch
+    key = (dev.type, dev.index)
+    if key not in _XSTREAM:
+        _XSTREAM[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return _XSTREAM[key]
+
+
+def gather_records_start(records, col_offset, cap, dist=None, device=None):
+    """First half of gather_records for callers that pipeline steps: every rank sends ONE piece of fixed capacity
+    (`cap` records, the same number on every rank -- e.g. 3 x the largest candidate-column count of the step, which the
+    count all-gather already made known to everybody; the piece starts with its own record count), so that no second
+    all-gather of the sizes is needed, and nothing here waits for the device: on a GPU the piece goes up from a pinned
+    buffer by an asynchronous copy, the collective is queued on the communicator's stream (RCCL), and rank 0's copy of
+    the gathered pieces back into pinned memory is queued behind it with an event that gather_records_wait waits for.
+    -> PendingGather.  `cap` too small for this rank's records raises before anything is sent."""
+    rec = records.copy()
+    rec["col"] += int(col_offset)
+    h = PendingGather()
+    h.records, h.work, h.big, h.mine, h.stage, h.host, h.ev = rec, None, None, None, None, None, None
+    h.rdtype = rec.dtype
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES):
+        return h
+    import torch
+    h.ws, h.rank, h.cap = dist.get_world_size(), dist.get_rank(), max(int(cap), 1)
+    if len(rec) > h.cap:
+        raise ValueError("gather_records_start: %d records, capacity %d" % (len(rec), h.cap))
+    dev = torch.device(device or "cpu")
+    width = h.rdtype.itemsize
+    piece = _GATHER_HDR + h.cap * width
+    on_gpu = dev.type != "cpu"
+    if on_gpu:
+        h.stage = _pinned_get(piece)
+        buf = h.stage.numpy()
+        buf[8:_GATHER_HDR] = 0
+    else:
+        buf = np.zeros(piece, np.uint8)
+    buf[:8] = np.array([len(rec)], np.int64).view(np.uint8)
+    buf[_GATHER_HDR: _GATHER_HDR + len(rec) * width] = rec.view(np.uint8).reshape(-1)
+    if not on_gpu:
+        h.mine = torch.from_numpy(buf)
+        pieces = None
+        if h.rank == 0:
+            h.big = torch.empty(h.ws * piece, dtype=torch.uint8)
+            pieces = list(h.big.view(h.ws, piece).unbind(0))
+        h.work = dist.gather(h.mine, pieces, dst=0, async_op=True)
+        h.records = None
+        return h
+    with torch.cuda.stream(_exchange_stream(dev)):
+        h.mine = h.stage.to(dev, non_blocking=True)
+        pieces = None
+        if h.rank == 0:
+            h.big = torch.empty(h.ws * piece, dtype=torch.uint8, device=dev)    # one buffer, one copy back to the host
+            pieces = list(h.big.view(h.ws, piece).unbind(0))
+        h.work = dist.gather(h.mine, pieces, dst=0, async_op=True)
+        h.work.wait()                   # (RCCL: the exchange STREAM waits for the collective, not the host)
+        if h.rank == 0:
+            h.host = _pinned_get(h.ws * piece)
+            h.host.copy_(h.big, non_blocking=True)
+        h.ev = torch.cuda.Event()
+        h.ev.record()
+    h.records = None
+    return h
+
+
+def gather_records_wait(h):
+    """Second half: the records of all ranks in shard order on rank 0, None elsewhere (every rank waits for its own side
+    of the collective, so that the buffers it handed over are free again)."""
+    if h.work is None:
+        return h.records
+    if h.ev is not None:
+        h.ev.synchronize()
+    else:
+        h.work.wait()
+    _pinned_put(h.stage)
+    h.stage = h.mine = None
+    if h.rank != 0:
+        return None
+    width = h.rdtype.itemsize
+    piece = _GATHER_HDR + h.cap * width
+    host = (h.host.numpy() if h.host is not None else h.big.numpy()).reshape(h.ws, piece)
+    parts = []
+    for r in range(h.ws):
+        n = int(host[r, :8].view(np.int64)[0])
+        parts.append(host[r, _GATHER_HDR: _GATHER_HDR + n * width].view(h.rdtype))
+    out = np.concatenate(parts)         # (a copy: the pinned buffer goes back to the pool)
+    _pinned_put(h.host)
+    h.big = h.host = None
+    return out
+
+
+def finish_shard_start(conf, pvals, n_tested_local, ref_base, col_offset, dist=None, device=None):
+    """Host + exchange half of one sharded step up to the point where the records are on their way: ONE all-gather of
+    {tested columns, candidate columns} per rank (exact running Bonferroni prefix; the largest candidate count bounds
+    every rank's records: at most three per column), the exact emit test on this shard's records, and the gather to
+    rank 0 STARTED.  -> (PendingGather for finish_shard_wait, total tested columns).  Updates conf like the reference's
+    single-process loop would."""
+    allc, prefix = exchange_counts([int(n_tested_local), len(pvals)], dist, device)
+    if conf.bonf_dynamic:
+        pvals = rebase_bonferroni(pvals, int(prefix[0]))
+    recs = finalize_pvals(conf, pvals, ref_base)
+    h = gather_records_start(recs, col_offset, 3 * int(allc[:, 1].max()), dist, device)
+    total = int(allc[:, 0].sum())
+    if total > 0:
+        if conf.bonf_dynamic:
+            conf.c.bonf_subst = (0 if conf.c.bonf_subst == 1 else conf.c.bonf_subst) + 3 * total
+        conf.c.num_snv_tests += 3 * total
+    return h, total
+
+
+def finish_shard_wait(h):
+    """-> the step's records on rank 0 (shard order), None elsewhere."""
+    return gather_records_wait(h)
+
+
 def finish_shard(conf, pvals, n_tested_local, ref_base, col_offset, dist=None, device=None):
     """Host + exchange half of one sharded step: exact running Bonferroni, emit test, gather.
 
     `pvals` are this shard's sparse device records (local Bonferroni factors, computed with the
     batch-start factor `conf.bonf_subst`, identical on every rank); returns (records on rank 0 or
-    None, total tested columns).  Updates conf like the reference's single-process loop would."""
-    counts, prefix = exchange_test_counts(n_tested_local, dist, device)
-    if conf.bonf_dynamic:
-        pvals = rebase_bonferroni(pvals, prefix)
-    recs = finalize_pvals(conf, pvals, ref_base)
-    allrecs = gather_records(recs, col_offset, dist, device)
-    total = sum(counts)
-    if total > 0:
-        if conf.bonf_dynamic:
-            conf.c.bonf_subst = (0 if conf.c.bonf_subst == 1 else conf.c.bonf_subst) + 3 * total
-        conf.c.num_snv_tests += 3 * total
-    return allrecs, total
+    None, total tested columns).  Updates conf like the reference's single-process loop would.
+    (= finish_shard_start + finish_shard_wait: one all-gather and one gather.)"""
+    h, total = finish_shard_start(conf, pvals, n_tested_local, ref_base, col_offset, dist, device)
+    return finish_shard_wait(h), total
 
 
 def finish_indel_shard(conf, bonf_indel_start, records, n_tests_local, col_offset, dist=None, device=None):

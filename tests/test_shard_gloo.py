@@ -90,6 +90,71 @@ def test_sharded_equals_single_process(tmp_path, world):
     assert got.tobytes() == exp.tobytes()
 
 
+def _lagged_worker(rank, world, port, out):
+    """three steps pipelined as bench.py's sharded loop runs them: the counts over a host group of their own, every
+    step's record gather started and collected one step later (the last one after the loop)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    shard.set_host_group(dist.new_group(backend="gloo"))
+    ncols, tested, prefix, ref, pv = _scenario(la)
+    lo, hi = shard.shard_ranges(ncols, world)[rank]
+    before = int(tested[:lo].sum())
+    outs, prev = [], None
+    for step in range(3):
+        # (step 1: this rank's shard has no candidate column at all; step 2: only rank 0's has any)
+        sel = (pv["col"] >= lo) & (pv["col"] < hi) & ((step == 0) | ((step == 2) & (rank == 0)))
+        mine = pv[sel].copy()
+        mine["col"] -= lo
+        mine["bonf"] -= 3 * before
+        conf = la.VarcallConf()
+        h, total = shard.finish_shard_start(conf, mine, int(tested[lo:hi].sum()), ref[lo:hi], lo, dist, None)
+        if prev is not None:
+            outs.append(shard.finish_shard_wait(prev))
+        prev = h
+        assert total == int(tested.sum()) and conf.bonf_subst == 3 * total
+    outs.append(shard.finish_shard_wait(prev))
+    if rank == 0:
+        for i, r in enumerate(outs):
+            np.save("%s.%d.npy" % (out, i), r.view(np.uint8))
+    else:
+        assert all(r is None for r in outs)
+    shard.set_host_group(None)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_lagged_gather_equals_single_process(tmp_path, world):
+    """finish_shard_start / finish_shard_wait (one all-gather over the host group, one asynchronous fixed-capacity
+    gather, collected a step later) give the records of the one-process run, also for steps in which some or all
+    shards have nothing to report"""
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    out = str(tmp_path / "lag")
+    mp.spawn(_lagged_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    ncols, tested, prefix, ref, pv = _scenario(la)
+    lo0, hi0 = shard.shard_ranges(ncols, world)[0]
+    for step in range(3):
+        got = np.load("%s.%d.npy" % (out, step)).view(la.SNV_RECORD_DTYPE)
+        sel = np.ones(len(pv), bool) if step == 0 else (np.zeros(len(pv), bool) if step == 1 else
+                                                        ((pv["col"] >= lo0) & (pv["col"] < hi0)))
+        conf = la.VarcallConf()
+        exp, _ = shard.finish_shard(conf, pv[sel], int(tested.sum()), ref, 0, None, None)
+        assert got.tobytes() == exp.tobytes(), step
+        assert (len(exp) > 10) == (step != 1)
+
+
+def test_gather_capacity_is_checked():
+    import lofreq_amd as la
+    from lofreq_amd import shard
+    recs = np.zeros(5, la.SNV_RECORD_DTYPE)
+    h = shard.gather_records_start(recs, 7, 2)            # no communicator: nothing is sent, nothing to bound
+    assert (shard.gather_records_wait(h)["col"] == 7).all()
+
+
 def test_shard_ranges():
     from lofreq_amd import shard
     assert shard.shard_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
