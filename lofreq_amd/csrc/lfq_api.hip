@@ -140,7 +140,8 @@ int lfq_make_params(const lfq_conf *conf, const lfq_tracks *tr, LfqParams *P, bo
     P->phase1_chunks = lfq_knobs().phase1_chunks;
     P->seg_budget_mid = lfq_knobs().seg_budget_mid;
     P->seg_budget_big = lfq_knobs().seg_budget_big;
-    P->seg_max = lfq_knobs().seg_max;                            /* experiments: fewer, longer row segments */
+    P->seg_max = lfq_knobs().seg_max >= 0 ? lfq_knobs().seg_max : LFQ_SEG_MAX;      /* (lfq_batch_device_impl: by the gate) */
+    P->seg_max_mid = lfq_knobs().seg_max_mid >= 0 ? lfq_knobs().seg_max_mid : LFQ_SEG_MAX;
     if (indel_mode) {
         /* call_indels: no base / merged-quality filters, every event is a test (lofreq_call.c:684-725);
          * the alignment-quality track is "used" wherever the packer filled it in */
@@ -573,6 +574,20 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
     hipStream_t side_i[2] = {side0, side1};
     LfqParams P;
     LFQ_TRY(lfq_make_params(conf, tr, &P, indel_mode));
+    /* Row segments per long column.  A batch whose DP kernels have the device to themselves wants SHORT chains: up to
+     * LFQ_SEG_MAX segments side by side, put together by a fold tree.  A context that queues its batches without a gate
+     * runs them beside the next batch's count kernel, where the chains' length is hidden and what they cost the step is
+     * their WORK and their residency (fold workgroups of 121 KB LDS, seven convolutions per column): there a big column
+     * is cut in two and a mid-class column runs on in one piece after its first stretch -- C3 2.90 -> 2.79-2.81 ms per
+     * step, C2 0.60 -> 0.53 (profiles/NOTES.md; alone the same choice costs C3 3.32 -> 3.73).  LFQ_SEG_MAX[_MID|_BIG] override. */
+    if (c->batch_gate == LFQ_GATE_NONE && !indel_mode) {
+        if (kn.seg_max < 0) {
+            P.seg_max = 2;
+        }
+        if (kn.seg_max_mid < 0) {
+            P.seg_max_mid = 2;
+        }
+    }
     P.detlim_af = indel_mode ? nullptr : c->detlim_af;      /* set only inside lfq_uniq_detlim_batch */
     P.lazy_strand = (c->lazy_now && !indel_mode && !P.general && !P.detlim_af) ? 1 : 0;
     /* the context's own dense array inside lfq_call_snvs_batch without h_counts: nobody sees the entries of untested

@@ -905,7 +905,7 @@ __device__ __forceinline__ void lfq_wave_column(const LfqColCtx &cx, LfqRaw raw,
              * the state reached here becomes segment 0 (lfq_dp_segw_kernel, lfq_dp_combine_kernel) */
             /* fewer, longer segments when many columns are long anyway: the fold costs (segments - 1) convolutions */
             const int n_new = lfq_split_plan(K, n_chunks - (ch + 1), 1,
-                                             min(P.seg_max, max(2, P.seg_budget_mid / max(W.counters[LFQ_CNT_MID], 1))));
+                                             min(P.seg_max_mid, max(2, P.seg_budget_mid / max(W.counters[LFQ_CNT_MID], 1))));
             if (n_new > 0) {
                 const int n_seg = n_new + 1;
                 const int cells = 2 * n_seg * (K + 1);      /* segments + intermediates of the fold tree */

@@ -65,7 +65,12 @@ const LfqKnobs &lfq_knobs(void)
         x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 4));
         x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));
         x.phase1_chunks = (int)std::max(1L, geti("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
-        x.seg_max = (int)std::min((long)LFQ_SEG_MAX, std::max(2L, geti("LFQ_SEG_MAX", LFQ_SEG_MAX)));
+        {
+            const long both = geti("LFQ_SEG_MAX", -1);
+            const long big = geti("LFQ_SEG_MAX_BIG", both), mid = geti("LFQ_SEG_MAX_MID", both);
+            x.seg_max = big < 0 ? -1 : (int)std::min((long)LFQ_SEG_MAX, std::max(2L, big));
+            x.seg_max_mid = mid < 0 ? -1 : (int)std::min((long)LFQ_SEG_MAX, std::max(2L, mid));
+        }
         x.seg_budget_mid = (int)std::max(1L, geti("LFQ_SEG_BUDGET_MID", 4096));
         x.seg_budget_big = (int)std::max(1L, geti("LFQ_SEG_BUDGET_BIG", 4096));
         x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));

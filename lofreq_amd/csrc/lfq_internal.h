@@ -37,7 +37,8 @@ struct LfqParams {
     int32_t bonf_reset_first; /* SNVs: the first tested column SETS the factor to 3 instead of adding (lofreq_call.c:795-796) */
     double sig;               /* (double)(float)conf->sig */
     double prune_slack;       /* prune only if P*bonf > sig*(1+slack); host applies the exact test */
-    int32_t seg_max;          /* row segments per split column, 2..LFQ_SEG_MAX */
+    int32_t seg_max;          /* row segments per split column of the big class, 2..LFQ_SEG_MAX */
+    int32_t seg_max_mid;      /* ... of the mid class, its first stretch included (2 = the rest of the column in one piece) */
     int32_t seg_budget_mid, seg_budget_big;   /* segments per column = min(seg_max, budget / columns of the class): a few
                                                * thousand wavefronts of row segments fill the chip, more only cost folds */
     int32_t phase1_chunks;    /* mid class: 64-row chunks run unsplit before a surviving column is cut up */
@@ -195,7 +196,8 @@ struct LfqKnobs {
     int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (4): the screen is latency-bound per column, more wavefronts only crowd the two critical chains */
     int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
     int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
-    int seg_max;               /* LFQ_SEG_MAX */
+    int seg_max;               /* LFQ_SEG_MAX: both classes; LFQ_SEG_MAX_BIG / LFQ_SEG_MAX_MID: one of them (-1 = not given) */
+    int seg_max_mid;
     int seg_budget_mid, seg_budget_big;   /* LFQ_SEG_BUDGET_MID (4096), LFQ_SEG_BUDGET_BIG (4096) */
     int split_pool_cells;      /* LFQ_SPLIT_POOL_CELLS (8 Mi; 0 disables the row split) */
     long count_multi_below;    /* LFQ_COUNT_MULTI_BELOW (4096) */

@@ -31,6 +31,8 @@ CASES = [
     ("LFQ_COUNT_LPG4_BELOW=0", DP),          # ... never four
     ("LFQ_COUNT_WAVES_PER_WG=4 LFQ_COUNT_MULTI_BELOW=0", DP),    # the lean count kernel with 4 columns per workgroup (default 16) ...
     ("LFQ_COUNT_WAVES_PER_WG=8 LFQ_COUNT_MULTI_BELOW=0", DP),    # ... and 8, on every batch
+    ("LFQ_SEG_MAX=2", DP),                   # a big column in two row segments, a mid-class column in one piece after its first stretch (what a context with LFQ_GATE_NONE runs)
+    ("LFQ_SEG_MAX_MID=3 LFQ_SEG_MAX_BIG=4", DP),   # ... other segment counts per class
     ("LFQ_BIG_ON_SIDE=1", DP),               # the unsplit big columns behind the big chain (what a context with LFQ_GATE_NONE runs)
     ("LFQ_JOIN_ON_SIDE=0 LFQ_TAIL_LIGHT=0 LFQ_HEAVY_AFTER_SCREEN=0", DP),   # the stream plan of round 4: join on the light chain's stream, tail event behind the retry kernel
     ("LFQ_TAIL_LIGHT=2", DP),                # tail event of the light chain behind the scan
