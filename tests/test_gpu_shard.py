@@ -121,6 +121,44 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     assert p2.returncode != 0 and "WORLD_SIZE" in (p2.stderr + p2.stdout)
 
 
+@pytest.mark.timeout(900)
+def test_bench_sharded_step_through_a_one_rank_rccl_communicator():
+    """The N > 1 form of bench.py's step on one GPU: layer 1 + the shard exchange with a ONE-rank RCCL communicator
+    (LFQ_BENCH_FORCE_DIST=1) -- test counts over the host group, the record gather asynchronous over RCCL and collected a
+    step later -- gives the records of the layer-2 run, checked against the oracle by the run itself; so do the blocking
+    forms kept for A/B runs (LFQ_BENCH_EXCHANGE=rccl, LFQ_BENCH_EXCHANGE_LAG=0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LFQ_BENCH_ONE_GPU"):
+        base.pop(k, None)
+
+    def run(extra_env, *args):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--cols", "40000",
+                            "--repeats", "1", "--no-pmc", "--no-cpu-baseline", "--no-secondary"] + list(args),
+                           env=dict(base, **extra_env), capture_output=True, text=True, timeout=400)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+        assert len(lines) == 1, p.stdout[-2000:]
+        return json.loads(lines[0])
+
+    ref = run({})
+    assert ref["config"]["vcf_identical"] is True and ref["config"]["records_per_step"] > 10
+    for env in ({"LFQ_BENCH_FORCE_DIST": "1"},
+                {"LFQ_BENCH_FORCE_DIST": "1", "LFQ_BENCH_EXCHANGE": "rccl"},
+                {"LFQ_BENCH_FORCE_DIST": "1", "LFQ_BENCH_EXCHANGE_LAG": "0"}):
+        d = run(env, "--shard-path")
+        c = d["config"]
+        assert c["exchange_backend"] == "nccl" and c["rccl_ranks"] == 1, c
+        assert ("gloo" in c["exchange"]["counts"]) == (env.get("LFQ_BENCH_EXCHANGE") != "rccl"), c["exchange"]
+        assert "rccl gather" in c["exchange"]["records"]
+        assert c["vcf_identical"] is True and c["records_per_step"] == ref["config"]["records_per_step"], (env, c)
+        assert c["records_compared"] == ref["config"]["records_compared"]
+
+
 _PAR_WORKER = r'''
 import ctypes as C, os, sys
 import numpy as np
