@@ -2,6 +2,7 @@
 # preloaded into scalar registers at wave start; the four header loads requested back to back) against three behind one another
 # (kernel arguments -> null tests -> reference base -> column offsets).  Libraries: old = before; nopre = new code without
 # -amdgpu-kernarg-preload-count; default = new code with it (every kernel of the library compiled with the flag).
+# (the three libraries were built from profiles/experiments/r05_count_header_one_round_trip.patch; the code was reverted -- profiles/NOTES.md)
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

@@ -1,6 +1,7 @@
 # Round 5: the screen kernel's wavefronts as 1024-thread workgroups on a quarter of the CUs (LFQ_SCREEN_WG=1024) instead of one
 # 256-thread workgroup on every CU: beside the next batch's count kernel a 256-thread DP workgroup leaves its CU room for ONE
 # 1024-thread count workgroup instead of two (5 of 8 wave slots per SIMD in use); a 1024-thread one replaces a count workgroup
+# (LFQ_SCREEN_WG existed for this measurement only, removed again -- profiles/NOTES.md)
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

@@ -2,6 +2,7 @@
 # (LFQ_BENCH_FORCE_DIST=1), the communicator's stream at normal / high priority, host side of the steps traced;
 # (b) two sets of DP streams taken in turn by the contexts (LFQ_DP_STREAM_SETS=2) at the shallow shapes, where a batch's
 # period is its mid chain behind the previous batch's on the same stream
+# (LFQ_DP_STREAM_SETS existed for this measurement only, removed again -- profiles/NOTES.md)
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

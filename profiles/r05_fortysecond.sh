@@ -1,6 +1,7 @@
 # Round 5: the DP streams confined to N CUs (LFQ_DP_CUS; hipExtStreamCreateWithCUMask) under the queue form of the second half
 # of the round (four batches queued, no gate, lean count kernel with 1024-thread workgroups): does the count kernel keep its
 # residency on the other CUs?  (Round 3 measured masks with two batches in flight and the host in the loop: NOTES.)
+# (LFQ_DP_CUS existed for this measurement only: a dozen lines in acquire_streams, removed again -- profiles/NOTES.md)
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

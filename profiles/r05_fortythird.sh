@@ -1,6 +1,7 @@
 # Round 5: the LAUNCH stream (count kernels) confined to N of the 256 CUs (LFQ_COUNT_CUS), DP streams unmasked at high priority:
 # the DP kernels of the batch before then find CUs no count workgroup ever takes.  (The other way round -- DP streams masked,
 # r05_fortysecond.sh -- loses the priority with the mask and the DP kernels starve beside the count kernel.)
+# (LFQ_COUNT_CUS existed for this measurement only, removed again -- profiles/NOTES.md)
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
