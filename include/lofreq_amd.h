@@ -490,8 +490,10 @@ int lfq_call_snvs_wait(lfq_ctx *ctx);
  *   LFQ_GATE_END   all of that batch's kernels are done: batch after batch on the device with no host round trip between
  *                  them -- `submit(k + 1); wait(k); collect(k)` then hides every host latency without putting two batches'
  *                  kernels on the machine at once (the loop of lofreq_call.c:735-879 has no such gap to hide: it is serial);
- *   LFQ_GATE_NONE  nothing: it starts as soon as its stream is free.
- * Results do not depend on the choice.  LFQ_ERR_INVALID for another value. */
+ *   LFQ_GATE_NONE  nothing: it starts as soon as its stream is free.  The context then shapes its DP work for running BESIDE
+ *                  a count kernel (a long column is cut into two row segments at most instead of eight: less work and
+ *                  residency at the price of a longer chain, which is hidden there).
+ * Results do not depend on the choice (p-values within the tolerance the parity tests hold every decomposition to).  LFQ_ERR_INVALID for another value. */
 #define LFQ_GATE_TAIL 0
 #define LFQ_GATE_END 1
 #define LFQ_GATE_NONE 2
