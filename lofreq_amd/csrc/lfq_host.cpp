@@ -85,7 +85,7 @@ const LfqKnobs &lfq_knobs(void)
         }
         x.count_cols_per_wave = (int)std::min(std::max(geti("LFQ_COUNT_COLS_PER_WAVE", 1), 1L), 16L);
         x.big_on_side = has("LFQ_BIG_ON_SIDE");
-        x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 20000);
+        x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 4000);
         x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);
         x.pileup_tiles = (int)geti("LFQ_PILEUP_TILES", 1);
         x.baq_one_variant = has("LFQ_BAQ_ONE_VARIANT") ? 1 : 0;

@@ -210,7 +210,7 @@ struct LfqKnobs {
     int baq_one_variant;       /* LFQ_BAQ_ONE_VARIANT: every wavefront of the plain narrow-band BAQ launches through the instantiation with the N case */
     int pileup_tiles;          /* LFQ_PILEUP_TILES (1): SNV pileup of sorted reads by tiles of 64 positions; 0 = a wavefront per position */
     long host_loop_threads;    /* LFQ_HOST_LOOP_THREADS (8): threads (caller included) a host loop over reads / positions / events is cut for, at most 16 */
-    long sb_par_min_cost;      /* LFQ_SB_PAR_MIN_COST (20000): summed alt counts of the strand-bias tests of a batch from which they go to the host pool */
+    long sb_par_min_cost;      /* LFQ_SB_PAR_MIN_COST (4000; 20000 until the end of round 5: a 200x batch's 700 tables of 10-30 alt bases were 0.22 ms of a host-paced 0.85 ms step on one thread): summed alt counts of the strand-bias tests of a batch from which they go to the host pool */
     long count_lpg4_below, count_lpg8_below;   /* LFQ_COUNT_LPG4_BELOW (320), LFQ_COUNT_LPG8_BELOW (900): deepest column up to which 4 / 8 lanes share a column */
     long host_spin_us;         /* LFQ_HOST_SPIN_US (2000): how long the helper threads of the host loops spin for the next loop; -1 = no pool */
     int sync_upload;           /* LFQ_SYNC_UPLOAD: 1 = lfq_readset_create waits for its copies itself (no helper thread), 2 = helper thread whatever the size */
