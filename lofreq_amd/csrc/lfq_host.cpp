@@ -257,7 +257,13 @@ public:
             f();
             return;
         }
-        std::unique_lock<std::mutex> call_lock(call_m_);      /* one batch at a time */
+        /* one batch at a time -- and a caller that finds the pool taken (several host threads with a context each: the
+         * genome runs) does its batch alone at once instead of queueing for helpers */
+        std::unique_lock<std::mutex> call_lock(call_m_, std::try_to_lock);
+        if (!call_lock.owns_lock()) {
+            f();
+            return;
+        }
         {
             std::lock_guard<std::mutex> lk(m_);
             job_ = &f;
