@@ -972,11 +972,7 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);      /* enters the window for row i + 1 */
         const double e_eq = 1. - qli, e_ne = qli * LFQ_BAQ_EM;           /* lfq_baq_emit's two non-trivial values */
         LfqBaqPair *fp = FP(i);
-#ifdef LFQ_BAQ_NO_STORE                             /* timing experiment: what the forward matrix's stores cost */
-        const bool store = false;
-#else
         const bool store = (i & 1) == 0;             /* odd rows >= 3 are recomputed by the backward sweep (lfq_baq_refwd_row) */
-#endif
         if constexpr (INTERIOR) {                    /* interior row: all 15 cells, for every read of the wavefront */
             const bool has_n = qyi > 3 || (win & lfq_baq_nibbles<NB, WinT>(4u)) != 0;
             /* ONE instantiation of the row (the N case always handled: a handful of instructions per slot): with two or
@@ -1018,12 +1014,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         if ((i & 15) == 15) {                        /* the next 16 codes have had 16 rows to arrive; request the ones after */
             nxt = lfq_baq_pack16(pd0, pd1, pd2, pd3);
             const int p = i + 18 + NB - bw;          /* row i + 17's code: position (i + 17) - bw + NB + 1 */
-#ifdef LFQ_BAQ_TEST_NOPD                            /* timing experiment: no loads in the forward loop (wrong results) */
-            pd0 = 0x41434754u + (uint32_t)p; pd1 = pd0 ^ 0x02020202u; pd2 = pd0; pd3 = pd1;
-#else
             pd0 = lfq_baq_ref4(refw, p, l_ref); pd1 = lfq_baq_ref4(refw, p + 4, l_ref);
             pd2 = lfq_baq_ref4(refw, p + 8, l_ref); pd3 = lfq_baq_ref4(refw, p + 12, l_ref);
-#endif
         }
         if (i <= l_query) {
             if (IDAQ) {
@@ -1050,12 +1042,6 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
         }
     }
 
-#ifdef LFQ_BAQ_FWD_ONLY                             /* timing experiment (profiles/ab_baq.sh): the forward pass alone */
-    if (A.rows >= 0) {
-        if (act) out[0] = (uint8_t)(s_last + s_fin);
-        return;
-    }
-#endif
     /* ---- expected reference offset of every matched query base (bam_md_ext.c:409-447) ---- */
     for (int i = 0; i < l_query; i++) {
         expect[(size_t)i * 64 + lane] = INT32_MIN;       /* not in a match block (the offset itself can be negative) */

@@ -39,7 +39,21 @@
 #include "lofreq_amd.h"
 #include "lfq_internal.h"
 
-/* the environment knobs, parsed once (lfq_internal.h) */
+/* the environment knobs, parsed once (lfq_internal.h).
+ *
+ * A release build reads TEN variables, none of which changes a result (DESIGN.md "Environment knobs"): LFQ_TIMING,
+ * LFQ_SINGLE_STREAM, LFQ_DEBUG_SYNC, LFQ_PRIVATE_STREAM, LFQ_SYNC_UPLOAD, LFQ_BAQ_SCRATCH_MB, LFQ_HOST_THREADS,
+ * LFQ_HOST_LOOP_THREADS, LFQ_HOST_SPIN_US and torchrun's LOCAL_WORLD_SIZE.  Everything else -- the launch-shape and
+ * fallback selectors the knob tests drive (tests/test_gpu_knobs.py) and LFQ_DEBUG_SKIP, which drops DP classes and with them
+ * calls -- exists only in the tuning build (-DLFQ_TUNE: lofreq_amd/liblofreq_amd_tune.so, `make tune`; same kernels, same
+ * objects, this one file compiled twice). */
+#ifdef LFQ_TUNE
+#define LFQ_TUNE_I(name, dflt) geti(name, dflt)
+#define LFQ_TUNE_HAS(name) has(name)
+#else
+#define LFQ_TUNE_I(name, dflt) ((long)(dflt))
+#define LFQ_TUNE_HAS(name) false
+#endif
 const LfqKnobs &lfq_knobs(void)
 {
     static const LfqKnobs k = [] {
@@ -50,10 +64,20 @@ const LfqKnobs &lfq_knobs(void)
             return (e && *e) ? atol(e) : dflt;
         };
         auto has = [](const char *name) { return getenv(name) != nullptr; };
+        /* ---- release: ten variables ---- */
         x.timing = has("LFQ_TIMING");
         x.single_stream = has("LFQ_SINGLE_STREAM");
-        x.no_sb_precompute = has("LFQ_NO_SB_PRECOMPUTE");
         x.debug_sync = has("LFQ_DEBUG_SYNC");
+        x.private_stream = (int)geti("LFQ_PRIVATE_STREAM", 0);
+        x.sync_upload = (int)geti("LFQ_SYNC_UPLOAD", 0);
+        x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
+        x.host_threads = (int)geti("LFQ_HOST_THREADS", -1);
+        x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);
+        x.host_spin_us = geti("LFQ_HOST_SPIN_US", 2000);
+        x.local_world_size = (int)std::max(1L, geti("LOCAL_WORLD_SIZE", 1));
+        /* ---- tuning build only (defaults otherwise) ---- */
+        x.no_sb_precompute = LFQ_TUNE_HAS("LFQ_NO_SB_PRECOMPUTE");
+#ifdef LFQ_TUNE
         if (const char *sk = getenv("LFQ_DEBUG_SKIP")) {
             x.skip_light = strstr(sk, "light") != nullptr;
             x.skip_mid = strstr(sk, "mid") != nullptr;
@@ -62,52 +86,48 @@ const LfqKnobs &lfq_knobs(void)
         if (const char *lk = getenv("LFQ_LIGHT_KERNEL")) {
             x.light_kernel = !strcmp(lk, "wave") ? 2 : 0;
         }
-        x.screen_waves_per_cu = (int)std::max(1L, geti("LFQ_SCREEN_WAVES_PER_CU", 4));
-        x.screen_rounds = (int)std::max(1L, geti("LFQ_SCREEN_ROUNDS", 24));
-        x.phase1_chunks = (int)std::max(1L, geti("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
+#endif
+        x.screen_waves_per_cu = (int)std::max(1L, LFQ_TUNE_I("LFQ_SCREEN_WAVES_PER_CU", 4));
+        x.screen_rounds = (int)std::max(1L, LFQ_TUNE_I("LFQ_SCREEN_ROUNDS", 24));
+        x.phase1_chunks = (int)std::max(1L, LFQ_TUNE_I("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
         {
-            const long both = geti("LFQ_SEG_MAX", -1);
-            const long big = geti("LFQ_SEG_MAX_BIG", both), mid = geti("LFQ_SEG_MAX_MID", both);
+            const long both = LFQ_TUNE_I("LFQ_SEG_MAX", -1);
+            const long big = LFQ_TUNE_I("LFQ_SEG_MAX_BIG", both), mid = LFQ_TUNE_I("LFQ_SEG_MAX_MID", both);
             x.seg_max = big < 0 ? -1 : (int)std::min((long)LFQ_SEG_MAX, std::max(2L, big));
             x.seg_max_mid = mid < 0 ? -1 : (int)std::min((long)LFQ_SEG_MAX, std::max(2L, mid));
         }
-        x.seg_budget_mid = (int)std::max(1L, geti("LFQ_SEG_BUDGET_MID", 4096));
-        x.seg_budget_big = (int)std::max(1L, geti("LFQ_SEG_BUDGET_BIG", 4096));
-        x.split_pool_cells = (int)std::max(0L, geti("LFQ_SPLIT_POOL_CELLS", 8L << 20));
-        x.count_multi_below = geti("LFQ_COUNT_MULTI_BELOW", 4096);
+        x.seg_budget_mid = (int)std::max(1L, LFQ_TUNE_I("LFQ_SEG_BUDGET_MID", 4096));
+        x.seg_budget_big = (int)std::max(1L, LFQ_TUNE_I("LFQ_SEG_BUDGET_BIG", 4096));
+        x.split_pool_cells = (int)std::max(0L, LFQ_TUNE_I("LFQ_SPLIT_POOL_CELLS", 8L << 20));
+        x.count_multi_below = LFQ_TUNE_I("LFQ_COUNT_MULTI_BELOW", 4096);
         {
-            const long w = geti("LFQ_COUNT_WAVES_PER_WG", 16);
+            const long w = LFQ_TUNE_I("LFQ_COUNT_WAVES_PER_WG", 16);
             x.count_waves_per_wg = (w == 4 || w == 8 || w == 12) ? (int)w : 16;
         }
         {
-            const long u = geti("LFQ_COUNT_AHEAD_DEEP", 2);
+            const long u = LFQ_TUNE_I("LFQ_COUNT_AHEAD_DEEP", 2);
             x.count_ahead_deep = (u == 3 || u == 4) ? (int)u : 2;
         }
-        x.count_cols_per_wave = (int)std::min(std::max(geti("LFQ_COUNT_COLS_PER_WAVE", 1), 1L), 16L);
-        x.big_on_side = has("LFQ_BIG_ON_SIDE");
-        x.sb_par_min_cost = geti("LFQ_SB_PAR_MIN_COST", 4000);
-        x.host_loop_threads = geti("LFQ_HOST_LOOP_THREADS", 8);
-        x.pileup_tiles = (int)geti("LFQ_PILEUP_TILES", 1);
-        x.baq_one_variant = has("LFQ_BAQ_ONE_VARIANT") ? 1 : 0;
-        x.count_lpg4_below = geti("LFQ_COUNT_LPG4_BELOW", 320);
-        x.count_lpg8_below = geti("LFQ_COUNT_LPG8_BELOW", 900);
-        x.sync_upload = (int)geti("LFQ_SYNC_UPLOAD", 0);
-        x.host_spin_us = geti("LFQ_HOST_SPIN_US", 2000);
-        x.host_threads = (int)geti("LFQ_HOST_THREADS", -1);
-        x.host_par_min = std::max(1L, geti("LFQ_HOST_PAR_MIN", 200000));
-        x.local_world_size = (int)std::max(1L, geti("LOCAL_WORLD_SIZE", 1));
-        x.indel_host_pack = has("LFQ_INDEL_HOST_PACK");
-        x.pileup_atomic = has("LFQ_PILEUP_ATOMIC");
-        x.baq_lds = geti("LFQ_BAQ_LDS", 1) != 0;
-        x.baq_idaq_beside = (int)geti("LFQ_BAQ_IDAQ_BESIDE", 0);
-        x.baq_scratch_mb = geti("LFQ_BAQ_SCRATCH_MB", -1);
-        x.tail_light = (int)std::min(2L, std::max(0L, geti("LFQ_TAIL_LIGHT", 1)));
-        x.count_shallow_wgs_none = (int)std::min(4L, std::max(0L, geti("LFQ_COUNT_SHALLOW_WGS_NONE", 2)));
-        x.count_lean_lds_pad = (int)std::min(160000L, std::max(0L, geti("LFQ_COUNT_LEAN_LDS_PAD", 0)));
-        x.count_shallow_lds_pad = (int)std::min(120000L, std::max(0L, geti("LFQ_COUNT_SHALLOW_LDS_PAD", 0)));
-        x.join_on_side = (int)geti("LFQ_JOIN_ON_SIDE", 1);
-        x.private_stream = (int)geti("LFQ_PRIVATE_STREAM", 0);
-        x.heavy_after_screen = (int)geti("LFQ_HEAVY_AFTER_SCREEN", 1);
+        x.count_cols_per_wave = (int)std::min(std::max(LFQ_TUNE_I("LFQ_COUNT_COLS_PER_WAVE", 1), 1L), 16L);
+        x.big_on_side = LFQ_TUNE_HAS("LFQ_BIG_ON_SIDE");
+        x.sb_par_min_cost = LFQ_TUNE_I("LFQ_SB_PAR_MIN_COST", 4000);
+        x.pileup_tiles = (int)LFQ_TUNE_I("LFQ_PILEUP_TILES", 1);
+        x.baq_one_variant = LFQ_TUNE_HAS("LFQ_BAQ_ONE_VARIANT") ? 1 : 0;
+        x.count_lpg4_below = LFQ_TUNE_I("LFQ_COUNT_LPG4_BELOW", 320);
+        x.count_lpg8_below = LFQ_TUNE_I("LFQ_COUNT_LPG8_BELOW", 900);
+        x.host_par_min = std::max(1L, LFQ_TUNE_I("LFQ_HOST_PAR_MIN", 200000));
+        x.indel_host_pack = LFQ_TUNE_HAS("LFQ_INDEL_HOST_PACK");
+        x.pileup_atomic = LFQ_TUNE_HAS("LFQ_PILEUP_ATOMIC");
+        x.baq_lds = LFQ_TUNE_I("LFQ_BAQ_LDS", 1) != 0;
+        x.baq_idaq_beside = (int)LFQ_TUNE_I("LFQ_BAQ_IDAQ_BESIDE", 0);
+        x.tail_light = (int)std::min(2L, std::max(0L, LFQ_TUNE_I("LFQ_TAIL_LIGHT", 1)));
+        x.count_shallow_wgs_none = (int)std::min(4L, std::max(0L, LFQ_TUNE_I("LFQ_COUNT_SHALLOW_WGS_NONE", 2)));
+        x.count_lean_lds_pad = (int)std::min(160000L, std::max(0L, LFQ_TUNE_I("LFQ_COUNT_LEAN_LDS_PAD", 0)));
+        x.count_shallow_lds_pad = (int)std::min(120000L, std::max(0L, LFQ_TUNE_I("LFQ_COUNT_SHALLOW_LDS_PAD", 0)));
+        x.join_on_side = (int)LFQ_TUNE_I("LFQ_JOIN_ON_SIDE", 1);
+        x.heavy_after_screen = (int)LFQ_TUNE_I("LFQ_HEAVY_AFTER_SCREEN", 1);
+        (void)geti;
+        (void)has;
         return x;
     }();
     return k;

@@ -798,7 +798,59 @@ def main_baq():
     run_baq("baq_plain", 32, 330, 250, sites, mq_mix, extra=("-e",))
 
 
+# ---- real-size fixtures: the reads are NOT stored, only how to make them (tests/golden_reads.py) ------------------------------
+
+def run_big(name, params, call_args, note):
+    """A C1- or C4-shaped run of the 2.1.4 binary (BASELINE.json configs[0] / [3]): seeded reads from tests/golden_reads.py
+    -> SAM -> `lofreq call` (+ its `lofreq filter` epilogue unless --no-default-filter, lofreq_call.c:1506-1551).  The fixture
+    holds the generator's parameters and version, the SHA-256 of the SAM text, the binary's VCF lines and its test counts."""
+    import time
+    sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+    import golden_reads as gr
+    with tempfile.TemporaryDirectory() as tmp:
+        R = gr.make(**params)
+        open(os.path.join(tmp, "t.fa"), "w").write(">chr1\n" + R["ref"].decode() + "\n")
+        sha = gr.write_sam(R, os.path.join(tmp, "t.sam"))
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        env = dict(os.environ)
+        env["PATH"] = os.path.dirname(os.path.abspath(LOFREQ)) + ":" + env["PATH"]
+        t0 = time.time()
+        res = subprocess.run([LOFREQ, "call", "-f", "t.fa", "-o", "out.vcf"] + call_args + ["t.sam"], cwd=tmp,
+                             check=True, capture_output=True, text=True, env=env)
+        secs = time.time() - t0
+        nt = {}
+        for line in res.stderr.splitlines():
+            if "tests performed" in line:
+                nt["indel" if "indel" in line else "snv"] = int(line.split(":")[-1])
+        vcf = [l for l in open(os.path.join(tmp, "out.vcf")).read().splitlines() if not l.startswith("#")]
+    n_ind = sum(1 for l in vcf if "INDEL" in l.split("\t")[7])
+    fix = {"name": name, "generator": {"module": "tests/golden_reads.py", "version": gr.GENERATOR_VERSION, "params": params},
+           "reference_binary": "lofreq 2.1.4 (dist tgz)", "call_args": call_args, "note": note,
+           "n_reads": int(R["n"]), "n_bases": int(R["seq_off"][-1]), "sam_sha256": sha, "num_tests": nt, "vcf": vcf,
+           "n_snv_lines": len(vcf) - n_ind, "n_indel_lines": n_ind, "binary_seconds_in_the_build_container": round(secs, 1)}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d reads, %d SNV + %d indel vcf records, tests %s, %.1f s in the binary, %d bytes"
+          % (name, R["n"], len(vcf) - n_ind, n_ind, nt, secs, os.path.getsize(path)))
+
+
+def main_big():
+    # C1 shape (tests/bonf_auto_vs_dyn.sh:10-30: denv2, 10.7 kb, depth 10^3..10^4): `lofreq call` defaults = extended BAQ on the
+    # fly, dynamic Bonferroni, the `lofreq filter` epilogue.  Qualities >= 6: the 2.1.4 / HEAD raw-count delta cannot show.
+    run_big("big_c1_default", dict(seed=601, glen=10700, depth_lo=1000, depth_hi=5000, min_q=6), [],
+            "C1 shape, lofreq call defaults")
+    # the same shape with base qualities from 2 (alt bases below min_bq 6 exist: AF differs between 2.1.4 and HEAD where
+    # such bases carry the alt allele; everything else must still agree) and without the default filter
+    run_big("big_c1_lowbq_nofilter", dict(seed=602, glen=10700, depth_lo=1000, depth_hi=3000, min_q=2),
+            ["--no-default-filter"], "C1 shape, low base qualities (documented 2.1.4-vs-HEAD raw-count delta), no default filter")
+    # C4 shape at a size the binary does in a minute: 500x, planted insertions / deletions, BI / BD tags, --call-indels
+    run_big("big_c4_indels", dict(seed=603, glen=24000, depth_lo=500, depth_hi=500, min_q=6, snv_every=60, indel_every=240),
+            ["--call-indels"], "C4 shape (500x, --call-indels, defaults otherwise)")
+
+
 def main():
+    if "--big-only" in sys.argv:
+        return main_big()
     if "--indels-only" in sys.argv:
         return main_indels()
     if "--baq-only" in sys.argv:

@@ -107,3 +107,22 @@ def test_host_side_functions_match_oracle(oracle):
     assert la.pvalue_from_log(-1e5, la.LFQ_PV_UNDERFLOW) == LDBL_MIN
     p = la.pvalue_from_log(-3670.2412275820329, la.LFQ_PV_LOG)
     assert abs(float(np.log(p)) + 3670.2412275820329) < 1e-12
+
+
+def test_release_library_reads_ten_environment_variables():
+    """VERDICT r05 item 7: lfq_knobs() of the release library reads ten documented variables, none of which changes a result;
+    device selection (lfq_pick_device) reads three more.  LFQ_DEBUG_SKIP and the launch-shape / fallback selectors are strings
+    of the tuning build only (liblofreq_amd_tune.so, lfq_host.cpp under -DLFQ_TUNE)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def env_names(lib):
+        data = open(os.path.join(root, "lofreq_amd", lib), "rb").read()
+        return {m.decode() for m in re.findall(rb"(?<![A-Z0-9_])((?:LFQ|LOCAL)_[A-Z0-9_]{3,})\x00", data)}
+    knobs = {"LFQ_TIMING", "LFQ_SINGLE_STREAM", "LFQ_DEBUG_SYNC", "LFQ_PRIVATE_STREAM", "LFQ_SYNC_UPLOAD", "LFQ_BAQ_SCRATCH_MB",
+             "LFQ_HOST_THREADS", "LFQ_HOST_LOOP_THREADS", "LFQ_HOST_SPIN_US", "LOCAL_WORLD_SIZE"}
+    device = {"LFQ_DEVICE", "LFQ_SLOT_DIR", "LOCAL_RANK"}
+    rel = env_names("liblofreq_amd.so")
+    assert rel == knobs | device, sorted(rel ^ (knobs | device))
+    tune = env_names("liblofreq_amd_tune.so")
+    assert rel < tune and {"LFQ_DEBUG_SKIP", "LFQ_LIGHT_KERNEL", "LFQ_PILEUP_ATOMIC", "LFQ_SPLIT_POOL_CELLS"} <= tune

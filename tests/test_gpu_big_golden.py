@@ -1,0 +1,79 @@
+"""-m gpu: the device's reads -> VCF chain (resident read set: BAQ / IDAQ -> pileups -> SNV + indel tests -> filter -> VCF text)
+against what the REFERENCE's 2.1.4 binary wrote at real size (tests/golden/big_*.json, oracle/make_golden.py --big-only):
+C1 shape with `lofreq call` defaults, C1 shape with low base qualities, C4 shape with --call-indels.  The reads are regenerated
+by tests/golden_reads.py and checked against the SHA-256 of the SAM the binary was given.
+
+Byte-identical lines (;HQA= is HEAD-only and stripped).  The one documented 2.1.4-vs-HEAD delta (raw alt counts before the BQ
+filter, snpcaller.c:414-420 -> AF) can only show in big_c1_lowbq_nofilter: there the lines must agree outside AF=, agree fully
+where the oracle's two modes give the same raw count, and be the oracle's HEAD-mode lines everywhere."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_reads as gr
+import golden_util as gu
+import oracle_chain as oc
+from test_big_golden import big_fixtures
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+
+def device_chain(la, caller, R, kw, ndf, chrom="chr1"):
+    """-> (lines in position order with indels first in a column, conf after the run, n_indel_tests)"""
+    glen = R["glen"]
+    indels = bool(kw["flag"] & 8)
+    rs = la.ReadSet.from_arrays(caller, R)
+    rs.baq(extended=True, idaq=indels)
+    conf = la.VarcallConf(**kw)
+    lines, n_indel_tests = [], 0
+    if indels:
+        cols, col_pos = rs.pileup_indels(0, glen)
+        irecs, n_indel_tests = la.call_indels(caller, cols, conf)
+        ikeep = la.filter_indel_records(irecs, la.snvqual_thresh(conf.sig, conf.bonf_indel), apply_defaults=not ndf)
+        for r, k in zip(irecs, ikeep):
+            if k:
+                p0 = int(col_pos[int(r["col"])])
+                lines.append((p0, 0, la.format_indel_record(chrom, p0, cols, r, "PASS").rstrip("\n")))
+    dt = rs.pileup_snv(0, glen)
+    if indels:
+        la.skip_snv_columns(caller, cols.cons_indel)
+    recs, _, _ = caller.call_snvs(dt, conf)
+    keep = la.filter_records(recs, la.snvqual_thresh(conf.sig, conf.bonf_subst), apply_defaults=not ndf)
+    for r, k in zip(recs, keep):
+        if k:
+            p0 = int(dt.col_pos[int(r["col"])])
+            lines.append((p0, 1, la.format_vcf(np.array([r]), chrom, pos0=np.array([p0]), filter_str="PASS").rstrip("\n")))
+    rs.close()
+    return [l[2] for l in sorted(lines, key=lambda t: (t[0], t[1]))], conf, n_indel_tests
+
+
+def _no_af(line):
+    f = line.split("\t")
+    f[7] = ";".join(x for x in f[7].split(";") if not x.startswith("AF="))
+    return "\t".join(f)
+
+
+@pytest.mark.parametrize("path", big_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_device_chain_writes_the_binarys_vcf_at_real_size(caller, oracle, path):
+    import lofreq_amd as la
+    fx = json.load(open(path))
+    R = gr.make_from_fixture(fx)
+    assert gr.sam_sha256(R) == fx["sam_sha256"]
+    kw, ndf = gu.conf_kwargs(fx["call_args"])
+    lines, conf, n_indel_tests = device_chain(la, caller, R, kw, ndf)
+    assert conf.num_snv_tests == fx["num_tests"]["snv"] and n_indel_tests == fx["num_tests"]["indel"]
+    got = [gu.strip_hqa(l) for l in lines]
+    if fx["generator"]["params"]["min_q"] >= 6:
+        assert got == fx["vcf"]                                  # every line the binary wrote, byte for byte
+    else:
+        assert [_no_af(l) for l in got] == [_no_af(l) for l in fx["vcf"]]
+        # the device is HEAD: its lines are the oracle's in HEAD mode; the binary's are the oracle's in 2.1.4 mode (CPU test)
+        P = dict(R)
+        oracle.baq_idaq_reads(P, extended=True, idaq=False, procs=min(16, os.cpu_count() or 1))
+        head = oc.call_region(oracle, P, R["ref"], 0, R["glen"], kw, call_indels=False, no_default_filter=ndf)
+        assert lines == head["lines"]
+        n_delta = sum(1 for g, e in zip(got, fx["vcf"]) if g != e)
+        assert 0 < n_delta < len(got)                            # the delta is exercised, and is not everywhere
+    assert len(got) == fx["n_snv_lines"] + fx["n_indel_lines"]

@@ -2,7 +2,11 @@
 no pool space, unsorted reads, wide bands, shallow / deep launch shapes; the measured-and-rejected A/B paths of rounds
 1-3 were deleted in round 4, profiles/NOTES.md) get the parity tests of their area, each in a process of its own with the
 knob set -- so that nothing that can be selected at run time is untested.  The knobs are read once per process
-(lfq_knobs(), lfq_internal.h); DESIGN.md lists them."""
+(lfq_knobs(), lfq_internal.h); DESIGN.md lists them.
+
+Round 6: the release library reads ten variables, none of which changes a result; every other knob exists only in the tuning
+build lofreq_amd/liblofreq_amd_tune.so (the same objects, lfq_host.cpp compiled under -DLFQ_TUNE), which the child processes
+here load through LFQ_AMD_LIB.  test_release_library_ignores_the_tuning_knobs holds the release library to that."""
 import os
 import subprocess
 import sys
@@ -11,6 +15,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+TUNE_LIB = os.path.join(ROOT, "lofreq_amd", "liblofreq_amd_tune.so")
 
 DP = ["tests/test_gpu_parity.py", "-k", "default_conf_random or row_split or ragged_deep or underflow or fe_clamp or cells_below or "
       "golden_reference or dynamic_bonferroni or edge_cases"]
@@ -52,9 +58,40 @@ CASES = [
 
 @pytest.mark.parametrize("knob,sel", CASES, ids=[c[0] for c in CASES])
 def test_knob_selected_paths(knob, sel):
-    env = dict(os.environ, **dict(kv.split("=") for kv in knob.split()))
+    env = dict(os.environ, LFQ_AMD_LIB=TUNE_LIB, **dict(kv.split("=") for kv in knob.split()))
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"] + sel, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=800)
     tail = (p.stdout + p.stderr)[-1500:]
     assert p.returncode == 0, tail
     assert " passed" in p.stdout and "failed" not in p.stdout.splitlines()[-1], tail
+
+
+_SKIP_PROBE = r"""
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+import lofreq_amd as la
+import util
+caller = la.SnvCaller(0)
+host = util.random_batch(np.random.default_rng(5), 64, 800, 1500, planted={c: 0.05 for c in range(0, 64, 2)})
+recs, _, st = caller.call_snvs(util.to_pileup_batch(la, host), la.VarcallConf())
+print("RECS", len(recs))
+"""
+
+
+def test_release_library_ignores_the_tuning_knobs():
+    """LFQ_DEBUG_SKIP drops DP classes -- i.e. calls -- in the tuning build and must do nothing in the release library"""
+    out = {}
+    for name, lib in (("release", None), ("tune", TUNE_LIB)):
+        env = dict(os.environ, LFQ_DEBUG_SKIP="light,mid,big")
+        env.pop("LFQ_AMD_LIB", None)
+        if lib:
+            env["LFQ_AMD_LIB"] = lib
+        p = subprocess.run([sys.executable, "-c", _SKIP_PROBE], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        out[name] = int(p.stdout.split("RECS")[1])
+    env = dict(os.environ)
+    env.pop("LFQ_AMD_LIB", None)
+    p = subprocess.run([sys.executable, "-c", _SKIP_PROBE], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    plain = int(p.stdout.split("RECS")[1])
+    assert plain >= 20 and out["release"] == plain and out["tune"] < plain, (plain, out)

@@ -365,7 +365,8 @@ def test_host_loops_parallel_equals_serial(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for par_min in ("500", "1000000000"):
-        env = dict(os.environ, LFQ_HOST_PAR_MIN=par_min)
+        env = dict(os.environ, LFQ_HOST_PAR_MIN=par_min,          # a knob of the tuning build (lfq_knobs(), -DLFQ_TUNE)
+                   LFQ_AMD_LIB=os.path.join(root, "lofreq_amd", "liblofreq_amd_tune.so"))
         r = subprocess.run([sys.executable, "-c", _chain_digest_script()], cwd=root, env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
