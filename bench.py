@@ -93,7 +93,7 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the host-abi / chain measurements of config.secondary")
     ap.add_argument("--nt-bytes", action="store_true",
                     help="one byte per observation in the nt track instead of the packed layout (LFQ_TRACKS_NT_PACKED)")
-    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 6, 8],
                     help="pipelined loop: batches submitted and not yet waited for (1: step k + 1 is submitted when the kernels "
                          "of step k are done; 2-4: that many are queued on the device, --gate says what a queued batch's count "
                          "kernel waits for; 0 = default: the warm-up times the candidates and keeps the fastest)")
@@ -120,6 +120,8 @@ def parse_args():
                     help="N = 1: skip the whole-batch oracle run on all host cores (config.vcf_concordance then covers the "
                          "cpu_baseline sample only)")
     ap.add_argument("--full-check-procs", type=int, default=None, help="oracle processes of the whole-batch check")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="C3, N = 1: skip the short C2 / C4 / C5 child runs whose scalars (c2_*, c4_*, c5_*) the line's config carries")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -729,12 +731,62 @@ def genome_cpu_baseline(cfg, sample_len):
                 os.sched_setaffinity(0, old_aff)
             except OSError:
                 pass
-    return {"value": ncols / (t2 - t0), "unit": "columns/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+    return R, out["lines"], {"value": ncols / (t2 - t0), "unit": "columns/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "host_cpus": os.cpu_count(), "pinned_to_core": pinned,
             "sample": "the first %d bases of a bin of the same workload (%d reads, %d called columns): %.1f s on one pinned core; "
                       "BAQ%s %.1f s / pileup + calls %.1f s"
                       % (sample_len, int(R["n"]), ncols, t2 - t0, " + IDAQ" if cfg["call_indels"] else "", t1 - t0, t2 - t1),
             "reads_per_s": int(R["n"]) / (t2 - t0), "vcf_lines_of_the_sample": len(out["lines"])}
+
+
+def genome_sample_device_lines(cfg, caller, la, R, sample_len, chrom="chr1"):
+    """The device's reads -> VCF chain on the cpu_baseline's sample (the first `sample_len` bases of a bin as a region of its
+    own, or its targets in genome order with ONE running Bonferroni factor: `lofreq call -l bed`), so that the VCF lines the
+    oracle wrote while it was timed are compared with the device's: the concordance flag of a C4 / C5 line."""
+    gs = lambda l: l.split(";HQA=")[0]
+    flag = la.LFQ_USE_BAQ | la.LFQ_USE_MQ | (la.LFQ_USE_IDAQ if cfg["call_indels"] else 0)
+    from lofreq_amd import _lib
+    caller.set_dense_strand_counts(True)
+    caller.set_dense_counts(True)
+    _lib.load().lfq_set_indel_arrays_on_host(caller.h, 1)      # (the timed steps keep a bin's indel arrays in HBM)
+    rs = la.ReadSet.from_arrays(caller, R)
+    rs.baq(extended=True, idaq=cfg["call_indels"])
+    conf = la.VarcallConf(flag=flag)
+    lines = []
+    if cfg["targets"]:
+        tg = R["target"]
+        edges = np.flatnonzero(np.diff(np.concatenate([[0], tg, [0]])))
+        recs_all = []
+        for b, e in zip(edges[0::2], edges[1::2]):
+            dt = rs.pileup_snv(int(b), int(e))
+            recs, _, _ = caller.call_snvs(dt, conf)
+            recs_all += [(int(dt.col_pos[int(r["col"])]), r) for r in recs]
+        thr = la.snvqual_thresh(conf.sig, conf.bonf_subst)
+        for p0, r in recs_all:
+            if la.filter_records(np.array([r]), thr, apply_defaults=False)[0]:
+                lines.append((p0, 1, la.format_vcf(np.array([r]), chrom, pos0=np.array([p0]), filter_str="PASS").rstrip("\n")))
+    else:
+        if cfg["call_indels"]:
+            cols, col_pos = rs.pileup_indels(0, sample_len)
+            irecs, _ = la.call_indels(caller, cols, conf)
+            ikeep = la.filter_indel_records(irecs, la.snvqual_thresh(conf.sig, conf.bonf_indel), apply_defaults=True)
+            for r, k in zip(irecs, ikeep):
+                if k:
+                    p0 = int(col_pos[int(r["col"])])
+                    lines.append((p0, 0, la.format_indel_record(chrom, p0, cols, r, "PASS").rstrip("\n")))
+        dt = rs.pileup_snv(0, sample_len)
+        if cfg["call_indels"]:
+            la.skip_snv_columns(caller, cols.cons_indel)
+        recs, _, _ = caller.call_snvs(dt, conf)
+        keep = la.filter_records(recs, la.snvqual_thresh(conf.sig, conf.bonf_subst), apply_defaults=True)
+        for r, k in zip(recs, keep):
+            if k:
+                p0 = int(dt.col_pos[int(r["col"])])
+                lines.append((p0, 1, la.format_vcf(np.array([r]), chrom, pos0=np.array([p0]), filter_str="PASS").rstrip("\n")))
+    rs.close()
+    caller.set_dense_strand_counts(False)
+    caller.set_dense_counts(False)
+    return [gs(l[2]) for l in sorted(lines, key=lambda t: (t[0], t[1]))]
 
 
 def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev, comm_ranks):
@@ -1005,7 +1057,7 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_cols)
     dt, called = float(tmax.item()), int(tot_cols.item())
-    roof = base = None
+    roof = base = concord = None
     if rank == 0 and world == 1:
         try:
             roof = genome_baq_roofline(args, cfg_name, cfg, caller, la, R, dev)
@@ -1013,7 +1065,13 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
             roof = {"error": repr(e)}
         if not args.no_cpu_baseline:
             try:
-                base = genome_cpu_baseline(cfg, min(tile_len, args.cpu_sample_cols or (60000 if cfg["call_indels"] else 400000)))
+                sample_len = min(tile_len, args.cpu_sample_cols or (60000 if cfg["call_indels"] else 400000))
+                Rs, olines, base = genome_cpu_baseline(cfg, sample_len)
+                # the lines the oracle wrote while it was timed against the device chain on the same sample
+                gs = lambda l: l.split(";HQA=")[0]
+                dlines = genome_sample_device_lines(cfg, caller, la, Rs, sample_len)
+                concord = {"sample": "the cpu_baseline's sample as a run of its own", "oracle_lines": len(olines),
+                           "device_lines": len(dlines), "identical": [gs(l) for l in olines] == dlines}
             except Exception as e:
                 base = {"error": repr(e)}
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
@@ -1040,10 +1098,57 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
                    "snv_tests": int(conf.num_snv_tests), "indel_tests": int(conf.num_indel_tests),
                    "snv_records_before_filter": nrecs[0], "indel_records": nrecs[1],
                    "vcf_lines": text.count("\n"), "vcf_sha256": hashlib.sha256(text.encode()).hexdigest(),
+                   "vcf_concordance": concord, "vcf_identical": (concord or {}).get("identical"),
+                   "records_compared": (concord or {}).get("oracle_lines"),
                    "speedup_vs_cpu_1thread": (called * args.steps / dt / base["value"]) if (base and base.get("value")) else None,
                    "note": "1 step = the whole genome; the dominant kernel is lfq_baq_reg_kernel, FP64-issue-bound (DESIGN 6b): "
                            "`roofline` is one bin's BAQ call on a resident read set"},
     }, text
+
+
+def other_configs(budget_s=420.0):
+    """BASELINE.json configs[1], [3], [4] (C2, C4, C5) as short runs of this same script in child processes, after the C3
+    line's own work: their figures go into the C3 line's `config` as SCALARS (c2_*, c4_*, c5_*), so that one driver run
+    witnesses every config with its concordance flag.  A child that fails or runs out of time leaves `<cfg>_error`."""
+    runs = [("c2", ["--config", "C2", "--steps", "60", "--warmup", "5", "--no-secondary", "--no-pmc", "--no-other-configs"], 150),
+            ("c4", ["--config", "C4", "--steps", "2", "--warmup", "1", "--no-pmc", "--cpu-sample-cols", "30000"], 200),
+            ("c5", ["--config", "C5", "--steps", "2", "--warmup", "1", "--no-pmc", "--cpu-sample-cols", "150000"], 200)]
+    out = {}
+    t_start = time.perf_counter()
+    for name, argv, limit in runs:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 30:
+            out[name + "_error"] = "skipped: the run's time budget for the other configs is spent"
+            continue
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True,
+                               timeout=min(limit, left), cwd=ROOT)
+            ln = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:
+            out[name + "_error"] = repr(e)[:300]
+            continue
+        cfg, roof, base = ln.get("config") or {}, ln.get("roofline") or {}, ln.get("cpu_baseline") or {}
+        out[name + "_workload"] = cfg.get("workload")
+        out[name + "_columns_per_s"] = ln.get("value")
+        out[name + ("_ms_per_step" if name == "c2" else "_ms_per_genome")] = ln.get("ms_per_step")
+        out[name + "_steps"] = ln.get("steps")
+        out[name + "_vcf_identical"] = cfg.get("vcf_identical")
+        out[name + "_records_compared"] = cfg.get("records_compared")
+        out[name + "_roofline_frac"] = roof.get("frac")
+        out[name + "_roofline_kernel"] = roof.get("kernel")
+        out[name + "_cpu_baseline_columns_per_s"] = base.get("value")
+        out[name + "_child_seconds"] = round(time.perf_counter() - t0, 1)
+        if name == "c2":
+            out["c2_roofline_kernel_alone_frac"] = (roof.get("kernel_alone") or {}).get("frac")
+            out["c2_step_frac_of_hbm_peak"] = (roof.get("step") or {}).get("frac")
+            out["c2_columns_compared"] = cfg.get("columns_compared")
+        else:
+            out[name + "_ms_per_genome_with_upload"] = cfg.get("ms_per_step_with_upload")
+            out[name + "_vcf_sha256"] = cfg.get("vcf_sha256")
+            out[name + "_vcf_lines"] = cfg.get("vcf_lines")
+            out[name + "_baq_call_ms"] = roof.get("avg_launch_ms")
+    return out
 
 
 def _rccl_options(dist):
@@ -1240,7 +1345,8 @@ def main():
     # LFQ_BENCH_EXCHANGE=rccl: everything through the RCCL communicator (the A/B run).
     exchange = {"counts": None, "records": None}
     if (world > 1 or force_dist) and dist.get_backend() == "nccl":
-        exchange = {"counts": "rccl all-gather", "records": "rccl gather (asynchronous, collected one step later)"}
+        exchange = {"counts": "lfq_shard_exchange_counts over the RCCL communicator",
+                    "records": "lfq_shard_gather_start / _wait: ncclAllGather of fixed-capacity pieces on a stream of its own, collected one step later"}
         if os.environ.get("LFQ_BENCH_EXCHANGE", "host") != "rccl":
             try:
                 import socket
@@ -1249,13 +1355,15 @@ def main():
                 except OSError:
                     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: the loopback interface will do
                 shard.set_host_group(dist.new_group(backend="gloo"))
-                exchange["counts"] = "gloo all-gather (host integers)"
+                exchange["counts"] = ("lfq_shard_exchange_counts over the library's shared-memory host transport (one node; "
+                                      "a gloo group otherwise)")
             except Exception as e:                                         # no host transport: RCCL for the counts too
                 sys.stderr.write("bench.py: no gloo group for the test counts (%r); using RCCL\n" % (e,))
     elif world > 1:
-        exchange = {"counts": "gloo all-gather", "records": "gloo gather"}
+        exchange = {"counts": "lfq_shard_exchange_counts, host transport", "records": "lfq_shard_gather_start / _wait, host transport"}
 
     caller = la.SnvCaller(local_rank)
+    shard.set_context(caller)                     # the context the exchange's RCCL road stages through (lfq_shard_*)
     caller.set_dense_strand_counts(False)         # DP4 only for the columns that emit (what layer 2 does by itself)
     caller.set_dense_counts(False)                # ... and dense entries only for the tested columns (likewise)
 
@@ -1267,6 +1375,7 @@ def main():
                 open(args.vcf_out, "w").write(text)
             print(json.dumps(line))
         if world > 1:
+            shard.shutdown()
             dist.destroy_process_group()
         caller.close()
         return
@@ -1394,7 +1503,7 @@ def main():
     layer2 = world == 1 and not args.shard_path
     if pipelined:
         # one context per batch in flight: four in the automatic mode
-        NCTX = max(args.in_flight, 2) if args.in_flight else 4
+        NCTX = max(args.in_flight, 2) if args.in_flight else 8
         callers = [caller] + [la.SnvCaller(local_rank) for _ in range(NCTX - 1)]
         for c_ in callers[1:]:
             c_.set_dense_strand_counts(False)
@@ -1524,13 +1633,14 @@ def main():
             # where the DP tail is short latency-bound work next to a short count kernel: 1000x; the device-side gate at the
             # end of the previous batch takes the host's wake-up + launch latency out of every step): measured here,
             # outside the timed region
-            # (first in the list = the default: batches one after another on the device, four queued, so that a host thread
-            # that loses the CPU for a few milliseconds -- the boxes grant 16 of 256 cores and have neighbours -- does not
-            # leave the device idle; another mode has to beat the best one before it by 2 %.  "none": the count kernel of
+            # (first in the list = the default: batches one after another on the device, eight queued (four until round 6:
+            # on some boxes one `finish` in six takes 7-16 ms instead of 0.4 -- the boxes grant 16 of 256 cores and have
+            # neighbours -- which four queued batches, 11 ms of work, do not cover: profiles/r06_host_hiccups.md), so that
+            # a host thread that loses the CPU for a few milliseconds does not leave the device idle; another mode has to beat the best one before it by 2 %.  "none": the count kernel of
             # batch k + 1 beside the DP kernels of batch k -- pays at 10 000x now that the count kernel runs 1024-thread
             # workgroups and the queue is deep enough to keep count kernels back to back; "tail" pays at 1000x)
             modes = [(2, "end"), (2, "tail"), (2, "none")] if args.in_flight == 2 else \
-                    [(4, "end"), (4, "none"), (3, "tail"), (1, "tail")]
+                    [(8, "end"), (8, "none"), (4, "none"), (3, "tail"), (1, "tail")]
             trial = {}
             for m in modes * 3:                     # (three rounds, the fastest of each mode: a box's first seconds are noisy)
                 set_mode(*m)
@@ -1767,8 +1877,12 @@ def main():
             except BaseException as e:
                 sec["chain_2_workers"] = {"error": repr(e)}
             line["config"]["secondary"] = sec
+        if world == 1 and args.config == "C3" and not (args.depth or args.cols or args.no_other_configs or args.no_secondary):
+            # the other BASELINE configs on the same record: scalars only
+            line["config"].update(other_configs())
         print(json.dumps(line))
     if world > 1 or force_dist:
+        shard.shutdown()
         dist.destroy_process_group()
     if pipelined:
         for c_ in callers[1:]:

@@ -39,7 +39,7 @@ extern "C" {
  * bindings in integration/ and the Python loader do. */
 /* 4: lfq_set_batch_gate, lfq_last_baq_times; lfq_call_snvs_collect refuses h_counts for a batch whose dense entries are sparse. */
 /* 5: lfq_set_private_stream. */
-#define LFQ_ABI_VERSION 5
+#define LFQ_ABI_VERSION 6
 
 typedef enum lfq_status {
     LFQ_OK = 0,
@@ -703,12 +703,22 @@ int lfq_last_dp_work(lfq_ctx *ctx, lfq_dp_work *w);
  *     lfq_shard_advance_conf      conf->bonf_subst / num_snv_tests as after the single-process loop over all shards
  * `comm` is an ncclComm_t of RCCL (one rank per process, created by the caller: ncclCommInitRank) or NULL when
  * world == 1.  RCCL is looked up at run time (dlopen of librccl): the library has no link-time dependency on it.
- * lofreq_amd/shard.py is the same exchange on torch.distributed; tests/test_shard_c.py holds the two against each other. */
+ * lofreq_amd/shard.py calls these same functions (round 6: ONE implementation of the exchange; torch.distributed only
+ * carries the ncclUniqueId to the ranks and, as a gloo group, serves as the host transport for the counts). */
 /* A launcher that has no RCCL communicator (MPI, a shared directory, a test double) supplies the one collective the
  * exchange needs: all-gather of `bytes` bytes per rank, host buffers, recv = world * bytes in rank order; 0 = ok.
  * While set (process-wide; NULL restores RCCL) `comm` is ignored by the lfq_shard_* calls. */
 typedef int (*lfq_host_allgather_fn)(void *user, int world, int rank, const void *send, void *recv, size_t bytes);
 int lfq_shard_set_host_allgather(lfq_host_allgather_fn fn, void *user);
+/* The library's own host transport for the ranks of ONE node: an all-gather through a POSIX shared-memory segment (a slot
+ * per rank, double-buffered, sequence numbers with release / acquire order; microseconds where a loopback TCP ring takes
+ * milliseconds at eight ranks).  lfq_shard_shm_open maps /dev/shm<name> (created by whoever comes first; `name` = "/..." and
+ * NEW PER RUN -- a nonce every rank of the run knows) and installs it as the host all-gather; once every rank has opened
+ * it (any barrier, e.g. a first all-gather through it), one rank calls lfq_shard_shm_unlink so that nothing is left behind
+ * if the run dies; lfq_shard_shm_close unmaps and uninstalls. */
+int lfq_shard_shm_open(const char *name, int world, int rank);
+int lfq_shard_shm_unlink(void);
+int lfq_shard_shm_close(void);
 /* the collective itself: `bytes` bytes of every rank, in rank order (all = world * bytes) */
 int lfq_shard_allgather(lfq_ctx *ctx, void *comm, int world, int rank, const void *mine, int64_t bytes, void *all);
 int lfq_shard_exchange_counts(lfq_ctx *ctx, void *comm, int world, int rank, const int64_t *local, int n,
@@ -717,6 +727,20 @@ int lfq_shard_rebase_bonferroni(lfq_col_pvals *pvals, int64_t n, int64_t prefix_
 int lfq_shard_gather_records(lfq_ctx *ctx, void *comm, int world, int rank, const lfq_snv_record *recs, int64_t n,
                              int64_t col_offset, lfq_snv_record *out, int64_t capacity, int64_t *n_out);
 int lfq_shard_advance_conf(lfq_conf *conf, int64_t total_tested);
+/* The gather in two halves, for a caller that pipelines steps (bench.py's sharded step, lofreq_amd/shard.py): every rank hands
+ * over ONE piece of `piece_bytes` bytes (the same size on every rank; what is inside -- a record count in front of a fixed
+ * number of record slots -- is the caller's business).  _start returns at once: with a communicator the piece goes up from
+ * a pinned copy, the collective (ncclAllGather) and -- where want_all is set -- the copy of all pieces back to pinned memory
+ * are queued on a high-priority stream of the handle's own, and nothing waits for the device; without one (a host transport
+ * set by lfq_shard_set_host_allgather, or world == 1) the blocking all-gather runs inside _start.  _wait blocks until this
+ * rank's side is done and copies the world * piece_bytes bytes in rank order into `all` (NULL, or a rank that did not set
+ * want_all: nothing is copied).  Unlike the blocking calls above, _start uses the communicator when one is given even
+ * while a host transport is set: the test counts are host integers and take the host road, the records the device's.
+ * Every rank must call _start and _wait for every gather, in the same order. */
+typedef struct lfq_shard_gather lfq_shard_gather;
+int lfq_shard_gather_start(lfq_ctx *ctx, void *comm, int world, int rank, const void *piece, int64_t piece_bytes,
+                           int want_all, lfq_shard_gather **handle_out);
+int lfq_shard_gather_wait(lfq_shard_gather *handle, void *all_or_null, int64_t all_bytes);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,7 @@ struct lfq_par {
     long seq;                       /* collectives done so far (files transport) */
     double timeout_s;
     uint64_t job;                   /* this run's nonce: every rendezvous file starts with it (see job_nonce) */
+    int made_job_file;              /* 1: this run's rank 0 wrote <rdv>.job (the handshake of job_nonce) and removes it at exit */
 };
 
 /* Every file that passes through the rendezvous path starts with this header.  A file another run left behind under
@@ -148,61 +149,126 @@ static int env_int(const char *name, int dflt)
     return (end == e || *end) ? dflt : (int)v;
 }
 
+/* 64 bits nobody else has: /dev/urandom, or pid + clocks where that cannot be read */
+static uint64_t fresh_token(void)
+{
+    uint64_t t = 0;
+    struct timespec ts;
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (f) {
+        if (fread(&t, sizeof(t), 1, f) != 1) {
+            t = 0;
+        }
+        fclose(f);
+    }
+    clock_gettime(CLOCK_REALTIME, &ts);
+    t ^= ((uint64_t)getpid() << 40) ^ ((uint64_t)ts.tv_sec << 20) ^ (uint64_t)ts.tv_nsec;
+    return t ? t : 1;
+}
+
 /* The run's nonce.  LFQ_PAR_JOB, when the launcher exports one with the other LFQ_PAR_* variables (any string that is
- * new per run: its pid and start time will do), is the strong form: nothing of another run can be mistaken for this
- * one's.  Without it rank 0 draws a nonce, removes what an earlier run left of <rdv>.job / <rdv>.id and publishes the
- * nonce in <rdv>.job; the other ranks take the <rdv>.job they find unless it is older than the time any rank 0 waits
- * for them (LFQ_PAR_TIMEOUT_S) -- a crashed run's files younger than that can still be picked up by a rank that
- * starts before its rank 0 does: export LFQ_PAR_JOB where that matters.  In between: what the usual launchers already give
- * every rank of ONE launch and no other -- SLURM's job and step ids, torchrun's run id together with its rendezvous endpoint
- * -- is taken as the job string when LFQ_PAR_JOB is not set, so that a launch under them never looks at <rdv>.job at all. */
+ * new per run: its pid and start time will do), is taken as it is.  Without it the ranks agree on a nonce by a handshake
+ * that no file of ANOTHER run under the same LFQ_PAR_RENDEZVOUS can take part in -- a crashed earlier attempt, a torchrun
+ * restart with the same run id and port, a second `lofreq call` inside the same srun step (what the launcher exports is
+ * the same for all of those, so it is not used):
+ *   rank r > 0   draws a token T_r, writes <rdv>.hello.<r> = T_r, waits for a <rdv>.job whose r-th token IS T_r (a stale
+ *                .job cannot hold it), takes its nonce and answers <rdv>.ack.<r> = T_r under that nonce;
+ *   rank 0       draws the nonce, removes what it finds of <rdv>.id / <rdv>.job, publishes <rdv>.job = {nonce, the tokens
+ *                of the hello files it currently sees} again whenever a hello file changes (a stale hello is overwritten
+ *                by its rank's fresh one), and is done when every rank's ack carries the nonce and that rank's token.
+ * Every later file (<rdv>.id, <rdv>.ag<k>.<r>) starts with the nonce; files with another one are waited past. */
 static int job_nonce(lfq_par *p)
 {
     const char *e = getenv("LFQ_PAR_JOB");
-    char path[1024], from_launcher[512];
-    snprintf(path, sizeof(path), "%s.job", p->rdv);
-    if (!(e && *e)) {
-        const char *sj = getenv("SLURM_JOB_ID"), *ss = getenv("SLURM_STEP_ID");
-        const char *tr = getenv("TORCHELASTIC_RUN_ID"), *ma = getenv("MASTER_ADDR"), *mp = getenv("MASTER_PORT");
-        if (sj && *sj && ss && *ss) {
-            snprintf(from_launcher, sizeof(from_launcher), "slurm:%s.%s", sj, ss);
-            e = from_launcher;
-        } else if (tr && *tr && strcmp(tr, "none") != 0 && mp && *mp) {     /* ("none": torchrun's default id, the same every run) */
-            snprintf(from_launcher, sizeof(from_launcher), "torchrun:%s@%s:%s", tr, ma ? ma : "", mp);
-            e = from_launcher;
-        }
-    }
+    char path[1024];
+    const double t0 = now_s();
+    const size_t job_bytes = sizeof(uint64_t) * (size_t)(1 + p->world);
+    uint64_t *msg;
+    int r, rc = -1;
     if (e && *e) {
         uint64_t h = 1469598103934665603ULL;                /* FNV-1a of the string */
         for (; *e; e++) {
             h = (h ^ (uint64_t)(unsigned char)*e) * 1099511628211ULL;
         }
-        p->job = h;
+        p->job = h ? h : 1;
         return 0;
     }
-    if (p->rank == 0) {
-        struct timespec ts;
-        char old[1024];
-        clock_gettime(CLOCK_REALTIME, &ts);
-        p->job = ((uint64_t)getpid() << 40) ^ ((uint64_t)ts.tv_sec << 20) ^ (uint64_t)ts.tv_nsec;
-        snprintf(old, sizeof(old), "%s.id", p->rdv);
-        unlink(old);
-        unlink(path);
-        return put_file(0, path, &p->job, sizeof(p->job));
+    msg = (uint64_t *)calloc((size_t)(1 + p->world) * 2, sizeof(uint64_t));      /* {nonce, tokens[world]} now and last published */
+    if (!msg) {
+        return -1;
+    }
+    if (p->rank != 0) {
+        const uint64_t mine = fresh_token();
+        snprintf(path, sizeof(path), "%s.hello.%d", p->rdv, p->rank);
+        if (put_file(0, path, &mine, sizeof(mine)) == 0) {
+            for (;;) {
+                snprintf(path, sizeof(path), "%s.job", p->rdv);
+                if (get_file(0, path, msg, job_bytes, 0.0) == 0 && msg[1 + p->rank] == mine && msg[0] != 0) {
+                    p->job = msg[0];
+                    snprintf(path, sizeof(path), "%s.ack.%d", p->rdv, p->rank);
+                    rc = put_file(p->job, path, &mine, sizeof(mine));
+                    break;
+                }
+                if (now_s() - t0 > p->timeout_s) {
+                    break;
+                }
+                nap();
+            }
+        }
     } else {
-        const double t0 = now_s();
+        uint64_t *pub = msg + 1 + p->world;
+        int published = 0;
+        msg[0] = fresh_token();
+        snprintf(path, sizeof(path), "%s.id", p->rdv);
+        unlink(path);
+        snprintf(path, sizeof(path), "%s.job", p->rdv);
+        unlink(path);
         for (;;) {
-            struct stat st;
-            if (stat(path, &st) == 0 && (double)(time(NULL) - st.st_mtime) <= p->timeout_s
-                && get_file(0, path, &p->job, sizeof(p->job), 0.0) == 0) {
-                return 0;
+            int have = 1, acked = 1;
+            for (r = 1; r < p->world; r++) {
+                uint64_t t = 0;
+                snprintf(path, sizeof(path), "%s.hello.%d", p->rdv, r);
+                if (get_file(0, path, &t, sizeof(t), 0.0) == 0 && t != 0) {
+                    msg[1 + r] = t;
+                } else if (msg[1 + r] == 0) {
+                    have = 0;
+                }
+            }
+            if (have && (!published || memcmp(msg, pub, job_bytes) != 0)) {
+                snprintf(path, sizeof(path), "%s.job", p->rdv);
+                if (put_file(0, path, msg, job_bytes) != 0) {
+                    break;
+                }
+                memcpy(pub, msg, job_bytes);
+                published = 1;
+            }
+            for (r = 1; r < p->world && published; r++) {
+                uint64_t t = 0;
+                snprintf(path, sizeof(path), "%s.ack.%d", p->rdv, r);
+                if (!(get_file(msg[0], path, &t, sizeof(t), 0.0) == 0 && t == msg[1 + r])) {
+                    acked = 0;
+                }
+            }
+            if (published && acked) {
+                p->job = msg[0];
+                p->made_job_file = 1;
+                for (r = 1; r < p->world; r++) {           /* the handshake's files have done their work */
+                    snprintf(path, sizeof(path), "%s.hello.%d", p->rdv, r);
+                    unlink(path);
+                    snprintf(path, sizeof(path), "%s.ack.%d", p->rdv, r);
+                    unlink(path);
+                }
+                rc = 0;
+                break;
             }
             if (now_s() - t0 > p->timeout_s) {
-                return -1;
+                break;
             }
             nap();
         }
     }
+    free(msg);
+    return rc;
 }
 
 /* what a run that died left of THIS rank under the rendezvous path (a finished one leaves its closing barrier's file) */
@@ -358,7 +424,7 @@ void lfq_par_destroy(lfq_par *p)
             snprintf(path, sizeof(path), "%s.id", p->rdv);
             unlink(path);
         }
-        if (!getenv("LFQ_PAR_JOB") && p->job) {
+        if (p->made_job_file) {
             snprintf(path, sizeof(path), "%s.job", p->rdv);
             unlink(path);
         }

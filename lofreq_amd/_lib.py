@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFQ_AMD_LIB") or os.path.join(_HERE, "liblofreq_amd.so")   # LFQ_AMD_LIB: another build of the same library (A/B runs)
 
 LFQ_OK = 0
-LFQ_ABI_VERSION = 5      # include/lofreq_amd.h; load() refuses a library built from another header
+LFQ_ABI_VERSION = 6      # include/lofreq_amd.h; load() refuses a library built from another header
 LFQ_ERR_CAPACITY = -4
 LFQ_USE_BAQ, LFQ_USE_MQ, LFQ_USE_SQ, LFQ_USE_IDAQ = 1, 2, 4, 8
 LFQ_PV_NONE, LFQ_PV_LOG, LFQ_PV_LOG_FECLAMP, LFQ_PV_UNDERFLOW = 0, 1, 2, 3
@@ -129,7 +129,7 @@ EXPORTS = [
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
     "lfq_uniq_detlim_batch", "lfq_uniq_binom_batch", "lfq_uniq_mtc", "lfq_binom_cdf",
     "lfq_shard_exchange_counts", "lfq_shard_rebase_bonferroni", "lfq_shard_gather_records", "lfq_shard_advance_conf",
-    "lfq_set_pileup_nt_packed", "lfq_set_baq_hmm_params", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
+    "lfq_set_pileup_nt_packed", "lfq_set_baq_hmm_params", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_shard_gather_start", "lfq_shard_gather_wait", "lfq_shard_shm_open", "lfq_shard_shm_unlink", "lfq_shard_shm_close", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
     "lfq_readset_create", "lfq_readset_destroy", "lfq_readset_baq", "lfq_readset_source_qual",
     "lfq_readset_pileup_snv", "lfq_readset_pileup_indels", "lfq_readset_fetch_tags",
     "lfq_filter_conf_init", "lfq_filter_conf_defaults", "lfq_filter_vars", "lfq_filter_id", "lfq_filter_string",
@@ -151,6 +151,10 @@ FILTER_VAR_DTYPE = np.dtype([("is_indel", "i4"), ("qual", "i4"), ("dp", "i4"), (
 assert FILTER_VAR_DTYPE.itemsize == 32
 
 _lib = None
+
+
+# lfq_host_allgather_fn (include/lofreq_amd.h): int (*)(void *user, int world, int rank, const void *send, void *recv, size_t bytes)
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 def load():
@@ -239,6 +243,10 @@ def load():
     L.lfq_shard_gather_records.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int64, vp, C.c_int64,
                                            C.POINTER(C.c_int64)]
     L.lfq_shard_advance_conf.argtypes = [C.POINTER(Conf), C.c_int64]
+    L.lfq_shard_gather_start.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+    L.lfq_shard_gather_wait.argtypes = [vp, vp, C.c_int64]
+    L.lfq_shard_set_host_allgather.argtypes = [HOST_ALLGATHER_FN, vp]
+    L.lfq_shard_shm_open.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.lfq_binom_cdf.restype = C.c_double
     L.lfq_binom_cdf.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
     L.lfq_readset_create.argtypes = [vp, C.POINTER(PileupReads), C.POINTER(PileupIndelTags), C.POINTER(vp)]

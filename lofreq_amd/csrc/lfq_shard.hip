@@ -4,6 +4,9 @@
  */
 #include "lfq_ctx.h"
 
+#include <sys/mman.h>
+#include <time.h>
+
 extern "C" {
 
 int lfq_device_count(void)
@@ -112,10 +115,10 @@ void *g_host_allgather_user = nullptr;
 int shard_allgather_bytes(lfq_ctx *c, void *comm, int world, int rank, const void *mine, size_t bytes, void *all)
 {
     if (world > 1 && g_host_allgather) {
-        /* a launcher-supplied host transport (MPI, files, a test double) instead of RCCL */
+        /* a launcher-supplied host transport (MPI, files, gloo, a test double) instead of RCCL */
         return g_host_allgather(g_host_allgather_user, world, rank, mine, all, bytes) == 0 ? LFQ_OK : LFQ_ERR_HIP;
     }
-    if (world == 1 || !comm) {
+    if (!comm) {
         if (world != 1) {
             return LFQ_ERR_INVALID;
         }
@@ -157,10 +160,295 @@ int lfq_shard_allgather(lfq_ctx *c, void *comm, int world, int rank, const void 
     return shard_allgather_bytes(c, comm, world, rank, mine, (size_t)bytes, all);
 }
 
+/* ---- the record gather in two halves: started (nothing waits for the device), collected a step later ---------------------
+ * A handle owns its staging buffers (device + pinned host), a high-priority stream of its own and an event; handles go back to
+ * a process-wide free list, so that a pipelined caller allocates nothing per step (hipMalloc / hipHostMalloc synchronise). */
+struct lfq_shard_gather {
+    int device = -1;
+    int world = 0;
+    size_t piece = 0, padded = 0;
+    size_t cap_dev = 0, cap_host = 0;           /* bytes: d_buf holds (world + 1) * padded, h_buf the same */
+    uint8_t *d_buf = nullptr, *h_buf = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    bool on_device = false, want_all = false;
+    std::vector<uint8_t> host_all;              /* host transport / one process: the gathered pieces */
+};
+
+namespace {
+std::mutex g_gather_m;
+std::vector<lfq_shard_gather *> g_gather_free;
+
+lfq_shard_gather *gather_acquire(int device)
+{
+    std::lock_guard<std::mutex> lk(g_gather_m);
+    for (size_t i = 0; i < g_gather_free.size(); i++) {
+        if (g_gather_free[i]->device == device) {
+            lfq_shard_gather *g = g_gather_free[i];
+            g_gather_free.erase(g_gather_free.begin() + (long)i);
+            return g;
+        }
+    }
+    lfq_shard_gather *g = new (std::nothrow) lfq_shard_gather();
+    if (g) {
+        g->device = device;
+    }
+    return g;
+}
+
+void gather_release(lfq_shard_gather *g)
+{
+    std::lock_guard<std::mutex> lk(g_gather_m);
+    g_gather_free.push_back(g);
+}
+}  // namespace
+
+int lfq_shard_gather_start(lfq_ctx *c, void *comm, int world, int rank, const void *piece, int64_t piece_bytes, int want_all,
+                           lfq_shard_gather **out)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world || piece_bytes <= 0 || !piece) {
+        return LFQ_ERR_INVALID;
+    }
+    *out = nullptr;
+    const bool rccl = comm != nullptr;
+    if (rccl && (!c || !lfq_rccl_allgather())) {
+        return LFQ_ERR_UNSUPPORTED;
+    }
+    if (!rccl && world > 1 && !g_host_allgather) {
+        return LFQ_ERR_INVALID;
+    }
+    lfq_shard_gather *g = gather_acquire(rccl ? c->device : -1);
+    if (!g) {
+        return LFQ_ERR_NOMEM;
+    }
+    g->world = world;
+    g->piece = (size_t)piece_bytes;
+    g->want_all = want_all != 0;
+    g->on_device = rccl;
+    if (!rccl) {
+        /* a host transport (or one process): the collective is the caller's blocking all-gather, done here */
+        g->host_all.resize((size_t)world * g->piece);
+        int rc = LFQ_OK;
+        if (world == 1) {
+            memcpy(g->host_all.data(), piece, g->piece);
+        } else {
+            rc = g_host_allgather(g_host_allgather_user, world, rank, piece, g->host_all.data(), g->piece) == 0 ? LFQ_OK : LFQ_ERR_HIP;
+        }
+        if (rc != LFQ_OK) {
+            gather_release(g);
+            return rc;
+        }
+        *out = g;
+        return LFQ_OK;
+    }
+    auto fail = [&](int rc) {
+        gather_release(g);
+        return rc;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) {
+        return fail(LFQ_ERR_HIP);
+    }
+    g->padded = (g->piece + 255) / 256 * 256;
+    const size_t need = g->padded * (size_t)(world + 1);
+    if (!g->stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           /* hi = the numerically lowest = the highest priority */
+        if (hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess) {
+            return fail(LFQ_ERR_HIP);
+        }
+    }
+    if (g->cap_dev < need) {
+        if (g->d_buf) {
+            (void)hipFree(g->d_buf);
+            g->d_buf = nullptr;
+        }
+        if (hipMalloc((void **)&g->d_buf, need) != hipSuccess) {
+            g->cap_dev = 0;
+            return fail(LFQ_ERR_NOMEM);
+        }
+        g->cap_dev = need;
+    }
+    if (g->cap_host < need) {
+        if (g->h_buf) {
+            (void)hipHostFree(g->h_buf);
+            g->h_buf = nullptr;
+        }
+        if (hipHostMalloc((void **)&g->h_buf, need, hipHostMallocDefault) != hipSuccess) {
+            g->cap_host = 0;
+            return fail(LFQ_ERR_NOMEM);
+        }
+        g->cap_host = need;
+    }
+    uint8_t *h_send = g->h_buf, *h_recv = g->h_buf + g->padded;
+    uint8_t *d_send = g->d_buf, *d_recv = g->d_buf + g->padded;
+    memcpy(h_send, piece, g->piece);
+    if (hipMemcpyAsync(d_send, h_send, g->padded, hipMemcpyHostToDevice, g->stream) != hipSuccess) {
+        return fail(LFQ_ERR_HIP);
+    }
+    if (lfq_rccl_allgather()(d_send, d_recv, g->padded, /* ncclUint8 */ 1, comm, g->stream) != 0) {
+        return fail(LFQ_ERR_HIP);
+    }
+    if (g->want_all &&
+        hipMemcpyAsync(h_recv, d_recv, g->padded * (size_t)world, hipMemcpyDeviceToHost, g->stream) != hipSuccess) {
+        return fail(LFQ_ERR_HIP);
+    }
+    if (hipEventRecord(g->ev, g->stream) != hipSuccess) {
+        return fail(LFQ_ERR_HIP);
+    }
+    *out = g;
+    return LFQ_OK;
+}
+
+int lfq_shard_gather_wait(lfq_shard_gather *g, void *all, int64_t all_bytes)
+{
+    if (!g) {
+        return LFQ_ERR_INVALID;
+    }
+    int rc = LFQ_OK;
+    const size_t total = (size_t)g->world * g->piece;
+    if (all && (all_bytes < 0 || (size_t)all_bytes < total)) {
+        rc = LFQ_ERR_CAPACITY;                  /* (the collective is still waited for: the buffers go back to the pool) */
+    }
+    if (g->on_device) {
+        if (hipEventSynchronize(g->ev) != hipSuccess) {
+            rc = LFQ_ERR_HIP;
+        } else if (all && rc == LFQ_OK) {
+            if (!g->want_all) {
+                rc = LFQ_ERR_INVALID;
+            } else {
+                const uint8_t *h_recv = g->h_buf + g->padded;
+                for (int r = 0; r < g->world; r++) {
+                    memcpy((uint8_t *)all + (size_t)r * g->piece, h_recv + (size_t)r * g->padded, g->piece);
+                }
+            }
+        }
+    } else if (all && rc == LFQ_OK) {
+        memcpy(all, g->host_all.data(), total);
+    }
+    gather_release(g);
+    return rc;
+}
+
 int lfq_shard_set_host_allgather(lfq_host_allgather_fn fn, void *user)
 {
     g_host_allgather = fn;
     g_host_allgather_user = user;
+    return LFQ_OK;
+}
+
+/* ---- a host transport of the library's own for the ranks of ONE node: all-gather through POSIX shared memory ---------------
+ * The per-step test counts are a few host integers per rank; over a loopback TCP ring (gloo) eight ranks take ~2 ms for
+ * them, a collective staged through the GPU waits for wave slots behind the count kernels.  Here a rank writes its piece into
+ * its slot of a shared segment, publishes the collective's number with release order and reads the others' slots once their
+ * numbers have arrived: microseconds.  Two buffers per slot, taken in turn: a rank can only be one collective ahead of the
+ * slowest one (it needs everybody's number k + 1 to finish collective k + 1), so buffer k & 1 is never rewritten (collective
+ * k + 2) before everybody has read collective k.  Pieces larger than a buffer go in several rounds. */
+namespace {
+constexpr size_t LFQ_SHM_BUF = 32768;
+struct LfqShmSlot {
+    std::atomic<uint64_t> seq;
+    uint8_t pad[56];
+    uint8_t buf[2][LFQ_SHM_BUF];
+};
+struct LfqShm {
+    LfqShmSlot *slots = nullptr;
+    size_t bytes = 0;
+    int world = 0, rank = 0;
+    uint64_t k = 0;                 /* collectives (rounds) done */
+    double timeout_s = 600.;
+    char name[256] = {0};
+};
+LfqShm g_shm;
+
+int shm_allgather(void *user, int world, int rank, const void *send, void *recv, size_t bytes)
+{
+    LfqShm *m = (LfqShm *)user;
+    if (!m->slots || world != m->world || rank != m->rank) {
+        return -1;
+    }
+    for (size_t off = 0; off < bytes; off += LFQ_SHM_BUF) {
+        const size_t n = std::min(LFQ_SHM_BUF, bytes - off);
+        const uint64_t k = m->k++;
+        LfqShmSlot &mine = m->slots[rank];
+        memcpy(mine.buf[k & 1], (const uint8_t *)send + off, n);
+        mine.seq.store(k + 1, std::memory_order_release);
+        const double t0 = lfq_now_ms();
+        for (int r = 0; r < world; r++) {
+            LfqShmSlot &s = m->slots[r];
+            long spins = 0;
+            while (s.seq.load(std::memory_order_acquire) < k + 1) {
+                LFQ_CPU_PAUSE();
+                if ((++spins & 1023) == 0) {
+                    const double waited = lfq_now_ms() - t0;
+                    if (waited > m->timeout_s * 1e3) {
+                        return -1;
+                    }
+                    if (waited > 0.2) {             /* a rank that is late by more than a moment: stop burning the core */
+                        struct timespec ts = {0, 50000};
+                        nanosleep(&ts, nullptr);
+                    }
+                }
+            }
+            memcpy((uint8_t *)recv + (size_t)r * bytes + off, s.buf[k & 1], n);
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+int lfq_shard_shm_open(const char *name, int world, int rank)
+{
+    if (!name || !*name || strlen(name) >= sizeof(g_shm.name) || world < 1 || rank < 0 || rank >= world) {
+        return LFQ_ERR_INVALID;
+    }
+    (void)lfq_shard_shm_close();
+    const size_t bytes = sizeof(LfqShmSlot) * (size_t)world;
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) {
+        return LFQ_ERR_UNSUPPORTED;
+    }
+    if (ftruncate(fd, (off_t)bytes) != 0) {            /* (a fresh segment reads as zeros: every number starts at 0) */
+        close(fd);
+        return LFQ_ERR_NOMEM;
+    }
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        return LFQ_ERR_NOMEM;
+    }
+    g_shm.slots = (LfqShmSlot *)p;
+    g_shm.bytes = bytes;
+    g_shm.world = world;
+    g_shm.rank = rank;
+    g_shm.k = 0;
+    snprintf(g_shm.name, sizeof(g_shm.name), "%s", name);
+    g_host_allgather = shm_allgather;
+    g_host_allgather_user = &g_shm;
+    return LFQ_OK;
+}
+
+int lfq_shard_shm_unlink(void)
+{
+    if (!g_shm.slots || !g_shm.name[0]) {
+        return LFQ_ERR_INVALID;
+    }
+    shm_unlink(g_shm.name);                             /* the mappings stay until every rank has closed */
+    return LFQ_OK;
+}
+
+int lfq_shard_shm_close(void)
+{
+    if (!g_shm.slots) {
+        return LFQ_OK;
+    }
+    if (g_host_allgather == shm_allgather) {
+        g_host_allgather = nullptr;
+        g_host_allgather_user = nullptr;
+    }
+    munmap(g_shm.slots, g_shm.bytes);
+    g_shm.slots = nullptr;
+    g_shm.name[0] = 0;
     return LFQ_OK;
 }
 

@@ -8,8 +8,9 @@ contiguous genomic ranges, one per worker, no data-path exchange; what *is* exch
       local running Bonferroni factor into the single-process one, and
   (2) the reported variants, gathered to rank 0 in shard order (the reference runs
       ``bcftools concat``, :164-185).
-Over RCCL/xGMI on GPUs (backend "nccl"), gloo in the CPU tests.  Payloads are tens of bytes to a
-few KB: latency-bound, so one collective of each kind and nothing else.
+Over RCCL/xGMI on GPUs, gloo in the CPU tests -- both through the C ABI's lfq_shard_* functions (round 6: one implementation
+of the exchange, shared with the C workers of integration/lofreq_amd_parallel.c; see "the transport" below).  Payloads are
+tens of bytes to a few KB: latency-bound, so one collective of each kind and nothing else.
 
 What a collective costs a rank whose GPU is running count kernels back to back (measured with a one-rank
 communicator, profiles/NOTES.md round 5): every device-side piece of it -- the staging copies of a
@@ -129,37 +130,172 @@ def plan_regions(regions, cost_fn, world_size, bins_per_worker=BIN_PER_THREAD, b
 # tests: run the collectives even in a world of one rank (the RCCL calls of the N > 1 path on a one-GPU box)
 _FORCE_COLLECTIVES = __import__("os").environ.get("LFQ_SHARD_FORCE_COLLECTIVES") == "1"
 
-
-# A host-side process group (gloo) for the counts, which are host integers on every rank: see the module docstring.
-_HOST_GROUP = None
+# ---- the transport: ONE implementation of the exchange, the C ABI's (lfq_shard_* in lofreq_amd/csrc/lfq_shard.hip) ------------
+# What a C worker (integration/lofreq_amd_parallel.c) and this module run is the same code: lfq_shard_exchange_counts for the
+# test counts, lfq_shard_gather_start / _wait for the records.  torch.distributed only (i) carries rank 0's ncclUniqueId to the
+# other ranks, from which every rank makes the RCCL communicator the ABI takes (ncclCommInitRank through ctypes, the same
+# librccl the process already holds), and (ii) as a gloo group serves as the host transport (lfq_shard_set_host_allgather).
+_HOST_GROUP = None      # a gloo group for the counts (host integers on both ends): see the module docstring
+_T = {"dist": None, "cb": None, "cb_group": None, "comm": None, "rccl": None, "ctx": None, "own_ctx": None}
 
 
 def set_host_group(group):
     """`group` = a torch.distributed group whose backend takes CPU tensors (gloo), spanning the same ranks as the
-    default group, or None: exchange_counts then goes through it instead of staging 8 bytes per rank through the GPU."""
+    default group, or None: the test counts then travel through it (lfq_shard_set_host_allgather) instead of being staged
+    through the GPU."""
     global _HOST_GROUP
     _HOST_GROUP = group
+    _T["cb_group"] = None           # (re-registered at the next exchange)
+    if group is None:
+        if _T["cb"] is not None:
+            _lib.load().lfq_shard_set_host_allgather(_lib.HOST_ALLGATHER_FN(), None)
+            _T["cb"] = None
+        if _T.get("shm"):
+            _lib.load().lfq_shard_shm_close()
+            _T["shm"] = False
+
+
+def set_context(caller):
+    """The SnvCaller whose context the RCCL path stages through (its device, its stream); without one the first exchange on
+    a GPU makes a context of its own."""
+    _T["ctx"] = caller
+
+
+def shutdown():
+    """Before dist.destroy_process_group(): the communicator and the host transport go."""
+    L = _lib.load()
+    if _T["cb"] is not None:
+        L.lfq_shard_set_host_allgather(_lib.HOST_ALLGATHER_FN(), None)
+    if _T.get("shm"):
+        L.lfq_shard_shm_close()
+    if _T["comm"] is not None and _T["rccl"] is not None:
+        _T["rccl"].ncclCommDestroy(_T["comm"])
+    if _T["own_ctx"] is not None:
+        _T["own_ctx"].close()
+    _T.update(dist=None, cb=None, cb_group=None, comm=None, own_ctx=None, shm=False)
+
+
+def _distributed(dist):
+    return dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES)
+
+
+def _host_transport(dist, group):
+    """The ABI's host all-gather for the test counts: the library's shared-memory transport when every rank of `group` is on
+    this node (lfq_shard_shm_open; LFQ_SHARD_HOST_TRANSPORT=gloo keeps it off), else `group` (gloo) itself through a callback."""
+    if _T["cb_group"] is group and (_T["cb"] is not None or _T.get("shm")):
+        return
+    import ctypes as C
+    import os
+    import socket
+    import torch
+    L = _lib.load()
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    if ws > 1 and os.environ.get("LFQ_SHARD_HOST_TRANSPORT", "shm") != "gloo":
+        names = [None] * ws
+        dist.all_gather_object(names, socket.gethostname(), group=group)
+        if len(set(names)) == 1:
+            name = ["/lofreq_amd.%d.%s" % (os.getuid(), os.urandom(8).hex())]       # new per run: rank 0 draws it
+            dist.broadcast_object_list(name, src=0, group=group)
+            ok = torch.tensor([1 if L.lfq_shard_shm_open(name[0].encode(), ws, rank) == 0 else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)                   # everybody has it mapped, or nobody uses it
+            if int(ok.item()) == 1:
+                if rank == 0:
+                    L.lfq_shard_shm_unlink()                                         # nothing stays behind in /dev/shm
+                _T["shm"], _T["cb"], _T["cb_group"] = True, None, group
+                return
+            L.lfq_shard_shm_close()
+
+    def cb(user, world, rank, send, recv, nbytes):
+        try:
+            mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+            out = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, mine, group=group)
+            C.memmove(recv, out.data_ptr(), world * nbytes)
+            return 0
+        except Exception as e:          # the C side turns this into LFQ_ERR_HIP
+            __import__("sys").stderr.write("lofreq_amd.shard: host all-gather failed: %r\n" % (e,))
+            return -1
+    _T["cb"] = _lib.HOST_ALLGATHER_FN(cb)
+    _T["cb_group"] = group
+    _lib.load().lfq_shard_set_host_allgather(_T["cb"], None)
+
+
+def _rccl_comm(dist, device):
+    """-> (lfq_ctx handle, ncclComm_t) of this process: made once, from rank 0's ncclUniqueId"""
+    import ctypes as C
+    import os
+    import torch
+    if _T["comm"] is not None:
+        return _T["ctx"].h, _T["comm"]
+    dev = torch.device(device)
+    if _T["ctx"] is None:
+        from .caller import SnvCaller
+        _T["own_ctx"] = _T["ctx"] = SnvCaller(dev.index or 0)
+    rccl = None
+    for mode in (os.RTLD_NOW | os.RTLD_NOLOAD, os.RTLD_NOW | os.RTLD_GLOBAL):     # the copy the process already has first
+        for name in ("librccl.so", "librccl.so.1"):
+            try:
+                rccl = C.CDLL(name, mode=mode)
+                break
+            except OSError:
+                continue
+        if rccl is not None:
+            break
+    if rccl is None:
+        raise RuntimeError("lofreq_amd.shard: no librccl in this process")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    uid = UniqueId()
+    if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8)
+    if _HOST_GROUP is not None:
+        dist.broadcast(t, src=0, group=_HOST_GROUP)
+    else:
+        td = t.to(dev)
+        dist.broadcast(td, src=0)
+        t = td.cpu()
+    C.memmove(C.byref(uid), t.numpy().ctypes.data, 128)
+    comm = C.c_void_p()
+    with torch.cuda.device(dev):
+        if rccl.ncclCommInitRank(C.byref(comm), ws, uid, rank) != 0:
+            raise RuntimeError("ncclCommInitRank failed")
+    _T["rccl"], _T["comm"] = rccl, comm
+    return _T["ctx"].h, comm
+
+
+def _transport(dist, device, want_device):
+    """-> (ctx handle or None, comm or None) for an exchange.  The host transport is registered whenever there is a host
+    group or the default group itself takes host tensors (gloo); a communicator is made when the default group is RCCL and
+    (a) no host group exists, or (b) the caller wants the device's road (`want_device`: the record gather)."""
+    backend = dist.get_backend()
+    if _HOST_GROUP is not None:
+        _host_transport(dist, _HOST_GROUP)
+    elif backend != "nccl":
+        _host_transport(dist, None)
+    if backend == "nccl" and (_HOST_GROUP is None or want_device):
+        return _rccl_comm(dist, device)
+    return None, None
 
 
 def exchange_counts(local_counts, dist=None, device=None):
-    """One all-gather of a small int64 vector per rank ({tested SNV columns, indel tests}).
-    -> (array [world, len(local_counts)], exclusive prefix of this rank as an array)."""
-    v = np.asarray(local_counts, np.int64).reshape(-1)
-    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES):
+    """One all-gather of a small int64 vector per rank ({tested SNV columns, indel tests}), by
+    lfq_shard_exchange_counts.  -> (array [world, len(local_counts)], exclusive prefix of this rank as an array)."""
+    v = np.ascontiguousarray(np.asarray(local_counts, np.int64).reshape(-1))
+    if not _distributed(dist):
         return v.reshape(1, -1), np.zeros_like(v)
-    import torch
     ws, rank = dist.get_world_size(), dist.get_rank()
-    if _HOST_GROUP is not None:
-        mine = torch.from_numpy(v.copy())
-        allc = torch.zeros(ws * len(v), dtype=torch.int64)
-        dist.all_gather_into_tensor(allc, mine, group=_HOST_GROUP)
-        allc = allc.numpy().reshape(ws, len(v))
-        return allc, allc[:rank].sum(axis=0)
-    mine = torch.from_numpy(v.copy()).to(device or "cpu")
-    allc = torch.zeros(ws * len(v), dtype=torch.int64, device=mine.device)
-    dist.all_gather_into_tensor(allc, mine)
-    allc = allc.cpu().numpy().reshape(ws, len(v))
-    return allc, allc[:rank].sum(axis=0)
+    ctx, comm = _transport(dist, device, want_device=False)
+    allc = np.zeros((ws, len(v)), np.int64)
+    prefix = np.zeros(len(v), np.int64)
+    _lib.check(_lib.load().lfq_shard_exchange_counts(ctx, comm, ws, rank, v.ctypes.data, len(v), allc.ctypes.data,
+                                                     prefix.ctypes.data), "lfq_shard_exchange_counts")
+    return allc, prefix
 
 
 def exchange_test_counts(n_tested_local, dist=None, device=None):
@@ -171,127 +307,61 @@ def exchange_test_counts(n_tested_local, dist=None, device=None):
 def rebase_bonferroni(pvals, prefix_tested):
     """Turn shard-local running Bonferroni factors into the single-process ones: every tested column
     of an earlier shard contributes 3 tests (lofreq_call.c:794-801)."""
-    pvals = pvals.copy()
-    pvals["bonf"] += 3 * int(prefix_tested)
+    pvals = np.ascontiguousarray(pvals.copy())
+    _lib.check(_lib.load().lfq_shard_rebase_bonferroni(pvals.ctypes.data, len(pvals), int(prefix_tested)),
+               "lfq_shard_rebase_bonferroni")
     return pvals
 
 
 def gather_records(records, col_offset, dist=None, device=None):
     """Gather reported variants to rank 0 in shard order; `col` becomes a global column index.
-    Works for SNV and indel records (any structured dtype with a `col` field)."""
-    rec = records.copy()
-    rdtype = rec.dtype
-    rec["col"] += int(col_offset)
-    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES):
+    Works for SNV and indel records (any structured dtype with a `col` field).  One all-gather of the record counts (every
+    rank needs the largest one: the pieces are of equal size), then ONE gather of the fixed-size pieces."""
+    if not _distributed(dist):
+        rec = records.copy()
+        rec["col"] += int(col_offset)
         return rec
-    import torch
-    ws, rank = dist.get_world_size(), dist.get_rank()
-    dev = device or "cpu"
-    # the record counts (every rank needs the largest one: a gather moves equal-sized pieces) ...
-    n_mine = torch.tensor([len(rec)], dtype=torch.int64, device=dev)
-    n_all = torch.zeros(ws, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(n_all, n_mine)
-    n_all = [int(x) for x in n_all.cpu().tolist()]
-    width = rdtype.itemsize
-    cap = max(max(n_all), 1)
-    buf = np.zeros(cap * width, np.uint8)
-    buf[: len(rec) * width] = rec.view(np.uint8).reshape(-1)
-    mine = torch.from_numpy(buf).to(dev)
-    # ... then ONE gather of the fixed-size records to rank 0 (north_star: "a single RCCL gather for the final VCF merge")
-    pieces = [torch.zeros(cap * width, dtype=torch.uint8, device=dev) for _ in range(ws)] if rank == 0 else None
-    dist.gather(mine, pieces, dst=0)
-    if rank != 0:
-        return None
-    parts = [pieces[r].cpu().numpy()[: n_all[r] * width].view(rdtype) for r in range(ws)]
-    return np.concatenate(parts) if parts else rec[:0]
+    allc, _ = exchange_counts([len(records)], dist, device)
+    return gather_records_wait(gather_records_start(records, col_offset, int(allc[:, 0].max()), dist, device))
 
 
 class PendingGather:
     """A record gather that has been started (gather_records_start) and not yet collected."""
-    __slots__ = ("records", "work", "big", "mine", "stage", "host", "ev", "cap", "rdtype", "ws", "rank")
+    __slots__ = ("records", "handle", "piece", "cap", "rdtype", "ws", "rank", "buf")
 
 
 _GATHER_HDR = 16        # bytes in front of a piece's records: int64 record count, int64 reserved (keeps the records aligned)
-_PINNED = {}            # size -> free pinned staging buffers (hipHostMalloc per step would cost more than the exchange)
-
-
-def _pinned_get(nbytes):
-    import torch
-    free = _PINNED.setdefault(int(nbytes), [])
-    return free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
-
-
-def _pinned_put(t):
-    if t is not None:
-        _PINNED.setdefault(int(t.numel()), []).append(t)
-
-
-_XSTREAM = {}           # device -> the stream the gather's copies and its communicator wait are queued on
-
-
-def _exchange_stream(dev):
-    """A high-priority stream of its own for the record gather's device-side pieces: the caller's current stream carries
-    the blocking copies of its next step's results, which must not queue up behind them."""
-    import torch
-    key = (dev.type, dev.index)
-    if key not in _XSTREAM:
-        _XSTREAM[key] = torch.cuda.Stream(device=dev, priority=-1)
-    return _XSTREAM[key]
 
 
 def gather_records_start(records, col_offset, cap, dist=None, device=None):
-    """First half of gather_records for callers that pipeline steps: every rank sends ONE piece of fixed capacity
-    (`cap` records, the same number on every rank -- e.g. 3 x the largest candidate-column count of the step, which the
-    count all-gather already made known to everybody; the piece starts with its own record count), so that no second
-    all-gather of the sizes is needed, and nothing here waits for the device: on a GPU the piece goes up from a pinned
-    buffer by an asynchronous copy, the collective is queued on the communicator's stream (RCCL), and rank 0's copy of
-    the gathered pieces back into pinned memory is queued behind it with an event that gather_records_wait waits for.
-    -> PendingGather.  `cap` too small for this rank's records raises before anything is sent."""
+    """First half of gather_records for callers that pipeline steps (lfq_shard_gather_start): every rank sends ONE piece
+    of fixed capacity (`cap` records, the same number on every rank -- e.g. 3 x the largest candidate-column count of the
+    step, which the count all-gather already made known to everybody; the piece starts with its own record count), so
+    that no second all-gather of the sizes is needed, and nothing here waits for the device: with a communicator the
+    piece goes up from a pinned copy, the collective and rank 0's copy back are queued on the handle's own high-priority
+    stream with an event that gather_records_wait waits for.  -> PendingGather.  `cap` too small for this rank's records
+    raises before anything is sent."""
     rec = records.copy()
     rec["col"] += int(col_offset)
     h = PendingGather()
-    h.records, h.work, h.big, h.mine, h.stage, h.host, h.ev = rec, None, None, None, None, None, None
+    h.records, h.handle, h.buf = rec, None, None
     h.rdtype = rec.dtype
-    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE_COLLECTIVES):
+    if not _distributed(dist):
         return h
-    import torch
+    import ctypes as C
     h.ws, h.rank, h.cap = dist.get_world_size(), dist.get_rank(), max(int(cap), 1)
     if len(rec) > h.cap:
         raise ValueError("gather_records_start: %d records, capacity %d" % (len(rec), h.cap))
-    dev = torch.device(device or "cpu")
     width = h.rdtype.itemsize
-    piece = _GATHER_HDR + h.cap * width
-    on_gpu = dev.type != "cpu"
-    if on_gpu:
-        h.stage = _pinned_get(piece)
-        buf = h.stage.numpy()
-        buf[8:_GATHER_HDR] = 0
-    else:
-        buf = np.zeros(piece, np.uint8)
+    h.piece = _GATHER_HDR + h.cap * width
+    buf = np.zeros(h.piece, np.uint8)
     buf[:8] = np.array([len(rec)], np.int64).view(np.uint8)
-    buf[_GATHER_HDR: _GATHER_HDR + len(rec) * width] = rec.view(np.uint8).reshape(-1)
-    if not on_gpu:
-        h.mine = torch.from_numpy(buf)
-        pieces = None
-        if h.rank == 0:
-            h.big = torch.empty(h.ws * piece, dtype=torch.uint8)
-            pieces = list(h.big.view(h.ws, piece).unbind(0))
-        h.work = dist.gather(h.mine, pieces, dst=0, async_op=True)
-        h.records = None
-        return h
-    with torch.cuda.stream(_exchange_stream(dev)):
-        h.mine = h.stage.to(dev, non_blocking=True)
-        pieces = None
-        if h.rank == 0:
-            h.big = torch.empty(h.ws * piece, dtype=torch.uint8, device=dev)    # one buffer, one copy back to the host
-            pieces = list(h.big.view(h.ws, piece).unbind(0))
-        h.work = dist.gather(h.mine, pieces, dst=0, async_op=True)
-        h.work.wait()                   # (RCCL: the exchange STREAM waits for the collective, not the host)
-        if h.rank == 0:
-            h.host = _pinned_get(h.ws * piece)
-            h.host.copy_(h.big, non_blocking=True)
-        h.ev = torch.cuda.Event()
-        h.ev.record()
+    buf[_GATHER_HDR: _GATHER_HDR + len(rec) * width] = np.ascontiguousarray(rec).view(np.uint8).reshape(-1)
+    ctx, comm = _transport(dist, device, want_device=True)
+    handle = C.c_void_p()
+    _lib.check(_lib.load().lfq_shard_gather_start(ctx, comm, h.ws, h.rank, buf.ctypes.data, h.piece, 1 if h.rank == 0 else 0,
+                                                  C.byref(handle)), "lfq_shard_gather_start")
+    h.handle = handle
     h.records = None
     return h
 
@@ -299,27 +369,22 @@ def gather_records_start(records, col_offset, cap, dist=None, device=None):
 def gather_records_wait(h):
     """Second half: the records of all ranks in shard order on rank 0, None elsewhere (every rank waits for its own side
     of the collective, so that the buffers it handed over are free again)."""
-    if h.work is None:
+    if h.handle is None:
         return h.records
-    if h.ev is not None:
-        h.ev.synchronize()
-    else:
-        h.work.wait()
-    _pinned_put(h.stage)
-    h.stage = h.mine = None
+    L = _lib.load()
     if h.rank != 0:
+        _lib.check(L.lfq_shard_gather_wait(h.handle, None, 0), "lfq_shard_gather_wait")
+        h.handle = None
         return None
+    host = np.zeros((h.ws, h.piece), np.uint8)
+    _lib.check(L.lfq_shard_gather_wait(h.handle, host.ctypes.data, host.nbytes), "lfq_shard_gather_wait")
+    h.handle = None
     width = h.rdtype.itemsize
-    piece = _GATHER_HDR + h.cap * width
-    host = (h.host.numpy() if h.host is not None else h.big.numpy()).reshape(h.ws, piece)
     parts = []
     for r in range(h.ws):
         n = int(host[r, :8].view(np.int64)[0])
         parts.append(host[r, _GATHER_HDR: _GATHER_HDR + n * width].view(h.rdtype))
-    out = np.concatenate(parts)         # (a copy: the pinned buffer goes back to the pool)
-    _pinned_put(h.host)
-    h.big = h.host = None
-    return out
+    return np.concatenate(parts)
 
 
 def finish_shard_start(conf, pvals, n_tested_local, ref_base, col_offset, dist=None, device=None):

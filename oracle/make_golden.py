@@ -841,7 +841,7 @@ def main_big():
             "C1 shape, lofreq call defaults")
     # the same shape with base qualities from 2 (alt bases below min_bq 6 exist: AF differs between 2.1.4 and HEAD where
     # such bases carry the alt allele; everything else must still agree) and without the default filter
-    run_big("big_c1_lowbq_nofilter", dict(seed=602, glen=10700, depth_lo=1000, depth_hi=3000, min_q=2),
+    run_big("big_c1_lowbq_nofilter", dict(seed=602, glen=10700, depth_lo=1000, depth_hi=3000, min_q=2, low_q_frac=0.04),
             ["--no-default-filter"], "C1 shape, low base qualities (documented 2.1.4-vs-HEAD raw-count delta), no default filter")
     # C4 shape at a size the binary does in a minute: 500x, planted insertions / deletions, BI / BD tags, --call-indels
     run_big("big_c4_indels", dict(seed=603, glen=24000, depth_lo=500, depth_hi=500, min_q=6, snv_every=60, indel_every=240),

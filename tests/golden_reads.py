@@ -17,14 +17,15 @@ GENERATOR_VERSION = 1
 _OPS = "MIDNSHP=X"
 
 
-def make(seed, glen, depth_lo, depth_hi, rl=150, min_q=6, snv_every=20, indel_every=0, mapq_mix=True):
+def make(seed, glen, depth_lo, depth_hi, rl=150, min_q=6, snv_every=20, indel_every=0, mapq_mix=True, low_q_frac=0.0):
     """Position-sorted reads over a random genome of `glen` bases.
 
     depth: the read starts follow a density that swings between depth_lo and depth_hi with a period of glen / 3 bases;
     SNV sites every `snv_every` bases, allele frequency cycling 0.5, 1, 2, 5, 10, 25, 50 %; with indel_every > 0 an
     insertion / deletion site (1..3 bases, alternating) every `indel_every` bases at 3 / 10 / 30 % of the reads that cover it
     with 12 bases to spare on both sides, and BI / BD tags (30..49) on every read; base qualities ~ N(34, 6) clipped to
-    [min_q, 41]; sequencing errors by the quality of the base; mapping quality 60 (92 %), else 0..59 or 255; random strand.
+    [min_q, 41], a fraction low_q_frac of them replaced by U{2..5} (below `lofreq call`'s min_bq 6); sequencing errors by the
+    quality of the base; mapping quality 60 (92 %), else 0..59 or 255; random strand.
     -> dict of flat arrays in the layout of lfq_pileup_reads / oracle/pyoracle.py::pack_reads."""
     rng = np.random.default_rng([GENERATOR_VERSION, seed])
     genome = rng.integers(0, 4, glen).astype(np.uint8)
@@ -84,6 +85,9 @@ def make(seed, glen, depth_lo, depth_hi, rl=150, min_q=6, snv_every=20, indel_ev
     flip = rng.random(len(ri)) < snv_af[sidx]
     seqs[ri[flip], ci[flip]] = snv_alt[sidx[flip]]
     qual = np.clip(np.round(rng.normal(34, 6, seqs.shape)), min_q, 41).astype(np.uint8)
+    if low_q_frac > 0:
+        low = rng.random(seqs.shape) < low_q_frac
+        qual[low] = rng.integers(2, 6, int(low.sum())).astype(np.uint8)
     err = rng.random(seqs.shape) < np.power(10.0, -(qual.astype(np.float64)) / 10.0)
     seqs[err] = (seqs[err] + 1 + rng.integers(0, 3, int(err.sum()))) % 4
     cig_off = np.zeros(n + 1, np.int64)

@@ -73,7 +73,7 @@ def test_device_chain_writes_the_binarys_vcf_at_real_size(caller, oracle, path):
         P = dict(R)
         oracle.baq_idaq_reads(P, extended=True, idaq=False, procs=min(16, os.cpu_count() or 1))
         head = oc.call_region(oracle, P, R["ref"], 0, R["glen"], kw, call_indels=False, no_default_filter=ndf)
-        assert lines == head["lines"]
+        assert got == [gu.strip_hqa(l) for l in head["lines"]]
         n_delta = sum(1 for g, e in zip(got, fx["vcf"]) if g != e)
-        assert 0 < n_delta < len(got)                            # the delta is exercised, and is not everywhere
+        assert n_delta > 0                                       # the delta is exercised (AF only: checked above)
     assert len(got) == fx["n_snv_lines"] + fx["n_indel_lines"]

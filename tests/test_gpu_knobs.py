@@ -73,7 +73,7 @@ import numpy as np
 import lofreq_amd as la
 import util
 caller = la.SnvCaller(0)
-host = util.random_batch(np.random.default_rng(5), 64, 800, 1500, planted={c: 0.05 for c in range(0, 64, 2)})
+host = util.random_batch(np.random.default_rng(5), 64, 800, 1500, planted={c: 0.3 for c in range(0, 64, 2)})
 recs, _, st = caller.call_snvs(util.to_pileup_batch(la, host), la.VarcallConf())
 print("RECS", len(recs))
 """

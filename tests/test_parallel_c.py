@@ -90,9 +90,22 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
         for k, n in ((0, 32), (1, 24)):
             with open("%s.ag%d.%d" % (rdv, k, r), "wb") as f:
                 f.write(np.array([0x3152415051464c, 12345], np.uint64).tobytes() + b"\x07" * (n - 16))
+    # ... and what a crashed attempt of the SAME launch leaves (a torchrun restart keeps run id and port, a second run inside
+    # one srun step keeps job and step id -- ADVICE r05): a fresh <rdv>.job of the right size with that attempt's nonce and
+    # tokens, its hello / ack files, an <rdv>.id and collective files under that nonce.  The late rank 0 below makes the
+    # other ranks meet all of it first; the handshake of job_nonce() must not accept any of it
+    stale = 0xDEADBEEF12345678
+    hdr = lambda job: np.array([0x3152415051464c, job], np.uint64).tobytes()
     with open(rdv + ".job", "wb") as f:
-        f.write(np.array([0x3152415051464c, 0, 12345], np.uint64).tobytes())
-    os.utime(rdv + ".job", (1.0e9, 1.0e9))
+        f.write(hdr(0) + np.array([stale] + [1000 + r for r in range(world)], np.uint64).tobytes())
+    with open(rdv + ".id", "wb") as f:
+        f.write(hdr(stale) + b"\x05" * 128)
+    for r in range(1, world):
+        open("%s.hello.%d" % (rdv, r), "wb").write(hdr(0) + np.array([1000 + r], np.uint64).tobytes())
+        open("%s.ack.%d" % (rdv, r), "wb").write(hdr(stale) + np.array([1000 + r], np.uint64).tobytes())
+    for k, n in ((2, 32), (3, 24)):
+        for r in range(world):
+            open("%s.ag%d.%d" % (rdv, k, r), "wb").write(hdr(stale) + b"\x09" * (n - 16))
     procs = []
     for r, (pv, n_tested, n_indel) in enumerate(shards):
         g = pv.copy()
@@ -102,13 +115,18 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
             f.write(np.array([n_tested, n_indel, len(g)], np.int64).tobytes())
             f.write(g.tobytes())
         env = dict(os.environ, LFQ_PAR_WORLD=str(world), LFQ_PAR_RANK=str(r), LFQ_PAR_RENDEZVOUS=rdv,
-                   LFQ_PAR_TRANSPORT="files", LFQ_PAR_TIMEOUT_S="60")
-        procs.append(subprocess.Popen([harness, path, str(tmp_path / ("out%d" % r))], env=env, stderr=subprocess.PIPE))
+                   LFQ_PAR_TRANSPORT="files", LFQ_PAR_TIMEOUT_S="60",
+                   SLURM_JOB_ID="77", SLURM_STEP_ID="0", TORCHELASTIC_RUN_ID="abc", MASTER_ADDR="127.0.0.1", MASTER_PORT="29500")
+        cmd = [harness, path, str(tmp_path / ("out%d" % r))]
+        if r == 0:                                   # rank 0 comes last
+            cmd = ["sh", "-c", "sleep 0.5; exec \"$@\"", "sh"] + cmd
+        procs.append(subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE))
     for p in procs:
         _, err = p.communicate(timeout=120)
         assert p.returncode == 0, err.decode()
     raw = open(tmp_path / "out0", "rb").read()
     assert not os.path.exists(tmp_path / "out1")
+    assert not [f for f in os.listdir(tmp_path) if ".hello." in f or ".ack." in f or f in ("rdv.job", "rdv.id")]
     cs = C.sizeof(_lib.Conf)
     got_conf = _lib.Conf.from_buffer_copy(raw[:cs])
     n_rec = int(np.frombuffer(raw[cs:cs + 8], np.int64)[0])
@@ -121,8 +139,8 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
     off = cs + 8 + 64 * n_rec
     n_txt = int(np.frombuffer(raw[off:off + 8], np.int64)[0])
     assert raw[off + 8:off + 8 + n_txt].decode() == "".join("%d\tchr%d\n" % (r, r + 1) for r in range(world))
-    left = [f for f in os.listdir(tmp_path) if f.startswith("rdv.ag")]
-    assert len(left) <= world, left                    # only the closing barrier's files stay behind
+    left = [f for f in os.listdir(tmp_path) if f.startswith("rdv.ag") and open(tmp_path / f, "rb").read()[8:16] != hdr(stale)[8:]]
+    assert len(left) <= world, left                    # only the closing barrier's files stay behind (+ the stale run's)
 
 
 def test_fixed_bonferroni_is_not_rebased(harness, tmp_path):
