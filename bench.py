@@ -104,6 +104,9 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: one context, every step waits for its own host finish before the next batch is launched "
                          "(default: two contexts; the host finish of step k runs under the kernels of step k + 1)")
+    ap.add_argument("--one-host-thread", action="store_true",
+                    help="pipelined loop: submit and finish in turn on one thread (the round-5 form; default: a submit thread "
+                         "beside the finishing thread)")
     ap.add_argument("--shard-path", action="store_true",
                     help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
     ap.add_argument("--workers", type=int, default=1,
@@ -174,7 +177,49 @@ def cpu_baseline(seed, depth, plant_period, sample_cols, default_filter):
         "dp_cells_reference_order": cells_ref,
         "dp_cells_per_s": cells_ref / tm.t_dp if tm.t_dp > 0 else None,
     }
+    try:
+        out["reference_cli"] = reference_cli_baseline(depth, default_filter)
+    except Exception as e:              # the reference's binary is an extra: the port's figure above stands without it
+        out["reference_cli"] = {"error": repr(e)[:200]}
     return out, res
+
+
+def reference_cli_baseline(depth, default_filter, glen=1300):
+    """`lofreq call` of the REFERENCE ITSELF on this box's host, one pinned core: the prebuilt 2.1.4 binary of the reference
+    tree's dist/ tarball, unpacked into oracle/_ref by `make -C oracle ref` in the build container (git-ignored, travels with
+    the other built files).  north_star's target is stated against this: "the single-thread CPU `lofreq call` rate in
+    pileup-columns/sec" at the config's depth.  The whole CLI -- SAM parsing, on-the-fly BAQ, pileup, calls, VCF -- on a bounded
+    sample (seeded reads of tests/golden_reads.py over `glen` bases at `depth`x), not only the column path the port above times:
+    reported beside it, never as the headline's denominator.  -> dict or None (no binary here)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "bin", "lofreq")
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_reads as gr
+    R = gr.make(seed=900 + depth, glen=glen, depth_lo=depth, depth_hi=depth, min_q=6, snv_every=97, mapq_mix=False)
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        open(os.path.join(tmp, "t.fa"), "w").write(">chr1\n" + R["ref"].decode() + "\n")
+        gr.write_sam(R, os.path.join(tmp, "t.sam"))
+        subprocess.check_call([exe, "faidx", "t.fa"], cwd=tmp)
+        env = dict(os.environ, PATH=os.path.dirname(exe) + ":" + os.environ.get("PATH", ""))
+        try:
+            core = min(os.sched_getaffinity(0))
+            pin = lambda: os.sched_setaffinity(0, {core})
+        except (AttributeError, OSError):
+            core, pin = None, None
+        args = [exe, "call", "-f", "t.fa", "-o", "out.vcf"] + ([] if default_filter else ["--no-default-filter"]) + ["t.sam"]
+        t0 = time.perf_counter()
+        p = subprocess.run(args, cwd=tmp, env=env, capture_output=True, text=True, timeout=300, preexec_fn=pin)
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            raise RuntimeError(p.stderr[-200:])
+        n_vcf = sum(1 for l in open(os.path.join(tmp, "out.vcf")) if not l.startswith("#"))
+    return {"value": glen / dt, "unit": "columns/s", "cores": 1, "kind": "reference", "pinned_to_core": core,
+            "binary": "lofreq 2.1.4 (the reference tree's dist/lofreq_star-2.1.4_linux-x86-64.tgz, oracle/_ref/bin/lofreq)",
+            "command": "lofreq call%s -f t.fa -o out.vcf t.sam" % ("" if default_filter else " --no-default-filter"),
+            "sample": "%d reads x 150 bp over %d bases at %dx (tests/golden_reads.py, an SNV site every 97 bases): %.1f s wall "
+                      "on one pinned core, %d VCF lines; SAM parsing + BAQ + pileup + calls (the whole CLI)"
+                      % (R["n"], glen, depth, dt, n_vcf)}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -376,6 +421,7 @@ def make_reads(n, glen, rl=150, seed=3, indel_frac=0.04):
         "bi": rng.integers(33 + 30, 33 + 50, n * rl).astype(np.uint8),
         "bd": rng.integers(33 + 30, 33 + 50, n * rl).astype(np.uint8),
         "mapq": np.full(n, 60, np.uint8), "rev": (rng.random(n) < 0.5).astype(np.uint8), "n_indel_reads": int(has.sum()),
+        "flags": np.full(max(n, 1), 3, np.uint8),       # every read carries BI and BD (bits 0 / 1 of lfq_pileup_indel_tags.tag_flags)
     }
 
 
@@ -1070,8 +1116,11 @@ def bench_genome(args, cfg_name, caller, la, shard, dist, world, rank, dev, xdev
                 # the lines the oracle wrote while it was timed against the device chain on the same sample
                 gs = lambda l: l.split(";HQA=")[0]
                 dlines = genome_sample_device_lines(cfg, caller, la, Rs, sample_len)
+                ol = [gs(l) for l in olines]
                 concord = {"sample": "the cpu_baseline's sample as a run of its own", "oracle_lines": len(olines),
-                           "device_lines": len(dlines), "identical": [gs(l) for l in olines] == dlines}
+                           "device_lines": len(dlines), "identical": ol == dlines,
+                           "only_oracle": [l for l in ol if l not in set(dlines)][:6],
+                           "only_device": [l for l in dlines if l not in set(ol)][:6]}
             except Exception as e:
                 base = {"error": repr(e)}
     L.lfq_set_indel_arrays_on_host(caller.h, 1)
@@ -1121,12 +1170,13 @@ def other_configs(budget_s=420.0):
             out[name + "_error"] = "skipped: the run's time budget for the other configs is spent"
             continue
         t0 = time.perf_counter()
+        p = None
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True,
                                timeout=min(limit, left), cwd=ROOT)
             ln = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         except Exception as e:
-            out[name + "_error"] = repr(e)[:300]
+            out[name + "_error"] = (repr(e) + (" | stderr: " + p.stderr[-400:] if p is not None else ""))[:700]
             continue
         cfg, roof, base = ln.get("config") or {}, ln.get("roofline") or {}, ln.get("cpu_baseline") or {}
         out[name + "_workload"] = cfg.get("workload")
@@ -1578,15 +1628,67 @@ def main():
 
         set_mode(in_flight["n"], in_flight["gate"])
 
+        # The loop's two host halves on two threads: a SUBMIT thread launches batch k + depth as soon as the context it takes
+        # is free, the main thread waits for batch k and finishes it (sparse D2H, exact emit test, strand bias, filter, VCF
+        # text).  The library's calls release the GIL (ctypes), contexts are thread-compatible (one per batch), so a step's
+        # host cost becomes max(submit, finish) instead of their sum -- what paces the 1000x batches (0.17 + 0.33 ms of host
+        # against a count kernel of 0.3 ms) -- and a finish that loses the CPU for a few milliseconds no longer delays the
+        # launches behind it.  Every step is still submitted, waited for and finished inside the timed region.
+        # `--one-host-thread` keeps the round-5 form (submit and finish in turn on one thread).
+        import queue
+        import threading
+        sub = {"cmd": queue.SimpleQueue(), "done": queue.SimpleQueue(), "thread": None}
+
+        def submit_loop():
+            while True:
+                k = sub["cmd"].get()
+                if k is None:
+                    return
+                try:
+                    t0_ = time.perf_counter()
+                    conf_ = submit(k)
+                    sub["done"].put((k, conf_, time.perf_counter() - t0_, None))
+                except BaseException as e:          # handed to the main thread, which raises it
+                    sub["done"].put((k, None, 0.0, e))
+
+        two_threads = not args.one_host_thread
+        if two_threads:
+            sub["thread"] = threading.Thread(target=submit_loop, name="lfq-bench-submit", daemon=True)
+            sub["thread"].start()
+
         def run_steps(n):
             acc = None
             out = None
+            if in_flight["n"] >= 2 and two_threads:
+                depth = in_flight["n"]
+                for j in range(min(depth, n)):
+                    sub["cmd"].put(j)
+                prev = None
+                for k in range(n):
+                    tr0 = time.perf_counter()
+                    kk, conf_k, t_sub, err = sub["done"].get()          # (submitted in order: kk == k)
+                    if err is not None:
+                        raise err
+                    assert kk == k
+                    wait(k)
+                    tr1 = time.perf_counter()
+                    prev, done = finish(k, conf_k, prev)
+                    out = done or out
+                    if k + depth < n:
+                        sub["cmd"].put(k + depth)                       # the context of step k is free again
+                    kt_ = (prev or done)[3 if prev else 4]
+                    if step_trace is not None:
+                        step_trace.append((tr1 - tr0, time.perf_counter() - tr1, t_sub, kt_["ms_total"]))
+                    acc = dict(kt_) if acc is None else {x: acc[x] + kt_[x] for x in acc}
+                if prev is not None:
+                    out = finish_end(prev)
+                return out, acc
             if in_flight["n"] >= 2:
-                # two batches in flight: batch k + 1 is launched BEFORE batch k is waited for; n submits and n finishes,
-                # every batch complete inside the timed region.  Gate "end": its count kernel starts when batch k's last
-                # kernel is done (an event on the device, no host latency between the batches; one batch's kernels at a
-                # time); "tail": when batch k is past its row-bound DP kernels (it runs beside the folds and the join);
-                # "none": as soon as the count kernel of batch k is done (beside all of batch k's DP kernels)
+                # one host thread (--one-host-thread): batch k + depth is launched after batch k is finished; n submits and n
+                # finishes, every batch complete inside the timed region.  Gate "end": a batch's count kernel starts when the
+                # previous batch's last kernel is done (an event on the device, no host latency between the batches; one
+                # batch's kernels at a time); "tail": when it is past its row-bound DP kernels (beside the folds and the
+                # join); "none": as soon as the previous count kernel is done (beside all of that batch's DP kernels)
                 depth = in_flight["n"]
                 confs = {j: submit(j) for j in range(min(depth, n))}
                 prev = None
@@ -1885,6 +1987,9 @@ def main():
         shard.shutdown()
         dist.destroy_process_group()
     if pipelined:
+        if sub["thread"] is not None:
+            sub["cmd"].put(None)
+            sub["thread"].join()
         for c_ in callers[1:]:
             c_.close()
     caller.close()

@@ -469,6 +469,11 @@ int lfq_set_baq_hmm_params(lfq_ctx *ctx, float gap_open, float gap_ext);
 /* nt layout of the tracks the device pileup returns: on = 1 (default) LFQ_TRACKS_NT_PACKED, on = 0 one byte per
  * observation.  lfq_pack_nt_track: the same packing for a host byte track (packed_out: (n_obs + 7) / 8 * 4 bytes). */
 int lfq_set_pileup_nt_packed(lfq_ctx *ctx, int on);
+/* Reads that are NOT sorted by position: off (default) = the pileup calls return LFQ_ERR_INVALID, as mpileup stops at a file
+ * that is not coordinate-sorted (bam_mplp_auto, plp.c:1406-1447); on = they are taken by the read-major kernels (one thread per
+ * read, an atomic cursor per column): the same columns and the same observations per column, but in no fixed ORDER within a
+ * column, so that the last bits of a p-value can differ from run to run (QUAL and every integer output do not). */
+int lfq_set_pileup_unsorted(lfq_ctx *ctx, int on);
 int lfq_pack_nt_track(const uint8_t *nt_bytes, int64_t n_obs, uint8_t *packed_out);
 
 /* lfq_call_snvs_batch in two halves, for callers that keep more than one batch in flight (one context per batch in

@@ -129,7 +129,7 @@ EXPORTS = [
     "lfq_source_qual_batch", "lfq_pileup_indel_columns", "lfq_pileup_skip_snv_columns",
     "lfq_uniq_detlim_batch", "lfq_uniq_binom_batch", "lfq_uniq_mtc", "lfq_binom_cdf",
     "lfq_shard_exchange_counts", "lfq_shard_rebase_bonferroni", "lfq_shard_gather_records", "lfq_shard_advance_conf",
-    "lfq_set_pileup_nt_packed", "lfq_set_baq_hmm_params", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_shard_gather_start", "lfq_shard_gather_wait", "lfq_shard_shm_open", "lfq_shard_shm_unlink", "lfq_shard_shm_close", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
+    "lfq_set_pileup_nt_packed", "lfq_set_pileup_unsorted", "lfq_set_baq_hmm_params", "lfq_pack_nt_track", "lfq_shard_allgather", "lfq_shard_set_host_allgather", "lfq_shard_gather_start", "lfq_shard_gather_wait", "lfq_shard_shm_open", "lfq_shard_shm_unlink", "lfq_shard_shm_close", "lfq_call_snvs_collect_pvals", "lfq_device_count", "lfq_pick_device", "lfq_host_alloc", "lfq_host_free",
     "lfq_readset_create", "lfq_readset_destroy", "lfq_readset_baq", "lfq_readset_source_qual",
     "lfq_readset_pileup_snv", "lfq_readset_pileup_indels", "lfq_readset_fetch_tags",
     "lfq_filter_conf_init", "lfq_filter_conf_defaults", "lfq_filter_vars", "lfq_filter_id", "lfq_filter_string",

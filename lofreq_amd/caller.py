@@ -188,6 +188,11 @@ class SnvCaller:
         """lfq_set_pileup_nt_packed: layout of the nt track the device pileup hands out (default: packed nibbles)"""
         _lib.check(self.L.lfq_set_pileup_nt_packed(self.h, 1 if on else 0), "lfq_set_pileup_nt_packed")
 
+    def set_pileup_unsorted(self, on):
+        """lfq_set_pileup_unsorted: take reads that are not position-sorted (read-major kernels, no fixed order within a
+        column) instead of refusing them like mpileup does"""
+        _lib.check(self.L.lfq_set_pileup_unsorted(self.h, 1 if on else 0), "lfq_set_pileup_unsorted")
+
     def set_baq_hmm_params(self, gap_open=1e-5, gap_ext=0.4):
         """lfq_set_baq_hmm_params: kpa_ext_par_t.d / .e of the BAQ HMM (defaults: kpa_ext_par_lofreq_illumina,
         kprobaln_ext.c:50; a -DPACBIO_REALN build of the reference uses 0.1 / 0.4, :51)"""

@@ -914,6 +914,15 @@ int lfq_set_pileup_nt_packed(lfq_ctx *c, int on)
     return LFQ_OK;
 }
 
+int lfq_set_pileup_unsorted(lfq_ctx *c, int on)
+{
+    if (!c) {
+        return LFQ_ERR_INVALID;
+    }
+    c->plp_unsorted_ok = on ? 1 : 0;
+    return LFQ_OK;
+}
+
 int lfq_set_baq_hmm_params(lfq_ctx *c, float gap_open, float gap_ext)
 {
     if (!c || !(gap_open > 0.f) || !(gap_open < 0.5f) || !(gap_ext > 0.f) || !(gap_ext < 1.f)) {

@@ -347,6 +347,8 @@ struct lfq_ctx {
     int batch_recorded;              /* ev[3] has been recorded: a batch of this context may still be running */
     float baq_par_d, baq_par_e;      /* lfq_set_baq_hmm_params; kpa_ext_par_lofreq_illumina (kprobaln_ext.c:50) by default */
     int plp_nt_bytes;                /* lfq_set_pileup_nt_packed(ctx, 0): the device pileup hands out one nt byte per observation */
+    int plp_unsorted_ok;             /* lfq_set_pileup_unsorted(ctx, 1): reads that are not position-sorted go to the read-major kernels
+                                      * instead of being refused (a column's observations then arrive in no fixed order) */
     const uint8_t *sub_ref_host;
     double sub_t0, sub_t1;
     const float *detlim_af;          /* device: per-column allele frequency while lfq_uniq_detlim_batch runs, else null */

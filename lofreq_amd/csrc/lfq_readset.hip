@@ -503,6 +503,16 @@ static const int32_t *readset_pmax(lfq_ctx *c, lfq_readset *rs, hipStream_t st)
     return rs->pmax_state == 1 ? rs->d_pmax : nullptr;
 }
 
+/* Reads that are not position-sorted: the column-major kernels cannot take them (no window to search), the read-major ones hand
+ * a column's observations out in the order their threads get there (an atomic cursor), so that the last bits of a p-value can
+ * differ from run to run.  The reference cannot take such input at all (bam_mplp_auto needs a coordinate-sorted file,
+ * plp.c:1406-1447): refused unless the caller asked for it (lfq_set_pileup_unsorted; the tuning build's LFQ_PILEUP_ATOMIC sends
+ * even sorted reads that way, for the tests that hold the two kernel families against each other). */
+static bool readset_unsorted_ok(const lfq_ctx *c, const lfq_readset *rs)
+{
+    return rs->n == 0 || c->plp_unsorted_ok || lfq_knobs().pileup_atomic;
+}
+
 int lfq_readset_fetch_tags(lfq_ctx *c, lfq_readset *rs, uint8_t *lb_out, uint8_t *ai_out, uint8_t *ad_out, uint8_t *tag_flags)
 {
     if (!c || !rs || rs->c != c) {
@@ -1091,6 +1101,9 @@ int lfq_readset_pileup_snv(lfq_ctx *c, lfq_readset *rs, int64_t region_begin, in
     /* position-sorted reads (the normal case): the column-major kernels; otherwise one thread per read + atomics */
     A.pmax_end = readset_pmax(c, rs, ps);
     const bool sorted = A.pmax_end != nullptr;
+    if (!sorted && !readset_unsorted_ok(c, rs)) {
+        return LFQ_ERR_INVALID;             /* as mpileup: bam_mplp_auto stops at a file that is not coordinate-sorted (plp.c:1406-1447) */
+    }
     LFQ_TRY(sorted ? lfq_launch_pileup_columns(A, 0, ps) : lfq_launch_pileup_count(A, ps));
     /* columns from the counters on the device (lfq_launch_plp_compact_*): the host waits once, for three numbers */
     LfqPin<int64_t> tot(c, 4);
@@ -1395,6 +1408,11 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
         }
         if (rc == LFQ_OK) {
             A.pmax_end = readset_pmax(c, rs, ps);
+            if (!A.pmax_end && !readset_unsorted_ok(c, rs)) {
+                rc = LFQ_ERR_INVALID;       /* not coordinate-sorted: refused like mpileup does (lfq_set_pileup_unsorted) */
+            }
+        }
+        if (rc == LFQ_OK) {
             rc = A.pmax_end ? lfq_launch_plp_indel_columns(A, 0, ps) : lfq_launch_plp_indel(A, 0, ps);
         }
         const bool have_qsum = A.pmax_end != nullptr;       /* the column-major kernel sums the qualities itself */

@@ -121,6 +121,12 @@ def test_pileup_unsorted_reads_take_the_read_major_kernels(caller):
     rng = np.random.default_rng(1)
     perm = rng.permutation(len(reads))
     res = []
+    # refused by default, like a file that is not coordinate-sorted is by mpileup (plp.c:1406-1447) ...
+    with pytest.raises(RuntimeError):
+        la.pileup_snv_tracks(caller, [reads[i] for i in perm], ref, 0, len(ref), lb=[lb[i] for i in perm])
+    with pytest.raises(RuntimeError):
+        la.pileup_indel_columns(caller, [reads[i] for i in perm], ref, 0, len(ref))
+    caller.set_pileup_unsorted(True)            # ... taken when the caller asks for it (lfq_set_pileup_unsorted)
     for order in (np.arange(len(reads)), perm):
         dt = la.pileup_snv_tracks(caller, [reads[i] for i in order], ref, 0, len(ref), lb=[lb[i] for i in order])
         t = dt._tracks()
@@ -132,6 +138,7 @@ def test_pileup_unsorted_reads_take_the_read_major_kernels(caller):
         res.append((dt.col_pos.tolist(), cols, recs.tobytes()))
         icols, ipos = la.pileup_indel_columns(caller, [reads[i] for i in order], ref, 0, len(ref))
         res[-1] += (ipos.tolist(), icols.num_non_indels.tolist(), icols.num_tails.tolist(), icols.coverage_plp.tolist())
+    caller.set_pileup_unsorted(False)
     assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2]
     assert res[0][3:] == res[1][3:]
 
@@ -152,6 +159,7 @@ def test_window_search_at_its_round_boundaries(caller, n_reads):
     if n_reads > 1 and all(reads[perm[i]]["pos0"] <= reads[perm[i + 1]]["pos0"] for i in range(n_reads - 1)):
         perm = perm[::-1].copy()                            # (two reads: make sure the second list is not sorted)
     res = []
+    caller.set_pileup_unsorted(True)
     for order in (np.arange(n_reads), perm):
         rd = [reads[i] for i in order]
         dt = la.pileup_snv_tracks(caller, rd, ref, 0, glen)
@@ -163,6 +171,7 @@ def test_window_search_at_its_round_boundaries(caller, n_reads):
         icols, ipos = la.pileup_indel_columns(caller, rd, ref, 0, glen)
         res.append((dt.col_pos.tolist(), cols, ipos.tolist(), icols.coverage_plp.tolist(), icols.num_non_indels.tolist(),
                     icols.num_tails.tolist(), icols.num_ins.tolist(), icols.num_dels.tolist()))
+    caller.set_pileup_unsorted(False)
     assert res[0] == res[1]
     assert len(res[0][0]) > 0
 

@@ -153,8 +153,8 @@ def test_bench_sharded_step_through_a_one_rank_rccl_communicator():
         d = run(env, "--shard-path")
         c = d["config"]
         assert c["exchange_backend"] == "nccl" and c["rccl_ranks"] == 1, c
-        assert ("gloo" in c["exchange"]["counts"]) == (env.get("LFQ_BENCH_EXCHANGE") != "rccl"), c["exchange"]
-        assert "rccl gather" in c["exchange"]["records"]
+        assert ("host transport" in c["exchange"]["counts"]) == (env.get("LFQ_BENCH_EXCHANGE") != "rccl"), c["exchange"]
+        assert "lfq_shard_gather_start" in c["exchange"]["records"] and "ncclAllGather" in c["exchange"]["records"]
         assert c["vcf_identical"] is True and c["records_per_step"] == ref["config"]["records_per_step"], (env, c)
         assert c["records_compared"] == ref["config"]["records_compared"]
 

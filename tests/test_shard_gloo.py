@@ -364,6 +364,58 @@ def test_plan_regions_balances_ragged_targets(world):
     assert all(e - b == 8_000_000 // (4 * world) for _, b, e in bins)
 
 
+def _max_over_mean(bins, owner, cost, world):
+    load = np.zeros(world)
+    for b, o in zip(bins, owner):
+        load[o] += cost(*b)
+    return load.max() / load.mean(), np.bincount(owner, minlength=world)
+
+
+def test_plan_regions_at_eight_workers_on_the_c4_and_c5_depth_profiles():
+    """what an 8-GPU node gets of BASELINE configs[3] and [4] -- the heaviest GPU's cost within 10 % of
+    the mean.  C4: one 4.6 Mb contig, 500x with the ripple a real BAM has (+- 30 %, a few 5-fold pile-ups) and insertion /
+    deletion sites whose columns cost a DP each; C5: ragged exome targets (150 .. 3500 bp, the generator of bench.py's
+    make_tile) over 64 Mb at 200x with log-normal depth per target.  Also: the uniform synthetic genomes bench.py runs."""
+    from lofreq_amd import shard
+    rng = np.random.default_rng(64)
+    W = 8
+    # C4 shape, 100-base windows
+    nwin = 46000
+    depth = 500.0 * (1.0 + 0.3 * np.sin(np.arange(nwin) / 700.0)) * rng.lognormal(0.0, 0.1, nwin)
+    depth[rng.integers(0, nwin, 40)] *= 5.0
+    kest = np.zeros(nwin)
+    kest[rng.integers(0, nwin, 900)] = rng.integers(5, 150, 900)           # planted variants: K ~ AF x depth
+    cost = shard.make_cost_fn({"ecoli": depth}, {"ecoli": kest / 100.0}, bin_size=100)
+    bins, owner = shard.plan_regions([("ecoli", 0, 4_600_000)], cost, W)
+    r, per = _max_over_mean(bins, owner, cost, W)
+    assert r <= 1.10 and per.min() >= shard.BIN_PER_THREAD, (r, per)
+    assert sum(e - b for _, b, e in bins) == 4_600_000
+    # C5 shape
+    targets, x = [], 300
+    while x < 64_000_000 - 4000:
+        l = int(rng.choice([150, 300, 600, 1200, 2000, 3500], p=[0.2, 0.25, 0.2, 0.15, 0.12, 0.08]))
+        targets.append(("chrE", x, x + l))
+        x += l + int(rng.integers(200, 1900))
+    tdepth = {t: 200.0 * rng.lognormal(0.0, 0.6) for t in targets}
+    starts = np.array([t[1] for t in targets])
+    ends = np.array([t[2] for t in targets])
+    dens = np.array([tdepth[t] for t in targets])
+
+    def cost5(c, b, e):
+        lo = np.clip(b, starts, ends)
+        hi = np.clip(e, starts, ends)
+        return float(((hi - lo) * dens).sum())
+    bins, owner = shard.plan_regions(targets, cost5, W)
+    r, per = _max_over_mean(bins, owner, cost5, W)
+    assert r <= 1.10 and per.min() >= shard.BIN_PER_THREAD, (r, per)
+    assert 25_000_000 < sum(e - b for _, b, e in bins) < 32_000_000      # ~29 Mb of targets, every base in exactly one bin
+    # the uniform genomes of `bench.py --config C4 / C5 --gpus 8`: 32 equal bins, four per GPU, whatever N is
+    for glen, d in ((4_600_000, 500), (64_000_000, 200)):
+        glen = glen // 32 * 32
+        bins, owner = shard.plan_regions([("synth", 0, glen)], lambda c, b, e: float(d) * (e - b), W, bins_per_worker=2)
+        assert len(bins) == 32 and sorted(np.bincount(owner)) == [4] * W and len({e - b for _, b, e in bins}) == 1
+
+
 def _bins_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
