@@ -104,9 +104,10 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: one context, every step waits for its own host finish before the next batch is launched "
                          "(default: two contexts; the host finish of step k runs under the kernels of step k + 1)")
-    ap.add_argument("--one-host-thread", action="store_true",
-                    help="pipelined loop: submit and finish in turn on one thread (the round-5 form; default: a submit thread "
-                         "beside the finishing thread)")
+    ap.add_argument("--submit-thread", action="store_true",
+                    help="pipelined loop: a submit thread beside the finishing thread instead of submit and finish in turn on "
+                         "one thread (measured in round 6: C2 0.573 against 0.542 ms per step, C3 the same -- the device, "
+                         "not the host, is what paces both -- so it is off by default; profiles/r06_host_threads.md)")
     ap.add_argument("--shard-path", action="store_true",
                     help="use the layer-1 + shard-exchange step (what N > 1 runs) even at N = 1")
     ap.add_argument("--workers", type=int, default=1,
@@ -1634,7 +1635,7 @@ def main():
         # host cost becomes max(submit, finish) instead of their sum -- what paces the 1000x batches (0.17 + 0.33 ms of host
         # against a count kernel of 0.3 ms) -- and a finish that loses the CPU for a few milliseconds no longer delays the
         # launches behind it.  Every step is still submitted, waited for and finished inside the timed region.
-        # `--one-host-thread` keeps the round-5 form (submit and finish in turn on one thread).
+        # Opt-in (`--submit-thread`): measured, the device paces both shapes and the extra thread buys nothing.
         import queue
         import threading
         sub = {"cmd": queue.SimpleQueue(), "done": queue.SimpleQueue(), "thread": None}
@@ -1651,7 +1652,7 @@ def main():
                 except BaseException as e:          # handed to the main thread, which raises it
                     sub["done"].put((k, None, 0.0, e))
 
-        two_threads = not args.one_host_thread
+        two_threads = bool(args.submit_thread)
         if two_threads:
             sub["thread"] = threading.Thread(target=submit_loop, name="lfq-bench-submit", daemon=True)
             sub["thread"].start()
@@ -1684,7 +1685,7 @@ def main():
                     out = finish_end(prev)
                 return out, acc
             if in_flight["n"] >= 2:
-                # one host thread (--one-host-thread): batch k + depth is launched after batch k is finished; n submits and n
+                # one host thread (the default): batch k + depth is launched after batch k is finished; n submits and n
                 # finishes, every batch complete inside the timed region.  Gate "end": a batch's count kernel starts when the
                 # previous batch's last kernel is done (an event on the device, no host latency between the batches; one
                 # batch's kernels at a time); "tail": when it is past its row-bound DP kernels (beside the folds and the

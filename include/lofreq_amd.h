@@ -315,8 +315,12 @@ int lfq_format_indel_record(char *buf, int buflen, const char *chrom, int64_t po
  * lb_out[seq_off[r] .. seq_off[r+1]) as the read's `lb:Z` tag (bytes are BAQ + 33, capped at '~').
  * lfq_baq_idaq_batch additionally computes the indel alignment qualities (idaq, :73-248): ai_out / ad_out get the
  * bytes of the `ai` / `ad` tags ('~' where there is nothing), tag_flags[r] bit 0 / bit 1 say whether read r gets an
- * ai / ad tag at all (n_ins / n_del > 0, :238-243).  Reads whose bases carry IUPAC ambiguity codes other than N
- * compare as N in the repeat scan (:197); more than 64 indels or 1024 repeat cells per read are not tracked. */
+ * ai / ad tag at all (n_ins / n_del > 0, :238-243).  More than 64 indels or 1024 repeat cells per read are not tracked.
+ * BASE CODES (every `seq` array of this header): 0..3 = A, C, G, T, 4 = N -- seq_nt16_int of the BAM base -- and 5..15 = the
+ * other letters of htslib's seq_nt16_str in its order, "=MRSVWYHKDB" (LFQ_SEQ_LETTERS "ACGTN=MRSVWYHKDB"[code]).  A code
+ * above 3 behaves like N in the HMM, the pileups and the tests, as it does in the reference; where the reference compares or
+ * prints the LETTER of a read base -- the repeat scan of idaq (:197), count_cigar_ops (samutils.c:486-489), the key of an
+ * insertion (plp.c:1092-1093) -- an ambiguity code is its own letter.  A caller that only knows "not A, C, G, T" passes 4. */
 typedef struct lfq_baq_reads {
     int64_t n_reads;
     const int32_t *pos;        /* [n]   bam1_core_t.pos (0-based leftmost reference coordinate) */

@@ -179,8 +179,10 @@ int lfq_region_begin(lfq_region *r, const char *target_name, const char *ref, in
 int lfq_region_add_read(lfq_region *r, int32_t pos, int flag, int mapq, int n_cigar, const uint32_t *cigar, int l_qseq,
                         const uint8_t *seq4, const uint8_t *qual, const char *bi, const char *bd)
 {
-    /* seq_nt16_int (htslib hts.c): the 4-bit BAM base "=ACMGRSVTWYHKDBN" -> 0..3 = A, C, G, T, 4 = anything else */
-    static const uint8_t nt16_int[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};
+    /* the 4-bit BAM base "=ACMGRSVTWYHKDBN" -> the library's base code: 0..3 = A, C, G, T and 4 = N as seq_nt16_int (htslib
+     * hts.c) has them, 5..15 = the other letters in the order "=MRSVWYHKDB" (include/lofreq_amd.h: they behave like N except
+     * where the reference compares or prints the LETTER of a read base) */
+    static const uint8_t nt16_int[16] = {5, 0, 1, 6, 2, 7, 8, 9, 3, 10, 11, 12, 13, 14, 15, 4};
     reg_buf *b;
     int i;
     if (!r || !r->open || n_cigar < 0 || l_qseq < 0 || (n_cigar > 0 && !cigar) || (l_qseq > 0 && (!seq4 || !qual))) {

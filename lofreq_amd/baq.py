@@ -9,13 +9,14 @@ from . import _lib
 
 _OPS = "MIDNSHP=X"
 _CODE = np.full(256, 4, np.uint8)
-for _i, _c in enumerate("ACGT"):
+for _i, _c in enumerate("ACGTN=MRSVWYHKDB"):          # LFQ_SEQ_LETTERS: htslib's seq_nt16_str with A, C, G, T, N in front
     _CODE[ord(_c)] = _i
     _CODE[ord(_c.lower())] = _i
 
 
 def encode_seq(s):
-    """ASCII bases -> 0..3 / 4 (seq_nt16_int of the BAM base)"""
+    """ASCII bases -> the library's base codes: 0..3 = A, C, G, T, 4 = N (seq_nt16_int of the BAM base) and 5..15 = the other
+    letters a BAM base can be ("=MRSVWYHKDB"), which behave like N except where the reference compares or prints the letter"""
     return _CODE[np.frombuffer(s.encode() if isinstance(s, str) else s, np.uint8)]
 
 

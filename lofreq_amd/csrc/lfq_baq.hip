@@ -269,8 +269,8 @@ __global__ __launch_bounds__(64) void lfq_baq_kernel(LfqBaqArgs A, int64_t n_lau
                 y += oplen;
                 int ref_i = x, rep = 0, rep_i = 0;
                 while (ref_i < xe) {
-                    const int b = query[1 + qpos + rep_i];                     /* 0..4 -> seq_nt16_str letter */
-                    if (A.ref[ref_i] != (uint8_t)"ACGTN"[b > 4 ? 4 : b]) break;
+                    const unsigned b = query[1 + qpos + rep_i];                /* code -> seq_nt16_str letter */
+                    if (A.ref[ref_i] != (uint8_t)lfq_seq_letter(b)) break;
                     rep += 1; ref_i += 1; rep_i += 1;
                     if (rep_i >= oplen) rep_i = 0;
                 }
@@ -1119,8 +1119,8 @@ __global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqAr
                 y += oplen;
                 int ref_i = x, rep = 0, rep_i = 0;
                 while (ref_i < xe) {
-                    const int b = query[1 + qpos + rep_i];                     /* 0..4 -> seq_nt16_str letter */
-                    if (A.ref[ref_i] != (uint8_t)"ACGTN"[b > 4 ? 4 : b]) break;
+                    const unsigned b = query[1 + qpos + rep_i];                /* code -> seq_nt16_str letter */
+                    if (A.ref[ref_i] != (uint8_t)lfq_seq_letter(b)) break;
                     rep += 1; ref_i += 1; rep_i += 1;
                     if (rep_i >= oplen) rep_i = 0;
                 }

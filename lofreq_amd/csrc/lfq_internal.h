@@ -185,6 +185,20 @@ struct LfqWork {
 /* ---- experiment / debugging knobs ----------------------------------------------------------------
  * Environment variables, read ONCE per process (first lfq_create / first use) into this struct; no entry point
  * calls getenv() on its own.  All optional; DESIGN.md "Environment knobs" documents them. */
+/* Read bases are codes: 0..3 = A, C, G, T, 4 = N (seq_nt16_int of the BAM base; everything the HMM, the pileups and the tests
+ * look at), and -- round 6 -- 5..15 = the other letters of htslib's seq_nt16_str in its order, "=MRSVWYHKDB".  Wherever the
+ * reference compares the LETTER of a read base with a reference letter (idaq's repeat scan bam_md_ext.c:197, count_cigar_ops
+ * samutils.c:486-489) or prints it (the key of an insertion, plp.c:1046-1060) an ambiguity code now is its own letter instead of
+ * N; everywhere else a code above 3 behaves like N, as the reference's seq_nt16_int / bam_nt16_nt4_table do. */
+#define LFQ_SEQ_LETTERS "ACGTN=MRSVWYHKDB"
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline char lfq_seq_letter(unsigned code)
+{
+    return code > 15u ? 'N' : LFQ_SEQ_LETTERS[code];
+}
+
 struct LfqKnobs {
     int timing;                /* LFQ_TIMING: host phases of the layer-2 calls to stderr */
     int single_stream;         /* LFQ_SINGLE_STREAM: every kernel on the caller's stream (rocprofv3 --pmc passes) */

@@ -1473,7 +1473,7 @@ int lfq_readset_pileup_indels(lfq_ctx *c, lfq_readset *rs, int64_t region_begin,
                             for (int j = 1; j <= e.indel; j++) {
                                 const int64_t q = e.qpos + j;
                                 const uint8_t code = q < lq ? rd->seq[s0 + q] : 4;
-                                key.push_back("ACGTN"[code > 4 ? 4 : code]);
+                                key.push_back(lfq_seq_letter(code));
                             }
                         } else {                                        /* deleted reference bases, :1127-1131 */
                             for (int j = 1; j <= -e.indel; j++) {

@@ -95,9 +95,8 @@ __global__ __launch_bounds__(LFQ_SRCQ_WAVES * 64) void lfq_srcq_kernel(LfqSrcqAr
                 for (int j = lane; j < l; j += 64) {
                     const int64_t t = tpos + j;
                     const int bq = qual[qpos + j];
-                    const uint32_t code = seq[qpos + j] > 4 ? 4u : seq[qpos + j];
                     const char ref_nt = (t >= 0 && t < A.ref_len) ? A.ref[t] : '\0';
-                    const bool mism = (ref_nt != "ACGTN"[code]) || op == 8;
+                    const bool mism = (ref_nt != lfq_seq_letter(seq[qpos + j])) || op == 8;       /* letters, samutils.c:486-489 */
                     if (bq < A.min_bq) {
                         continue;
                     }

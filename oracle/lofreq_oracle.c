@@ -1338,8 +1338,8 @@ static inline uint8_t orc_ap_to_char(double p)
 
 /* idaq (bam_md_ext.c:73-248): indel alignment qualities from the posterior matrix.  iaq / daq: l_qseq bytes
  * ('~' = nothing); returns bit 0 = an `ai` tag is written (n_ins > 0), bit 1 = an `ad` tag (n_del > 0).
- * The read's bases are "ACGTN"[code]: ambiguity codes other than N are not representable (they would compare
- * unequal to a same-coded reference base in the repeat scan, :197). */
+ * The read's bases are ORC_SEQ_LETTERS[code] (0..4 = ACGTN, 5..15 = the other letters of seq_nt16_str, "=MRSVWYHKDB": an
+ * ambiguity code is its own letter in the repeat scan, :197, as in the reference; everywhere else it behaves like N). */
 static int orc_idaq(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *seq, int l_qseq, const char *ref,
                     const double *pd, int W, int xe, int xb, int bw, uint8_t *iaq, uint8_t *daq)
 {
@@ -1386,7 +1386,7 @@ static int orc_idaq(int pos, const uint32_t *cigar, int n_cigar, const uint8_t *
             n_ins += 1;
             if (qpos == 0) continue;
             for (j = 0; j < oplen; j++) {
-                ins_seq[j] = "ACGTN"[seq[y] > 4 ? 4 : seq[y]];
+                ins_seq[j] = ORC_SEQ_LETTER(seq[y]);
                 y++;
             }
             ref_i = x;
@@ -1532,8 +1532,8 @@ int orc_baq_idaq_read(int pos, const uint32_t *cigar, int n_cigar, const uint8_t
  * orc_count_cigar_ops restates count_cigar_ops (samutils.c:437-614), orc_source_qual restates source_qual
  * (plp.c:427-593) as mplp_func calls it (plp.c:727-730; the caller then stores max(sq, 0) in the `sq` tag).
  * Pinned against the SQ track printed by the 2.1.4 binary's `lofreq plpsummary -s` (tests/golden/srcq_*.json).
- * seq holds codes 0..4 (A,C,G,T, anything else): seq_nt16_str of the BAM base is compared with the reference
- * letter as is (:486-489), so an N base matches an N reference; other IUPAC letters are taken as N here.
+ * seq holds codes 0..4 (A,C,G,T,N) and 5..15 (the other letters of seq_nt16_str): seq_nt16_str of the BAM base is compared
+ * with the reference letter as is (:486-489), so an N base matches an N reference and an R an R.
  * ign (optional): one byte per reference position, != 0 where the -S/--ign-vcf list holds a variant
  * (var_in_ign_list, plp.c:305-323, keyed by chrom and pos only). */
 #define ORC_INDEL_QUAL_DEFAULT 45                                   /* samutils.c:51 */
@@ -1552,7 +1552,7 @@ int orc_count_cigar_ops(int counts[4], int *quals[4], int pos, const uint32_t *c
             int64_t t;
             for (t = tpos; t < tpos + l; t++) {
                 const char ref_nt = (t >= 0 && t < ref_len) ? ref[t] : '\0';
-                const char read_nt = "ACGTN"[seq[qpos] > 4 ? 4 : seq[qpos]];
+                const char read_nt = ORC_SEQ_LETTER(seq[qpos]);
                 const int bq = qual[qpos];
                 const int actual = (ref_nt != read_nt || op == 8) ? 1 : 0;      /* :489-493 */
                 if (bq < min_bq) {                                  /* :496-502 */

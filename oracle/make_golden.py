@@ -789,6 +789,72 @@ def main_filter():
                       ["--no-defaults", "-k", "holm", "-A", "0.5", "-V", "500"]])
 
 
+
+def run_baq_iupac(name, seed):
+    """IUPAC ambiguity codes in reads and reference (bam_md_ext.c:176-200: the repeat scan of idaq compares LETTERS): a
+    genome with R / Y / M / N letters, insertions whose inserted bases repeat the reference letters behind them -- ambiguity
+    letters included, identical and different ones -- and ambiguity codes inside match blocks -> `lofreq alnqual` -> lb / ai /
+    ad of every read."""
+    rng = np.random.default_rng(seed)
+    glen, rl = 400, 80
+    g = list(rng.choice(list("ACGT"), glen))
+    sites = {}
+    # (site, letters of the reference right behind it, what the read inserts)
+    plan = [(60, "R", "R"), (100, "RR", "R"), (140, "YN", "YN"), (180, "M", "R"), (220, "N", "R"), (260, "R", "N"),
+            (300, "AR", "AR"), (330, "K", "K")]
+    for p0, after, ins in plan:
+        g[p0 + 1:p0 + 1 + len(after)] = list(after)
+        sites[p0] = ins
+    for p0 in (75, 155, 245):                      # ambiguity letters inside match blocks
+        g[p0] = "S"
+    genome = "".join(g)
+    reads = []
+    for i in range(160):
+        pos = int(rng.integers(0, glen - rl - 6))
+        seq, cigar, run, gp = [], [], 0, pos
+        while len(seq) < rl and gp < glen - 2:
+            c = genome[gp]
+            if c not in "ACGT" and rng.random() < 0.5:
+                c = str(rng.choice(list("ACGT")))          # half of the reads resolve an ambiguous reference letter
+            seq.append(c)
+            run += 1
+            if gp in sites and run > 3 and len(seq) < rl - 8 and rng.random() < 0.6:
+                cigar.append("%dM" % run)
+                run = 0
+                seq.extend(sites[gp])
+                cigar.append("%dI" % len(sites[gp]))
+            gp += 1
+        if run == 0:
+            continue
+        cigar.append("%dM" % run)
+        if rng.random() < 0.1:
+            seq[int(rng.integers(0, len(seq)))] = str(rng.choice(list("RYWN")))
+        qual = "".join(chr(33 + int(q)) for q in np.clip(np.round(rng.normal(35, 4, len(seq))), 8, 41))
+        reads.append((pos, 16 if rng.random() < 0.5 else 0, 60, "".join(cigar), "".join(seq), qual))
+    reads.sort()
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "t.fa"), "w").write(">chr1\n" + genome + "\n")
+        with open(os.path.join(tmp, "t.sam"), "w") as f:
+            f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:%d\n" % glen)
+            for i, (pos, flag, mapq, cg, sq, q) in enumerate(reads):
+                f.write("r%d\t%d\tchr1\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\n" % (i, flag, pos + 1, mapq, cg, sq, q))
+        subprocess.check_call([LOFREQ, "faidx", "t.fa"], cwd=tmp)
+        sam = subprocess.run([LOFREQ, "alnqual", "t.sam", "t.fa"], cwd=tmp, check=True, capture_output=True, text=True).stdout
+    out = []
+    for line in sam.splitlines():
+        if line.startswith("@"):
+            continue
+        f = line.split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        out.append({"pos0": int(f[3]) - 1, "flag": int(f[1]), "cigar": f[5], "seq": f[9], "qual": f[10],
+                    "lb": tags.get("lb"), "ai": tags.get("ai"), "ad": tags.get("ad")})
+    fix = {"name": name, "generator": "oracle/make_golden.py", "reference_binary": "lofreq 2.1.4 (dist tgz)",
+           "alnqual_args": [], "genome": genome, "reads": out}
+    path = os.path.join(OUT, name + ".json")
+    json.dump(fix, open(path, "w"), separators=(",", ":"))
+    print("%s: %d reads, %d with ai, %d bytes" % (name, len(out), sum(1 for r in out if r["ai"]), os.path.getsize(path)))
+
+
 def main_baq():
     mq_mix = [60] * 24 + [40, 30, 20, 10, 0, 255]
     sites = {70: [("+", "AC", 0.10)], 100: [("-", 3, 0.08)], 130: [("+", "G", 0.03), ("+", "GGT", 0.03)],
@@ -796,6 +862,7 @@ def main_baq():
              240: [("-", 12, 0.3), ("+", "CCCCCCCCCC", 0.05)]}
     run_baq("baq_extended", 31, 330, 250, sites, mq_mix)
     run_baq("baq_plain", 32, 330, 250, sites, mq_mix, extra=("-e",))
+    run_baq_iupac("baq_iupac", 33)
 
 
 # ---- real-size fixtures: the reads are NOT stored, only how to make them (tests/golden_reads.py) ------------------------------

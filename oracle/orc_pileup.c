@@ -125,7 +125,6 @@ orc_plp_region *orc_pileup_region(const orc_reads *rd, int64_t begin, int64_t en
     orc_plp_region *R = (orc_plp_region *)calloc(1, sizeof(*R));
     ovec act = OV(orc_cursor), evs[2] = {OV(orc_event), OV(orc_event)};
     int64_t next = 0, pos, s;
-    static const char nt4_letters[6] = "ACGTN";
     if (!R) {
         return NULL;
     }
@@ -297,8 +296,7 @@ orc_plp_region *orc_pileup_region(const orc_reads *rd, int64_t begin, int64_t en
                 }
                 for (j = 1; j <= klen; j++) {
                     const int64_t q = qpos + j;
-                    const int c = (q < lq) ? (rd->seq[so + q] > 4 ? 4 : rd->seq[so + q]) : 4;
-                    key[j - 1] = nt4_letters[c];
+                    key[j - 1] = (q < lq) ? ORC_SEQ_LETTER(rd->seq[so + q]) : 'N';     /* seq_nt16_str letter, plp.c:1092-1093 */
                 }
                 num_ins += 1;
                 e = find_event(&evs[0], key, klen);

@@ -119,10 +119,13 @@ def parse_cigar(s):
     return [(op, int(n)) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", s)]
 
 
+SEQ_LETTERS = "ACGTN=MRSVWYHKDB"       # include/lofreq_amd.h: base codes 0..4 and, for the other letters of a BAM base, 5..15
+
+
 def load_baq(path):
-    """-> (fixture, list of reads as dicts: pos0, cigar [(op, len)], seq codes 0..4, qual phred, lb bytes or None)"""
+    """-> (fixture, list of reads as dicts: pos0, cigar [(op, len)], seq codes, qual phred, lb bytes or None)"""
     fx = json.load(open(path))
-    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    code = {c: i for i, c in enumerate(SEQ_LETTERS)}
     reads = []
     for r in fx["reads"]:
         reads.append({"pos0": r["pos0"], "cigar": parse_cigar(r["cigar"]),
@@ -169,7 +172,7 @@ def py_pileup(reads, min_plp_bq=3):
             if op in "M=X":
                 for i in range(l):
                     if r["qual"][y + i] >= min_plp_bq:
-                        cols.setdefault(x + i, {}).setdefault("ACGTN"[r["seq"][y + i]], []).append((ri, y + i))
+                        cols.setdefault(x + i, {}).setdefault("ACGTN"[min(int(r["seq"][y + i]), 4)], []).append((ri, y + i))
                 x += l
                 y += l
             elif op in "IS":
@@ -279,7 +282,7 @@ def py_indel_pileup(reads, ref, min_plp_idq=0):
                         continue
                     mq, sq = r["mapq"], (-1 if r.get("sq") is None else r["sq"])
                     if indel > 0:
-                        key = "".join("ACGTN"[b] for b in r["seq"][qpos + 1:qpos + 1 + indel])
+                        key = "".join(SEQ_LETTERS[b] for b in r["seq"][qpos + 1:qpos + 1 + indel])      # seq_nt16_str letters (plp.c:1092)
                         aq = int(r["ai"][qpos]) - 33 if r.get("ai") is not None else -1
                         c["ev"][0].setdefault(key, []).append((iq, aq, mq, sq, rev))
                         c["n_ins"] += 1

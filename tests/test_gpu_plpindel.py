@@ -123,7 +123,9 @@ def _random_indel_reads(rng, n, glen, genome):
             if j + 1 < nops:
                 u = rng.random()
                 if u < 0.35:
-                    k = int(rng.integers(1, 4)); cigar.append(("I", k)); seq.extend(rng.integers(0, 4, k).tolist())
+                    # (one inserted base in twelve is an ambiguity code, 5..15: its own letter in the insertion's key)
+                    k = int(rng.integers(1, 4)); cigar.append(("I", k))
+                    seq.extend(int(b) if rng.random() > 0.08 else int(rng.integers(4, 16)) for b in rng.integers(0, 4, k))
                 elif u < 0.7:
                     k = int(rng.integers(1, 4)); cigar.append(("D", k)); x += k
                     if rng.random() < 0.15:        # a deletion directly followed by an insertion

@@ -53,7 +53,12 @@ def test_source_qual_random_reads_vs_oracle(caller, oracle):
     rng = np.random.default_rng(7)
     glen = 6000
     genome = rng.integers(0, 4, glen).astype(np.uint8)
-    ref = bytes(b"ACGT"[c] for c in genome)
+    # ambiguity letters in the reference and in the reads: count_cigar_ops compares LETTERS (samutils.c:486-489), so a read's
+    # R on a reference R is a match and on a reference N a mismatch (base codes 5..15, include/lofreq_amd.h)
+    amb = rng.random(glen) < 0.02
+    genome[amb] = rng.integers(4, 16, int(amb.sum()))
+    genome[genome == 5] = 4                                  # ('=' is not a reference letter)
+    ref = bytes(gu.SEQ_LETTERS[c].encode()[0] for c in genome)
     reads = []
     for i in range(600):
         long_read = i % 50 == 0
@@ -72,7 +77,7 @@ def test_source_qual_random_reads_vs_oracle(caller, oracle):
             for j in range(l):
                 b = int(genome[x + j]) if x + j < glen else 0
                 if rng.random() < rate:
-                    b = int(rng.integers(0, 5))
+                    b = int(rng.integers(0, 5)) if rng.random() < 0.8 else int(rng.integers(5, 16))
                 seq.append(b)
             cigar.append((op, l)); x += l; left -= l
             u = rng.random()
