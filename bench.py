@@ -1804,6 +1804,7 @@ def main():
             sys.stderr.write("[step %3d] wait %.3f  finish %.3f  submit %.3f  sum %.3f ms   kernels %.3f ms\n"
                              % (i, 1e3 * w, 1e3 * f, 1e3 * sb, 1e3 * (w + f + sb), kms))
 
+    final_line = None
     if rank == 0:
         steps = max(args.steps, 1)
         ms_per_step = 1e3 * elapsed / steps
@@ -1980,10 +1981,7 @@ def main():
             except BaseException as e:
                 sec["chain_2_workers"] = {"error": repr(e)}
             line["config"]["secondary"] = sec
-        if world == 1 and args.config == "C3" and not (args.depth or args.cols or args.no_other_configs or args.no_secondary):
-            # the other BASELINE configs on the same record: scalars only
-            line["config"].update(other_configs())
-        print(json.dumps(line))
+        final_line = line
     if world > 1 or force_dist:
         shard.shutdown()
         dist.destroy_process_group()
@@ -1994,6 +1992,17 @@ def main():
         for c_ in callers[1:]:
             c_.close()
     caller.close()
+    if final_line is not None:
+        if world == 1 and args.config == "C3" and not (args.depth or args.cols or args.no_other_configs or args.no_secondary):
+            # the other BASELINE configs on the same record: scalars only.  This process's HBM goes back
+            # first (the contexts are closed, the tracks and the outputs dropped): a genome run sizes its BAQ scratch from the
+            # free memory it finds
+            batch = d_counts = d_pvals = out_bufs = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            final_line["config"].update(other_configs())
+        print(json.dumps(final_line))
 
 
 if __name__ == "__main__":

@@ -188,7 +188,9 @@ def assert_pvalue_close(pv_gpu, pv_ref, tol=None, ctx="", n_obs=None):
     d = abs(log_of(pv_gpu) - lp)
     deep = abs(lp) > PV_DEEP_LOG
     if tol is None:
-        tol = pv_deep_bound(lp, 10000 if n_obs is None else n_obs) if deep else PV_LOG_TOL
+        # a caller that knows the column's depth passes it and gets the measured bound for that depth; one that does not gets
+        # the bound of a 10 000-deep column, capped at 1e-9 (a default must not loosen with |log p|)
+        tol = (pv_deep_bound(lp, n_obs) if n_obs is not None else min(pv_deep_bound(lp, 10000), 1e-9)) if deep else PV_LOG_TOL
     st = PV_ERR_MAX["|log p| > 600" if deep else "|log p| <= 600"]
     st[0] = max(st[0], d)
     st[1] += 1
