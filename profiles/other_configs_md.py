@@ -22,6 +22,8 @@ if rnd not in ("r02", "r03"):   # round 4 on: the depth-200 / depth-500 shapes a
              "--mode chain --overlap-regions (one worker; region k + 1 started before region k is finished)",
              "--mode chain --workers 2 (two region workers = processes on the one GPU)",
              "--mode baq (400 K reads x 150 bp)", "--mode baq --idaq"]
+if rnd not in ("r02", "r03", "r04", "r05"):     # round 6: no two-worker chain line
+    NAMES = [n for n in NAMES if "--workers 2" not in n]
 lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
 print("# bench.py on the other configurations (1 MI355X; round %s).  C2 / depth 200 / depth 500: --steps 60 --warmup 5 --no-cpu-baseline --no-pmc" % rnd[1:].lstrip("0"))
 print("# --no-secondary, pipelined two-context loop; host-abi, chain, baq: the --mode runs.  The headline configuration (C3) is in %s_bench_line.json." % rnd)

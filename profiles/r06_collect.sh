@@ -22,10 +22,11 @@ tail -c 400 gpurun_out/r06_bench_line.json
 python bench.py --config C2 --steps 60 --warmup 5 --no-secondary 2>/dev/null | tail -1 > gpurun_out/r06_bench_c2_line.json
 python bench.py --config C4 2>/dev/null | tail -1 > gpurun_out/r06_bench_c4_line.json
 python bench.py --config C5 2>/dev/null | tail -1 > gpurun_out/r06_bench_c5_line.json
-cat gpurun_out/r06_bench_c2_line.json gpurun_out/r06_bench_c4_line.json gpurun_out/r06_bench_c5_line.json >> gpurun_out/r06_other_configs.jsonl
+cat gpurun_out/r06_bench_c2_line.json >> gpurun_out/r06_other_configs.jsonl
 for cfg in "--cols 3750000 --depth 200" "--cols 4600000 --depth 500"; do
   python bench.py $cfg --steps 60 --warmup 5 --no-cpu-baseline --no-pmc --no-secondary --no-full-check 2>/dev/null | tail -1 >> gpurun_out/r06_other_configs.jsonl
 done
+cat gpurun_out/r06_bench_c4_line.json gpurun_out/r06_bench_c5_line.json >> gpurun_out/r06_other_configs.jsonl
 python bench.py --mode host-abi --steps 100 2>/dev/null | tail -1 >> gpurun_out/r06_other_configs.jsonl
 python bench.py --mode chain --steps 400 2>/dev/null | tail -1 >> gpurun_out/r06_other_configs.jsonl
 python bench.py --mode chain --steps 800 --overlap-regions 2>/dev/null | tail -1 >> gpurun_out/r06_other_configs.jsonl

@@ -122,10 +122,11 @@ def test_pileup_unsorted_reads_take_the_read_major_kernels(caller):
     perm = rng.permutation(len(reads))
     res = []
     # refused by default, like a file that is not coordinate-sorted is by mpileup (plp.c:1406-1447) ...
-    with pytest.raises(RuntimeError):
-        la.pileup_snv_tracks(caller, [reads[i] for i in perm], ref, 0, len(ref), lb=[lb[i] for i in perm])
-    with pytest.raises(RuntimeError):
-        la.pileup_indel_columns(caller, [reads[i] for i in perm], ref, 0, len(ref))
+    if not os.environ.get("LFQ_PILEUP_ATOMIC"):     # (the tuning build's knob sends every read set to the read-major kernels)
+        with pytest.raises(RuntimeError):
+            la.pileup_snv_tracks(caller, [reads[i] for i in perm], ref, 0, len(ref), lb=[lb[i] for i in perm])
+        with pytest.raises(RuntimeError):
+            la.pileup_indel_columns(caller, [reads[i] for i in perm], ref, 0, len(ref))
     caller.set_pileup_unsorted(True)            # ... taken when the caller asks for it (lfq_set_pileup_unsorted)
     for order in (np.arange(len(reads)), perm):
         dt = la.pileup_snv_tracks(caller, [reads[i] for i in order], ref, 0, len(ref), lb=[lb[i] for i in order])
