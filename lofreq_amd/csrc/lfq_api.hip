@@ -482,11 +482,6 @@ void lfq_destroy(lfq_ctx *c)
         }
         if (c->h_pin2) (void)hipHostFree(c->h_pin2);
         if (c->d_detlim) (void)hipFree(c->d_detlim);
-        for (int i = 0; i < LFQ_BAQ_NBUF; i++) {
-            if (c->ev_baq_f[i]) (void)hipEventDestroy(c->ev_baq_f[i]);
-            if (c->ev_baq_b[i]) (void)hipEventDestroy(c->ev_baq_b[i]);
-        }
-        if (c->baq_stream) (void)hipStreamDestroy(c->baq_stream);
         if (c->ev_baq_t[0]) (void)hipEventDestroy(c->ev_baq_t[0]);
         if (c->ev_baq_t[1]) (void)hipEventDestroy(c->ev_baq_t[1]);
         if (c->d_baq_scr) (void)hipFree(c->d_baq_scr);

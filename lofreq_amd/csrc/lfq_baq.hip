@@ -775,11 +775,8 @@ __global__ __launch_bounds__(64) void lfq_baq_nflag_kernel(LfqBaqArgs A, int64_t
     }
 }
 
-/* PHASE: 0 = the whole kernel; 1 = the forward pass alone (stored rows, 1 / s[i], and s[1], s[l_query], s[l_query + 1] handed
- * over in free slots of the wavefront's scale array); 2 = everything after it (the same preamble, then the hand-over read back).
- * 1 and 2 over the same grid and scratch, one after the other, are the whole kernel: same operations, same values. */
-template <int NB, bool IDAQ, bool HN = true, int PHASE = 0>
-__global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqArgs A, int64_t n_launch)
+template <int NB, bool IDAQ, bool HN = true>
+__global__ __launch_bounds__(64, LFQ_BAQ_WAVES) void lfq_baq_reg_kernel(LfqBaqArgs A, int64_t n_launch)
 {
     if (A.nflag && (A.nflag[blockIdx.x] != 0) != HN) {
         return;                                      /* the other instantiation's wavefront (lfq_baq_nflag_kernel) */
@@ -827,12 +824,8 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
     /* (base code | quality << 8) of every row into LDS: 64 bases per step as eight unaligned 16-byte loads of the read's own
      * bytes, all in flight before the first LDS write (one byte pair per iteration waited out a full memory round trip
      * 150 times per wavefront: a quarter of the forward pass) */
-    /* (PHASE 1, the forward pass as a kernel of its own, takes its rows' bytes from a ring of registers instead, see below: no
-     * dynamic LDS at all, so that four of its wavefronts fit a CU beside four of the sweep's) */
-    if constexpr (PHASE != 1) {
     s_rowq[lane] = (uint16_t)4;                      /* row 0 */
-    }
-    for (int i0 = 1; PHASE != 1 && i0 <= Lmax + 1; i0 += 64) {
+    for (int i0 = 1; i0 <= Lmax + 1; i0 += 64) {
         uint4 qv[4], bv[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -899,55 +892,16 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
     for (int j = 0; j <= NB; j++) {
         O0[j] = O1[j] = O2[j] = 0.;
     }
-    /* (base code | quality << 8) of row i for the forward pass: out of LDS, or (PHASE 1) out of a ring of registers -- the
-     * read's own bytes of rows r0 .. r0 + 15 in `cq` / `cb`, those of the next sixteen rows on their way in `nq` / `nb` (requested
-     * sixteen rows before their first use, like the reference codes in `pd`).  The forward pass asks for rows 1, 2, 3, ... in
-     * order; i is the same in every lane. */
-    uint4 cq = make_uint4(0u, 0u, 0u, 0u), cb = cq, nq = cq, nb = cq;
-    int ring0 = 1;
-    auto ring_load = [&](int i0, uint4 &q, uint4 &b) __attribute__((always_inline)) {
-        q = b = make_uint4(0u, 0u, 0u, 0u);
-        if (i0 <= l_query) {                         /* the arrays carry 16 bytes of padding behind the last read */
-            __builtin_memcpy(&q, query + i0, 16);
-            __builtin_memcpy(&b, iqual + i0, 16);
-        }
-    };
-    if constexpr (PHASE == 1) {
-        ring_load(1, cq, cb);
-        ring_load(17, nq, nb);
-    }
-    auto rowq_f = [&](int i) __attribute__((always_inline)) -> int {
-        if constexpr (PHASE != 1) {
-            return ROWQ(i);
-        } else {
-            if (i >= ring0 + 16) {                   /* wave-uniform */
-                cq = nq;
-                cb = nb;
-                ring0 += 16;
-                ring_load(ring0 + 16, nq, nb);
-            }
-            const int t = i - ring0, w = t >> 2, sh = 8 * (t & 3);
-            const uint32_t qw = w == 0 ? cq.x : (w == 1 ? cq.y : (w == 2 ? cq.z : cq.w));
-            const uint32_t bw_ = w == 0 ? cb.x : (w == 1 ? cb.y : (w == 2 ? cb.z : cb.w));
-            return i <= l_query ? (int)(((qw >> sh) & 0xffu) | (((bw_ >> sh) & 0xffu) << 8)) : 4;
-        }
-    };
-    double s_row1 = 1., s_last = 1., s_fin = 0.;     /* s[1], s[l_query], s[l_query + 1] */
-    WinT win = 0;
-    unsigned long long nxt;
-    uint32_t pd0, pd1, pd2, pd3;
-#define HAND(k_) S[(size_t)((k_) == 0 ? 0 : rows + (k_) - 1) * 64 + lane]   /* SQ(0), SQ(rows), SQ(rows + 1): never a row's */
-    if constexpr (PHASE != 2) {
     /* ---- forward (:134-190): rows >= 2 stay unscaled in the registers and in HBM, 1 / s[i] is applied by the reader ---- */
     RQ(0) = 1.;
     RQ(1) = 1.;
+    double s_row1 = 1., s_last = 1., s_fin = 0.;     /* s[1], s[l_query], s[l_query + 1] */
     {
         /* row 1 (:141-157): k = 1 .. min(l_ref, bw + 1) -> slots bw .. 2 bw */
         double sum = 0.;
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
-        const int rq1 = rowq_f(1);
-        const double ql = s_q2p[rq1 >> 8];
-        const int qy1 = rq1 & 0xff;
+        const double ql = s_q2p[ROWQ(1) >> 8];
+        const int qy1 = ROWQ(1) & 0xff;
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             const int k = 1 - bw + j;
@@ -977,7 +931,9 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
     /* codes of reference positions i - bw .. i - bw + NB of the row about to be computed, 4 bits each (slot j = nibble j,
      * nibble NB = the code that becomes slot NB - 1 of the next row); the code that enters after row i (position
      * i - bw + NB + 1) is nibble i & 15 of `nxt`, the codes of the 16 rows after that are on their way in `pd` */
-    win = 0;
+    WinT win = 0;
+    unsigned long long nxt;
+    uint32_t pd0, pd1, pd2, pd3;
 #pragma unroll
     for (int q = 0; q < (NB + 1 + 3) / 4; q++) {     /* positions 2 - bw .. 2 - bw + NB: the slots of row 2 and the lookahead */
         const uint32_t d = lfq_baq_ref4(refw, 2 - bw + 4 * q, l_ref);
@@ -997,7 +953,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
     }
     double rs_next = 1.;                             /* RQ(1) */
     /* base code and quality of a row come out of LDS one row ahead */
-    int rq_next = rowq_f(2);
+    int rq_next = ROWQ(2);
     double ql_next = s_q2p[rq_next >> 8];
     if (l_query == 1) {
         s_fin = lfq_baq_sfin<NB>(O0, O1, 1., sM, sI, l_query, l_ref, bw);
@@ -1011,7 +967,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
         const double qli = ql_next;
         const double rs = rs_next;                   /* pending scale of row i-1 */
         const int qyi = rq_next & 0xff;
-        rq_next = rowq_f(i + 1);
+        rq_next = ROWQ(i + 1);
         ql_next = s_q2p[rq_next >> 8];
         const int code_in = (int)((nxt >> (4 * (i & 15))) & 15ull);      /* enters the window for row i + 1 */
         const double e_eq = 1. - qli, e_ne = qli * LFQ_BAQ_EM;           /* lfq_baq_emit's two non-trivial values */
@@ -1086,18 +1042,6 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
         }
     }
 
-    }
-    if constexpr (PHASE == 1) {
-        HAND(0) = s_row1;
-        HAND(1) = s_last;
-        HAND(2) = s_fin;
-        return;
-    }
-    if constexpr (PHASE == 2) {
-        s_row1 = HAND(0);
-        s_last = HAND(1);
-        s_fin = HAND(2);
-    }
     /* ---- expected reference offset of every matched query base (bam_md_ext.c:409-447) ---- */
     for (int i = 0; i < l_query; i++) {
         expect[(size_t)i * 64 + lane] = INT32_MIN;       /* not in a match block (the offset itself can be negative) */
@@ -1374,7 +1318,7 @@ __global__ __launch_bounds__(64, PHASE == 1 ? 3 : LFQ_BAQ_WAVES) void lfq_baq_re
 }
 
 /* lds: 0 = the all-HBM kernel (any band), 1 = band <= 7 (rows in registers / LDS), 2 = band 8 (rows in registers) */
-int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream, int nmode, void *stream_sweep, void *ev_fwd)
+int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream, int nmode)
 {
     if (n_launch <= 0) {
         return LFQ_OK;
@@ -1384,24 +1328,6 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream,
         /* (base | quality) of every row, later the BAQ bytes (see the kernel) */
         const size_t lds_bytes = ((size_t)a.lds_rows + 2) * 64 * 2 + (size_t)(lds == 2 ? LFQ_BAQ_NB_WIDE : LFQ_BAQ_NB) * 64 * 16;
         const hipStream_t st = (hipStream_t)stream;
-        /* LFQ_BAQ_SPLIT = 1: forward pass and sweep as two launches where the caller pipelines them (ev_fwd given); 2: always
-         * (both on `stream`: a test of the hand-over) */
-        const bool split = ev_fwd != nullptr || lfq_knobs().baq_split == 2;
-        /* one instantiation of the narrow-band kernel, whole or as its two phases one behind the other */
-#define LFQ_BAQ_LAUNCH(NB_, ID_, HN_)                                                                                \
-        do {                                                                                                         \
-            if (split) {                                                                                             \
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<NB_, ID_, HN_, 1>), dim3(blocks), dim3(64), 0, st, a, n_launch); \
-                if (ev_fwd) {                       /* the sweep on its own stream, behind this launch's forward pass */ \
-                    (void)hipEventRecord((hipEvent_t)ev_fwd, st);                                                    \
-                    (void)hipStreamWaitEvent((hipStream_t)stream_sweep, (hipEvent_t)ev_fwd, 0);                      \
-                }                                                                                                    \
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<NB_, ID_, HN_, 2>), dim3(blocks), dim3(64), lds_bytes,         \
-                                   ev_fwd ? (hipStream_t)stream_sweep : st, a, n_launch);                            \
-            } else {                                                                                                 \
-                hipLaunchKernelGGL((lfq_baq_reg_kernel<NB_, ID_, HN_, 0>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch); \
-            }                                                                                                        \
-        } while (0)
         if (lds == 2 && a.itab) {
             hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB_WIDE, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
         } else if (lds == 2) {
@@ -1411,15 +1337,14 @@ int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream,
         } else if (a.nflag) {
             if (nmode != 2) {
                 hipLaunchKernelGGL(lfq_baq_nflag_kernel, dim3(blocks), dim3(64), 0, st, a, n_launch);
-                LFQ_BAQ_LAUNCH(LFQ_BAQ_NB, false, false);
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             }
             if (nmode != 1) {
-                LFQ_BAQ_LAUNCH(LFQ_BAQ_NB, false, true);
+                hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false, true>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
             }
         } else {
-            LFQ_BAQ_LAUNCH(LFQ_BAQ_NB, false, true);
+            hipLaunchKernelGGL((lfq_baq_reg_kernel<LFQ_BAQ_NB, false>), dim3(blocks), dim3(64), lds_bytes, st, a, n_launch);
         }
-#undef LFQ_BAQ_LAUNCH
     } else {
         hipLaunchKernelGGL(lfq_baq_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, a, n_launch);
     }

@@ -75,7 +75,6 @@ static inline double lfq_now_ms()
 /* most threads a host loop is cut for (the arrays of per-part results are this long); how many it really uses:
  * LFQ_HOST_LOOP_THREADS, the process's CPU budget, the loop's length */
 #define LFQ_HOST_PARTS 16
-#define LFQ_BAQ_NBUF 8              /* scratch buffers (chunks of wavefronts in flight) of the pipelined BAQ launches */
 
 class LfqLoopPool {
 public:
@@ -339,8 +338,6 @@ struct lfq_ctx {
     int dense_counts;                /* lfq_set_dense_counts: 0 = a caller's dense array may keep stale entries for untested columns */
     int dense_strand;                /* lfq_set_dense_strand_counts: layer 1 / async layer 2 fill the strand fields of every dense entry */
     int lazy_forced;                 /* set by lfq_call_snvs_batch around its submit */
-    hipStream_t baq_stream;          /* LFQ_BAQ_SPLIT: the sweep launches of the plain narrow-band reads (created on first use) */
-    hipEvent_t ev_baq_f[LFQ_BAQ_NBUF], ev_baq_b[LFQ_BAQ_NBUF];   /* per scratch buffer: forward pass queued / sweep done */
     hipEvent_t ev_baq_t[2];          /* around the BAQ kernels of the last lfq_readset_baq / lfq_baq_batch call (timing; created on first use) */
     int32_t baq_launches;            /* kernel launches between them on the context's stream */
     int64_t baq_reads, baq_bases;    /* reads / bases of that call */

@@ -119,8 +119,6 @@ const LfqKnobs &lfq_knobs(void)
         x.indel_host_pack = LFQ_TUNE_HAS("LFQ_INDEL_HOST_PACK");
         x.pileup_atomic = LFQ_TUNE_HAS("LFQ_PILEUP_ATOMIC");
         x.baq_lds = LFQ_TUNE_I("LFQ_BAQ_LDS", 1) != 0;
-        x.baq_split = (int)LFQ_TUNE_I("LFQ_BAQ_SPLIT", 0);
-        x.baq_split_rounds = (int)std::min(16L, std::max(1L, LFQ_TUNE_I("LFQ_BAQ_SPLIT_ROUNDS", 1)));
         x.baq_idaq_beside = (int)LFQ_TUNE_I("LFQ_BAQ_IDAQ_BESIDE", 0);
         x.tail_light = (int)std::min(2L, std::max(0L, LFQ_TUNE_I("LFQ_TAIL_LIGHT", 1)));
         x.count_shallow_wgs_none = (int)std::min(4L, std::max(0L, LFQ_TUNE_I("LFQ_COUNT_SHALLOW_WGS_NONE", 2)));

@@ -234,9 +234,6 @@ struct LfqKnobs {
     int indel_host_pack;       /* LFQ_INDEL_HOST_PACK */
     int pileup_atomic;         /* LFQ_PILEUP_ATOMIC: read-major pileup kernels even for sorted reads */
     int baq_lds;               /* LFQ_BAQ_LDS (1) */
-    int baq_split;             /* LFQ_BAQ_SPLIT (0): 1 = the plain narrow-band BAQ kernel as two pipelined launches per chunk of wavefronts,
-                                * forward pass and sweep; 2 = two launches on one stream (test of the hand-over) */
-    int baq_split_rounds;      /* LFQ_BAQ_SPLIT_ROUNDS (1): wavefronts per SIMD in a chunk */
     int baq_idaq_beside;       /* LFQ_BAQ_IDAQ_BESIDE (0): the narrow-band reads with indels on a side stream beside the plain launches (a lone BAQ + IDAQ call 6.2 -> 5.3 ms per 400 K reads, the reads -> VCF chain 37.7 -> 39.0 ms per region: off) */
     long baq_scratch_mb;       /* LFQ_BAQ_SCRATCH_MB: -1 = from free HBM */
     int tail_light;            /* LFQ_TAIL_LIGHT (1): where the light chain records the device's tail event (what the next batch's count
@@ -316,10 +313,7 @@ struct LfqBaqArgs {
                                   * scalars (128 B per query base) + 1 KiB stay below 64 KiB of LDS per wavefront */
 /* nmode (launches with a.nflag): 0 = flag kernel and both instantiations; 1 = flag kernel and the instantiation without the
  * N case; 2 = only the one with it (the flagged wavefronts of an earlier nmode 1 call with the same arguments) */
-/* stream_sweep / ev_fwd (LFQ_BAQ_SPLIT, plain narrow-band launches only): the sweep phase goes to stream_sweep behind an event
- * recorded after the forward phase on `stream`; null = both phases on `stream` */
-int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream, int nmode = 0, void *stream_sweep = nullptr,
-                   void *ev_fwd = nullptr);
+int lfq_launch_baq(const LfqBaqArgs &a, int64_t n_launch, int lds, void *stream, int nmode = 0);
 
 /* ---- device-side pileup (lfq_pileup.hip) ------------------------------------------------------------------ */
 struct LfqPileupArgs {

@@ -889,66 +889,29 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
         c->baq_reads = n;
         c->baq_bases = n_bases;
         {
+            LfqBaqArgs Ap = A;                      /* the plain instantiation: no indel table */
+            Ap.itab = nullptr;
+            Ap.terms = nullptr;
+            Ap.ai_out = Ap.ad_out = nullptr;
+            Ap.tag_flags = nullptr;
             /* (while the reads are still arriving the first launch takes one round only: it starts when the small first
              * chunk of lfq_readset_create has landed, and the link stays ahead of the kernel from there on) */
             const bool early = (rs->up_thread || rs->up_events) && rs->up_nchunks == LFQ_UP_CHUNKS && waves_n >= 4 * round
                                && n_plain > 16 * round * 64;
             int64_t ramp = early ? round : waves_n;             /* wavefronts of the next launch: 1, 2, 4 rounds, then all slots */
             std::vector<std::pair<LfqBaqArgs, int64_t>> with_n;
-            /* LFQ_BAQ_SPLIT: the forward pass and the sweep of a chunk of wavefronts as two launches on two streams, so that the
-             * sweep of chunk k (bound by what it issues) and the forward pass of chunk k + 1 (bound by what it stores) share the
-             * SIMDs -- each fits 256 registers once it is a kernel of its own, the forward pass without dynamic LDS.  A chunk =
-             * split_rounds x one wavefront per SIMD; chunk k works in scratch buffer k mod n_buf (slots of its own), its forward
-             * launch waits for the sweep that used the buffer before. */
-            const int64_t chunk_w = round * std::max(1, lfq_knobs().baq_split_rounds);
-            const int n_buf = (int)std::min<int64_t>(LFQ_BAQ_NBUF, waves_n / std::max<int64_t>(chunk_w, 1));
-            bool pipe = lfq_knobs().baq_split == 1 && !early && n_buf >= 2 && (n_plain + 63) / 64 >= 2 * chunk_w
-                        && !lfq_knobs().single_stream;
-            if (pipe) {
-                if (!c->baq_stream && hipStreamCreateWithFlags(&c->baq_stream, hipStreamNonBlocking) != hipSuccess) {
-                    c->baq_stream = nullptr;
-                    pipe = false;
-                }
-                for (int i = 0; pipe && i < LFQ_BAQ_NBUF; i++) {
-                    if ((!c->ev_baq_f[i] && hipEventCreateWithFlags(&c->ev_baq_f[i], hipEventDisableTiming) != hipSuccess)
-                        || (!c->ev_baq_b[i] && hipEventCreateWithFlags(&c->ev_baq_b[i], hipEventDisableTiming) != hipSuccess)) {
-                        pipe = false;
-                    }
-                }
-            }
-            int64_t chunk_i = 0;
-            for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt, chunk_i++) {
-                cnt = std::min<int64_t>((pipe ? chunk_w : std::min(ramp, waves_n)) * 64, n_plain - first);
+            for (int64_t first = 0, cnt = 0; rc == LFQ_OK && first < n_plain; first += cnt) {
+                cnt = std::min<int64_t>(std::min(ramp, waves_n) * 64, n_plain - first);
                 ramp = ramp < 4 * round ? ramp * 2 : waves_n;
                 rc = readset_upload_wait_reads(rs, order[(size_t)(first + cnt - 1)], c->stream);
-                const int buf = pipe ? (int)(chunk_i % n_buf) : 0;
-                LfqBaqArgs Ac = pipe ? at_slot((int64_t)buf * chunk_w) : A;
-                Ac.itab = nullptr;                  /* the plain instantiation: no indel table */
-                Ac.terms = nullptr;
-                Ac.ai_out = Ac.ad_out = nullptr;
-                Ac.tag_flags = nullptr;
-                Ac.first_read = (int32_t)first;
+                Ap.first_read = (int32_t)first;
                 /* (first is a multiple of 64: the launches are cut to whole wavefronts) */
-                Ac.nflag = (c->d_baq_nflag && !lfq_knobs().baq_one_variant) ? c->d_baq_nflag + first / 64 : nullptr;
-                if (rc == LFQ_OK && pipe && chunk_i >= n_buf && hipStreamWaitEvent(c->stream, c->ev_baq_b[buf], 0) != hipSuccess) {
-                    rc = LFQ_ERR_HIP;               /* the buffer's previous sweep is done */
-                }
+                Ap.nflag = (c->d_baq_nflag && !lfq_knobs().baq_one_variant) ? c->d_baq_nflag + first / 64 : nullptr;
                 if (rc == LFQ_OK) {
-                    rc = lfq_launch_baq(Ac, cnt, 1, c->stream, Ac.nflag ? 1 : 0, pipe ? c->baq_stream : nullptr,
-                                        pipe ? c->ev_baq_f[buf] : nullptr);
+                    rc = lfq_launch_baq(Ap, cnt, 1, c->stream, Ap.nflag ? 1 : 0);
                     c->baq_launches++;
-                    if (rc == LFQ_OK && pipe && hipEventRecord(c->ev_baq_b[buf], c->baq_stream) != hipSuccess) {
-                        rc = LFQ_ERR_HIP;
-                    }
-                    if (Ac.nflag) {
-                        with_n.push_back({Ac, cnt});
-                    }
-                }
-            }
-            if (pipe) {                             /* the main stream goes on when every sweep is done */
-                for (int i = 0; rc == LFQ_OK && i < n_buf && i < chunk_i; i++) {
-                    if (hipStreamWaitEvent(c->stream, c->ev_baq_b[i], 0) != hipSuccess) {
-                        rc = LFQ_ERR_HIP;
+                    if (Ap.nflag) {
+                        with_n.push_back({Ap, cnt});
                     }
                 }
             }
