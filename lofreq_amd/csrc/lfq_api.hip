@@ -746,7 +746,13 @@ int lfq_batch_device_impl(lfq_ctx *c, const lfq_conf *conf, const lfq_tracks *tr
         const int64_t seg_cols = c1 - c0;
         /* the light kernel is throughput work and persistent: it must leave wave slots for the short
          * latency-bound kernels of the long columns, or they only start when it ends */
-        const int light_waves_per_cu = kn.light_kernel == 0 ? kn.screen_waves_per_cu : 10;
+        /* How many screen wavefronts per CU follows the gate like the row segments do (round 6): alone, four make the light
+         * chain short (0.69 ms at C3); a context that queues its batches without a gate runs the chain beside the next batch's
+         * count kernel, where its length is hidden (1.7 ms with one wavefront per CU against a period of 2.8) and every resident
+         * screen wavefront costs the count kernel a slot -- C3 2.82-2.84 -> 2.77-2.79 ms per step with one, C2 0.523-0.528 ->
+         * 0.505-0.512 with one or two; shallow batches keep two (their chain is the longer part of a shorter period). */
+        const int screen_auto = (c->batch_gate == LFQ_GATE_NONE && !indel_mode) ? (tr->max_col_obs >= 4096 ? 1 : 2) : 4;
+        const int light_waves_per_cu = kn.light_kernel == 0 ? (kn.screen_waves_per_cu >= 1 ? kn.screen_waves_per_cu : screen_auto) : 10;
         const int n_light_waves = (int)std::min<int64_t>((int64_t)c->n_cu * light_waves_per_cu, std::max<int64_t>(seg_cols / 8, 4));
         const int n_mid_waves = (int)std::min<int64_t>((int64_t)c->n_cu * 4, std::max<int64_t>(seg_cols, 4));
         const bool run_big = !kn.skip_big, run_mid = !kn.skip_mid;     /* profiling aid: run the DP classes in isolation */

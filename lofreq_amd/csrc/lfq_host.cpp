@@ -87,7 +87,7 @@ const LfqKnobs &lfq_knobs(void)
             x.light_kernel = !strcmp(lk, "wave") ? 2 : 0;
         }
 #endif
-        x.screen_waves_per_cu = (int)std::max(1L, LFQ_TUNE_I("LFQ_SCREEN_WAVES_PER_CU", 4));
+        x.screen_waves_per_cu = (int)LFQ_TUNE_I("LFQ_SCREEN_WAVES_PER_CU", -1);      /* < 1: by the context's gate and the batch's depth */
         x.screen_rounds = (int)std::max(1L, LFQ_TUNE_I("LFQ_SCREEN_ROUNDS", 24));
         x.phase1_chunks = (int)std::max(1L, LFQ_TUNE_I("LFQ_PHASE1_CHUNKS", LFQ_PHASE1_CHUNKS));
         {

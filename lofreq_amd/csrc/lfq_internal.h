@@ -207,7 +207,8 @@ struct LfqKnobs {
     int skip_light, skip_mid, skip_big;   /* LFQ_DEBUG_SKIP=light,mid,big: run the DP classes in isolation */
     int light_kernel;          /* LFQ_LIGHT_KERNEL=wave: 2 = one light column per wavefront instead of the screen kernel (the
                                 * kernel that serves K >= 32 anyway); 0 = screen (one light column per lane) */
-    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (4): the screen is latency-bound per column, more wavefronts only crowd the two critical chains */
+    int screen_waves_per_cu;   /* LFQ_SCREEN_WAVES_PER_CU (-1 = auto: 4, and for a context that queues its batches without a gate 1 for deep / 2 for
+                                * shallow batches): the screen is latency-bound per column, more wavefronts only crowd the other chains */
     int screen_rounds;         /* LFQ_SCREEN_ROUNDS (24): 16-row windows before a light column goes to the retry kernel */
     int phase1_chunks;         /* LFQ_PHASE1_CHUNKS */
     int seg_max;               /* LFQ_SEG_MAX: both classes; LFQ_SEG_MAX_BIG / LFQ_SEG_MAX_MID: one of them (-1 = not given) */
