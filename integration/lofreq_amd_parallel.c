@@ -27,6 +27,7 @@ typedef int (*nccl_destroy_fn)(void *);
 struct lfq_par {
     int world, rank;
     int files;                      /* 1: the files transport is asked for */
+    int shm;                        /* 1: the library's shared-memory transport (one node; lfq_shard_shm_open) */
     int installed;                  /* 1: ... and installed (lfq_shard_set_host_allgather) */
     lfq_ctx *ctx;
     void *comm;                     /* ncclComm_t */
@@ -327,13 +328,14 @@ int lfq_par_init(lfq_par **out, int need_gpu)
     p->timeout_s = (double)env_int("LFQ_PAR_TIMEOUT_S", 600);
     strcpy(p->rdv, rdv);
     p->files = (tr && strcmp(tr, "files") == 0) ? 1 : 0;
+    p->shm = (tr && strcmp(tr, "shm") == 0) ? 1 : 0;
 
     if (lfq_abi_version() != LFQ_ABI_VERSION) {        /* lfq_conf / record layouts belong to the version */
         free(p);
         return LFQ_ERR_UNSUPPORTED;
     }
     if (need_gpu) {
-        if (!p->files && !getenv("LFQ_DEVICE")) {
+        if (!p->files && !p->shm && !getenv("LFQ_DEVICE")) {
             const int n = lfq_device_count();
             dev = n > 0 ? rank % n : LFQ_ERR_NO_DEVICE;     /* RCCL: one GPU per rank */
         } else {
@@ -359,6 +361,25 @@ int lfq_par_init(lfq_par **out, int need_gpu)
     if (p->files) {
         lfq_shard_set_host_allgather(files_allgather, p);
         p->installed = 1;
+    } else if (p->shm) {
+        /* the workers of ONE node: every collective through the library's shared segment, named after the run's nonce (new per
+         * run by construction); a first all-gather tells rank 0 that everybody has it mapped, then the name goes */
+        char name[64];
+        int64_t one = 1, *all = (int64_t *)malloc(sizeof(int64_t) * (size_t)world);
+        snprintf(name, sizeof(name), "/lofreq_amd.%016llx", (unsigned long long)p->job);
+        rc = all ? lfq_shard_shm_open(name, world, rank) : LFQ_ERR_NOMEM;
+        if (rc == LFQ_OK) {
+            p->shm = 2;                             /* open: lfq_par_destroy closes it */
+            rc = lfq_shard_allgather(NULL, NULL, world, rank, &one, 8, all);
+        }
+        free(all);
+        if (rc == LFQ_OK && rank == 0) {
+            (void)lfq_shard_shm_unlink();
+        }
+        if (rc != LFQ_OK) {
+            lfq_par_destroy(p);
+            return rc;
+        }
     } else {
         /* ncclUniqueId of rank 0 through <rdv>.id, then ncclCommInitRank on every rank (blocks until all are in) */
         lfq_nccl_id id;
@@ -415,12 +436,20 @@ void lfq_par_destroy(lfq_par *p)
             }
         }
     }
+    if (p->shm == 2) {
+        int64_t one = 1, *all = (int64_t *)malloc(sizeof(int64_t) * (size_t)p->world);
+        if (all) {      /* nobody unmaps while somebody still reads */
+            (void)lfq_shard_allgather(NULL, NULL, p->world, p->rank, &one, 8, all);
+            free(all);
+        }
+        (void)lfq_shard_shm_close();
+    }
     if (p->comm && p->comm_destroy) {
         p->comm_destroy(p->comm);
     }
     if (p->rank == 0) {
         char path[1024];
-        if (!p->files) {
+        if (!p->files && !p->shm) {
             snprintf(path, sizeof(path), "%s.id", p->rdv);
             unlink(path);
         }

@@ -13,8 +13,10 @@
  *     LFQ_PAR_RANK        0 .. world-1, in genome order of the workers' regions
  *     LFQ_PAR_RENDEZVOUS  a path all workers can write next to (the ncclUniqueId of rank 0 travels through
  *                         <path>.id; nothing else does with the RCCL transport)
- *     LFQ_PAR_TRANSPORT   "rccl" (default) | "files": all-gathers through files next to the rendezvous path -- for hosts
- *                         without RCCL and for the CPU tests (installed as lfq_shard_set_host_allgather)
+ *     LFQ_PAR_TRANSPORT   "rccl" (default) | "shm": the library's shared-memory all-gather (lfq_shard_shm_open; the workers of ONE
+ *                         node, microseconds per collective, no RCCL needed) | "files": all-gathers through files next to the
+ *                         rendezvous path -- for hosts without RCCL whose workers do not share a /dev/shm, and for the CPU tests
+ *                         (installed as lfq_shard_set_host_allgather)
  *     LFQ_PAR_TIMEOUT_S   how long a worker waits for its peers (default 600)
  * Device of a worker: lfq_pick_device() (LFQ_DEVICE > LOCAL_RANK > a free slot of the node), except that with the rccl
  * transport rank r takes GPU r mod device-count unless LFQ_DEVICE says otherwise: RCCL wants one GPU per rank.

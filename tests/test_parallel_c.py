@@ -58,8 +58,8 @@ def _fake_shard(rng, n_cols, first_factor_cols):
     return pv, n_tested
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_workers_merge_like_one_process(harness, tmp_path, world):
+@pytest.mark.parametrize("world,transport", [(2, "files"), (3, "files"), (2, "shm"), (8, "shm")])
+def test_workers_merge_like_one_process(harness, tmp_path, world, transport):
     rng = np.random.default_rng(40 + world)
     n_cols = 50000
     shards, prefix = [], 0
@@ -115,7 +115,7 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
             f.write(np.array([n_tested, n_indel, len(g)], np.int64).tobytes())
             f.write(g.tobytes())
         env = dict(os.environ, LFQ_PAR_WORLD=str(world), LFQ_PAR_RANK=str(r), LFQ_PAR_RENDEZVOUS=rdv,
-                   LFQ_PAR_TRANSPORT="files", LFQ_PAR_TIMEOUT_S="60",
+                   LFQ_PAR_TRANSPORT=transport, LFQ_PAR_TIMEOUT_S="60",
                    SLURM_JOB_ID="77", SLURM_STEP_ID="0", TORCHELASTIC_RUN_ID="abc", MASTER_ADDR="127.0.0.1", MASTER_PORT="29500")
         cmd = [harness, path, str(tmp_path / ("out%d" % r))]
         if r == 0:                                   # rank 0 comes last
@@ -139,8 +139,10 @@ def test_workers_merge_like_one_process(harness, tmp_path, world):
     off = cs + 8 + 64 * n_rec
     n_txt = int(np.frombuffer(raw[off:off + 8], np.int64)[0])
     assert raw[off + 8:off + 8 + n_txt].decode() == "".join("%d\tchr%d\n" % (r, r + 1) for r in range(world))
-    left = [f for f in os.listdir(tmp_path) if f.startswith("rdv.ag") and open(tmp_path / f, "rb").read()[8:16] != hdr(stale)[8:]]
-    assert len(left) <= world, left                    # only the closing barrier's files stay behind (+ the stale run's)
+    left = [f for f in os.listdir(tmp_path) if f.startswith("rdv.ag")
+            and open(tmp_path / f, "rb").read()[8:16] not in (hdr(stale)[8:], hdr(12345)[8:])]      # (not the planted ones)
+    assert len(left) <= (world if transport == "files" else 0), left     # only the closing barrier's files stay behind (+ the stale run's)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("lofreq_amd.")]      # the shared segment's name is gone
 
 
 def test_fixed_bonferroni_is_not_rebased(harness, tmp_path):
