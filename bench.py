@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100,
                     help="untimed steps before the timed ones (default 100 = 0.3 s: the first 200-step block after 10 was 1 %% slower than the blocks behind it)")
-    ap.add_argument("--config", choices=sorted(CONFIGS) + sorted(GENOME_CONFIGS), default="C3",
+    ap.add_argument("--config", choices=["C1"] + sorted(CONFIGS) + sorted(GENOME_CONFIGS), default="C3",
                     help="C3 (default, the metric) / C2: resident synthetic pileups; C4 / C5: a whole genome of reads through the "
                          "reads -> VCF chain, region- / BED-sharded over --gpus (strong scaling)")
     ap.add_argument("--vcf-out", default=None, help="C4 / C5: rank 0 writes the VCF text of the last step here")
@@ -1160,7 +1160,8 @@ def other_configs(budget_s=420.0):
     """BASELINE.json configs[1], [3], [4] (C2, C4, C5) as short runs of this same script in child processes, after the C3
     line's own work: their figures go into the C3 line's `config` as SCALARS (c2_*, c4_*, c5_*), so that one driver run
     witnesses every config with its concordance flag.  A child that fails or runs out of time leaves `<cfg>_error`."""
-    runs = [("c2", ["--config", "C2", "--steps", "60", "--warmup", "5", "--no-secondary", "--no-pmc", "--no-other-configs"], 150),
+    runs = [("c1", ["--config", "C1", "--steps", "2", "--warmup", "1"], 120),
+            ("c2", ["--config", "C2", "--steps", "60", "--warmup", "5", "--no-secondary", "--no-pmc", "--no-other-configs"], 150),
             ("c4", ["--config", "C4", "--steps", "2", "--warmup", "1", "--no-pmc", "--cpu-sample-cols", "30000"], 200),
             ("c5", ["--config", "C5", "--steps", "2", "--warmup", "1", "--no-pmc", "--cpu-sample-cols", "150000"], 200)]
     out = {}
@@ -1190,7 +1191,11 @@ def other_configs(budget_s=420.0):
         out[name + "_roofline_kernel"] = roof.get("kernel")
         out[name + "_cpu_baseline_columns_per_s"] = base.get("value")
         out[name + "_child_seconds"] = round(time.perf_counter() - t0, 1)
-        if name == "c2":
+        if name == "c1":
+            out["c1_reference"] = cfg.get("reference")
+            for k in ("c1_roofline_frac", "c1_roofline_kernel", "c1_cpu_baseline_columns_per_s"):
+                out.pop(k, None)
+        elif name == "c2":
             out["c2_roofline_kernel_alone_frac"] = (roof.get("kernel_alone") or {}).get("frac")
             out["c2_step_frac_of_hbm_peak"] = (roof.get("step") or {}).get("frac")
             out["c2_columns_compared"] = cfg.get("columns_compared")
@@ -1322,8 +1327,50 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def bench_c1(args):
+    """BASELINE.json configs[0] as far as it can exist here (the denv2 BAM is not in the reference tree): the C1-SHAPED run of the
+    reference's own 2.1.4 binary that tests/golden/big_c1_default.json holds (10.7 kb, 1 000 - 5 000x, `lofreq call` defaults:
+    on-the-fly extended BAQ, dynamic Bonferroni, the `lofreq filter` epilogue; oracle/make_golden.py --big-only).  The reads are
+    regenerated (tests/golden_reads.py, SHA-256 of the SAM text checked), go through the device's reads -> VCF chain, and the VCF
+    lines are compared with the binary's byte for byte (;HQA= is HEAD-only and stripped).  A parity line with a clock on it."""
+    import hashlib
+    import torch
+    import lofreq_amd as la
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_reads as gr
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "big_c1_default.json")))
+    R = gr.make_from_fixture(fx)
+    sha_ok = gr.sam_sha256(R) == fx["sam_sha256"]
+    caller = la.SnvCaller(0)
+    cfg = {"call_indels": False, "targets": False}
+    times = []
+    lines = None
+    for _ in range(max(args.warmup if args.warmup != 100 else 1, 1) + max(min(args.steps, 5), 1)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lines = genome_sample_device_lines(cfg, caller, la, R, R["glen"])
+        times.append(time.perf_counter() - t0)
+    caller.close()
+    n_warm = max(args.warmup if args.warmup != 100 else 1, 1)
+    t = float(np.mean(times[n_warm:]))
+    same = lines == fx["vcf"]
+    return {"metric": "pileup columns/sec, reads -> VCF, C1 shape (10.7 kb, 1 000 - 5 000x, lofreq call defaults)",
+            "value": R["glen"] / t, "unit": "columns/s", "n_gpus": 1, "steps": len(times) - n_warm, "warmup": n_warm,
+            "ms_per_step": 1e3 * t, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "seeded reads of tests/golden_reads.py; expected output written by the reference's lofreq 2.1.4 binary",
+            "config": {"workload": "C1 shape: BASELINE.json configs[0] at its own size with seeded reads (the denv2 BAM is not in the "
+                                   "reference tree); 1 step = upload + BAQ + pileup + calls + filter + VCF text of the whole genome",
+                       "reads": int(R["n"]), "sam_sha256_matches_fixture": sha_ok,
+                       "vcf_identical": bool(same and sha_ok), "records_compared": len(fx["vcf"]),
+                       "reference": fx["reference_binary"], "vcf_sha256": hashlib.sha256("\n".join(lines).encode()).hexdigest(),
+                       "reference_binary_seconds_in_the_build_container": fx.get("binary_seconds_in_the_build_container")}}
+
+
 def main():
     args = parse_args()
+    if args.config == "C1":
+        print(json.dumps(bench_c1(args)))
+        return
     genome_cfg = args.config in GENOME_CONFIGS
     if genome_cfg:
         if args.steps == 200:                              # the defaults are C3's: a genome step takes ~0.3-0.6 s
