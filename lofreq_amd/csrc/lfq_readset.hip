@@ -815,6 +815,18 @@ int lfq_readset_baq(lfq_ctx *c, lfq_readset *rs, int baq_extended, int want_idaq
             }
         };
         keep(&c->d_baq_scr, &c->baq_scr_bytes, waves * per_wave);
+        /* several contexts of one process (a host thread each) size their scratch from the same "free" figure at the same time: a
+         * context that comes too late for its share takes fewer wavefronts per launch instead of failing -- down to one round of the
+         * SIMDs, below which the kernel would leave part of the device idle */
+        while (rc == LFQ_ERR_NOMEM && waves > (int64_t)c->n_cu * 4) {
+            (void)hipGetLastError();
+            rc = LFQ_OK;
+            waves = std::max<int64_t>((int64_t)c->n_cu * 4, waves / 2);
+            keep(&c->d_baq_scr, &c->baq_scr_bytes, waves * per_wave);
+        }
+        if (rc == LFQ_OK && c->baq_scr_bytes / per_wave < waves) {
+            waves = c->baq_scr_bytes / per_wave;
+        }
         keep(&c->d_baq_expect, &c->baq_expect_bytes, waves * A.rows * 64 * 4);
         keep(&c->d_baq_tmp8, &c->baq_tmp8_bytes, waves * 2 * A.rows * 64);
         if (!lfq_knobs().baq_one_variant) {
