@@ -172,7 +172,7 @@ def shutdown():
         _T["rccl"].ncclCommDestroy(_T["comm"])
     if _T["own_ctx"] is not None:
         _T["own_ctx"].close()
-    _T.update(dist=None, cb=None, cb_group=None, comm=None, own_ctx=None, shm=False)
+    _T.update(dist=None, cb=None, cb_group=None, comm=None, own_ctx=None, shm=False, no_rccl=False)
 
 
 def _distributed(dist):
@@ -278,8 +278,15 @@ def _transport(dist, device, want_device):
         _host_transport(dist, _HOST_GROUP)
     elif backend != "nccl":
         _host_transport(dist, None)
-    if backend == "nccl" and (_HOST_GROUP is None or want_device):
-        return _rccl_comm(dist, device)
+    if backend == "nccl" and (_HOST_GROUP is None or want_device) and not _T.get("no_rccl"):
+        try:
+            return _rccl_comm(dist, device)
+        except Exception as e:
+            # (every rank runs the same code on the same image: a failure to find or initialise RCCL is every rank's)
+            if _HOST_GROUP is None:
+                raise
+            __import__("sys").stderr.write("lofreq_amd.shard: no RCCL communicator (%r): the records take the host transport too\n" % (e,))
+            _T["no_rccl"] = True
     return None, None
 
 
