@@ -47,3 +47,16 @@ def test_sharded_genome_equals_one_process(tmp_path, cfg, scale):
     assert b["roofline"] is None and b["cpu_baseline"] is None
     if cfg == "C4":
         assert a["config"]["indel_tests"] > 100 and "INDEL" in one
+
+
+def test_sharded_genome_at_eight_ranks(tmp_path):
+    """what an 8-GPU node runs, on the one GPU of this box: eight ranks (four bins each), the test counts over the library's
+    shared-memory host transport, records merged on rank 0 -- the one-process VCF, byte for byte (round 6; no node with eight
+    GPUs has been available to any round)"""
+    a = _run("C4", 1, str(tmp_path / "one.vcf"), 1 / 20)
+    b = _run("C4", 8, str(tmp_path / "eight.vcf"), 1 / 20)
+    assert b["n_gpus"] == 8 and b["config"]["rccl_ranks"] == 8 and b["config"]["bins"] == 32 and b["config"]["bins_rank0"] == 4
+    one, eight = open(tmp_path / "one.vcf").read(), open(tmp_path / "eight.vcf").read()
+    assert one == eight and one.count("\n") > 50 and "INDEL" in one
+    for k in ("snv_tests", "indel_tests", "called_columns", "vcf_sha256"):
+        assert a["config"][k] == b["config"][k], k
