@@ -88,7 +88,8 @@ typedef struct lfq_tracks {
     const uint8_t *mq;
     const uint8_t *sq;         /* may be NULL */
     const uint64_t *col_off;   /* ncols + 1 entries */
-    const uint8_t *ref_base;   /* ncols ASCII reference bases (plp_col_t.ref_base) */
+    const uint8_t *ref_base;   /* ncols ASCII reference bases (plp_col_t.ref_base); no alignment required (a count kernel reads the aligned
+                                * 32-bit word around a column's byte: same page, never past a mapping) */
     const int32_t *coverage_plp; /* ncols, or NULL: = observation count (plp_col_t.coverage_plp) */
     const int32_t *num_bases;    /* ncols, or NULL: = observation count (plp_col_t.num_bases) */
     int64_t ncols;

@@ -1081,6 +1081,9 @@ __device__ __forceinline__ LfqColHdr lfq_load_col_hdr(const LfqCountArgs &T, int
     h.off1 = T.col_off[col + 1];
     h.cov = T.coverage_plp ? T.coverage_plp[col] : 0;
     h.nb = T.num_bases ? T.num_bases[col] : 0;
+    /* the aligned 32-bit word AROUND the column's byte: up to three bytes in front of ref_base[0] / behind ref_base[ncols - 1] are
+     * read (never used).  That cannot fault -- an aligned word that holds a valid byte lies in that byte's page -- and puts no
+     * alignment requirement on a caller's device array; a memory checker may report it as a read past the array. */
     const uint8_t *p = T.ref_base + col;                 /* (pointer arithmetic, no integer round trip: the load stays a scalar one) */
     h.rb_word = *reinterpret_cast<const uint32_t *>(p - (reinterpret_cast<uintptr_t>(p) & 3u));
     return h;
